@@ -1,0 +1,46 @@
+"""numpy loss restatements vs goldens from the reference's loss code."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import recipe
+from conftest import PKG
+from oracle import clip_oracle as co
+
+DSPH = [(32, 64, 24), (48, 16, 80), (16, 128, 21), (8, 32, 24)]
+
+
+@pytest.mark.parametrize("B,K,C", DSPH)
+def test_dsph_hyp_loss(golden, B, K, C):
+    g = golden("loss_dsph.npz")
+    tag, seed = f"B{B}_K{K}_C{C}", 21
+    prox = recipe.features(C, K, seed, f"dsph_prox_{tag}")
+    x = np.tanh(recipe.features(B, K, seed, f"dsph_x_{tag}"))
+    y = np.tanh(recipe.features(B, K, seed, f"dsph_y_{tag}"))
+    lab = recipe.labels(B, C, seed, p=float(g[f"{tag}_p"]), tag=f"dsph_lab_{tag}")
+    loss = co.dsph_hyp_loss(x, y, lab, prox, float(g[f"{tag}_threshold"]), float(g[f"{tag}_alpha"]))
+    assert abs(float(loss) - float(g[f"{tag}_loss"])) < 1e-5 * max(1, abs(float(loss)))
+
+
+@pytest.mark.parametrize("B,K,C", DSPH)
+def test_dsph_threshold_table(golden, B, K, C):
+    g = golden("loss_dsph.npz")
+    rows = json.load(open(os.path.join(PKG, "train", "DSPH", "codetable.json")))["rows"]
+    assert rows[str(K)][math.ceil(math.log(C, 2))] == float(g[f"B{B}_K{K}_C{C}_threshold"])
+
+
+@pytest.mark.parametrize("B,K,C,fn,lt", [(32, 16, 24, "euclidean", "l2"), (32, 16, 24, "cosine", "l2"),
+                                          (24, 64, 24, "euclidean", "l1"), (24, 64, 80, "cosine", "l1")])
+def test_dchmt_our_loss(golden, B, K, C, fn, lt):
+    g = golden("loss_dchmt.npz")
+    tag, seed = f"B{B}_K{K}_C{C}_{fn}_{lt}", 31
+    zi = recipe.features(B, 2 * K, seed, f"dchmt_zi_{tag}").reshape(B, K, 2)
+    zt = recipe.features(B, 2 * K, seed, f"dchmt_zt_{tag}").reshape(B, K, 2)
+    hi = co.softmax(2 * zi, -1).reshape(B, 2 * K).astype(np.float32)
+    ht = co.softmax(2 * zt, -1).reshape(B, 2 * K).astype(np.float32)
+    lab = recipe.labels(B, C, seed, tag=f"dchmt_lab_{tag}")
+    loss = co.dchmt_our_loss(hi, ht, lab, K, fn, lt)
+    assert abs(float(loss) - float(g[f"{tag}_loss"])) < 1e-4 * max(1, abs(float(loss)))
