@@ -1,0 +1,326 @@
+"""ctypes binding of libcmh.so (include/cmh.h) for the Python host side.
+
+PyTorch is plumbing here: it owns device memory and streams; every computation of the hot path
+happens inside libcmh.so (hand-written HIP, gfx950).  There is NO CPU or eager-PyTorch fallback:
+a missing library or a non-GPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "build", "libcmh.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
+TIE_REFERENCE, TIE_STABLE = 0, 1
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class BlockWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "ln1_w", "ln1_b", "ln2_w", "ln2_b",
+        "fc_w", "fc_b", "proj_w", "proj_b")]
+
+
+class VitWeights(C.Structure):
+    _fields_ = [("gemm_dtype", C.c_int32), ("resolution", C.c_int32), ("patch", C.c_int32),
+                ("width", C.c_int32), ("layers", C.c_int32), ("embed_dim", C.c_int32),
+                ("conv1_w", C.c_void_p), ("class_embedding", C.c_void_p),
+                ("positional_embedding", C.c_void_p), ("ln_pre_w", C.c_void_p), ("ln_pre_b", C.c_void_p),
+                ("ln_post_w", C.c_void_p), ("ln_post_b", C.c_void_p), ("proj_t", C.c_void_p),
+                ("blocks", C.POINTER(BlockWeights))]
+
+
+class TextWeights(C.Structure):
+    _fields_ = [("gemm_dtype", C.c_int32), ("context_length", C.c_int32), ("vocab_size", C.c_int32),
+                ("width", C.c_int32), ("layers", C.c_int32), ("embed_dim", C.c_int32),
+                ("token_embedding", C.c_void_p), ("positional_embedding", C.c_void_p),
+                ("ln_final_w", C.c_void_p), ("ln_final_b", C.c_void_p), ("text_projection_t", C.c_void_p),
+                ("blocks", C.POINTER(BlockWeights))]
+
+
+class Taps(C.Structure):
+    _fields_ = [("ptrs", C.POINTER(C.c_void_p)), ("count", C.c_int32)]
+
+
+_lib = None
+_lock = threading.Lock()
+
+_i32, _i64, _f, _p, _sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
+
+# name -> (restype, argtypes); exactly the symbols include/cmh.h declares
+SIGNATURES = {
+    "cmh_last_error": (C.c_char_p, []),
+    "cmh_version": (C.c_int, []),
+    "cmh_vit_workspace_bytes": (_sz, [C.POINTER(VitWeights), _i32]),
+    "cmh_text_workspace_bytes": (_sz, [C.POINTER(TextWeights), _i32, _i32]),
+    "cmh_vit_encode": (C.c_int, [C.POINTER(VitWeights), _p, _i32, _p, _p, _sz, C.POINTER(Taps), _p]),
+    "cmh_text_encode": (C.c_int, [C.POINTER(TextWeights), _p, _i32, _i32, _p, _p, _p, _sz, C.POINTER(Taps), _p]),
+    "cmh_linear_gemm": (C.c_int, [_i32, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
+    "cmh_layernorm": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _p]),
+    "cmh_attention": (C.c_int, [_i32, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
+    "cmh_cast_f32_to_bf16": (C.c_int, [_p, _p, _i64, _p]),
+    "cmh_linear_act": (C.c_int, [_p, _p, _p, _p, _f, _i32, _p, _i32, _i32, _i32, _p]),
+    "cmh_pair_softmax": (C.c_int, [_p, _p, _i32, _i32, _p]),
+    "cmh_sign_codes": (C.c_int, [_p, _p, _i64, _p]),
+    "cmh_pair_argmax_codes": (C.c_int, [_p, _p, _i32, _i32, _p]),
+    "cmh_pack_codes": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p]),
+    "cmh_pack_labels": (C.c_int, [_p, _i64, _i32, _p, _p, _p]),
+    "cmh_hamming_dist": (C.c_int, [_p, _p, _p, _p, _i32, _i64, _i32, _p, _p]),
+    "cmh_calc_neighbor": (C.c_int, [_p, _p, _i32, _i32, _i32, _p, _p]),
+    "cmh_map_workspace_bytes": (_sz, [_i32, _i64, _i32, _i32]),
+    "cmh_hamming_map": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i64, _i32, _i32, _i64, _i32, _i32, _p, _p, _p,
+                                  _p, _sz, _p]),
+    "cmh_loss_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "cmh_dsph_hyp_loss": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _f, _f, _p, _p, _sz, _p]),
+    "cmh_dchmt_loss": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _f, _f, _p, _p, _sz, _p]),
+}
+
+
+def lib():
+    """Load libcmh.so (built by `__graft_entry__.build()` / `make -C csrc`).  Fails loudly."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise NativeError(
+                    f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` (or `make -C "
+                    f"{os.path.dirname(os.path.dirname(LIB_PATH))}`); there is no CPU fallback for the hot path")
+            l = C.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(l, name)          # AttributeError if the ABI lost a symbol
+                fn.restype, fn.argtypes = res, args
+            _lib = l
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise NativeError(f"{what} failed (code {rc}): {lib().cmh_last_error().decode(errors='replace')}")
+
+
+# ------------------------------------------------------------------------------------------ helpers
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise NativeError("libcmh runs on the GPU only (tensor on %s); there is no CPU fallback" % t.device)
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+_ws_cache: dict = {}
+
+
+def workspace(nbytes: int, device, tag: str = "") -> torch.Tensor:
+    """Per-(device, tag) grow-only scratch buffer (uint8, 256-byte aligned by the caching allocator)."""
+    key = (str(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def cast_bf16(src: torch.Tensor) -> torch.Tensor:
+    """f32 -> bf16 copy through the library's RNE cast kernel."""
+    src = f32c(src)
+    require_gpu(src)
+    dst = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+    check(lib().cmh_cast_f32_to_bf16(ptr(src), ptr(dst), src.numel(), stream_ptr(src.device)), "cmh_cast_f32_to_bf16")
+    return dst
+
+
+# ------------------------------------------------------------------------------------------ tower blocks
+EPI_BIAS, EPI_QUICKGELU, EPI_RESIDUAL, EPI_OUT_BF16 = 1, 2, 4, 8
+
+
+def linear_gemm(x, w, bias=None, residual=None, quickgelu=False, out_bf16=False):
+    """out = epi(x @ w.T); x,w both f32 or both bf16 (dtype picks the MFMA path)."""
+    require_gpu(x, w, bias, residual)
+    dt = BF16 if x.dtype == torch.bfloat16 else F32
+    if (w.dtype == torch.bfloat16) != (dt == BF16):
+        raise NativeError("linear_gemm: x and w must share a dtype")
+    x, w = x.contiguous(), w.contiguous()
+    M, K = x.shape
+    Nn = w.shape[0]
+    out = torch.empty(M, Nn, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    epi = (EPI_BIAS if bias is not None else 0) | (EPI_QUICKGELU if quickgelu else 0) | \
+          (EPI_RESIDUAL if residual is not None else 0) | (EPI_OUT_BF16 if out_bf16 else 0)
+    check(lib().cmh_linear_gemm(dt, ptr(x), ptr(w), ptr(None if bias is None else f32c(bias)),
+                                ptr(None if residual is None else f32c(residual)), ptr(out), M, Nn, K, epi,
+                                stream_ptr(x.device)), "cmh_linear_gemm")
+    return out
+
+
+def layernorm(x, w, b, out_bf16=False):
+    x, w, b = f32c(x), f32c(w), f32c(b)
+    require_gpu(x, w, b)
+    M, d = x.shape
+    out = torch.empty(M, d, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    check(lib().cmh_layernorm(ptr(x), ptr(w), ptr(b), ptr(out), BF16 if out_bf16 else F32, M, d, stream_ptr(x.device)),
+          "cmh_layernorm")
+    return out
+
+
+def attention(qkv, B, T, causal, key_padding_mask=None):
+    require_gpu(qkv, key_padding_mask)
+    qkv = qkv.contiguous()
+    dt = BF16 if qkv.dtype == torch.bfloat16 else F32
+    d = qkv.shape[1] // 3
+    o = torch.empty(B * T, d, dtype=qkv.dtype, device=qkv.device)
+    kpm = None if key_padding_mask is None else key_padding_mask.to(torch.uint8).contiguous()
+    check(lib().cmh_attention(dt, ptr(qkv), ptr(o), B, T, d, int(bool(causal)), ptr(kpm), stream_ptr(qkv.device)),
+          "cmh_attention")
+    return o
+
+
+# ------------------------------------------------------------------------------------------ heads
+def linear_act(x, w, b, act=ACT_NONE, drop_mask=None, p=0.2):
+    x, w = f32c(x), f32c(w)
+    b = None if b is None else f32c(b)
+    require_gpu(x, w, b, drop_mask)
+    M, K = x.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise NativeError(f"linear_act: x [{M},{K}] vs w {tuple(w.shape)}")
+    y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    dm = None if drop_mask is None else f32c(drop_mask)
+    check(lib().cmh_linear_act(ptr(x), ptr(w), ptr(b), ptr(dm), 1.0 / (1.0 - p), act, ptr(y), M, N, K,
+                               stream_ptr(x.device)), "cmh_linear_act")
+    return y
+
+
+def pair_softmax(z):
+    z = f32c(z)
+    require_gpu(z)
+    M, K2 = z.shape
+    out = torch.empty_like(z)
+    check(lib().cmh_pair_softmax(ptr(z), ptr(out), M, K2 // 2, stream_ptr(z.device)), "cmh_pair_softmax")
+    return out
+
+
+def sign_codes(h):
+    h = f32c(h)
+    require_gpu(h)
+    out = torch.empty_like(h)
+    check(lib().cmh_sign_codes(ptr(h), ptr(out), h.numel(), stream_ptr(h.device)), "cmh_sign_codes")
+    return out
+
+
+def pair_argmax_codes(p):
+    p = f32c(p)
+    require_gpu(p)
+    M, K2 = p.shape
+    out = torch.empty(M, K2 // 2, dtype=torch.float32, device=p.device)
+    check(lib().cmh_pair_argmax_codes(ptr(p), ptr(out), M, K2 // 2, stream_ptr(p.device)), "cmh_pair_argmax_codes")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ hamming / mAP
+def pack_codes(codes):
+    """f32 codes in {-1,0,+1} [n, K] -> (sign_plane, nz_plane) int32 [n, ceil(K/32)]."""
+    codes = f32c(codes)
+    require_gpu(codes)
+    n, K = codes.shape
+    W = (K + 31) // 32
+    sp = torch.empty(n, W, dtype=torch.int32, device=codes.device)
+    nz = torch.empty(n, W, dtype=torch.int32, device=codes.device)
+    bad = torch.zeros(1, dtype=torch.int32, device=codes.device)
+    check(lib().cmh_pack_codes(ptr(codes), n, K, ptr(sp), ptr(nz), ptr(bad), stream_ptr(codes.device)), "cmh_pack_codes")
+    if int(bad.item()):
+        raise NativeError("pack_codes: hash codes must be exactly -1, 0 or +1 (sign()/argmax codes)")
+    return sp, nz
+
+
+def pack_labels(labels):
+    labels = f32c(labels)
+    require_gpu(labels)
+    n, Cn = labels.shape
+    LW = (Cn + 31) // 32
+    out = torch.empty(n, LW, dtype=torch.int32, device=labels.device)
+    bad = torch.zeros(1, dtype=torch.int32, device=labels.device)
+    check(lib().cmh_pack_labels(ptr(labels), n, Cn, ptr(out), ptr(bad), stream_ptr(labels.device)), "cmh_pack_labels")
+    if int(bad.item()):
+        raise NativeError("pack_labels: labels must be non-negative (multi-hot)")
+    return out
+
+
+def hamming_dist(q_planes, r_planes, bits):
+    (qs, qn), (rs, rn) = q_planes, r_planes
+    Q, N = qs.shape[0], rs.shape[0]
+    out = torch.empty(Q, N, dtype=torch.float32, device=qs.device)
+    check(lib().cmh_hamming_dist(ptr(qs), ptr(qn), ptr(rs), ptr(rn), Q, N, bits, ptr(out), stream_ptr(qs.device)),
+          "cmh_hamming_dist")
+    return out
+
+
+def calc_neighbor(la, lb, classes):
+    A, B = la.shape[0], lb.shape[0]
+    out = torch.empty(A, B, dtype=torch.float32, device=la.device)
+    check(lib().cmh_calc_neighbor(ptr(la), ptr(lb), A, B, classes, ptr(out), stream_ptr(la.device)), "cmh_calc_neighbor")
+    return out
+
+
+def hamming_map(q_planes, q_lab, r_planes, r_lab, bits, classes, topk=None, tie_order=TIE_REFERENCE,
+                want_perm=False, depth_limit=-1):
+    """-> (map 0-dim f32 tensor, ap [Q] f32, perm [Q,N] int32 or None)"""
+    (qs, qn), (rs, rn) = q_planes, r_planes
+    dev = qs.device
+    Q, N = qs.shape[0], rs.shape[0]
+    ap = torch.empty(Q, dtype=torch.float32, device=dev)
+    mp = torch.empty(1, dtype=torch.float32, device=dev)
+    perm = torch.empty(Q, N, dtype=torch.int32, device=dev) if want_perm else None
+    need = lib().cmh_map_workspace_bytes(Q, N, bits, tie_order)
+    ws = workspace(need, dev, "map")
+    check(lib().cmh_hamming_map(ptr(qs), ptr(qn), ptr(q_lab), ptr(rs), ptr(rn), ptr(r_lab), Q, N, bits, classes,
+                                0 if topk is None else int(topk), tie_order, depth_limit, ptr(ap), ptr(mp), ptr(perm),
+                                ptr(ws), ws.numel(), stream_ptr(dev)), "cmh_hamming_map")
+    return mp[0], ap, perm
+
+
+# ------------------------------------------------------------------------------------------ losses
+def dsph_hyp_loss(x, y, label, proxies, threshold, alpha):
+    x, y, label, proxies = f32c(x), f32c(y), f32c(label), f32c(proxies)
+    require_gpu(x, y, label, proxies)
+    B, K = x.shape
+    Cn = label.shape[1]
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    ws = workspace(lib().cmh_loss_workspace_bytes(B, K, Cn), x.device, "loss")
+    check(lib().cmh_dsph_hyp_loss(ptr(x), ptr(y), ptr(label), ptr(proxies), B, K, Cn, float(threshold), float(alpha),
+                                  ptr(out), ptr(ws), ws.numel(), stream_ptr(x.device)), "cmh_dsph_hyp_loss")
+    return out[0]
+
+
+def dchmt_loss(img, txt, label, output_dim, similarity="euclidean", loss_type="l2", vartheta=0.5, sim_threshold=0.1):
+    img, txt, label = f32c(img), f32c(txt), f32c(label)
+    require_gpu(img, txt, label)
+    B, D = img.shape
+    Cn = label.shape[1]
+    out = torch.empty(1, dtype=torch.float32, device=img.device)
+    ws = workspace(lib().cmh_loss_workspace_bytes(B, D, Cn), img.device, "loss")
+    sim = {"euclidean": 0, "cosine": 1}[similarity]
+    lt = {"l1": 1, "l2": 2}[loss_type]
+    check(lib().cmh_dchmt_loss(ptr(img), ptr(txt), ptr(label), B, D, Cn, int(output_dim), sim, lt, float(vartheta),
+                               float(sim_threshold), ptr(out), ptr(ws), ws.numel(), stream_ptr(img.device)),
+          "cmh_dchmt_loss")
+    return out[0]

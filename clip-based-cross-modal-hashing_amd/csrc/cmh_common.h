@@ -1,0 +1,84 @@
+// Internal helpers shared by the HIP translation units of libcmh.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/cmh.h"
+
+namespace cmh {
+
+// thread-local error text behind cmh_last_error()
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+
+#define CMH_CHECK_ARG(cond, ...) \
+  do {                           \
+    if (!(cond)) return ::cmh::fail(CMH_ERR_INVALID, __VA_ARGS__); \
+  } while (0)
+
+#define CMH_CHECK_LAUNCH(what)                                                            \
+  do {                                                                                    \
+    hipError_t e__ = hipGetLastError();                                                   \
+    if (e__ != hipSuccess)                                                                \
+      return ::cmh::fail(CMH_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e__));          \
+  } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- bf16 (stored as uint16_t) ---------------------------------------------------------------
+typedef uint16_t bf16_t;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+  return __uint_as_float(static_cast<uint32_t>(v) << 16);
+}
+// round-to-nearest-even; NaN stays NaN (quiet)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<bf16_t>((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return static_cast<bf16_t>(u >> 16);
+}
+
+// ---- epilogue flags of the GEMM ---------------------------------------------------------------
+enum : int {
+  EPI_BIAS = 1,       // + bias[n]
+  EPI_QUICKGELU = 2,  // x * sigmoid(1.702 x)      (model/base/model.py:162-164)
+  EPI_RESIDUAL = 4,   // + residual[m,n] (f32)
+  EPI_OUT_BF16 = 8    // store bf16 instead of f32
+};
+
+// C[M,N] = epilogue(A[M,K] . W[N,K]^T).  A/W dtype = dt (f32 or bf16); residual f32; out f32|bf16.
+int launch_gemm(int dt, const void* A, const void* W, const float* bias, const float* residual,
+                void* out, int M, int N, int K, int epi, hipStream_t st);
+
+// LayerNorm over rows of x[M,d] (f32) -> out (f32 or bf16 per out_bf16). rows optionally gathered:
+// row r reads x[row_index[r]] when row_index != null.
+int launch_layernorm(const float* x, const int32_t* row_index, const float* w, const float* b,
+                     void* out, int out_bf16, int M, int d, hipStream_t st);
+
+// image [B,3,R,R] f32 -> patches [B*g*g, 3*p*p] (dt)
+int launch_patchify(const float* image, void* patches, int dt, int B, int R, int p, hipStream_t st);
+// tokens: x[b,0]=cls+pos[0]; x[b,1+i]=patch_out[b*g2+i]+pos[1+i]; then ln_pre -> x f32 [B*(g2+1), d]
+int launch_vit_assemble_lnpre(const float* patch_out, const float* cls, const float* pos,
+                              const float* lnw, const float* lnb, float* x, int B, int g2, int d,
+                              hipStream_t st);
+// x[b,t] = tok_emb[tokens[b,t]] + pos[t]; eot_row[b] = b*L + argmax_t tokens[b,t]
+int launch_text_embed(const int64_t* tokens, const float* tok_emb, const float* pos, float* x,
+                      int32_t* eot_row, int B, int L, int d, int vocab, hipStream_t st);
+// cls_row[b] = b*T
+int launch_iota_rows(int32_t* rows, int B, int T, hipStream_t st);
+
+// attention over qkv [B*T, 3d] (dt) -> o [B*T, d] (dt); heads = d/64; causal adds the -inf triu mask
+int launch_attention(const void* qkv, void* o, int dt, int B, int T, int d, int causal,
+                     const uint8_t* key_padding_mask, hipStream_t st);
+
+// y[M,N] f32 = act((x[M,K] . w[N,K]^T + bias) * mask*keep_scale); x,w dtype dt; any N, K%4==0, K<=4096
+int launch_small_linear(int dt, const void* x, const void* w, const float* bias, const float* mask,
+                        float keep_scale, int act, float* y, int M, int N, int K, hipStream_t st);
+
+}  // namespace cmh

@@ -1,0 +1,208 @@
+// C-ABI entry points of the two CLIP towers: kernel sequencing only (every kernel lives in gemm.hip,
+// norm_embed.hip, attention.hip, heads.hip).  Nothing here allocates or synchronises: all launches go
+// to the caller's stream and all scratch comes from the caller's workspace, so a whole encode is
+// graph-capturable.
+//
+// Data layout in HBM (per call, M = B*T rows, d = width, e = GEMM element size 4|2):
+//   x    f32 [M, d]    residual stream (kept fp32 in both modes)
+//   h    e   [M, d]    LayerNorm output / attention output (GEMM A operand)
+//   qkv  e   [M, 3d]   packed in_proj output            (vision: patch_out f32 [B*g2, d] aliases it)
+//   mlp  e   [M, 4d]   c_fc output after QuickGELU      (vision: patches e [B*g2, 3p^2] aliases it)
+//   rows i32 [B]       pooled row per sample (class token / EOT token)
+//   pool e   [B, d]    ln_post / ln_final of the pooled rows
+#include <cstring>
+
+#include "cmh_common.h"
+
+namespace cmh {
+
+static thread_local char g_err[512] = "";
+char* err_buf() { return g_err; }
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+struct Arena {
+  char* base;
+  size_t off = 0;
+  explicit Arena(void* p) : base(static_cast<char*>(p)) {}
+  void* take(size_t bytes) {
+    void* p = base ? base + off : nullptr;
+    off += align_up(bytes, 256);
+    return p;
+  }
+};
+
+struct TowerBufs {
+  float* x;
+  void* h;
+  void* qkv;
+  void* mlp;
+  int32_t* rows;
+  void* pool;
+  size_t total;
+};
+
+static TowerBufs carve(void* ws, size_t M, size_t B, size_t d, size_t e, size_t extra_qkv, size_t extra_mlp) {
+  Arena a(ws);
+  TowerBufs t;
+  t.x = static_cast<float*>(a.take(M * d * 4));
+  t.h = a.take(M * d * e);
+  size_t qkv_b = M * 3 * d * e, mlp_b = M * 4 * d * e;
+  t.qkv = a.take(qkv_b > extra_qkv ? qkv_b : extra_qkv);
+  t.mlp = a.take(mlp_b > extra_mlp ? mlp_b : extra_mlp);
+  t.rows = static_cast<int32_t*>(a.take(B * 4));
+  t.pool = a.take(B * d * e);
+  t.total = a.off;
+  return t;
+}
+
+static int tap(const cmh_taps* taps, int idx, const float* x, size_t bytes, hipStream_t st) {
+  if (!taps || idx >= taps->count || !taps->ptrs[idx]) return CMH_OK;
+  if (hipMemcpyAsync(taps->ptrs[idx], x, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return fail(CMH_ERR_LAUNCH, "tap copy failed");
+  return CMH_OK;
+}
+
+// One ResidualAttentionBlock (model/base/model.py:191-196):
+//   x += out_proj(attn(in_proj(ln_1(x))));  x += c_proj(QuickGELU(c_fc(ln_2(x))))
+static int run_block(const cmh_block_weights& w, int dt, const TowerBufs& t, int B, int T, int d, int causal,
+                     const uint8_t* kpm, hipStream_t st) {
+  const int M = B * T;
+  const int obf = dt == CMH_BF16 ? EPI_OUT_BF16 : 0;
+  int rc;
+  if ((rc = launch_layernorm(t.x, nullptr, w.ln1_w, w.ln1_b, t.h, dt == CMH_BF16, M, d, st))) return rc;
+  if ((rc = launch_gemm(dt, t.h, w.in_proj_w, w.in_proj_b, nullptr, t.qkv, M, 3 * d, d, EPI_BIAS | obf, st))) return rc;
+  if ((rc = launch_attention(t.qkv, t.h, dt, B, T, d, causal, kpm, st))) return rc;
+  if ((rc = launch_gemm(dt, t.h, w.out_proj_w, w.out_proj_b, t.x, t.x, M, d, d, EPI_BIAS | EPI_RESIDUAL, st))) return rc;
+  if ((rc = launch_layernorm(t.x, nullptr, w.ln2_w, w.ln2_b, t.h, dt == CMH_BF16, M, d, st))) return rc;
+  if ((rc = launch_gemm(dt, t.h, w.fc_w, w.fc_b, nullptr, t.mlp, M, 4 * d, d, EPI_BIAS | EPI_QUICKGELU | obf, st))) return rc;
+  if ((rc = launch_gemm(dt, t.mlp, w.proj_w, w.proj_b, t.x, t.x, M, d, 4 * d, EPI_BIAS | EPI_RESIDUAL, st))) return rc;
+  return CMH_OK;
+}
+
+static int final_projection(int dt, const void* pool, const void* w_t, float* feat, int B, int embed, int d,
+                            hipStream_t st) {
+  const int bk = dt == CMH_F32 ? 32 : 64;
+  if (embed % 128 == 0 && d % bk == 0) return launch_gemm(dt, pool, w_t, nullptr, nullptr, feat, B, embed, d, 0, st);
+  return launch_small_linear(dt, pool, w_t, nullptr, nullptr, 1.f, CMH_ACT_NONE, feat, B, embed, d, st);
+}
+
+static int check_tower(int dt, int width, int layers, int embed, const cmh_block_weights* blocks) {
+  CMH_CHECK_ARG(dt == CMH_F32 || dt == CMH_BF16, "bad gemm_dtype %d", dt);
+  CMH_CHECK_ARG(width > 0 && width % 128 == 0 && width <= 1024, "width %d must be a multiple of 128, <= 1024", width);
+  CMH_CHECK_ARG(layers >= 0 && embed > 0 && embed % 4 == 0, "bad layers/embed_dim");
+  CMH_CHECK_ARG(layers == 0 || blocks, "blocks is null");
+  return CMH_OK;
+}
+
+}  // namespace cmh
+
+using namespace cmh;
+
+extern "C" const char* cmh_last_error(void) { return err_buf(); }
+extern "C" int cmh_version(void) { return CMH_VERSION; }
+
+extern "C" size_t cmh_vit_workspace_bytes(const cmh_vit_weights* w, int32_t batch) {
+  if (!w || batch <= 0 || w->patch <= 0) return 0;
+  const size_t g = w->resolution / w->patch, g2 = g * g, T = g2 + 1, d = w->width;
+  const size_t e = w->gemm_dtype == CMH_BF16 ? 2 : 4;
+  const size_t B = batch, pk = 3ull * w->patch * w->patch;
+  return carve(nullptr, B * T, B, d, e, B * g2 * d * 4, B * g2 * pk * e).total;
+}
+
+extern "C" int cmh_vit_encode(const cmh_vit_weights* w, const float* image, int32_t batch, float* feat,
+                              void* workspace, size_t workspace_bytes, const cmh_taps* taps, void* stream) {
+  CMH_CHECK_ARG(w && image && feat && workspace, "vit_encode: null pointer");
+  CMH_CHECK_ARG(batch > 0, "vit_encode: batch %d", batch);
+  int rc = check_tower(w->gemm_dtype, w->width, w->layers, w->embed_dim, w->blocks);
+  if (rc) return rc;
+  CMH_CHECK_ARG(w->patch > 0 && w->resolution % w->patch == 0 && w->patch % 4 == 0, "vit_encode: resolution %d / patch %d",
+                w->resolution, w->patch);
+  const int dt = w->gemm_dtype, d = w->width, B = batch;
+  const int g = w->resolution / w->patch, g2 = g * g, T = g2 + 1, M = B * T;
+  const int pk = 3 * w->patch * w->patch;
+  const size_t e = dt == CMH_BF16 ? 2 : 4;
+  CMH_CHECK_ARG(pk % (dt == CMH_F32 ? 32 : 64) == 0, "vit_encode: 3*patch^2 = %d not a multiple of the GEMM K-step", pk);
+  const size_t need = cmh_vit_workspace_bytes(w, batch);
+  if (workspace_bytes < need) return fail(CMH_ERR_WORKSPACE, "vit_encode: workspace %zu < %zu bytes", workspace_bytes, need);
+  CMH_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "vit_encode: workspace must be 256-byte aligned");
+  hipStream_t st = as_stream(stream);
+  TowerBufs t = carve(workspace, static_cast<size_t>(M), B, d, e, static_cast<size_t>(B) * g2 * d * 4,
+                      static_cast<size_t>(B) * g2 * pk * e);
+  void* patches = t.mlp;
+  float* patch_out = static_cast<float*>(t.qkv);
+
+  // conv1 (kernel = stride = patch, no bias) as patch-matrix GEMM  (model.py:215,231-235)
+  if ((rc = launch_patchify(image, patches, dt, B, w->resolution, w->patch, st))) return rc;
+  if ((rc = launch_gemm(dt, patches, w->conv1_w, nullptr, nullptr, patch_out, B * g2, d, pk, 0, st))) return rc;
+  // [class ; patches] + positional, ln_pre  (:237-239)
+  if ((rc = launch_vit_assemble_lnpre(patch_out, w->class_embedding, w->positional_embedding, w->ln_pre_w,
+                                      w->ln_pre_b, t.x, B, g2, d, st))) return rc;
+  if ((rc = tap(taps, 0, t.x, static_cast<size_t>(M) * d * 4, st))) return rc;
+  for (int i = 0; i < w->layers; ++i) {
+    if ((rc = run_block(w->blocks[i], dt, t, B, T, d, /*causal=*/0, nullptr, st))) return rc;
+    if ((rc = tap(taps, 1 + i, t.x, static_cast<size_t>(M) * d * 4, st))) return rc;
+  }
+  // ln_post on the class token, @ proj  (:247-250)
+  if ((rc = launch_iota_rows(t.rows, B, T, st))) return rc;
+  if ((rc = launch_layernorm(t.x, t.rows, w->ln_post_w, w->ln_post_b, t.pool, dt == CMH_BF16, B, d, st))) return rc;
+  return final_projection(dt, t.pool, w->proj_t, feat, B, w->embed_dim, d, st);
+}
+
+extern "C" size_t cmh_text_workspace_bytes(const cmh_text_weights* w, int32_t batch, int32_t seq_len) {
+  if (!w || batch <= 0 || seq_len <= 0) return 0;
+  const size_t e = w->gemm_dtype == CMH_BF16 ? 2 : 4;
+  return carve(nullptr, static_cast<size_t>(batch) * seq_len, batch, w->width, e, 0, 0).total;
+}
+
+extern "C" int cmh_text_encode(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
+                               const uint8_t* key_padding_mask, float* feat, void* workspace,
+                               size_t workspace_bytes, const cmh_taps* taps, void* stream) {
+  CMH_CHECK_ARG(w && tokens && feat && workspace, "text_encode: null pointer");
+  CMH_CHECK_ARG(batch > 0 && seq_len > 0, "text_encode: batch %d seq_len %d", batch, seq_len);
+  int rc = check_tower(w->gemm_dtype, w->width, w->layers, w->embed_dim, w->blocks);
+  if (rc) return rc;
+  CMH_CHECK_ARG(seq_len <= w->context_length, "text_encode: seq_len %d > context_length %d", seq_len, w->context_length);
+  const int dt = w->gemm_dtype, d = w->width, B = batch, L = seq_len, M = B * L;
+  const size_t e = dt == CMH_BF16 ? 2 : 4;
+  const size_t need = cmh_text_workspace_bytes(w, batch, seq_len);
+  if (workspace_bytes < need) return fail(CMH_ERR_WORKSPACE, "text_encode: workspace %zu < %zu bytes", workspace_bytes, need);
+  CMH_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "text_encode: workspace must be 256-byte aligned");
+  hipStream_t st = as_stream(stream);
+  TowerBufs t = carve(workspace, static_cast<size_t>(M), B, d, e, 0, 0);
+
+  // token_embedding gather + positional_embedding[:L]; EOT row = argmax(tokens)  (model.py:360-362,370)
+  if ((rc = launch_text_embed(tokens, w->token_embedding, w->positional_embedding, t.x, t.rows, B, L, d,
+                              w->vocab_size, st))) return rc;
+  for (int i = 0; i < w->layers; ++i) {
+    if ((rc = run_block(w->blocks[i], dt, t, B, L, d, /*causal=*/1, key_padding_mask, st))) return rc;
+    if ((rc = tap(taps, 1 + i, t.x, static_cast<size_t>(M) * d * 4, st))) return rc;
+  }
+  // ln_final (row-wise, so only the pooled rows are normalised), @ text_projection  (:366-370)
+  if ((rc = launch_layernorm(t.x, t.rows, w->ln_final_w, w->ln_final_b, t.pool, dt == CMH_BF16, B, d, st))) return rc;
+  return final_projection(dt, t.pool, w->text_projection_t, feat, B, w->embed_dim, d, st);
+}
+
+extern "C" int cmh_linear_gemm(int32_t dtype, const void* x, const void* w, const float* bias, const float* residual,
+                               void* out, int32_t M, int32_t N, int32_t K, int32_t epilogue, void* stream) {
+  CMH_CHECK_ARG(x && w && out, "linear_gemm: null pointer");
+  return launch_gemm(dtype, x, w, bias, residual, out, M, N, K, epilogue, as_stream(stream));
+}
+
+extern "C" int cmh_layernorm(const float* x, const float* w, const float* b, void* out, int32_t out_dtype, int32_t M,
+                             int32_t d, void* stream) {
+  CMH_CHECK_ARG(x && w && b && out && M > 0, "layernorm: bad arguments");
+  return launch_layernorm(x, nullptr, w, b, out, out_dtype == CMH_BF16, M, d, as_stream(stream));
+}
+
+extern "C" int cmh_attention(int32_t dtype, const void* qkv, void* o, int32_t B, int32_t T, int32_t d, int32_t causal,
+                             const uint8_t* key_padding_mask, void* stream) {
+  CMH_CHECK_ARG(qkv && o, "attention: null pointer");
+  CMH_CHECK_ARG(dtype == CMH_F32 || dtype == CMH_BF16, "attention: bad dtype");
+  return launch_attention(qkv, o, dtype, B, T, d, causal, key_padding_mask, as_stream(stream));
+}

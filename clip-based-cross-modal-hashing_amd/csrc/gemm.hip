@@ -1,0 +1,210 @@
+// GEMM with fused epilogue for the CLIP towers:  out[M,N] = epi( X[M,K] . W[N,K]^T )
+//
+// Replaces every nn.Linear / in_proj / conv1-as-GEMM of the reference's transformer blocks
+// (model/base/model.py:171-196 ResidualAttentionBlock, :215 conv1, :250 proj, :370 text_projection).
+//
+// gfx950 design
+//  * one 128(n) x 128(m) output tile per 256-thread workgroup, 4 waves as 2(n) x 2(m), each wave a
+//    64x64 sub-tile = 4x4 MFMA 16x16 accumulators (64 acc VGPRs).
+//  * operands are both K-contiguous ([rows, K] row-major), so W rows feed the MFMA "A" operand and X
+//    rows the "B" operand: D = W_tile . X_tile^T, i.e. each lane ends up with 4 CONSECUTIVE n for one
+//    m -> 16-byte (f32) / 8-byte (bf16) epilogue loads+stores, bias as one float4.
+//  * a tile row is always 128 bytes: 64 bf16 (BK=64, v_mfma_f32_16x16x32_bf16, 2 k-steps) or 32 f32
+//    (BK=32, v_mfma_f32_16x16x4_f32, exact fp32 FMA chain; k is visited in a permuted order so one
+//    ds_read_b128 feeds 4 MFMAs).  Same staging code for both dtypes.
+//  * LDS image [128 rows][8 chunks of 16 B], chunk index XOR (row & 7): conflict-free for both the
+//    ds_write_b128 of the staging pass (8 lanes cover one 128-B row) and the ds_read_b128 fragment
+//    reads (16 lanes of a read group hit 16 distinct (row parity, chunk) pairs).
+//  * global -> register -> LDS double buffering, one barrier per K-step; loads for step k+1 are issued
+//    before the MFMAs of step k.
+//  * XCD-aware tile order: blocks that share an XCD (blockIdx % 8) walk n fastest over a contiguous
+//    range of tiles, so an X panel is re-used from that XCD's L2 across the N/128 column tiles and
+//    the whole W (<= 4.7 MB bf16) stays L2-resident.
+#include "cmh_common.h"
+
+namespace cmh {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+
+constexpr int kTile = 128;             // rows per operand tile
+constexpr int kRowBytes = 128;         // bytes per tile row
+constexpr int kTileBytes = kTile * kRowBytes;
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * kRowBytes + ((chunk ^ (row & 7)) << 4); }
+
+__device__ __forceinline__ float quick_gelu(float v) { return v / (1.0f + __expf(-1.702f * v)); }
+
+template <bool F32>
+__global__ __launch_bounds__(256) void gemm_kernel(const char* __restrict__ X, const char* __restrict__ W,
+                                                   const float* __restrict__ bias,
+                                                   const float* residual, void* out,
+                                                   int M, int N, int K, int epi) {
+  __shared__ __attribute__((aligned(16))) char lds[2][2][kTileBytes];   // [buf][0=W,1=X]
+
+  constexpr int ELT = F32 ? 4 : 2;
+  constexpr int BK = kRowBytes / ELT;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wn = wid >> 1, wm = wid & 1;
+
+  // ---- XCD-aware, bijective block -> tile map ------------------------------------------------
+  const int tiles_n = N / kTile;
+  const int tiles_m = (M + kTile - 1) / kTile;
+  const int total = tiles_n * tiles_m;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, local = bid >> 3;
+  const int q = total >> 3, r = total & 7;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  const int tile_m = logical / tiles_n;
+  const int tile_n = logical - tile_m * tiles_n;
+  const int m0 = tile_m * kTile, n0 = tile_n * kTile;
+
+  // ---- staging: each thread moves 4 x 16 B of the W tile and 4 x 16 B of the X tile ---------
+  const size_t row_stride = static_cast<size_t>(K) * ELT;
+  const char* gW[4];
+  const char* gX[4];
+  int lds_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = tid + 256 * i;
+    const int row = id >> 3, c = id & 7;
+    lds_off[i] = swz(row, c);
+    gW[i] = W + static_cast<size_t>(n0 + row) * row_stride + c * 16;
+    int xr = m0 + row;
+    xr = xr < M ? xr : M - 1;   // clamp: rows past M are computed on duplicated data, never stored
+    gX[i] = X + static_cast<size_t>(xr) * row_stride + c * 16;
+  }
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  u32x4_t rW[4], rX[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    rW[i] = *reinterpret_cast<const u32x4_t*>(gW[i]);
+    rX[i] = *reinterpret_cast<const u32x4_t*>(gX[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    *reinterpret_cast<u32x4_t*>(&lds[0][0][lds_off[i]]) = rW[i];
+    *reinterpret_cast<u32x4_t*>(&lds[0][1][lds_off[i]]) = rX[i];
+  }
+  __syncthreads();
+
+  const int nk = K / BK;
+  const int frow = lane & 15;     // row inside a 16-row fragment
+  const int fq = lane >> 4;       // k-group of the lane
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      const size_t koff = static_cast<size_t>(kt + 1) * kRowBytes;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        rW[i] = *reinterpret_cast<const u32x4_t*>(gW[i] + koff);
+        rX[i] = *reinterpret_cast<const u32x4_t*>(gX[i] + koff);
+      }
+    }
+    const char* tW = &lds[cur][0][0];
+    const char* tX = &lds[cur][1][0];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int chunk = ks * 4 + fq;
+      u32x4_t fw[4], fx[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        fw[t] = *reinterpret_cast<const u32x4_t*>(tW + swz(wn * 64 + t * 16 + frow, chunk));
+        fx[t] = *reinterpret_cast<const u32x4_t*>(tX + swz(wm * 64 + t * 16 + frow, chunk));
+      }
+      if constexpr (F32) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fw[a][s]),
+                                                               __uint_as_float(fx[b][s]), acc[a][b], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[a]),
+                                                                __builtin_bit_cast(bf16x8_t, fx[b]),
+                                                                acc[a][b], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nk) {
+      const int nxt = cur ^ 1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<u32x4_t*>(&lds[nxt][0][lds_off[i]]) = rW[i];
+        *reinterpret_cast<u32x4_t*>(&lds[nxt][1][lds_off[i]]) = rX[i];
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds n = nbase + 4*fq + {0..3} for m = mbase + frow -------------------
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int m = m0 + wm * 64 + b * 16 + frow;
+    if (m >= M) continue;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int n = n0 + wn * 64 + a * 16 + fq * 4;
+      f32x4_t v = acc[a][b];
+      if (epi & EPI_BIAS) {
+        const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(bias + n);
+        v += bv;
+      }
+      if (epi & EPI_QUICKGELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = quick_gelu(v[j]);
+      }
+      const size_t o = static_cast<size_t>(m) * N + n;
+      if (epi & EPI_RESIDUAL) {
+        const f32x4_t rv = *reinterpret_cast<const f32x4_t*>(residual + o);
+        v += rv;
+      }
+      if (epi & EPI_OUT_BF16) {
+        uint2 pk;
+        pk.x = static_cast<uint32_t>(f32_to_bf16(v[0])) | (static_cast<uint32_t>(f32_to_bf16(v[1])) << 16);
+        pk.y = static_cast<uint32_t>(f32_to_bf16(v[2])) | (static_cast<uint32_t>(f32_to_bf16(v[3])) << 16);
+        *reinterpret_cast<uint2*>(static_cast<bf16_t*>(out) + o) = pk;
+      } else {
+        *reinterpret_cast<f32x4_t*>(static_cast<float*>(out) + o) = v;
+      }
+    }
+  }
+}
+
+int launch_gemm(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out,
+                int M, int N, int K, int epi, hipStream_t st) {
+  const int bk = dt == CMH_F32 ? 32 : 64;
+  CMH_CHECK_ARG(dt == CMH_F32 || dt == CMH_BF16, "gemm: bad dtype %d", dt);
+  CMH_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
+  CMH_CHECK_ARG(N % kTile == 0, "gemm: N=%d must be a multiple of %d", N, kTile);
+  CMH_CHECK_ARG(K % bk == 0, "gemm: K=%d must be a multiple of %d", K, bk);
+  CMH_CHECK_ARG(!(epi & EPI_BIAS) || bias, "gemm: EPI_BIAS without bias");
+  CMH_CHECK_ARG(!(epi & EPI_RESIDUAL) || residual, "gemm: EPI_RESIDUAL without residual");
+  const int total = (N / kTile) * ((M + kTile - 1) / kTile);
+  if (dt == CMH_F32)
+    hipLaunchKernelGGL(gemm_kernel<true>, dim3(total), dim3(256), 0, st, static_cast<const char*>(A),
+                       static_cast<const char*>(W), bias, residual, out, M, N, K, epi);
+  else
+    hipLaunchKernelGGL(gemm_kernel<false>, dim3(total), dim3(256), 0, st, static_cast<const char*>(A),
+                       static_cast<const char*>(W), bias, residual, out, M, N, K, epi);
+  CMH_CHECK_LAUNCH("gemm");
+  return CMH_OK;
+}
+
+}  // namespace cmh

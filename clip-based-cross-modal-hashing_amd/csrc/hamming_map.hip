@@ -1,0 +1,631 @@
+// Hamming ranking + mAP on packed codes — replaces utils/calc_utils.py of the reference:
+//   calc_hammingDist  :8-13   0.5*(K - q.r)         -> AND/XOR + popcount on bit-planes
+//   calc_neighbor     :42-45  (la.lb^T > 0)         -> any(la & lb)
+//   calc_map_k_matrix :16-39  per-query sort + AP   -> map_query_kernel below
+//
+// Tie order.  The reference ranks with torch.sort(stable=False) on the CPU, i.e. libstdc++
+// std::sort (introsort) over (key, index) pairs with a key-only comparator; Hamming keys take <= 2K+1
+// values, so mAP depends on where introsort leaves equal keys (stable order differs by up to 2.7e-3).
+// map_query_kernel therefore EMULATES libstdc++'s introsort exactly, but breadth-first and in parallel:
+//   * the recursion tree of __introsort_loop is processed level by level (both children of a
+//     partition inherit the same depth budget, so a level == one depth value);
+//   * __unguarded_partition (Hoare, both pointers stop on keys equal to the pivot) is replaced by its
+//     closed form: with L = ascending positions whose key >= pivot and R = descending positions whose
+//     key <= pivot (original values), the sequential loop swaps exactly the pairs (L_i, R_i) for
+//     i < s, s = #{i : L_i < R_i} (a prefix), and returns cut = min(L_s, R_{s-1}).  L and R are built
+//     with wave ballots (+ a 16-entry scan when the whole workgroup shares one big segment), the swaps
+//     are independent;
+//   * __move_median_to_first and the depth-exhausted heapsort (__partial_sort) are restated verbatim
+//     (sequential, one lane; the latter is a rare fallback);
+//   * __final_insertion_sort is a stable sort of an array whose unsorted runs are the <=16-element
+//     leaves, so it equals a stable insertion sort of each leaf (one thread per leaf).
+// Keys: key = K - q.r in [0, 2K] (an order-preserving integer image of 0.5*(K - q.r)), exact for codes in
+// {-1,0,+1}: q.r = popc(nzq & nzr) - 2*popc((sq ^ sr) & nzq & nzr).
+//
+// One 1024-thread workgroup per query (grid-strided).  Elements are u32 = key << 19 | index, kept in
+// LDS when the query's working set fits (N <= ~23k: MIRFlickr-scale) and in a per-workgroup slice of the
+// caller's workspace otherwise (COCO / NUS-WIDE scale).  Integer/byte work, HBM/LDS-latency bound — no
+// MFMA on purpose.
+#include "cmh_common.h"
+
+namespace cmh {
+
+constexpr int NT = 1024;           // threads per workgroup
+constexpr int NWAVE = NT / 64;
+constexpr int kIdxBits = 19;       // N < 2^19 = 524288
+constexpr uint32_t kIdxMask = (1u << kIdxBits) - 1;
+constexpr int kMaxWords = 64;      // K <= 2048 bits
+constexpr int kCoopMin = 2048;     // segments at least this long are partitioned by the whole workgroup
+constexpr int kLeaf = 16;          // libstdc++ _S_threshold
+
+__device__ __forceinline__ int ekey(uint32_t e) { return static_cast<int>(e >> kIdxBits); }
+__device__ __forceinline__ int eidx(uint32_t e) { return static_cast<int>(e & kIdxMask); }
+
+__device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
+
+// positions map for the tmp lists: a segment [f,l) with l-f >= 17 owns tmp[g(f) .. g(l)) which holds
+// 2*((l-f)/2+1) <= (l-f)+2 entries.
+__device__ __host__ __forceinline__ int tmp_base(int x) { return x + 2 * (x / 17); }
+
+struct QueryStore {
+  uint32_t* elem;     // [N]
+  uint32_t* tmp;      // [tmp_base(N) + 8]
+  uint32_t* qa;       // segment queue A: pairs (f,l)  [2*(N/17+2)]
+  uint32_t* qb;       // segment queue B
+  uint32_t* leafbits; // [(N+31)/32] bit x = a segment starts at x
+  uint32_t* relbits;  // [(N+31)/32] bit j = database item j is relevant to the query
+};
+
+__host__ __device__ inline size_t store_words(int64_t N) {
+  const size_t n = static_cast<size_t>(N);
+  const size_t tmpw = n + 2 * (n / 17) + 8;
+  const size_t qw = 2 * (n / 17 + 2);
+  const size_t bw = (n + 31) / 32;
+  return n + tmpw + 2 * qw + 2 * bw + 16;
+}
+
+__device__ inline QueryStore carve_store(uint32_t* base, int N) {
+  QueryStore s;
+  const size_t n = static_cast<size_t>(N);
+  const size_t tmpw = n + 2 * (n / 17) + 8;
+  const size_t qw = 2 * (n / 17 + 2);
+  const size_t bw = (n + 31) / 32;
+  s.elem = base;
+  s.tmp = s.elem + n;
+  s.qa = s.tmp + tmpw;
+  s.qb = s.qa + qw;
+  s.leafbits = s.qb + qw;
+  s.relbits = s.leafbits + bw;
+  return s;
+}
+
+// ---- sync helpers -----------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <bool BLOCK>
+__device__ __forceinline__ void group_sync() {
+  if constexpr (BLOCK) __syncthreads();
+  else wave_sync();
+}
+
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---- libstdc++ pieces restated -------------------------------------------------------------------------
+// std::__move_median_to_first(result=f, a=f+1, b=mid, c=l-1) with a key-only '<'   (bits/stl_algo.h)
+__device__ inline void median_to_first(uint32_t* e, int f, int l) {
+  const int a = f + 1, b = f + (l - f) / 2, c = l - 1;
+  const uint32_t ea = e[a], eb = e[b], ec = e[c];
+  const int ka = ekey(ea), kb = ekey(eb), kc = ekey(ec);
+  int pick;
+  if (ka < kb) {
+    if (kb < kc) pick = b;
+    else if (ka < kc) pick = c;
+    else pick = a;
+  } else if (ka < kc) pick = a;
+  else if (kb < kc) pick = c;
+  else pick = b;
+  const uint32_t ef = e[f];
+  e[f] = e[pick];
+  e[pick] = ef;
+}
+
+// std::__adjust_heap + std::__push_heap (bits/stl_heap.h), key-only '<'
+__device__ inline void adjust_heap(uint32_t* first, int hole, int len, uint32_t value) {
+  const int top = hole;
+  int child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (ekey(first[child]) < ekey(first[child - 1])) child--;
+    first[hole] = first[child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    first[hole] = first[child - 1];
+    hole = child - 1;
+  }
+  int parent = (hole - 1) / 2;
+  while (hole > top && ekey(first[parent]) < ekey(value)) {
+    first[hole] = first[parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  first[hole] = value;
+}
+
+// std::__partial_sort(first, last, last) == __heap_select (make_heap) + __sort_heap
+__device__ inline void heap_sort_segment(uint32_t* e, int f, int l) {
+  uint32_t* first = e + f;
+  const int len = l - f;
+  if (len < 2) return;
+  for (int parent = (len - 2) / 2;; --parent) {
+    const uint32_t v = first[parent];
+    adjust_heap(first, parent, len, v);
+    if (parent == 0) break;
+  }
+  for (int last = len; last > 1;) {
+    --last;
+    const uint32_t v = first[last];
+    first[last] = first[0];
+    adjust_heap(first, 0, last, v);
+  }
+}
+
+// ---- one Hoare partition, closed form -------------------------------------------------------------------
+// Executed by a wave (BLOCK=false; lane in [0,64), wid=0, nw=1) or by the workgroup (BLOCK=true).
+// cnt: LDS scratch of 2*NWAVE+2 ints (BLOCK only).  Returns cut (same value in every participating lane).
+template <bool BLOCK>
+__device__ inline int partition_segment(const QueryStore& S, int f, int l, int lane, int wid, int nw, int* cnt) {
+  uint32_t* e = S.elem;
+  const int n = l - f;
+  if (wid == 0 && lane == 0) median_to_first(e, f, l);
+  group_sync<BLOCK>();
+  const int p = ekey(e[f]);
+  const int cap = n / 2 + 1;
+  uint32_t* tL = S.tmp + tmp_base(f);
+  uint32_t* tR = tL + cap;
+
+  // this wave's contiguous share of [f+1, l)
+  const int len = n - 1;
+  const int per = (((len + nw - 1) / nw) + 63) & ~63;
+  int a = f + 1 + wid * per;
+  a = a < l ? a : l;
+  int b = a + per;
+  b = b < l ? b : l;
+
+  int cL = 0, cR = 0;
+  for (int x0 = a; x0 < b; x0 += 64) {
+    const int x = x0 + lane;
+    const bool v = x < b;
+    const int k = v ? ekey(e[x]) : 0;
+    cL += __popcll(__ballot(v && k >= p));
+    cR += __popcll(__ballot(v && k <= p));
+  }
+  int offL = 0, offR = 0, Lc = cL, Rc = cR;
+  if constexpr (BLOCK) {
+    if (lane == 0) { cnt[wid] = cL; cnt[NWAVE + wid] = cR; }
+    __syncthreads();
+    Lc = 0; Rc = 0;
+    for (int w = 0; w < nw; ++w) {
+      const int l_ = cnt[w], r_ = cnt[NWAVE + w];
+      if (w < wid) offL += l_;
+      if (w > wid) offR += r_;
+      Lc += l_; Rc += r_;
+    }
+  }
+  int runL = 0, runR = 0;
+  const uint64_t lt = lanemask_lt(lane);
+  for (int x0 = a; x0 < b; x0 += 64) {
+    const int x = x0 + lane;
+    const bool v = x < b;
+    const int k = v ? ekey(e[x]) : 0;
+    const bool isL = v && k >= p, isR = v && k <= p;
+    const uint64_t mL = __ballot(isL), mR = __ballot(isR);
+    if (isL) {
+      const int rk = offL + runL + __popcll(mL & lt);
+      if (rk < cap) tL[rk] = static_cast<uint32_t>(x);
+    }
+    if (isR) {   // R is ordered by DEscending position
+      const int rk = offR + (cR - 1 - (runR + __popcll(mR & lt)));
+      if (rk < cap) tR[rk] = static_cast<uint32_t>(x);
+    }
+    runL += __popcll(mL);
+    runR += __popcll(mR);
+  }
+  if constexpr (BLOCK) {
+    if (wid == 0 && lane == 0) cnt[2 * NWAVE] = 0;
+  }
+  group_sync<BLOCK>();
+
+  int npairs = Lc < Rc ? Lc : Rc;
+  npairs = npairs < cap ? npairs : cap;
+  const int gtid = BLOCK ? wid * 64 + lane : lane;
+  const int gsize = BLOCK ? nw * 64 : 64;
+  int mine = 0;
+  for (int i = gtid; i < npairs; i += gsize) {
+    const uint32_t xl = tL[i], xr = tR[i];
+    if (xl < xr) {
+      const uint32_t t0 = e[xl];
+      e[xl] = e[xr];
+      e[xr] = t0;
+      ++mine;
+    }
+  }
+  int s = wave_sum_i(mine);
+  if constexpr (BLOCK) {
+    if (lane == 0 && s) atomicAdd(&cnt[2 * NWAVE], s);
+    __syncthreads();
+    s = cnt[2 * NWAVE];
+  }
+  const int lim = Lc < cap ? Lc : cap;
+  const uint32_t c1 = s < lim ? tL[s] : 0x7fffffffu;
+  const uint32_t c2 = s >= 1 ? tR[s - 1] : 0x7fffffffu;
+  const int cut = static_cast<int>(c1 < c2 ? c1 : c2);
+  group_sync<BLOCK>();
+  return cut;
+}
+
+__device__ __forceinline__ void push_seg(uint32_t* q, int* qcount, int f, int l) {
+  if (l - f > kLeaf) {
+    const int i = atomicAdd(qcount, 1);
+    q[2 * i] = static_cast<uint32_t>(f);
+    q[2 * i + 1] = static_cast<uint32_t>(l);
+  }
+}
+
+// ---- the per-query kernel ----------------------------------------------------------------------------------
+struct MapArgs {
+  const uint32_t *q_sign, *q_nz, *q_label, *r_sign, *r_nz, *r_label;
+  int Q, N, bits, W, LW;      // W = code words, LW = label words
+  long long topk;
+  int depth_limit;            // < 0: 2*floor(log2 N)
+  float* ap;
+  int32_t* perm;              // may be null
+  uint32_t* gstore;           // global slices (USE_LDS=false): gridDim.x * store_words(N)
+};
+
+template <bool USE_LDS>
+__global__ __launch_bounds__(NT) void map_query_kernel(MapArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t dyn_smem[];
+  __shared__ uint32_t sq[3][kMaxWords];     // query planes: sign, nz, label
+  __shared__ int scnt[2 * NWAVE + 4];
+  __shared__ int sqcount[2];
+  __shared__ int swork[NWAVE + 2];
+  __shared__ double sred[NWAVE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int N = A.N, W = A.W, LW = A.LW;
+  QueryStore S;
+  if constexpr (USE_LDS) S = carve_store(dyn_smem, N);
+  else S = carve_store(A.gstore + static_cast<size_t>(blockIdx.x) * store_words(N), N);
+  uint32_t* e = S.elem;
+  const int bw = (N + 31) / 32;
+
+  for (int qi = blockIdx.x; qi < A.Q; qi += gridDim.x) {
+    __syncthreads();
+    // ---- phase 0: keys + relevance ---------------------------------------------------------------
+    if (tid < W) { sq[0][tid] = A.q_sign[static_cast<size_t>(qi) * W + tid]; sq[1][tid] = A.q_nz[static_cast<size_t>(qi) * W + tid]; }
+    if (tid < LW) sq[2][tid] = A.q_label[static_cast<size_t>(qi) * LW + tid];
+    for (int i = tid; i < bw; i += NT) { S.leafbits[i] = 0; S.relbits[i] = 0; }
+    __syncthreads();
+    int myrel = 0;
+    for (int j0 = 0; j0 < N; j0 += NT) {
+      const int j = j0 + tid;
+      bool rel = false;
+      if (j < N) {
+        int both = 0, diff = 0;
+        const uint32_t* rs = A.r_sign + static_cast<size_t>(j) * W;
+        const uint32_t* rn = A.r_nz + static_cast<size_t>(j) * W;
+        for (int w = 0; w < W; ++w) {
+          const uint32_t nz = sq[1][w] & rn[w];
+          both += __popc(nz);
+          diff += __popc((sq[0][w] ^ rs[w]) & nz);
+        }
+        const int key = A.bits - (both - 2 * diff);        // = K - q.r, in [0, 2K]
+        e[j] = (static_cast<uint32_t>(key) << kIdxBits) | static_cast<uint32_t>(j);
+        const uint32_t* rl = A.r_label + static_cast<size_t>(j) * LW;
+        uint32_t any = 0;
+        for (int w = 0; w < LW; ++w) any |= sq[2][w] & rl[w];
+        rel = any != 0;
+      }
+      const uint64_t m = __ballot(rel);
+      if (lane == 0 && j0 + wid * 64 < N) {                  // 64 consecutive j per wave -> two bitmap words
+        const int wbase = (j0 + wid * 64) >> 5;
+        S.relbits[wbase] = static_cast<uint32_t>(m);
+        if (wbase + 1 < bw) S.relbits[wbase + 1] = static_cast<uint32_t>(m >> 32);
+      }
+      myrel += rel ? 1 : 0;
+    }
+    myrel = wave_sum_i(myrel);
+    if (lane == 0) swork[wid] = myrel;
+    if (tid == 0) { sqcount[0] = 0; sqcount[1] = 0; }
+    __syncthreads();
+    int tsum = 0;
+    for (int w = 0; w < NWAVE; ++w) tsum += swork[w];
+    if (tsum == 0) {                                          // utils/calc_utils.py:27-29 `continue`
+      if (tid == 0) A.ap[qi] = 0.f;
+      if (A.perm)
+        for (int j = tid; j < N; j += NT) A.perm[static_cast<size_t>(qi) * N + j] = -1;
+      continue;
+    }
+
+    // ---- phase 1: introsort loop, breadth-first ------------------------------------------------------
+    int depth = A.depth_limit >= 0 ? A.depth_limit : 2 * (31 - __clz(N));   // std::__lg(n) * 2
+    uint32_t* qcur = S.qa;
+    uint32_t* qnxt = S.qb;
+    int cur = 0;
+    if (tid == 0) {
+      S.leafbits[0] = 1u;
+      if (N > kLeaf) { qcur[0] = 0; qcur[1] = static_cast<uint32_t>(N); sqcount[0] = 1; }
+    }
+    __syncthreads();
+    while (true) {
+      const int nseg = sqcount[cur];
+      if (nseg == 0) break;
+      if (depth == 0) {                                       // depth budget exhausted -> heapsort each segment
+        for (int si = tid; si < nseg; si += NT) heap_sort_segment(e, static_cast<int>(qcur[2 * si]), static_cast<int>(qcur[2 * si + 1]));
+        break;
+      }
+      --depth;
+      if (tid == 0) sqcount[cur ^ 1] = 0;
+      __syncthreads();
+      // big segments first, one at a time, by the whole workgroup (nseg is small whenever any exist)
+      for (int si = 0; si < nseg; ++si) {
+        const int f = static_cast<int>(qcur[2 * si]), l = static_cast<int>(qcur[2 * si + 1]);
+        if (l - f < kCoopMin) continue;
+        const int cut = partition_segment<true>(S, f, l, lane, wid, NWAVE, scnt);
+        if (tid == 0) {
+          atomicOr(&S.leafbits[cut >> 5], 1u << (cut & 31));
+          push_seg(qnxt, &sqcount[cur ^ 1], f, cut);
+          push_seg(qnxt, &sqcount[cur ^ 1], cut, l);
+        }
+      }
+      // the rest: one wave per segment
+      for (int si = wid; si < nseg; si += NWAVE) {
+        const int f = static_cast<int>(qcur[2 * si]), l = static_cast<int>(qcur[2 * si + 1]);
+        if (l - f >= kCoopMin) continue;
+        const int cut = partition_segment<false>(S, f, l, lane, 0, 1, nullptr);
+        if (lane == 0) {
+          atomicOr(&S.leafbits[cut >> 5], 1u << (cut & 31));
+          push_seg(qnxt, &sqcount[cur ^ 1], f, cut);
+          push_seg(qnxt, &sqcount[cur ^ 1], cut, l);
+        }
+      }
+      __syncthreads();
+      uint32_t* t = qcur; qcur = qnxt; qnxt = t;
+      cur ^= 1;
+    }
+    __syncthreads();
+
+    // ---- phase 2: final insertion sort == stable sort of each <=16-element leaf ---------------------------
+    for (int wi = tid; wi < bw; wi += NT) {
+      uint32_t bitsw = S.leafbits[wi];
+      while (bitsw) {
+        const int bpos = __ffs(bitsw) - 1;
+        bitsw &= bitsw - 1;
+        const int s0 = wi * 32 + bpos;
+        int e1 = -1;                                          // next segment start within 16 positions
+        for (int x = s0 + 1; x <= s0 + kLeaf && x <= N; ++x) {
+          if (x == N || ((S.leafbits[x >> 5] >> (x & 31)) & 1u)) { e1 = x; break; }
+        }
+        if (e1 < 0) continue;                                 // longer than a leaf: heap-sorted, already in order
+        for (int i = s0 + 1; i < e1; ++i) {                   // std::__insertion_sort (stable)
+          const uint32_t v = e[i];
+          const int kv = ekey(v);
+          int j = i;
+          while (j > s0 && kv < ekey(e[j - 1])) { e[j] = e[j - 1]; --j; }
+          e[j] = v;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- phase 3: AP = mean_{r<=total} r / position_r   (utils/calc_utils.py:33-37) -----------------------
+    const long long total = A.topk > 0 && A.topk < tsum ? A.topk : tsum;
+    const int per = (((N + NWAVE - 1) / NWAVE) + 63) & ~63;
+    int a = wid * per; a = a < N ? a : N;
+    int b = a + per; b = b < N ? b : N;
+    int crel = 0;
+    for (int x0 = a; x0 < b; x0 += 64) {
+      const int x = x0 + lane;
+      bool r = false;
+      if (x < b) { const int id = eidx(e[x]); r = (S.relbits[id >> 5] >> (id & 31)) & 1u; }
+      crel += __popcll(__ballot(r));
+    }
+    __syncthreads();
+    if (lane == 0) swork[wid] = crel;
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < wid; ++w) off += swork[w];
+    double acc = 0.0;
+    int run = 0;
+    for (int x0 = a; x0 < b; x0 += 64) {
+      const int x = x0 + lane;
+      bool r = false;
+      int id = 0;
+      if (x < b) { id = eidx(e[x]); r = (S.relbits[id >> 5] >> (id & 31)) & 1u; }
+      const uint64_t m = __ballot(r);
+      if (r) {
+        const int rank = off + run + __popcll(m & lanemask_lt(lane)) + 1;
+        if (rank <= total) acc += static_cast<double>(static_cast<float>(rank) / static_cast<float>(x + 1));
+      }
+      run += __popcll(m);
+      if (A.perm && x < b) A.perm[static_cast<size_t>(qi) * N + x] = id;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) sred[wid] = acc;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int w = 0; w < NWAVE; ++w) t += sred[w];
+      A.ap[qi] = static_cast<float>(t / static_cast<double>(total));
+    }
+  }
+}
+
+// map = (((ap[0] + ap[1]) + ...) / Q) in f32, query order, like the reference's `map += AP` (:37-38)
+__global__ __launch_bounds__(64) void map_mean_kernel(const float* __restrict__ ap, int Q, float* __restrict__ out) {
+  __shared__ float buf[1024];
+  float acc = 0.f;
+  for (int q0 = 0; q0 < Q; q0 += 1024) {
+    const int n = Q - q0 < 1024 ? Q - q0 : 1024;
+    for (int i = threadIdx.x; i < n; i += 64) buf[i] = ap[q0 + i];
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (int i = 0; i < n; ++i) acc += buf[i];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = acc / static_cast<float>(Q);
+}
+
+// ---- packing ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_codes_kernel(const float* __restrict__ codes, int64_t n, int bits, int W,
+                                                         uint32_t* __restrict__ sp, uint32_t* __restrict__ np,
+                                                         int32_t* __restrict__ bad) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n * W) return;
+  const int64_t row = i / W;
+  const int w = static_cast<int>(i - row * W);
+  const float* c = codes + row * bits + w * 32;
+  const int cntb = bits - w * 32 < 32 ? bits - w * 32 : 32;
+  uint32_t s = 0, z = 0;
+  bool isbad = false;
+  for (int t = 0; t < cntb; ++t) {
+    const float v = c[t];
+    if (v == 1.f) { s |= 1u << t; z |= 1u << t; }
+    else if (v == -1.f) z |= 1u << t;
+    else if (v != 0.f) isbad = true;      // also catches NaN
+  }
+  sp[i] = s;
+  np[i] = z;
+  if (isbad) *bad = 1;
+}
+
+__global__ __launch_bounds__(256) void pack_labels_kernel(const float* __restrict__ lab, int64_t n, int classes, int LW,
+                                                          uint32_t* __restrict__ out, int32_t* __restrict__ bad) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n * LW) return;
+  const int64_t row = i / LW;
+  const int w = static_cast<int>(i - row * LW);
+  const float* c = lab + row * classes + w * 32;
+  const int cntb = classes - w * 32 < 32 ? classes - w * 32 : 32;
+  uint32_t s = 0;
+  bool isbad = false;
+  for (int t = 0; t < cntb; ++t) {
+    const float v = c[t];
+    if (v > 0.f) s |= 1u << t;
+    else if (!(v == 0.f)) isbad = true;   // negative or NaN
+  }
+  out[i] = s;
+  if (isbad) *bad = 1;
+}
+
+__global__ __launch_bounds__(256) void hamming_dist_kernel(const uint32_t* __restrict__ qs, const uint32_t* __restrict__ qn,
+                                                           const uint32_t* __restrict__ rs, const uint32_t* __restrict__ rn,
+                                                           int Q, int64_t N, int bits, int W, float* __restrict__ dist) {
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int q = blockIdx.y;
+  if (j >= N) return;
+  int both = 0, diff = 0;
+  for (int w = 0; w < W; ++w) {
+    const uint32_t nz = qn[static_cast<size_t>(q) * W + w] & rn[j * W + w];
+    both += __popc(nz);
+    diff += __popc((qs[static_cast<size_t>(q) * W + w] ^ rs[j * W + w]) & nz);
+  }
+  dist[static_cast<size_t>(q) * N + j] = 0.5f * static_cast<float>(bits - (both - 2 * diff));
+}
+
+__global__ __launch_bounds__(256) void neighbor_kernel(const uint32_t* __restrict__ la, const uint32_t* __restrict__ lb,
+                                                       int A, int B, int LW, float* __restrict__ sim) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  if (j >= B) return;
+  uint32_t any = 0;
+  for (int w = 0; w < LW; ++w) any |= la[static_cast<size_t>(i) * LW + w] & lb[static_cast<size_t>(j) * LW + w];
+  sim[static_cast<size_t>(i) * B + j] = any ? 1.f : 0.f;
+}
+
+static size_t lds_bytes_needed(int64_t N) { return store_words(N) * 4; }
+constexpr size_t kLdsBudget = 150 * 1024;   // of 160 KiB; static __shared__ of the kernel takes ~2 KiB
+
+static int map_slots(int Q) { return Q < 1024 ? Q : 1024; }
+
+}  // namespace cmh
+
+using namespace cmh;
+
+extern "C" int cmh_pack_codes(const float* codes, int64_t n, int32_t bits, uint32_t* sign_plane, uint32_t* nz_plane,
+                              int32_t* bad_flag, void* stream) {
+  CMH_CHECK_ARG(codes && sign_plane && nz_plane && bad_flag, "pack_codes: null pointer");
+  CMH_CHECK_ARG(n > 0 && bits > 0 && bits <= 32 * kMaxWords, "pack_codes: n=%lld bits=%d", static_cast<long long>(n), bits);
+  const int W = (bits + 31) / 32;
+  const int64_t total = n * W;
+  hipLaunchKernelGGL(pack_codes_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                     codes, n, bits, W, sign_plane, nz_plane, bad_flag);
+  CMH_CHECK_LAUNCH("pack_codes");
+  return CMH_OK;
+}
+
+extern "C" int cmh_pack_labels(const float* labels, int64_t n, int32_t classes, uint32_t* packed, int32_t* bad_flag,
+                               void* stream) {
+  CMH_CHECK_ARG(labels && packed && bad_flag, "pack_labels: null pointer");
+  CMH_CHECK_ARG(n > 0 && classes > 0 && classes <= 32 * kMaxWords, "pack_labels: n=%lld classes=%d",
+                static_cast<long long>(n), classes);
+  const int LW = (classes + 31) / 32;
+  const int64_t total = n * LW;
+  hipLaunchKernelGGL(pack_labels_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0,
+                     as_stream(stream), labels, n, classes, LW, packed, bad_flag);
+  CMH_CHECK_LAUNCH("pack_labels");
+  return CMH_OK;
+}
+
+extern "C" int cmh_hamming_dist(const uint32_t* q_sign, const uint32_t* q_nz, const uint32_t* r_sign,
+                                const uint32_t* r_nz, int32_t Q, int64_t N, int32_t bits, float* dist, void* stream) {
+  CMH_CHECK_ARG(q_sign && q_nz && r_sign && r_nz && dist, "hamming_dist: null pointer");
+  CMH_CHECK_ARG(Q > 0 && Q <= 65535 && N > 0 && bits > 0 && bits <= 32 * kMaxWords, "hamming_dist: Q=%d N=%lld bits=%d", Q,
+                static_cast<long long>(N), bits);
+  const int W = (bits + 31) / 32;
+  hipLaunchKernelGGL(hamming_dist_kernel, dim3(static_cast<unsigned>((N + 255) / 256), Q), dim3(256), 0,
+                     as_stream(stream), q_sign, q_nz, r_sign, r_nz, Q, N, bits, W, dist);
+  CMH_CHECK_LAUNCH("hamming_dist");
+  return CMH_OK;
+}
+
+extern "C" int cmh_calc_neighbor(const uint32_t* la, const uint32_t* lb, int32_t A, int32_t B, int32_t classes,
+                                 float* sim, void* stream) {
+  CMH_CHECK_ARG(la && lb && sim, "calc_neighbor: null pointer");
+  CMH_CHECK_ARG(A > 0 && A <= 65535 && B > 0 && classes > 0 && classes <= 32 * kMaxWords, "calc_neighbor: bad shape");
+  const int LW = (classes + 31) / 32;
+  hipLaunchKernelGGL(neighbor_kernel, dim3((B + 255) / 256, A), dim3(256), 0, as_stream(stream), la, lb, A, B, LW, sim);
+  CMH_CHECK_LAUNCH("calc_neighbor");
+  return CMH_OK;
+}
+
+extern "C" size_t cmh_map_workspace_bytes(int32_t Q, int64_t N, int32_t bits, int32_t tie_order) {
+  (void)bits; (void)tie_order;
+  if (Q <= 0 || N <= 0) return 0;
+  if (lds_bytes_needed(N) <= kLdsBudget) return 256;
+  return static_cast<size_t>(map_slots(Q)) * store_words(N) * 4 + 256;
+}
+
+extern "C" int cmh_hamming_map(const uint32_t* q_sign, const uint32_t* q_nz, const uint32_t* q_label,
+                               const uint32_t* r_sign, const uint32_t* r_nz, const uint32_t* r_label, int32_t Q,
+                               int64_t N, int32_t bits, int32_t classes, int64_t topk, int32_t tie_order,
+                               int32_t depth_limit_override, float* ap, float* map, int32_t* perm, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  CMH_CHECK_ARG(q_sign && q_nz && q_label && r_sign && r_nz && r_label && ap && map, "hamming_map: null pointer");
+  CMH_CHECK_ARG(Q > 0 && N > 0, "hamming_map: Q=%d N=%lld", Q, static_cast<long long>(N));
+  CMH_CHECK_ARG(N < (1ll << kIdxBits), "hamming_map: N=%lld exceeds %d", static_cast<long long>(N), (1 << kIdxBits) - 1);
+  CMH_CHECK_ARG(bits > 0 && bits <= 32 * kMaxWords && 2 * bits < (1 << (32 - kIdxBits)), "hamming_map: bits=%d unsupported", bits);
+  CMH_CHECK_ARG(classes > 0 && classes <= 32 * kMaxWords, "hamming_map: classes=%d unsupported", classes);
+  CMH_CHECK_ARG(tie_order == CMH_TIE_REFERENCE, "hamming_map: tie_order %d not implemented (only CMH_TIE_REFERENCE)", tie_order);
+  const size_t need = cmh_map_workspace_bytes(Q, N, bits, tie_order);
+  if (workspace_bytes < need || !workspace) return fail(CMH_ERR_WORKSPACE, "hamming_map: workspace %zu < %zu bytes", workspace_bytes, need);
+  hipStream_t st = as_stream(stream);
+  MapArgs a;
+  a.q_sign = q_sign; a.q_nz = q_nz; a.q_label = q_label; a.r_sign = r_sign; a.r_nz = r_nz; a.r_label = r_label;
+  a.Q = Q; a.N = static_cast<int>(N); a.bits = bits; a.W = (bits + 31) / 32; a.LW = (classes + 31) / 32;
+  a.topk = topk; a.depth_limit = depth_limit_override; a.ap = ap; a.perm = perm;
+  a.gstore = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+  const size_t lds = lds_bytes_needed(N);
+  if (lds <= kLdsBudget) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(map_query_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)
+      return fail(CMH_ERR_LAUNCH, "hamming_map: cannot reserve %zu bytes of LDS", lds);
+    hipLaunchKernelGGL(map_query_kernel<true>, dim3(map_slots(Q)), dim3(NT), lds, st, a);
+  } else {
+    hipLaunchKernelGGL(map_query_kernel<false>, dim3(map_slots(Q)), dim3(NT), 0, st, a);
+  }
+  CMH_CHECK_LAUNCH("hamming_map");
+  hipLaunchKernelGGL(map_mean_kernel, dim3(1), dim3(64), 0, st, ap, Q, map);
+  CMH_CHECK_LAUNCH("map_mean");
+  return CMH_OK;
+}

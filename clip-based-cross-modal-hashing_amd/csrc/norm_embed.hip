@@ -1,0 +1,249 @@
+// Row-wise kernels of the CLIP towers: LayerNorm (fp32 statistics, model/base/model.py:153-159),
+// conv1 patch extraction (:215,:231-235), class/positional embedding + ln_pre (:237-239),
+// token embedding gather + positional (:360-362), EOT row selection (:370), f32->bf16 casts.
+// All HBM-bound; one wave per row, 16-byte accesses.
+#include "cmh_common.h"
+
+namespace cmh {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+constexpr int kMaxVec = 4;  // up to 4 float4 per lane -> d <= 1024
+
+// Normalise one row held as float4 fragments v[0..nv) (lane owns elements lane*4 + 256*j).
+__device__ __forceinline__ void ln_row(float4 (&v)[kMaxVec], int nv, int d, int lane, const float* __restrict__ w,
+                                       const float* __restrict__ b, void* __restrict__ out_row, int out_bf16) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < kMaxVec; ++j)
+    if (j < nv && lane * 4 + 256 * j < d) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  const float mean = wave_sum(s) / static_cast<float>(d);
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < kMaxVec; ++j)
+    if (j < nv && lane * 4 + 256 * j < d) {
+      const float a = v[j].x - mean, bb = v[j].y - mean, c = v[j].z - mean, e = v[j].w - mean;
+      ss += (a * a + bb * bb) + (c * c + e * e);
+    }
+  const float rstd = 1.0f / sqrtf(wave_sum(ss) / static_cast<float>(d) + 1e-5f);
+#pragma unroll
+  for (int j = 0; j < kMaxVec; ++j) {
+    const int e0 = lane * 4 + 256 * j;
+    if (j < nv && e0 < d) {
+      const float4 wv = *reinterpret_cast<const float4*>(w + e0);
+      const float4 bv = *reinterpret_cast<const float4*>(b + e0);
+      float4 y;
+      y.x = (v[j].x - mean) * rstd * wv.x + bv.x;
+      y.y = (v[j].y - mean) * rstd * wv.y + bv.y;
+      y.z = (v[j].z - mean) * rstd * wv.z + bv.z;
+      y.w = (v[j].w - mean) * rstd * wv.w + bv.w;
+      if (out_bf16) {
+        uint2 pk;
+        pk.x = static_cast<uint32_t>(f32_to_bf16(y.x)) | (static_cast<uint32_t>(f32_to_bf16(y.y)) << 16);
+        pk.y = static_cast<uint32_t>(f32_to_bf16(y.z)) | (static_cast<uint32_t>(f32_to_bf16(y.w)) << 16);
+        *reinterpret_cast<uint2*>(static_cast<bf16_t*>(out_row) + e0) = pk;
+      } else {
+        *reinterpret_cast<float4*>(static_cast<float*>(out_row) + e0) = y;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const int32_t* __restrict__ row_index,
+                                                        const float* __restrict__ w, const float* __restrict__ b,
+                                                        void* __restrict__ out, int out_bf16, int M, int d) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const size_t src = row_index ? static_cast<size_t>(row_index[row]) : static_cast<size_t>(row);
+  const float* xr = x + src * d;
+  const int nv = (d + 255) / 256;
+  float4 v[kMaxVec];
+#pragma unroll
+  for (int j = 0; j < kMaxVec; ++j) {
+    const int e0 = lane * 4 + 256 * j;
+    v[j] = (j < nv && e0 < d) ? *reinterpret_cast<const float4*>(xr + e0) : float4{0.f, 0.f, 0.f, 0.f};
+  }
+  char* orow = static_cast<char*>(out) + static_cast<size_t>(row) * d * (out_bf16 ? 2 : 4);
+  ln_row(v, nv, d, lane, w, b, orow, out_bf16);
+}
+
+int launch_layernorm(const float* x, const int32_t* row_index, const float* w, const float* b, void* out,
+                     int out_bf16, int M, int d, hipStream_t st) {
+  CMH_CHECK_ARG(d % 4 == 0 && d <= 256 * kMaxVec, "layernorm: d=%d must be a multiple of 4 and <= 1024", d);
+  hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, row_index, w, b, out, out_bf16, M, d);
+  CMH_CHECK_LAUNCH("layernorm");
+  return CMH_OK;
+}
+
+// ---- conv1 as GEMM: patch extraction -----------------------------------------------------------
+// patches[(b*g + gy)*g + gx][c*p*p + py*p + px] = image[b][c][gy*p+py][gx*p+px]
+// one thread moves 4 consecutive px (16-B read; 16-B f32 / 8-B bf16 write).
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ image, void* __restrict__ patches,
+                                                       int out_bf16, int B, int R, int p) {
+  const int g = R / p;
+  const size_t total4 = static_cast<size_t>(B) * 3 * R * R / 4;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total4;
+       i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    const size_t e = i * 4;                       // flat index into image
+    const int x = static_cast<int>(e % R);
+    const int y = static_cast<int>((e / R) % R);
+    const int c = static_cast<int>((e / (static_cast<size_t>(R) * R)) % 3);
+    const int b = static_cast<int>(e / (static_cast<size_t>(R) * R * 3));
+    const int gx = x / p, px = x % p, gy = y / p, py = y % p;
+    const float4 v = *reinterpret_cast<const float4*>(image + e);
+    const size_t row = (static_cast<size_t>(b) * g + gy) * g + gx;
+    const size_t col = (static_cast<size_t>(c) * p + py) * p + px;
+    const size_t o = row * (3 * p * p) + col;
+    if (out_bf16) {
+      uint2 pk;
+      pk.x = static_cast<uint32_t>(f32_to_bf16(v.x)) | (static_cast<uint32_t>(f32_to_bf16(v.y)) << 16);
+      pk.y = static_cast<uint32_t>(f32_to_bf16(v.z)) | (static_cast<uint32_t>(f32_to_bf16(v.w)) << 16);
+      *reinterpret_cast<uint2*>(static_cast<bf16_t*>(patches) + o) = pk;
+    } else {
+      *reinterpret_cast<float4*>(static_cast<float*>(patches) + o) = v;
+    }
+  }
+}
+
+int launch_patchify(const float* image, void* patches, int dt, int B, int R, int p, hipStream_t st) {
+  CMH_CHECK_ARG(p % 4 == 0 && R % p == 0, "patchify: resolution %d / patch %d unsupported", R, p);
+  const size_t total4 = static_cast<size_t>(B) * 3 * R * R / 4;
+  const int blocks = static_cast<int>(total4 / 256 + 1 < 4096 ? total4 / 256 + 1 : 4096);
+  hipLaunchKernelGGL(patchify_kernel, dim3(blocks), dim3(256), 0, st, image, patches, dt == CMH_BF16, B, R, p);
+  CMH_CHECK_LAUNCH("patchify");
+  return CMH_OK;
+}
+
+// ---- [cls ; patches] + positional -> ln_pre -------------------------------------------------------
+__global__ __launch_bounds__(256) void vit_assemble_lnpre_kernel(const float* __restrict__ patch_out,
+                                                                 const float* __restrict__ cls,
+                                                                 const float* __restrict__ pos,
+                                                                 const float* __restrict__ lnw,
+                                                                 const float* __restrict__ lnb, float* __restrict__ x,
+                                                                 int B, int g2, int d) {
+  const int lane = threadIdx.x & 63;
+  const int T = g2 + 1;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B * T) return;
+  const int b = row / T, t = row - b * T;
+  const float* src = t == 0 ? cls : patch_out + (static_cast<size_t>(b) * g2 + (t - 1)) * d;
+  const float* pr = pos + static_cast<size_t>(t) * d;
+  const int nv = (d + 255) / 256;
+  float4 v[kMaxVec];
+#pragma unroll
+  for (int j = 0; j < kMaxVec; ++j) {
+    const int e0 = lane * 4 + 256 * j;
+    if (j < nv && e0 < d) {
+      const float4 a = *reinterpret_cast<const float4*>(src + e0);
+      const float4 q = *reinterpret_cast<const float4*>(pr + e0);
+      v[j] = float4{a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w};
+    } else {
+      v[j] = float4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  ln_row(v, nv, d, lane, lnw, lnb, x + static_cast<size_t>(row) * d, 0);
+}
+
+int launch_vit_assemble_lnpre(const float* patch_out, const float* cls, const float* pos, const float* lnw,
+                              const float* lnb, float* x, int B, int g2, int d, hipStream_t st) {
+  CMH_CHECK_ARG(d % 4 == 0 && d <= 256 * kMaxVec, "vit_assemble: width %d unsupported", d);
+  const int rows = B * (g2 + 1);
+  hipLaunchKernelGGL(vit_assemble_lnpre_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, patch_out, cls, pos, lnw,
+                     lnb, x, B, g2, d);
+  CMH_CHECK_LAUNCH("vit_assemble_lnpre");
+  return CMH_OK;
+}
+
+// ---- token embedding + positional; EOT row = first argmax of the token ids ------------------------
+__global__ __launch_bounds__(256) void text_embed_kernel(const int64_t* __restrict__ tokens,
+                                                         const float* __restrict__ tok_emb,
+                                                         const float* __restrict__ pos, float* __restrict__ x,
+                                                         int32_t* __restrict__ eot_row, int B, int L, int d,
+                                                         int vocab) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B * L) return;
+  const int b = row / L, t = row - b * L;
+  int64_t id = tokens[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);   // out-of-vocabulary ids would fault; clamp
+  const float* er = tok_emb + static_cast<size_t>(id) * d;
+  const float* pr = pos + static_cast<size_t>(t) * d;
+  float* xr = x + static_cast<size_t>(row) * d;
+  for (int e0 = lane * 4; e0 < d; e0 += 256) {
+    const float4 a = *reinterpret_cast<const float4*>(er + e0);
+    const float4 q = *reinterpret_cast<const float4*>(pr + e0);
+    *reinterpret_cast<float4*>(xr + e0) = float4{a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w};
+  }
+  if (t == 0) {   // this wave also finds argmax over the caption (first maximum, like torch.argmax)
+    int64_t best = INT64_MIN;
+    int besti = 0;
+    for (int i = lane; i < L; i += 64) {
+      const int64_t v = tokens[static_cast<size_t>(b) * L + i];
+      if (v > best) { best = v; besti = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const int64_t ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(besti, o, 64);
+      if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+    }
+    if (lane == 0) eot_row[b] = b * L + besti;
+  }
+}
+
+int launch_text_embed(const int64_t* tokens, const float* tok_emb, const float* pos, float* x, int32_t* eot_row,
+                      int B, int L, int d, int vocab, hipStream_t st) {
+  CMH_CHECK_ARG(d % 4 == 0, "text_embed: width %d unsupported", d);
+  const int rows = B * L;
+  hipLaunchKernelGGL(text_embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, tokens, tok_emb, pos, x, eot_row,
+                     B, L, d, vocab);
+  CMH_CHECK_LAUNCH("text_embed");
+  return CMH_OK;
+}
+
+__global__ void iota_rows_kernel(int32_t* rows, int B, int T) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) rows[i] = i * T;
+}
+
+int launch_iota_rows(int32_t* rows, int B, int T, hipStream_t st) {
+  hipLaunchKernelGGL(iota_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, st, rows, B, T);
+  CMH_CHECK_LAUNCH("iota_rows");
+  return CMH_OK;
+}
+
+// ---- f32 -> bf16 ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                                        int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  const int64_t n4 = n / 4;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 v = *reinterpret_cast<const float4*>(src + i * 4);
+    uint2 pk;
+    pk.x = static_cast<uint32_t>(f32_to_bf16(v.x)) | (static_cast<uint32_t>(f32_to_bf16(v.y)) << 16);
+    pk.y = static_cast<uint32_t>(f32_to_bf16(v.z)) | (static_cast<uint32_t>(f32_to_bf16(v.w)) << 16);
+    *reinterpret_cast<uint2*>(dst + i * 4) = pk;
+  }
+  for (int64_t i = n4 * 4 + static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
+    dst[i] = f32_to_bf16(src[i]);
+}
+
+}  // namespace cmh
+
+extern "C" int cmh_cast_f32_to_bf16(const float* src, void* dst_bf16, int64_t n, void* stream) {
+  using namespace cmh;
+  CMH_CHECK_ARG(n >= 0, "cast: negative n");
+  if (n == 0) return CMH_OK;
+  CMH_CHECK_ARG((reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst_bf16) & 7) == 0,
+                "cast: pointers must be 16-byte (src) / 8-byte (dst) aligned");
+  const int64_t blocks = (n / 4 + 255) / 256 + 1;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(static_cast<unsigned>(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
+                     as_stream(stream), src, static_cast<bf16_t*>(dst_bf16), n);
+  CMH_CHECK_LAUNCH("cast_f32_to_bf16");
+  return CMH_OK;
+}

@@ -1,0 +1,42 @@
+"""Synthetic stand-in for the reference's data layer (dataset/base.py, dataset/dataloader.py — host
+input pipeline, out of scope).  Honours the path's INPUT CONTRACT:
+  __getitem__ -> (image f32 [3,R,R] ~N(0,1), caption i64 [maxWords] SOT..EOT,0-pad, label f32 [C], index)
+  get_all_label() -> [n, C]
+and the reference's split rule (dataset/dataloader.py:6-11): seeded permutation, first query_num =
+queries, next train_num = train, everything after the queries (train included) = retrieval DB."""
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+SOT, EOT = 49406, 49407
+
+
+class SyntheticPairs(Dataset):
+    def __init__(self, ids, labels, max_words, resolution, seed):
+        self.ids, self.labels = ids, labels
+        self.max_words, self.resolution, self.seed = max_words, resolution, seed
+
+    def __len__(self):
+        return len(self.ids)
+
+    def get_all_label(self):
+        return torch.from_numpy(self.labels)
+
+    def __getitem__(self, index):
+        rng = np.random.default_rng([self.seed, int(self.ids[index])])
+        image = torch.from_numpy(rng.standard_normal((3, self.resolution, self.resolution)).astype(np.float32))
+        cap = np.zeros(self.max_words, np.int64)
+        n = int(rng.integers(2, self.max_words))
+        cap[0] = SOT
+        cap[1:n] = rng.integers(1, SOT, size=n - 1)
+        cap[n] = EOT
+        return image, torch.from_numpy(cap), torch.from_numpy(self.labels[index]), index
+
+
+def dataloader(total, nclass, maxWords=32, imageResolution=224, query_num=5000, train_num=10000, seed=None):
+    rng = np.random.default_rng(seed)
+    labels = (rng.random((total, nclass)) < 0.15).astype(np.float32)
+    perm = np.random.RandomState(seed).permutation(total)
+    q, t, r = perm[:query_num], perm[query_num:query_num + train_num], perm[query_num:]
+    mk = lambda ids: SyntheticPairs(ids, labels[ids], maxWords, imageResolution, seed or 0)
+    return mk(t), mk(q), mk(r)

@@ -1,0 +1,44 @@
+"""Method registry + CLI with the reference's surface (main.py:18-46): `trainers` maps the method
+name to a Trainer class and `trainer(args, 0)` constructs AND runs it.  Methods are imported lazily
+(the reference's eager imports make `python main.py` un-importable as shipped)."""
+import argparse
+import importlib
+
+from argsbase import str2bool
+
+_REGISTRY = {
+    'DSPH': ("train.DSPH.hash_train", "DSPHTrainer"),
+    'DCHMT': ("train.DCHMT.hash_train", "DCHMTTrainer"),
+}
+_NOT_BUILT = ['TwDH', 'MITH', 'DNPH', 'DHaPH', 'DMsH_LN', 'DNpH', 'DPBE', 'DDWSH', 'DDBH', 'DScPH', 'DPSIH', 'DGHDGH']
+
+
+class _LazyTrainers(dict):
+    def __missing__(self, key):
+        if key in _REGISTRY:
+            mod, cls = _REGISTRY[key]
+            self[key] = getattr(importlib.import_module(mod), cls)
+            return self[key]
+        if key in _NOT_BUILT:
+            raise NotImplementedError(f"method {key}: trainer not built in this round (see DESIGN.md scope table)")
+        raise KeyError(key)
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+
+trainers = _LazyTrainers()
+
+if __name__ == "__main__":
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--method", type=str, default='DSPH', help="Trainer method name")
+    parser.add_argument("--dataset", type=str, default="flickr", help="name of dataset")
+    parser.add_argument("--output-dim", type=int, default=16)
+    parser.add_argument("--is-train", type=str2bool, default=True)
+    args, _ = parser.parse_known_args()
+
+    trainer = trainers.get(args.method)
+    trainer(args, 0)

@@ -1,0 +1,15 @@
+"""DSPH model (reference model/DSPH.py): Baseclip with LinearHash heads."""
+import logging
+
+from model.modelbase import Baseclip
+
+
+class MDSPH(Baseclip):
+
+    def __init__(self, outputDim=64, clipPath="./ViT-B-32.pt", writer=None, saveDir="./result/log",
+                 logger: logging.Logger = None, is_train=True):
+        super(MDSPH, self).__init__(outputDim=outputDim, clipPath=clipPath, writer=writer,
+                                    saveDir=saveDir, logger=logger, is_train=is_train)
+
+    def forward(self, image, text):
+        return self.encode_image(image), self.encode_text(text)

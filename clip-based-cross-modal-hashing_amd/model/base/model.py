@@ -1,0 +1,366 @@
+"""CLIP ViT trunk with the reference's module tree and state_dict, executed by libcmh.so.
+
+Mirror of the reference's model/base/model.py (ViT path only; the ModifiedResNet path is not
+reachable with a ViT-B/32 checkpoint):
+  LayerNorm / QuickGELU            model/base/model.py:153-164
+  ResidualAttentionBlock           :167-196
+  Transformer                      :199-207
+  VisionTransformer                :210-252
+  CLIP (encode_image/encode_text)  :255-372
+  convert_weights / build_model    :391-455
+The nn.Modules here are parameter containers with the SAME names and shapes (302 tensors for
+ViT-B/32, so OpenAI `ViT-B-32.pt` and reference `model-N.pth` checkpoints load strict); `forward`
+never touches ATen math: encode_image / encode_text call cmh_vit_encode / cmh_text_encode.
+
+Arithmetic mode (`CLIP.set_gemm_dtype`): "f32" = exact fp32 MFMA, the parity mode for the
+reference's `model.float()` trainers; "bf16" = bf16 MFMA operands with fp32 accumulation,
+LayerNorm/softmax/residual in fp32 (the throughput mode, BASELINE.json configs[1]).
+Backward through the towers is not implemented yet (SURVEY §8f "next" #2): outputs carry a grad_fn
+that raises, so `loss.backward()` fails loudly instead of silently training nothing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+from torch import nn
+
+import cmh_native as N
+
+
+class LayerNorm(nn.LayerNorm):
+    """Parameter container; statistics are always fp32 inside the HIP kernel."""
+
+
+class QuickGELU(nn.Module):
+    """x * sigmoid(1.702 x): fused into the c_fc GEMM epilogue."""
+
+
+class ResidualAttentionBlock(nn.Module):
+    def __init__(self, d_model: int, n_head: int, attn_mask=None):
+        super().__init__()
+        self.attn = nn.MultiheadAttention(d_model, n_head)
+        self.ln_1 = LayerNorm(d_model)
+        self.mlp = nn.Sequential(OrderedDict([
+            ("c_fc", nn.Linear(d_model, d_model * 4)),
+            ("gelu", QuickGELU()),
+            ("c_proj", nn.Linear(d_model * 4, d_model)),
+        ]))
+        self.ln_2 = LayerNorm(d_model)
+        self.attn_mask = attn_mask
+
+
+class Transformer(nn.Module):
+    def __init__(self, width: int, layers: int, heads: int, attn_mask=None):
+        super().__init__()
+        self.width = width
+        self.layers = layers
+        self.resblocks = nn.Sequential(*[ResidualAttentionBlock(width, heads, attn_mask) for _ in range(layers)])
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, input_resolution: int, patch_size: int, width: int, layers: int, heads: int, output_dim: int):
+        super().__init__()
+        self.input_resolution = input_resolution
+        self.output_dim = output_dim
+        self.conv1 = nn.Conv2d(3, width, kernel_size=patch_size, stride=patch_size, bias=False)
+        scale = width ** -0.5
+        self.class_embedding = nn.Parameter(scale * torch.randn(width))
+        self.positional_embedding = nn.Parameter(scale * torch.randn((input_resolution // patch_size) ** 2 + 1, width))
+        self.ln_pre = LayerNorm(width)
+        self.transformer = Transformer(width, layers, heads)
+        self.ln_post = LayerNorm(width)
+        self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
+
+
+class _NoBackward(torch.autograd.Function):
+    """Attaches a grad_fn to native outputs so that a backward pass fails loudly."""
+
+    @staticmethod
+    def forward(ctx, out, anchor):
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, grad):
+        raise NotImplementedError(
+            "backward through the libcmh CLIP towers / hash heads is not implemented yet "
+            "(SURVEY.md §8f next #2); this build covers encode -> hash -> loss(forward) -> mAP")
+
+
+def no_backward(out: torch.Tensor, anchor: torch.Tensor) -> torch.Tensor:
+    if torch.is_grad_enabled() and anchor.requires_grad:
+        return _NoBackward.apply(out, anchor)
+    return out
+
+
+class _TowerCache:
+    """Device-resident weights in the layout libcmh wants + the ctypes structs that point at them.
+    Rebuilt when any parameter changed (data_ptr/_version) or the arithmetic mode changed."""
+
+    def __init__(self):
+        self.key = None
+        self.keep = []          # tensors that must outlive the structs
+        self.struct = None
+        self.blocks = None
+
+
+def _prep(p: torch.Tensor, keep: list) -> torch.Tensor:
+    t = p.detach()
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.float().contiguous()
+    keep.append(t)
+    return t
+
+
+def _gemm_w(p: torch.Tensor, dt: int, keep: list, transpose: bool = False) -> torch.Tensor:
+    t = p.detach().float()
+    t = t.t().contiguous() if transpose else t.contiguous()
+    t = t.reshape(t.shape[0], -1)
+    if dt == N.BF16:
+        t = N.cast_bf16(t)
+    keep.append(t)
+    return t
+
+
+def _fill_blocks(resblocks, dt: int, keep: list):
+    arr = (N.BlockWeights * len(resblocks))()
+    for i, blk in enumerate(resblocks):
+        b = arr[i]
+        b.in_proj_w = _gemm_w(blk.attn.in_proj_weight, dt, keep).data_ptr()
+        b.in_proj_b = _prep(blk.attn.in_proj_bias, keep).data_ptr()
+        b.out_proj_w = _gemm_w(blk.attn.out_proj.weight, dt, keep).data_ptr()
+        b.out_proj_b = _prep(blk.attn.out_proj.bias, keep).data_ptr()
+        b.ln1_w = _prep(blk.ln_1.weight, keep).data_ptr()
+        b.ln1_b = _prep(blk.ln_1.bias, keep).data_ptr()
+        b.ln2_w = _prep(blk.ln_2.weight, keep).data_ptr()
+        b.ln2_b = _prep(blk.ln_2.bias, keep).data_ptr()
+        b.fc_w = _gemm_w(blk.mlp.c_fc.weight, dt, keep).data_ptr()
+        b.fc_b = _prep(blk.mlp.c_fc.bias, keep).data_ptr()
+        b.proj_w = _gemm_w(blk.mlp.c_proj.weight, dt, keep).data_ptr()
+        b.proj_b = _prep(blk.mlp.c_proj.bias, keep).data_ptr()
+    return arr
+
+
+_DT = {"f32": N.F32, "fp32": N.F32, "float32": N.F32, "bf16": N.BF16, "bfloat16": N.BF16}
+
+
+class CLIP(nn.Module):
+    def __init__(self, embed_dim: int, image_resolution: int, vision_layers, vision_width: int,
+                 vision_patch_size: int, context_length: int, vocab_size: int, transformer_width: int,
+                 transformer_heads: int, transformer_layers: int):
+        super().__init__()
+        if isinstance(vision_layers, (tuple, list)):
+            raise NotImplementedError("ModifiedResNet (RN50) visual towers are out of scope; ViT checkpoints only")
+        self.context_length = context_length
+        self.vision_heads = vision_width // 64
+        self.visual = VisionTransformer(input_resolution=image_resolution, patch_size=vision_patch_size,
+                                        width=vision_width, layers=vision_layers, heads=self.vision_heads,
+                                        output_dim=embed_dim)
+        self.transformer = Transformer(width=transformer_width, layers=transformer_layers, heads=transformer_heads,
+                                       attn_mask=self.build_attention_mask)
+        self.vocab_size = vocab_size
+        self.token_embedding = nn.Embedding(vocab_size, transformer_width)
+        self.positional_embedding = nn.Parameter(torch.empty(self.context_length, transformer_width))
+        self.ln_final = LayerNorm(transformer_width)
+        self.text_projection = nn.Parameter(torch.empty(transformer_width, embed_dim))
+        self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
+        self.initialize_parameters()
+        self._gemm_dtype = _DT[os.environ.get("CMH_GEMM_DTYPE", "f32").lower()]
+        self._vit_cache = _TowerCache()
+        self._txt_cache = _TowerCache()
+        self.assume_frozen = False     # True: skip the per-call parameter-version scan (pure inference)
+
+    # -- reference API ---------------------------------------------------------------------------
+    def initialize_parameters(self):
+        nn.init.normal_(self.token_embedding.weight, std=0.02)
+        nn.init.normal_(self.positional_embedding, std=0.01)
+        for tr in (self.transformer,):
+            proj_std = (tr.width ** -0.5) * ((2 * tr.layers) ** -0.5)
+            attn_std = tr.width ** -0.5
+            fc_std = (2 * tr.width) ** -0.5
+            for block in tr.resblocks:
+                nn.init.normal_(block.attn.in_proj_weight, std=attn_std)
+                nn.init.normal_(block.attn.out_proj.weight, std=proj_std)
+                nn.init.normal_(block.mlp.c_fc.weight, std=fc_std)
+                nn.init.normal_(block.mlp.c_proj.weight, std=proj_std)
+        nn.init.normal_(self.text_projection, std=self.transformer.width ** -0.5)
+
+    def build_attention_mask(self, context_length):
+        """Kept for API parity; the kernel applies the causal mask itself."""
+        mask = torch.empty(context_length, context_length)
+        mask.fill_(float("-inf"))
+        mask.triu_(1)
+        return mask.to(self.device)
+
+    @property
+    def dtype(self):
+        return self.visual.conv1.weight.dtype
+
+    @property
+    def device(self):
+        return self.visual.conv1.weight.device
+
+    def set_gemm_dtype(self, name: str):
+        self._gemm_dtype = _DT[name.lower()]
+        return self
+
+    @property
+    def gemm_dtype(self) -> str:
+        return "bf16" if self._gemm_dtype == N.BF16 else "f32"
+
+    # -- native weight structs -------------------------------------------------------------------
+    def _key(self, params):
+        if self.assume_frozen:
+            return (self._gemm_dtype, str(self.device), "frozen")
+        return (self._gemm_dtype, str(self.device)) + tuple((p.data_ptr(), p._version) for p in params)
+
+    def _vit_struct(self):
+        v, c = self.visual, self._vit_cache
+        key = self._key(list(v.parameters()))
+        if c.key != key:
+            keep, dt = [], self._gemm_dtype
+            s = N.VitWeights()
+            s.gemm_dtype = dt
+            s.resolution = v.input_resolution
+            s.patch = v.conv1.weight.shape[-1]
+            s.width = v.conv1.weight.shape[0]
+            s.layers = len(v.transformer.resblocks)
+            s.embed_dim = v.proj.shape[1]
+            s.conv1_w = _gemm_w(v.conv1.weight, dt, keep).data_ptr()
+            s.class_embedding = _prep(v.class_embedding, keep).data_ptr()
+            s.positional_embedding = _prep(v.positional_embedding, keep).data_ptr()
+            s.ln_pre_w = _prep(v.ln_pre.weight, keep).data_ptr()
+            s.ln_pre_b = _prep(v.ln_pre.bias, keep).data_ptr()
+            s.ln_post_w = _prep(v.ln_post.weight, keep).data_ptr()
+            s.ln_post_b = _prep(v.ln_post.bias, keep).data_ptr()
+            s.proj_t = _gemm_w(v.proj, dt, keep, transpose=True).data_ptr()
+            c.blocks = _fill_blocks(v.transformer.resblocks, dt, keep)
+            s.blocks = C.cast(c.blocks, C.POINTER(N.BlockWeights))
+            c.struct, c.keep, c.key = s, keep, key
+        return c.struct
+
+    def _text_struct(self):
+        c = self._txt_cache
+        params = [self.token_embedding.weight, self.positional_embedding, self.ln_final.weight, self.ln_final.bias,
+                  self.text_projection] + list(self.transformer.parameters())
+        key = self._key(params)
+        if c.key != key:
+            keep, dt = [], self._gemm_dtype
+            s = N.TextWeights()
+            s.gemm_dtype = dt
+            s.context_length = self.positional_embedding.shape[0]
+            s.vocab_size = self.token_embedding.weight.shape[0]
+            s.width = self.ln_final.weight.shape[0]
+            s.layers = len(self.transformer.resblocks)
+            s.embed_dim = self.text_projection.shape[1]
+            s.token_embedding = _prep(self.token_embedding.weight, keep).data_ptr()
+            s.positional_embedding = _prep(self.positional_embedding, keep).data_ptr()
+            s.ln_final_w = _prep(self.ln_final.weight, keep).data_ptr()
+            s.ln_final_b = _prep(self.ln_final.bias, keep).data_ptr()
+            s.text_projection_t = _gemm_w(self.text_projection, dt, keep, transpose=True).data_ptr()
+            c.blocks = _fill_blocks(self.transformer.resblocks, dt, keep)
+            s.blocks = C.cast(c.blocks, C.POINTER(N.BlockWeights))
+            c.struct, c.keep, c.key = s, keep, key
+        return c.struct
+
+    @staticmethod
+    def _taps(tap_list):
+        if not tap_list:
+            return None, None
+        arr = (C.c_void_p * len(tap_list))(*[None if t is None else t.data_ptr() for t in tap_list])
+        taps = N.Taps(C.cast(arr, C.POINTER(C.c_void_p)), len(tap_list))
+        return taps, arr
+
+    # -- the two hot-path entry points -----------------------------------------------------------
+    def encode_image(self, image, taps=None):
+        """image f32 [B,3,R,R] -> [B, embed_dim] f32  (reference model/base/model.py:356-357,228-252)."""
+        image = N.f32c(image)
+        N.require_gpu(image, self.visual.proj)
+        s = self._vit_struct()
+        B = image.shape[0]
+        if tuple(image.shape[1:]) != (3, s.resolution, s.resolution):
+            raise N.NativeError(f"encode_image: expected [B,3,{s.resolution},{s.resolution}], got {tuple(image.shape)}")
+        feat = torch.empty(B, s.embed_dim, dtype=torch.float32, device=image.device)
+        need = N.lib().cmh_vit_workspace_bytes(C.byref(s), B)
+        ws = N.workspace(need, image.device, "vit")
+        tp, _arr = self._taps(taps)
+        N.check(N.lib().cmh_vit_encode(C.byref(s), N.ptr(image), B, N.ptr(feat), N.ptr(ws), ws.numel(),
+                                       None if tp is None else C.byref(tp), N.stream_ptr(image.device)),
+                "cmh_vit_encode")
+        return no_backward(feat, self.visual.proj)
+
+    def encode_text(self, text, key_padding_mask=None, taps=None):
+        """text i64 [B,L] -> [B, embed_dim] f32  (reference model/base/model.py:359-372)."""
+        N.require_gpu(text, self.text_projection)
+        text = text.to(torch.int64).contiguous()
+        s = self._text_struct()
+        B, L = text.shape
+        feat = torch.empty(B, s.embed_dim, dtype=torch.float32, device=text.device)
+        need = N.lib().cmh_text_workspace_bytes(C.byref(s), B, L)
+        ws = N.workspace(need, text.device, "text")
+        kpm = None if key_padding_mask is None else key_padding_mask.to(torch.uint8).contiguous()
+        tp, _arr = self._taps(taps)
+        N.check(N.lib().cmh_text_encode(C.byref(s), N.ptr(text), B, L, N.ptr(kpm), N.ptr(feat), N.ptr(ws), ws.numel(),
+                                        None if tp is None else C.byref(tp), N.stream_ptr(text.device)),
+                "cmh_text_encode")
+        return no_backward(feat, self.text_projection)
+
+    def forward(self, image, text):
+        """Cosine-similarity logits (reference :374-388); assembled from the two native encodes."""
+        i = self.encode_image(image)
+        t = self.encode_text(text)
+        i = i / i.norm(dim=-1, keepdim=True)
+        t = t / t.norm(dim=-1, keepdim=True)
+        logits = self.logit_scale.exp() * i @ t.t()
+        return logits, logits.t()
+
+
+def convert_weights(model: nn.Module):
+    """Reference :391-412: Conv/Linear weight+bias, MHA in_proj/bias and the two projections go to fp16.
+    Checkpoints loaded afterwards are therefore rounded through fp16, exactly as upstream."""
+
+    def _convert(l):
+        if isinstance(l, (nn.Conv1d, nn.Conv2d, nn.Linear)):
+            l.weight.data = l.weight.data.half()
+            if l.bias is not None:
+                l.bias.data = l.bias.data.half()
+        if isinstance(l, nn.MultiheadAttention):
+            for attr in [*[f"{s}_proj_weight" for s in ["in", "q", "k", "v"]], "in_proj_bias", "bias_k", "bias_v"]:
+                tensor = getattr(l, attr)
+                if tensor is not None:
+                    tensor.data = tensor.data.half()
+        for name in ["text_projection", "proj"]:
+            if hasattr(l, name):
+                attr = getattr(l, name)
+                if attr is not None:
+                    attr.data = attr.data.half()
+
+    model.apply(_convert)
+
+
+def build_model(state_dict: dict):
+    """Reference :415-455: infer the architecture from tensor shapes, fp16-convert, load strict."""
+    if "visual.proj" not in state_dict:
+        raise NotImplementedError("only ViT CLIP checkpoints are supported (no visual.proj in state_dict)")
+    vision_width = state_dict["visual.conv1.weight"].shape[0]
+    vision_layers = len([k for k in state_dict if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")])
+    vision_patch_size = state_dict["visual.conv1.weight"].shape[-1]
+    grid_size = round((state_dict["visual.positional_embedding"].shape[0] - 1) ** 0.5)
+    image_resolution = vision_patch_size * grid_size
+    embed_dim = state_dict["text_projection"].shape[1]
+    context_length = state_dict["positional_embedding"].shape[0]
+    vocab_size = state_dict["token_embedding.weight"].shape[0]
+    transformer_width = state_dict["ln_final.weight"].shape[0]
+    transformer_heads = transformer_width // 64
+    transformer_layers = len(set(k.split(".")[2] for k in state_dict if k.startswith("transformer.resblocks")))
+    model = CLIP(embed_dim, image_resolution, vision_layers, vision_width, vision_patch_size, context_length,
+                 vocab_size, transformer_width, transformer_heads, transformer_layers)
+    for key in ["input_resolution", "context_length", "vocab_size"]:
+        if key in state_dict:
+            del state_dict[key]
+    convert_weights(model)
+    model.load_state_dict(state_dict)
+    return model

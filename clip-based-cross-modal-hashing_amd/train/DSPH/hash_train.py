@@ -1,0 +1,56 @@
+"""DSPH trainer (reference train/DSPH/hash_train.py:16-73; paper: Deep Semantic-aware Proxy Hashing,
+TCSVT 2023).  Forward, loss and validation run on libcmh; the optimiser step is not built yet:
+BertAdam + encoder backward are SURVEY §8f "next" #1/#2, so train_epoch stops loudly at backward."""
+import os
+import time
+
+import torch
+
+from model.DSPH import MDSPH
+from train.base import TrainBase
+from .get_args import get_args
+from .loss import HyP
+
+
+class DSPHTrainer(TrainBase):
+
+    def __init__(self, args, rank=0):
+        args = get_args(args)
+        args.rank = rank
+        super(DSPHTrainer, self).__init__(args)
+        self.logger.info("dataset len: {}".format(len(self.train_loader.dataset)))
+        self.run()
+
+    def _init_model(self):
+        self.logger.info("init model.")
+        self.model = MDSPH(outputDim=self.args.output_dim, clipPath=self.args.clip_path,
+                           writer=self.writer, logger=self.logger, is_train=self.args.is_train).to(self.rank)
+        if self.args.pretrained != "" and os.path.exists(self.args.pretrained):
+            self.logger.info("load pretrained model.")
+            self.model.load_state_dict(torch.load(self.args.pretrained, map_location=f"cuda:{self.rank}"))
+        self.model.float()
+        self.model.clip.set_gemm_dtype(self.args.gemm_dtype)
+        self.args.numclass = self.args.nclass
+        self.hyp = HyP(self.args).to(self.rank)
+        self.optimizer = None
+        self.total_time = 0
+
+    def compute_loss(self, hash_img, hash_text, label):
+        return self.hyp(hash_img, hash_text, label)
+
+    def train_epoch(self, epoch):
+        self.change_state(mode="train")
+        self.logger.info(">>>>>> epochs: %d/%d" % (epoch, self.args.epochs))
+        all_loss = 0
+        for image, text, label, index in self.train_loader:
+            start_time = time.time()
+            self.global_step += 1
+            image = image.to(self.rank, non_blocking=True)
+            text = text.to(self.rank, non_blocking=True)
+            label = label.to(self.rank, non_blocking=True)
+            hash_img, hash_text = self.model(image, text)
+            loss = self.compute_loss(hash_img, hash_text, label)
+            all_loss += loss
+            loss.backward()      # raises NotImplementedError: backward kernels are the next scope row
+            self.total_time += time.time() - start_time
+        self.logger.info(f">>>>>> [{epoch}/{self.args.epochs}] loss: {all_loss.data / (len(self.train_loader))}, time: {self.total_time}")

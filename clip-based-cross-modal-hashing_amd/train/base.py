@@ -1,0 +1,204 @@
+"""Trainer base with the reference's hooks (train/base.py:14-349): _init_dataset/_init_model/
+_init_writer/run/change_state/get_code*/train/valid/test/save_model/save_mat and the attributes
+subclasses read (model, optimizer, loaders, train_labels, query_labels, retrieval_labels, rank,
+logger, global_step).
+
+Differences from upstream, all deliberate:
+  * `rank` really is the device index passed by main.py (upstream drops it and lands on cuda:1, F7);
+  * valid() dispatches get_code_DNPH on 'DNPH' (upstream tests 'DNPH-TOMM', which never matches);
+  * code generation runs under no_grad (upstream builds and discards an autograd graph);
+  * codes are sign()/argmax'd by libcmh kernels and ranked on the GPU (utils/calc_utils.py).
+Real `.mat` datasets are the host input pipeline (out of scope); `--dataset synthetic`
+exercises the same contract."""
+import os
+import time
+
+import torch
+from torch.utils.data import DataLoader
+
+import cmh_native as N
+from utils import get_logger, get_summary_writer
+from utils.calc_utils import calc_map_k_matrix as calc_map_k
+
+NCLASS = {'flickr': 24, 'coco': 80, 'nuswide': 21, 'iapr': 291, 'synthetic': 24}
+
+
+class TrainBase(object):
+
+    def __init__(self, args, rank=0):
+        self.args = args
+        os.makedirs(args.save_dir, exist_ok=True)
+        self._init_writer()
+        self.logger.info(self.args)
+        self.rank = getattr(args, "rank", rank)   # GPU ID
+        self._init_dataset()
+        self._init_model()
+        self.global_step = 0
+        self.max_mapi2t = 0
+        self.max_mapt2i = 0
+        self.best_epoch_i = 0
+        self.best_epoch_t = 0
+
+    def _init_dataset(self):
+        self.logger.info("init dataset.")
+        self.logger.info(f"Using {self.args.dataset} dataset.")
+        if self.args.dataset not in NCLASS:
+            raise ValueError("Unknown dataset")
+        self.args.nclass = NCLASS[self.args.dataset]
+        if self.args.dataset == 'synthetic':
+            from dataset.synthetic import dataloader
+            train_data, query_data, retrieval_data = dataloader(
+                total=self.args.synthetic_size, nclass=self.args.nclass, maxWords=self.args.max_words,
+                imageResolution=self.args.resolution, query_num=self.args.query_num,
+                train_num=self.args.train_num, seed=self.args.seed)
+        else:
+            raise NotImplementedError(
+                "real .mat datasets (index.mat / caption.mat / label.mat + PIL/BPE preprocessing) are the host "
+                "input pipeline, out of scope this round; use --dataset synthetic or feed tensors honouring the "
+                "input contract (image f32 [B,3,224,224], caption i64 [B,maxWords], label [B,C], index)")
+        self.train_labels = train_data.get_all_label().to(self.rank)
+        self.query_labels = query_data.get_all_label()
+        self.retrieval_labels = retrieval_data.get_all_label()
+        self.args.retrieval_num = len(self.retrieval_labels)
+        self.args.query_num = len(self.query_labels)
+        self.logger.info(f"query shape: {self.query_labels.shape}")
+        self.logger.info(f"retrieval shape: {self.retrieval_labels.shape}")
+        mk = lambda d: DataLoader(dataset=d, batch_size=self.args.batch_size, num_workers=self.args.num_workers,
+                                  pin_memory=True, shuffle=True)
+        self.train_loader, self.query_loader, self.retrieval_loader = mk(train_data), mk(query_data), mk(retrieval_data)
+
+    def _init_model(self):
+        self.model = None
+        self.model_ddp = None
+
+    def _init_writer(self):
+        self.logger = get_logger(os.path.join(self.args.save_dir, "train.log" if self.args.is_train else "test.log"))
+        self.writer = get_summary_writer(os.path.join(self.args.save_dir, "tensorboard"))
+
+    def run(self):
+        if self.args.is_train:
+            self.train()
+        else:
+            self.test()
+
+    def change_state(self, mode):
+        if mode == "train":
+            self.model.train()
+        elif mode == "valid":
+            self.model.eval()
+
+    # ---- code generation (train/base.py:130-223) ---------------------------------------------------
+    def _code_loop(self, data_loader, length, encode):
+        img_buffer = torch.empty(length, self.args.output_dim, dtype=torch.float).to(self.rank)
+        text_buffer = torch.empty(length, self.args.output_dim, dtype=torch.float).to(self.rank)
+        encoder_time = 0
+        with torch.no_grad():
+            for batch in data_loader:
+                start_encoder_time = time.time()
+                image, text, index = batch[0], batch[1], batch[-1]
+                image = image.to(self.rank, non_blocking=True)
+                text = text.to(self.rank, non_blocking=True)
+                index = index.to(self.rank)
+                image_hash, text_hash = encode(image, text, batch)
+                encoder_time = time.time() - start_encoder_time
+                img_buffer[index, :] = image_hash
+                text_buffer[index, :] = text_hash
+        return img_buffer, text_buffer, encoder_time
+
+    def get_code(self, data_loader, length: int):
+        return self._code_loop(data_loader, length, lambda i, t, b: (
+            N.sign_codes(self.model.encode_image(i)), N.sign_codes(self.model.encode_text(t))))
+
+    def make_hash_code_DCHMT(self, code) -> torch.Tensor:
+        """argmax over each pair; index 0 -> -1, 1 -> +1 (train/base.py:150-158)."""
+        p = torch.cat(code, dim=-1) if isinstance(code, (list, tuple)) else code
+        return N.pair_argmax_codes(p)
+
+    def get_code_DCHMT(self, data_loader, length: int):
+        return self._code_loop(data_loader, length, lambda i, t, b: (
+            self.make_hash_code_DCHMT(self.model.encode_image(i)), self.make_hash_code_DCHMT(self.model.encode_text(t))))
+
+    def get_code_DNPH(self, data_loader, length: int):
+        return self._code_loop(data_loader, length, lambda i, t, b: (
+            N.sign_codes(self.model.encode_image(i)[0]), N.sign_codes(self.model.encode_text(t)[0])))
+
+    def save_model(self, epoch):
+        torch.save(self.model.state_dict(), os.path.join(self.args.save_dir, "model-" + str(epoch) + ".pth"))
+        self.logger.info("save mode to {}".format(os.path.join(self.args.save_dir, "model-" + str(epoch) + ".pth")))
+
+    def train_epoch(self, epoch):
+        raise NotImplementedError("Function of 'train' doesn't implement.")
+
+    def train(self):
+        self.logger.info("Start train.")
+        for epoch in range(self.args.epochs):
+            self.train_epoch(epoch)
+            self.valid(epoch)
+            self.save_model(epoch)
+        self.logger.info(
+            f">>>>>>> FINISHED >>>>>> Best epoch, I-T: {self.best_epoch_i}, mAP: {self.max_mapi2t}, T-I: {self.best_epoch_t}, mAP: {self.max_mapt2i}")
+
+    def _codes_for_eval(self):
+        if self.args.method == 'DCHMT':
+            gc = self.get_code_DCHMT
+        elif self.args.method in ('DNPH', 'DNPH-TOMM'):
+            gc = self.get_code_DNPH
+        else:
+            gc = self.get_code
+        q_img, q_txt, q_t = gc(self.query_loader, self.args.query_num)
+        r_img, r_txt, r_t = gc(self.retrieval_loader, self.args.retrieval_num)
+        return q_img, q_txt, r_img, r_txt, q_t, r_t
+
+    def _four_maps(self, query_img, query_txt, retrieval_img, retrieval_txt):
+        mAPi2t = calc_map_k(query_img, retrieval_txt, self.query_labels, self.retrieval_labels, None, self.rank)
+        mAPt2i = calc_map_k(query_txt, retrieval_img, self.query_labels, self.retrieval_labels, None, self.rank)
+        mAPi2i = calc_map_k(query_img, retrieval_img, self.query_labels, self.retrieval_labels, None, self.rank)
+        mAPt2t = calc_map_k(query_txt, retrieval_txt, self.query_labels, self.retrieval_labels, None, self.rank)
+        return mAPi2t, mAPt2i, mAPi2i, mAPt2t
+
+    def valid(self, epoch):
+        self.logger.info("Valid.")
+        self.change_state(mode="valid")
+        query_img, query_txt, retrieval_img, retrieval_txt, q_encoder_time, r_encoder_time = self._codes_for_eval()
+        mAPi2t, mAPt2i, mAPi2i, mAPt2t = self._four_maps(query_img, query_txt, retrieval_img, retrieval_txt)
+        if self.max_mapi2t < mAPi2t:
+            self.best_epoch_i = epoch
+            self.save_mat(query_img, query_txt, retrieval_img, retrieval_txt, mode_name="i2t")
+        self.max_mapi2t = max(self.max_mapi2t, mAPi2t)
+        if self.max_mapt2i < mAPt2i:
+            self.best_epoch_t = epoch
+            self.save_mat(query_img, query_txt, retrieval_img, retrieval_txt, mode_name="t2i")
+        self.max_mapt2i = max(self.max_mapt2i, mAPt2i)
+        self.logger.info(
+            f">>>>>> [{epoch}/{self.args.epochs}], MAP(i->t): {mAPi2t}, MAP(t->i): {mAPt2i}, MAP(t->t): {mAPt2t}, MAP(i->i): {mAPi2i}, \
+                            MAX MAP(i->t): {self.max_mapi2t}, MAX MAP(t->i): {self.max_mapt2i}, query_encoder_time: {q_encoder_time}, retrieval_encoder_time: {r_encoder_time}")
+        return mAPi2t, mAPt2i, mAPi2i, mAPt2t
+
+    def test(self, mode_name="i2t"):
+        if self.args.pretrained == "":
+            raise RuntimeError("test step must load a model! please set the --pretrained argument.")
+        self.change_state(mode="valid")
+        query_img, query_txt, retrieval_img, retrieval_txt, _, _ = self._codes_for_eval()
+        mAPi2t, mAPt2i, mAPi2i, mAPt2t = self._four_maps(query_img, query_txt, retrieval_img, retrieval_txt)
+        self.max_mapt2i = max(self.max_mapt2i, mAPt2i)
+        self.logger.info(f">>>>>> MAP(i->t): {mAPi2t}, MAP(t->i): {mAPt2i}, MAP(t->t): {mAPt2t}, MAP(i->i): {mAPi2i}")
+        self.save_mat(query_img, query_txt, retrieval_img, retrieval_txt, mode_name=mode_name)
+        self.logger.info(">>>>>> save all data!")
+
+    def compute_loss(self):
+        raise NotImplementedError("Function of 'compute_loss' doesn't implement.")
+
+    def save_mat(self, query_img, query_txt, retrieval_img, retrieval_txt, mode_name="i2t"):
+        """PR_cruve/<bits>-ours-<dataset>-<mode>.mat with q_img q_txt r_img r_txt q_l r_l (train/base.py:328-349)."""
+        if not getattr(self.args, "save_mat", True):
+            return
+        import scipy.io as scio
+        save_dir = os.path.join(self.args.save_dir, "PR_cruve")
+        os.makedirs(save_dir, exist_ok=True)
+        result_dict = {
+            'q_img': query_img.cpu().detach().numpy(), 'q_txt': query_txt.cpu().detach().numpy(),
+            'r_img': retrieval_img.cpu().detach().numpy(), 'r_txt': retrieval_txt.cpu().detach().numpy(),
+            'q_l': self.query_labels.numpy(), 'r_l': self.retrieval_labels.numpy(),
+        }
+        scio.savemat(os.path.join(save_dir, str(self.args.output_dim) + "-ours-" + self.args.dataset + "-" + mode_name + ".mat"), result_dict)
+        self.logger.info(f">>>>>> save best {mode_name} data!")

@@ -1,0 +1,240 @@
+/*
+ * cmh.h — C ABI of libcmh.so, the MI355X (gfx950) native hot path of CLIP-based cross-modal hashing.
+ *
+ * Drop-in boundary.  The reference (QinLab-WFU/CLIP-based-Cross-Modal-Hashing) is pure Python on
+ * PyTorch and has no FFI of its own; these entry points are what a ctypes binding
+ * for its hot path binds.  Each one names the reference interface it replaces (paths relative to
+ * the reference root).  The Python mirror of the reference API that calls them lives in
+ * clip-based-cross-modal-hashing_amd/ (model/modelbase.py, model/base/model.py, utils/calc_utils.py ...);
+ * INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no torch types.  All data pointers are DEVICE pointers unless
+ *    a parameter says "host".  `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *  - the library never allocates or frees device memory and never synchronises the device:
+ *    every call only enqueues kernels on `stream` (graph-capturable).  Scratch comes from the
+ *    caller (`workspace`, size from the matching *_workspace_bytes()).
+ *  - return value: 0 on success, negative cmh_status on error; cmh_last_error() gives the text
+ *    (thread-local).  No exceptions cross the ABI.
+ *  - matrices are dense row-major.  Linear weights are [out_features, in_features] exactly as
+ *    torch.nn.Linear / nn.MultiheadAttention store them.
+ *  - activations are token-major [B*T, d] (batch folded into rows), not the reference's [T,B,d];
+ *    values are identical.
+ */
+#ifndef CMH_H_
+#define CMH_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMH_VERSION 1
+
+typedef enum cmh_status {
+  CMH_OK = 0,
+  CMH_ERR_INVALID = -1,     /* bad argument / unsupported shape */
+  CMH_ERR_WORKSPACE = -2,   /* workspace too small */
+  CMH_ERR_LAUNCH = -3,      /* HIP launch / runtime error */
+  CMH_ERR_DATA = -4         /* input data outside the domain (e.g. codes not in {-1,0,+1}) */
+} cmh_status;
+
+/* GEMM arithmetic of the encoder.  CMH_F32: f32 operands on v_mfma_f32_16x16x4_f32 (exact fp32 FMA
+ * chain; the parity mode against the fp32 reference, train/.../hash_train.py `self.model.float()`).
+ * CMH_BF16: bf16 operands, fp32 accumulate on v_mfma_f32_16x16x32_bf16; LayerNorm/softmax/residual
+ * stream stay fp32. */
+typedef enum cmh_dtype { CMH_F32 = 0, CMH_BF16 = 1 } cmh_dtype;
+
+const char* cmh_last_error(void);
+int cmh_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Encoder weights.  Pointers borrow caller-owned device memory.  `*_w` GEMM weights are in the
+ * dtype named by cmh_*_weights.gemm_dtype (f32 or bf16 copies made with cmh_cast_f32_to_bf16);
+ * biases, LayerNorm parameters and embeddings are always f32.
+ * One transformer block = reference model/base/model.py:167-196 ResidualAttentionBlock.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct cmh_block_weights {
+  const void* in_proj_w;    /* [3d, d]  attn.in_proj_weight */
+  const float* in_proj_b;   /* [3d]     attn.in_proj_bias   */
+  const void* out_proj_w;   /* [d, d]   attn.out_proj.weight */
+  const float* out_proj_b;  /* [d] */
+  const float* ln1_w;       /* [d] ln_1 */
+  const float* ln1_b;
+  const float* ln2_w;       /* [d] ln_2 */
+  const float* ln2_b;
+  const void* fc_w;         /* [4d, d]  mlp.c_fc.weight */
+  const float* fc_b;        /* [4d] */
+  const void* proj_w;       /* [d, 4d]  mlp.c_proj.weight */
+  const float* proj_b;      /* [d] */
+} cmh_block_weights;
+
+/* Image tower = reference model/base/model.py:210-252 VisionTransformer. */
+typedef struct cmh_vit_weights {
+  int32_t gemm_dtype;       /* cmh_dtype of every `const void*` weight below and in blocks[] */
+  int32_t resolution;       /* input H = W (224) */
+  int32_t patch;            /* 32 */
+  int32_t width;            /* 768; heads = width/64 (model.py:284) */
+  int32_t layers;           /* 12 */
+  int32_t embed_dim;        /* 512 */
+  const void* conv1_w;      /* [width, 3*patch*patch]  visual.conv1.weight flattened (c,py,px) */
+  const float* class_embedding;      /* [width] */
+  const float* positional_embedding; /* [grid*grid+1, width] */
+  const float* ln_pre_w;  const float* ln_pre_b;
+  const float* ln_post_w; const float* ln_post_b;
+  const void* proj_t;       /* [embed_dim, width] = visual.proj TRANSPOSED (Linear layout) */
+  const cmh_block_weights* blocks;   /* host array [layers] */
+} cmh_vit_weights;
+
+/* Text tower = reference model/base/model.py:359-372 CLIP.encode_text (+ :340-346 causal mask). */
+typedef struct cmh_text_weights {
+  int32_t gemm_dtype;
+  int32_t context_length;   /* 77 */
+  int32_t vocab_size;       /* 49408 */
+  int32_t width;            /* 512; heads = width/64 (model.py:437) */
+  int32_t layers;           /* 12 */
+  int32_t embed_dim;        /* 512 */
+  const float* token_embedding;      /* [vocab, width] */
+  const float* positional_embedding; /* [context_length, width] */
+  const float* ln_final_w; const float* ln_final_b;
+  const void* text_projection_t;     /* [embed_dim, width] = text_projection TRANSPOSED */
+  const cmh_block_weights* blocks;   /* host array [layers] */
+} cmh_text_weights;
+
+/* Optional taps for parity tests: when non-NULL the f32 residual stream [B*T, width] after
+ * ln_pre (vision only, index 0) / after block i (index 1+i) is copied to taps[index]. */
+typedef struct cmh_taps {
+  float* const* ptrs;       /* host array of device pointers (entries may be NULL) */
+  int32_t count;
+} cmh_taps;
+
+size_t cmh_vit_workspace_bytes(const cmh_vit_weights* w, int32_t batch);
+size_t cmh_text_workspace_bytes(const cmh_text_weights* w, int32_t batch, int32_t seq_len);
+
+/* encode_image: replaces CLIP.encode_image / VisionTransformer.forward (model/base/model.py:228-252,
+ * :356-357).  image f32 [B,3,R,R] NCHW -> feat f32 [B, embed_dim]. */
+int cmh_vit_encode(const cmh_vit_weights* w, const float* image, int32_t batch, float* feat,
+                   void* workspace, size_t workspace_bytes, const cmh_taps* taps, void* stream);
+
+/* encode_text: replaces CLIP.encode_text (model/base/model.py:359-372).
+ * tokens i64 [B, L] (L <= context_length) -> feat f32 [B, embed_dim]; the pooled row is
+ * argmax(tokens[b]) (first maximum), as the reference takes it.
+ * key_padding_mask (optional, u8 [B,L], 1 = ignore key) serves the MITH trunk (model/MITH.py:120-144). */
+int cmh_text_encode(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
+                    const uint8_t* key_padding_mask, float* feat, void* workspace,
+                    size_t workspace_bytes, const cmh_taps* taps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Building blocks of the towers, exported for unit-level parity tests and for heads that want them.
+ * ------------------------------------------------------------------------------------------- */
+#define CMH_EPI_BIAS 1        /* + bias[n] */
+#define CMH_EPI_QUICKGELU 2   /* x*sigmoid(1.702x), model/base/model.py:162-164 */
+#define CMH_EPI_RESIDUAL 4    /* + residual[m,n] (f32; may alias out) */
+#define CMH_EPI_OUT_BF16 8    /* out is bf16 instead of f32 */
+/* out[M,N] = epi(x[M,K] . w[N,K]^T): nn.Linear with the epilogue fused.  x,w in `dtype`.
+ * Needs N % 128 == 0 and K % 32 (f32) / 64 (bf16) == 0. */
+int cmh_linear_gemm(int32_t dtype, const void* x, const void* w, const float* bias, const float* residual,
+                    void* out, int32_t M, int32_t N, int32_t K, int32_t epilogue, void* stream);
+/* LayerNorm over the last dim of x f32 [M,d] (eps 1e-5, fp32 statistics; model/base/model.py:153-159). */
+int cmh_layernorm(const float* x, const float* w, const float* b, void* out, int32_t out_dtype, int32_t M,
+                  int32_t d, void* stream);
+/* softmax(q k^T / 8 [+causal] [+key padding]) v per head (head dim 64) on packed qkv [B*T, 3d] -> o [B*T, d]. */
+int cmh_attention(int32_t dtype, const void* qkv, void* o, int32_t B, int32_t T, int32_t d, int32_t causal,
+                  const uint8_t* key_padding_mask, void* stream);
+
+/* f32 -> bf16 (round-to-nearest-even) copy used to prepare CMH_BF16 GEMM weights. */
+int cmh_cast_f32_to_bf16(const float* src, void* dst_bf16, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Hash heads and code generation.
+ * ------------------------------------------------------------------------------------------- */
+typedef enum cmh_act { CMH_ACT_NONE = 0, CMH_ACT_TANH = 1, CMH_ACT_RELU = 2 } cmh_act;
+
+/* y[M,N] = act( scale_mask ? (x W^T + b) * drop_mask/(1-p) : x W^T + b ), all f32.
+ * Replaces LinearHash.forward (model/modelbase.py:25-35: fc -> dropout(0.2) -> tanh; drop_mask
+ * NULL = eval), HashLayer.fc (model/DCHMT.py:13,20-21), Pre_Layer (model/DNPH_TOMM.py:7-14).
+ * drop_mask: optional f32 [M,N] of {0,1}; keep_scale = 1/(1-p). */
+int cmh_linear_act(const float* x, const float* w, const float* b, const float* drop_mask,
+                   float keep_scale, int32_t act, float* y, int32_t M, int32_t N, int32_t K,
+                   void* stream);
+
+/* DCHMT select head: softmax over each adjacent pair of z[M, 2K] -> p[M, 2K]
+ * (model/DCHMT.py:24 torch.softmax(item(embed), -1) for the K two-way Linears, concatenated as the
+ * trainer does at train/DCHMT/hash_train.py:55-57). */
+int cmh_pair_softmax(const float* z, float* p, int32_t M, int32_t K, void* stream);
+
+/* codes = sign(h) in {-1,0,+1} f32 (train/base.py:141-143 torch.sign). */
+int cmh_sign_codes(const float* h, float* codes, int64_t n, void* stream);
+
+/* codes[M,K] from pair probabilities p[M,2K]: argmax of the pair, index 0 -> -1, 1 -> +1, tie -> -1
+ * (train/base.py:150-158 make_hash_code_DCHMT). */
+int cmh_pair_argmax_codes(const float* p, float* codes, int32_t M, int32_t K, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Hamming ranking / mAP  (reference utils/calc_utils.py).
+ * Codes are packed to two bit-planes of W = ceil(K/32) u32 words per code:
+ *   sign plane bit t = (code[t] > 0), nz plane bit t = (code[t] != 0).
+ * Labels are packed to ceil(C/32) u32 words, bit c = (label[c] != 0).
+ * ------------------------------------------------------------------------------------------- */
+/* bad_flag (device i32, caller zeroes it) is set to 1 if any code is not exactly -1, 0 or +1. */
+int cmh_pack_codes(const float* codes, int64_t n, int32_t bits, uint32_t* sign_plane,
+                   uint32_t* nz_plane, int32_t* bad_flag, void* stream);
+/* bad_flag set if any label is negative or NaN (the reference's `L.L^T > 0` test then stops
+ * being an intersection test). */
+int cmh_pack_labels(const float* labels, int64_t n, int32_t classes, uint32_t* packed,
+                    int32_t* bad_flag, void* stream);
+
+/* calc_hammingDist (utils/calc_utils.py:8-13): dist[Q,N] f32 = 0.5*(K - q.r), exact for codes in
+ * {-1,0,+1}, computed by AND/XOR + popcount on the packed planes. */
+int cmh_hamming_dist(const uint32_t* q_sign, const uint32_t* q_nz, const uint32_t* r_sign,
+                     const uint32_t* r_nz, int32_t Q, int64_t N, int32_t bits, float* dist,
+                     void* stream);
+
+/* calc_neighbor (utils/calc_utils.py:42-45): sim[A,B] f32 = (la . lb^T > 0). */
+int cmh_calc_neighbor(const uint32_t* la, const uint32_t* lb, int32_t A, int32_t B, int32_t classes,
+                      float* sim, void* stream);
+
+typedef enum cmh_tie_order {
+  CMH_TIE_REFERENCE = 0,    /* torch.sort(stable=False) on CPU == libstdc++ introsort order */
+  CMH_TIE_STABLE = 1        /* ties by ascending database index */
+} cmh_tie_order;
+
+size_t cmh_map_workspace_bytes(int32_t Q, int64_t N, int32_t bits, int32_t tie_order);
+
+/* calc_map_k_matrix (utils/calc_utils.py:16-39).  topk <= 0 means k = N (the reference's k=None).
+ *   ap[Q]   f32  per-query AP (0 for queries with no relevant item; they still count in the mean)
+ *   map[1]  f32  sum(ap)/Q accumulated in f32 in query order like the reference's `map += ...`
+ *   perm    optional i32 [Q,N]: the full ranking `ind` (utils/calc_utils.py:31) per query
+ * depth_limit_override < 0 : libstdc++'s 2*floor(log2 N); >= 0 forces the introsort depth limit
+ * (test hook for the heapsort fallback). */
+int cmh_hamming_map(const uint32_t* q_sign, const uint32_t* q_nz, const uint32_t* q_label,
+                    const uint32_t* r_sign, const uint32_t* r_nz, const uint32_t* r_label,
+                    int32_t Q, int64_t N, int32_t bits, int32_t classes, int64_t topk,
+                    int32_t tie_order, int32_t depth_limit_override, float* ap, float* map,
+                    int32_t* perm, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pairwise similarity / quantisation losses (forward).  All f32; `loss` is a device scalar.
+ * ------------------------------------------------------------------------------------------- */
+size_t cmh_loss_workspace_bytes(int32_t B, int32_t K, int32_t C);
+
+/* DSPH HyP.forward (train/DSPH/loss.py:22-72).  x,y [B,K] hash outputs, label [B,C] in {0,1},
+ * proxies [C,K]. */
+int cmh_dsph_hyp_loss(const float* x, const float* y, const float* label, const float* proxies,
+                      int32_t B, int32_t K, int32_t C, float threshold, float alpha, float* loss,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* DCHMT our_loss with hash_layer == "select" (train/DCHMT/hash_train.py:82-150).
+ * img,txt [B,D] (D = 2*output_dim), label [B,C].  similarity: 0 = euclidean, 1 = cosine;
+ * loss_type: 1 = l1, 2 = l2. */
+int cmh_dchmt_loss(const float* img, const float* txt, const float* label, int32_t B, int32_t D,
+                   int32_t C, int32_t output_dim, int32_t similarity, int32_t loss_type,
+                   float vartheta, float sim_threshold, float* loss, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* CMH_H_ */

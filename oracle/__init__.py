@@ -5,4 +5,4 @@ CPU restatement of the reference's hot path, pinned to outputs of the reference 
 import this package; the product path (clip-based-cross-modal-hashing_amd/) never does.
 """
 from . import clip_oracle  # noqa: F401
-from .map_oracle import hamming_row, map_k, sort_perm, build  # noqa: F401
+from .map_oracle import hamming_row, map_k, sort_perm, sort_perm_depth, build  # noqa: F401

@@ -61,6 +61,19 @@ void oracle_sort_perm(const float* keys, int64_t N, int64_t* ind_out) {
   for (int64_t j = 0; j < N; ++j) ind_out[j] = kv[j].idx;
 }
 
+// Same, but with the introsort depth budget forced (libstdc++ uses 2*floor(log2 N)); drives the
+// heapsort fallback in tests.  Uses libstdc++'s own internals, not a re-implementation.
+void oracle_sort_perm_depth(const float* keys, int64_t N, int64_t depth_limit, int64_t* ind_out) {
+  std::vector<KV> kv(static_cast<size_t>(N));
+  for (int64_t j = 0; j < N; ++j) kv[j] = KV{keys[j], j};
+  if (N > 0) {
+    auto cmp = __gnu_cxx::__ops::__iter_comp_iter(KeyLess());
+    std::__introsort_loop(kv.begin(), kv.end(), depth_limit, cmp);
+    std::__final_insertion_sort(kv.begin(), kv.end(), cmp);
+  }
+  for (int64_t j = 0; j < N; ++j) ind_out[j] = kv[j].idx;
+}
+
 // Full restatement of calc_map_k_matrix.  k <= 0 means "k = N" (reference's k=None).
 // ap_out[Q]  : per-query AP (0 for skipped queries)      (may be null)
 // ind_out    : Q*N permutation, only written if non-null

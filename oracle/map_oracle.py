@@ -29,6 +29,8 @@ def _load():
         lib.oracle_hamming_row.restype = None
         lib.oracle_sort_perm.argtypes = [p, i64, p]
         lib.oracle_sort_perm.restype = None
+        lib.oracle_sort_perm_depth.argtypes = [p, i64, i64, p]
+        lib.oracle_sort_perm_depth.restype = None
         lib.oracle_map_k.argtypes = [p, p, p, p, i64, i64, i64, i64, i64, ctypes.c_int, p, p]
         lib.oracle_map_k.restype = ctypes.c_float
         _lib = lib
@@ -50,6 +52,14 @@ def sort_perm(keys):
     keys = _f32(keys)
     out = np.empty(keys.shape[0], np.int64)
     _load().oracle_sort_perm(keys.ctypes.data, keys.shape[0], out.ctypes.data)
+    return out
+
+
+def sort_perm_depth(keys, depth_limit):
+    """std::sort's permutation with the introsort depth budget forced to `depth_limit`."""
+    keys = _f32(keys)
+    out = np.empty(keys.shape[0], np.int64)
+    _load().oracle_sort_perm_depth(keys.ctypes.data, keys.shape[0], int(depth_limit), out.ctypes.data)
     return out
 
 

@@ -119,7 +119,7 @@ def clip_state_dict(cfg: dict, seed: int, fp16_roundtrip: bool = False) -> dict:
     out = {}
     for key, shape in sorted(clip_state_shapes(cfg).items()):
         off, std = _scale_for(key, shape, cfg)
-        a = (off + std * _rng(seed, key).standard_normal(shape)).astype(np.float32)
+        a = np.asarray(off + std * _rng(seed, key).standard_normal(shape), dtype=np.float32)
         if fp16_roundtrip and is_fp16_converted(key):
             a = fp16_round(a)
         out[key] = a

@@ -1,0 +1,110 @@
+"""encode_image / encode_text on the GPU (C ABI cmh_vit_encode / cmh_text_encode, through the
+reference-shaped CLIP module) vs the goldens produced by the reference and vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import recipe
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _clip(cfg, seed, mode, fp16_roundtrip=False):
+    from model.base.model import CLIP
+    m = CLIP(cfg["embed_dim"], cfg["image_resolution"], cfg["vision_layers"], cfg["vision_width"],
+             cfg["vision_patch_size"], cfg["context_length"], cfg["vocab_size"], cfg["transformer_width"],
+             cfg["transformer_heads"], cfg["transformer_layers"])
+    sd = {k: torch.from_numpy(v) for k, v in recipe.clip_state_dict(cfg, seed, fp16_roundtrip).items()}
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV).float().set_gemm_dtype(mode)
+
+
+def test_tiny_f32_matches_reference_goldens_with_taps(golden):
+    g = golden("clip_tiny.npz")
+    cfg, seed = recipe.CLIP_TINY, int(g["seed"])
+    m = _clip(cfg, seed, "f32")
+    B, T, d = 3, 5, cfg["vision_width"]
+    taps = [torch.empty(B * T, d, device=DEV) for _ in range(1 + cfg["vision_layers"])]
+    img = m.encode_image(torch.from_numpy(recipe.images(B, cfg["image_resolution"], seed)).to(DEV), taps=taps)
+    tol = dict(rtol=1e-4, atol=1e-4)          # north_star: floats within 1e-4
+    np.testing.assert_allclose(taps[0].cpu().numpy().reshape(B, T, d), g["v_ln_pre"], **tol)
+    for i in range(cfg["vision_layers"]):
+        np.testing.assert_allclose(taps[1 + i].cpu().numpy().reshape(B, T, d), g[f"v_block{i}"], **tol)
+    np.testing.assert_allclose(img.detach().cpu().numpy(), g["img_feat"], **tol)
+    for L, s in ((16, seed), (9, seed + 1)):
+        tw = cfg["transformer_width"]
+        taps = [None] + [torch.empty(B * L, tw, device=DEV) for _ in range(cfg["transformer_layers"])]
+        txt = m.encode_text(torch.from_numpy(recipe.captions(B, L, cfg["vocab_size"], s)).to(DEV), taps=taps)
+        for i in range(cfg["transformer_layers"]):
+            np.testing.assert_allclose(taps[1 + i].cpu().numpy().reshape(B, L, tw), g[f"t_block{i}_L{L}"], **tol)
+        np.testing.assert_allclose(txt.detach().cpu().numpy(), g[f"txt_feat_L{L}"], **tol)
+
+
+def test_vitb32_f32_matches_reference_goldens(golden):
+    g = golden("clip_vitb32.npz")
+    cfg, seed = recipe.CLIP_VITB32, int(g["seed"])
+    m = _clip(cfg, seed, "f32")
+    rows = g["v_rows"]
+    taps = [torch.empty(2 * 50, 768, device=DEV) for _ in range(13)]
+    img = m.encode_image(torch.from_numpy(recipe.images(2, 224, seed)).to(DEV), taps=taps)
+    np.testing.assert_allclose(taps[0].cpu().numpy().reshape(2, 50, 768)[:, rows], g["v_ln_pre_rows"], rtol=1e-4, atol=1e-4)
+    for i in (0, 5, 11):
+        np.testing.assert_allclose(taps[1 + i].cpu().numpy().reshape(2, 50, 768)[:, rows], g[f"v_block{i}_rows"],
+                                   rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(img.detach().cpu().numpy(), g["img_feat"], rtol=1e-3, atol=1e-4)
+    txt = m.encode_text(torch.from_numpy(recipe.captions(2, 77, cfg["vocab_size"], seed)).to(DEV))
+    np.testing.assert_allclose(txt.detach().cpu().numpy(), g["txt_feat_L77"], rtol=1e-3, atol=1e-4)
+    txt = m.encode_text(torch.from_numpy(recipe.captions(2, 32, cfg["vocab_size"], seed + 1)).to(DEV))
+    np.testing.assert_allclose(txt.detach().cpu().numpy(), g["txt_feat_L32"], rtol=1e-3, atol=1e-4)
+
+
+def test_vitb32_bf16_close_to_f32_and_flip_rate(golden):
+    """bf16 GEMM operands: features stay within bf16 noise of the fp32 reference; report sign-flip rate
+    of 64-bit codes (SURVEY hard part: 'bit-exact sign()' only holds away from 0)."""
+    g = golden("clip_vitb32.npz")
+    cfg, seed = recipe.CLIP_VITB32, int(g["seed"])
+    m = _clip(cfg, seed, "bf16")
+    img = m.encode_image(torch.from_numpy(recipe.images(2, 224, seed)).to(DEV)).detach().cpu().numpy()
+    txt = m.encode_text(torch.from_numpy(recipe.captions(2, 77, cfg["vocab_size"], seed)).to(DEV)).detach().cpu().numpy()
+    for a, r in ((img, g["img_feat"]), (txt, g["txt_feat_L77"])):
+        cos = (a * r).sum(-1) / np.linalg.norm(a, axis=-1) / np.linalg.norm(r, axis=-1)
+        assert cos.min() > 0.999, cos
+        assert np.abs(a - r).max() < 0.05 * np.abs(r).max()
+    w, b = recipe.head_linear(512, 64, seed, "flip")
+    flips = np.mean(np.sign(img @ w.T + b) != np.sign(g["img_feat"] @ w.T + b))
+    print(f"bf16 sign flip rate on 64-bit codes: {flips:.4f}")
+    assert flips < 0.05
+
+
+def test_eot_is_first_argmax_and_batch_independence():
+    """Pooled row = first argmax of the ids (model/base/model.py:370); rows of a batch do not interact."""
+    cfg, seed = recipe.CLIP_TINY, 7
+    m = _clip(cfg, seed, "f32")
+    t = recipe.captions(4, 16, cfg["vocab_size"], 3)
+    t[1, 5] = cfg["vocab_size"] - 1                      # an earlier EOT id: argmax must pick position 5
+    full = m.encode_text(torch.from_numpy(t).to(DEV)).detach().cpu().numpy()
+    one = m.encode_text(torch.from_numpy(t[1:2]).to(DEV)).detach().cpu().numpy()
+    np.testing.assert_allclose(full[1:2], one, rtol=1e-5, atol=1e-6)
+    from oracle import clip_oracle as co
+    ref = co.encode_text(recipe.clip_state_dict(cfg, seed), t)
+    np.testing.assert_allclose(full, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_large_batch_matches_small_batches():
+    """M-tail handling of the GEMM tiles: B=37 (M=185, 592) equals per-sample encodes."""
+    cfg, seed = recipe.CLIP_TINY, 7
+    m = _clip(cfg, seed, "f32")
+    img = torch.from_numpy(recipe.images(37, cfg["image_resolution"], 9)).to(DEV)
+    full = m.encode_image(img).detach().cpu().numpy()
+    part = torch.cat([m.encode_image(img[i:i + 5]).detach() for i in range(0, 37, 5)]).cpu().numpy()
+    np.testing.assert_allclose(full, part, rtol=1e-5, atol=1e-6)
+
+
+def test_backward_fails_loudly():
+    cfg, seed = recipe.CLIP_TINY, 7
+    m = _clip(cfg, seed, "f32")
+    out = m.encode_text(torch.from_numpy(recipe.captions(2, 16, cfg["vocab_size"], 3)).to(DEV))
+    assert out.requires_grad
+    with pytest.raises(NotImplementedError):
+        out.sum().backward()

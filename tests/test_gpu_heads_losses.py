@@ -1,0 +1,162 @@
+"""Hash heads, code generation, Baseclip API and the fused losses on the GPU vs reference goldens / oracle."""
+import numpy as np
+import pytest
+import torch
+
+import recipe
+from oracle import clip_oracle as co
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = dict(rtol=1e-4, atol=1e-4)
+
+
+def _state(seed=7):
+    return {k: torch.from_numpy(v) for k, v in recipe.clip_state_dict(recipe.CLIP_TINY, seed).items()}
+
+
+@pytest.mark.parametrize("K", [16, 64])
+def test_baseclip_dsph_and_dchmt_match_reference(golden, tmp_path, K):
+    from model.DCHMT import MDCMHT
+    from model.DSPH import MDSPH
+    from train.base import TrainBase
+    g = golden("baseclip_tiny.npz")
+    cfg, seed = recipe.CLIP_TINY, int(g["seed"])
+    image = torch.from_numpy(recipe.images(3, cfg["image_resolution"], seed)).to(DEV)
+    text = torch.from_numpy(recipe.captions(3, 16, cfg["vocab_size"], seed)).to(DEV)
+    import cmh_native as N
+
+    m = MDSPH(outputDim=K, clipPath=_state(seed), saveDir=str(tmp_path)).to(DEV)
+    m.float()
+    for side in ("image", "text"):
+        w, b = recipe.head_linear(cfg["embed_dim"], K, seed, f"dsph_{side}_{K}")
+        getattr(m, f"{side}_hash").fc.weight.data.copy_(torch.from_numpy(w))
+        getattr(m, f"{side}_hash").fc.bias.data.copy_(torch.from_numpy(b))
+    m.eval()
+    with torch.no_grad():
+        hi, ht = m(image, text)
+        np.testing.assert_allclose(m.clip.encode_image(image).cpu().numpy(), g["feat_img_fp16w"], **TOL)
+    for h, s in ((hi, "img"), (ht, "txt")):
+        ref = g[f"dsph_{s}_K{K}"]
+        np.testing.assert_allclose(h.cpu().numpy(), ref, **TOL)
+        safe = np.abs(ref) > 1e-3                      # sign() is only pinned away from 0
+        assert np.array_equal(N.sign_codes(h).cpu().numpy()[safe], g[f"dsph_{s}_code_K{K}"][safe])
+
+    d = MDCMHT(outputDim=K, clipPath=_state(seed), saveDir=str(tmp_path)).to(DEV)
+    d.float()
+    for side in ("image", "text"):
+        hl = getattr(d, f"{side}_hash")
+        w, b = recipe.head_linear(cfg["embed_dim"], 128, seed, f"dchmt_{side}_fc_{K}")
+        hl.fc.weight.data.copy_(torch.from_numpy(w)); hl.fc.bias.data.copy_(torch.from_numpy(b))
+        w2, b2 = recipe.head_linear(128, 2 * K, seed, f"dchmt_{side}_bits_{K}")
+        for j, lin in enumerate(hl.hash_list):
+            lin.weight.data.copy_(torch.from_numpy(w2[2 * j:2 * j + 2])); lin.bias.data.copy_(torch.from_numpy(b2[2 * j:2 * j + 2]))
+    d.eval()
+    with torch.no_grad():
+        li, lt = d(image, text)
+    assert isinstance(li, list) and len(li) == K and li[0].shape == (3, 2)
+    for l, s in ((li, "img"), (lt, "txt")):
+        ref = g[f"dchmt_{s}_K{K}"]
+        np.testing.assert_allclose(torch.stack(l, 1).cpu().numpy(), ref, **TOL)
+        codes = TrainBase.make_hash_code_DCHMT(None, l).cpu().numpy()
+        safe = np.abs(ref[..., 0] - ref[..., 1]) > 1e-3
+        assert np.array_equal(codes[safe], g[f"dchmt_{s}_code_K{K}"][safe])
+
+
+def test_dnph_heads_match_reference(golden, tmp_path):
+    from model.DNPH_TOMM import MDNPH
+    g = golden("baseclip_tiny.npz")
+    cfg, seed = recipe.CLIP_TINY, int(g["seed"])
+    m = MDNPH(outputDim=16, num_classes=21, clipPath=_state(seed), saveDir=str(tmp_path)).to(DEV)
+    m.float()
+    for side in ("image", "text"):
+        w, b = recipe.head_linear(cfg["embed_dim"], 16, seed, f"dnph_{side}_hash")
+        getattr(m, f"{side}_hash").fc.weight.data.copy_(torch.from_numpy(w)); getattr(m, f"{side}_hash").fc.bias.data.copy_(torch.from_numpy(b))
+        w, b = recipe.head_linear(cfg["embed_dim"], 21, seed, f"dnph_{side}_pre")
+        getattr(m, f"{side}_pre").fc.weight.data.copy_(torch.from_numpy(w)); getattr(m, f"{side}_pre").fc.bias.data.copy_(torch.from_numpy(b))
+    m.eval()
+    with torch.no_grad():
+        hi, pi, ht, pt = m(torch.from_numpy(recipe.images(3, cfg["image_resolution"], seed)).to(DEV),
+                           torch.from_numpy(recipe.captions(3, 16, cfg["vocab_size"], seed)).to(DEV))
+    for a, k in ((hi, "dnph_img"), (pi, "dnph_img_pre"), (ht, "dnph_txt"), (pt, "dnph_txt_pre")):
+        np.testing.assert_allclose(a.cpu().numpy(), g[k], **TOL)
+
+
+def test_linear_hash_dropout_mask_and_code_edge_cases():
+    """Training-mode LinearHash with an injected keep-mask (GPU RNG != CPU RNG) vs the oracle; sign(0)=0;
+    argmax tie -> -1 (train/base.py:150-158)."""
+    import cmh_native as N
+    from model.modelbase import LinearHash
+    f = recipe.features(9, 512, 3, "lh")
+    w, b = recipe.head_linear(512, 64, 3, "lhw")
+    lh = LinearHash(512, 64).to(DEV)
+    lh.fc.weight.data.copy_(torch.from_numpy(w)); lh.fc.bias.data.copy_(torch.from_numpy(b))
+    mask = (np.random.default_rng(0).random((9, 64)) >= 0.2).astype(np.float32)
+    lh.train()
+    out = lh(torch.from_numpy(f).to(DEV), drop_mask=torch.from_numpy(mask).to(DEV)).detach().cpu().numpy()
+    np.testing.assert_allclose(out, co.linear_hash(f, w, b, drop_mask=mask), **TOL)
+    assert (out[mask == 0] == 0).all()
+    rnd = lh(torch.from_numpy(f).to(DEV)).detach().cpu().numpy()       # device-drawn mask: ~20 % exact zeros
+    assert 0.05 < (rnd == 0).mean() < 0.4
+    h = torch.tensor([[0.0, -0.0, 1e-30, -3.0, float("nan")]], device=DEV)
+    c = N.sign_codes(h).cpu().numpy()[0]
+    assert list(c[:4]) == [0.0, 0.0, 1.0, -1.0] and np.isnan(c[4])
+    p = torch.tensor([[0.5, 0.5, 0.2, 0.8, 0.9, 0.1]], device=DEV)
+    assert N.pair_argmax_codes(p).cpu().numpy().tolist() == [[-1.0, 1.0, -1.0]]
+
+
+@pytest.mark.parametrize("B,K,C", [(32, 64, 24), (48, 16, 80), (16, 128, 21), (8, 32, 24)])
+def test_dsph_hyp_loss_matches_reference(golden, B, K, C):
+    from train.DSPH.loss import HyP
+    g = golden("loss_dsph.npz")
+    tag, seed = f"B{B}_K{K}_C{C}", 21
+    hyp = HyP(numclass=C, output_dim=K, hypseed=0, alpha=float(g[f"{tag}_alpha"])).to(DEV)
+    hyp.proxies.data.copy_(torch.from_numpy(recipe.features(C, K, seed, f"dsph_prox_{tag}")))
+    x = torch.tanh(torch.from_numpy(recipe.features(B, K, seed, f"dsph_x_{tag}"))).to(DEV)
+    y = torch.tanh(torch.from_numpy(recipe.features(B, K, seed, f"dsph_y_{tag}"))).to(DEV)
+    lab = torch.from_numpy(recipe.labels(B, C, seed, p=float(g[f"{tag}_p"]), tag=f"dsph_lab_{tag}"))
+    loss = hyp(x, y, lab)
+    assert abs(float(loss) - float(g[f"{tag}_loss"])) < 1e-4          # north_star tolerance for float losses
+
+
+@pytest.mark.parametrize("B,K,C,fn,lt", [(32, 16, 24, "euclidean", "l2"), (32, 16, 24, "cosine", "l2"),
+                                          (24, 64, 24, "euclidean", "l1"), (24, 64, 80, "cosine", "l1")])
+def test_dchmt_loss_matches_reference(golden, B, K, C, fn, lt):
+    import cmh_native as N
+    g = golden("loss_dchmt.npz")
+    tag, seed = f"B{B}_K{K}_C{C}_{fn}_{lt}", 31
+    zi = recipe.features(B, 2 * K, seed, f"dchmt_zi_{tag}")
+    zt = recipe.features(B, 2 * K, seed, f"dchmt_zt_{tag}")
+    hi = N.pair_softmax(torch.from_numpy(2 * zi).to(DEV))
+    ht = N.pair_softmax(torch.from_numpy(2 * zt).to(DEV))
+    lab = torch.from_numpy(recipe.labels(B, C, seed, tag=f"dchmt_lab_{tag}")).to(DEV)
+    loss = N.dchmt_loss(hi, ht, lab, K, fn, lt)
+    ref = float(g[f"{tag}_loss"])
+    assert abs(float(loss) - ref) < 1e-4 * max(1.0, abs(ref))
+
+
+def test_trainer_valid_end_to_end(tmp_path, monkeypatch):
+    """DSPH trainer on the synthetic dataset: get_code -> 4x calc_map_k (train/base.py:242-275) runs natively
+    and its i->t mAP equals the oracle on the very codes it produced."""
+    import argparse
+    import sys
+    import oracle
+    import main
+    from model.DSPH import MDSPH
+    ck = tmp_path / "clip.pt"
+    torch.save(_state(), ck)
+    monkeypatch.setattr(sys, "argv", ["main.py", "-clip-path", str(ck), "--save-dir", str(tmp_path), "--batch-size", "16",
+                                      "--num-workers", "0", "--resolution", "64", "--max-words", "16",
+                                      "--query-num", "40", "--train-num", "60", "--synthetic-size", "200",
+                                      "--epochs", "0"])
+    args = argparse.Namespace(method="DSPH", dataset="synthetic", output_dim=16, is_train=True)
+    import dataset.synthetic as ds
+    monkeypatch.setattr(ds, "SOT", 510); monkeypatch.setattr(ds, "EOT", 511)   # tiny vocabulary
+    tr = main.trainers["DSPH"](args, 0)
+    q_img, q_txt, r_img, r_txt, _, _ = tr._codes_for_eval()
+    assert set(np.unique(q_img.cpu().numpy())) <= {-1.0, 0.0, 1.0} and r_img.shape == (160, 16)
+    maps = tr.valid(0)
+    m_ref, _, _ = oracle.map_k(q_img.cpu().numpy(), r_txt.cpu().numpy(), tr.query_labels.numpy(), tr.retrieval_labels.numpy())
+    assert abs(float(maps[0]) - float(m_ref)) < 2e-6
+    with pytest.raises(NotImplementedError):
+        tr.train_epoch(0)

@@ -1,0 +1,94 @@
+"""Unit-level parity of the tower building blocks, called through the C ABI (cmh_linear_gemm,
+cmh_layernorm, cmh_attention) against a plain fp32/fp64 torch-CPU / numpy statement of the same op."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 128, 64), (130, 128, 128), (256, 512, 768), (333, 384, 3072), (2000, 2304, 768)])
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_gemm_epilogues(M, N, K, mode):
+    import cmh_native as Nn
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    if mode == "bf16":
+        xd, wd = x.bfloat16().to(_dev()), w.bfloat16().to(_dev())
+        xr, wr = x.bfloat16().double(), w.bfloat16().double()      # same rounded operands
+        tol = dict(rtol=2e-3, atol=2e-3)
+    else:
+        xd, wd = x.to(_dev()), w.to(_dev())
+        xr, wr = x.double(), w.double()
+        tol = dict(rtol=1e-5, atol=2e-5)
+    base = xr @ wr.t()
+    # plain
+    out = Nn.linear_gemm(xd, wd)
+    torch.testing.assert_close(out.cpu().double(), base, **tol)
+    # bias + quickgelu -> bf16/f32 out
+    v = base + b.double()
+    ref = v * torch.sigmoid(1.702 * v)
+    out = Nn.linear_gemm(xd, wd, bias=b.to(_dev()), quickgelu=True, out_bf16=(mode == "bf16"))
+    t2 = dict(rtol=1e-2, atol=1e-2) if mode == "bf16" else tol
+    torch.testing.assert_close(out.cpu().double(), ref, **t2)
+    # bias + residual (in-place style)
+    out = Nn.linear_gemm(xd, wd, bias=b.to(_dev()), residual=r.to(_dev()))
+    torch.testing.assert_close(out.cpu().double(), base + b.double() + r.double(), **tol)
+
+
+def test_gemm_asymmetric_identity():
+    """A = I against an ASYMMETRIC W catches a transposed C write (cdna guide §3)."""
+    import cmh_native as Nn
+    K = N = 128
+    x = torch.eye(K)
+    w = torch.arange(N * K, dtype=torch.float32).reshape(N, K) / 1000.0
+    out = Nn.linear_gemm(x.to(_dev()), w.to(_dev()))
+    torch.testing.assert_close(out.cpu(), w.t().contiguous(), rtol=0, atol=0)
+    xb, wb = x.bfloat16(), (torch.arange(N * K) % 251 - 125).float().reshape(N, K).bfloat16()
+    out = Nn.linear_gemm(xb.to(_dev()), wb.to(_dev()))
+    torch.testing.assert_close(out.cpu(), wb.float().t().contiguous(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("M,d", [(5, 128), (300, 512), (1000, 768), (7, 1024)])
+def test_layernorm(M, d):
+    import cmh_native as Nn
+    g = torch.Generator().manual_seed(d)
+    x = torch.randn(M, d, generator=g) * 3 + 0.5
+    w, b = torch.randn(d, generator=g), torch.randn(d, generator=g)
+    ref = torch.nn.functional.layer_norm(x.double(), (d,), w.double(), b.double(), 1e-5)
+    out = Nn.layernorm(x.to(_dev()), w.to(_dev()), b.to(_dev()))
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-5, atol=1e-5)
+    outb = Nn.layernorm(x.to(_dev()), w.to(_dev()), b.to(_dev()), out_bf16=True)
+    torch.testing.assert_close(outb.cpu().double(), ref, rtol=1e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("B,T,d,causal", [(2, 5, 128, 0), (3, 50, 768, 0), (2, 77, 512, 1), (2, 16, 128, 1),
+                                          (1, 130, 128, 1), (2, 9, 128, 1)])
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_attention(B, T, d, causal, mode):
+    import cmh_native as Nn
+    g = torch.Generator().manual_seed(T * 3 + d)
+    qkv = torch.randn(B * T, 3 * d, generator=g)
+    kpm = None
+    if causal and T >= 9:
+        kpm = torch.zeros(B, T, dtype=torch.bool)
+        kpm[0, T - 3:] = True                      # MITH-style padding mask on the tail
+    src = qkv.bfloat16() if mode == "bf16" else qkv
+    h = d // 64
+    q, k, v = (src.double()[:, i * d:(i + 1) * d].reshape(B, T, h, 64).permute(0, 2, 1, 3) for i in range(3))
+    s = (q * 0.125) @ k.transpose(-1, -2)
+    if causal:
+        s = s + torch.full((T, T), float("-inf"), dtype=torch.float64).triu(1)
+    if kpm is not None:
+        s = s.masked_fill(kpm[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * T, d)
+    out = Nn.attention(src.to(_dev()), B, T, causal, None if kpm is None else kpm.to(_dev()))
+    tol = dict(rtol=1e-2, atol=1e-2) if mode == "bf16" else dict(rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(out.cpu().double(), ref, **tol)

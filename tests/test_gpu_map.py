@@ -1,0 +1,123 @@
+"""Hamming ranking + mAP on the GPU (C ABI cmh_pack_* / cmh_hamming_map / cmh_hamming_dist) vs the goldens
+produced by the reference's calc_map_k_matrix and vs the C++ oracle: per-query AP, mAP, and the full
+ranking permutation bit-exact (tie order included)."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from maputil import CASES, case_inputs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _gpu_map(qB, rB, qL, rL, k=None, want_perm=False, depth_limit=-1, nq=None):
+    import cmh_native as N
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    if nq is not None:
+        qB, qL = qB[:nq], qL[:nq]
+    return N.hamming_map(N.pack_codes(t(qB)), N.pack_labels(t(qL)), N.pack_codes(t(rB)), N.pack_labels(t(rL)),
+                         rB.shape[1], rL.shape[1], topk=k, want_perm=want_perm, depth_limit=depth_limit)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_map_matches_reference_goldens(golden, name):
+    g = golden("map.npz")
+    qB, rB, qL, rL, k = case_inputs(g, name)
+    N = rB.shape[0]
+    mp, ap, _ = _gpu_map(qB, rB, qL, rL, k)
+    np.testing.assert_allclose(ap.cpu().numpy(), g[f"{name}_ap"], rtol=0, atol=2e-6)
+    assert abs(float(mp) - float(g[f"{name}_map"])) < 2e-6
+    # bit-exact Hamming ranks for the recorded queries
+    nperm = len(g[f"{name}_ind_sha"])
+    _, _, perm = _gpu_map(qB, rB, qL, rL, k, want_perm=True, nq=nperm)
+    perm = perm.cpu().numpy()
+    tsum = (qL[:nperm] @ rL.T > 0).sum(1)
+    for i in range(nperm):
+        if tsum[i] == 0:
+            assert (perm[i] == -1).all()       # skipped query (utils/calc_utils.py:27-29)
+            continue
+        assert hashlib.sha256(perm[i].astype(np.int64).tobytes()).hexdigest() == str(g[f"{name}_ind_sha"][i])
+        if N <= 5003:
+            assert np.array_equal(perm[i], g[f"{name}_ind{i}"])
+
+
+def test_entry_point_calc_map_k_matrix(golden):
+    """The reference-shaped API (utils/calc_utils.py) with CPU labels, like train/base.py:259 passes them."""
+    from utils.calc_utils import calc_hammingDist, calc_map_k_matrix, calc_neighbor
+    g = golden("map.npz")
+    qB, rB, qL, rL, k = case_inputs(g, "corr_1k_64_k50")
+    m = calc_map_k_matrix(torch.from_numpy(qB).to(DEV), torch.from_numpy(rB).to(DEV), torch.from_numpy(qL),
+                          torch.from_numpy(rL), k, 0)
+    assert m.dim() == 0 and abs(float(m) - float(g["corr_1k_64_k50_map"])) < 2e-6
+    d = calc_hammingDist(torch.from_numpy(qB[3]).to(DEV), torch.from_numpy(rB).to(DEV))
+    assert d.shape == (1, rB.shape[0])
+    np.testing.assert_array_equal(d.cpu().numpy()[0], oracle.hamming_row(qB[3], rB))
+    s = calc_neighbor(torch.from_numpy(qL[:50]).to(DEV), torch.from_numpy(rL[:70]).to(DEV))
+    np.testing.assert_array_equal(s.cpu().numpy(), (qL[:50] @ rL[:70].T > 0).astype(np.float32))
+
+
+def test_codes_with_zeros_and_half_integer_distances(golden):
+    g = golden("map.npz")
+    qB, rB, qL, rL, k = case_inputs(g, "zeros_300_32")
+    assert (qB == 0).any() and (rB == 0).any()
+    import cmh_native as N
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    d = N.hamming_dist(N.pack_codes(t(qB)), N.pack_codes(t(rB)), 32).cpu().numpy()
+    ref = np.stack([oracle.hamming_row(q, rB) for q in qB])
+    np.testing.assert_array_equal(d, ref)
+    assert (d % 1 == 0.5).any()
+
+
+@pytest.mark.parametrize("depth", [0, 1, 3, 6])
+def test_heapsort_fallback_matches_libstdcpp(depth):
+    """Force the introsort depth budget so the __partial_sort (heapsort) branch runs on the GPU."""
+    rng = np.random.default_rng(depth)
+    Q, N, K, C = 6, 3000, 32, 8
+    qB = np.where(rng.random((Q, K)) < 0.5, -1.0, 1.0).astype(np.float32)
+    rB = np.where(rng.random((N, K)) < 0.5, -1.0, 1.0).astype(np.float32)
+    qL = np.ones((Q, C), np.float32)
+    rL = (rng.random((N, C)) < 0.3).astype(np.float32)
+    _, _, perm = _gpu_map(qB, rB, qL, rL, want_perm=True, depth_limit=depth)
+    perm = perm.cpu().numpy()
+    for i in range(Q):
+        ref = oracle.sort_perm_depth(oracle.hamming_row(qB[i], rB), depth)
+        assert np.array_equal(perm[i], ref), (depth, i)
+
+
+def test_size_independent_properties_at_full_size():
+    """NUS-WIDE scale (N=190 834, 128-bit): ranking is a permutation, keys are sorted, AP in [0,1], identical
+    queries give identical APs, and a query that equals a relevant DB code ranks a relevant item first."""
+    import cmh_native as N
+    rng = np.random.default_rng(5)
+    Q, Nn, K, C = 8, 190834, 128, 21
+    rL = (rng.random((Nn, C)) < 0.15).astype(np.float32)
+    rB = np.where(rng.random((Nn, K)) < 0.5, -1.0, 1.0).astype(np.float32)
+    qB = rB[:Q].copy()
+    qL = rL[:Q].copy()
+    qL[qL.sum(1) == 0, 0] = 1
+    rL[:Q] = qL
+    qB[1], qL[1] = qB[0], qL[0]
+    mp, ap, perm = _gpu_map(qB, rB, qL, rL, want_perm=True)
+    ap, perm = ap.cpu().numpy(), perm.cpu().numpy()
+    assert ((ap >= 0) & (ap <= 1)).all() and ap[0] == ap[1]
+    for i in range(Q):
+        assert np.array_equal(np.sort(perm[i]), np.arange(Nn))
+        keys = oracle.hamming_row(qB[i], rB)[perm[i]]
+        assert (np.diff(keys) >= 0).all()
+        assert keys[0] == 0
+    m_ref, ap_ref, _ = oracle.map_k(qB, rB, qL, rL)
+    np.testing.assert_allclose(ap, ap_ref, rtol=0, atol=2e-6)
+
+
+def test_bad_codes_are_refused():
+    import cmh_native as N
+    c = torch.ones(4, 16, device=DEV)
+    c[2, 3] = 0.5
+    with pytest.raises(N.NativeError):
+        N.pack_codes(c)
+    with pytest.raises(N.NativeError):
+        N.pack_labels(-torch.ones(2, 5, device=DEV))
