@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the hot path (BASELINE.json metric: image+text pairs/s encoded+hashed per GPU).
+
+One "step" = one pass of the hot path over one batch of synthetic input already resident in HBM:
+  encode_image (ViT-B/32, 224x224) + encode_text (77 tokens) -> LinearHash heads (tanh) -> sign() codes ->
+  bit-packed codes -> [N>1: ONE fused RCCL all-gather of the hash outputs + labels] -> DSPH HyP loss (forward).
+Workload = BASELINE.json configs[1]: "DSPH --dataset flickr25k --output-dim 64, ViT-B/32 bf16, 1xMI355X,
+batch=256" (per-GPU batch fixed as N grows -> weak scaling).  Random-init weights, synthetic data.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline     dominant kernel (the MFMA GEMM): algorithmic FLOPs / HIP-event launch durations, live, over
+               the timed region (cmh_prof_gemm_*), vs the dense MFMA peak of the dtype.
+  cpu_baseline the oracle (numpy fp32 restatement of the reference path) timed on the host cores, rank 0, N=1.
+  map_eval     secondary metric: wall-clock of the 4 calc_map_k directions (64-bit, MIRFlickr scale), codes
+               resident; not part of `value`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "clip-based-cross-modal-hashing_amd")
+for p in (ROOT, PKG, os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}      # /opt/skills/guides/MI355X_MICROARCH.md, dense
+FLOP_IMG = 8.818e9                                  # BASELINE.md §3 (fwd, per image)
+VITB32 = dict(embed_dim=512, image_resolution=224, vision_layers=12, vision_width=768, vision_patch_size=32,
+              context_length=77, vocab_size=49408, transformer_width=512, transformer_heads=8, transformer_layers=12)
+
+
+def text_flops(L):
+    d, layers = 512, 12
+    per_tok = layers * (2 * d * 3 * d + 2 * d * d + 2 * 2 * d * 4 * d + 2 * 2 * L * d)
+    return L * per_tok + 2 * d * 512
+
+
+def synthetic_batch(B, L, C, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    image = torch.randn(B, 3, 224, 224, generator=g)
+    text = torch.zeros(B, L, dtype=torch.int64)
+    n = torch.randint(3, L, (B,), generator=g)
+    for i in range(B):
+        text[i, 0] = 49406
+        text[i, 1:n[i]] = torch.randint(1, 49406, (int(n[i]) - 1,), generator=g)
+        text[i, n[i]] = 49407
+    label = (torch.rand(B, C, generator=g) < 0.15).float()
+    return image.to(dev), text.to(dev), label.to(dev)
+
+
+def cpu_baseline(L, bits, budget_s=12.0):
+    """The oracle (a port of the reference path) on the host cores: encode+hash pairs/s."""
+    import recipe
+    from oracle import clip_oracle as co
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count() or 1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    sd = recipe.clip_state_dict(recipe.CLIP_VITB32, 11)
+    B = 8
+    img = recipe.images(B, 224, 3)
+    txt = recipe.captions(B, L, 49408, 3)
+    wi, bi = recipe.head_linear(512, bits, 3, "bi")
+    wt, bt = recipe.head_linear(512, bits, 3, "bt")
+
+    def one():
+        hi = co.linear_hash(co.encode_image(sd, img), wi, bi)
+        ht = co.linear_hash(co.encode_text(sd, txt), wt, bt)
+        return co.sign_codes(hi), co.sign_codes(ht)
+    one()
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s:
+        one()
+        n += B
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 2), "unit": "pairs/s", "cores": int(cores), "kind": "port",
+            "sample": f"{n} pairs (batches of {B}, 224x224 + {L} tokens, ViT-B/32 fp32 numpy oracle, {dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (configs[1]: 256)")
+    ap.add_argument("--seq-len", type=int, default=77)
+    ap.add_argument("--bits", type=int, default=64)
+    ap.add_argument("--classes", type=int, default=24)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-map-eval", action="store_true")
+    ap.add_argument("--map-queries", type=int, default=5000)
+    ap.add_argument("--map-db", type=int, default=15015)
+    a = ap.parse_args()
+
+    import cmh_native as N
+    import dist_utils as du
+    from model.base.model import CLIP
+    from model.modelbase import LinearHash
+    from train.DSPH.loss import HyP
+
+    rank, world, local = du.init_from_env()
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    B, L, K, C = a.batch, a.seq_len, a.bits, a.classes
+
+    torch.manual_seed(1814)
+    clip = CLIP(**VITB32).to(dev).float().set_gemm_dtype(a.dtype)
+    clip.assume_frozen = True
+    img_head, txt_head = LinearHash(512, K).to(dev).eval(), LinearHash(512, K).to(dev).eval()
+    hyp = HyP(numclass=C, output_dim=K, hypseed=0, alpha=0.8).to(dev)
+    image, text, label = synthetic_batch(B, L, C, 1814 + rank, dev)
+
+    def step():
+        with torch.no_grad():
+            hi = img_head(clip.encode_image(image))
+            ht = txt_head(clip.encode_text(text))
+            ci, ct = N.sign_codes(hi), N.sign_codes(ht)
+            N.pack_codes(ci, check=False)
+            N.pack_codes(ct, check=False)
+            if world > 1:   # the path's one exchange step: fused all-gather of the per-rank code blocks
+                fused, widths = du.fuse_columns(hi, ht, label)
+                hi_g, ht_g, lab_g = du.split_columns(du.all_gather_rows(fused), widths)
+            else:
+                hi_g, ht_g, lab_g = hi, ht, label
+            return hyp(hi_g, ht_g, lab_g)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    N.prof_gemm_begin(a.steps * 128)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    barrier()
+    t1 = time.perf_counter()
+    gemm_ms, gemm_flops, gemm_launches = N.prof_gemm_end()
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    assert torch.isfinite(loss).item(), "non-finite loss"
+
+    pairs = a.steps * B * world
+    value = pairs / elapsed
+    flops_pair = FLOP_IMG + text_flops(L)
+    peak = PEAK_TFLOPS[a.dtype]
+    achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    out = {
+        "metric": "image+text pairs/s encoded+hashed per GPU; mAP@K eval wallclock (64-bit)",
+        "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": "configs[1]: DSPH flickr25k output-dim 64, ViT-B/32, batch 256/GPU, 224x224 + "
+                               f"{L}-token captions: encode_image+encode_text -> LinearHash -> sign -> pack -> "
+                               "[all-gather] -> HyP loss fwd", "per_gpu_batch": B, "global_batch": B * world,
+                   "seq_len": L, "bits": K, "weights": "random-init ViT-B/32", "parallelism": f"batch-shard x{world}"},
+        "per_gpu_value": round(value / world, 2),
+        "end_to_end_tflops_per_gpu": round(value / world * flops_pair / 1e12, 2),
+        "roofline": {"bound": "mfma", "kernel": "cmh::gemm_kernel<%s>" % ("true" if a.dtype == "f32" else "false"),
+                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                     "traffic": None, "launches": int(gemm_launches),
+                     "avg_launch_us": round(gemm_ms * 1e3 / max(gemm_launches, 1), 2),
+                     "gemm_share_of_step": round(gemm_ms / (elapsed * 1e3), 4)},
+    }
+
+    if not a.no_map_eval:
+        # secondary metric: 4 x calc_map_k at MIRFlickr scale, 64-bit, codes resident; queries sharded over ranks
+        Q, Nn = a.map_queries, a.map_db
+        g = torch.Generator().manual_seed(1234)
+        rL = (torch.rand(Nn, C, generator=g) < 0.15).float()
+        qL = (torch.rand(Q, C, generator=g) < 0.15).float()
+        W = torch.randn(C, K, generator=g)
+        mk = lambda lab: torch.sign(lab @ W + 0.5 * torch.randn(lab.shape[0], K, generator=g) + 1e-3).to(dev)
+        r_img, r_txt, q_img, q_txt = mk(rL), mk(rL), mk(qL), mk(qL)
+        lo, hi_ = du.shard_range(Q, rank, world)
+        rLp, qLp = N.pack_labels(rL.to(dev)), N.pack_labels(qL[lo:hi_].to(dev))
+        planes = {k: N.pack_codes(v) for k, v in dict(r_img=r_img, r_txt=r_txt, q_img=q_img[lo:hi_], q_txt=q_txt[lo:hi_]).items()}
+
+        def four():
+            res = []
+            for qk, rk in (("q_img", "r_txt"), ("q_txt", "r_img"), ("q_img", "r_img"), ("q_txt", "r_txt")):
+                _, ap_l, _ = N.hamming_map(planes[qk], qLp, planes[rk], rLp, K, C)
+                res.append(du.mean_in_query_order(du.gather_query_sharded_ap(ap_l, Q)) if world > 1 else ap_l.mean())
+            return res
+        four()
+        barrier()
+        t0 = time.perf_counter()
+        maps = four()
+        barrier()
+        out["map_eval"] = {"ms": round((time.perf_counter() - t0) * 1e3, 3), "directions": 4, "Q": Q, "N": Nn,
+                           "bits": K, "tie_order": "reference (libstdc++ introsort)", "mAP_i2t": round(float(maps[0]), 6)}
+
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cb = cpu_baseline(L, K)
+        out["cpu_baseline"] = cb
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -67,6 +67,8 @@ SIGNATURES = {
     "cmh_linear_gemm": (C.c_int, [_i32, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "cmh_layernorm": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _p]),
     "cmh_attention": (C.c_int, [_i32, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
+    "cmh_prof_gemm_begin": (C.c_int, [_i32]),
+    "cmh_prof_gemm_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "cmh_cast_f32_to_bf16": (C.c_int, [_p, _p, _i64, _p]),
     "cmh_linear_act": (C.c_int, [_p, _p, _p, _p, _f, _i32, _p, _i32, _i32, _i32, _p]),
     "cmh_pair_softmax": (C.c_int, [_p, _p, _i32, _i32, _p]),
@@ -148,6 +150,17 @@ def cast_bf16(src: torch.Tensor) -> torch.Tensor:
     dst = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
     check(lib().cmh_cast_f32_to_bf16(ptr(src), ptr(dst), src.numel(), stream_ptr(src.device)), "cmh_cast_f32_to_bf16")
     return dst
+
+
+def prof_gemm_begin(max_launches: int):
+    check(lib().cmh_prof_gemm_begin(int(max_launches)), "cmh_prof_gemm_begin")
+
+
+def prof_gemm_end():
+    """-> (sum of GEMM launch durations [ms], sum of algorithmic FLOPs, number of launches)"""
+    ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
+    check(lib().cmh_prof_gemm_end(C.byref(ms), C.byref(fl), C.byref(n)), "cmh_prof_gemm_end")
+    return ms.value, fl.value, n.value
 
 
 # ------------------------------------------------------------------------------------------ tower blocks
@@ -237,8 +250,9 @@ def pair_argmax_codes(p):
 
 
 # ------------------------------------------------------------------------------------------ hamming / mAP
-def pack_codes(codes):
-    """f32 codes in {-1,0,+1} [n, K] -> (sign_plane, nz_plane) int32 [n, ceil(K/32)]."""
+def pack_codes(codes, check=True):
+    """f32 codes in {-1,0,+1} [n, K] -> (sign_plane, nz_plane) int32 [n, ceil(K/32)].
+    check=True reads the device-side domain flag back (one host sync); pass False on a timed path."""
     codes = f32c(codes)
     require_gpu(codes)
     n, K = codes.shape
@@ -247,7 +261,7 @@ def pack_codes(codes):
     nz = torch.empty(n, W, dtype=torch.int32, device=codes.device)
     bad = torch.zeros(1, dtype=torch.int32, device=codes.device)
     check(lib().cmh_pack_codes(ptr(codes), n, K, ptr(sp), ptr(nz), ptr(bad), stream_ptr(codes.device)), "cmh_pack_codes")
-    if int(bad.item()):
+    if check and int(bad.item()):
         raise NativeError("pack_codes: hash codes must be exactly -1, 0 or +1 (sign()/argmax codes)")
     return sp, nz
 

@@ -20,6 +20,8 @@
 //  * XCD-aware tile order: blocks that share an XCD (blockIdx % 8) walk n fastest over a contiguous
 //    range of tiles, so an X panel is re-used from that XCD's L2 across the N/128 column tiles and
 //    the whole W (<= 4.7 MB bf16) stays L2-resident.
+#include <vector>
+
 #include "cmh_common.h"
 
 namespace cmh {
@@ -187,6 +189,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const char* __restrict__ X, c
   }
 }
 
+// ---- optional launch timing (bench.py roofline): HIP events around every GEMM launch on its own stream ----
+struct GemmProf {
+  bool on = false;
+  std::vector<hipEvent_t> ev;     // pairs
+  std::vector<double> flops;
+  size_t used = 0;
+};
+static GemmProf g_prof;
+
 int launch_gemm(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out,
                 int M, int N, int K, int epi, hipStream_t st) {
   const int bk = dt == CMH_F32 ? 32 : 64;
@@ -197,14 +208,54 @@ int launch_gemm(int dt, const void* A, const void* W, const float* bias, const f
   CMH_CHECK_ARG(!(epi & EPI_BIAS) || bias, "gemm: EPI_BIAS without bias");
   CMH_CHECK_ARG(!(epi & EPI_RESIDUAL) || residual, "gemm: EPI_RESIDUAL without residual");
   const int total = (N / kTile) * ((M + kTile - 1) / kTile);
+  const bool timed = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
+  if (timed) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
   if (dt == CMH_F32)
     hipLaunchKernelGGL(gemm_kernel<true>, dim3(total), dim3(256), 0, st, static_cast<const char*>(A),
                        static_cast<const char*>(W), bias, residual, out, M, N, K, epi);
   else
     hipLaunchKernelGGL(gemm_kernel<false>, dim3(total), dim3(256), 0, st, static_cast<const char*>(A),
                        static_cast<const char*>(W), bias, residual, out, M, N, K, epi);
+  if (timed) {
+    (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
+    g_prof.flops.push_back(2.0 * M * static_cast<double>(N) * K);   // algorithmic FLOPs: real rows only
+    g_prof.used += 2;
+  }
   CMH_CHECK_LAUNCH("gemm");
   return CMH_OK;
 }
 
 }  // namespace cmh
+
+extern "C" int cmh_prof_gemm_begin(int32_t max_launches) {
+  using namespace cmh;
+  CMH_CHECK_ARG(max_launches > 0 && max_launches <= (1 << 20), "prof_gemm_begin: bad max_launches");
+  while (g_prof.ev.size() < static_cast<size_t>(max_launches) * 2) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return fail(CMH_ERR_LAUNCH, "prof_gemm_begin: hipEventCreate failed");
+    g_prof.ev.push_back(e);
+  }
+  g_prof.used = 0;
+  g_prof.flops.clear();
+  g_prof.on = true;
+  return CMH_OK;
+}
+
+extern "C" int cmh_prof_gemm_end(double* total_ms, double* total_flops, int64_t* launches) {
+  using namespace cmh;
+  CMH_CHECK_ARG(total_ms && total_flops && launches, "prof_gemm_end: null pointer");
+  g_prof.on = false;
+  double ms = 0.0, fl = 0.0;
+  for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+    if (hipEventSynchronize(g_prof.ev[i + 1]) != hipSuccess) return fail(CMH_ERR_LAUNCH, "prof_gemm_end: event sync failed");
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]) != hipSuccess)
+      return fail(CMH_ERR_LAUNCH, "prof_gemm_end: hipEventElapsedTime failed");
+    ms += t;
+    fl += g_prof.flops[i / 2];
+  }
+  *total_ms = ms;
+  *total_flops = fl;
+  *launches = static_cast<int64_t>(g_prof.used / 2);
+  return CMH_OK;
+}

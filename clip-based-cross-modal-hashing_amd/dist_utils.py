@@ -1,0 +1,94 @@
+"""Multi-GPU plumbing for the hot path: one process per GPU, torch.distributed (backend "nccl" = RCCL
+over xGMI on ROCm, "gloo" in the CPU tests).
+
+The reference has no distributed code at all; north_star adds exactly one exchange step:
+an ALL-GATHER of per-rank code blocks (hash outputs / sign codes, plus labels and dataset indices) so
+that (i) pairwise losses see the global batch and (ii) every rank holds the whole retrieval database
+(3 MB packed at NUS-WIDE scale) while QUERIES are sharded.  Messages are tens of KiB: latency-bound,
+so each step issues ONE fused all-gather of a [B_local, width] block, never one per tensor.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str | None = None):
+    """Initialise the default process group from RANK/WORLD_SIZE/MASTER_* (torchrun).  -> (rank, world, local)"""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous shard [lo, hi) of n items; the first n % world ranks get one extra item."""
+    q, r = divmod(n, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def fuse_columns(*blocks: torch.Tensor) -> tuple[torch.Tensor, list[int]]:
+    """[B, w_i] blocks -> one [B, sum w_i] f32 block (one collective instead of len(blocks))."""
+    widths = [b.shape[1] for b in blocks]
+    return torch.cat([b.float() for b in blocks], dim=1).contiguous(), widths
+
+
+def split_columns(fused: torch.Tensor, widths: list[int]) -> list[torch.Tensor]:
+    return list(torch.split(fused, widths, dim=1))
+
+
+def all_gather_rows(block: torch.Tensor, counts: list[int] | None = None) -> torch.Tensor:
+    """Concatenate the [B_r, w] blocks of all ranks in rank order.  Equal B_r -> one all_gather_into_tensor
+    (RCCL ring over xGMI); ragged -> pad to the max, gather, and strip (counts = rows per rank)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return block
+    world = dist.get_world_size()
+    block = block.contiguous()
+    if counts is None or len(set(counts)) == 1:
+        out = torch.empty((world * block.shape[0],) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
+        dist.all_gather_into_tensor(out, block)
+        return out
+    mx = max(counts)
+    pad = torch.zeros((mx,) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
+    pad[:block.shape[0]] = block
+    out = torch.empty((world * mx,) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
+    dist.all_gather_into_tensor(out, pad)
+    return torch.cat([out[r * mx:r * mx + counts[r]] for r in range(world)], dim=0)
+
+
+def gather_query_sharded_ap(ap_local: torch.Tensor, n_query: int) -> torch.Tensor:
+    """Per-query APs computed on query shards -> the full [Q] vector in QUERY ORDER on every rank, so the final
+    mean is accumulated in the same order as a single-GPU run (the reference sums in query order)."""
+    world = world_size()
+    if world == 1:
+        return ap_local
+    counts = [shard_range(n_query, r, world)[1] - shard_range(n_query, r, world)[0] for r in range(world)]
+    return all_gather_rows(ap_local.reshape(-1, 1), counts).reshape(-1)
+
+
+def mean_in_query_order(ap: torch.Tensor) -> torch.Tensor:
+    """f32 running sum in query order / Q (utils/calc_utils.py:37-38 `map += AP; map / num_query`)."""
+    acc = torch.zeros((), dtype=torch.float32)
+    for v in ap.detach().float().cpu():
+        acc = acc + v
+    return acc / ap.numel()
+
+
+def scatter_by_index(buffer: torch.Tensor, index: torch.Tensor, rows: torch.Tensor) -> None:
+    """buffer[index] = rows for the gathered (index, rows) of all ranks — the reference's code buffers and the
+    MITH memory bank are indexed by dataset position (train/base.py:145-146, train/MITH/hash_train.py:72-78)."""
+    buffer[index.long()] = rows.to(buffer.dtype)

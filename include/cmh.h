@@ -144,6 +144,13 @@ int cmh_layernorm(const float* x, const float* w, const float* b, void* out, int
 int cmh_attention(int32_t dtype, const void* qkv, void* o, int32_t B, int32_t T, int32_t d, int32_t causal,
                   const uint8_t* key_padding_mask, void* stream);
 
+/* Measurement hook (bench.py `roofline`): while enabled, every GEMM launch of the library is bracketed by
+ * HIP events recorded on the launch stream.  _end() synchronises on those events and returns the summed
+ * launch durations, the summed algorithmic FLOPs (2*M*N*K, real rows only) and the launch count.
+ * Not thread-safe; single-stream benchmarking only. */
+int cmh_prof_gemm_begin(int32_t max_launches);
+int cmh_prof_gemm_end(double* total_ms, double* total_flops, int64_t* launches);
+
 /* f32 -> bf16 (round-to-nearest-even) copy used to prepare CMH_BF16 GEMM weights. */
 int cmh_cast_f32_to_bf16(const float* src, void* dst_bf16, int64_t n, void* stream);
 

@@ -1,0 +1,77 @@
+"""world_size-2 gloo test of the multi-GPU exchange step (CPU tensors; the kernels themselves are covered
+by the -m gpu tests): fused all-gather of code blocks, ragged shards, query-sharded AP gathered in query
+order, index-scatter into the global buffers."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    import sys
+    from conftest import PKG  # noqa: F401  (puts the package on sys.path)
+    import dist_utils as du
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    r, w, _ = du.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    n, K, C = 37, 16, 5                                   # ragged: 19 + 18
+    g = torch.Generator().manual_seed(0)
+    codes_i = torch.sign(torch.randn(n, K, generator=g))
+    codes_t = torch.sign(torch.randn(n, K, generator=g))
+    labels = (torch.rand(n, C, generator=g) < 0.3).float()
+    index = torch.randperm(n, generator=g)
+    lo, hi = du.shard_range(n, rank, world)
+    counts = [du.shard_range(n, q, world)[1] - du.shard_range(n, q, world)[0] for q in range(world)]
+    fused, widths = du.fuse_columns(codes_i[lo:hi], codes_t[lo:hi], labels[lo:hi], index[lo:hi].float().unsqueeze(1))
+    allb = du.all_gather_rows(fused, counts)
+    gi, gt, gl, gidx = du.split_columns(allb, widths)
+    assert torch.equal(gi, codes_i) and torch.equal(gt, codes_t) and torch.equal(gl, labels)
+    buf = torch.zeros(n, K)
+    du.scatter_by_index(buf, gidx.squeeze(1), gi)
+    ref = torch.zeros(n, K)
+    ref[index] = codes_i
+    assert torch.equal(buf, ref)
+    # equal shards take the single-collective path
+    eq = du.all_gather_rows(codes_i[rank * 10:(rank + 1) * 10])
+    assert torch.equal(eq, codes_i[:20])
+    # query-sharded AP, gathered in query order, summed like the reference
+    ap = torch.rand(n, generator=g)
+    full = du.gather_query_sharded_ap(ap[lo:hi], n)
+    assert torch.equal(full, ap)
+    m = du.mean_in_query_order(full)
+    acc = np.float32(0)
+    for v in ap.numpy():
+        acc = np.float32(acc + v)
+    assert float(m) == float(acc / np.float32(n))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+
+
+def test_world2_gloo_exchange(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_shard_range_covers_everything():
+    from conftest import PKG  # noqa: F401
+    import dist_utils as du
+    for n in (0, 1, 7, 256, 5000, 190834):
+        for world in (1, 2, 3, 4, 8):
+            spans = [du.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1

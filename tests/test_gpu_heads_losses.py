@@ -153,6 +153,7 @@ def test_trainer_valid_end_to_end(tmp_path, monkeypatch):
     import dataset.synthetic as ds
     monkeypatch.setattr(ds, "SOT", 510); monkeypatch.setattr(ds, "EOT", 511)   # tiny vocabulary
     tr = main.trainers["DSPH"](args, 0)
+    tr.change_state(mode="valid")                    # heads to eval: no dropout in the codes
     q_img, q_txt, r_img, r_txt, _, _ = tr._codes_for_eval()
     assert set(np.unique(q_img.cpu().numpy())) <= {-1.0, 0.0, 1.0} and r_img.shape == (160, 16)
     maps = tr.valid(0)
