@@ -128,8 +128,8 @@ def main():
             hi = img_head(clip.encode_image(image))
             ht = txt_head(clip.encode_text(text))
             ci, ct = N.sign_codes(hi), N.sign_codes(ht)
-            N.pack_codes(ci, check=False)
-            N.pack_codes(ct, check=False)
+            N.pack_codes(ci, validate=False)
+            N.pack_codes(ct, validate=False)
             if world > 1:   # the path's one exchange step: fused all-gather of the per-rank code blocks
                 fused, widths = du.fuse_columns(hi, ht, label)
                 hi_g, ht_g, lab_g = du.split_columns(du.all_gather_rows(fused), widths)

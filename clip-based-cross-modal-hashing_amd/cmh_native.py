@@ -250,9 +250,9 @@ def pair_argmax_codes(p):
 
 
 # ------------------------------------------------------------------------------------------ hamming / mAP
-def pack_codes(codes, check=True):
+def pack_codes(codes, validate=True):
     """f32 codes in {-1,0,+1} [n, K] -> (sign_plane, nz_plane) int32 [n, ceil(K/32)].
-    check=True reads the device-side domain flag back (one host sync); pass False on a timed path."""
+    validate=True reads the device-side domain flag back (one host sync); pass False on a timed path."""
     codes = f32c(codes)
     require_gpu(codes)
     n, K = codes.shape
@@ -261,7 +261,7 @@ def pack_codes(codes, check=True):
     nz = torch.empty(n, W, dtype=torch.int32, device=codes.device)
     bad = torch.zeros(1, dtype=torch.int32, device=codes.device)
     check(lib().cmh_pack_codes(ptr(codes), n, K, ptr(sp), ptr(nz), ptr(bad), stream_ptr(codes.device)), "cmh_pack_codes")
-    if check and int(bad.item()):
+    if validate and int(bad.item()):
         raise NativeError("pack_codes: hash codes must be exactly -1, 0 or +1 (sign()/argmax codes)")
     return sp, nz
 
