@@ -164,11 +164,160 @@ __global__ __launch_bounds__(64) void attention_kernel(const T* __restrict__ qkv
   }
 }
 
+// ---- bf16 MFMA path (T <= 128) ---------------------------------------------------------------------------
+// One wave per (batch, head).  All K rows sit in registers as MFMA A-fragments (16-byte global loads, no LDS);
+// V goes through LDS once to be re-read key-major (the PV product needs V^T fragments) and then also stays in
+// registers.  Scores are computed TRANSPOSED, S^T = K.Q^T, so a lane owns 4 keys x 1 query per tile: the row
+// softmax is in-lane + two xor-shuffles, and the S^T accumulators are already laid out as the B operand of
+// O^T = V^T.P^T (k order permuted identically on both operands: key(g,j) = 32s + 16(j>>2) + 4g + (j&3)).
+typedef __attribute__((ext_vector_type(8))) __bf16 abf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float af32x4_t;
+
+template <int NKT>
+__global__ __launch_bounds__(64) void attention_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                            int B, int Tn, int d, int causal,
+                                                            const uint8_t* __restrict__ kpm) {
+  constexpr int NKS = NKT / 2;
+  constexpr int TP = NKT * 16;
+  constexpr int VST = 66;   // LDS row stride in bf16 elements (132 B): the 4 lane groups land on different banks
+  __shared__ __attribute__((aligned(16))) bf16_t sV[TP * VST];
+
+  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  const int heads = d / HD;
+  const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+  const size_t ld = static_cast<size_t>(3) * d;
+  const bf16_t* base = qkv + static_cast<size_t>(b) * Tn * ld + h * HD;
+
+  // V -> LDS (rows >= T zeroed so that 0 * garbage can never be NaN)
+  for (int slot = lane; slot < TP * 8; slot += 64) {
+    const int row = slot >> 3, ch = slot & 7;
+    uint4 v = uint4{0u, 0u, 0u, 0u};
+    if (row < Tn) v = *reinterpret_cast<const uint4*>(base + static_cast<size_t>(row) * ld + 2 * d + ch * 8);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&sV[row * VST + ch * 8]);
+    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+  }
+  // K fragments: A operand rows = keys
+  abf16x8_t kf[NKT][2];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    int row = kt * 16 + c;
+    row = row < Tn ? row : Tn - 1;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      kf[kt][s] = *reinterpret_cast<const abf16x8_t*>(base + static_cast<size_t>(row) * ld + d + s * 32 + g * 8);
+  }
+  // which of this lane's keys (kt, r) -> key = 16kt + 4g + r are usable at all
+  uint32_t keyok = 0;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kt * 16 + 4 * g + r;
+      bool ok = key < Tn;
+      if (ok && kpm) ok = kpm[static_cast<size_t>(b) * Tn + key] == 0;
+      keyok |= (ok ? 1u : 0u) << (kt * 4 + r);
+    }
+  __syncthreads();
+  // V^T fragments: A operand rows = head-dim, k = keys in the permuted order
+  abf16x8_t vf[NKS][4];
+#pragma unroll
+  for (int s = 0; s < NKS; ++s)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      abf16x8_t t;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int key = 32 * s + 16 * (j >> 2) + 4 * g + (j & 3);
+        t[j] = __builtin_bit_cast(__bf16, sV[key * VST + 16 * dt + c]);
+      }
+      vf[s][dt] = t;
+    }
+
+  const int nqt = (Tn + 15) >> 4;
+  for (int qt = 0; qt < nqt; ++qt) {
+    const int qrow = qt * 16 + c;
+    const int qr = qrow < Tn ? qrow : Tn - 1;
+    abf16x8_t qf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      qf[s] = *reinterpret_cast<const abf16x8_t*>(base + static_cast<size_t>(qr) * ld + s * 32 + g * 8);
+    af32x4_t sc[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      sc[kt] = af32x4_t{0.f, 0.f, 0.f, 0.f};
+      if (!causal || kt <= qt) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][s], qf[s], sc[kt], 0, 0, 0);
+      }
+    }
+    float m = -1e30f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + 4 * g + r;
+        const bool ok = ((keyok >> (kt * 4 + r)) & 1u) && (!causal || key <= qrow);
+        sc[kt][r] = ok ? sc[kt][r] * 0.125f : -1e30f;
+        m = fmaxf(m, sc[kt][r]);
+      }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = sc[kt][r] > -1e29f ? __expf(sc[kt][r] - m) : 0.f;
+        sc[kt][r] = p;
+        l += p;
+      }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    af32x4_t oc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oc[dt] = af32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+      abf16x8_t pb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pb[j] = static_cast<__bf16>(sc[2 * s + (j >> 2)][j & 3]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) oc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[s][dt], pb, oc[dt], 0, 0, 0);
+    }
+    if (qrow < Tn) {
+      const float inv = 1.0f / l;
+      bf16_t* op = o + (static_cast<size_t>(b) * Tn + qrow) * d + h * HD + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        uint2 pk;
+        pk.x = static_cast<uint32_t>(f32_to_bf16(oc[dt][0] * inv)) | (static_cast<uint32_t>(f32_to_bf16(oc[dt][1] * inv)) << 16);
+        pk.y = static_cast<uint32_t>(f32_to_bf16(oc[dt][2] * inv)) | (static_cast<uint32_t>(f32_to_bf16(oc[dt][3] * inv)) << 16);
+        *reinterpret_cast<uint2*>(op + 16 * dt) = pk;
+      }
+    }
+  }
+}
+
+template <int NKT>
+static void launch_attention_mfma(const void* qkv, void* o, int B, int T, int d, int causal, const uint8_t* kpm,
+                                  hipStream_t st) {
+  hipLaunchKernelGGL(attention_mfma_kernel<NKT>, dim3(B * (d / HD)), dim3(64), 0, st, static_cast<const bf16_t*>(qkv),
+                     static_cast<bf16_t*>(o), B, T, d, causal, kpm);
+}
+
 int launch_attention(const void* qkv, void* o, int dt, int B, int T, int d, int causal,
                      const uint8_t* key_padding_mask, hipStream_t st) {
   CMH_CHECK_ARG(d % HD == 0, "attention: width %d is not a multiple of 64", d);
   CMH_CHECK_ARG(B > 0 && T > 0, "attention: empty batch");
   const dim3 grid(B * (d / HD), (T + 63) / 64);
+  if (dt == CMH_BF16 && T <= 128) {
+    if (T <= 32) launch_attention_mfma<2>(qkv, o, B, T, d, causal, key_padding_mask, st);
+    else if (T <= 64) launch_attention_mfma<4>(qkv, o, B, T, d, causal, key_padding_mask, st);
+    else if (T <= 96) launch_attention_mfma<6>(qkv, o, B, T, d, causal, key_padding_mask, st);
+    else launch_attention_mfma<8>(qkv, o, B, T, d, causal, key_padding_mask, st);
+    CMH_CHECK_LAUNCH("attention_mfma");
+    return CMH_OK;
+  }
   if (dt == CMH_F32)
     hipLaunchKernelGGL(attention_kernel<float>, grid, dim3(64), 0, st, static_cast<const float*>(qkv),
                        static_cast<float*>(o), B, T, d, causal, key_padding_mask);
