@@ -20,6 +20,8 @@
 //  * XCD-aware tile order: blocks that share an XCD (blockIdx % 8) walk n fastest over a contiguous
 //    range of tiles, so an X panel is re-used from that XCD's L2 across the N/128 column tiles and
 //    the whole W (<= 4.7 MB bf16) stays L2-resident.
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "cmh_common.h"
@@ -198,6 +200,15 @@ struct GemmProf {
 };
 static GemmProf g_prof;
 
+void launch_gemm_glds(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out,
+                      int M, int N, int K, int epi, hipStream_t st);   // gemm_glds.hip
+
+// CMH_GEMM_IMPL=regstage selects the v1 register-staged kernel (A/B testing); default = LDS-DMA kernel.
+static int gemm_impl_from_env() {
+  const char* e = getenv("CMH_GEMM_IMPL");
+  return (e && !strcmp(e, "regstage")) ? 0 : 1;
+}
+
 int launch_gemm(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out,
                 int M, int N, int K, int epi, hipStream_t st) {
   const int bk = dt == CMH_F32 ? 32 : 64;
@@ -210,7 +221,10 @@ int launch_gemm(int dt, const void* A, const void* W, const float* bias, const f
   const int total = (N / kTile) * ((M + kTile - 1) / kTile);
   const bool timed = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
   if (timed) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
-  if (dt == CMH_F32)
+  static const int impl = gemm_impl_from_env();
+  if (impl == 1)
+    launch_gemm_glds(dt, A, W, bias, residual, out, M, N, K, epi, st);
+  else if (dt == CMH_F32)
     hipLaunchKernelGGL(gemm_kernel<true>, dim3(total), dim3(256), 0, st, static_cast<const char*>(A),
                        static_cast<const char*>(W), bias, residual, out, M, N, K, epi);
   else
