@@ -202,6 +202,9 @@ static GemmProf g_prof;
 
 void launch_gemm_glds(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out,
                       int M, int N, int K, int epi, hipStream_t st);   // gemm_glds.hip
+bool gemm_wide_supported(int N);                                         // gemm_wide.hip
+int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out,
+                     int M, int N, int K, int epi, hipStream_t st);
 
 // CMH_GEMM_IMPL=regstage selects the v1 register-staged kernel (A/B testing); default = LDS-DMA kernel.
 static int gemm_impl_from_env() {
@@ -222,7 +225,10 @@ int launch_gemm(int dt, const void* A, const void* W, const float* bias, const f
   const bool timed = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
   if (timed) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
   static const int impl = gemm_impl_from_env();
-  if (impl == 1)
+  static const bool wide = []() { const char* e = getenv("CMH_GEMM_WIDE"); return !(e && !strcmp(e, "0")); }();
+  if (impl == 1 && wide && gemm_wide_supported(N))
+    launch_gemm_wide(dt, A, W, bias, residual, out, M, N, K, epi, st);
+  else if (impl == 1)
     launch_gemm_glds(dt, A, W, bias, residual, out, M, N, K, epi, st);
   else if (dt == CMH_F32)
     hipLaunchKernelGGL(gemm_kernel<true>, dim3(total), dim3(256), 0, st, static_cast<const char*>(A),
