@@ -44,6 +44,14 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   return static_cast<bf16_t>(u >> 16);
 }
 
+// two f32 -> packed bf16x2 (lo = a) in ONE instruction (v_cvt_pk_bf16_f32, RNE, NaN-preserving on gfx950)
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  typedef __attribute__((ext_vector_type(2))) float f2_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 b2_t;
+  const f2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, b2_t));
+}
+
 // ---- epilogue flags of the GEMM ---------------------------------------------------------------
 enum : int {
   EPI_BIAS = 1,       // + bias[n]

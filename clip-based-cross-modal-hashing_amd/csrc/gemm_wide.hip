@@ -113,9 +113,48 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
     }
   };
 
+  // ---- rotated, software-pipelined K loop --------------------------------------------------------------------
+  // Per K-step s (stage s in LDS buffer s%3), with F0 = fragments of (s, k 0..31) already in registers:
+  //   1. issue the ds_reads of F1 = (s, k 32..63)
+  //   2. 20 MFMAs on F0                                    <- cover the F1 reads
+  //   3. lgkmcnt(0) (own F1 reads done), vmcnt: stage s+1 landed (stage s+2 may stay in flight), s_barrier
+  //      -> every wave has finished reading buffer s%3 and sees stage s+1
+  //   4. LDS-DMA of stage s+3 into buffer s%3              <- two full K-steps of flight
+  //   5. issue the ds_reads of F0' = (s+1, k 0..31)
+  //   6. 20 MFMAs on F1                                    <- cover the F0' reads and the DMA issue
+  // Fragment reads are inline asm so that THEIR waits are ours: hipcc's own bookkeeping turns any ds_read that is
+  // still pending at a loop back-edge into s_waitcnt lgkmcnt(0) in front of the next MFMA block, which would serialise
+  // reads and MFMAs.  The waits below are counted (LDS returns in order) and carry the fragment registers as "+v"
+  // operands, so no MFMA that consumes them can be scheduled above the wait (cdna guide §5.4 rule 18).
+  const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((w_lptr_t)lds));
+  auto load_frags = [&](w_u32x4_t (&fw)[4], w_u32x4_t (&fx)[5], int buf, int ks) {
+    const uint32_t tW = lds_base + buf * wStageBytes;
+    const uint32_t tX = tW + wWBytes;
+    const int chunk = ks * 4 + fq;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      asm volatile("ds_read_b128 %0, %1" : "=v"(fw[t]) : "v"(tW + w_swz(wn * 64 + t * 16 + frow, chunk)));
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+      asm volatile("ds_read_b128 %0, %1" : "=v"(fx[t]) : "v"(tX + w_swz(wm * 80 + t * 16 + frow, chunk)));
+  };
+#define W_WAIT_FRAGS(cnt, fw, fx)                                                                              \
+  asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                                   \
+               : "+v"(fw[0]), "+v"(fw[1]), "+v"(fw[2]), "+v"(fw[3]), "+v"(fx[0]), "+v"(fx[1]), "+v"(fx[2]),    \
+                 "+v"(fx[3]), "+v"(fx[4])::"memory")
+
   set_issue_tile(0);
   issue_next();
   issue_next();
+  issue_next();
+  // stage 0 landed (two younger stages may fly), visible to everyone
+  if (issued >= 3) {
+    if (three) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
 
   int consumed = 0, cur = 0;
   for (int ti = 0; ti < my_tiles; ++ti) {
@@ -125,50 +164,100 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
 #pragma unroll
       for (int b = 0; b < 5; ++b) acc[a][b] = w_f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    w_u32x4_t f0w[4], f0x[5], f1w[4], f1x[5];
+    load_frags(f0w, f0x, cur, 0);
+
+    auto mma = [&](const w_u32x4_t (&fw)[4], const w_u32x4_t (&fx)[5]) {
+      if constexpr (F32) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 5; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fw[a][s]), __uint_as_float(fx[b][s]),
+                                                               acc[a][b], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 5; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(w_bf16x8_t, fw[a]),
+                                                                __builtin_bit_cast(w_bf16x8_t, fx[b]), acc[a][b], 0, 0, 0);
+      }
+    };
+
     for (int kt = 0; kt < nk; ++kt) {
-      // stage `consumed` must have landed; at most ONE younger stage may stay in flight.  (Epilogue stores of the
-      // previous tile are younger than both stages: the counted wait then also retires the DMAs - safe.)
-      if (issued - consumed > 1) {
+      load_frags(f1w, f1x, cur, 1);                                   // 1
+      W_WAIT_FRAGS(9, f0w, f0x);                                      //    F0 (older than the 9 F1 reads) is in registers
+      __builtin_amdgcn_sched_barrier(0);
+      mma(f0w, f0x);                                                  // 2
+      __builtin_amdgcn_sched_barrier(0);
+      // 3: own LDS reads done; stage consumed+1 landed, at most one younger stage still in flight.  (Epilogue stores of
+      //    a previous tile are younger than the DMAs: the counted wait then retires the DMAs as well - safe.)
+      W_WAIT_FRAGS(0, f1w, f1x);
+      if (issued - consumed > 2) {
         if (three) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      __builtin_amdgcn_s_barrier();   // stage visible to all waves; every wave is done with stage consumed-1
-      issue_next();                   // refills the buffer that stage consumed-1 occupied
-      const char* tW = lds + cur * wStageBytes;
-      const char* tX = tW + wWBytes;
+      __builtin_amdgcn_s_barrier();
+      // 4-6 interleaved: one DMA piece / one fragment read between groups of 3 MFMAs.  Issued as one burst, the 52
+      // pieces of a stage queue up in the CU's address path (~16 clk each) and every wave sits in a VMEM issue stall
+      // while the matrix pipe idles; trickled in, they ride under the MFMAs.
+      const int nxt = cur == 2 ? 0 : cur + 1;
+      {
+        const bool do_issue = issued < total_steps;
+        char* ibase = lds + issue_buf * wStageBytes;
+        const size_t koff = static_cast<size_t>(issue_kt) * wRowBytes;
+        const bool pref = kt + 1 < nk;
+        const uint32_t nW = lds_base + nxt * wStageBytes, nX = nW + wWBytes;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int chunk = ks * 4 + fq;
-        w_u32x4_t fw[4], fx[5];
+        for (int i = 0; i < 20; ++i) {
+          if (i % 3 == 0 && do_issue) {
+            const int p = i / 3;
+            if (p < 4)
+              __builtin_amdgcn_global_load_lds((w_gptr_t)(gW[p] + koff), (w_lptr_t)(ibase + (wid * 4 + p) * 1024), 16, 0, 0);
+            else if (p < 6)
+              __builtin_amdgcn_global_load_lds((w_gptr_t)(gX[p - 4] + koff),
+                                               (w_lptr_t)(ibase + wWBytes + (wid + 8 * (p - 4)) * 1024), 16, 0, 0);
+            else if (three)
+              __builtin_amdgcn_global_load_lds((w_gptr_t)(gX[2] + koff), (w_lptr_t)(ibase + wWBytes + (wid + 16) * 1024), 16, 0, 0);
+          }
+          if (pref && i >= 1 && i <= 9) {
+            const int t = i - 1;
+            if (t < 4)
+              asm volatile("ds_read_b128 %0, %1" : "=v"(f0w[t]) : "v"(nW + w_swz(wn * 64 + t * 16 + frow, fq)));
+            else
+              asm volatile("ds_read_b128 %0, %1" : "=v"(f0x[t - 4]) : "v"(nX + w_swz(wm * 80 + (t - 4) * 16 + frow, fq)));
+          }
+          const int a = i / 5, b = i % 5;
+          if constexpr (F32) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-          fw[t] = *reinterpret_cast<const w_u32x4_t*>(tW + w_swz(wn * 64 + t * 16 + frow, chunk));
-#pragma unroll
-        for (int t = 0; t < 5; ++t)
-          fx[t] = *reinterpret_cast<const w_u32x4_t*>(tX + w_swz(wm * 80 + t * 16 + frow, chunk));
-        if constexpr (F32) {
-#pragma unroll
-          for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-              for (int b = 0; b < 5; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fw[a][s]), __uint_as_float(fx[b][s]),
-                                                                 acc[a][b], 0, 0, 0);
-        } else {
-#pragma unroll
-          for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 5; ++b)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(w_bf16x8_t, fw[a]),
-                                                                  __builtin_bit_cast(w_bf16x8_t, fx[b]), acc[a][b], 0, 0, 0);
+            for (int s = 0; s < 4; ++s)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(f1w[a][s]), __uint_as_float(f1x[b][s]),
+                                                               acc[a][b], 0, 0, 0);
+          } else {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(w_bf16x8_t, f1w[a]),
+                                                                __builtin_bit_cast(w_bf16x8_t, f1x[b]), acc[a][b], 0, 0, 0);
+          }
+          if (i % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (do_issue) {
+          ++issued;
+          issue_buf = issue_buf == 2 ? 0 : issue_buf + 1;
+          if (++issue_kt == nk) {
+            issue_kt = 0;
+            if (++issue_tile < my_tiles) set_issue_tile(issue_tile);
+          }
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
       ++consumed;
-      cur = cur == 2 ? 0 : cur + 1;
+      cur = nxt;
     }
+
 
     // ---- epilogue of tile ti (the next tile's first two stages are already in flight) -----------------------
     const int logical = range_lo + slot + ti * per_xcd_blocks;
@@ -208,22 +297,41 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
 #pragma unroll
         for (int b = 0; b < 5; ++b) acc[a][b] += rv[a][b];
     }
+    // Stores.  Row-scattered 8-byte stores are issue-bound (measured: ~5.5 us per tile, i.e. as much as 5 K-steps),
+    // so the bf16 path first widens them: v_permlane16_swap exchanges, between the lane pairs (l, l+16), the packed
+    // words of two neighbouring n-tiles, after which an even lane-row owns 8 consecutive n of tile a and an odd
+    // lane-row 8 consecutive n of tile a+1 -> one 16-byte store per lane, half the store instructions.
+    if (epi & EPI_OUT_BF16) {
+      const int col = n0 + wn * 64 + (fq & 1) * 16 + (fq & 2) * 4;    // + 32*pair
 #pragma unroll
-    for (int b = 0; b < 5; ++b) {
-      const int m = m0 + wm * 80 + b * 16 + frow;
-      if (m >= M) continue;
+      for (int b = 0; b < 5; ++b) {
+        const int m = m0 + wm * 80 + b * 16 + frow;
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const int n = n0 + wn * 64 + a * 16 + fq * 4;
-        const w_f32x4_t v = acc[a][b];
-        const size_t o = static_cast<size_t>(m) * N + n;
-        if (epi & EPI_OUT_BF16) {
-          uint2 pk;
-          pk.x = static_cast<uint32_t>(f32_to_bf16(v[0])) | (static_cast<uint32_t>(f32_to_bf16(v[1])) << 16);
-          pk.y = static_cast<uint32_t>(f32_to_bf16(v[2])) | (static_cast<uint32_t>(f32_to_bf16(v[3])) << 16);
-          *reinterpret_cast<uint2*>(static_cast<bf16_t*>(out) + o) = pk;
-        } else {
-          *reinterpret_cast<w_f32x4_t*>(static_cast<float*>(out) + o) = v;
+        for (int pr = 0; pr < 2; ++pr) {
+          uint32_t lo[2], hi[2];   // packed words of tiles a = 2pr (lo) and 2pr+1 (hi)
+#pragma unroll
+          for (int w = 0; w < 2; ++w) {
+            lo[w] = pack_bf16x2(acc[2 * pr][b][2 * w], acc[2 * pr][b][2 * w + 1]);
+            hi[w] = pack_bf16x2(acc[2 * pr + 1][b][2 * w], acc[2 * pr + 1][b][2 * w + 1]);
+          }
+          typedef __attribute__((ext_vector_type(2))) unsigned w_u2_t;
+          const w_u2_t s0 = __builtin_amdgcn_permlane16_swap(lo[0], hi[0], false, false);
+          const w_u2_t s1 = __builtin_amdgcn_permlane16_swap(lo[1], hi[1], false, false);
+          w_u32x4_t pk;
+          pk[0] = s0[0]; pk[1] = s1[0]; pk[2] = s0[1]; pk[3] = s1[1];
+          if (m < M && !(epi & 256))   // 256 = timing-only ablation: skip stores
+            *reinterpret_cast<w_u32x4_t*>(static_cast<bf16_t*>(out) + static_cast<size_t>(m) * N + col + 32 * pr) = pk;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {
+        const int m = m0 + wm * 80 + b * 16 + frow;
+        if (m >= M || (epi & 256)) continue;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int n = n0 + wn * 64 + a * 16 + fq * 4;
+          *reinterpret_cast<w_f32x4_t*>(static_cast<float*>(out) + static_cast<size_t>(m) * N + n) = acc[a][b];
         }
       }
     }
