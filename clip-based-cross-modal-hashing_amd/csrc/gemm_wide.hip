@@ -157,6 +157,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   __builtin_amdgcn_s_barrier();
 
   int consumed = 0, cur = 0;
+  int since_epi = 2, epi_stores = 0;   // K-steps since the last epilogue / store instructions it issued per wave
   for (int ti = 0; ti < my_tiles; ++ti) {
     w_f32x4_t acc[4][5];   // [n-tile][m-tile]
 #pragma unroll
@@ -196,11 +197,24 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
       // 3: own LDS reads done; stage consumed+1 landed, at most one younger stage still in flight.  (Epilogue stores of
       //    a previous tile are younger than the DMAs: the counted wait then retires the DMAs as well - safe.)
       W_WAIT_FRAGS(0, f1w, f1x);
-      if (issued - consumed > 2) {
-        if (three) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      {
+        // vmcnt is ONE in-order queue of loads, stores and LDS-DMA.  Younger than the stage we need are: one more
+        // stage (P pieces) if the pipeline is still being fed, and - during the first two K-steps after an epilogue -
+        // that epilogue's S stores (the stage we need was issued before them).  Allowing exactly P+S outstanding
+        // lets the stores drain behind the MFMAs instead of stalling every wave at the barrier.
+        const int allow = (issued - consumed > 2 ? (three ? 7 : 6) : 0) + (since_epi < 2 ? epi_stores : 0);
+        ++since_epi;
+        switch (allow) {
+          case 27: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
+          case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
+          case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+          case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+          case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+          case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+          case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+          case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+          default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
       }
       __builtin_amdgcn_s_barrier();
       // 4-6 interleaved: one DMA piece / one fragment read between groups of 3 MFMAs.  Issued as one burst, the 52
@@ -335,6 +349,14 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
         }
       }
     }
+    // bookkeeping for the counted waits of the next tile's first two K-steps
+    if (m0 + wBM > M || (epi & 256)) {   // partial tile: some store instructions were skipped -> drain, count nothing
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      epi_stores = 0;
+    } else {
+      epi_stores = (epi & EPI_OUT_BF16) ? 10 : 20;
+    }
+    since_epi = 0;
   }
 }
 
