@@ -84,6 +84,10 @@ SIGNATURES = {
     "cmh_loss_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "cmh_dsph_hyp_loss": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _f, _f, _p, _p, _sz, _p]),
     "cmh_dchmt_loss": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _f, _f, _p, _p, _sz, _p]),
+    "cmh_batchnorm1d_train": (C.c_int, [_p, _p, _p, _f, _p, _i32, _i32, _p]),
+    "cmh_twdh_targets": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _p]),
+    "cmh_twdh_loss": (C.c_int, [_p, _p, _p, _i32, _i32, _p, _p, _sz, _p]),
+    "cmh_dnph_loss": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f, _f, _p, _p, _sz, _p]),
 }
 
 
@@ -338,3 +342,53 @@ def dchmt_loss(img, txt, label, output_dim, similarity="euclidean", loss_type="l
                                float(sim_threshold), ptr(out), ptr(ws), ws.numel(), stream_ptr(img.device)),
           "cmh_dchmt_loss")
     return out[0]
+
+
+# ------------------------------------------------------------------------------------------ DNPH / TwDH
+def batchnorm1d_train(x, w, b, eps=1e-5):
+    x, w, b = f32c(x), f32c(w), f32c(b)
+    require_gpu(x, w, b)
+    B, d = x.shape
+    y = torch.empty_like(x)
+    check(lib().cmh_batchnorm1d_train(ptr(x), ptr(w), ptr(b), float(eps), ptr(y), B, d, stream_ptr(x.device)),
+          "cmh_batchnorm1d_train")
+    return y
+
+
+def twdh_targets(label, center, random_center):
+    label, center, random_center = f32c(label), f32c(center), f32c(random_center)
+    require_gpu(label, center, random_center)
+    B, Cn = label.shape
+    K = center.shape[1]
+    code = torch.empty(B, K, dtype=torch.float32, device=label.device)
+    check(lib().cmh_twdh_targets(ptr(label), ptr(center), ptr(random_center), ptr(code), B, Cn, K,
+                                 stream_ptr(label.device)), "cmh_twdh_targets")
+    return code
+
+
+def twdh_loss(p_img, p_txt, target):
+    """-> (nce, quan) 0-dim tensors for one code length."""
+    p_img, p_txt, target = f32c(p_img), f32c(p_txt), f32c(target)
+    require_gpu(p_img, p_txt, target)
+    B, K = target.shape
+    out = torch.empty(2, dtype=torch.float32, device=p_img.device)
+    ws = workspace(256, p_img.device, "loss")
+    check(lib().cmh_twdh_loss(ptr(p_img), ptr(p_txt), ptr(target), B, K, ptr(out), ptr(ws), ws.numel(),
+                              stream_ptr(p_img.device)), "cmh_twdh_loss")
+    return out[0], out[1]
+
+
+def dnph_loss(hash_img, hash_txt, pre_img, pre_txt, label, proxies, noise_img=None, noise_txt=None, margin=1.0,
+              noise_weight=0.1):
+    """-> (loss, p_loss + d_loss, noise) 0-dim tensors."""
+    ts = [f32c(t) for t in (hash_img, hash_txt, pre_img, pre_txt, label, proxies)]
+    ni = None if noise_img is None else f32c(noise_img)
+    nt = None if noise_txt is None else f32c(noise_txt)
+    require_gpu(*ts, ni, nt)
+    B, K = ts[0].shape
+    Cn = ts[4].shape[1]
+    out = torch.empty(3, dtype=torch.float32, device=ts[0].device)
+    ws = workspace(256, ts[0].device, "loss")
+    check(lib().cmh_dnph_loss(*[ptr(t) for t in ts], ptr(ni), ptr(nt), B, K, Cn, float(margin), float(noise_weight),
+                              ptr(out), ptr(ws), ws.numel(), stream_ptr(ts[0].device)), "cmh_dnph_loss")
+    return out[0], out[1], out[2]

@@ -9,8 +9,10 @@ from argsbase import str2bool
 _REGISTRY = {
     'DSPH': ("train.DSPH.hash_train", "DSPHTrainer"),
     'DCHMT': ("train.DCHMT.hash_train", "DCHMTTrainer"),
+    'TwDH': ("train.TwDH.hash_train", "TwDHTrainer"),
+    'DNPH': ("train.DNPH_TOMM.hash_train", "DNPHTOMMTrainer"),
 }
-_NOT_BUILT = ['TwDH', 'MITH', 'DNPH', 'DHaPH', 'DMsH_LN', 'DNpH', 'DPBE', 'DDWSH', 'DDBH', 'DScPH', 'DPSIH', 'DGHDGH']
+_NOT_BUILT = ['MITH', 'DHaPH', 'DMsH_LN', 'DNpH', 'DPBE', 'DDWSH', 'DDBH', 'DScPH', 'DPSIH', 'DGHDGH']
 
 
 class _LazyTrainers(dict):

@@ -241,6 +241,35 @@ int cmh_dchmt_loss(const float* img, const float* txt, const float* label, int32
                    float vartheta, float sim_threshold, float* loss, void* workspace,
                    size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * DNPH (TOMM) and TwDH heads / losses (BASELINE.json configs 4 and 5).
+ * ------------------------------------------------------------------------------------------- */
+/* nn.BatchNorm1d in TRAINING mode (batch mean, biased batch variance): the TwDH image head's `norm`
+ * (model/TwDH.py:61,78), which the reference never switches to eval.  x,y f32 [B,d]. */
+int cmh_batchnorm1d_train(const float* x, const float* w, const float* b, float eps, float* y, int32_t B,
+                          int32_t d, void* stream);
+
+/* hash_center_multilables (train/TwDH/hash_train.py:93-115): code[b,k] = sign(mean of the centers of b's
+ * classes), exact zeros replaced by random_center[k] (a +-1 vector drawn once per call by the caller).
+ * label f32 [B,C], center f32 [C,K] (+-1), code f32 [B,K]. */
+int cmh_twdh_targets(const float* label, const float* center, const float* random_center, float* code,
+                     int32_t B, int32_t C, int32_t K, void* stream);
+
+/* TwDH loss terms for one code length (train/TwDH/hash_train.py:117-139): p_img/p_txt f32 [B,2K] pair
+ * probabilities, target f32 [B,K] in {-1,+1}.  out2[0] = (BCE_img + BCE_txt)/2 with hash_convert one-hot
+ * targets, out2[1] = ((1-mean((2p_img-1)^2)) + (1-mean((2p_txt-1)^2)))/2.  workspace >= 256 bytes. */
+int cmh_twdh_loss(const float* p_img, const float* p_txt, const float* target, int32_t B, int32_t K,
+                  float* out2, void* workspace, size_t workspace_bytes, void* stream);
+
+/* DNPH_out.forward + the noise term of the DNPH step (train/DNPH_TOMM/loss.py:14-32,
+ * train/DNPH_TOMM/hash_train.py:70-81).  hash_* f32 [B,K], pre_* f32 [B,C], label f32 [B,C], proxies [C,K],
+ * noise_* f32 [B,K] (the Hungarian-assigned +-1 rows, host-side as upstream) or both NULL.
+ * out3[0] = p_loss + d_loss - noise_weight*noise, out3[1] = p_loss + d_loss, out3[2] = noise. */
+int cmh_dnph_loss(const float* hash_img, const float* hash_txt, const float* pre_img, const float* pre_txt,
+                  const float* label, const float* proxies, const float* noise_img, const float* noise_txt,
+                  int32_t B, int32_t K, int32_t C, float margin, float noise_weight, float* out3,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
