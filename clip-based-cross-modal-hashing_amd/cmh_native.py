@@ -88,6 +88,18 @@ SIGNATURES = {
     "cmh_twdh_targets": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _p]),
     "cmh_twdh_loss": (C.c_int, [_p, _p, _p, _i32, _i32, _p, _p, _sz, _p]),
     "cmh_dnph_loss": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f, _f, _p, _p, _sz, _p]),
+    "cmh_vit_encode_tokens": (C.c_int, [C.POINTER(VitWeights), _p, _i32, _p, _p, _sz, _p]),
+    "cmh_text_encode_tokens": (C.c_int, [C.POINTER(TextWeights), _p, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
+    "cmh_blocks_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "cmh_transformer_blocks": (C.c_int, [C.POINTER(BlockWeights), _i32, _i32, _p, _i32, _i32, _i32, _i32, _p, _p, _sz, _p]),
+    "cmh_mith_lta": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    "cmh_add_positional": (C.c_int, [_p, _p, _i32, _i32, _i32, _p]),
+    "cmh_bitwise_hash": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _p]),
+    "cmh_l2_normalize_rows": (C.c_int, [_p, _p, _i32, _i32, _p]),
+    "cmh_mith_mix": (C.c_int, [_p, _p, _p, _p, _f, _p, _p, _p, _i64, _p]),
+    "cmh_sq_diff_sum": (C.c_int, [_p, _p, _i64, _p, _p, _sz, _p]),
+    "cmh_mith_bayesian_loss": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _sz, _p]),
+    "cmh_info_nce": (C.c_int, [_p, _p, _i32, _i32, _i32, _f, _p, _p, _sz, _p]),
 }
 
 

@@ -57,8 +57,12 @@ enum : int {
   EPI_BIAS = 1,       // + bias[n]
   EPI_QUICKGELU = 2,  // x * sigmoid(1.702 x)      (model/base/model.py:162-164)
   EPI_RESIDUAL = 4,   // + residual[m,n] (f32)
-  EPI_OUT_BF16 = 8    // store bf16 instead of f32
+  EPI_OUT_BF16 = 8,   // store bf16 instead of f32
+  EPI_GELU = 16,      // exact GELU 0.5 x (1 + erf(x/sqrt 2))  (nn.GELU(), MITH ResidualMLPs model/MITH.py:224-233)
+  EPI_RELU = 32       // max(x, 0)
 };
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
 
 // C[M,N] = epilogue(A[M,K] . W[N,K]^T).  A/W dtype = dt (f32 or bf16); residual f32; out f32|bf16.
 int launch_gemm(int dt, const void* A, const void* W, const float* bias, const float* residual,

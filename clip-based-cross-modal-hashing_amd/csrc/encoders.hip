@@ -115,9 +115,9 @@ extern "C" size_t cmh_vit_workspace_bytes(const cmh_vit_weights* w, int32_t batc
   return carve(nullptr, B * T, B, d, e, B * g2 * d * 4, B * g2 * pk * e).total;
 }
 
-extern "C" int cmh_vit_encode(const cmh_vit_weights* w, const float* image, int32_t batch, float* feat,
-                              void* workspace, size_t workspace_bytes, const cmh_taps* taps, void* stream) {
-  CMH_CHECK_ARG(w && image && feat && workspace, "vit_encode: null pointer");
+static int vit_encode_impl(const cmh_vit_weights* w, const float* image, int32_t batch, float* feat, float* tokens_out,
+                           void* workspace, size_t workspace_bytes, const cmh_taps* taps, void* stream) {
+  CMH_CHECK_ARG(w && image && (feat || tokens_out) && workspace, "vit_encode: null pointer");
   CMH_CHECK_ARG(batch > 0, "vit_encode: batch %d", batch);
   int rc = check_tower(w->gemm_dtype, w->width, w->layers, w->embed_dim, w->blocks);
   if (rc) return rc;
@@ -148,10 +148,30 @@ extern "C" int cmh_vit_encode(const cmh_vit_weights* w, const float* image, int3
     if ((rc = run_block(w->blocks[i], dt, t, B, T, d, /*causal=*/0, nullptr, st))) return rc;
     if ((rc = tap(taps, 1 + i, t.x, static_cast<size_t>(M) * d * 4, st))) return rc;
   }
-  // ln_post on the class token, @ proj  (:247-250)
-  if ((rc = launch_iota_rows(t.rows, B, T, st))) return rc;
-  if ((rc = launch_layernorm(t.x, t.rows, w->ln_post_w, w->ln_post_b, t.pool, dt == CMH_BF16, B, d, st))) return rc;
-  return final_projection(dt, t.pool, w->proj_t, feat, B, w->embed_dim, d, st);
+  if (tokens_out) {
+    // MITH trunk (model/MITH.py:70-80): ln_post and proj on EVERY token
+    if ((rc = launch_layernorm(t.x, nullptr, w->ln_post_w, w->ln_post_b, t.h, dt == CMH_BF16, M, d, st))) return rc;
+    if ((rc = final_projection(dt, t.h, w->proj_t, tokens_out, M, w->embed_dim, d, st))) return rc;
+  }
+  if (feat) {
+    // ln_post on the class token, @ proj  (:247-250)
+    if ((rc = launch_iota_rows(t.rows, B, T, st))) return rc;
+    if ((rc = launch_layernorm(t.x, t.rows, w->ln_post_w, w->ln_post_b, t.pool, dt == CMH_BF16, B, d, st))) return rc;
+    if ((rc = final_projection(dt, t.pool, w->proj_t, feat, B, w->embed_dim, d, st))) return rc;
+  }
+  return CMH_OK;
+}
+
+extern "C" int cmh_vit_encode(const cmh_vit_weights* w, const float* image, int32_t batch, float* feat,
+                              void* workspace, size_t workspace_bytes, const cmh_taps* taps, void* stream) {
+  CMH_CHECK_ARG(feat, "vit_encode: null pointer");
+  return vit_encode_impl(w, image, batch, feat, nullptr, workspace, workspace_bytes, taps, stream);
+}
+
+extern "C" int cmh_vit_encode_tokens(const cmh_vit_weights* w, const float* image, int32_t batch, float* tokens_out,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  CMH_CHECK_ARG(tokens_out, "vit_encode_tokens: null pointer");
+  return vit_encode_impl(w, image, batch, nullptr, tokens_out, workspace, workspace_bytes, nullptr, stream);
 }
 
 extern "C" size_t cmh_text_workspace_bytes(const cmh_text_weights* w, int32_t batch, int32_t seq_len) {
@@ -160,10 +180,10 @@ extern "C" size_t cmh_text_workspace_bytes(const cmh_text_weights* w, int32_t ba
   return carve(nullptr, static_cast<size_t>(batch) * seq_len, batch, w->width, e, 0, 0).total;
 }
 
-extern "C" int cmh_text_encode(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
-                               const uint8_t* key_padding_mask, float* feat, void* workspace,
-                               size_t workspace_bytes, const cmh_taps* taps, void* stream) {
-  CMH_CHECK_ARG(w && tokens && feat && workspace, "text_encode: null pointer");
+static int text_encode_impl(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
+                            const uint8_t* key_padding_mask, float* feat, float* tokens_out, int32_t* eot_rows_out,
+                            void* workspace, size_t workspace_bytes, const cmh_taps* taps, void* stream) {
+  CMH_CHECK_ARG(w && tokens && (feat || tokens_out) && workspace, "text_encode: null pointer");
   CMH_CHECK_ARG(batch > 0 && seq_len > 0, "text_encode: batch %d seq_len %d", batch, seq_len);
   int rc = check_tower(w->gemm_dtype, w->width, w->layers, w->embed_dim, w->blocks);
   if (rc) return rc;
@@ -183,9 +203,60 @@ extern "C" int cmh_text_encode(const cmh_text_weights* w, const int64_t* tokens,
     if ((rc = run_block(w->blocks[i], dt, t, B, L, d, /*causal=*/1, key_padding_mask, st))) return rc;
     if ((rc = tap(taps, 1 + i, t.x, static_cast<size_t>(M) * d * 4, st))) return rc;
   }
-  // ln_final (row-wise, so only the pooled rows are normalised), @ text_projection  (:366-370)
-  if ((rc = launch_layernorm(t.x, t.rows, w->ln_final_w, w->ln_final_b, t.pool, dt == CMH_BF16, B, d, st))) return rc;
-  return final_projection(dt, t.pool, w->text_projection_t, feat, B, w->embed_dim, d, st);
+  if (tokens_out) {
+    // MITH trunk (model/MITH.py:136-139): ln_final and text_projection on EVERY token
+    if ((rc = launch_layernorm(t.x, nullptr, w->ln_final_w, w->ln_final_b, t.h, dt == CMH_BF16, M, d, st))) return rc;
+    if ((rc = final_projection(dt, t.h, w->text_projection_t, tokens_out, M, w->embed_dim, d, st))) return rc;
+  }
+  if (eot_rows_out &&
+      hipMemcpyAsync(eot_rows_out, t.rows, static_cast<size_t>(B) * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return fail(CMH_ERR_LAUNCH, "text_encode: eot row copy failed");
+  if (feat) {
+    // ln_final (row-wise, so only the pooled rows are normalised), @ text_projection  (:366-370)
+    if ((rc = launch_layernorm(t.x, t.rows, w->ln_final_w, w->ln_final_b, t.pool, dt == CMH_BF16, B, d, st))) return rc;
+    if ((rc = final_projection(dt, t.pool, w->text_projection_t, feat, B, w->embed_dim, d, st))) return rc;
+  }
+  return CMH_OK;
+}
+
+extern "C" int cmh_text_encode(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
+                               const uint8_t* key_padding_mask, float* feat, void* workspace,
+                               size_t workspace_bytes, const cmh_taps* taps, void* stream) {
+  CMH_CHECK_ARG(feat, "text_encode: null pointer");
+  return text_encode_impl(w, tokens, batch, seq_len, key_padding_mask, feat, nullptr, nullptr, workspace,
+                          workspace_bytes, taps, stream);
+}
+
+extern "C" int cmh_text_encode_tokens(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
+                                      const uint8_t* key_padding_mask, float* tokens_out, int32_t* eot_rows_out,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  CMH_CHECK_ARG(tokens_out, "text_encode_tokens: null pointer");
+  return text_encode_impl(w, tokens, batch, seq_len, key_padding_mask, nullptr, tokens_out, eot_rows_out, workspace,
+                          workspace_bytes, nullptr, stream);
+}
+
+// A stack of ResidualAttentionBlocks on a caller-owned f32 residual stream x [B*T, d] (in place): the 2-layer
+// concept transformer of MITH's LocalConceptTransforming (model/MITH.py:379-396 over model/MITH.py:11-46 blocks).
+extern "C" size_t cmh_blocks_workspace_bytes(int32_t dtype, int32_t B, int32_t T, int32_t d) {
+  if (B <= 0 || T <= 0 || d <= 0) return 0;
+  return carve(nullptr, static_cast<size_t>(B) * T, B, d, dtype == CMH_BF16 ? 2 : 4, 0, 0).total;
+}
+
+extern "C" int cmh_transformer_blocks(const cmh_block_weights* blocks, int32_t layers, int32_t dtype, float* x, int32_t B,
+                                      int32_t T, int32_t d, int32_t causal, const uint8_t* key_padding_mask,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  CMH_CHECK_ARG(blocks && x && workspace && layers > 0 && B > 0 && T > 0, "transformer_blocks: bad arguments");
+  int rc = check_tower(dtype, d, layers, 4, blocks);
+  if (rc) return rc;
+  if (workspace_bytes < cmh_blocks_workspace_bytes(dtype, B, T, d)) return fail(CMH_ERR_WORKSPACE, "transformer_blocks: workspace too small");
+  hipStream_t st = as_stream(stream);
+  const size_t M = static_cast<size_t>(B) * T;
+  TowerBufs t = carve(workspace, M, B, d, dtype == CMH_BF16 ? 2 : 4, 0, 0);
+  if (hipMemcpyAsync(t.x, x, M * d * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(CMH_ERR_LAUNCH, "transformer_blocks: copy failed");
+  for (int i = 0; i < layers; ++i)
+    if ((rc = run_block(blocks[i], dtype, t, B, T, d, causal, key_padding_mask, st))) return rc;
+  if (hipMemcpyAsync(x, t.x, M * d * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(CMH_ERR_LAUNCH, "transformer_blocks: copy failed");
+  return CMH_OK;
 }
 
 extern "C" int cmh_linear_gemm(int32_t dtype, const void* x, const void* w, const float* bias, const float* residual,

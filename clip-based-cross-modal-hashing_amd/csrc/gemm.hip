@@ -174,6 +174,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const char* __restrict__ X, c
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = quick_gelu(v[j]);
       }
+      if (epi & (EPI_GELU | EPI_RELU)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (epi & EPI_GELU) ? gelu_erf(v[j]) : fmaxf(v[j], 0.f);
+      }
       const size_t o = static_cast<size_t>(m) * N + n;
       if (epi & EPI_RESIDUAL) {
         const f32x4_t rv = *reinterpret_cast<const f32x4_t*>(residual + o);

@@ -151,6 +151,10 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const char* __restrict__
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = g_quick_gelu(v[j]);
       }
+      if (epi & (EPI_GELU | EPI_RELU)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (epi & EPI_GELU) ? gelu_erf(v[j]) : fmaxf(v[j], 0.f);
+      }
       const size_t o = static_cast<size_t>(m) * N + n;
       if (epi & EPI_RESIDUAL) v += *reinterpret_cast<const g_f32x4_t*>(residual + o);
       if (epi & EPI_OUT_BF16) {

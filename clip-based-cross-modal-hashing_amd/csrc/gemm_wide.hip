@@ -296,6 +296,15 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[a][b][j] = w_quick_gelu(acc[a][b][j]);
     }
+    if (epi & (EPI_GELU | EPI_RELU)) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 5; ++b)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[a][b][j] = (epi & EPI_GELU) ? gelu_erf(acc[a][b][j]) : fmaxf(acc[a][b][j], 0.f);
+    }
     if (epi & EPI_RESIDUAL) {
       w_f32x4_t rv[4][5];
 #pragma unroll

@@ -1,0 +1,335 @@
+// MITH (config 3): the pieces of HashingModel and of the MITH losses that are not plain GEMM / LayerNorm / attention.
+//   LocalizedTokenAggregation   model/MITH.py:317-376   (positive-only, per-token top-k over concepts, softmax over tokens, bmm)
+//   PositionalEncoding add      model/MITH.py:249-273
+//   BitwiseHashing              model/MITH.py:276-293   (K x Linear(512,1) + tanh)
+//   F.normalize                 model/MITH.py:442-443,450-451
+//   losses                      train/MITH/hash_train.py:80-83,103-147,168-201 (bayesian vs memory bank, InfoNCE,
+//                               token-level InfoNCE, quantisation / distillation squared errors, B = sign(mix))
+// Activations are batch-major ([N, K, D] where the reference holds [K, N, D]); values are identical.
+#include "cmh_common.h"
+
+namespace cmh {
+
+__device__ __forceinline__ float m_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double m_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float m_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double m_block_sum(double v, double* sh) {
+  v = m_wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wid] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < static_cast<int>(blockDim.x >> 6); ++w) t += sh[w];
+  return t;
+}
+
+constexpr int kLtaMaxL = 80;     // tokens per sample (49 patches / <= 77 words)
+constexpr int kLtaMaxK = 128;    // concepts (= hash bits)
+constexpr int kTop = 8;          // compile-time bound of top_k_label (reference default 8)
+constexpr float kNegInf = -__builtin_huge_valf();
+
+// One workgroup per sample.  sim rows [row0 + l] (l < L) of a [B*Ltot, K] matrix, tokens rows likewise of [B*Ltot, D].
+__global__ __launch_bounds__(256) void lta_kernel(const float* __restrict__ tokens, const float* __restrict__ sim,
+                                                  const uint8_t* __restrict__ kpm, float* __restrict__ out, int Ltot,
+                                                  int l0, int L, int K, int D, int top_k) {
+  __shared__ float w[kLtaMaxL][kLtaMaxK + 1];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const size_t row0 = static_cast<size_t>(b) * Ltot + l0;
+  // 1. load, key-padding -> -inf, non-positive -> -inf   (:350-361)
+  for (int i = tid; i < L * K; i += 256) {
+    const int l = i / K, k = i - l * K;
+    float v = sim[(row0 + l) * K + k];
+    if (kpm && kpm[static_cast<size_t>(b) * L + l]) v = kNegInf;
+    w[l][k] = v > 0.f ? v : kNegInf;
+  }
+  __syncthreads();
+  // 2. per token: keep entries >= the top_k-th largest value (ties keep more, like torch.ge against min(topk))  (:322-333)
+  if (tid < L) {
+    float top[kTop];
+#pragma unroll
+    for (int j = 0; j < kTop; ++j) top[j] = kNegInf;
+    for (int k = 0; k < K; ++k) {
+      float v = w[tid][k];
+      if (v > top[kTop - 1]) {
+        top[kTop - 1] = v;
+#pragma unroll
+        for (int j = kTop - 1; j > 0; --j)
+          if (top[j] > top[j - 1]) { const float t = top[j]; top[j] = top[j - 1]; top[j - 1] = t; }
+      }
+    }
+    // the top_k-th largest with multiplicity sits at index top_k-1 once at least top_k finite values were seen;
+    // with fewer positives it is -inf and everything is kept
+    float vmin = kNegInf;
+#pragma unroll
+    for (int j = 0; j < kTop; ++j)
+      if (j == top_k - 1) vmin = top[j];
+    for (int k = 0; k < K; ++k)
+      if (!(w[tid][k] >= vmin)) w[tid][k] = kNegInf;
+  }
+  __syncthreads();
+  // 3. softmax over the tokens for every concept; an all -inf column gives NaN upstream, replaced by 0  (:364-366)
+  if (tid < K) {
+    float m = kNegInf;
+    for (int l = 0; l < L; ++l) m = fmaxf(m, w[l][tid]);
+    if (m == kNegInf) {
+      for (int l = 0; l < L; ++l) w[l][tid] = 0.f;
+    } else {
+      float s = 0.f;
+      for (int l = 0; l < L; ++l) {
+        const float e = expf(w[l][tid] - m);
+        w[l][tid] = e;
+        s += e;
+      }
+      const float inv = 1.0f / s;
+      for (int l = 0; l < L; ++l) w[l][tid] *= inv;
+    }
+  }
+  __syncthreads();
+  // 4. merge[b,k,:] = sum_l w[l,k] * tokens[b,l,:]   (:370-375)
+  for (int d = tid; d < D; d += 256) {
+    float acc[kLtaMaxK];
+#pragma unroll
+    for (int k = 0; k < kLtaMaxK; ++k) acc[k] = 0.f;
+    for (int l = 0; l < L; ++l) {
+      const float xv = tokens[(row0 + l) * D + d];
+#pragma unroll
+      for (int k = 0; k < kLtaMaxK; ++k)
+        if (k < K) acc[k] = fmaf(w[l][k], xv, acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < kLtaMaxK; ++k)
+      if (k < K) out[(static_cast<size_t>(b) * K + k) * D + d] = acc[k];
+  }
+}
+
+__global__ __launch_bounds__(256) void add_pos_kernel(float* __restrict__ x, const float* __restrict__ pe, int64_t n, int T,
+                                                      int D) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int d = static_cast<int>(i % D);
+  const int t = static_cast<int>((i / D) % T);
+  x[i] += pe[static_cast<size_t>(t) * D + d];
+}
+
+// out[b,k] = tanh(x[b,k,:] . w[k,:] + bias[k]); one wave per (b,k)
+__global__ __launch_bounds__(256) void bitwise_hash_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           int B, int K, int D) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= B * K) return;
+  const int k = i % K;
+  const float* xr = x + static_cast<size_t>(i) * D;
+  const float* wr = w + static_cast<size_t>(k) * D;
+  float s = 0.f;
+  for (int d = lane * 4; d < D; d += 256) {
+    const float4 a = *reinterpret_cast<const float4*>(xr + d);
+    const float4 c = *reinterpret_cast<const float4*>(wr + d);
+    s = fmaf(a.x, c.x, s); s = fmaf(a.y, c.y, s); s = fmaf(a.z, c.z, s); s = fmaf(a.w, c.w, s);
+  }
+  s = m_wave_sum(s);
+  if (lane == 0) out[i] = tanhf(s + bias[k]);
+}
+
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int R, int D) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  float ss = 0.f;
+  for (int d = lane; d < D; d += 64) { const float v = x[static_cast<size_t>(r) * D + d]; ss = fmaf(v, v, ss); }
+  const float inv = 1.0f / fmaxf(sqrtf(m_wave_sum(ss)), 1e-12f);
+  for (int d = lane; d < D; d += 64) y[static_cast<size_t>(r) * D + d] = x[static_cast<size_t>(r) * D + d] * inv;
+}
+
+// B = sign(lambda*(ic + tc) + (1-lambda)*(it + tt)); Hi = .5 ic + .5 it; Ht = .5 tc + .5 tt   (hash_train.py:80-83,179-180)
+__global__ __launch_bounds__(256) void mith_mix_kernel(const float* __restrict__ ic, const float* __restrict__ it,
+                                                       const float* __restrict__ tc, const float* __restrict__ tt,
+                                                       float lam, float* __restrict__ Bc, float* __restrict__ Hi,
+                                                       float* __restrict__ Ht, int64_t n) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = (ic[i] * lam + it[i] * (1.f - lam)) + (tc[i] * lam + tt[i] * (1.f - lam));
+  Bc[i] = v > 0.f ? 1.f : (v < 0.f ? -1.f : v);
+  Hi[i] = ic[i] * 0.5f + it[i] * 0.5f;
+  Ht[i] = tc[i] * 0.5f + tt[i] * 0.5f;
+}
+
+// acc[slot] += sum (a-b)^2
+__global__ __launch_bounds__(256) void sq_diff_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+                                                      double* __restrict__ acc) {
+  __shared__ double sh[4];
+  double v = 0.0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const double d = static_cast<double>(a[i]) - static_cast<double>(b[i]);
+    v += d * d;
+  }
+  const double s = m_block_sum(v, sh);
+  if (threadIdx.x == 0 && s != 0.0) atomicAdd(acc, s);
+}
+
+// bayesian_loss(bank, batch, label_sim) partial: acc += sum_{m,b} (ls*s - log(1+e^s)), s = .5*clamp(bank_m.batch_b, +-64),
+// ls = (bank_label_m . label_b > 0).  One thread per (m,b).
+__global__ __launch_bounds__(256) void bayes_kernel(const float* __restrict__ bank, const float* __restrict__ batch,
+                                                    const float* __restrict__ bank_label, const float* __restrict__ label,
+                                                    int Mb, int B, int K, int C, double* __restrict__ acc) {
+  __shared__ double sh[4];
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  double v = 0.0;
+  if (i < static_cast<int64_t>(Mb) * B) {
+    const int m = static_cast<int>(i / B), b = static_cast<int>(i - static_cast<int64_t>(m) * B);
+    float dot = 0.f;
+    for (int k = 0; k < K; ++k) dot = fmaf(bank[static_cast<size_t>(m) * K + k], batch[static_cast<size_t>(b) * K + k], dot);
+    float ll = 0.f;
+    for (int c = 0; c < C; ++c) ll = fmaf(bank_label[static_cast<size_t>(m) * C + c], label[static_cast<size_t>(b) * C + c], ll);
+    const float s = 0.5f * fminf(fmaxf(dot, -64.f), 64.f);
+    v = static_cast<double>((ll > 0.f ? s : 0.f) - logf(1.f + expf(s)));
+  }
+  const double s = m_block_sum(v, sh);
+  if (threadIdx.x == 0 && s != 0.0) atomicAdd(acc, s);
+}
+
+// Grouped row cross-entropy with diagonal targets: row i (group g = i / G, index t = i % G) scores a_i . b_j / temp against
+// the G rows j of its group; acc += logsumexp_j - score_{i,t}.  G = N: info_nce_loss; G = L: info_nce_loss_bmm.
+__global__ __launch_bounds__(256) void row_ce_kernel(const float* __restrict__ a, const float* __restrict__ b, int R, int G,
+                                                     int D, float inv_temp, double* __restrict__ acc) {
+  extern __shared__ float sa[];   // 4 waves x D
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + wid;
+  if (i >= R) return;
+  const int g0 = (i / G) * G;
+  float* ar = sa + wid * D;
+  for (int d = lane; d < D; d += 64) ar[d] = a[static_cast<size_t>(i) * D + d];
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  float mx = -1e30f, diag = 0.f;
+  // pass 1: scores for this lane's candidates (kept in registers for up to 4 candidates per lane: G <= 256) else recomputed
+  for (int j = lane; j < G; j += 64) {
+    const float* br = b + static_cast<size_t>(g0 + j) * D;
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) s = fmaf(ar[d], br[d], s);
+    s *= inv_temp;
+    mx = fmaxf(mx, s);
+    if (g0 + j == i) diag = s;
+  }
+  mx = m_wave_max(mx);
+  float se = 0.f;
+  for (int j = lane; j < G; j += 64) {
+    const float* br = b + static_cast<size_t>(g0 + j) * D;
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) s = fmaf(ar[d], br[d], s);
+    se += expf(s * inv_temp - mx);
+  }
+  se = m_wave_sum(se);
+  diag = m_wave_sum(diag);
+  if (lane == 0) atomicAdd(acc, static_cast<double>(mx + logf(se) - diag));
+}
+
+__global__ void read_acc_kernel(const double* __restrict__ acc, double scale, float* __restrict__ out) {
+  out[0] = static_cast<float>(acc[0] * scale);
+}
+
+}  // namespace cmh
+
+using namespace cmh;
+
+extern "C" int cmh_mith_lta(const float* tokens, const float* sim, const uint8_t* key_padding_mask, float* out, int32_t B,
+                            int32_t Ltot, int32_t l0, int32_t L, int32_t K, int32_t D, int32_t top_k, void* stream) {
+  CMH_CHECK_ARG(tokens && sim && out, "mith_lta: null pointer");
+  CMH_CHECK_ARG(B > 0 && L > 0 && L <= kLtaMaxL && l0 >= 0 && l0 + L <= Ltot, "mith_lta: token range (L <= %d)", kLtaMaxL);
+  CMH_CHECK_ARG(K > 0 && K <= kLtaMaxK && D > 0, "mith_lta: K must be <= %d", kLtaMaxK);
+  CMH_CHECK_ARG(top_k >= 1 && top_k <= kTop, "mith_lta: top_k must be in 1..%d", kTop);
+  hipLaunchKernelGGL(lta_kernel, dim3(B), dim3(256), 0, as_stream(stream), tokens, sim, key_padding_mask, out, Ltot, l0, L,
+                     K, D, top_k);
+  CMH_CHECK_LAUNCH("mith_lta");
+  return CMH_OK;
+}
+
+extern "C" int cmh_add_positional(float* x, const float* pe, int32_t B, int32_t T, int32_t D, void* stream) {
+  CMH_CHECK_ARG(x && pe && B > 0 && T > 0 && D > 0, "add_positional: bad arguments");
+  const int64_t n = static_cast<int64_t>(B) * T * D;
+  hipLaunchKernelGGL(add_pos_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, as_stream(stream), x, pe, n, T, D);
+  CMH_CHECK_LAUNCH("add_positional");
+  return CMH_OK;
+}
+
+extern "C" int cmh_bitwise_hash(const float* x, const float* w, const float* bias, float* out, int32_t B, int32_t K,
+                                int32_t D, void* stream) {
+  CMH_CHECK_ARG(x && w && bias && out && B > 0 && K > 0 && D > 0 && D % 4 == 0, "bitwise_hash: bad arguments");
+  hipLaunchKernelGGL(bitwise_hash_kernel, dim3((B * K + 3) / 4), dim3(256), 0, as_stream(stream), x, w, bias, out, B, K, D);
+  CMH_CHECK_LAUNCH("bitwise_hash");
+  return CMH_OK;
+}
+
+extern "C" int cmh_l2_normalize_rows(const float* x, float* y, int32_t R, int32_t D, void* stream) {
+  CMH_CHECK_ARG(x && y && R > 0 && D > 0, "l2_normalize_rows: bad arguments");
+  hipLaunchKernelGGL(l2norm_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, as_stream(stream), x, y, R, D);
+  CMH_CHECK_LAUNCH("l2_normalize_rows");
+  return CMH_OK;
+}
+
+extern "C" int cmh_mith_mix(const float* img_cls, const float* img_tok, const float* txt_cls, const float* txt_tok,
+                            float hyper_lambda, float* B_codes, float* H_img, float* H_txt, int64_t n, void* stream) {
+  CMH_CHECK_ARG(img_cls && img_tok && txt_cls && txt_tok && B_codes && H_img && H_txt && n > 0, "mith_mix: bad arguments");
+  hipLaunchKernelGGL(mith_mix_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, as_stream(stream), img_cls,
+                     img_tok, txt_cls, txt_tok, hyper_lambda, B_codes, H_img, H_txt, n);
+  CMH_CHECK_LAUNCH("mith_mix");
+  return CMH_OK;
+}
+
+extern "C" int cmh_sq_diff_sum(const float* a, const float* b, int64_t n, float* out, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  CMH_CHECK_ARG(a && b && out && workspace && n > 0 && workspace_bytes >= 256, "sq_diff_sum: bad arguments");
+  hipStream_t st = as_stream(stream);
+  double* acc = static_cast<double*>(workspace);
+  if (hipMemsetAsync(acc, 0, 8, st) != hipSuccess) return fail(CMH_ERR_LAUNCH, "sq_diff_sum: memset failed");
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(sq_diff_kernel, dim3(static_cast<unsigned>(blocks < 1024 ? blocks : 1024)), dim3(256), 0, st, a, b, n, acc);
+  hipLaunchKernelGGL(read_acc_kernel, dim3(1), dim3(1), 0, st, acc, 1.0, out);
+  CMH_CHECK_LAUNCH("sq_diff_sum");
+  return CMH_OK;
+}
+
+extern "C" int cmh_mith_bayesian_loss(const float* bank, const float* batch, const float* bank_label, const float* label,
+                                      int32_t Mb, int32_t B, int32_t K, int32_t C, float* out, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  CMH_CHECK_ARG(bank && batch && bank_label && label && out && workspace && workspace_bytes >= 256, "mith_bayesian_loss: bad arguments");
+  CMH_CHECK_ARG(Mb > 0 && B > 0 && K > 0 && C > 0, "mith_bayesian_loss: bad shape");
+  hipStream_t st = as_stream(stream);
+  double* acc = static_cast<double*>(workspace);
+  if (hipMemsetAsync(acc, 0, 8, st) != hipSuccess) return fail(CMH_ERR_LAUNCH, "mith_bayesian_loss: memset failed");
+  const int64_t n = static_cast<int64_t>(Mb) * B;
+  hipLaunchKernelGGL(bayes_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, bank, batch, bank_label,
+                     label, Mb, B, K, C, acc);
+  hipLaunchKernelGGL(read_acc_kernel, dim3(1), dim3(1), 0, st, acc, -1.0 / static_cast<double>(n), out);
+  CMH_CHECK_LAUNCH("mith_bayesian_loss");
+  return CMH_OK;
+}
+
+extern "C" int cmh_info_nce(const float* a, const float* b, int32_t R, int32_t G, int32_t D, float temperature, float* out,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+  CMH_CHECK_ARG(a && b && out && workspace && workspace_bytes >= 256, "info_nce: bad arguments");
+  CMH_CHECK_ARG(R > 0 && G > 0 && R % G == 0 && D > 0 && D <= 4096 && temperature > 0.f, "info_nce: bad shape");
+  hipStream_t st = as_stream(stream);
+  double* acc = static_cast<double*>(workspace);
+  if (hipMemsetAsync(acc, 0, 8, st) != hipSuccess) return fail(CMH_ERR_LAUNCH, "info_nce: memset failed");
+  const size_t smem = static_cast<size_t>(4) * D * sizeof(float);
+  hipLaunchKernelGGL(row_ce_kernel, dim3((R + 3) / 4), dim3(256), smem, st, a, b, R, G, D, 1.0f / temperature, acc);
+  hipLaunchKernelGGL(row_ce_kernel, dim3((R + 3) / 4), dim3(256), smem, st, b, a, R, G, D, 1.0f / temperature, acc);
+  hipLaunchKernelGGL(read_acc_kernel, dim3(1), dim3(1), 0, st, acc, 0.5 / static_cast<double>(R), out);
+  CMH_CHECK_LAUNCH("info_nce");
+  return CMH_OK;
+}

@@ -40,3 +40,18 @@ def dataloader(total, nclass, maxWords=32, imageResolution=224, query_num=5000, 
     q, t, r = perm[:query_num], perm[query_num:query_num + train_num], perm[query_num:]
     mk = lambda ids: SyntheticPairs(ids, labels[ids], maxWords, imageResolution, seed or 0)
     return mk(t), mk(q), mk(r)
+
+
+class SyntheticPairsMITH(SyntheticPairs):
+    """train/MITH/data.py contract: (image, caption, key_padding_mask = caption == 0, label, index)."""
+
+    def __getitem__(self, index):
+        image, cap, label, index = super().__getitem__(index)
+        return image, cap, cap == 0, label, index
+
+
+def dataloader_mith(total, nclass, maxWords=32, imageResolution=224, query_num=5000, train_num=10000, seed=None):
+    tr, q, r = dataloader(total, nclass, maxWords, imageResolution, query_num, train_num, seed)
+    for d in (tr, q, r):
+        d.__class__ = SyntheticPairsMITH
+    return tr, q, r

@@ -11,8 +11,9 @@ _REGISTRY = {
     'DCHMT': ("train.DCHMT.hash_train", "DCHMTTrainer"),
     'TwDH': ("train.TwDH.hash_train", "TwDHTrainer"),
     'DNPH': ("train.DNPH_TOMM.hash_train", "DNPHTOMMTrainer"),
+    'MITH': ("train.MITH.hash_train", "MITHTrainer"),
 }
-_NOT_BUILT = ['MITH', 'DHaPH', 'DMsH_LN', 'DNpH', 'DPBE', 'DDWSH', 'DDBH', 'DScPH', 'DPSIH', 'DGHDGH']
+_NOT_BUILT = ['DHaPH', 'DMsH_LN', 'DNpH', 'DPBE', 'DDWSH', 'DDBH', 'DScPH', 'DPSIH', 'DGHDGH']
 
 
 class _LazyTrainers(dict):

@@ -1,0 +1,137 @@
+"""ctypes wrappers of the MITH entry points of libcmh.so (signatures registered in cmh_native.SIGNATURES)."""
+import ctypes as C
+
+import torch
+
+import cmh_native as N
+
+EPI_BIAS, EPI_QUICKGELU, EPI_RESIDUAL, EPI_OUT_BF16, EPI_GELU, EPI_RELU = 1, 2, 4, 8, 16, 32
+
+
+def gemm(x, w, bias=None, residual=None, act=None):
+    """f32 out = act(x @ w.T + bias) (+ residual); x,w f32 (exact-fp32 MFMA path). act in {None,'gelu','relu','quickgelu'}."""
+    x, w = N.f32c(x), N.f32c(w)
+    N.require_gpu(x, w, bias, residual)
+    M, K = x.shape
+    Nn = w.shape[0]
+    out = torch.empty(M, Nn, dtype=torch.float32, device=x.device)
+    epi = (EPI_BIAS if bias is not None else 0) | (EPI_RESIDUAL if residual is not None else 0)
+    epi |= {None: 0, "gelu": EPI_GELU, "relu": EPI_RELU, "quickgelu": EPI_QUICKGELU}[act]
+    N.check(N.lib().cmh_linear_gemm(N.F32, N.ptr(x), N.ptr(w), N.ptr(None if bias is None else N.f32c(bias)),
+                                    N.ptr(None if residual is None else N.f32c(residual)), N.ptr(out), M, Nn, K, epi,
+                                    N.stream_ptr(x.device)), "cmh_linear_gemm")
+    return out
+
+
+def vit_encode_tokens(clip, image):
+    image = N.f32c(image)
+    N.require_gpu(image)
+    s = clip._vit_struct()
+    B = image.shape[0]
+    T = (s.resolution // s.patch) ** 2 + 1
+    out = torch.empty(B * T, s.embed_dim, dtype=torch.float32, device=image.device)
+    ws = N.workspace(N.lib().cmh_vit_workspace_bytes(C.byref(s), B), image.device, "vit")
+    N.check(N.lib().cmh_vit_encode_tokens(C.byref(s), N.ptr(image), B, N.ptr(out), N.ptr(ws), ws.numel(),
+                                          N.stream_ptr(image.device)), "cmh_vit_encode_tokens")
+    return out.view(B, T, s.embed_dim)
+
+
+def text_encode_tokens(clip, text, key_padding_mask):
+    N.require_gpu(text)
+    text = text.to(torch.int64).contiguous()
+    s = clip._text_struct()
+    B, L = text.shape
+    out = torch.empty(B * L, s.embed_dim, dtype=torch.float32, device=text.device)
+    rows = torch.empty(B, dtype=torch.int32, device=text.device)
+    kpm = None if key_padding_mask is None else key_padding_mask.to(torch.uint8).contiguous()
+    ws = N.workspace(N.lib().cmh_text_workspace_bytes(C.byref(s), B, L), text.device, "text")
+    N.check(N.lib().cmh_text_encode_tokens(C.byref(s), N.ptr(text), B, L, N.ptr(kpm), N.ptr(out), N.ptr(rows), N.ptr(ws),
+                                           ws.numel(), N.stream_ptr(text.device)), "cmh_text_encode_tokens")
+    return out.view(B, L, s.embed_dim), rows
+
+
+def transformer_blocks(block_array, layers, x, B, T):
+    """x f32 [B*T, d] -> same shape, after `layers` ResidualAttentionBlocks (no mask)."""
+    x = N.f32c(x).clone()
+    d = x.shape[1]
+    ws = N.workspace(N.lib().cmh_blocks_workspace_bytes(N.F32, B, T, d), x.device, "blocks")
+    N.check(N.lib().cmh_transformer_blocks(C.cast(block_array, C.POINTER(N.BlockWeights)), layers, N.F32, N.ptr(x), B, T,
+                                           d, 0, None, N.ptr(ws), ws.numel(), N.stream_ptr(x.device)),
+            "cmh_transformer_blocks")
+    return x
+
+
+def lta(tokens, sim, key_padding_mask, l0, L, top_k):
+    """tokens f32 [B, Ltot, D], sim f32 [B, Ltot, K] -> merged concepts [B, K, D]."""
+    tokens, sim = N.f32c(tokens), N.f32c(sim)
+    B, Ltot, D = tokens.shape
+    K = sim.shape[2]
+    out = torch.empty(B, K, D, dtype=torch.float32, device=tokens.device)
+    kpm = None if key_padding_mask is None else key_padding_mask.to(torch.uint8).contiguous()
+    N.check(N.lib().cmh_mith_lta(N.ptr(tokens), N.ptr(sim), N.ptr(kpm), N.ptr(out), B, Ltot, l0, L, K, D, top_k,
+                                 N.stream_ptr(tokens.device)), "cmh_mith_lta")
+    return out
+
+
+def add_positional(x, pe):
+    x = N.f32c(x).clone()
+    B, T, D = x.shape
+    N.check(N.lib().cmh_add_positional(N.ptr(x), N.ptr(N.f32c(pe)), B, T, D, N.stream_ptr(x.device)), "cmh_add_positional")
+    return x
+
+
+def bitwise_hash(x, w, bias):
+    x = N.f32c(x)
+    B, K, D = x.shape
+    out = torch.empty(B, K, dtype=torch.float32, device=x.device)
+    N.check(N.lib().cmh_bitwise_hash(N.ptr(x), N.ptr(N.f32c(w)), N.ptr(N.f32c(bias)), N.ptr(out), B, K, D,
+                                     N.stream_ptr(x.device)), "cmh_bitwise_hash")
+    return out
+
+
+def l2_normalize_rows(x):
+    x = N.f32c(x)
+    y = torch.empty_like(x)
+    R = x.numel() // x.shape[-1]
+    N.check(N.lib().cmh_l2_normalize_rows(N.ptr(x), N.ptr(y), R, x.shape[-1], N.stream_ptr(x.device)), "cmh_l2_normalize_rows")
+    return y
+
+
+def mith_mix(ic, it, tc, tt, lam):
+    ic, it, tc, tt = (N.f32c(t) for t in (ic, it, tc, tt))
+    Bc, Hi, Ht = torch.empty_like(ic), torch.empty_like(ic), torch.empty_like(ic)
+    N.check(N.lib().cmh_mith_mix(N.ptr(ic), N.ptr(it), N.ptr(tc), N.ptr(tt), float(lam), N.ptr(Bc), N.ptr(Hi), N.ptr(Ht),
+                                 ic.numel(), N.stream_ptr(ic.device)), "cmh_mith_mix")
+    return Bc, Hi, Ht
+
+
+def _scalar(dev):
+    return torch.empty(1, dtype=torch.float32, device=dev)
+
+
+def sq_diff_sum(a, b):
+    a, b = N.f32c(a), N.f32c(b)
+    out, ws = _scalar(a.device), N.workspace(256, a.device, "loss")
+    N.check(N.lib().cmh_sq_diff_sum(N.ptr(a), N.ptr(b), a.numel(), N.ptr(out), N.ptr(ws), ws.numel(), N.stream_ptr(a.device)),
+            "cmh_sq_diff_sum")
+    return out[0]
+
+
+def bayesian_loss(bank, batch, bank_label, label):
+    bank, batch, bank_label, label = (N.f32c(t) for t in (bank, batch, bank_label, label))
+    out, ws = _scalar(bank.device), N.workspace(256, bank.device, "loss")
+    N.check(N.lib().cmh_mith_bayesian_loss(N.ptr(bank), N.ptr(batch), N.ptr(bank_label), N.ptr(label), bank.shape[0],
+                                           batch.shape[0], bank.shape[1], label.shape[1], N.ptr(out), N.ptr(ws), ws.numel(),
+                                           N.stream_ptr(bank.device)), "cmh_mith_bayesian_loss")
+    return out[0]
+
+
+def info_nce(a, b, group=None, temperature=0.07):
+    a, b = N.f32c(a), N.f32c(b)
+    D = a.shape[-1]
+    R = a.numel() // D
+    G = R if group is None else group
+    out, ws = _scalar(a.device), N.workspace(256, a.device, "loss")
+    N.check(N.lib().cmh_info_nce(N.ptr(a), N.ptr(b), R, G, D, float(temperature), N.ptr(out), N.ptr(ws), ws.numel(),
+                                 N.stream_ptr(a.device)), "cmh_info_nce")
+    return out[0]

@@ -1,0 +1,210 @@
+"""MITH model (reference model/MITH.py) on libcmh: token-returning CLIP trunk (ViT / CLIP1, :49-160) and HashingModel
+(:212-453).  Modules are parameter containers with the reference's names (so `clip.*` / `hash.*` checkpoints load
+strict, including the shared `hash.gcl_i` / `hash.gcl_t` module and the `position.pe` buffers); every forward is native:
+
+  ResidualMLPs                 LayerNorm + GEMM(GELU epilogue) + GEMM(residual epilogue)
+  GlobalConceptLearning        ... + Linear(512,K,no bias)+tanh in one launch
+  LocalizedTokenAggregation    cmh_mith_lta (mask, per-token top-k, softmax over tokens, weighted token sum)
+  PositionalEncoding           cmh_add_positional
+  concept Transformer          cmh_transformer_blocks (the same block kernels as the CLIP towers)
+  BitwiseHashing               cmh_bitwise_hash
+  F.normalize                  cmh_l2_normalize_rows
+Layouts: tensors are produced batch-major and returned as views in the reference's layouts ([L,N,D] / [K,N,D]).
+The trunk's attention maps are returned as None (MITH.forward discards them, model/MITH.py:464-465)."""
+import math
+
+import torch
+from torch import nn
+
+import cmh_native as N
+import mith_ops as M
+from model.base.model import CLIP, Transformer, VisionTransformer, _fill_blocks, convert_weights, no_backward  # noqa: F401
+
+
+class ViT(VisionTransformer):
+    """model/MITH.py:49-82: returns (seq_tokens [g*g, B, E], attn_weight=None, cls_token [B, E])."""
+
+
+class CLIP1(CLIP):
+    def encode_image(self, image):
+        tok = M.vit_encode_tokens(self, image)                       # [B, T, E]
+        tok = no_backward(tok, self.visual.proj)
+        return tok[:, 1:].permute(1, 0, 2), None, tok[:, 0]
+
+    def encode_text(self, text, key_padding_mask):
+        tok, rows = M.text_encode_tokens(self, text, key_padding_mask)   # [B, L, E]
+        tok = no_backward(tok, self.text_projection)
+        B, L, E = tok.shape
+        new_kpm = key_padding_mask + (text == 49407)                 # model/MITH.py:134 (bool OR)
+        eos = tok.reshape(B * L, E)[rows.long()]
+        return tok.permute(1, 0, 2), None, new_kpm, eos
+
+
+def build_model(state_dict: dict):
+    """model/MITH.py:163-204 (same shape inference as model/base/model.py::build_model, CLIP1 instead of CLIP)."""
+    vision_width = state_dict["visual.conv1.weight"].shape[0]
+    vision_layers = len([k for k in state_dict if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")])
+    vision_patch_size = state_dict["visual.conv1.weight"].shape[-1]
+    grid_size = round((state_dict["visual.positional_embedding"].shape[0] - 1) ** 0.5)
+    embed_dim = state_dict["text_projection"].shape[1]
+    tw = state_dict["ln_final.weight"].shape[0]
+    layers = len(set(k.split(".")[2] for k in state_dict if k.startswith("transformer.resblocks")))
+    model = CLIP1(embed_dim, vision_patch_size * grid_size, vision_layers, vision_width, vision_patch_size,
+                  state_dict["positional_embedding"].shape[0], state_dict["token_embedding.weight"].shape[0], tw, tw // 64,
+                  layers)
+    for key in ["input_resolution", "context_length", "vocab_size"]:
+        if key in state_dict:
+            del state_dict[key]
+    convert_weights(model)
+    model.load_state_dict(state_dict)
+    return model
+
+
+def load_download_clip(clip_path) -> nn.Module:
+    if isinstance(clip_path, dict):
+        return build_model(dict(clip_path))
+    try:
+        state_dict = torch.jit.load(clip_path, map_location="cpu").eval().state_dict()
+    except RuntimeError:
+        state_dict = torch.load(clip_path, map_location="cpu")
+    return build_model(state_dict)
+
+
+class ResidualMLPs(nn.Module):
+    def __init__(self, org_dim, dropout=0., num_layers=2, activation='relu'):
+        super().__init__()
+        assert dropout == 0, "MITH runs its residual MLPs with dropout 0 (train/MITH/get_args.py:11)"
+        self.num_layers = num_layers
+        self.activation = activation
+        self.activation_layer = nn.ReLU() if activation == 'relu' else nn.GELU()
+        self.mlps = nn.ModuleList(nn.Sequential(nn.Linear(org_dim, 4 * org_dim), self.activation_layer,
+                                                nn.Dropout(p=dropout), nn.Linear(4 * org_dim, org_dim))
+                                  for _ in range(num_layers))
+        self.lns = nn.ModuleList(nn.LayerNorm(org_dim) for _ in range(num_layers))
+
+    def forward(self, x):
+        shape = x.shape
+        x = N.f32c(x).reshape(-1, shape[-1])
+        for i in range(self.num_layers):
+            h = N.layernorm(x, self.lns[i].weight, self.lns[i].bias)
+            u = M.gemm(h, self.mlps[i][0].weight, self.mlps[i][0].bias, act=self.activation)
+            x = M.gemm(u, self.mlps[i][3].weight, self.mlps[i][3].bias, residual=x)
+        return x.reshape(shape)
+
+
+class PositionalEncoding(nn.Module):
+    def __init__(self, d_model, dropout=0., max_len=128):
+        super().__init__()
+        pe = torch.zeros(max_len, d_model)
+        position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        pe = pe.unsqueeze(0).transpose(0, 1) / (d_model ** 0.5)      # [max_len, 1, d_model]
+        self.register_buffer('pe', pe)
+
+    def forward(self, x):
+        """x batch-major [N, K, D] (reference: [K, N, D])."""
+        return M.add_positional(x, self.pe[:x.shape[1], 0, :])
+
+
+class BitwiseHashing(nn.Module):
+    def __init__(self, org_dim, k_bits=32):
+        super().__init__()
+        self.k = k_bits
+        self.fc_list = nn.ModuleList(nn.Linear(org_dim, 1) for _ in range(k_bits))
+
+    def forward(self, x):
+        """x [N, K, D] -> tanh codes [N, K]."""
+        w = torch.cat([l.weight for l in self.fc_list], 0)
+        b = torch.cat([l.bias for l in self.fc_list], 0)
+        return M.bitwise_hash(x, w, b)
+
+
+class GlobalConceptLearning(nn.Module):
+    def __init__(self, k_concept, org_dim, dropout=0., activation='relu', res_mlp_layers=0):
+        super().__init__()
+        self.mlp = ResidualMLPs(org_dim=org_dim, dropout=dropout, num_layers=res_mlp_layers,
+                                activation=activation) if res_mlp_layers != 0 else nn.Identity()
+        self.common_concept_embedding = nn.Linear(org_dim, k_concept, bias=False)
+
+    def forward(self, x):
+        x = self.mlp(x)
+        flat = N.f32c(x).reshape(-1, x.shape[-1])
+        c = N.linear_act(flat, self.common_concept_embedding.weight, None, N.ACT_TANH)
+        return x, c.reshape(*x.shape[:-1], -1)
+
+
+class LocalizedTokenAggregation(nn.Module):
+    def __init__(self, top_k):
+        super().__init__()
+        self.top_k = top_k
+
+
+class LocalConceptTransforming(nn.Module):
+    def __init__(self, clip_embed_dim, k_bits, transformer_layers, dropout, top_k):
+        super().__init__()
+        self.lta = LocalizedTokenAggregation(top_k=top_k)
+        self.position = PositionalEncoding(clip_embed_dim, dropout=dropout, max_len=k_bits)
+        self.transformer = Transformer(width=clip_embed_dim, layers=transformer_layers, heads=clip_embed_dim // 64)
+        self.hashing = BitwiseHashing(org_dim=clip_embed_dim, k_bits=k_bits)
+        self._blocks = None
+
+    def forward(self, tokens_bm, sim_bm, l0, L, key_padding_mask=None):
+        """tokens_bm [N, Ltot, D], sim_bm [N, Ltot, K] batch-major -> (hash [N,K], transformed concept tokens [N,K,D])."""
+        x = M.lta(tokens_bm, sim_bm, key_padding_mask, l0, L, self.lta.top_k)          # [N, K, D]
+        x = self.position(x)
+        Nb, K, D = x.shape
+        keep = []
+        arr = _fill_blocks(self.transformer.resblocks, N.F32, keep)
+        y = M.transformer_blocks(arr, len(self.transformer.resblocks), x.reshape(Nb * K, D), Nb, K).reshape(Nb, K, D)
+        del keep
+        return self.hashing(y), y
+
+
+class HashingModel(nn.Module):
+    def __init__(self, clip_embed_dim=512, args=None):
+        super().__init__()
+        self.k_bits = k_bits = args.output_dim
+        self.gcl_i = self.gcl_t = GlobalConceptLearning(k_concept=k_bits, org_dim=clip_embed_dim, dropout=args.dropout,
+                                                        activation=args.activation, res_mlp_layers=args.res_mlp_layers)
+        self.lct_i = LocalConceptTransforming(clip_embed_dim, k_bits, args.transformer_layers, 0, args.top_k_label)
+        self.lct_t = LocalConceptTransforming(clip_embed_dim, k_bits, args.transformer_layers, 0, args.top_k_label)
+        self.img_concept_proj = nn.Linear(clip_embed_dim, clip_embed_dim)
+        self.txt_concept_proj = nn.Linear(clip_embed_dim, clip_embed_dim)
+
+    def forward(self, img_tokens, txt_tokens, img_cls, txt_eos, key_padding_mask):
+        """Reference layouts in (img_tokens [49,N,D], txt_tokens [L,N,D]) and out (trans_tokens_* [K,N,D])."""
+        out = {}
+        nb = lambda t: no_backward(t, self.img_concept_proj.weight)
+        res_img_cls, img_cls_hash = self.gcl_i(img_cls)
+        res_txt_cls, txt_cls_hash = self.gcl_t(txt_eos)
+        out['img_cls_hash'], out['txt_cls_hash'] = nb(img_cls_hash), nb(txt_cls_hash)
+        out['res_img_cls'] = nb(M.l2_normalize_rows(res_img_cls))
+        out['res_txt_cls'] = nb(M.l2_normalize_rows(res_txt_cls))
+        it = img_tokens.permute(1, 0, 2).contiguous()                                    # [N, 49, D]
+        tt = txt_tokens.permute(1, 0, 2).contiguous()                                    # [N, L, D]
+        sim_i = self.gcl_i(it)[1]
+        sim_t = self.gcl_t(tt)[1]
+        hash_i, trans_i = self.lct_i(it, sim_i, 0, it.shape[1], None)
+        hash_t, trans_t = self.lct_t(tt, sim_t, 0, tt.shape[1], key_padding_mask)
+        out['img_tokens_hash'], out['txt_tokens_hash'] = nb(hash_i), nb(hash_t)
+        Nb, K, D = trans_i.shape
+        pi = M.gemm(trans_i.reshape(Nb * K, D), self.img_concept_proj.weight, self.img_concept_proj.bias)
+        pt = M.gemm(trans_t.reshape(Nb * K, D), self.txt_concept_proj.weight, self.txt_concept_proj.bias)
+        out['trans_tokens_i'] = nb(M.l2_normalize_rows(pi).reshape(Nb, K, D).permute(1, 0, 2))
+        out['trans_tokens_t'] = nb(M.l2_normalize_rows(pt).reshape(Nb, K, D).permute(1, 0, 2))
+        return out
+
+
+class MITH(nn.Module):
+    def __init__(self, args=None):
+        super(MITH, self).__init__()
+        self.args = args
+        self.clip = load_download_clip(self.args.clip_path)
+        self.hash = HashingModel(clip_embed_dim=512, args=args)
+
+    def forward(self, image, text, key_padding_mask):
+        img_tokens, _, img_cls = self.clip.encode_image(image)
+        txt_tokens, _, new_key_padding_mask, txt_eos = self.clip.encode_text(text, key_padding_mask)
+        return self.hash(img_tokens, txt_tokens, img_cls, txt_eos, new_key_padding_mask)

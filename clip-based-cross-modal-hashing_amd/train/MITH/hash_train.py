@@ -1,0 +1,120 @@
+"""MITH trainer (reference train/MITH/hash_train.py; paper: Multi-Granularity Interactive Transformer Hashing, ACM MM 2023).
+Forward (token-returning trunk + HashingModel), the memory-bank update, all five loss groups and validation run on libcmh;
+backward/optimiser are the next scope row.  Under data parallelism the bank update needs every rank's (index, codes):
+dist_utils.all_gather_rows + scatter_by_index."""
+import os
+
+import torch
+
+import cmh_native as N
+import mith_ops as M
+from model.MITH import MITH
+from model.base.model import no_backward
+from train.base import TrainBase
+from .get_args import get_args
+
+
+class MITHTrainer(TrainBase):
+
+    def __init__(self, args, rank=0):
+        args = get_args(args)
+        args.rank = rank
+        super(MITHTrainer, self).__init__(args)
+        self.logger.info("dataset len: {}".format(len(self.train_loader.dataset)))
+        self.run()
+
+    def _init_model(self):
+        self.logger.info("init model.")
+        self.model = MITH(args=self.args).to(self.rank)
+        if self.args.pretrained != "" and os.path.exists(self.args.pretrained):
+            self.model.load_state_dict(torch.load(self.args.pretrained, map_location=f"cuda:{self.rank}"))
+        self.model.float()
+        self.model.clip.set_gemm_dtype(self.args.gemm_dtype)
+        self.optimizer = None
+        self.k_bits = self.args.output_dim
+        n = len(self.train_loader.dataset)
+        mk = lambda: torch.randn(n, self.k_bits).to(self.rank, non_blocking=True)
+        self.img_buffer_tokens, self.img_buffer_cls = mk(), mk()
+        self.txt_buffer_tokens, self.txt_buffer_cls = mk(), mk()
+
+    def change_state(self, mode):
+        self.model.train() if mode == "train" else self.model.eval()
+
+    # ---- reference loss helpers (:103-147), each ONE native call ---------------------------------------
+    def info_nce_loss(self, out_1, out_2, temperature=0.07):
+        return M.info_nce(out_1, out_2, None, temperature)
+
+    def info_nce_loss_bmm(self, out_1, out_2, temperature=0.07):
+        a = out_1.permute(1, 0, 2).contiguous()            # [K,N,D] -> [N,K,D]
+        b = out_2.permute(1, 0, 2).contiguous()
+        return M.info_nce(a, b, a.shape[1], temperature)
+
+    def bayesian_loss(self, a, b, label_pair):
+        """label_pair = (bank_labels [M,C], batch_labels [B,C]); the [M,B] label_sim is formed inside the kernel."""
+        return M.bayesian_loss(a, b, label_pair[0], label_pair[1])
+
+    def quantization_loss_2(self, hash_feature, B):
+        return M.sq_diff_sum(hash_feature, B) / (hash_feature.shape[0]) / self.k_bits
+
+    def make_B(self, output_dict):
+        ic, it = output_dict['img_cls_hash'].detach(), output_dict['img_tokens_hash'].detach()
+        tc, tt = output_dict['txt_cls_hash'].detach(), output_dict['txt_tokens_hash'].detach()
+        return M.mith_mix(ic, it, tc, tt, self.args.hyper_lambda)
+
+    def compute_loss(self, output_dict, label, B=None, mixes=None):
+        a = self.args
+        pair = (self.train_labels.float(), label.to(self.rank).float())
+        ic, tc = output_dict['img_cls_hash'], output_dict['txt_cls_hash']
+        it, tt = output_dict['img_tokens_hash'], output_dict['txt_tokens_hash']
+        Bc, H_i, H_t = mixes if mixes is not None else self.make_B(output_dict)
+        if B is not None:
+            Bc = B
+        L = {}
+        L['tokens_intra_likelihood'] = a.hyper_tokens_intra * (self.bayesian_loss(self.img_buffer_tokens, it, pair) +
+                                                               self.bayesian_loss(self.txt_buffer_tokens, tt, pair))
+        L['cls_inter_likelihood'] = a.hyper_cls_inter * (self.bayesian_loss(self.img_buffer_cls, tc, pair) +
+                                                         self.bayesian_loss(self.txt_buffer_cls, ic, pair))
+        L['quantization'] = a.hyper_quan * (self.quantization_loss_2(H_i, Bc) + self.quantization_loss_2(H_t, Bc))
+        L['infoNCE'] = a.hyper_info_nce * (self.info_nce_loss(output_dict['res_img_cls'], output_dict['res_txt_cls']) +
+                                           a.hyper_alpha * self.info_nce_loss_bmm(output_dict['trans_tokens_i'],
+                                                                                  output_dict['trans_tokens_t']))
+        item = M.sq_diff_sum(ic, it) + M.sq_diff_sum(tc, tt)       # value of item_1; item_2 = 0.1 * the same value
+        L['distillation'] = a.hyper_distill * (item + 0.1 * item) / ic.shape[0]
+        return {k: no_backward(v, self.model.hash.img_concept_proj.weight) for k, v in L.items()}
+
+    def train_epoch(self, epoch):
+        self.change_state(mode="train")
+        self.logger.info(">>>>>> epochs: %d/%d" % (epoch, self.args.epochs))
+        for image, text, key_padding_mask, label, index in self.train_loader:
+            self.global_step += 1
+            image = image.to(self.rank, non_blocking=True)
+            text = text.to(self.rank, non_blocking=True)
+            key_padding_mask = key_padding_mask.to(self.rank, non_blocking=True)
+            output_dict = self.model(image, text, key_padding_mask)
+            index = index.to(self.rank)
+            self.img_buffer_cls[index] = output_dict['img_cls_hash'].detach()
+            self.txt_buffer_cls[index] = output_dict['txt_cls_hash'].detach()
+            self.img_buffer_tokens[index] = output_dict['img_tokens_hash'].detach()
+            self.txt_buffer_tokens[index] = output_dict['txt_tokens_hash'].detach()
+            losses = self.compute_loss(output_dict, label)
+            loss = sum(losses.values())
+            loss.backward()      # raises NotImplementedError: backward kernels are the next scope row
+
+    def get_code_MITH(self, data_loader, length: int):
+        img_buffer = torch.empty(length, self.args.output_dim, dtype=torch.float).to(self.rank)
+        text_buffer = torch.empty(length, self.args.output_dim, dtype=torch.float).to(self.rank)
+        with torch.no_grad():
+            for image, text, key_padding_mask, label, index in data_loader:
+                image = image.to(self.rank, non_blocking=True)
+                text = text.to(self.rank, non_blocking=True)
+                key_padding_mask = key_padding_mask.to(self.rank, non_blocking=True)
+                od = self.model(image, text, key_padding_mask)
+                index = index.to(self.rank)
+                img_buffer[index, :] = N.sign_codes(od['img_tokens_hash'] + od['img_cls_hash'])
+                text_buffer[index, :] = N.sign_codes(od['txt_tokens_hash'] + od['txt_cls_hash'])
+        return img_buffer, text_buffer, 0
+
+    def _codes_for_eval(self):
+        q_img, q_txt, q_t = self.get_code_MITH(self.query_loader, self.args.query_num)
+        r_img, r_txt, r_t = self.get_code_MITH(self.retrieval_loader, self.args.retrieval_num)
+        return q_img, q_txt, r_img, r_txt, q_t, r_t

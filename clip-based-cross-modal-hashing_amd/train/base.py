@@ -46,7 +46,10 @@ class TrainBase(object):
             raise ValueError("Unknown dataset")
         self.args.nclass = NCLASS[self.args.dataset]
         if self.args.dataset == 'synthetic':
-            from dataset.synthetic import dataloader
+            if self.args.method == 'MITH':      # MITH batches carry a key_padding_mask (train/MITH/data.py)
+                from dataset.synthetic import dataloader_mith as dataloader
+            else:
+                from dataset.synthetic import dataloader
             train_data, query_data, retrieval_data = dataloader(
                 total=self.args.synthetic_size, nclass=self.args.nclass, maxWords=self.args.max_words,
                 imageResolution=self.args.resolution, query_num=self.args.query_num,

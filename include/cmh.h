@@ -270,6 +270,59 @@ int cmh_dnph_loss(const float* hash_img, const float* hash_txt, const float* pre
                   int32_t B, int32_t K, int32_t C, float margin, float noise_weight, float* out3,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * MITH (BASELINE.json config 3): token-returning trunk, HashingModel pieces, losses.
+ * Activations are batch-major: [N, K, D] where the reference holds [K, N, D].
+ * ------------------------------------------------------------------------------------------- */
+#define CMH_EPI_GELU 16       /* exact GELU (nn.GELU()) in cmh_linear_gemm's epilogue, model/MITH.py:224-233 */
+#define CMH_EPI_RELU 32
+
+/* ViT.forward of the MITH trunk (model/MITH.py:56-82): ln_post + proj on EVERY token.
+ * tokens_out f32 [B*(g*g+1), embed_dim]; row b*(g*g+1) is the class token, the rest the patch tokens. */
+int cmh_vit_encode_tokens(const cmh_vit_weights* w, const float* image, int32_t batch, float* tokens_out,
+                          void* workspace, size_t workspace_bytes, void* stream);
+/* CLIP1.encode_text (model/MITH.py:120-144): causal mask + key_padding_mask in every block, ln_final +
+ * text_projection on every token.  tokens_out f32 [B*L, embed_dim]; eot_rows_out i32 [B] = b*L + argmax(tokens[b]). */
+int cmh_text_encode_tokens(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
+                           const uint8_t* key_padding_mask, float* tokens_out, int32_t* eot_rows_out,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* `layers` ResidualAttentionBlocks applied in place to a caller-owned residual stream x f32 [B*T, d]
+ * (MITH's 2-layer concept transformer, model/MITH.py:385-395). */
+size_t cmh_blocks_workspace_bytes(int32_t dtype, int32_t B, int32_t T, int32_t d);
+int cmh_transformer_blocks(const cmh_block_weights* blocks, int32_t layers, int32_t dtype, float* x, int32_t B,
+                           int32_t T, int32_t d, int32_t causal, const uint8_t* key_padding_mask,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* LocalizedTokenAggregation.forward (model/MITH.py:317-376).  tokens f32 [B*Ltot, D], sim f32 [B*Ltot, K] (tanh
+ * concept scores of every token); the L tokens l0..l0+L-1 of each sample take part (image: Ltot=50, l0=1, L=49).
+ * key_padding_mask u8 [B, L] optional.  out f32 [B, K, D].  L <= 80, K <= 128, top_k <= 8. */
+int cmh_mith_lta(const float* tokens, const float* sim, const uint8_t* key_padding_mask, float* out, int32_t B,
+                 int32_t Ltot, int32_t l0, int32_t L, int32_t K, int32_t D, int32_t top_k, void* stream);
+/* x[b,t,:] += pe[t,:]   (PositionalEncoding.forward, model/MITH.py:270-273; pe is the registered buffer). */
+int cmh_add_positional(float* x, const float* pe, int32_t B, int32_t T, int32_t D, void* stream);
+/* BitwiseHashing (model/MITH.py:276-293): out[b,k] = tanh(x[b,k,:] . w[k,:] + bias[k]). */
+int cmh_bitwise_hash(const float* x, const float* w, const float* bias, float* out, int32_t B, int32_t K,
+                     int32_t D, void* stream);
+/* F.normalize(x, dim=-1) (eps 1e-12) over rows of x f32 [R, D]. */
+int cmh_l2_normalize_rows(const float* x, float* y, int32_t R, int32_t D, void* stream);
+/* B = sign(lambda*(img_cls+txt_cls) + (1-lambda)*(img_tok+txt_tok)); H_img = .5 img_cls + .5 img_tok; H_txt likewise
+ * (train/MITH/hash_train.py:80-83,179-180). */
+int cmh_mith_mix(const float* img_cls, const float* img_tok, const float* txt_cls, const float* txt_tok,
+                 float hyper_lambda, float* B_codes, float* H_img, float* H_txt, int64_t n, void* stream);
+/* out[0] = sum (a-b)^2   (F.mse_loss(reduction='sum'): quantisation and distillation terms, :146-147,193-200). */
+int cmh_sq_diff_sum(const float* a, const float* b, int64_t n, float* out, void* workspace, size_t workspace_bytes,
+                    void* stream);
+/* bayesian_loss (train/MITH/hash_train.py:138-144) of a memory bank [Mb,K] against the batch codes [B,K] with
+ * label_sim = (bank_label . label^T > 0) computed on the fly (bank_label f32 [Mb,C], label f32 [B,C]). */
+int cmh_mith_bayesian_loss(const float* bank, const float* batch, const float* bank_label, const float* label,
+                           int32_t Mb, int32_t B, int32_t K, int32_t C, float* out, void* workspace,
+                           size_t workspace_bytes, void* stream);
+/* Symmetric InfoNCE with diagonal targets inside groups of G consecutive rows: G = R reproduces info_nce_loss
+ * (:103-114), a/b = [N*L, D] with G = L reproduces info_nce_loss_bmm (:116-136). */
+int cmh_info_nce(const float* a, const float* b, int32_t R, int32_t G, int32_t D, float temperature, float* out,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,102 @@
+"""MITH on the GPU: token-returning trunk (a5), HashingModel (a8) and the loss groups (a13) vs goldens produced by the
+reference's model/MITH.py and train/MITH/hash_train.py."""
+import argparse
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+import mithutil as mu
+import recipe
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def test_trunk_returns_all_tokens(golden):
+    from model.MITH import build_model
+    g = golden("mith.npz")
+    cfg, seed = mu.CLIP_TINY512, 7
+    clip = build_model({k: torch.from_numpy(v) for k, v in recipe.clip_state_dict(cfg, seed).items()}).to(DEV).float()
+    image = tt(recipe.images(3, cfg["image_resolution"], seed))
+    text = recipe.captions(3, 16, cfg["vocab_size"], seed)
+    with torch.no_grad():
+        seq_i, aw, cls_i = clip.encode_image(image)
+        seq_t, _, new_kpm, eos = clip.encode_text(tt(text), tt(text == 0))
+    assert aw is None and seq_i.shape == (4, 3, 512) and seq_t.shape == (16, 3, 512) and new_kpm.dtype == torch.bool
+    tol = dict(rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(seq_i.cpu().numpy(), g["trunk_seq_i"], **tol)
+    np.testing.assert_allclose(cls_i.cpu().numpy(), g["trunk_cls_i"], **tol)
+    # padded positions attend to nothing meaningful upstream either; compare the rows a caption really has + EOS
+    valid = (text != 0).T
+    np.testing.assert_allclose(seq_t.cpu().numpy()[valid], g["trunk_seq_t"][valid], **tol)
+    np.testing.assert_allclose(eos.cpu().numpy(), g["trunk_eos_t"], **tol)
+
+
+@pytest.mark.parametrize("Nb,L,K", [(3, 12, 16), (4, 32, 64)])
+def test_hashing_model_matches_reference(golden, Nb, L, K):
+    from model.MITH import HashingModel
+    g = golden("mith.npz")
+    tag = f"N{Nb}_L{L}_K{K}"
+    hm = HashingModel(clip_embed_dim=512, args=SimpleNamespace(output_dim=K, **mu.ARGS))
+    ref_keys = sorted(str(k) for k in g[f"{tag}_keys"])
+    assert sorted(hm.state_dict().keys()) == ref_keys            # state_dict contract incl. shared gcl_i/gcl_t and pe buffers
+    st = mu.fill_state({k: tuple(v.shape) for k, v in hm.state_dict().items()}, 100 + K)
+    hm.load_state_dict({k: (torch.from_numpy(st[k]) if k in st else v) for k, v in hm.state_dict().items()})
+    hm = hm.to(DEV).eval()
+    c = mu.hash_inputs(Nb, L, K)
+    with torch.no_grad():
+        od = hm(tt(c["img_tokens"]), tt(c["txt_tokens"]), tt(c["img_cls"]), tt(c["txt_eos"]), tt(c["kpm"]))
+    assert od["trans_tokens_i"].shape == (K, Nb, 512) and od["img_tokens_hash"].shape == (Nb, K)
+    for k, v in od.items():
+        v = v.cpu().numpy()
+        if k.startswith("trans_tokens") and K == 64:
+            v = v[::4]
+        np.testing.assert_allclose(v, g[f"{tag}_{k}"], rtol=2e-3, atol=2e-4, err_msg=k)
+
+
+@pytest.mark.parametrize("Nb,K,C,Mb", [(8, 16, 24, 50), (16, 64, 80, 200)])
+def test_losses_match_reference(golden, Nb, K, C, Mb):
+    from train.MITH.hash_train import MITHTrainer
+    g = golden("mith.npz")
+    tag = f"loss_N{Nb}_K{K}"
+    od, banks, label, train_labels = mu.loss_inputs(Nb, K, C, Mb)
+    self = SimpleNamespace(args=SimpleNamespace(**mu.HP), rank=0, k_bits=K, train_labels=tt(train_labels),
+                           img_buffer_tokens=tt(banks["img_tokens"]), img_buffer_cls=tt(banks["img_cls"]),
+                           txt_buffer_tokens=tt(banks["txt_tokens"]), txt_buffer_cls=tt(banks["txt_cls"]),
+                           model=SimpleNamespace(hash=SimpleNamespace(img_concept_proj=SimpleNamespace(weight=torch.zeros(1)))))
+    for name in ("bayesian_loss", "info_nce_loss", "info_nce_loss_bmm", "quantization_loss_2", "make_B"):
+        setattr(self, name, (lambda n: (lambda *a, **k: getattr(MITHTrainer, n)(self, *a, **k)))(name))
+    tod = {k: tt(v) for k, v in od.items()}
+    with torch.no_grad():
+        Bc, _, _ = self.make_B(tod)
+        L = MITHTrainer.compute_loss(self, tod, tt(label))
+    np.testing.assert_array_equal(Bc.cpu().numpy(), g[f"{tag}_B"])
+    for k, v in L.items():
+        ref = float(g[f"{tag}_{k}"])
+        assert abs(float(v) - ref) < 1e-4 * max(1.0, abs(ref)), (k, float(v), ref)
+
+
+def test_mith_trainer_end_to_end(tmp_path, monkeypatch):
+    import dataset.synthetic as ds
+    import main
+    ck = tmp_path / "clip.pt"
+    torch.save({k: torch.from_numpy(v) for k, v in recipe.clip_state_dict(mu.CLIP_TINY512, 7).items()}, ck)
+    monkeypatch.setattr(ds, "SOT", 510); monkeypatch.setattr(ds, "EOT", 511)
+    monkeypatch.setattr(sys, "argv", ["main.py", "-clip-path", str(ck), "--save-dir", str(tmp_path), "--batch-size", "8",
+                                      "--num-workers", "0", "--resolution", "64", "--max-words", "16", "--query-num", "16",
+                                      "--train-num", "24", "--synthetic-size", "64", "--epochs", "0"])
+    tr = main.trainers["MITH"](argparse.Namespace(method="MITH", dataset="synthetic", output_dim=16, is_train=True), 0)
+    maps = tr.valid(0)
+    assert all(0.0 <= float(m) <= 1.0 for m in maps)
+    image, text, kpm, label, index = next(iter(tr.train_loader))
+    with torch.no_grad():
+        od = tr.model(image.to(DEV), text.to(DEV), kpm.to(DEV))
+        losses = tr.compute_loss(od, label)
+    assert set(losses) == {"tokens_intra_likelihood", "cls_inter_likelihood", "quantization", "infoNCE", "distillation"}
+    assert all(torch.isfinite(v).item() for v in losses.values())
+    with pytest.raises(NotImplementedError):
+        tr.train_epoch(0)

@@ -60,7 +60,9 @@ def test_registry_is_lazy_and_cli_tolerant(monkeypatch):
     t = main.trainers.get("DSPH")
     assert t.__name__ == "DSPHTrainer"
     with pytest.raises(NotImplementedError):
-        main.trainers["MITH"]
+        main.trainers["DHaPH"]
+    for m in ("DCHMT", "TwDH", "DNPH", "MITH"):
+        assert main.trainers[m].__name__.endswith("Trainer")
     # both parsers tolerate each other's flags
     monkeypatch.setattr(sys, "argv", ["main.py", "--method", "DSPH", "--dataset", "synthetic", "--output-dim", "64",
                                       "--batch-size", "8", "--alpha", "0.5"])
