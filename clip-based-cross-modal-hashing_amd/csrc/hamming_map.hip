@@ -26,6 +26,8 @@
 // LDS when the query's working set fits (N <= ~23k: MIRFlickr-scale) and in a per-workgroup slice of the
 // caller's workspace otherwise (COCO / NUS-WIDE scale).  Integer/byte work, HBM/LDS-latency bound — no
 // MFMA on purpose.
+#include <cstdlib>
+
 #include "cmh_common.h"
 
 namespace cmh {
@@ -37,6 +39,7 @@ constexpr uint32_t kIdxMask = (1u << kIdxBits) - 1;
 constexpr int kMaxWords = 64;      // K <= 2048 bits
 constexpr int kCoopMin = 2048;     // segments at least this long are partitioned by the whole workgroup
 constexpr int kLeaf = 16;          // libstdc++ _S_threshold
+constexpr int kSeqMax = 64;        // segments of 17..kSeqMax elements are finished sequentially, one lane each
 
 __device__ __forceinline__ int ekey(uint32_t e) { return static_cast<int>(e >> kIdxBits); }
 __device__ __forceinline__ int eidx(uint32_t e) { return static_cast<int>(e & kIdxMask); }
@@ -54,6 +57,7 @@ struct QueryStore {
   uint32_t* qb;       // segment queue B
   uint32_t* leafbits; // [(N+31)/32] bit x = a segment starts at x
   uint32_t* relbits;  // [(N+31)/32] bit j = database item j is relevant to the query
+  uint32_t* smallbits;// [(N+31)/32] bit x = a parked (17..kSeqMax element) segment starts at x
 };
 
 __host__ __device__ inline size_t store_words(int64_t N) {
@@ -61,7 +65,7 @@ __host__ __device__ inline size_t store_words(int64_t N) {
   const size_t tmpw = n + 2 * (n / 17) + 8;
   const size_t qw = 2 * (n / 17 + 2);
   const size_t bw = (n + 31) / 32;
-  return n + tmpw + 2 * qw + 2 * bw + 16;
+  return n + tmpw + 2 * qw + 3 * bw + 16;
 }
 
 __device__ inline QueryStore carve_store(uint32_t* base, int N) {
@@ -76,6 +80,7 @@ __device__ inline QueryStore carve_store(uint32_t* base, int N) {
   s.qb = s.qa + qw;
   s.leafbits = s.qb + qw;
   s.relbits = s.leafbits + bw;
+  s.smallbits = s.relbits + bw;
   return s;
 }
 
@@ -180,13 +185,23 @@ __device__ inline int partition_segment(const QueryStore& S, int f, int l, int l
   int b = a + per;
   b = b < l ? b : l;
 
+  // Both passes walk 4 chunks per iteration: the 4 LDS (or L2) reads are issued back to back, so their latency is paid
+  // once per 256 elements instead of once per 64 (these loops are pure latency chains otherwise).
   int cL = 0, cR = 0;
-  for (int x0 = a; x0 < b; x0 += 64) {
-    const int x = x0 + lane;
-    const bool v = x < b;
-    const int k = v ? ekey(e[x]) : 0;
-    cL += __popcll(__ballot(v && k >= p));
-    cR += __popcll(__ballot(v && k <= p));
+  for (int x0 = a; x0 < b; x0 += 256) {
+    int k[4];
+    bool v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int x = x0 + 64 * u + lane;
+      v[u] = x < b;
+      k[u] = v[u] ? ekey(e[x]) : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      cL += __popcll(__ballot(v[u] && k[u] >= p));
+      cR += __popcll(__ballot(v[u] && k[u] <= p));
+    }
   }
   int offL = 0, offR = 0, Lc = cL, Rc = cR;
   if constexpr (BLOCK) {
@@ -202,22 +217,31 @@ __device__ inline int partition_segment(const QueryStore& S, int f, int l, int l
   }
   int runL = 0, runR = 0;
   const uint64_t lt = lanemask_lt(lane);
-  for (int x0 = a; x0 < b; x0 += 64) {
-    const int x = x0 + lane;
-    const bool v = x < b;
-    const int k = v ? ekey(e[x]) : 0;
-    const bool isL = v && k >= p, isR = v && k <= p;
-    const uint64_t mL = __ballot(isL), mR = __ballot(isR);
-    if (isL) {
-      const int rk = offL + runL + __popcll(mL & lt);
-      if (rk < cap) tL[rk] = static_cast<uint32_t>(x);
+  for (int x0 = a; x0 < b; x0 += 256) {
+    int k[4];
+    bool v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int x = x0 + 64 * u + lane;
+      v[u] = x < b;
+      k[u] = v[u] ? ekey(e[x]) : 0;
     }
-    if (isR) {   // R is ordered by DEscending position
-      const int rk = offR + (cR - 1 - (runR + __popcll(mR & lt)));
-      if (rk < cap) tR[rk] = static_cast<uint32_t>(x);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int x = x0 + 64 * u + lane;
+      const bool isL = v[u] && k[u] >= p, isR = v[u] && k[u] <= p;
+      const uint64_t mL = __ballot(isL), mR = __ballot(isR);
+      if (isL) {
+        const int rk = offL + runL + __popcll(mL & lt);
+        if (rk < cap) tL[rk] = static_cast<uint32_t>(x);
+      }
+      if (isR) {   // R is ordered by DEscending position
+        const int rk = offR + (cR - 1 - (runR + __popcll(mR & lt)));
+        if (rk < cap) tR[rk] = static_cast<uint32_t>(x);
+      }
+      runL += __popcll(mL);
+      runR += __popcll(mR);
     }
-    runL += __popcll(mL);
-    runR += __popcll(mR);
   }
   if constexpr (BLOCK) {
     if (wid == 0 && lane == 0) cnt[2 * NWAVE] = 0;
@@ -252,11 +276,64 @@ __device__ inline int partition_segment(const QueryStore& S, int f, int l, int l
   return cut;
 }
 
-__device__ __forceinline__ void push_seg(uint32_t* q, int* qcount, int f, int l) {
-  if (l - f > kLeaf) {
+// Children of a partition: > kSeqMax elements -> next breadth-first level; 17..kSeqMax -> parked for the sequential
+// finisher (start bit in smallbits, (end, depth budget) in the segment's own slice of tmp); <= 16 -> leaf.
+__device__ __forceinline__ void push_seg(const QueryStore& S, uint32_t* q, int* qcount, int f, int l, int depth) {
+  const int n = l - f;
+  if (n > kSeqMax) {
     const int i = atomicAdd(qcount, 1);
     q[2 * i] = static_cast<uint32_t>(f);
     q[2 * i + 1] = static_cast<uint32_t>(l);
+  } else if (n > kLeaf) {
+    uint32_t* slot = S.tmp + tmp_base(f);
+    slot[0] = static_cast<uint32_t>(l);
+    slot[1] = static_cast<uint32_t>(depth);
+    atomicOr(&S.smallbits[f >> 5], 1u << (f & 31));
+  }
+}
+
+// std::__unguarded_partition_pivot, sequential (one lane), exactly as libstdc++ walks it.
+__device__ inline int seq_partition_pivot(uint32_t* e, int first, int last) {
+  median_to_first(e, first, last);
+  const int pk = ekey(e[first]);
+  int i = first + 1, j = last;
+  while (true) {
+    while (ekey(e[i]) < pk) ++i;
+    --j;
+    while (pk < ekey(e[j])) --j;
+    if (!(i < j)) return i;
+    const uint32_t t = e[i];
+    e[i] = e[j];
+    e[j] = t;
+    ++i;
+  }
+}
+
+// std::__introsort_loop + the final insertion sort, restricted to one parked segment [f,l) (17..kSeqMax elements) and run by
+// ONE lane: small segments are latency chains, so a wave finishes 64 of them side by side instead of spending a whole
+// ballot/scan round trip on each.  Explicit stack (packed first|last|depth, relative to f) in the segment's tmp slice:
+// it never holds more than min(depth, n-16) <= n entries.
+__device__ inline void seq_finish_segment(uint32_t* e, uint32_t* stack, int f, int l, int depth) {
+  // entries: bits 0..7 first, 8..15 last (last <= kSeqMax = 128 < 256), 16..31 depth budget
+  int sp = 1;
+  stack[0] = 0u | (static_cast<uint32_t>(l - f) << 8) | (static_cast<uint32_t>(depth) << 16);
+  while (sp > 0) {
+    const uint32_t ent = stack[--sp];
+    int a = static_cast<int>(ent & 0xffu), b = static_cast<int>((ent >> 8) & 0xffu), d = static_cast<int>(ent >> 16);
+    while (b - a > kLeaf) {
+      if (d == 0) { heap_sort_segment(e, f + a, f + b); break; }
+      --d;
+      const int cut = seq_partition_pivot(e, f + a, f + b) - f;
+      stack[sp++] = static_cast<uint32_t>(cut) | (static_cast<uint32_t>(b) << 8) | (static_cast<uint32_t>(d) << 16);
+      b = cut;
+    }
+  }
+  for (int i = f + 1; i < l; ++i) {   // std::__final_insertion_sort == stable insertion sort of the nearly sorted range
+    const uint32_t v = e[i];
+    const int kv = ekey(v);
+    int j = i;
+    while (j > f && kv < ekey(e[j - 1])) { e[j] = e[j - 1]; --j; }
+    e[j] = v;
   }
 }
 
@@ -269,6 +346,7 @@ struct MapArgs {
   float* ap;
   int32_t* perm;              // may be null
   uint32_t* gstore;           // global slices (USE_LDS=false): gridDim.x * store_words(N)
+  unsigned long long* stamps; // optional: 6 cycle stamps of (workgroup 0, first query) at the phase boundaries (diagnostics)
 };
 
 template <bool USE_LDS>
@@ -290,10 +368,11 @@ __global__ __launch_bounds__(NT) void map_query_kernel(MapArgs A) {
 
   for (int qi = blockIdx.x; qi < A.Q; qi += gridDim.x) {
     __syncthreads();
+    if (A.stamps && blockIdx.x == 0 && qi == 0 && tid == 0) A.stamps[0] = __builtin_readcyclecounter();
     // ---- phase 0: keys + relevance ---------------------------------------------------------------
     if (tid < W) { sq[0][tid] = A.q_sign[static_cast<size_t>(qi) * W + tid]; sq[1][tid] = A.q_nz[static_cast<size_t>(qi) * W + tid]; }
     if (tid < LW) sq[2][tid] = A.q_label[static_cast<size_t>(qi) * LW + tid];
-    for (int i = tid; i < bw; i += NT) { S.leafbits[i] = 0; S.relbits[i] = 0; }
+    for (int i = tid; i < bw; i += NT) { S.leafbits[i] = 0; S.relbits[i] = 0; S.smallbits[i] = 0; }
     __syncthreads();
     int myrel = 0;
     for (int j0 = 0; j0 < N; j0 += NT) {
@@ -336,6 +415,7 @@ __global__ __launch_bounds__(NT) void map_query_kernel(MapArgs A) {
       continue;
     }
 
+    if (A.stamps && blockIdx.x == 0 && qi == 0 && tid == 0) A.stamps[1] = __builtin_readcyclecounter();
     // ---- phase 1: introsort loop, breadth-first ------------------------------------------------------
     int depth = A.depth_limit >= 0 ? A.depth_limit : 2 * (31 - __clz(N));   // std::__lg(n) * 2
     uint32_t* qcur = S.qa;
@@ -343,8 +423,9 @@ __global__ __launch_bounds__(NT) void map_query_kernel(MapArgs A) {
     int cur = 0;
     if (tid == 0) {
       S.leafbits[0] = 1u;
-      if (N > kLeaf) { qcur[0] = 0; qcur[1] = static_cast<uint32_t>(N); sqcount[0] = 1; }
     }
+    __syncthreads();
+    if (tid == 0) push_seg(S, qcur, &sqcount[0], 0, N, A.depth_limit >= 0 ? A.depth_limit : 2 * (31 - __clz(N)));
     __syncthreads();
     while (true) {
       const int nseg = sqcount[cur];
@@ -363,8 +444,8 @@ __global__ __launch_bounds__(NT) void map_query_kernel(MapArgs A) {
         const int cut = partition_segment<true>(S, f, l, lane, wid, NWAVE, scnt);
         if (tid == 0) {
           atomicOr(&S.leafbits[cut >> 5], 1u << (cut & 31));
-          push_seg(qnxt, &sqcount[cur ^ 1], f, cut);
-          push_seg(qnxt, &sqcount[cur ^ 1], cut, l);
+          push_seg(S, qnxt, &sqcount[cur ^ 1], f, cut, depth);
+          push_seg(S, qnxt, &sqcount[cur ^ 1], cut, l, depth);
         }
       }
       // the rest: one wave per segment
@@ -374,8 +455,8 @@ __global__ __launch_bounds__(NT) void map_query_kernel(MapArgs A) {
         const int cut = partition_segment<false>(S, f, l, lane, 0, 1, nullptr);
         if (lane == 0) {
           atomicOr(&S.leafbits[cut >> 5], 1u << (cut & 31));
-          push_seg(qnxt, &sqcount[cur ^ 1], f, cut);
-          push_seg(qnxt, &sqcount[cur ^ 1], cut, l);
+          push_seg(S, qnxt, &sqcount[cur ^ 1], f, cut, depth);
+          push_seg(S, qnxt, &sqcount[cur ^ 1], cut, l, depth);
         }
       }
       __syncthreads();
@@ -384,6 +465,21 @@ __global__ __launch_bounds__(NT) void map_query_kernel(MapArgs A) {
     }
     __syncthreads();
 
+    if (A.stamps && blockIdx.x == 0 && qi == 0 && tid == 0) A.stamps[2] = __builtin_readcyclecounter();
+    // ---- phase 1b: parked segments (17..kSeqMax elements): the rest of their introsort + insertion sort, one lane each
+    for (int wi = tid; wi < bw; wi += NT) {
+      uint32_t bitsw = S.smallbits[wi];
+      while (bitsw) {
+        const int f = wi * 32 + __ffs(bitsw) - 1;
+        bitsw &= bitsw - 1;
+        uint32_t* slot = S.tmp + tmp_base(f);
+        const int l = static_cast<int>(slot[0]), d = static_cast<int>(slot[1]);
+        seq_finish_segment(e, slot, f, l, d);
+      }
+    }
+    __syncthreads();
+
+    if (A.stamps && blockIdx.x == 0 && qi == 0 && tid == 0) A.stamps[3] = __builtin_readcyclecounter();
     // ---- phase 2: final insertion sort == stable sort of each <=16-element leaf ---------------------------
     for (int wi = tid; wi < bw; wi += NT) {
       uint32_t bitsw = S.leafbits[wi];
@@ -407,6 +503,7 @@ __global__ __launch_bounds__(NT) void map_query_kernel(MapArgs A) {
     }
     __syncthreads();
 
+    if (A.stamps && blockIdx.x == 0 && qi == 0 && tid == 0) A.stamps[4] = __builtin_readcyclecounter();
     // ---- phase 3: AP = mean_{r<=total} r / position_r   (utils/calc_utils.py:33-37) -----------------------
     const long long total = A.topk > 0 && A.topk < tsum ? A.topk : tsum;
     const int per = (((N + NWAVE - 1) / NWAVE) + 63) & ~63;
@@ -447,6 +544,7 @@ __global__ __launch_bounds__(NT) void map_query_kernel(MapArgs A) {
       double t = 0.0;
       for (int w = 0; w < NWAVE; ++w) t += sred[w];
       A.ap[qi] = static_cast<float>(t / static_cast<double>(total));
+      if (A.stamps && blockIdx.x == 0 && qi == 0) A.stamps[5] = __builtin_readcyclecounter();
     }
   }
 }
@@ -615,6 +713,7 @@ extern "C" int cmh_hamming_map(const uint32_t* q_sign, const uint32_t* q_nz, con
   a.Q = Q; a.N = static_cast<int>(N); a.bits = bits; a.W = (bits + 31) / 32; a.LW = (classes + 31) / 32;
   a.topk = topk; a.depth_limit = depth_limit_override; a.ap = ap; a.perm = perm;
   a.gstore = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+  a.stamps = getenv("CMH_MAP_STAMPS") ? reinterpret_cast<unsigned long long*>(a.gstore) : nullptr;   // LDS mode only: slice 0 unused
   const size_t lds = lds_bytes_needed(N);
   if (lds <= kLdsBudget) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(map_query_kernel<true>),
