@@ -110,9 +110,10 @@ def main():
     from model.modelbase import LinearHash
     from train.DSPH.loss import HyP
 
-    rank, world, local = du.init_from_env()
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
+    rank, world, _ = du.init_from_env()
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local)
     B, L, K, C = a.batch, a.seq_len, a.bits, a.classes
 

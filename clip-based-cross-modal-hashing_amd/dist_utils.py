@@ -25,8 +25,13 @@ def init_from_env(backend: str | None = None):
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            backend = os.environ.get("CMH_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {}
+        if backend == "nccl":      # bind the communicator to this rank's GPU up front (one process per GPU)
+            ndev = max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(local % ndev)
+            kw["device_id"] = torch.device("cuda", local % ndev)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 
