@@ -13,7 +13,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "build", "libcmh.so")
+LIB_PATH = os.environ.get("CMH_LIB") or os.path.join(_HERE, "csrc", "build", "libcmh.so")   # CMH_LIB: A/B a kernel build
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2

@@ -230,9 +230,10 @@ int launch_gemm(int dt, const void* A, const void* W, const float* bias, const f
   if (timed) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
   static const int impl = gemm_impl_from_env();
   static const bool wide = []() { const char* e = getenv("CMH_GEMM_WIDE"); return !(e && !strcmp(e, "0")); }();
-  if (impl == 1 && wide && gemm_wide_supported(N))
-    launch_gemm_wide(dt, A, W, bias, residual, out, M, N, K, epi, st);
-  else if (impl == 1)
+  if (impl == 1 && wide && gemm_wide_supported(N)) {
+    const int rc = launch_gemm_wide(dt, A, W, bias, residual, out, M, N, K, epi, st);
+    if (rc) return rc;
+  } else if (impl == 1)
     launch_gemm_glds(dt, A, W, bias, residual, out, M, N, K, epi, st);
   else if (dt == CMH_F32)
     hipLaunchKernelGGL(gemm_kernel<true>, dim3(total), dim3(256), 0, st, static_cast<const char*>(A),

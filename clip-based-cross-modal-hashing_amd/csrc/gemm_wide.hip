@@ -12,19 +12,25 @@
 //     being multiplied; waits are COUNTED (s_waitcnt vmcnt(pieces of one stage)), the barrier is a raw s_barrier,
 //     so LDS-DMA stays in flight across barriers (cdna guide §5 "Pipelining across barriers").
 // Why persistent.  With K = 512/768 a tile has only 8-12 K-steps and the non-overlapped per-tile cost (workgroup
-// launch, cold prologue DMA, epilogue store drain; ~12 us measured vs ~1.2 us per K-step) was ~45 % of the time.
-// Here the K-steps of ALL tiles of a workgroup form one flat pipeline: the first two stages of the next tile are
-// issued during the last two K-steps of the current one and land while its epilogue runs.
+// launch, cold prologue DMA, epilogue) was ~45 % of the time.  Here the K-steps of ALL tiles of a workgroup form one
+// flat pipeline: the first stages of the next tile are issued during the last K-steps of the current one.
+// Why deferred stores.  A CU drains stores at only ~10 B/clk: the 80 KB of a bf16 tile take ~4 us if the waves sit in
+// the epilogue until their stores are accepted (measured by ablation: 727 -> 1000 TF/s without stores).  So a tile's
+// packed outputs stay in 40 VGPRs and leave one 16-byte store per wave per K-step UNDER the next tile's MFMAs; only a
+// workgroup's last tile (and f32 / partial tiles) stores from the epilogue.
 // Everything else as in gemm_glds.hip: W rows feed the MFMA A operand (lane owns 4 consecutive n), lane-linear LDS
 // image with the XOR swizzle on the DMA source chunk and on the ds_read_b128, fused epilogue, XCD-aware tile order
 // (workgroups with equal blockIdx%8 share an XCD and take neighbouring tiles of one contiguous range, n fastest).
 #include "cmh_common.h"
+
+#include <type_traits>
 
 namespace cmh {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 w_bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float w_f32x4_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t w_u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned w_u2_t;
 
 constexpr int wBM = 160, wBN = 256;
 constexpr int wRowBytes = 128;
@@ -32,6 +38,7 @@ constexpr int wWBytes = wBN * wRowBytes;            // 32 KB
 constexpr int wXBytes = wBM * wRowBytes;            // 20 KB
 constexpr int wStageBytes = wWBytes + wXBytes;      // 52 KB
 constexpr int wXPieces = wBM / 8;                   // 20 pieces of 1 KiB
+constexpr int wPend = 10;                           // deferred 16-byte stores per lane per tile (5 m-tiles x 2 column pairs)
 
 __device__ __forceinline__ int w_swz(int row, int chunk) { return row * wRowBytes + ((chunk ^ (row & 7)) << 4); }
 // x * sigmoid(1.702 x) with v_exp + v_rcp (1 ulp) instead of an IEEE division (~10 VALU ops): the epilogue applies it to
@@ -43,7 +50,7 @@ __device__ __forceinline__ float w_quick_gelu(float v) {
 typedef const __attribute__((address_space(1))) void* w_gptr_t;
 typedef __attribute__((address_space(3))) void* w_lptr_t;
 
-template <bool F32>
+template <bool F32, bool OUTBF>
 __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__ X, const char* __restrict__ W,
                                                         const float* __restrict__ bias, const float* residual,
                                                         void* out, int M, int N, int K, int epi) {
@@ -73,95 +80,132 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   if (my_tiles == 0) return;
 
   const int nk = K / BK;
-  const size_t row_stride = static_cast<size_t>(K) * ELT;
-  const int total_steps = my_tiles * nk;
+  const uint32_t row_stride = static_cast<uint32_t>(K) * ELT;
 
-  // ---- issue side: DMA source pointers of the tile currently being staged ----------------------------------
-  const char* gW[4];
-  const char* gX[3];
+  // ---- issue side.  DMA source = uniform tile base (SGPRs) + 32-bit per-lane offset (one VGPR per piece):
+  // lane i of a 1-KiB piece fills LDS (row 8*piece + i/8, physical chunk i%8) and fetches logical chunk (i%8)^(row&7).
+  uint32_t offW[4], offX[3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wid * 4 + i) * 8 + sub;
+    offW[i] = static_cast<uint32_t>(row) * row_stride + (((lane & 7) ^ (row & 7)) << 4);
+  }
+  const char* Wt = W;   // W + n0*row_stride of the tile being staged
   auto set_issue_tile = [&](int ti) {
     const int logical = range_lo + slot + ti * per_xcd_blocks;
     const int tm = logical / tiles_n, tn = logical - tm * tiles_n;
     const int m0 = tm * wBM, n0 = tn * wBN;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (wid * 4 + i) * 8 + sub;
-      gW[i] = W + static_cast<size_t>(n0 + row) * row_stride + (((lane & 7) ^ (row & 7)) << 4);
-    }
+    Wt = W + static_cast<size_t>(n0) * row_stride;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int row = (wid + 8 * i) * 8 + sub;
       int xr = m0 + row;
       xr = xr < M ? xr : M - 1;   // rows past M are computed on duplicated data and never stored
-      gX[i] = X + static_cast<size_t>(xr) * row_stride + (((lane & 7) ^ (row & 7)) << 4);
+      offX[i] = static_cast<uint32_t>(xr) * row_stride + (((lane & 7) ^ (row & 7)) << 4);   // < 4 GiB: M*K*ELT checked on host
     }
   };
-  int issued = 0, issue_kt = 0, issue_tile = 0, issue_buf = 0;
-  auto issue_next = [&]() {
-    if (issued >= total_steps) return;
+  int issue_kt = 0, issue_tile = 0, issue_buf = 0;
+  auto issue_piece = [&](int p) {   // p is a compile-time constant at every call site
     char* base = lds + issue_buf * wStageBytes;
     const size_t koff = static_cast<size_t>(issue_kt) * wRowBytes;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((w_gptr_t)(gW[i] + koff), (w_lptr_t)(base + (wid * 4 + i) * 1024), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((w_gptr_t)(gX[i] + koff), (w_lptr_t)(base + wWBytes + (wid + 8 * i) * 1024), 16, 0, 0);
-    if (three)
-      __builtin_amdgcn_global_load_lds((w_gptr_t)(gX[2] + koff), (w_lptr_t)(base + wWBytes + (wid + 16) * 1024), 16, 0, 0);
-    ++issued;
+    if (p < 4)
+      __builtin_amdgcn_global_load_lds((w_gptr_t)(Wt + koff + offW[p]), (w_lptr_t)(base + (wid * 4 + p) * 1024), 16, 0, 0);
+    else if (p < 6)
+      __builtin_amdgcn_global_load_lds((w_gptr_t)(X + koff + offX[p - 4]),
+                                       (w_lptr_t)(base + wWBytes + (wid + 8 * (p - 4)) * 1024), 16, 0, 0);
+    else if (three)
+      __builtin_amdgcn_global_load_lds((w_gptr_t)(X + koff + offX[2]), (w_lptr_t)(base + wWBytes + (wid + 16) * 1024), 16, 0, 0);
+  };
+  // The K loop below is ONE straight-line steady state: it issues a stage in every K-step.  The three stages issued past
+  // the workgroup's last one re-stage its last tile into buffers nobody reads any more (drained before the kernel ends).
+  auto issue_done = [&]() {
     issue_buf = issue_buf == 2 ? 0 : issue_buf + 1;
     if (++issue_kt == nk) {
       issue_kt = 0;
       if (++issue_tile < my_tiles) set_issue_tile(issue_tile);
     }
   };
+  auto issue_stage = [&]() {
+#pragma unroll
+    for (int p = 0; p < 7; ++p) issue_piece(p);
+    issue_done();
+  };
 
-  // ---- rotated, software-pipelined K loop --------------------------------------------------------------------
-  // Per K-step s (stage s in LDS buffer s%3), with F0 = fragments of (s, k 0..31) already in registers:
-  //   1. issue the ds_reads of F1 = (s, k 32..63)
-  //   2. 20 MFMAs on F0                                    <- cover the F1 reads
-  //   3. lgkmcnt(0) (own F1 reads done), vmcnt: stage s+1 landed (stage s+2 may stay in flight), s_barrier
-  //      -> every wave has finished reading buffer s%3 and sees stage s+1
-  //   4. LDS-DMA of stage s+3 into buffer s%3              <- two full K-steps of flight
-  //   5. issue the ds_reads of F0' = (s+1, k 0..31)
-  //   6. 20 MFMAs on F1                                    <- cover the F0' reads and the DMA issue
-  // Fragment reads are inline asm so that THEIR waits are ours: hipcc's own bookkeeping turns any ds_read that is
-  // still pending at a loop back-edge into s_waitcnt lgkmcnt(0) in front of the next MFMA block, which would serialise
-  // reads and MFMAs.  The waits below are counted (LDS returns in order) and carry the fragment registers as "+v"
-  // operands, so no MFMA that consumes them can be scheduled above the wait (cdna guide §5.4 rule 18).
+  // ---- fragment reads: inline asm (their waits are ours, see W_WAIT_FRAGS) with immediate offsets: the 16-row fragment
+  // tiles of one operand sit 2048 bytes apart, the second 32-deep half is the first one's address XOR 64.
   const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((w_lptr_t)lds));
+  const uint32_t aW = lds_base + w_swz(wn * 64 + frow, fq);
+  const uint32_t aX = lds_base + wWBytes + w_swz(wm * 80 + frow, fq);
+#define W_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
   auto load_frags = [&](w_u32x4_t (&fw)[4], w_u32x4_t (&fx)[5], int buf, int ks) {
-    const uint32_t tW = lds_base + buf * wStageBytes;
-    const uint32_t tX = tW + wWBytes;
-    const int chunk = ks * 4 + fq;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-      asm volatile("ds_read_b128 %0, %1" : "=v"(fw[t]) : "v"(tW + w_swz(wn * 64 + t * 16 + frow, chunk)));
-#pragma unroll
-    for (int t = 0; t < 5; ++t)
-      asm volatile("ds_read_b128 %0, %1" : "=v"(fx[t]) : "v"(tX + w_swz(wm * 80 + t * 16 + frow, chunk)));
+    const uint32_t bo = static_cast<uint32_t>(buf) * wStageBytes;
+    const uint32_t w = (aW + bo) ^ (ks ? 64u : 0u), x = (aX + bo) ^ (ks ? 64u : 0u);
+    W_READ(fw[0], w, 0); W_READ(fw[1], w, 2048); W_READ(fw[2], w, 4096); W_READ(fw[3], w, 6144);
+    W_READ(fx[0], x, 0); W_READ(fx[1], x, 2048); W_READ(fx[2], x, 4096); W_READ(fx[3], x, 6144); W_READ(fx[4], x, 8192);
   };
 #define W_WAIT_FRAGS(cnt, fw, fx)                                                                              \
   asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                                   \
                : "+v"(fw[0]), "+v"(fw[1]), "+v"(fw[2]), "+v"(fw[3]), "+v"(fx[0]), "+v"(fx[1]), "+v"(fx[2]),    \
                  "+v"(fx[3]), "+v"(fx[4])::"memory")
 
+  // ---- deferred stores of the previous tile (bf16 outputs only) --------------------------------------------
+  w_u32x4_t pend[wPend];
+  bool pend_valid = false;
+  bf16_t* pend_ptr = nullptr;          // &out[(m0 + wm*80 + frow) * N + col] of the pending tile
+  const size_t row16 = static_cast<size_t>(16) * N;
+  const int sps = (wPend + nk - 1) / nk;   // stores per K-step so that all 10 leave within one tile's K loop
+  auto store_pending = [&](int idx) {
+    switch (idx) {   // compile-time register choice per case: no dynamically indexed vector arrays (they would go to scratch)
+#define W_ST(j) case j: *reinterpret_cast<w_u32x4_t*>(pend_ptr + (j / 2) * row16 + (j % 2) * 32) = pend[j]; break;
+      W_ST(0) W_ST(1) W_ST(2) W_ST(3) W_ST(4) W_ST(5) W_ST(6) W_ST(7) W_ST(8) W_ST(9)
+#undef W_ST
+      default: break;
+    }
+  };
+
+  // ---- rotated, software-pipelined K loop --------------------------------------------------------------------
+  // Per K-step s (stage s in LDS buffer s%3), with F0 = fragments of (s, k 0..31) already in registers:
+  //   1. issue the ds_reads of F1 = (s, k 32..63)
+  //   2. 20 MFMAs on F0 (+ up to `sps` deferred stores of the previous tile)
+  //   3. lgkmcnt(0) (own F1 reads done), vmcnt: stage s+1 landed (stage s+2 and this step's stores may stay in flight),
+  //      s_barrier -> every wave has finished reading buffer s%3 and sees stage s+1
+  //   4.-6. LDS-DMA of stage s+3 into buffer s%3 (two full K-steps of flight), the ds_reads of F0' = (s+1, k 0..31) and
+  //      the 20 MFMAs on F1, interleaved: one DMA piece / one read per 3 MFMAs.  Issued as one burst, the 52 pieces of a
+  //      stage queue up in the CU's address path and every wave sits in a VMEM issue stall while the matrix pipe idles.
+  // Anti-phase issue.  Waves w and w+4 share a SIMD and, released by the same barrier, would run the same instructions
+  // at the same time: both stuck in the ~100-cycle issue of an LDS-DMA piece (the CU's address path moves 64 B/clk) with
+  // the matrix pipe idle.  So group A (waves 0..3) issues its pieces of stage s+3 among the MFMAs of the SECOND half of
+  // K-step s and group B (waves 4..7) among those of the FIRST half of K-step s+1 (and its deferred stores in the other
+  // half): while one wave of a SIMD waits on the address path its partner streams MFMAs.
+  const bool group_b = wid >= 4;
   set_issue_tile(0);
-  issue_next();
-  issue_next();
-  issue_next();
-  // stage 0 landed (two younger stages may fly), visible to everyone
-  if (issued >= 3) {
-    if (three) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  issue_stage();
+  issue_stage();
+  if (!group_b) {
+    issue_stage();
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // stage 0 landed (two younger stages of >= 6 pieces may fly)
   } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // group B issues stage 2 in the first half of K-step 0
   }
   __builtin_amdgcn_s_barrier();
 
-  int consumed = 0, cur = 0;
-  int since_epi = 2, epi_stores = 0;   // K-steps since the last epilogue / store instructions it issued per wave
+  auto mfma = [&](const w_u32x4_t& fw, const w_u32x4_t& fx, w_f32x4_t& c) {
+    if constexpr (F32) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fw[s]), __uint_as_float(fx[s]), c, 0, 0, 0);
+    } else {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(w_bf16x8_t, fw), __builtin_bit_cast(w_bf16x8_t, fx), c,
+                                                  0, 0, 0);
+    }
+  };
+
+  auto run = [&](auto gb) {
+  constexpr bool GB = decltype(gb)::value;
+  int cur = 0;
+  int ns = 0;                   // deferred stores issued since the last counted wait
+  w_u32x4_t f0w[4], f0x[5], f1w[4], f1x[5];
+  load_frags(f0w, f0x, 0, 0);   // from here on F0 of K-step s+1 (also across tiles) is fetched in the second half of s
   for (int ti = 0; ti < my_tiles; ++ti) {
     w_f32x4_t acc[4][5];   // [n-tile][m-tile]
 #pragma unroll
@@ -169,122 +213,84 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
 #pragma unroll
       for (int b = 0; b < 5; ++b) acc[a][b] = w_f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    w_u32x4_t f0w[4], f0x[5], f1w[4], f1x[5];
-    load_frags(f0w, f0x, cur, 0);
-
-    auto mma = [&](const w_u32x4_t (&fw)[4], const w_u32x4_t (&fx)[5]) {
-      if constexpr (F32) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 5; ++b)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fw[a][s]), __uint_as_float(fx[b][s]),
-                                                               acc[a][b], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 5; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(w_bf16x8_t, fw[a]),
-                                                                __builtin_bit_cast(w_bf16x8_t, fx[b]), acc[a][b], 0, 0, 0);
-      }
-    };
-
     for (int kt = 0; kt < nk; ++kt) {
+#ifndef W_ABL_NOREAD
       load_frags(f1w, f1x, cur, 1);                                   // 1
+#endif
       W_WAIT_FRAGS(9, f0w, f0x);                                      //    F0 (older than the 9 F1 reads) is in registers
       __builtin_amdgcn_sched_barrier(0);
-      mma(f0w, f0x);                                                  // 2
-      __builtin_amdgcn_sched_barrier(0);
-      // 3: own LDS reads done; stage consumed+1 landed, at most one younger stage still in flight.  (Epilogue stores of
-      //    a previous tile are younger than the DMAs: the counted wait then retires the DMAs as well - safe.)
-      W_WAIT_FRAGS(0, f1w, f1x);
-      {
-        // vmcnt is ONE in-order queue of loads, stores and LDS-DMA.  Younger than the stage we need are: one more
-        // stage (P pieces) if the pipeline is still being fed, and - during the first two K-steps after an epilogue -
-        // that epilogue's S stores (the stage we need was issued before them).  Allowing exactly P+S outstanding
-        // lets the stores drain behind the MFMAs instead of stalling every wave at the barrier.
-        const int allow = (issued - consumed > 2 ? (three ? 7 : 6) : 0) + (since_epi < 2 ? epi_stores : 0);
-        ++since_epi;
-        switch (allow) {
-          case 27: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
-          case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
-          case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-          case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
-          case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-          case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-          case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-          case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-          default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      auto deferred_stores = [&]() {
+        if constexpr (OUTBF) {
+          if (pend_valid) {
+            for (int j = 0; j < sps; ++j) {
+              const int idx = kt * sps + j;
+              if (idx < wPend) { store_pending(idx); ++ns; }
+            }
+          }
         }
+      };
+      if constexpr (!GB) deferred_stores();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 20; ++i) {                                  // 2
+#ifndef W_ABL_NODMA
+        if constexpr (GB) { if (i % 3 == 0) issue_piece(i / 3); }
+#endif
+        mfma(f0w[i / 5], f0x[i % 5], acc[i / 5][i % 5]);
+        if constexpr (GB) { if (i % 3 == 2) __builtin_amdgcn_sched_barrier(0); }
       }
+      if constexpr (GB) issue_done();
+      __builtin_amdgcn_sched_barrier(0);
+      // 3: vmcnt is ONE in-order queue of loads, stores and LDS-DMA.  Younger than the stage we need: one more stage
+      //    (>= 6 pieces per wave) and the `ns` deferred stores issued since the last wait.  Every taken branch costs the
+      //    wave ~16 issue cycles, hence the short decision tree instead of a switch over all counts; a smaller count is
+      //    always safe.
+      W_WAIT_FRAGS(0, f1w, f1x);
+      if (ns == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (ns == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      ns = 0;
       __builtin_amdgcn_s_barrier();
-      // 4-6 interleaved: one DMA piece / one fragment read between groups of 3 MFMAs.  Issued as one burst, the 52
-      // pieces of a stage queue up in the CU's address path (~16 clk each) and every wave sits in a VMEM issue stall
-      // while the matrix pipe idles; trickled in, they ride under the MFMAs.
       const int nxt = cur == 2 ? 0 : cur + 1;
-      {
-        const bool do_issue = issued < total_steps;
-        char* ibase = lds + issue_buf * wStageBytes;
-        const size_t koff = static_cast<size_t>(issue_kt) * wRowBytes;
-        const bool pref = kt + 1 < nk;
-        const uint32_t nW = lds_base + nxt * wStageBytes, nX = nW + wWBytes;
+      {                                                               // 4-6: no branches between the MFMAs
+        const uint32_t bo = static_cast<uint32_t>(nxt) * wStageBytes;
+        const uint32_t nW = aW + bo, nX = aX + bo;
+        if constexpr (GB) deferred_stores();
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 20; ++i) {
-          if (i % 3 == 0 && do_issue) {
-            const int p = i / 3;
-            if (p < 4)
-              __builtin_amdgcn_global_load_lds((w_gptr_t)(gW[p] + koff), (w_lptr_t)(ibase + (wid * 4 + p) * 1024), 16, 0, 0);
-            else if (p < 6)
-              __builtin_amdgcn_global_load_lds((w_gptr_t)(gX[p - 4] + koff),
-                                               (w_lptr_t)(ibase + wWBytes + (wid + 8 * (p - 4)) * 1024), 16, 0, 0);
-            else if (three)
-              __builtin_amdgcn_global_load_lds((w_gptr_t)(gX[2] + koff), (w_lptr_t)(ibase + wWBytes + (wid + 16) * 1024), 16, 0, 0);
-          }
-          if (pref && i >= 1 && i <= 9) {
-            const int t = i - 1;
-            if (t < 4)
-              asm volatile("ds_read_b128 %0, %1" : "=v"(f0w[t]) : "v"(nW + w_swz(wn * 64 + t * 16 + frow, fq)));
-            else
-              asm volatile("ds_read_b128 %0, %1" : "=v"(f0x[t - 4]) : "v"(nX + w_swz(wm * 80 + (t - 4) * 16 + frow, fq)));
-          }
-          const int a = i / 5, b = i % 5;
-          if constexpr (F32) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(f1w[a][s]), __uint_as_float(f1x[b][s]),
-                                                               acc[a][b], 0, 0, 0);
-          } else {
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(w_bf16x8_t, f1w[a]),
-                                                                __builtin_bit_cast(w_bf16x8_t, f1x[b]), acc[a][b], 0, 0, 0);
-          }
+#ifndef W_ABL_NODMA
+          if constexpr (!GB) { if (i % 3 == 0) issue_piece(i / 3); }
+#endif
+#ifndef W_ABL_NOREAD
+          if (i == 1) W_READ(f0w[0], nW, 0);
+          if (i == 2) W_READ(f0w[1], nW, 2048);
+          if (i == 3) W_READ(f0w[2], nW, 4096);
+          if (i == 4) W_READ(f0w[3], nW, 6144);
+          if (i == 5) W_READ(f0x[0], nX, 0);
+          if (i == 6) W_READ(f0x[1], nX, 2048);
+          if (i == 7) W_READ(f0x[2], nX, 4096);
+          if (i == 8) W_READ(f0x[3], nX, 6144);
+          if (i == 9) W_READ(f0x[4], nX, 8192);
+#endif
+          mfma(f1w[i / 5], f1x[i % 5], acc[i / 5][i % 5]);
           if (i % 3 == 2) __builtin_amdgcn_sched_barrier(0);
         }
-        if (do_issue) {
-          ++issued;
-          issue_buf = issue_buf == 2 ? 0 : issue_buf + 1;
-          if (++issue_kt == nk) {
-            issue_kt = 0;
-            if (++issue_tile < my_tiles) set_issue_tile(issue_tile);
-          }
-        }
+        if constexpr (!GB) issue_done();
       }
       __builtin_amdgcn_sched_barrier(0);
-      ++consumed;
       cur = nxt;
     }
+    pend_valid = false;   // sps * nk >= 10: every deferred store of the previous tile has been issued
 
-
-    // ---- epilogue of tile ti (the next tile's first two stages are already in flight) -----------------------
+    // ---- epilogue of tile ti (the next tile's first stages are already in flight) ----------------------------
     const int logical = range_lo + slot + ti * per_xcd_blocks;
     const int tm = logical / tiles_n, tn = logical - tm * tiles_n;
     const int m0 = tm * wBM, n0 = tn * wBN;
-    // All loads first, then all stores: vmcnt counts loads, stores and LDS-DMA in one in-order queue, so a load
-    // issued behind a store (or waited for with DMA in flight) would wait for every older store to be acknowledged.
-    w_f32x4_t bv[4];
+    // All loads first, then all stores: a load issued behind a store (or waited for with DMA in flight) would wait for
+    // every older store to be acknowledged.
     if (epi & EPI_BIAS) {
+      w_f32x4_t bv[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) bv[a] = *reinterpret_cast<const w_f32x4_t*>(bias + n0 + wn * 64 + a * 16 + fq * 4);
 #pragma unroll
@@ -324,15 +330,13 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
 #pragma unroll
         for (int b = 0; b < 5; ++b) acc[a][b] += rv[a][b];
     }
-    // Stores.  Row-scattered 8-byte stores are issue-bound (measured: ~5.5 us per tile, i.e. as much as 5 K-steps),
-    // so the bf16 path first widens them: v_permlane16_swap exchanges, between the lane pairs (l, l+16), the packed
-    // words of two neighbouring n-tiles, after which an even lane-row owns 8 consecutive n of tile a and an odd
-    // lane-row 8 consecutive n of tile a+1 -> one 16-byte store per lane, half the store instructions.
-    if (epi & EPI_OUT_BF16) {
+    const bool full = m0 + wBM <= M;
+    if constexpr (OUTBF) {
+      // v_permlane16_swap exchanges, between the lane pairs (l, l+16), the packed words of two neighbouring n-tiles: an even
+      // lane-row then owns 8 consecutive n of tile a and an odd lane-row 8 consecutive n of tile a+1 -> 16-byte stores.
       const int col = n0 + wn * 64 + (fq & 1) * 16 + (fq & 2) * 4;    // + 32*pair
 #pragma unroll
       for (int b = 0; b < 5; ++b) {
-        const int m = m0 + wm * 80 + b * 16 + frow;
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
           uint32_t lo[2], hi[2];   // packed words of tiles a = 2pr (lo) and 2pr+1 (hi)
@@ -341,20 +345,25 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
             lo[w] = pack_bf16x2(acc[2 * pr][b][2 * w], acc[2 * pr][b][2 * w + 1]);
             hi[w] = pack_bf16x2(acc[2 * pr + 1][b][2 * w], acc[2 * pr + 1][b][2 * w + 1]);
           }
-          typedef __attribute__((ext_vector_type(2))) unsigned w_u2_t;
           const w_u2_t s0 = __builtin_amdgcn_permlane16_swap(lo[0], hi[0], false, false);
           const w_u2_t s1 = __builtin_amdgcn_permlane16_swap(lo[1], hi[1], false, false);
-          w_u32x4_t pk;
-          pk[0] = s0[0]; pk[1] = s1[0]; pk[2] = s0[1]; pk[3] = s1[1];
-          if (m < M && !(epi & 256))   // 256 = timing-only ablation: skip stores
-            *reinterpret_cast<w_u32x4_t*>(static_cast<bf16_t*>(out) + static_cast<size_t>(m) * N + col + 32 * pr) = pk;
+          pend[b * 2 + pr][0] = s0[0]; pend[b * 2 + pr][1] = s1[0]; pend[b * 2 + pr][2] = s0[1]; pend[b * 2 + pr][3] = s1[1];
         }
       }
-    } else {
+      pend_ptr = static_cast<bf16_t*>(out) + static_cast<size_t>(m0 + wm * 80 + frow) * N + col;
+      if (full && ti + 1 < my_tiles && !(epi & (256 | 512))) {   // 512 = ablation: store from the epilogue
+        pend_valid = true;                       // leave under the next tile's MFMAs
+      } else if (!(epi & 256)) {                 // 256 = timing-only ablation: skip stores
+#pragma unroll
+        for (int j = 0; j < wPend; ++j)
+          if (m0 + wm * 80 + (j / 2) * 16 + frow < M)
+            *reinterpret_cast<w_u32x4_t*>(pend_ptr + (j / 2) * row16 + (j % 2) * 32) = pend[j];
+      }
+    } else if (!(epi & 256)) {
 #pragma unroll
       for (int b = 0; b < 5; ++b) {
         const int m = m0 + wm * 80 + b * 16 + frow;
-        if (m >= M || (epi & 256)) continue;
+        if (m >= M) continue;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           const int n = n0 + wn * 64 + a * 16 + fq * 4;
@@ -362,21 +371,23 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
         }
       }
     }
-    // bookkeeping for the counted waits of the next tile's first two K-steps
-    if (m0 + wBM > M || (epi & 256)) {   // partial tile: some store instructions were skipped -> drain, count nothing
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      epi_stores = 0;
-    } else {
-      epi_stores = (epi & EPI_OUT_BF16) ? 10 : 20;
-    }
-    since_epi = 0;
+    // Epilogue-issued stores are younger than every DMA in flight, so the next counted waits (P + ns outstanding) would
+    // simply also retire the DMAs: safe, slightly conservative.  A partial tile may have skipped store instructions.
+    if (!full) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ns = 0; }
   }
+  };
+  if (group_b) run(std::true_type{}); else run(std::false_type{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the over-issued stages must land before the LDS is released
 }
 
 bool gemm_wide_supported(int N) { return N % wBN == 0; }
 
 int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out,
                      int M, int N, int K, int epi, hipStream_t st) {
+  const size_t esz = dt == CMH_F32 ? 4 : 2;
+  if (static_cast<size_t>(M) * K * esz >= (1ull << 32) || static_cast<size_t>(wBN) * K * esz >= (1ull << 32))
+    return fail(CMH_ERR_INVALID, "gemm: operand of %zu bytes exceeds the 32-bit offset range of the wide kernel",
+                static_cast<size_t>(M) * K * esz);
   const int total = (N / wBN) * ((M + wBM - 1) / wBM);
   static int cus = 0;
   if (!cus) {
@@ -387,12 +398,13 @@ int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, co
     cus &= ~7;   // whole groups of 8: blockIdx % 8 names the XCD share
   }
   int grid = total < cus ? ((total + 7) & ~7) : cus;
-  if (dt == CMH_F32)
-    hipLaunchKernelGGL(gemm_wide_kernel<true>, dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),
-                       static_cast<const char*>(W), bias, residual, out, M, N, K, epi);
-  else
-    hipLaunchKernelGGL(gemm_wide_kernel<false>, dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),
-                       static_cast<const char*>(W), bias, residual, out, M, N, K, epi);
+#define W_LAUNCH(F32, OUTBF)                                                                                   \
+  hipLaunchKernelGGL((gemm_wide_kernel<F32, OUTBF>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A), \
+                     static_cast<const char*>(W), bias, residual, out, M, N, K, epi)
+  const bool obf = epi & EPI_OUT_BF16;
+  if (dt == CMH_F32) { if (obf) W_LAUNCH(true, true); else W_LAUNCH(true, false); }
+  else { if (obf) W_LAUNCH(false, true); else W_LAUNCH(false, false); }
+#undef W_LAUNCH
   return 0;
 }
 
