@@ -176,7 +176,7 @@ def main():
                    "seq_len": L, "bits": K, "weights": "random-init ViT-B/32", "parallelism": f"batch-shard x{world}"},
         "per_gpu_value": round(value / world, 2),
         "end_to_end_tflops_per_gpu": round(value / world * flops_pair / 1e12, 2),
-        "roofline": {"bound": "mfma", "kernel": "cmh::gemm_kernel<%s>" % ("true" if a.dtype == "f32" else "false"),
+        "roofline": {"bound": "mfma", "kernel": "cmh::gemm_wide_kernel<%s, *>" % ("true" if a.dtype == "f32" else "false"),
                      "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                      "traffic": None, "launches": int(gemm_launches),
                      "avg_launch_us": round(gemm_ms * 1e3 / max(gemm_launches, 1), 2),

@@ -26,6 +26,9 @@
 
 #include "cmh_common.h"
 
+#include <array>
+#include <map>
+
 namespace cmh {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -200,6 +203,7 @@ struct GemmProf {
   bool on = false;
   std::vector<hipEvent_t> ev;     // pairs
   std::vector<double> flops;
+  std::vector<std::array<int, 4>> dims;   // M, N, K, epi of each timed launch (CMH_GEMM_PROF_DUMP breakdown)
   size_t used = 0;
 };
 static GemmProf g_prof;
@@ -244,6 +248,7 @@ int launch_gemm(int dt, const void* A, const void* W, const float* bias, const f
   if (timed) {
     (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
     g_prof.flops.push_back(2.0 * M * static_cast<double>(N) * K);   // algorithmic FLOPs: real rows only
+    g_prof.dims.push_back({M, N, K, epi});
     g_prof.used += 2;
   }
   CMH_CHECK_LAUNCH("gemm");
@@ -262,6 +267,7 @@ extern "C" int cmh_prof_gemm_begin(int32_t max_launches) {
   }
   g_prof.used = 0;
   g_prof.flops.clear();
+  g_prof.dims.clear();
   g_prof.on = true;
   return CMH_OK;
 }
@@ -278,6 +284,19 @@ extern "C" int cmh_prof_gemm_end(double* total_ms, double* total_flops, int64_t*
       return fail(CMH_ERR_LAUNCH, "prof_gemm_end: hipEventElapsedTime failed");
     ms += t;
     fl += g_prof.flops[i / 2];
+  }
+  if (getenv("CMH_GEMM_PROF_DUMP")) {   // per-shape breakdown of the timed launches, to stderr
+    std::map<std::array<int, 4>, std::array<double, 3>> by;   // dims -> {ms, flops, launches}
+    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+      float t = 0.f;
+      (void)hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]);
+      auto& e = by[g_prof.dims[i / 2]];
+      e[0] += t; e[1] += g_prof.flops[i / 2]; e[2] += 1;
+    }
+    for (const auto& kv : by)
+      fprintf(stderr, "gemm M=%6d N=%5d K=%5d epi=%3d  launches %5.0f  avg %8.2f us  %7.1f TF/s  share %5.1f%%\n", kv.first[0],
+              kv.first[1], kv.first[2], kv.first[3], kv.second[2], kv.second[0] * 1e3 / kv.second[2],
+              kv.second[1] / (kv.second[0] * 1e-3) / 1e12, 100.0 * kv.second[0] / ms);
   }
   *total_ms = ms;
   *total_flops = fl;

@@ -50,6 +50,10 @@ __device__ __forceinline__ float w_quick_gelu(float v) {
 typedef const __attribute__((address_space(1))) void* w_gptr_t;
 typedef __attribute__((address_space(3))) void* w_lptr_t;
 
+#ifdef W_STAMPS
+__device__ unsigned g_wide_stamps[256 * 8 * 4];
+#endif
+
 template <bool F32, bool OUTBF>
 __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__ X, const char* __restrict__ W,
                                                         const float* __restrict__ bias, const float* residual,
@@ -136,6 +140,11 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((w_lptr_t)lds));
   const uint32_t aW = lds_base + w_swz(wn * 64 + frow, fq);
   const uint32_t aX = lds_base + wWBytes + w_swz(wm * 80 + frow, fq);
+#ifdef W_STAMPS   // timing build only (tools/wide_stamps.py): per-wave cycle sums of the K loop's segments
+#define W_STAMP(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); st_sum[k] += static_cast<unsigned>(t_ - st_last); st_last = t_; } while (0)
+#else
+#define W_STAMP(k) do { } while (0)
+#endif
 #define W_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
   auto load_frags = [&](w_u32x4_t (&fw)[4], w_u32x4_t (&fx)[5], int buf, int ks) {
     const uint32_t bo = static_cast<uint32_t>(buf) * wStageBytes;
@@ -178,17 +187,12 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   // K-step s and group B (waves 4..7) among those of the FIRST half of K-step s+1 (and its deferred stores in the other
   // half): while one wave of a SIMD waits on the address path its partner streams MFMAs.
   const bool group_b = wid >= 4;
-  set_issue_tile(0);
-  issue_stage();
-  issue_stage();
-  if (!group_b) {
-    issue_stage();
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // stage 0 landed (two younger stages of >= 6 pieces may fly)
-  } else {
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // group B issues stage 2 in the first half of K-step 0
-  }
-  __builtin_amdgcn_s_barrier();
-
+  // Short K: the first tile's accumulators start as the residual tile (bias commutes, activations would not): its 20 loads
+  // per lane are older than every LDS-DMA, so the prologue's counted wait covers them and their HBM latency hides behind
+  // the prologue instead of sitting exposed in the epilogue (residual GEMMs have <= 1 tile per workgroup: N = 512 / 768).
+  // Measured inside the encoder: K = 512 / 768: -2.9 / -1.6 us per launch; K = 2048 / 3072: +0.3 / +2.3 us (the 40 MB burst
+  // delays the first stage and a long K loop has no trouble hiding the epilogue's loads behind other workgroups) -> nk <= 16.
+  const bool res_first = (epi & EPI_RESIDUAL) && !(epi & (EPI_QUICKGELU | EPI_GELU | EPI_RELU)) && nk <= 16;
   auto mfma = [&](const w_u32x4_t& fw, const w_u32x4_t& fx, w_f32x4_t& c) {
     if constexpr (F32) {
 #pragma unroll
@@ -200,20 +204,55 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
     }
   };
 
+#ifdef W_STAMPS
+  unsigned st_sum[4] = {0, 0, 0, 0};
+  unsigned long long st_last = __builtin_readcyclecounter();
+#endif
   auto run = [&](auto gb) {
   constexpr bool GB = decltype(gb)::value;
+  w_f32x4_t acc[4][5];   // [n-tile][m-tile]
+  if (res_first) {
+    const int logical = range_lo + slot;
+    const int tm = logical / tiles_n, tn = logical - tm * tiles_n;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+      int m = tm * wBM + wm * 80 + b * 16 + frow;
+      m = m < M ? m : M - 1;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+        acc[a][b] = *reinterpret_cast<const w_f32x4_t*>(residual + static_cast<size_t>(m) * N + tn * wBN + wn * 64 + a * 16 + fq * 4);
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 5; ++b) acc[a][b] = w_f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  set_issue_tile(0);
+  issue_stage();
+  issue_stage();
+  if constexpr (!GB) {
+    issue_stage();
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // stage 0 landed (two younger stages of >= 6 pieces may fly)
+  } else {
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // group B issues stage 2 in the first half of K-step 0
+  }
+  __builtin_amdgcn_s_barrier();
+
   int cur = 0;
   int ns = 0;                   // deferred stores issued since the last counted wait
   w_u32x4_t f0w[4], f0x[5], f1w[4], f1x[5];
   load_frags(f0w, f0x, 0, 0);   // from here on F0 of K-step s+1 (also across tiles) is fetched in the second half of s
   for (int ti = 0; ti < my_tiles; ++ti) {
-    w_f32x4_t acc[4][5];   // [n-tile][m-tile]
+    if (ti > 0) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int b = 0; b < 5; ++b) acc[a][b] = w_f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < 5; ++b) acc[a][b] = w_f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
 
     for (int kt = 0; kt < nk; ++kt) {
+      W_STAMP(0);   // second half of the previous K-step (+ epilogue at kt = 0)
 #ifndef W_ABL_NOREAD
       load_frags(f1w, f1x, cur, 1);                                   // 1
 #endif
@@ -246,11 +285,14 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
       //    wave ~16 issue cycles, hence the short decision tree instead of a switch over all counts; a smaller count is
       //    always safe.
       W_WAIT_FRAGS(0, f1w, f1x);
+      W_STAMP(1);   // first half
       if (ns == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       else if (ns == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       ns = 0;
+      W_STAMP(2);   // counted vmcnt wait
       __builtin_amdgcn_s_barrier();
+      W_STAMP(3);   // barrier
       const int nxt = cur == 2 ? 0 : cur + 1;
       {                                                               // 4-6: no branches between the MFMAs
         const uint32_t bo = static_cast<uint32_t>(nxt) * wStageBytes;
@@ -315,7 +357,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
           for (int j = 0; j < 4; ++j)
             acc[a][b][j] = (epi & EPI_GELU) ? gelu_erf(acc[a][b][j]) : fmaxf(acc[a][b][j], 0.f);
     }
-    if (epi & EPI_RESIDUAL) {
+    if ((epi & EPI_RESIDUAL) && !(res_first && ti == 0)) {
       w_f32x4_t rv[4][5];
 #pragma unroll
       for (int b = 0; b < 5; ++b) {
@@ -377,6 +419,10 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   }
   };
   if (group_b) run(std::true_type{}); else run(std::false_type{});
+#ifdef W_STAMPS
+  if (lane == 0)
+    for (int k = 0; k < 4; ++k) g_wide_stamps[(blockIdx.x * 8 + wid) * 4 + k] = st_sum[k];
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the over-issued stages must land before the LDS is released
 }
 
@@ -409,3 +455,9 @@ int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, co
 }
 
 }  // namespace cmh
+
+#ifdef W_STAMPS
+extern "C" int cmh_debug_wide_stamps(unsigned* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(cmh::g_wide_stamps), sizeof(unsigned) * 256 * 8 * 4) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -20,7 +20,7 @@ SHAPES = {
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--dtype", default="bf16")
-ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--iters", type=int, default=100)
 ap.add_argument("--only", default="")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -32,7 +32,7 @@ for name, (M, Nn, K) in SHAPES.items():
     x = torch.randn(M, K, device=dev).to(dt)
     w = (torch.randn(Nn, K, device=dev) * K ** -0.5).to(dt)
     b = torch.randn(Nn, device=dev)
-    for _ in range(3):
+    for _ in range(max(3, a.iters // 4)):   # also lets the clocks settle
         N.linear_gemm(x, w, bias=b, out_bf16=(a.dtype == "bf16"))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
