@@ -165,6 +165,14 @@ def main():
     flops_pair = FLOP_IMG + text_flops(L)
     peak = PEAK_TFLOPS[a.dtype]
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    # HBM-side bytes per GEMM launch cannot be counted from inside this process: they come from the two rocprofv3 --pmc
+    # passes of this same command (tools/pmc_bench_traffic.sh), committed under profiles/; null if absent / other dtype.
+    traffic, traffic_src = None, None
+    tfile = os.path.join(ROOT, "profiles", "r01_c_gemm_traffic.json")
+    if a.dtype == "bf16" and os.path.exists(tfile):
+        with open(tfile) as fh:
+            traffic = json.load(fh)["traffic_bytes_per_launch"]
+        traffic_src = "profiles/r01_c_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, (2*FETCH+WRITE)*1024)"
     out = {
         "metric": "image+text pairs/s encoded+hashed per GPU; mAP@K eval wallclock (64-bit)",
         "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -178,7 +186,8 @@ def main():
         "end_to_end_tflops_per_gpu": round(value / world * flops_pair / 1e12, 2),
         "roofline": {"bound": "mfma", "kernel": "cmh::gemm_wide_kernel<%s, *>" % ("true" if a.dtype == "f32" else "false"),
                      "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                     "traffic": None, "launches": int(gemm_launches),
+                     "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                     "launches": int(gemm_launches),
                      "avg_launch_us": round(gemm_ms * 1e3 / max(gemm_launches, 1), 2),
                      "gemm_share_of_step": round(gemm_ms / (elapsed * 1e3), 4)},
     }
