@@ -11,6 +11,7 @@ import torch.nn as nn
 import cmh_native as N
 from model.base.model import no_backward
 from model.modelbase import Baseclip, weights_init_kaiming
+from streams import overlapped
 
 
 class HashLayer(nn.Module):
@@ -48,4 +49,4 @@ class MDCMHT(Baseclip):
         self.text_hash = HashLayer(inputDim=self.embedDim, outputDim=outputDim)
 
     def forward(self, image, text):
-        return self.encode_image(image), self.encode_text(text)
+        return overlapped(lambda: self.encode_image(image), lambda: self.encode_text(text))

@@ -6,6 +6,7 @@ import torch.nn as nn
 import cmh_native as N
 from model.base.model import no_backward
 from model.modelbase import Baseclip
+from streams import overlapped
 
 
 class Pre_Layer(nn.Module):
@@ -35,6 +36,6 @@ class MDNPH(Baseclip):
         return self.text_hash(text_fea), self.text_pre(text_fea)
 
     def forward(self, image, text):
-        image_embed, image_pre = self.encode_image(image)
-        text_embed, text_pre = self.encode_text(text)
+        (image_embed, image_pre), (text_embed, text_pre) = overlapped(
+            lambda: self.encode_image(image), lambda: self.encode_text(text))
         return image_embed, image_pre, text_embed, text_pre

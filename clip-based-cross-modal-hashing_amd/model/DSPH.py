@@ -2,6 +2,7 @@
 import logging
 
 from model.modelbase import Baseclip
+from streams import overlapped
 
 
 class MDSPH(Baseclip):
@@ -12,4 +13,4 @@ class MDSPH(Baseclip):
                                     saveDir=saveDir, logger=logger, is_train=is_train)
 
     def forward(self, image, text):
-        return self.encode_image(image), self.encode_text(text)
+        return overlapped(lambda: self.encode_image(image), lambda: self.encode_text(text))

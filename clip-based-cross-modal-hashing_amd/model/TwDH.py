@@ -16,6 +16,7 @@ import torch.nn as nn
 import cmh_native as N
 from model.base.model import no_backward
 from model.modelbase import Baseclip, weights_init_kaiming
+from streams import overlapped
 
 
 def softmax_hash(embed, return_vector=True):
@@ -117,6 +118,6 @@ class MTwDH(Baseclip):
         return long_hash, self._short(self.txt_hash, long_hash)
 
     def forward(self, image, text):
-        img_long_hash, img_short_hash = self.encode_image(image)
-        txt_long_hash, txt_short_hash = self.encode_text(text)
+        (img_long_hash, img_short_hash), (txt_long_hash, txt_short_hash) = overlapped(
+            lambda: self.encode_image(image), lambda: self.encode_text(text))
         return img_long_hash, img_short_hash, txt_long_hash, txt_short_hash, self.long_center, self.short_center

@@ -15,6 +15,7 @@ import torch.nn as nn
 import cmh_native as N
 from model.base.model import build_model, no_backward
 from utils import get_logger, get_summary_writer
+from streams import overlapped
 
 
 def weights_init_kaiming(m):
@@ -103,6 +104,6 @@ class Baseclip(nn.Module):
         return text_embed
 
     def forward(self, image, text):
-        image_embed = self.encode_image(image)
-        text_embed = self.encode_text(text)
+        # the two towers are independent: one HIP stream each (streams.py)
+        image_embed, text_embed = overlapped(lambda: self.encode_image(image), lambda: self.encode_text(text))
         return image_embed, text_embed
