@@ -181,23 +181,31 @@ def prof_gemm_end():
 
 # ------------------------------------------------------------------------------------------ tower blocks
 EPI_BIAS, EPI_QUICKGELU, EPI_RESIDUAL, EPI_OUT_BF16 = 1, 2, 4, 8
+EPI_RES_F16, EPI_OUT_F16 = 64, 128
 
 
-def linear_gemm(x, w, bias=None, residual=None, quickgelu=False, out_bf16=False):
-    """out = epi(x @ w.T); x,w both f32 or both bf16 (dtype picks the MFMA path)."""
+def linear_gemm(x, w, bias=None, residual=None, quickgelu=False, out_bf16=False, out_f16=False):
+    """out = epi(x @ w.T); x,w both f32 or both bf16 (dtype picks the MFMA path).  A float16 `residual` / `out_f16` is the
+    bf16 mode's fp16 residual stream (CMH_EPI_RES_F16 / CMH_EPI_OUT_F16, N % 256 == 0)."""
     require_gpu(x, w, bias, residual)
     dt = BF16 if x.dtype == torch.bfloat16 else F32
     if (w.dtype == torch.bfloat16) != (dt == BF16):
         raise NativeError("linear_gemm: x and w must share a dtype")
+    if out_bf16 and out_f16:
+        raise NativeError("linear_gemm: out_bf16 and out_f16 exclude each other")
     x, w = x.contiguous(), w.contiguous()
     M, K = x.shape
     Nn = w.shape[0]
-    out = torch.empty(M, Nn, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    odt = torch.bfloat16 if out_bf16 else (torch.float16 if out_f16 else torch.float32)
+    out = torch.empty(M, Nn, dtype=odt, device=x.device)
+    res_f16 = residual is not None and residual.dtype == torch.float16
+    if residual is not None:
+        residual = residual.contiguous() if res_f16 else f32c(residual)
     epi = (EPI_BIAS if bias is not None else 0) | (EPI_QUICKGELU if quickgelu else 0) | \
-          (EPI_RESIDUAL if residual is not None else 0) | (EPI_OUT_BF16 if out_bf16 else 0)
-    check(lib().cmh_linear_gemm(dt, ptr(x), ptr(w), ptr(None if bias is None else f32c(bias)),
-                                ptr(None if residual is None else f32c(residual)), ptr(out), M, Nn, K, epi,
-                                stream_ptr(x.device)), "cmh_linear_gemm")
+          (EPI_RESIDUAL if residual is not None else 0) | (EPI_OUT_BF16 if out_bf16 else 0) | \
+          (EPI_RES_F16 if res_f16 else 0) | (EPI_OUT_F16 if out_f16 else 0)
+    check(lib().cmh_linear_gemm(dt, ptr(x), ptr(w), ptr(None if bias is None else f32c(bias)), ptr(residual), ptr(out),
+                                M, Nn, K, epi, stream_ptr(x.device)), "cmh_linear_gemm")
     return out
 
 

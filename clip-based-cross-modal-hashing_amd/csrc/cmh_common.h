@@ -52,6 +52,22 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, b2_t));
 }
 
+// two f32 -> packed f16x2 (lo = a), RNE
+__device__ __forceinline__ uint32_t pack_f16x2(float a, float b) {
+  typedef __attribute__((ext_vector_type(2))) float f2_t;
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+  const f2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h2_t));
+}
+__device__ __forceinline__ float f16lo_to_f32(uint32_t w) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+  return static_cast<float>(__builtin_bit_cast(h2_t, w)[0]);
+}
+__device__ __forceinline__ float f16hi_to_f32(uint32_t w) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+  return static_cast<float>(__builtin_bit_cast(h2_t, w)[1]);
+}
+
 // ---- epilogue flags of the GEMM ---------------------------------------------------------------
 enum : int {
   EPI_BIAS = 1,       // + bias[n]
@@ -59,7 +75,9 @@ enum : int {
   EPI_RESIDUAL = 4,   // + residual[m,n] (f32)
   EPI_OUT_BF16 = 8,   // store bf16 instead of f32
   EPI_GELU = 16,      // exact GELU 0.5 x (1 + erf(x/sqrt 2))  (nn.GELU(), MITH ResidualMLPs model/MITH.py:224-233)
-  EPI_RELU = 32       // max(x, 0)
+  EPI_RELU = 32,      // max(x, 0)
+  EPI_RES_F16 = 64,   // residual is IEEE fp16 (the bf16 mode's residual stream, see encoders.hip)
+  EPI_OUT_F16 = 128   // store fp16 instead of f32
 };
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
@@ -72,15 +90,18 @@ int launch_gemm(int dt, const void* A, const void* W, const float* bias, const f
 // row r reads x[row_index[r]] when row_index != null.
 int launch_layernorm(const float* x, const int32_t* row_index, const float* w, const float* b,
                      void* out, int out_bf16, int M, int d, hipStream_t st);
+// same, x either f32 or (x_f16) the fp16 residual stream of the bf16 mode
+int launch_layernorm_x(const void* x, int x_f16, const int32_t* row_index, const float* w, const float* b,
+                       void* out, int out_bf16, int M, int d, hipStream_t st);
 
 // image [B,3,R,R] f32 -> patches [B*g*g, 3*p*p] (dt)
 int launch_patchify(const float* image, void* patches, int dt, int B, int R, int p, hipStream_t st);
-// tokens: x[b,0]=cls+pos[0]; x[b,1+i]=patch_out[b*g2+i]+pos[1+i]; then ln_pre -> x f32 [B*(g2+1), d]
+// tokens: x[b,0]=cls+pos[0]; x[b,1+i]=patch_out[b*g2+i]+pos[1+i]; then ln_pre -> x f32|f16 [B*(g2+1), d]
 int launch_vit_assemble_lnpre(const float* patch_out, const float* cls, const float* pos,
-                              const float* lnw, const float* lnb, float* x, int B, int g2, int d,
+                              const float* lnw, const float* lnb, void* x, int x_f16, int B, int g2, int d,
                               hipStream_t st);
 // x[b,t] = tok_emb[tokens[b,t]] + pos[t]; eot_row[b] = b*L + argmax_t tokens[b,t]
-int launch_text_embed(const int64_t* tokens, const float* tok_emb, const float* pos, float* x,
+int launch_text_embed(const int64_t* tokens, const float* tok_emb, const float* pos, void* x, int x_f16,
                       int32_t* eot_row, int B, int L, int d, int vocab, hipStream_t st);
 // cls_row[b] = b*T
 int launch_iota_rows(int32_t* rows, int B, int T, hipStream_t st);

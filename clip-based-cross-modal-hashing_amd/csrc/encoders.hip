@@ -4,12 +4,16 @@
 // graph-capturable.
 //
 // Data layout in HBM (per call, M = B*T rows, d = width, e = GEMM element size 4|2):
-//   x    f32 [M, d]    residual stream (kept fp32 in both modes)
+//   x    f32 [M, d]    residual stream.  f32 mode: fp32.  bf16 mode: IEEE fp16 - the precision the reference
+//                      itself keeps it in on a GPU (convert_weights casts the towers to fp16, model/base/model.py:375-395):
+//                      halves the bytes of the 4 read-modify-write passes per layer (2 LayerNorms, 2 residual GEMMs).
+//                      CMH_RESID_F16=0, widths that are not a multiple of 256 or a taps request keep it fp32.
 //   h    e   [M, d]    LayerNorm output / attention output (GEMM A operand)
 //   qkv  e   [M, 3d]   packed in_proj output            (vision: patch_out f32 [B*g2, d] aliases it)
 //   mlp  e   [M, 4d]   c_fc output after QuickGELU      (vision: patches e [B*g2, 3p^2] aliases it)
 //   rows i32 [B]       pooled row per sample (class token / EOT token)
 //   pool e   [B, d]    ln_post / ln_final of the pooled rows
+#include <cstdlib>
 #include <cstring>
 
 #include "cmh_common.h"
@@ -39,6 +43,7 @@ struct Arena {
 
 struct TowerBufs {
   float* x;
+  int xh = 0;   // x holds fp16 (bf16 mode, see header)
   void* h;
   void* qkv;
   void* mlp;
@@ -74,14 +79,15 @@ static int run_block(const cmh_block_weights& w, int dt, const TowerBufs& t, int
                      const uint8_t* kpm, hipStream_t st) {
   const int M = B * T;
   const int obf = dt == CMH_BF16 ? EPI_OUT_BF16 : 0;
+  const int rx = EPI_BIAS | EPI_RESIDUAL | (t.xh ? EPI_RES_F16 | EPI_OUT_F16 : 0);
   int rc;
-  if ((rc = launch_layernorm(t.x, nullptr, w.ln1_w, w.ln1_b, t.h, dt == CMH_BF16, M, d, st))) return rc;
+  if ((rc = launch_layernorm_x(t.x, t.xh, nullptr, w.ln1_w, w.ln1_b, t.h, dt == CMH_BF16, M, d, st))) return rc;
   if ((rc = launch_gemm(dt, t.h, w.in_proj_w, w.in_proj_b, nullptr, t.qkv, M, 3 * d, d, EPI_BIAS | obf, st))) return rc;
   if ((rc = launch_attention(t.qkv, t.h, dt, B, T, d, causal, kpm, st))) return rc;
-  if ((rc = launch_gemm(dt, t.h, w.out_proj_w, w.out_proj_b, t.x, t.x, M, d, d, EPI_BIAS | EPI_RESIDUAL, st))) return rc;
-  if ((rc = launch_layernorm(t.x, nullptr, w.ln2_w, w.ln2_b, t.h, dt == CMH_BF16, M, d, st))) return rc;
+  if ((rc = launch_gemm(dt, t.h, w.out_proj_w, w.out_proj_b, t.x, t.x, M, d, d, rx, st))) return rc;
+  if ((rc = launch_layernorm_x(t.x, t.xh, nullptr, w.ln2_w, w.ln2_b, t.h, dt == CMH_BF16, M, d, st))) return rc;
   if ((rc = launch_gemm(dt, t.h, w.fc_w, w.fc_b, nullptr, t.mlp, M, 4 * d, d, EPI_BIAS | EPI_QUICKGELU | obf, st))) return rc;
-  if ((rc = launch_gemm(dt, t.mlp, w.proj_w, w.proj_b, t.x, t.x, M, d, 4 * d, EPI_BIAS | EPI_RESIDUAL, st))) return rc;
+  if ((rc = launch_gemm(dt, t.mlp, w.proj_w, w.proj_b, t.x, t.x, M, d, 4 * d, rx, st))) return rc;
   return CMH_OK;
 }
 
@@ -90,6 +96,12 @@ static int final_projection(int dt, const void* pool, const void* w_t, float* fe
   const int bk = dt == CMH_F32 ? 32 : 64;
   if (embed % 128 == 0 && d % bk == 0) return launch_gemm(dt, pool, w_t, nullptr, nullptr, feat, B, embed, d, 0, st);
   return launch_small_linear(dt, pool, w_t, nullptr, nullptr, 1.f, CMH_ACT_NONE, feat, B, embed, d, st);
+}
+
+// fp16 residual stream?  (bf16 mode only; the residual GEMMs must take the wide kernel; taps are defined on an f32 stream)
+static int resid_f16(int dt, int d, const cmh_taps* taps) {
+  static const bool off = []() { const char* e = getenv("CMH_RESID_F16"); return e && !strcmp(e, "0"); }();
+  return dt == CMH_BF16 && d % 256 == 0 && !taps && !off;
 }
 
 static int check_tower(int dt, int width, int layers, int embed, const cmh_block_weights* blocks) {
@@ -134,6 +146,7 @@ static int vit_encode_impl(const cmh_vit_weights* w, const float* image, int32_t
   hipStream_t st = as_stream(stream);
   TowerBufs t = carve(workspace, static_cast<size_t>(M), B, d, e, static_cast<size_t>(B) * g2 * d * 4,
                       static_cast<size_t>(B) * g2 * pk * e);
+  t.xh = resid_f16(dt, d, taps);
   void* patches = t.mlp;
   float* patch_out = static_cast<float*>(t.qkv);
 
@@ -142,7 +155,7 @@ static int vit_encode_impl(const cmh_vit_weights* w, const float* image, int32_t
   if ((rc = launch_gemm(dt, patches, w->conv1_w, nullptr, nullptr, patch_out, B * g2, d, pk, 0, st))) return rc;
   // [class ; patches] + positional, ln_pre  (:237-239)
   if ((rc = launch_vit_assemble_lnpre(patch_out, w->class_embedding, w->positional_embedding, w->ln_pre_w,
-                                      w->ln_pre_b, t.x, B, g2, d, st))) return rc;
+                                      w->ln_pre_b, t.x, t.xh, B, g2, d, st))) return rc;
   if ((rc = tap(taps, 0, t.x, static_cast<size_t>(M) * d * 4, st))) return rc;
   for (int i = 0; i < w->layers; ++i) {
     if ((rc = run_block(w->blocks[i], dt, t, B, T, d, /*causal=*/0, nullptr, st))) return rc;
@@ -150,13 +163,13 @@ static int vit_encode_impl(const cmh_vit_weights* w, const float* image, int32_t
   }
   if (tokens_out) {
     // MITH trunk (model/MITH.py:70-80): ln_post and proj on EVERY token
-    if ((rc = launch_layernorm(t.x, nullptr, w->ln_post_w, w->ln_post_b, t.h, dt == CMH_BF16, M, d, st))) return rc;
+    if ((rc = launch_layernorm_x(t.x, t.xh, nullptr, w->ln_post_w, w->ln_post_b, t.h, dt == CMH_BF16, M, d, st))) return rc;
     if ((rc = final_projection(dt, t.h, w->proj_t, tokens_out, M, w->embed_dim, d, st))) return rc;
   }
   if (feat) {
     // ln_post on the class token, @ proj  (:247-250)
     if ((rc = launch_iota_rows(t.rows, B, T, st))) return rc;
-    if ((rc = launch_layernorm(t.x, t.rows, w->ln_post_w, w->ln_post_b, t.pool, dt == CMH_BF16, B, d, st))) return rc;
+    if ((rc = launch_layernorm_x(t.x, t.xh, t.rows, w->ln_post_w, w->ln_post_b, t.pool, dt == CMH_BF16, B, d, st))) return rc;
     if ((rc = final_projection(dt, t.pool, w->proj_t, feat, B, w->embed_dim, d, st))) return rc;
   }
   return CMH_OK;
@@ -195,9 +208,10 @@ static int text_encode_impl(const cmh_text_weights* w, const int64_t* tokens, in
   CMH_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "text_encode: workspace must be 256-byte aligned");
   hipStream_t st = as_stream(stream);
   TowerBufs t = carve(workspace, static_cast<size_t>(M), B, d, e, 0, 0);
+  t.xh = resid_f16(dt, d, taps);
 
   // token_embedding gather + positional_embedding[:L]; EOT row = argmax(tokens)  (model.py:360-362,370)
-  if ((rc = launch_text_embed(tokens, w->token_embedding, w->positional_embedding, t.x, t.rows, B, L, d,
+  if ((rc = launch_text_embed(tokens, w->token_embedding, w->positional_embedding, t.x, t.xh, t.rows, B, L, d,
                               w->vocab_size, st))) return rc;
   for (int i = 0; i < w->layers; ++i) {
     if ((rc = run_block(w->blocks[i], dt, t, B, L, d, /*causal=*/1, key_padding_mask, st))) return rc;
@@ -205,7 +219,7 @@ static int text_encode_impl(const cmh_text_weights* w, const int64_t* tokens, in
   }
   if (tokens_out) {
     // MITH trunk (model/MITH.py:136-139): ln_final and text_projection on EVERY token
-    if ((rc = launch_layernorm(t.x, nullptr, w->ln_final_w, w->ln_final_b, t.h, dt == CMH_BF16, M, d, st))) return rc;
+    if ((rc = launch_layernorm_x(t.x, t.xh, nullptr, w->ln_final_w, w->ln_final_b, t.h, dt == CMH_BF16, M, d, st))) return rc;
     if ((rc = final_projection(dt, t.h, w->text_projection_t, tokens_out, M, w->embed_dim, d, st))) return rc;
   }
   if (eot_rows_out &&
@@ -213,7 +227,7 @@ static int text_encode_impl(const cmh_text_weights* w, const int64_t* tokens, in
     return fail(CMH_ERR_LAUNCH, "text_encode: eot row copy failed");
   if (feat) {
     // ln_final (row-wise, so only the pooled rows are normalised), @ text_projection  (:366-370)
-    if ((rc = launch_layernorm(t.x, t.rows, w->ln_final_w, w->ln_final_b, t.pool, dt == CMH_BF16, B, d, st))) return rc;
+    if ((rc = launch_layernorm_x(t.x, t.xh, t.rows, w->ln_final_w, w->ln_final_b, t.pool, dt == CMH_BF16, B, d, st))) return rc;
     if ((rc = final_projection(dt, t.pool, w->text_projection_t, feat, B, w->embed_dim, d, st))) return rc;
   }
   return CMH_OK;

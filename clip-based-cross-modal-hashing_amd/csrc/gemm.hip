@@ -229,12 +229,15 @@ int launch_gemm(int dt, const void* A, const void* W, const float* bias, const f
   CMH_CHECK_ARG(K % bk == 0, "gemm: K=%d must be a multiple of %d", K, bk);
   CMH_CHECK_ARG(!(epi & EPI_BIAS) || bias, "gemm: EPI_BIAS without bias");
   CMH_CHECK_ARG(!(epi & EPI_RESIDUAL) || residual, "gemm: EPI_RESIDUAL without residual");
+  CMH_CHECK_ARG(!(epi & (EPI_RES_F16 | EPI_OUT_F16)) || (gemm_wide_supported(N) && !(epi & EPI_OUT_BF16)),
+                "gemm: fp16 residual / output needs N %% 256 == 0 (N=%d) and excludes EPI_OUT_BF16", N);
   const int total = (N / kTile) * ((M + kTile - 1) / kTile);
   const bool timed = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
   if (timed) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
   static const int impl = gemm_impl_from_env();
   static const bool wide = []() { const char* e = getenv("CMH_GEMM_WIDE"); return !(e && !strcmp(e, "0")); }();
-  if (impl == 1 && wide && gemm_wide_supported(N)) {
+  const bool f16io = epi & (EPI_RES_F16 | EPI_OUT_F16);   // only the wide kernel implements the fp16 residual stream
+  if ((impl == 1 && wide && gemm_wide_supported(N)) || f16io) {
     const int rc = launch_gemm_wide(dt, A, W, bias, residual, out, M, N, K, epi, st);
     if (rc) return rc;
   } else if (impl == 1)

@@ -211,22 +211,58 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   auto run = [&](auto gb) {
   constexpr bool GB = decltype(gb)::value;
   w_f32x4_t acc[4][5];   // [n-tile][m-tile]
+  // acc += residual tile at (m0, n0): f32 rows, or (EPI_RES_F16) fp16 rows read in the 16-byte layout of the packed output
+  // (lane = one row x 8 consecutive n) and brought back to the accumulator layout by the same v_permlane16_swap.
+  auto add_residual = [&](int m0, int n0) __attribute__((always_inline)) {
+    if (epi & EPI_RES_F16) {
+      const uint16_t* res16 = reinterpret_cast<const uint16_t*>(residual);
+      const int col = n0 + wn * 64 + (fq & 1) * 16 + (fq & 2) * 4;    // + 32*pair
+      w_u32x4_t r[wPend];
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {
+        int m = m0 + wm * 80 + b * 16 + frow;
+        m = m < M ? m : M - 1;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr)
+          r[b * 2 + pr] = *reinterpret_cast<const w_u32x4_t*>(res16 + static_cast<size_t>(m) * N + col + 32 * pr);
+      }
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const w_u32x4_t q = r[b * 2 + pr];
+          const w_u2_t s0 = __builtin_amdgcn_permlane16_swap(q[0], q[2], false, false);   // -> words 0 of tiles 2pr, 2pr+1
+          const w_u2_t s1 = __builtin_amdgcn_permlane16_swap(q[1], q[3], false, false);   // -> words 1
+          acc[2 * pr][b][0] += f16lo_to_f32(s0[0]); acc[2 * pr][b][1] += f16hi_to_f32(s0[0]);
+          acc[2 * pr][b][2] += f16lo_to_f32(s1[0]); acc[2 * pr][b][3] += f16hi_to_f32(s1[0]);
+          acc[2 * pr + 1][b][0] += f16lo_to_f32(s0[1]); acc[2 * pr + 1][b][1] += f16hi_to_f32(s0[1]);
+          acc[2 * pr + 1][b][2] += f16lo_to_f32(s1[1]); acc[2 * pr + 1][b][3] += f16hi_to_f32(s1[1]);
+        }
+      }
+    } else {
+      w_f32x4_t rv[4][5];
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {
+        int m = m0 + wm * 80 + b * 16 + frow;
+        m = m < M ? m : M - 1;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+          rv[a][b] = *reinterpret_cast<const w_f32x4_t*>(residual + static_cast<size_t>(m) * N + n0 + wn * 64 + a * 16 + fq * 4);
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 5; ++b) acc[a][b] += rv[a][b];
+    }
+  };
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 5; ++b) acc[a][b] = w_f32x4_t{0.f, 0.f, 0.f, 0.f};
   if (res_first) {
     const int logical = range_lo + slot;
     const int tm = logical / tiles_n, tn = logical - tm * tiles_n;
-#pragma unroll
-    for (int b = 0; b < 5; ++b) {
-      int m = tm * wBM + wm * 80 + b * 16 + frow;
-      m = m < M ? m : M - 1;
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-        acc[a][b] = *reinterpret_cast<const w_f32x4_t*>(residual + static_cast<size_t>(m) * N + tn * wBN + wn * 64 + a * 16 + fq * 4);
-    }
-  } else {
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 5; ++b) acc[a][b] = w_f32x4_t{0.f, 0.f, 0.f, 0.f};
+    add_residual(tm * wBM, tn * wBN);
   }
   set_issue_tile(0);
   issue_stage();
@@ -357,21 +393,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
           for (int j = 0; j < 4; ++j)
             acc[a][b][j] = (epi & EPI_GELU) ? gelu_erf(acc[a][b][j]) : fmaxf(acc[a][b][j], 0.f);
     }
-    if ((epi & EPI_RESIDUAL) && !(res_first && ti == 0)) {
-      w_f32x4_t rv[4][5];
-#pragma unroll
-      for (int b = 0; b < 5; ++b) {
-        int m = m0 + wm * 80 + b * 16 + frow;
-        m = m < M ? m : M - 1;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-          rv[a][b] = *reinterpret_cast<const w_f32x4_t*>(residual + static_cast<size_t>(m) * N + n0 + wn * 64 + a * 16 + fq * 4);
-      }
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 5; ++b) acc[a][b] += rv[a][b];
-    }
+    if ((epi & EPI_RESIDUAL) && !(res_first && ti == 0)) add_residual(m0, n0);
     const bool full = m0 + wBM <= M;
     if constexpr (OUTBF) {
       // v_permlane16_swap exchanges, between the lane pairs (l, l+16), the packed words of two neighbouring n-tiles: an even
@@ -382,10 +404,18 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
           uint32_t lo[2], hi[2];   // packed words of tiles a = 2pr (lo) and 2pr+1 (hi)
+          if (epi & EPI_OUT_F16) {
 #pragma unroll
-          for (int w = 0; w < 2; ++w) {
-            lo[w] = pack_bf16x2(acc[2 * pr][b][2 * w], acc[2 * pr][b][2 * w + 1]);
-            hi[w] = pack_bf16x2(acc[2 * pr + 1][b][2 * w], acc[2 * pr + 1][b][2 * w + 1]);
+            for (int w = 0; w < 2; ++w) {
+              lo[w] = pack_f16x2(acc[2 * pr][b][2 * w], acc[2 * pr][b][2 * w + 1]);
+              hi[w] = pack_f16x2(acc[2 * pr + 1][b][2 * w], acc[2 * pr + 1][b][2 * w + 1]);
+            }
+          } else {
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+              lo[w] = pack_bf16x2(acc[2 * pr][b][2 * w], acc[2 * pr][b][2 * w + 1]);
+              hi[w] = pack_bf16x2(acc[2 * pr + 1][b][2 * w], acc[2 * pr + 1][b][2 * w + 1]);
+            }
           }
           const w_u2_t s0 = __builtin_amdgcn_permlane16_swap(lo[0], hi[0], false, false);
           const w_u2_t s1 = __builtin_amdgcn_permlane16_swap(lo[1], hi[1], false, false);
@@ -447,7 +477,7 @@ int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, co
 #define W_LAUNCH(F32, OUTBF)                                                                                   \
   hipLaunchKernelGGL((gemm_wide_kernel<F32, OUTBF>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A), \
                      static_cast<const char*>(W), bias, residual, out, M, N, K, epi)
-  const bool obf = epi & EPI_OUT_BF16;
+  const bool obf = epi & (EPI_OUT_BF16 | EPI_OUT_F16);   // 16-bit outputs share the packed store path
   if (dt == CMH_F32) { if (obf) W_LAUNCH(true, true); else W_LAUNCH(true, false); }
   else { if (obf) W_LAUNCH(false, true); else W_LAUNCH(false, false); }
 #undef W_LAUNCH

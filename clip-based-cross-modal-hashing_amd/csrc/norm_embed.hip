@@ -13,10 +13,11 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 constexpr int kMaxVec = 4;  // up to 4 float4 per lane -> d <= 1024
+constexpr int kOutF32 = 0, kOutBf16 = 1, kOutF16 = 2;
 
 // Normalise one row held as float4 fragments v[0..nv) (lane owns elements lane*4 + 256*j).
 __device__ __forceinline__ void ln_row(float4 (&v)[kMaxVec], int nv, int d, int lane, const float* __restrict__ w,
-                                       const float* __restrict__ b, void* __restrict__ out_row, int out_bf16) {
+                                       const float* __restrict__ b, void* __restrict__ out_row, int out_kind) {
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < kMaxVec; ++j)
@@ -41,11 +42,13 @@ __device__ __forceinline__ void ln_row(float4 (&v)[kMaxVec], int nv, int d, int 
       y.y = (v[j].y - mean) * rstd * wv.y + bv.y;
       y.z = (v[j].z - mean) * rstd * wv.z + bv.z;
       y.w = (v[j].w - mean) * rstd * wv.w + bv.w;
-      if (out_bf16) {
+      if (out_kind == kOutBf16) {
         uint2 pk;
         pk.x = static_cast<uint32_t>(f32_to_bf16(y.x)) | (static_cast<uint32_t>(f32_to_bf16(y.y)) << 16);
         pk.y = static_cast<uint32_t>(f32_to_bf16(y.z)) | (static_cast<uint32_t>(f32_to_bf16(y.w)) << 16);
         *reinterpret_cast<uint2*>(static_cast<bf16_t*>(out_row) + e0) = pk;
+      } else if (out_kind == kOutF16) {
+        *reinterpret_cast<uint2*>(static_cast<uint16_t*>(out_row) + e0) = uint2{pack_f16x2(y.x, y.y), pack_f16x2(y.z, y.w)};
       } else {
         *reinterpret_cast<float4*>(static_cast<float*>(out_row) + e0) = y;
       }
@@ -53,31 +56,51 @@ __device__ __forceinline__ void ln_row(float4 (&v)[kMaxVec], int nv, int d, int 
   }
 }
 
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const int32_t* __restrict__ row_index,
+// 4 consecutive elements of a residual-stream row: f32 (16-byte load) or fp16 (8-byte load), see encoders.hip
+template <bool XH>
+__device__ __forceinline__ float4 load_x4(const void* row, int e0) {
+  if constexpr (XH) {
+    const uint2 u = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(row) + e0);
+    return float4{f16lo_to_f32(u.x), f16hi_to_f32(u.x), f16lo_to_f32(u.y), f16hi_to_f32(u.y)};
+  } else {
+    return *reinterpret_cast<const float4*>(static_cast<const float*>(row) + e0);
+  }
+}
+
+template <bool XH>
+__global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ x, const int32_t* __restrict__ row_index,
                                                         const float* __restrict__ w, const float* __restrict__ b,
                                                         void* __restrict__ out, int out_bf16, int M, int d) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const size_t src = row_index ? static_cast<size_t>(row_index[row]) : static_cast<size_t>(row);
-  const float* xr = x + src * d;
+  const char* xr = static_cast<const char*>(x) + src * d * (XH ? 2 : 4);
   const int nv = (d + 255) / 256;
   float4 v[kMaxVec];
 #pragma unroll
   for (int j = 0; j < kMaxVec; ++j) {
     const int e0 = lane * 4 + 256 * j;
-    v[j] = (j < nv && e0 < d) ? *reinterpret_cast<const float4*>(xr + e0) : float4{0.f, 0.f, 0.f, 0.f};
+    v[j] = (j < nv && e0 < d) ? load_x4<XH>(xr, e0) : float4{0.f, 0.f, 0.f, 0.f};
   }
   char* orow = static_cast<char*>(out) + static_cast<size_t>(row) * d * (out_bf16 ? 2 : 4);
-  ln_row(v, nv, d, lane, w, b, orow, out_bf16);
+  ln_row(v, nv, d, lane, w, b, orow, out_bf16 ? kOutBf16 : kOutF32);
+}
+
+int launch_layernorm_x(const void* x, int x_f16, const int32_t* row_index, const float* w, const float* b, void* out,
+                       int out_bf16, int M, int d, hipStream_t st) {
+  CMH_CHECK_ARG(d % 4 == 0 && d <= 256 * kMaxVec, "layernorm: d=%d must be a multiple of 4 and <= 1024", d);
+  if (x_f16)
+    hipLaunchKernelGGL(layernorm_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, x, row_index, w, b, out, out_bf16, M, d);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, x, row_index, w, b, out, out_bf16, M, d);
+  CMH_CHECK_LAUNCH("layernorm");
+  return CMH_OK;
 }
 
 int launch_layernorm(const float* x, const int32_t* row_index, const float* w, const float* b, void* out,
                      int out_bf16, int M, int d, hipStream_t st) {
-  CMH_CHECK_ARG(d % 4 == 0 && d <= 256 * kMaxVec, "layernorm: d=%d must be a multiple of 4 and <= 1024", d);
-  hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, row_index, w, b, out, out_bf16, M, d);
-  CMH_CHECK_LAUNCH("layernorm");
-  return CMH_OK;
+  return launch_layernorm_x(x, 0, row_index, w, b, out, out_bf16, M, d, st);
 }
 
 // ---- conv1 as GEMM: patch extraction -----------------------------------------------------------
@@ -124,8 +147,8 @@ __global__ __launch_bounds__(256) void vit_assemble_lnpre_kernel(const float* __
                                                                  const float* __restrict__ cls,
                                                                  const float* __restrict__ pos,
                                                                  const float* __restrict__ lnw,
-                                                                 const float* __restrict__ lnb, float* __restrict__ x,
-                                                                 int B, int g2, int d) {
+                                                                 const float* __restrict__ lnb, void* __restrict__ x,
+                                                                 int x_f16, int B, int g2, int d) {
   const int lane = threadIdx.x & 63;
   const int T = g2 + 1;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -146,15 +169,16 @@ __global__ __launch_bounds__(256) void vit_assemble_lnpre_kernel(const float* __
       v[j] = float4{0.f, 0.f, 0.f, 0.f};
     }
   }
-  ln_row(v, nv, d, lane, lnw, lnb, x + static_cast<size_t>(row) * d, 0);
+  ln_row(v, nv, d, lane, lnw, lnb, static_cast<char*>(x) + static_cast<size_t>(row) * d * (x_f16 ? 2 : 4),
+         x_f16 ? kOutF16 : kOutF32);
 }
 
 int launch_vit_assemble_lnpre(const float* patch_out, const float* cls, const float* pos, const float* lnw,
-                              const float* lnb, float* x, int B, int g2, int d, hipStream_t st) {
+                              const float* lnb, void* x, int x_f16, int B, int g2, int d, hipStream_t st) {
   CMH_CHECK_ARG(d % 4 == 0 && d <= 256 * kMaxVec, "vit_assemble: width %d unsupported", d);
   const int rows = B * (g2 + 1);
   hipLaunchKernelGGL(vit_assemble_lnpre_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, patch_out, cls, pos, lnw,
-                     lnb, x, B, g2, d);
+                     lnb, x, x_f16, B, g2, d);
   CMH_CHECK_LAUNCH("vit_assemble_lnpre");
   return CMH_OK;
 }
@@ -162,8 +186,8 @@ int launch_vit_assemble_lnpre(const float* patch_out, const float* cls, const fl
 // ---- token embedding + positional; EOT row = first argmax of the token ids ------------------------
 __global__ __launch_bounds__(256) void text_embed_kernel(const int64_t* __restrict__ tokens,
                                                          const float* __restrict__ tok_emb,
-                                                         const float* __restrict__ pos, float* __restrict__ x,
-                                                         int32_t* __restrict__ eot_row, int B, int L, int d,
+                                                         const float* __restrict__ pos, void* __restrict__ x,
+                                                         int x_f16, int32_t* __restrict__ eot_row, int B, int L, int d,
                                                          int vocab) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -173,11 +197,15 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int64_t* __restri
   id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);   // out-of-vocabulary ids would fault; clamp
   const float* er = tok_emb + static_cast<size_t>(id) * d;
   const float* pr = pos + static_cast<size_t>(t) * d;
-  float* xr = x + static_cast<size_t>(row) * d;
+  char* xr = static_cast<char*>(x) + static_cast<size_t>(row) * d * (x_f16 ? 2 : 4);
   for (int e0 = lane * 4; e0 < d; e0 += 256) {
     const float4 a = *reinterpret_cast<const float4*>(er + e0);
     const float4 q = *reinterpret_cast<const float4*>(pr + e0);
-    *reinterpret_cast<float4*>(xr + e0) = float4{a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w};
+    const float4 y = float4{a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w};
+    if (x_f16)
+      *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(xr) + e0) = uint2{pack_f16x2(y.x, y.y), pack_f16x2(y.z, y.w)};
+    else
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(xr) + e0) = y;
   }
   if (t == 0) {   // this wave also finds argmax over the caption (first maximum, like torch.argmax)
     int64_t best = INT64_MIN;
@@ -196,12 +224,12 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int64_t* __restri
   }
 }
 
-int launch_text_embed(const int64_t* tokens, const float* tok_emb, const float* pos, float* x, int32_t* eot_row,
+int launch_text_embed(const int64_t* tokens, const float* tok_emb, const float* pos, void* x, int x_f16, int32_t* eot_row,
                       int B, int L, int d, int vocab, hipStream_t st) {
   CMH_CHECK_ARG(d % 4 == 0, "text_embed: width %d unsupported", d);
   const int rows = B * L;
-  hipLaunchKernelGGL(text_embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, tokens, tok_emb, pos, x, eot_row,
-                     B, L, d, vocab);
+  hipLaunchKernelGGL(text_embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, tokens, tok_emb, pos, x, x_f16,
+                     eot_row, B, L, d, vocab);
   CMH_CHECK_LAUNCH("text_embed");
   return CMH_OK;
 }

@@ -19,6 +19,7 @@ from torch import nn
 import cmh_native as N
 import mith_ops as M
 from model.base.model import CLIP, Transformer, VisionTransformer, _fill_blocks, convert_weights, no_backward  # noqa: F401
+from streams import overlapped
 
 
 class ViT(VisionTransformer):
@@ -205,6 +206,6 @@ class MITH(nn.Module):
         self.hash = HashingModel(clip_embed_dim=512, args=args)
 
     def forward(self, image, text, key_padding_mask):
-        img_tokens, _, img_cls = self.clip.encode_image(image)
-        txt_tokens, _, new_key_padding_mask, txt_eos = self.clip.encode_text(text, key_padding_mask)
+        (img_tokens, _, img_cls), (txt_tokens, _, new_key_padding_mask, txt_eos) = overlapped(
+            lambda: self.clip.encode_image(image), lambda: self.clip.encode_text(text, key_padding_mask))
         return self.hash(img_tokens, txt_tokens, img_cls, txt_eos, new_key_padding_mask)

@@ -92,3 +92,29 @@ def test_attention(B, T, d, causal, mode):
     out = Nn.attention(src.to(_dev()), B, T, causal, None if kpm is None else kpm.to(_dev()))
     tol = dict(rtol=1e-2, atol=1e-2) if mode == "bf16" else dict(rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(out.cpu().double(), ref, **tol)
+
+
+@pytest.mark.parametrize("M,N,K", [(160, 256, 64), (333, 512, 512), (2000, 768, 768), (700, 768, 3072), (1300, 512, 2048)])
+def test_gemm_fp16_residual_stream(M, N, K):
+    """bf16 mode's residual GEMM: out_f16 = fp16(x @ w.T + bias + fp16 residual), in place as the towers run it
+    (CMH_EPI_RES_F16 | CMH_EPI_OUT_F16); covers the residual pre-load (short K), the epilogue add (long K), partial tiles
+    and workgroups with more than one tile."""
+    import cmh_native as Nn
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16()
+    b = torch.randn(N, generator=g)
+    r = (3.0 * torch.randn(M, N, generator=g)).half()
+    ref = x.double() @ w.double().t() + b.double() + r.double()
+    out = Nn.linear_gemm(x.to(_dev()), w.to(_dev()), bias=b.to(_dev()), residual=r.to(_dev()), out_f16=True)
+    assert out.dtype == torch.float16
+    # fp16 output: half an ulp of |ref| (<= 2^-11 relative) on top of the bf16-operand accumulation noise
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=1.5e-3, atol=2e-3)
+    # f32 residual + fp16 out and fp16 residual + f32 out are legal combinations too
+    out2 = Nn.linear_gemm(x.to(_dev()), w.to(_dev()), bias=b.to(_dev()), residual=r.float().to(_dev()), out_f16=True)
+    torch.testing.assert_close(out2.cpu().double(), ref, rtol=1.5e-3, atol=2e-3)
+    out3 = Nn.linear_gemm(x.to(_dev()), w.to(_dev()), bias=b.to(_dev()), residual=r.to(_dev()))
+    assert out3.dtype == torch.float32
+    torch.testing.assert_close(out3.cpu().double(), ref, rtol=1e-3, atol=2e-3)
+    with pytest.raises(Nn.NativeError):
+        Nn.linear_gemm(x.to(_dev()), w[:128].to(_dev()), residual=r[:, :128].contiguous().to(_dev()), out_f16=True)
