@@ -87,9 +87,77 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
   ln_row(v, nv, d, lane, w, b, orow, out_bf16 ? kOutBf16 : kOutF32);
 }
 
+// The bf16 mode's LayerNorm: fp16 row in, bf16 row out, d a multiple of 256.  HALF a wave per row: a lane owns 8 consecutive
+// elements of every 256-element block, so a row is d/256 16-byte loads per lane (the one-wave-per-row kernel above moves
+// 8 bytes per lane per load and has too few bytes in flight: 39 MB in 12.4 us = 3.2 TB/s at width 768).
+template <int NB>   // d / 256
+__global__ __launch_bounds__(256) void layernorm_h2b_kernel(const uint16_t* __restrict__ x, const int32_t* __restrict__ row_index,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            uint16_t* __restrict__ out, int M) {
+  constexpr int d = NB * 256;
+  const int hl = threadIdx.x & 31;
+  const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (row >= M) return;
+  const size_t src = row_index ? static_cast<size_t>(row_index[row]) : static_cast<size_t>(row);
+  const uint16_t* xr = x + src * d;
+  typedef __attribute__((ext_vector_type(4))) uint32_t u4;
+  float v[NB][8];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const u4 u = *reinterpret_cast<const u4*>(xr + j * 256 + hl * 8);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[j][2 * k] = f16lo_to_f32(u[k]); v[j][2 * k + 1] = f16hi_to_f32(u[k]); }
+  }
+  auto half_sum = [](float t) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    return t;
+  };
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += v[j][k];
+  const float mean = half_sum(s) / static_cast<float>(d);
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const float c = v[j][k] - mean; ss += c * c; }
+  const float rstd = 1.0f / sqrtf(half_sum(ss) / static_cast<float>(d) + 1e-5f);
+  uint16_t* orow = out + static_cast<size_t>(row) * d;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int e0 = j * 256 + hl * 8;
+    const float4 w0 = *reinterpret_cast<const float4*>(w + e0), w1 = *reinterpret_cast<const float4*>(w + e0 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(b + e0), b1 = *reinterpret_cast<const float4*>(b + e0 + 4);
+    const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    u4 pk;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      pk[k] = pack_bf16x2((v[j][2 * k] - mean) * rstd * wv[2 * k] + bv[2 * k],
+                          (v[j][2 * k + 1] - mean) * rstd * wv[2 * k + 1] + bv[2 * k + 1]);
+    *reinterpret_cast<u4*>(orow + e0) = pk;
+  }
+}
+
 int launch_layernorm_x(const void* x, int x_f16, const int32_t* row_index, const float* w, const float* b, void* out,
                        int out_bf16, int M, int d, hipStream_t st) {
   CMH_CHECK_ARG(d % 4 == 0 && d <= 256 * kMaxVec, "layernorm: d=%d must be a multiple of 4 and <= 1024", d);
+  if (x_f16 && out_bf16 && d % 256 == 0) {
+    const uint16_t* xh = static_cast<const uint16_t*>(x);
+    uint16_t* oh = static_cast<uint16_t*>(out);
+    const dim3 grid((M + 7) / 8), block(256);
+    switch (d / 256) {
+      case 1: hipLaunchKernelGGL(layernorm_h2b_kernel<1>, grid, block, 0, st, xh, row_index, w, b, oh, M); break;
+      case 2: hipLaunchKernelGGL(layernorm_h2b_kernel<2>, grid, block, 0, st, xh, row_index, w, b, oh, M); break;
+      case 3: hipLaunchKernelGGL(layernorm_h2b_kernel<3>, grid, block, 0, st, xh, row_index, w, b, oh, M); break;
+      default: hipLaunchKernelGGL(layernorm_h2b_kernel<4>, grid, block, 0, st, xh, row_index, w, b, oh, M); break;
+    }
+    CMH_CHECK_LAUNCH("layernorm");
+    return CMH_OK;
+  }
   if (x_f16)
     hipLaunchKernelGGL(layernorm_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, x, row_index, w, b, out, out_bf16, M, d);
   else
