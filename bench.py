@@ -227,19 +227,26 @@ def main():
         rLp, qLp = N.pack_labels(rL.to(dev)), N.pack_labels(qL[lo:hi_].to(dev))
         planes = {k: N.pack_codes(v) for k, v in dict(r_img=r_img, r_txt=r_txt, q_img=q_img[lo:hi_], q_txt=q_txt[lo:hi_]).items()}
 
-        def four():
+        def four(tie=N.TIE_REFERENCE):
             res = []
             for qk, rk in (("q_img", "r_txt"), ("q_txt", "r_img"), ("q_img", "r_img"), ("q_txt", "r_txt")):
-                _, ap_l, _ = N.hamming_map(planes[qk], qLp, planes[rk], rLp, K, C)
+                _, ap_l, _ = N.hamming_map(planes[qk], qLp, planes[rk], rLp, K, C, tie_order=tie)
                 res.append(du.mean_in_query_order(du.gather_query_sharded_ap(ap_l, Q)) if world > 1 else ap_l.mean())
             return res
-        four()
-        barrier()
-        t0 = time.perf_counter()
-        maps = four()
-        barrier()
-        out["map_eval"] = {"ms": round((time.perf_counter() - t0) * 1e3, 3), "directions": 4, "Q": Q, "N": Nn,
-                           "bits": K, "tie_order": "reference (libstdc++ introsort)", "mAP_i2t": round(float(maps[0]), 6)}
+
+        def timed(tie):
+            four(tie)
+            barrier()
+            t0 = time.perf_counter()
+            maps = four(tie)
+            barrier()
+            return (time.perf_counter() - t0) * 1e3, maps
+        ms, maps = timed(N.TIE_REFERENCE)
+        ms_st, maps_st = timed(N.TIE_STABLE)
+        out["map_eval"] = {"ms": round(ms, 3), "directions": 4, "Q": Q, "N": Nn, "bits": K,
+                           "tie_order": "reference (libstdc++ introsort)", "mAP_i2t": round(float(maps[0]), 6),
+                           "stable_tie_order": {"ms": round(ms_st, 3), "mAP_i2t": round(float(maps_st[0]), 6),
+                                                "note": "CMH_TIE_STABLE (ties by index): not the reference's ranking"}}
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cb = cpu_baseline(L, K)

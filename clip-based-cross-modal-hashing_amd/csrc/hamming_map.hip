@@ -343,6 +343,7 @@ struct MapArgs {
   int Q, N, bits, W, LW;      // W = code words, LW = label words
   long long topk;
   int depth_limit;            // < 0: 2*floor(log2 N)
+  int stable;                 // CMH_TIE_STABLE: full sort of (key, index) instead of the introsort emulation
   float* ap;
   int32_t* perm;              // may be null
   uint32_t* gstore;           // global slices (USE_LDS=false): gridDim.x * store_words(N)
@@ -357,6 +358,7 @@ __global__ __launch_bounds__(NT) void map_query_kernel(MapArgs A) {
   __shared__ int sqcount[2];
   __shared__ int swork[NWAVE + 2];
   __shared__ double sred[NWAVE];
+  __shared__ int shist[NWAVE * 64];         // CMH_TIE_STABLE: (wave, digit) cells of the radix passes
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int N = A.N, W = A.W, LW = A.LW;
@@ -415,6 +417,77 @@ __global__ __launch_bounds__(NT) void map_query_kernel(MapArgs A) {
       continue;
     }
 
+    if (A.stable) {
+      // ---- CMH_TIE_STABLE: ties by ascending database index == ascending order of the (unique) u32 elements
+      // key << 19 | index.  LSD radix sort on the key alone, 6 bits per pass (2 passes for 64-bit codes), order-preserving:
+      // wave w owns the contiguous chunk [ca, cb) of the current array; per 64-element group a lane finds the lanes with
+      // its digit from 6 ballots (no waterfall), its destination is (exclusive prefix of its (digit, wave) cell) + (# equal
+      // digits in lower lanes), and the lowest lane of each digit class bumps the cell.
+      const int per_s = (((N + NWAVE - 1) / NWAVE) + 63) & ~63;
+      int ca = wid * per_s; ca = ca < N ? ca : N;
+      int cb = ca + per_s; cb = cb < N ? cb : N;
+      const int keybits = 32 - __clz(2 * A.bits);
+      uint32_t* src = e;
+      uint32_t* dst = S.tmp;
+      auto digit_class = [&](bool valid, int d) -> uint64_t {
+        uint64_t m = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 6; ++bit) {
+          const bool one = (d >> bit) & 1;
+          const uint64_t bb = __ballot(valid && one);
+          m &= one ? bb : ~bb;
+        }
+        return m;
+      };
+      for (int shift = 0; shift < keybits; shift += 6) {
+        shist[wid * 64 + lane] = 0;
+        wave_sync();
+        for (int x0 = ca; x0 < cb; x0 += 64) {
+          const int x = x0 + lane;
+          const bool valid = x < cb;
+          const int d = valid ? (ekey(src[x]) >> shift) & 63 : 0;
+          const uint64_t m = digit_class(valid, d);
+          if (valid && (m & lanemask_lt(lane)) == 0) shist[wid * 64 + d] += __popcll(m);
+          wave_sync();
+        }
+        __syncthreads();
+        // exclusive scan of the 64 x 16 cells in (digit major, wave minor) order: thread t <-> (digit t/16, wave t%16)
+        const int cell = (tid & (NWAVE - 1)) * 64 + (tid / NWAVE);
+        const int v = shist[cell];
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int up = __shfl_up(inc, o, 64);
+          if (lane >= o) inc += up;
+        }
+        if (lane == 63) swork[wid] = inc;
+        __syncthreads();
+        int wbase = 0;
+        for (int w = 0; w < wid; ++w) wbase += swork[w];
+        shist[cell] = wbase + inc - v;
+        __syncthreads();
+        for (int x0 = ca; x0 < cb; x0 += 64) {
+          const int x = x0 + lane;
+          const bool valid = x < cb;
+          const uint32_t val = valid ? src[x] : 0u;
+          const int d = valid ? (ekey(val) >> shift) & 63 : 0;
+          const uint64_t m = digit_class(valid, d);
+          const int base = valid ? shist[wid * 64 + d] : 0;
+          wave_sync();
+          if (valid) {
+            dst[base + __popcll(m & lanemask_lt(lane))] = val;
+            if ((m & lanemask_lt(lane)) == 0) shist[wid * 64 + d] = base + __popcll(m);
+          }
+          wave_sync();
+        }
+        __syncthreads();
+        uint32_t* t = src; src = dst; dst = t;
+      }
+      if (src != e) {                      // odd number of passes: bring the result home
+        for (int x = tid; x < N; x += NT) e[x] = src[x];
+      }
+      __syncthreads();
+    } else {
     if (A.stamps && blockIdx.x == 0 && qi == 0 && tid == 0) A.stamps[1] = __builtin_readcyclecounter();
     // ---- phase 1: introsort loop, breadth-first ------------------------------------------------------
     int depth = A.depth_limit >= 0 ? A.depth_limit : 2 * (31 - __clz(N));   // std::__lg(n) * 2
@@ -503,6 +576,7 @@ __global__ __launch_bounds__(NT) void map_query_kernel(MapArgs A) {
     }
     __syncthreads();
 
+    }
     if (A.stamps && blockIdx.x == 0 && qi == 0 && tid == 0) A.stamps[4] = __builtin_readcyclecounter();
     // ---- phase 3: AP = mean_{r<=total} r / position_r   (utils/calc_utils.py:33-37) -----------------------
     const long long total = A.topk > 0 && A.topk < tsum ? A.topk : tsum;
@@ -704,14 +778,14 @@ extern "C" int cmh_hamming_map(const uint32_t* q_sign, const uint32_t* q_nz, con
   CMH_CHECK_ARG(N < (1ll << kIdxBits), "hamming_map: N=%lld exceeds %d", static_cast<long long>(N), (1 << kIdxBits) - 1);
   CMH_CHECK_ARG(bits > 0 && bits <= 32 * kMaxWords && 2 * bits < (1 << (32 - kIdxBits)), "hamming_map: bits=%d unsupported", bits);
   CMH_CHECK_ARG(classes > 0 && classes <= 32 * kMaxWords, "hamming_map: classes=%d unsupported", classes);
-  CMH_CHECK_ARG(tie_order == CMH_TIE_REFERENCE, "hamming_map: tie_order %d not implemented (only CMH_TIE_REFERENCE)", tie_order);
+  CMH_CHECK_ARG(tie_order == CMH_TIE_REFERENCE || tie_order == CMH_TIE_STABLE, "hamming_map: bad tie_order %d", tie_order);
   const size_t need = cmh_map_workspace_bytes(Q, N, bits, tie_order);
   if (workspace_bytes < need || !workspace) return fail(CMH_ERR_WORKSPACE, "hamming_map: workspace %zu < %zu bytes", workspace_bytes, need);
   hipStream_t st = as_stream(stream);
   MapArgs a;
   a.q_sign = q_sign; a.q_nz = q_nz; a.q_label = q_label; a.r_sign = r_sign; a.r_nz = r_nz; a.r_label = r_label;
   a.Q = Q; a.N = static_cast<int>(N); a.bits = bits; a.W = (bits + 31) / 32; a.LW = (classes + 31) / 32;
-  a.topk = topk; a.depth_limit = depth_limit_override; a.ap = ap; a.perm = perm;
+  a.topk = topk; a.depth_limit = depth_limit_override; a.stable = tie_order == CMH_TIE_STABLE; a.ap = ap; a.perm = perm;
   a.gstore = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
   a.stamps = getenv("CMH_MAP_STAMPS") ? reinterpret_cast<unsigned long long*>(a.gstore) : nullptr;   // LDS mode only: slice 0 unused
   const size_t lds = lds_bytes_needed(N);

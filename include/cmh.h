@@ -205,7 +205,7 @@ int cmh_calc_neighbor(const uint32_t* la, const uint32_t* lb, int32_t A, int32_t
 
 typedef enum cmh_tie_order {
   CMH_TIE_REFERENCE = 0,    /* torch.sort(stable=False) on CPU == libstdc++ introsort order */
-  CMH_TIE_STABLE = 1        /* ties by ascending database index */
+  CMH_TIE_STABLE = 1        /* ties by ascending database index (torch.sort(stable=True)): LSD radix sort, ~4x faster */
 } cmh_tie_order;
 
 size_t cmh_map_workspace_bytes(int32_t Q, int64_t N, int32_t bits, int32_t tie_order);

@@ -121,3 +121,33 @@ def test_bad_codes_are_refused():
         N.pack_codes(c)
     with pytest.raises(N.NativeError):
         N.pack_labels(-torch.ones(2, 5, device=DEV))
+
+
+@pytest.mark.parametrize("Q,N,K,C,k,zeros", [(5, 7, 16, 4, None, False), (9, 200, 64, 8, 50, False), (6, 1000, 128, 12, None, True),
+                                              (4, 4097, 512, 24, 1000, False), (3, 5000, 2048, 24, None, True),
+                                              (3, 30000, 64, 24, 5000, False)])
+def test_stable_tie_order_matches_stable_sort(Q, N, K, C, k, zeros):
+    """CMH_TIE_STABLE: ties by ascending database index == the oracle's std::stable_sort ranking, bit-exact (1, 2 and 3
+    radix passes; LDS- and workspace-resident queries; codes with zeros; a query without relevant items)."""
+    import cmh_native as Nn
+    rng = np.random.default_rng(Q * 1000 + N + K)
+    vals = np.array([-1.0, 1.0, 0.0] if zeros else [-1.0, 1.0], np.float32)
+    qB = vals[rng.integers(0, len(vals), (Q, K))]
+    rB = vals[rng.integers(0, len(vals), (N, K))]
+    qL = (rng.random((Q, C)) < 0.2).astype(np.float32)
+    rL = (rng.random((N, C)) < 0.2).astype(np.float32)
+    qL[0] = 0                                             # no relevant item: skipped by the reference
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    mp, ap, perm = Nn.hamming_map(Nn.pack_codes(t(qB)), Nn.pack_labels(t(qL)), Nn.pack_codes(t(rB)), Nn.pack_labels(t(rL)),
+                                  K, C, topk=k, tie_order=Nn.TIE_STABLE, want_perm=True)
+    m_ref, ap_ref, ind = oracle.map_k(qB, rB, qL, rL, k, stable=True, want_ind=True)
+    perm = perm.cpu().numpy()
+    assert (perm[0] == -1).all()
+    np.testing.assert_array_equal(perm[1:], ind[1:])
+    np.testing.assert_allclose(ap.cpu().numpy(), ap_ref, rtol=0, atol=2e-6)
+    assert abs(float(mp) - float(m_ref)) < 2e-6
+    # and it is NOT the reference's order whenever ties exist (the two modes must not be confused)
+    if N >= 1000 and K <= 128:
+        _, _, perm_ref = Nn.hamming_map(Nn.pack_codes(t(qB)), Nn.pack_labels(t(qL)), Nn.pack_codes(t(rB)), Nn.pack_labels(t(rL)),
+                                        K, C, topk=k, want_perm=True)
+        assert not np.array_equal(perm_ref.cpu().numpy()[1:], perm[1:])
