@@ -47,6 +47,11 @@ class TextWeights(C.Structure):
                 ("blocks", C.POINTER(BlockWeights))]
 
 
+class AdamTensor(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64),
+                ("lr", C.c_float), ("weight_decay", C.c_float), ("max_grad_norm", C.c_float)]
+
+
 class Taps(C.Structure):
     _fields_ = [("ptrs", C.POINTER(C.c_void_p)), ("count", C.c_int32)]
 
@@ -100,6 +105,8 @@ SIGNATURES = {
     "cmh_sq_diff_sum": (C.c_int, [_p, _p, _i64, _p, _p, _sz, _p]),
     "cmh_mith_bayesian_loss": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _sz, _p]),
     "cmh_info_nce": (C.c_int, [_p, _p, _i32, _i32, _i32, _f, _p, _p, _sz, _p]),
+    "cmh_bert_adam_workspace_bytes": (_sz, [_i32, _i64]),
+    "cmh_bert_adam_step": (C.c_int, [C.POINTER(AdamTensor), _i32, C.c_double, C.c_double, C.c_double, _p, _sz, _p]),
 }
 
 
@@ -412,3 +419,25 @@ def dnph_loss(hash_img, hash_txt, pre_img, pre_txt, label, proxies, noise_img=No
     check(lib().cmh_dnph_loss(*[ptr(t) for t in ts], ptr(ni), ptr(nt), B, K, Cn, float(margin), float(noise_weight),
                               ptr(out), ptr(ws), ws.numel(), stream_ptr(ts[0].device)), "cmh_dnph_loss")
     return out[0], out[1], out[2]
+
+
+# ------------------------------------------------------------------------------------------ optimiser
+def bert_adam_step(entries, b1, b2, eps):
+    """One fused BertAdam step over `entries` = [(param, grad, next_m, next_v, lr_scheduled, weight_decay, max_grad_norm)]
+    (all f32, contiguous, on one GPU).  Updates param / next_m / next_v in place and, like clip_grad_norm_, the clipped grad."""
+    if not entries:
+        return
+    dev = entries[0][0].device
+    arr = (AdamTensor * len(entries))()
+    total = 0
+    for i, (p, g, m, v, lr, wd, mx) in enumerate(entries):
+        require_gpu(p, g, m, v)
+        for t in (p, g, m, v):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != p.numel():
+                raise NativeError("bert_adam_step: tensors must be contiguous f32 of one size")
+        arr[i] = AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(wd), float(mx))
+        total += p.numel()
+    need = lib().cmh_bert_adam_workspace_bytes(len(entries), total)
+    ws = workspace(need, dev, "adam")
+    check(lib().cmh_bert_adam_step(arr, len(entries), float(b1), float(b2), float(eps), ptr(ws), ws.numel(), stream_ptr(dev)),
+          "cmh_bert_adam_step")

@@ -1,12 +1,13 @@
 """DSPH trainer (reference train/DSPH/hash_train.py:16-73; paper: Deep Semantic-aware Proxy Hashing,
-TCSVT 2023).  Forward, loss and validation run on libcmh; the optimiser step is not built yet:
-BertAdam + encoder backward are SURVEY §8f "next" #1/#2, so train_epoch stops loudly at backward."""
+TCSVT 2023).  Forward, loss and validation run on libcmh, and so does the optimiser (fused BertAdam, SURVEY §8f "next"
+#1); encoder backward is "next" #2, so train_epoch still stops loudly at `loss.backward()`."""
 import os
 import time
 
 import torch
 
 from model.DSPH import MDSPH
+from model.base.optimization import BertAdam
 from train.base import TrainBase
 from .get_args import get_args
 from .loss import HyP
@@ -32,7 +33,14 @@ class DSPHTrainer(TrainBase):
         self.model.clip.set_gemm_dtype(self.args.gemm_dtype)
         self.args.numclass = self.args.nclass
         self.hyp = HyP(self.args).to(self.rank)
-        self.optimizer = None
+        # reference train/DSPH/hash_train.py:35-44: two learning rates, warm-up cosine, SGD for the proxies
+        self.optimizer = BertAdam([
+            {"params": self.model.clip.parameters(), "lr": self.args.clip_lr},
+            {"params": self.model.image_hash.parameters(), "lr": self.args.lr},
+            {"params": self.model.text_hash.parameters(), "lr": self.args.lr}],
+            lr=self.args.lr, warmup=self.args.warmup_proportion, schedule="warmup_cosine", b1=0.9, b2=0.98, e=1e-6,
+            t_total=len(self.train_loader) * self.args.epochs, weight_decay=self.args.weight_decay, max_grad_norm=1.0)
+        self.optimizer_loss = torch.optim.SGD(params=self.hyp.parameters(), lr=0.02, momentum=0.9, weight_decay=0.0005)
         self.total_time = 0
 
     def compute_loss(self, hash_img, hash_text, label):
@@ -51,6 +59,10 @@ class DSPHTrainer(TrainBase):
             hash_img, hash_text = self.model(image, text)
             loss = self.compute_loss(hash_img, hash_text, label)
             all_loss += loss
+            self.optimizer.zero_grad()
+            self.optimizer_loss.zero_grad()
             loss.backward()      # raises NotImplementedError: backward kernels are the next scope row
+            self.optimizer.step()
+            self.optimizer_loss.step()
             self.total_time += time.time() - start_time
         self.logger.info(f">>>>>> [{epoch}/{self.args.epochs}] loss: {all_loss.data / (len(self.train_loader))}, time: {self.total_time}")

@@ -325,6 +325,24 @@ int cmh_mith_bayesian_loss(const float* bank, const float* batch, const float* b
 int cmh_info_nce(const float* a, const float* b, int32_t R, int32_t G, int32_t D, float temperature, float* out,
                  void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * BertAdam, one fused multi-tensor step (model/base/optimization.py:103-168; SURVEY 8f "next" #1).
+ * `tensors` is a HOST array; p/g/m/v are device pointers to f32 tensors of n elements (m = state['next_m'],
+ * v = state['next_v']).  Per tensor: g *= min(1, max_grad_norm/(||g||+1e-6)) in place when max_grad_norm > 0 (:135-136);
+ * m = m*b1 + (1-b1)*g (:141); v = v*b2 + (1-b2)*g*g (:143); p -= lr * (m/(sqrt(v)+eps) + weight_decay*p) (:144-164),
+ * with lr = the caller's already scheduled rate (lr * schedule(step/t_total, warmup), :157-161).
+ * Synchronises `stream` once on entry (it re-uses a host staging table).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct cmh_adam_tensor {
+  float* p; float* g; float* m; float* v;
+  int64_t n;
+  float lr, weight_decay, max_grad_norm;
+} cmh_adam_tensor;
+size_t cmh_bert_adam_workspace_bytes(int32_t count, int64_t total_elems);
+/* b1 / b2 / eps are doubles because the reference forms 1 - b in python doubles before ATen rounds it to f32. */
+int cmh_bert_adam_step(const cmh_adam_tensor* tensors, int32_t count, double b1, double b2, double eps,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
