@@ -1,0 +1,55 @@
+"""ctypes wrappers of the backward building blocks (include/cmh.h, csrc/backward.hip, csrc/attention_bwd.hip).  Same rules as
+cmh_native: GPU tensors only, no fallback."""
+import torch
+
+import cmh_native as N
+
+KIND = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
+def transpose(src, dst_dtype=None):
+    """[R, C] -> [C, R], optionally cast (f32 -> bf16 for GEMM operands)."""
+    N.require_gpu(src)
+    src = src.contiguous()
+    R, Cc = src.shape
+    dst = torch.empty(Cc, R, dtype=dst_dtype or src.dtype, device=src.device)
+    N.check(N.lib().cmh_transpose(N.ptr(src), KIND[src.dtype], N.ptr(dst), KIND[dst.dtype], R, Cc, N.stream_ptr(src.device)),
+            "cmh_transpose")
+    return dst
+
+
+def colsum(x):
+    N.require_gpu(x)
+    x = x.contiguous()
+    R, Cc = x.shape
+    out = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    ws = N.workspace(N.lib().cmh_colsum_workspace_bytes(R, Cc), x.device, "bwd")
+    N.check(N.lib().cmh_colsum(N.ptr(x), KIND[x.dtype], R, Cc, N.ptr(out), N.ptr(ws), ws.numel(), N.stream_ptr(x.device)),
+            "cmh_colsum")
+    return out
+
+
+def layernorm_backward(x, dy, gamma, dx=None):
+    """-> (dx f32 [M,d] (accumulated into `dx` when given), dgamma, dbeta)"""
+    N.require_gpu(x, dy, gamma, dx)
+    x, dy, gamma = x.contiguous(), dy.contiguous(), N.f32c(gamma)
+    M, d = x.shape
+    acc = dx is not None
+    if dx is None:
+        dx = torch.empty(M, d, dtype=torch.float32, device=x.device)
+    dg = torch.empty(d, dtype=torch.float32, device=x.device)
+    db = torch.empty(d, dtype=torch.float32, device=x.device)
+    ws = N.workspace(N.lib().cmh_layernorm_backward_workspace_bytes(M, d), x.device, "bwd")
+    N.check(N.lib().cmh_layernorm_backward(N.ptr(x), KIND[x.dtype], N.ptr(dy), KIND[dy.dtype], N.ptr(gamma), M, d, N.ptr(dx),
+                                           int(acc), N.ptr(dg), N.ptr(db), N.ptr(ws), ws.numel(), N.stream_ptr(x.device)),
+            "cmh_layernorm_backward")
+    return dx, dg, db
+
+
+def quick_gelu(pre):
+    N.require_gpu(pre)
+    pre = pre.contiguous()
+    out = torch.empty_like(pre)
+    N.check(N.lib().cmh_quick_gelu(N.ptr(pre), N.ptr(out), pre.numel(), KIND[pre.dtype], N.stream_ptr(pre.device)),
+            "cmh_quick_gelu")
+    return out

@@ -1,0 +1,243 @@
+// Backward building blocks of the towers (SURVEY §8f "next" #2) — the row-wise / element-wise HBM-bound kernels:
+//   transpose (+ cast)        wgrad operands: dW = dY^T.X contracts over the M rows, and the GEMM kernels want both
+//                             operands contraction-contiguous, so dY and X are transposed (and cast to the GEMM dtype) once
+//   column sums               bias gradients  db = sum_m dY[m, :]
+//   LayerNorm backward        dx (+= into the gradient stream), dgamma, dbeta       (nn.LayerNorm, model/base/model.py:153-159)
+//   QuickGELU forward         mlp = pre * sigmoid(1.702 pre) from the saved pre-activation (model/base/model.py:162-164);
+//                             its derivative is fused into the dgrad GEMM's epilogue (EPI_MUL_DQGELU, gemm_wide.hip)
+// Data types: the gradient stream is f32; GEMM operands are f32 (f32 mode) or bf16; the forward residual stream x is f32 or
+// fp16 (bf16 mode).  "kind": 0 = f32, 1 = bf16, 2 = fp16.
+#include "cmh_common.h"
+
+namespace cmh {
+
+constexpr int kF32 = 0, kBF16 = 1, kF16 = 2;
+
+__device__ __forceinline__ float load_as_f32(const void* p, size_t i, int kind) {
+  if (kind == kF32) return static_cast<const float*>(p)[i];
+  const uint16_t h = static_cast<const uint16_t*>(p)[i];
+  if (kind == kBF16) return bf16_to_f32(h);
+  return static_cast<float>(__builtin_bit_cast(_Float16, h));
+}
+__device__ __forceinline__ void store_from_f32(void* p, size_t i, int kind, float v) {
+  if (kind == kF32) static_cast<float*>(p)[i] = v;
+  else if (kind == kBF16) static_cast<uint16_t*>(p)[i] = f32_to_bf16(v);
+  else static_cast<uint16_t*>(p)[i] = __builtin_bit_cast(uint16_t, static_cast<_Float16>(v));
+}
+
+// ---- transpose: dst[c, r] = cast(src[r, c]) -------------------------------------------------------------------------
+// 64x64 tile per 256-thread workgroup through LDS (row stride 65 words: conflict-free both ways); reads are coalesced
+// along c, writes along r.
+__global__ __launch_bounds__(256) void transpose_kernel(const void* __restrict__ src, void* __restrict__ dst, int R, int C,
+                                                        int skind, int dkind) {
+  __shared__ float tile[64][65];
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < C) ? load_as_f32(src, static_cast<size_t>(r) * C + c, skind) : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < C && r < R) store_from_f32(dst, static_cast<size_t>(c) * R + r, dkind, tile[tx][i]);
+  }
+}
+
+// ---- column sums: partial[b, c] = sum over the block's rows; then a second pass over the partials ------------------------
+constexpr int kColRows = 128;   // rows per workgroup
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const void* __restrict__ x, int kind, int R, int C,
+                                                             float* __restrict__ partial) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int r0 = blockIdx.y * kColRows;
+  const int r1 = r0 + kColRows < R ? r0 + kColRows : R;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += load_as_f32(x, static_cast<size_t>(r) * C + c, kind);
+  partial[static_cast<size_t>(blockIdx.y) * C + c] = s;
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nb, int C,
+                                                           float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int b = 0; b < nb; ++b) s += static_cast<double>(partial[static_cast<size_t>(b) * C + c]);
+  out[c] = static_cast<float>(s);
+}
+
+// ---- LayerNorm backward ------------------------------------------------------------------------------------------------------
+// y = (x - mean) * rstd * g + b.  With xh = (x - mean) * rstd and a = dy * g:
+//   dx = rstd * (a - mean(a) - xh * mean(a * xh)),  dg = sum_rows dy * xh,  db = sum_rows dy.
+// One wave per row (lane owns elements lane*4 + 256*j, d <= 1024); a workgroup of 4 waves walks kLnRows rows, every lane keeps
+// its dg/db columns in registers, the 4 waves are combined through LDS and one partial row per workgroup goes to HBM
+// (column-summed by colsum_final_kernel).
+constexpr int kLnRows = 32;
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ x, int xkind, const void* __restrict__ dy,
+                                                            int dykind, const float* __restrict__ g, float* __restrict__ dx,
+                                                            int accumulate, int M, int d, float* __restrict__ pg,
+                                                            float* __restrict__ pb) {
+  __shared__ float red[2][4][1024];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nv = (d + 255) / 256;
+  float gam[4][4], dg[4][4], db[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e = lane * 4 + 256 * j + k;
+      gam[j][k] = (j < nv && e < d) ? g[e] : 0.f;
+      dg[j][k] = 0.f; db[j][k] = 0.f;
+    }
+  const int rbase = blockIdx.x * kLnRows;
+  for (int rr = wid; rr < kLnRows; rr += 4) {
+    const int row = rbase + rr;
+    if (row >= M) break;
+    float xv[4][4], dv[4][4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = lane * 4 + 256 * j + k;
+        const bool ok = j < nv && e < d;
+        xv[j][k] = ok ? load_as_f32(x, static_cast<size_t>(row) * d + e, xkind) : 0.f;
+        dv[j][k] = ok ? load_as_f32(dy, static_cast<size_t>(row) * d + e, dykind) : 0.f;
+        s += xv[j][k];
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / static_cast<float>(d);
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = lane * 4 + 256 * j + k;
+        if (j < nv && e < d) { const float c = xv[j][k] - mean; ss += c * c; }
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float rstd = 1.0f / sqrtf(ss / static_cast<float>(d) + 1e-5f);
+    float sa = 0.f, sax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = lane * 4 + 256 * j + k;
+        if (j < nv && e < d) {
+          const float xh = (xv[j][k] - mean) * rstd;
+          const float a = dv[j][k] * gam[j][k];
+          sa += a; sax += a * xh;
+          dg[j][k] += dv[j][k] * xh;
+          db[j][k] += dv[j][k];
+          xv[j][k] = xh;            // keep xh, a for the dx pass
+          dv[j][k] = a;
+        }
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); sax += __shfl_xor(sax, o, 64); }
+    const float ma = sa / static_cast<float>(d), max_ = sax / static_cast<float>(d);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = lane * 4 + 256 * j + k;
+        if (j < nv && e < d) {
+          const float v = rstd * (dv[j][k] - ma - xv[j][k] * max_);
+          float* o = dx + static_cast<size_t>(row) * d + e;
+          *o = accumulate ? *o + v : v;
+        }
+      }
+  }
+  // combine the 4 waves' dg / db columns, one partial row per workgroup
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e = lane * 4 + 256 * j + k;
+      if (e < 1024) { red[0][wid][e] = dg[j][k]; red[1][wid][e] = db[j][k]; }
+    }
+  __syncthreads();
+  for (int e = threadIdx.x; e < d; e += 256) {
+    pg[static_cast<size_t>(blockIdx.x) * d + e] = (red[0][0][e] + red[0][1][e]) + (red[0][2][e] + red[0][3][e]);
+    pb[static_cast<size_t>(blockIdx.x) * d + e] = (red[1][0][e] + red[1][1][e]) + (red[1][2][e] + red[1][3][e]);
+  }
+}
+
+// ---- QuickGELU forward from the saved pre-activation -----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void quick_gelu_kernel(const void* __restrict__ pre, void* __restrict__ out, int64_t n, int kind) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float v = load_as_f32(pre, i, kind);
+    store_from_f32(out, i, kind, v / (1.0f + __expf(-1.702f * v)));
+  }
+}
+
+static int kind_ok(int k) { return k == kF32 || k == kBF16 || k == kF16; }
+
+}  // namespace cmh
+
+using namespace cmh;
+
+extern "C" int cmh_transpose(const void* src, int32_t src_kind, void* dst, int32_t dst_kind, int32_t rows, int32_t cols,
+                             void* stream) {
+  CMH_CHECK_ARG(src && dst && rows > 0 && cols > 0, "transpose: bad arguments");
+  CMH_CHECK_ARG(kind_ok(src_kind) && kind_ok(dst_kind), "transpose: bad element kind %d / %d", src_kind, dst_kind);
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, as_stream(stream), src, dst, rows,
+                     cols, src_kind, dst_kind);
+  CMH_CHECK_LAUNCH("transpose");
+  return CMH_OK;
+}
+
+extern "C" size_t cmh_colsum_workspace_bytes(int32_t rows, int32_t cols) {
+  if (rows <= 0 || cols <= 0) return 0;
+  return static_cast<size_t>((rows + kColRows - 1) / kColRows) * cols * 4 + 256;
+}
+
+extern "C" int cmh_colsum(const void* x, int32_t kind, int32_t rows, int32_t cols, float* out, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  CMH_CHECK_ARG(x && out && workspace && rows > 0 && cols > 0 && kind_ok(kind), "colsum: bad arguments");
+  if (workspace_bytes < cmh_colsum_workspace_bytes(rows, cols)) return fail(CMH_ERR_WORKSPACE, "colsum: workspace too small");
+  float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+  const int nb = (rows + kColRows - 1) / kColRows;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 255) / 256, nb), dim3(256), 0, st, x, kind, rows, cols, partial);
+  CMH_CHECK_LAUNCH("colsum_partial");
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, partial, nb, cols, out);
+  CMH_CHECK_LAUNCH("colsum_final");
+  return CMH_OK;
+}
+
+extern "C" size_t cmh_layernorm_backward_workspace_bytes(int32_t M, int32_t d) {
+  if (M <= 0 || d <= 0) return 0;
+  return static_cast<size_t>((M + kLnRows - 1) / kLnRows) * d * 8 + 512;
+}
+
+extern "C" int cmh_layernorm_backward(const void* x, int32_t x_kind, const void* dy, int32_t dy_kind, const float* gamma,
+                                      int32_t M, int32_t d, float* dx, int32_t accumulate, float* dgamma, float* dbeta,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  CMH_CHECK_ARG(x && dy && gamma && dx && dgamma && dbeta && workspace && M > 0, "layernorm_backward: bad arguments");
+  CMH_CHECK_ARG(d % 4 == 0 && d <= 1024, "layernorm_backward: d=%d must be a multiple of 4 and <= 1024", d);
+  CMH_CHECK_ARG((x_kind == kF32 || x_kind == kF16) && (dy_kind == kF32 || dy_kind == kBF16), "layernorm_backward: bad kinds");
+  if (workspace_bytes < cmh_layernorm_backward_workspace_bytes(M, d)) return fail(CMH_ERR_WORKSPACE, "layernorm_backward: workspace too small");
+  const int nb = (M + kLnRows - 1) / kLnRows;
+  float* pg = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+  float* pb = pg + static_cast<size_t>(nb) * d;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, st, x, x_kind, dy, dy_kind, gamma, dx, accumulate, M, d, pg, pb);
+  CMH_CHECK_LAUNCH("layernorm_backward");
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 255) / 256), dim3(256), 0, st, pg, nb, d, dgamma);
+  CMH_CHECK_LAUNCH("layernorm_backward dgamma");
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 255) / 256), dim3(256), 0, st, pb, nb, d, dbeta);
+  CMH_CHECK_LAUNCH("layernorm_backward dbeta");
+  return CMH_OK;
+}
+
+extern "C" int cmh_quick_gelu(const void* pre, void* out, int64_t n, int32_t kind, void* stream) {
+  CMH_CHECK_ARG(pre && out && n > 0 && kind_ok(kind), "quick_gelu: bad arguments");
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(quick_gelu_kernel, dim3(static_cast<unsigned>(blocks < 8192 ? blocks : 8192)), dim3(256), 0, as_stream(stream),
+                     pre, out, n, kind);
+  CMH_CHECK_LAUNCH("quick_gelu");
+  return CMH_OK;
+}

@@ -343,6 +343,27 @@ size_t cmh_bert_adam_workspace_bytes(int32_t count, int64_t total_elems);
 int cmh_bert_adam_step(const cmh_adam_tensor* tensors, int32_t count, double b1, double b2, double eps,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Backward building blocks of the towers (SURVEY 8f "next" #2).  Element kinds: 0 = f32, 1 = bf16, 2 = fp16.
+ * ------------------------------------------------------------------------------------------- */
+#define CMH_KIND_F32 0
+#define CMH_KIND_BF16 1
+#define CMH_KIND_F16 2
+/* dst[c, r] = cast(src[r, c]): wgrad operands (dW = dY^T . X contracts over rows). */
+int cmh_transpose(const void* src, int32_t src_kind, void* dst, int32_t dst_kind, int32_t rows, int32_t cols, void* stream);
+/* out[c] = sum_r x[r, c] (bias gradients), f32 result, deterministic two-pass reduction. */
+size_t cmh_colsum_workspace_bytes(int32_t rows, int32_t cols);
+int cmh_colsum(const void* x, int32_t kind, int32_t rows, int32_t cols, float* out, void* workspace, size_t workspace_bytes,
+               void* stream);
+/* nn.LayerNorm backward (model/base/model.py:153-159, eps 1e-5): x f32|fp16 [M,d] (the forward's input), dy f32|bf16 [M,d],
+ * dx f32 [M,d] (accumulate != 0: dx += ...), dgamma / dbeta f32 [d]. */
+size_t cmh_layernorm_backward_workspace_bytes(int32_t M, int32_t d);
+int cmh_layernorm_backward(const void* x, int32_t x_kind, const void* dy, int32_t dy_kind, const float* gamma, int32_t M,
+                           int32_t d, float* dx, int32_t accumulate, float* dgamma, float* dbeta, void* workspace,
+                           size_t workspace_bytes, void* stream);
+/* out = pre * sigmoid(1.702 pre) element-wise from a saved pre-activation (model/base/model.py:162-164). */
+int cmh_quick_gelu(const void* pre, void* out, int64_t n, int32_t kind, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

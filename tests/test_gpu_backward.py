@@ -1,0 +1,57 @@
+"""Backward building blocks (csrc/backward.hip, attention_bwd.hip, GEMM epilogues) against fp64 torch-CPU autograd of the
+same op."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("R,C", [(1, 1), (63, 65), (130, 768), (1000, 3072)])
+@pytest.mark.parametrize("sdt,ddt", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.bfloat16)])
+def test_transpose(R, C, sdt, ddt):
+    import backward_ops as B
+    x = torch.randn(R, C).to(sdt)
+    out = B.transpose(x.to(DEV), ddt)
+    assert out.shape == (C, R) and out.dtype == ddt
+    assert torch.equal(out.cpu(), x.t().contiguous().to(ddt))
+
+
+@pytest.mark.parametrize("R,C,dt", [(1, 5, torch.float32), (129, 768, torch.float32), (12800, 2304, torch.bfloat16)])
+def test_colsum(R, C, dt):
+    import backward_ops as B
+    x = torch.randn(R, C).to(dt)
+    out = B.colsum(x.to(DEV)).cpu().double()
+    ref = x.double().sum(0)
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-4 * R ** 0.5)
+
+
+@pytest.mark.parametrize("M,d", [(3, 128), (100, 512), (1000, 768), (33, 1024)])
+@pytest.mark.parametrize("xdt,gdt", [(torch.float32, torch.float32), (torch.float16, torch.bfloat16)])
+def test_layernorm_backward(M, d, xdt, gdt):
+    import backward_ops as B
+    g = torch.Generator().manual_seed(M + d)
+    x = (torch.randn(M, d, generator=g) * 2 + 0.5).to(xdt)
+    dy = torch.randn(M, d, generator=g).to(gdt)
+    gamma = torch.randn(d, generator=g)
+    beta = torch.randn(d, generator=g)
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr, (d,), gr, br, 1e-5).backward(dy.double())
+    base = torch.randn(M, d, generator=g)
+    dx, dg, db = B.layernorm_backward(x.to(DEV), dy.to(DEV), gamma.to(DEV), dx=base.clone().to(DEV))
+    torch.testing.assert_close(dx.cpu().double(), base.double() + xr.grad, rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(dg.cpu().double(), gr.grad, rtol=2e-4, atol=2e-4 * M ** 0.5)
+    torch.testing.assert_close(db.cpu().double(), br.grad, rtol=2e-4, atol=2e-4 * M ** 0.5)
+    dx2, _, _ = B.layernorm_backward(x.to(DEV), dy.to(DEV), gamma.to(DEV))
+    torch.testing.assert_close(dx2.cpu().double(), xr.grad, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_quick_gelu_forward(dt):
+    import backward_ops as B
+    x = (torch.randn(10007) * 3).to(dt)
+    out = B.quick_gelu(x.to(DEV)).cpu().double()
+    ref = x.double() * torch.sigmoid(1.702 * x.double())
+    torch.testing.assert_close(out, ref, rtol=1e-2 if dt == torch.bfloat16 else 1e-5, atol=1e-2 if dt == torch.bfloat16 else 1e-6)
