@@ -53,3 +53,16 @@ def quick_gelu(pre):
     N.check(N.lib().cmh_quick_gelu(N.ptr(pre), N.ptr(out), pre.numel(), KIND[pre.dtype], N.stream_ptr(pre.device)),
             "cmh_quick_gelu")
     return out
+
+
+def attention_backward(qkv, o, dout, B, T, causal, key_padding_mask=None):
+    """-> dqkv like qkv ([B*T, 3d]); o is the forward output of cmh_attention, dout its gradient."""
+    N.require_gpu(qkv, o, dout, key_padding_mask)
+    qkv, o, dout = qkv.contiguous(), o.contiguous(), dout.contiguous()
+    dt = N.BF16 if qkv.dtype == torch.bfloat16 else N.F32
+    d = qkv.shape[1] // 3
+    dqkv = torch.empty_like(qkv)
+    kpm = None if key_padding_mask is None else key_padding_mask.to(torch.uint8).contiguous()
+    N.check(N.lib().cmh_attention_backward(dt, N.ptr(qkv), N.ptr(o), N.ptr(dout), N.ptr(dqkv), B, T, d, int(causal), N.ptr(kpm),
+                                           N.stream_ptr(qkv.device)), "cmh_attention_backward")
+    return dqkv

@@ -111,6 +111,7 @@ SIGNATURES = {
     "cmh_layernorm_backward_workspace_bytes": (_sz, [_i32, _i32]),
     "cmh_layernorm_backward": (C.c_int, [_p, _i32, _p, _i32, _p, _i32, _i32, _p, _i32, _p, _p, _p, _sz, _p]),
     "cmh_quick_gelu": (C.c_int, [_p, _p, _i64, _i32, _p]),
+    "cmh_attention_backward": (C.c_int, [_i32, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "cmh_bert_adam_workspace_bytes": (_sz, [_i32, _i64]),
     "cmh_bert_adam_step": (C.c_int, [C.POINTER(AdamTensor), _i32, C.c_double, C.c_double, C.c_double, _p, _sz, _p]),
 }

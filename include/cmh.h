@@ -361,6 +361,10 @@ size_t cmh_layernorm_backward_workspace_bytes(int32_t M, int32_t d);
 int cmh_layernorm_backward(const void* x, int32_t x_kind, const void* dy, int32_t dy_kind, const float* gamma, int32_t M,
                            int32_t d, float* dx, int32_t accumulate, float* dgamma, float* dbeta, void* workspace,
                            size_t workspace_bytes, void* stream);
+/* Backward of cmh_attention (same layouts and masks): qkv [B*T,3d], o = the forward output [B*T,d], dout [B*T,d] ->
+ * dqkv [B*T,3d]; softmax probabilities are recomputed.  T <= 128. */
+int cmh_attention_backward(int32_t dtype, const void* qkv, const void* o, const void* dout, void* dqkv, int32_t B, int32_t T,
+                           int32_t d, int32_t causal, const uint8_t* key_padding_mask, void* stream);
 /* out = pre * sigmoid(1.702 pre) element-wise from a saved pre-activation (model/base/model.py:162-164). */
 int cmh_quick_gelu(const void* pre, void* out, int64_t n, int32_t kind, void* stream);
 

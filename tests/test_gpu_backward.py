@@ -55,3 +55,37 @@ def test_quick_gelu_forward(dt):
     out = B.quick_gelu(x.to(DEV)).cpu().double()
     ref = x.double() * torch.sigmoid(1.702 * x.double())
     torch.testing.assert_close(out, ref, rtol=1e-2 if dt == torch.bfloat16 else 1e-5, atol=1e-2 if dt == torch.bfloat16 else 1e-6)
+
+
+@pytest.mark.parametrize("B,T,d,causal,kpm", [(2, 5, 128, 0, False), (3, 50, 192, 0, False), (2, 77, 128, 1, False),
+                                              (2, 16, 128, 1, True), (1, 128, 64, 0, True)])
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_attention_backward(B, T, d, causal, kpm, mode):
+    import backward_ops as Bo
+    import cmh_native as N
+    g = torch.Generator().manual_seed(B * 100 + T + d)
+    qkv = torch.randn(B * T, 3 * d, generator=g)
+    dout = torch.randn(B * T, d, generator=g)
+    mask = None
+    if kpm:
+        mask = torch.zeros(B, T, dtype=torch.bool)
+        mask[:, T - 3:] = True                       # trailing pads; position 0 always visible (EOT/causal safe)
+    dt = torch.bfloat16 if mode == "bf16" else torch.float32
+    qd, dd = qkv.to(dt), dout.to(dt)
+    # fp64 reference on the same (rounded) operands
+    H = d // 64
+    x = qd.double().view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4).requires_grad_(True)     # [3, B, H, T, 64]
+    q, k, v = x[0], x[1], x[2]
+    s = q @ k.transpose(-1, -2) / 8.0
+    if causal:
+        s = s + torch.full((T, T), float("-inf"), dtype=torch.float64).triu(1)
+    if mask is not None:
+        s = s.masked_fill(mask[:, None, None, :], float("-inf"))
+    o = torch.softmax(s, -1) @ v                                                          # [B, H, T, 64]
+    o2 = o.permute(0, 2, 1, 3).reshape(B * T, d)
+    o2.backward(dd.double())
+    ref = x.grad.permute(1, 3, 0, 2, 4).reshape(B * T, 3 * d)
+    o_gpu = N.attention(qd.to(DEV), B, T, causal, None if mask is None else mask.to(DEV))
+    dqkv = Bo.attention_backward(qd.to(DEV), o_gpu, dd.to(DEV), B, T, causal, None if mask is None else mask.to(DEV))
+    tol = dict(rtol=3e-2, atol=3e-2) if mode == "bf16" else dict(rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dqkv.cpu().double(), ref, **tol)
