@@ -77,7 +77,9 @@ enum : int {
   EPI_GELU = 16,      // exact GELU 0.5 x (1 + erf(x/sqrt 2))  (nn.GELU(), MITH ResidualMLPs model/MITH.py:224-233)
   EPI_RELU = 32,      // max(x, 0)
   EPI_RES_F16 = 64,   // residual is IEEE fp16 (the bf16 mode's residual stream, see encoders.hip)
-  EPI_OUT_F16 = 128   // store fp16 instead of f32
+  EPI_OUT_F16 = 128,  // store fp16 instead of f32
+  EPI_MUL_DQGELU = 1024  // acc *= QuickGELU'(aux[m,n]); aux (in the residual slot) has the OUTPUT's type (bf16 with EPI_OUT_BF16,
+                         // else f32): the dgrad through c_fc's activation.  N % 256 == 0 (wide kernel only); 256/512 are ablation bits
 };
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }

@@ -236,7 +236,9 @@ int launch_gemm(int dt, const void* A, const void* W, const float* bias, const f
   if (timed) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
   static const int impl = gemm_impl_from_env();
   static const bool wide = []() { const char* e = getenv("CMH_GEMM_WIDE"); return !(e && !strcmp(e, "0")); }();
-  const bool f16io = epi & (EPI_RES_F16 | EPI_OUT_F16);   // only the wide kernel implements the fp16 residual stream
+  CMH_CHECK_ARG(!(epi & EPI_MUL_DQGELU) || (residual && gemm_wide_supported(N) && !(epi & (EPI_RESIDUAL | EPI_OUT_F16))),
+                "gemm: EPI_MUL_DQGELU needs aux in the residual slot, N %% 256 == 0 (N=%d), no residual / fp16 output", N);
+  const bool f16io = epi & (EPI_RES_F16 | EPI_OUT_F16 | EPI_MUL_DQGELU);   // only the wide kernel implements these epilogues
   if ((impl == 1 && wide && gemm_wide_supported(N)) || f16io) {
     const int rc = launch_gemm_wide(dt, A, W, bias, residual, out, M, N, K, epi, st);
     if (rc) return rc;

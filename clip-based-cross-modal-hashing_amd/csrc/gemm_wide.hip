@@ -394,6 +394,47 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
             acc[a][b][j] = (epi & EPI_GELU) ? gelu_erf(acc[a][b][j]) : fmaxf(acc[a][b][j], 0.f);
     }
     if ((epi & EPI_RESIDUAL) && !(res_first && ti == 0)) add_residual(m0, n0);
+    if (epi & EPI_MUL_DQGELU) {
+      // backward of c_fc's QuickGELU fused into the dgrad GEMM: acc *= d/dv [v sigmoid(1.702 v)] at the saved pre-activation
+      // `aux` (passed in the residual slot; bf16 in the packed 16-byte layout for 16-bit outputs, else f32 rows)
+      auto dq = [](float v) {
+        const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v));
+        return sg * (1.0f + 1.702f * v * (1.0f - sg));
+      };
+      if constexpr (OUTBF) {
+        const uint16_t* aux = reinterpret_cast<const uint16_t*>(residual);
+        const int col = n0 + wn * 64 + (fq & 1) * 16 + (fq & 2) * 4;
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+          int m = m0 + wm * 80 + b * 16 + frow;
+          m = m < M ? m : M - 1;
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            const w_u32x4_t q = *reinterpret_cast<const w_u32x4_t*>(aux + static_cast<size_t>(m) * N + col + 32 * pr);
+            const w_u2_t s0 = __builtin_amdgcn_permlane16_swap(q[0], q[2], false, false);
+            const w_u2_t s1 = __builtin_amdgcn_permlane16_swap(q[1], q[3], false, false);
+            auto lo16 = [](uint32_t w) { return __uint_as_float(w << 16); };
+            auto hi16 = [](uint32_t w) { return __uint_as_float(w & 0xffff0000u); };
+            acc[2 * pr][b][0] *= dq(lo16(s0[0])); acc[2 * pr][b][1] *= dq(hi16(s0[0]));
+            acc[2 * pr][b][2] *= dq(lo16(s1[0])); acc[2 * pr][b][3] *= dq(hi16(s1[0]));
+            acc[2 * pr + 1][b][0] *= dq(lo16(s0[1])); acc[2 * pr + 1][b][1] *= dq(hi16(s0[1]));
+            acc[2 * pr + 1][b][2] *= dq(lo16(s1[1])); acc[2 * pr + 1][b][3] *= dq(hi16(s1[1]));
+          }
+        }
+      } else {
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+          int m = m0 + wm * 80 + b * 16 + frow;
+          m = m < M ? m : M - 1;
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const w_f32x4_t pv = *reinterpret_cast<const w_f32x4_t*>(residual + static_cast<size_t>(m) * N + n0 + wn * 64 + a * 16 + fq * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[a][b][j] *= dq(pv[j]);
+          }
+        }
+      }
+    }
     const bool full = m0 + wBM <= M;
     if constexpr (OUTBF) {
       // v_permlane16_swap exchanges, between the lane pairs (l, l+16), the packed words of two neighbouring n-tiles: an even

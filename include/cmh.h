@@ -278,6 +278,8 @@ int cmh_dnph_loss(const float* hash_img, const float* hash_txt, const float* pre
 #define CMH_EPI_RELU 32
 #define CMH_EPI_RES_F16 64    /* residual is IEEE fp16 (the bf16 mode's residual stream); needs N % 256 == 0 */
 #define CMH_EPI_OUT_F16 128   /* out is fp16 instead of f32; needs N % 256 == 0, excludes CMH_EPI_OUT_BF16 */
+#define CMH_EPI_MUL_DQGELU 1024  /* out *= QuickGELU'(aux[m,n]), aux = the saved pre-activation passed as `residual`, typed like
+                                  * the output (bf16 with CMH_EPI_OUT_BF16, else f32); N % 256 == 0; excludes CMH_EPI_RESIDUAL */
 
 /* ViT.forward of the MITH trunk (model/MITH.py:56-82): ln_post + proj on EVERY token.
  * tokens_out f32 [B*(g*g+1), embed_dim]; row b*(g*g+1) is the class token, the rest the patch tokens. */

@@ -89,3 +89,26 @@ def test_attention_backward(B, T, d, causal, kpm, mode):
     dqkv = Bo.attention_backward(qd.to(DEV), o_gpu, dd.to(DEV), B, T, causal, None if mask is None else mask.to(DEV))
     tol = dict(rtol=3e-2, atol=3e-2) if mode == "bf16" else dict(rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(dqkv.cpu().double(), ref, **tol)
+
+
+@pytest.mark.parametrize("M,N,K", [(160, 256, 64), (333, 512, 128), (1000, 3072, 768)])
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_gemm_epilogue_mul_dquickgelu(M, N, K, mode):
+    """dgrad through c_fc's QuickGELU: out = (dY . W^T) * d/dv[v sigmoid(1.702 v)] at the saved pre-activation."""
+    import ctypes as C
+    import cmh_native as Nn
+    g = torch.Generator().manual_seed(M + N + K)
+    dt = torch.bfloat16 if mode == "bf16" else torch.float32
+    x = torch.randn(M, K, generator=g).to(dt)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dt)
+    pre = (torch.randn(M, N, generator=g) * 2).to(dt)
+    v = pre.double()
+    sg = torch.sigmoid(1.702 * v)
+    ref = (x.double() @ w.double().t()) * (sg * (1 + 1.702 * v * (1 - sg)))
+    xd, wd, pd = x.to(DEV), w.to(DEV), pre.to(DEV)
+    out = torch.empty(M, N, dtype=dt, device=DEV)
+    epi = 1024 | (8 if mode == "bf16" else 0)
+    Nn.check(Nn.lib().cmh_linear_gemm(Nn.BF16 if mode == "bf16" else Nn.F32, Nn.ptr(xd), Nn.ptr(wd), None, Nn.ptr(pd), Nn.ptr(out),
+                                      M, N, K, epi, Nn.stream_ptr(xd.device)), "gemm")
+    tol = dict(rtol=1e-2, atol=1e-2) if mode == "bf16" else dict(rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(out.cpu().double(), ref, **tol)
