@@ -47,6 +47,23 @@ class TextWeights(C.Structure):
                 ("blocks", C.POINTER(BlockWeights))]
 
 
+class BlockGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "ln1_w", "ln1_b", "ln2_w", "ln2_b",
+        "fc_w", "fc_b", "proj_w", "proj_b")]
+
+
+class VitGrads(C.Structure):
+    _fields_ = [("conv1_w", C.c_void_p), ("class_embedding", C.c_void_p), ("positional_embedding", C.c_void_p),
+                ("ln_pre_w", C.c_void_p), ("ln_pre_b", C.c_void_p), ("ln_post_w", C.c_void_p), ("ln_post_b", C.c_void_p),
+                ("proj", C.c_void_p), ("blocks", C.POINTER(BlockGrads))]
+
+
+class TextGrads(C.Structure):
+    _fields_ = [("token_embedding", C.c_void_p), ("positional_embedding", C.c_void_p), ("ln_final_w", C.c_void_p),
+                ("ln_final_b", C.c_void_p), ("text_projection", C.c_void_p), ("blocks", C.POINTER(BlockGrads))]
+
+
 class AdamTensor(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64),
                 ("lr", C.c_float), ("weight_decay", C.c_float), ("max_grad_norm", C.c_float)]
@@ -112,6 +129,12 @@ SIGNATURES = {
     "cmh_layernorm_backward": (C.c_int, [_p, _i32, _p, _i32, _p, _i32, _i32, _p, _i32, _p, _p, _p, _sz, _p]),
     "cmh_quick_gelu": (C.c_int, [_p, _p, _i64, _i32, _p]),
     "cmh_attention_backward": (C.c_int, [_i32, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
+    "cmh_vit_train_bytes": (_sz, [C.POINTER(VitWeights), _i32]),
+    "cmh_vit_forward_train": (C.c_int, [C.POINTER(VitWeights), _p, _i32, _p, _p, _sz, _p]),
+    "cmh_vit_backward": (C.c_int, [C.POINTER(VitWeights), _i32, _p, C.POINTER(VitGrads), _p, _sz, _p]),
+    "cmh_text_train_bytes": (_sz, [C.POINTER(TextWeights), _i32, _i32]),
+    "cmh_text_forward_train": (C.c_int, [C.POINTER(TextWeights), _p, _i32, _i32, _p, _p, _p, _sz, _p]),
+    "cmh_text_backward": (C.c_int, [C.POINTER(TextWeights), _p, _i32, _i32, _p, _p, C.POINTER(TextGrads), _p, _sz, _p]),
     "cmh_bert_adam_workspace_bytes": (_sz, [_i32, _i64]),
     "cmh_bert_adam_step": (C.c_int, [C.POINTER(AdamTensor), _i32, C.c_double, C.c_double, C.c_double, _p, _sz, _p]),
 }

@@ -11,25 +11,11 @@
 
 namespace cmh {
 
-constexpr int kF32 = 0, kBF16 = 1, kF16 = 2;
-
-__device__ __forceinline__ float load_as_f32(const void* p, size_t i, int kind) {
-  if (kind == kF32) return static_cast<const float*>(p)[i];
-  const uint16_t h = static_cast<const uint16_t*>(p)[i];
-  if (kind == kBF16) return bf16_to_f32(h);
-  return static_cast<float>(__builtin_bit_cast(_Float16, h));
-}
-__device__ __forceinline__ void store_from_f32(void* p, size_t i, int kind, float v) {
-  if (kind == kF32) static_cast<float*>(p)[i] = v;
-  else if (kind == kBF16) static_cast<uint16_t*>(p)[i] = f32_to_bf16(v);
-  else static_cast<uint16_t*>(p)[i] = __builtin_bit_cast(uint16_t, static_cast<_Float16>(v));
-}
-
 // ---- transpose: dst[c, r] = cast(src[r, c]) -------------------------------------------------------------------------
 // 64x64 tile per 256-thread workgroup through LDS (row stride 65 words: conflict-free both ways); reads are coalesced
 // along c, writes along r.
 __global__ __launch_bounds__(256) void transpose_kernel(const void* __restrict__ src, void* __restrict__ dst, int R, int C,
-                                                        int skind, int dkind) {
+                                                        int dst_ld, int skind, int dkind) {
   __shared__ float tile[64][65];
   const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -40,7 +26,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const void* __restrict__
   __syncthreads();
   for (int i = ty; i < 64; i += 4) {
     const int c = c0 + i, r = r0 + tx;
-    if (c < C && r < R) store_from_f32(dst, static_cast<size_t>(c) * R + r, dkind, tile[tx][i]);
+    if (c < C && r < R) store_from_f32(dst, static_cast<size_t>(c) * dst_ld + r, dkind, tile[tx][i]);
   }
 }
 
@@ -75,7 +61,7 @@ constexpr int kLnRows = 32;
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ x, int xkind, const void* __restrict__ dy,
                                                             int dykind, const float* __restrict__ g, float* __restrict__ dx,
                                                             int accumulate, int M, int d, float* __restrict__ pg,
-                                                            float* __restrict__ pb) {
+                                                            float* __restrict__ pb, const int32_t* __restrict__ row_index) {
   __shared__ float red[2][4][1024];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int nv = (d + 255) / 256;
@@ -92,6 +78,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
   for (int rr = wid; rr < kLnRows; rr += 4) {
     const int row = rbase + rr;
     if (row >= M) break;
+    const size_t xrow = row_index ? static_cast<size_t>(row_index[row]) : static_cast<size_t>(row);   // x / dx row (pooled rows)
     float xv[4][4], dv[4][4];
     float s = 0.f;
 #pragma unroll
@@ -100,7 +87,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
       for (int k = 0; k < 4; ++k) {
         const int e = lane * 4 + 256 * j + k;
         const bool ok = j < nv && e < d;
-        xv[j][k] = ok ? load_as_f32(x, static_cast<size_t>(row) * d + e, xkind) : 0.f;
+        xv[j][k] = ok ? load_as_f32(x, xrow * d + e, xkind) : 0.f;
         dv[j][k] = ok ? load_as_f32(dy, static_cast<size_t>(row) * d + e, dykind) : 0.f;
         s += xv[j][k];
       }
@@ -144,7 +131,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
         const int e = lane * 4 + 256 * j + k;
         if (j < nv && e < d) {
           const float v = rstd * (dv[j][k] - ma - xv[j][k] * max_);
-          float* o = dx + static_cast<size_t>(row) * d + e;
+          float* o = dx + xrow * d + e;
           *o = accumulate ? *o + v : v;
         }
       }
@@ -179,14 +166,20 @@ static int kind_ok(int k) { return k == kF32 || k == kBF16 || k == kF16; }
 
 using namespace cmh;
 
-extern "C" int cmh_transpose(const void* src, int32_t src_kind, void* dst, int32_t dst_kind, int32_t rows, int32_t cols,
-                             void* stream) {
-  CMH_CHECK_ARG(src && dst && rows > 0 && cols > 0, "transpose: bad arguments");
-  CMH_CHECK_ARG(kind_ok(src_kind) && kind_ok(dst_kind), "transpose: bad element kind %d / %d", src_kind, dst_kind);
-  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, as_stream(stream), src, dst, rows,
-                     cols, src_kind, dst_kind);
+namespace cmh {
+int launch_transpose(const void* src, int skind, void* dst, int dkind, int rows, int cols, int dst_ld, hipStream_t st) {
+  CMH_CHECK_ARG(src && dst && rows > 0 && cols > 0 && dst_ld >= rows, "transpose: bad arguments");
+  CMH_CHECK_ARG(kind_ok(skind) && kind_ok(dkind), "transpose: bad element kind %d / %d", skind, dkind);
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, st, src, dst, rows, cols, dst_ld,
+                     skind, dkind);
   CMH_CHECK_LAUNCH("transpose");
   return CMH_OK;
+}
+}  // namespace cmh
+
+extern "C" int cmh_transpose(const void* src, int32_t src_kind, void* dst, int32_t dst_kind, int32_t rows, int32_t cols,
+                             void* stream) {
+  return launch_transpose(src, src_kind, dst, dst_kind, rows, cols, rows, as_stream(stream));
 }
 
 extern "C" size_t cmh_colsum_workspace_bytes(int32_t rows, int32_t cols) {
@@ -213,9 +206,10 @@ extern "C" size_t cmh_layernorm_backward_workspace_bytes(int32_t M, int32_t d) {
   return static_cast<size_t>((M + kLnRows - 1) / kLnRows) * d * 8 + 512;
 }
 
-extern "C" int cmh_layernorm_backward(const void* x, int32_t x_kind, const void* dy, int32_t dy_kind, const float* gamma,
-                                      int32_t M, int32_t d, float* dx, int32_t accumulate, float* dgamma, float* dbeta,
-                                      void* workspace, size_t workspace_bytes, void* stream) {
+namespace cmh {
+int launch_layernorm_backward(const void* x, int x_kind, const void* dy, int dy_kind, const float* gamma, const int32_t* row_index,
+                              int M, int d, float* dx, int accumulate, float* dgamma, float* dbeta, void* workspace,
+                              size_t workspace_bytes, hipStream_t st) {
   CMH_CHECK_ARG(x && dy && gamma && dx && dgamma && dbeta && workspace && M > 0, "layernorm_backward: bad arguments");
   CMH_CHECK_ARG(d % 4 == 0 && d <= 1024, "layernorm_backward: d=%d must be a multiple of 4 and <= 1024", d);
   CMH_CHECK_ARG((x_kind == kF32 || x_kind == kF16) && (dy_kind == kF32 || dy_kind == kBF16), "layernorm_backward: bad kinds");
@@ -223,14 +217,22 @@ extern "C" int cmh_layernorm_backward(const void* x, int32_t x_kind, const void*
   const int nb = (M + kLnRows - 1) / kLnRows;
   float* pg = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
   float* pb = pg + static_cast<size_t>(nb) * d;
-  hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, st, x, x_kind, dy, dy_kind, gamma, dx, accumulate, M, d, pg, pb);
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, st, x, x_kind, dy, dy_kind, gamma, dx, accumulate, M, d, pg, pb,
+                     row_index);
   CMH_CHECK_LAUNCH("layernorm_backward");
   hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 255) / 256), dim3(256), 0, st, pg, nb, d, dgamma);
   CMH_CHECK_LAUNCH("layernorm_backward dgamma");
   hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 255) / 256), dim3(256), 0, st, pb, nb, d, dbeta);
   CMH_CHECK_LAUNCH("layernorm_backward dbeta");
   return CMH_OK;
+}
+}  // namespace cmh
+
+extern "C" int cmh_layernorm_backward(const void* x, int32_t x_kind, const void* dy, int32_t dy_kind, const float* gamma,
+                                      int32_t M, int32_t d, float* dx, int32_t accumulate, float* dgamma, float* dbeta,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  return launch_layernorm_backward(x, x_kind, dy, dy_kind, gamma, nullptr, M, d, dx, accumulate, dgamma, dbeta, workspace,
+                                   workspace_bytes, as_stream(stream));
 }
 
 extern "C" int cmh_quick_gelu(const void* pre, void* out, int64_t n, int32_t kind, void* stream) {

@@ -68,6 +68,22 @@ __device__ __forceinline__ float f16hi_to_f32(uint32_t w) {
   return static_cast<float>(__builtin_bit_cast(h2_t, w)[1]);
 }
 
+// ---- element kinds of the backward building blocks (CMH_KIND_*) ----------------------------------------------
+constexpr int kF32 = 0, kBF16 = 1, kF16 = 2;
+
+__device__ __forceinline__ float load_as_f32(const void* p, size_t i, int kind) {
+  if (kind == kF32) return static_cast<const float*>(p)[i];
+  const uint16_t h = static_cast<const uint16_t*>(p)[i];
+  if (kind == kBF16) return bf16_to_f32(h);
+  return static_cast<float>(__builtin_bit_cast(_Float16, h));
+}
+__device__ __forceinline__ void store_from_f32(void* p, size_t i, int kind, float v) {
+  if (kind == kF32) static_cast<float*>(p)[i] = v;
+  else if (kind == kBF16) static_cast<uint16_t*>(p)[i] = f32_to_bf16(v);
+  else static_cast<uint16_t*>(p)[i] = __builtin_bit_cast(uint16_t, static_cast<_Float16>(v));
+}
+
+
 // ---- epilogue flags of the GEMM ---------------------------------------------------------------
 enum : int {
   EPI_BIAS = 1,       // + bias[n]
@@ -107,6 +123,15 @@ int launch_text_embed(const int64_t* tokens, const float* tok_emb, const float* 
                       int32_t* eot_row, int B, int L, int d, int vocab, hipStream_t st);
 // cls_row[b] = b*T
 int launch_iota_rows(int32_t* rows, int B, int T, hipStream_t st);
+// norm_embed.hip (training forward): LayerNorm between any stream kinds; token assembly without ln_pre
+int launch_layernorm_any(const void* x, int x_kind, const int32_t* row_index, const float* w, const float* b, void* out,
+                         int out_kind, int M, int d, hipStream_t st);
+int launch_vit_assemble(const float* patch_out, const float* cls, const float* pos, float* x, int B, int g2, int d, hipStream_t st);
+// backward.hip: dst[c*dst_ld + r] = cast(src[r*cols + c]); LayerNorm backward with optional gathered rows (x / dx rows = row_index[r])
+int launch_transpose(const void* src, int skind, void* dst, int dkind, int rows, int cols, int dst_ld, hipStream_t st);
+int launch_layernorm_backward(const void* x, int x_kind, const void* dy, int dy_kind, const float* gamma, const int32_t* row_index,
+                              int M, int d, float* dx, int accumulate, float* dgamma, float* dbeta, void* workspace,
+                              size_t workspace_bytes, hipStream_t st);
 
 // attention over qkv [B*T, 3d] (dt) -> o [B*T, d] (dt); heads = d/64; causal adds the -inf triu mask
 int launch_attention(const void* qkv, void* o, int dt, int B, int T, int d, int causal,

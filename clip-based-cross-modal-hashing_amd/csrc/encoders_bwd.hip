@@ -1,0 +1,419 @@
+// Training forward (keeps a tape) and backward of the two CLIP towers (SURVEY §8f "next" #2): kernel sequencing only.
+//
+// Forward with a tape = the forward of encoders.hip with three differences: every block reads its input x_in and writes
+// x_mid / the next block's x_in to fresh tape buffers instead of updating one stream in place (the residual GEMMs already
+// take residual and output separately); c_fc stores the PRE-activation and QuickGELU runs as its own pass; LayerNorm and
+// attention outputs are kept.  Per block the tape holds x_in, h1 = ln_1(x_in), qkv, attn, x_mid, h2 = ln_2(x_mid), pre:
+// M*(2*xs*d + 10*e*d) bytes (xs = residual element size, e = GEMM element size): 236 MB per vision block at batch 256, bf16.
+//
+// Backward of one block, given dx = dL/dx_out (f32 gradient stream, updated in place to dL/dx_in).  With Y = X W^T + b:
+//   dX = dY W          -> the forward GEMM kernel on (dY, W^T): W is transposed once per use (<= 4.7 MB);
+//   dW = dY^T X        -> the same kernel on (dY^T, X^T): both activations are transposed (and cast to the GEMM dtype) first,
+//                         zero-padded along M to the K-step; f32 output straight into the gradient buffer;
+//   db = column sums of dY.
+//   1. dpre = (dx W_proj) o QuickGELU'(pre)     [epilogue EPI_MUL_DQGELU]     dW_proj = dx^T gelu(pre),  db_proj = sum dx
+//   2. dh2  = dpre W_fc                                                       dW_fc = dpre^T h2,        db_fc = sum dpre
+//   3. dx  += LayerNorm_bwd(x_mid, dh2) (+ dln_2)
+//   4. dattn = dx W_out                                                       dW_out = dx^T attn,       db_out = sum dx
+//   5. dqkv = attention_bwd(qkv, attn, dattn)
+//   6. dh1  = dqkv W_in                                                       dW_in = dqkv^T h1,        db_in = sum dqkv
+//   7. dx  += LayerNorm_bwd(x_in, dh1) (+ dln_1)
+// Gradients are WRITTEN (not accumulated) into caller-owned f32 buffers shaped like the reference's parameters.
+#include <cstring>
+#include <vector>
+
+#include "cmh_common.h"
+
+namespace cmh {
+
+namespace {
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* p) : base(static_cast<char*>(p)) {}
+  template <typename T = void> T* take(size_t bytes) {
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += align_up(bytes, 256);
+    return p;
+  }
+};
+
+struct LayerTape { void *x_in, *h1, *qkv, *attn, *x_mid, *h2, *pre; };
+
+struct TrainBufs {
+  std::vector<LayerTape> L;
+  void* x_last;        // [M,d] xs   output of the last block
+  void* patches;       // vision: [B*g2, pk] e
+  float* x_pre;        // vision: [M,d] f32 tokens + positional before ln_pre;   text: unused
+  float* patch_out;    // vision: [B*g2, d] f32
+  int32_t* rows;       // [B] pooled row of every sample
+  void* pool;          // [B,d] e    ln_post / ln_final of the pooled rows
+  // scratch
+  float* dx;           // [M,d] f32 gradient stream
+  float* dx2;          // [M,d] f32
+  void* dxe;           // [M,d] e
+  void* mlp;           // [M,4d] e   gelu(pre)
+  void* dpre;          // [M,4d] e
+  void* dh;            // [M,d] e
+  void* dqkv;          // [M,3d] e
+  void* tA;            // [rmax, Mpad] e   dY^T
+  void* tB;            // [rmax, Mpad] e   X^T
+  void* wT;            // [rmax * d] e     W^T
+  float* small;        // [2*B*max(d,E)] f32
+  void* red;           // reduction workspace
+  size_t red_bytes;
+  size_t tAB_bytes;
+  size_t total;
+};
+
+size_t pad64(size_t m) { return (m + 63) / 64 * 64; }
+
+TrainBufs carve_train(void* ws, size_t M, size_t B, size_t d, size_t e, size_t xs, int layers, size_t g2rows, size_t pk,
+                      size_t embed) {
+  Carver a(ws);
+  TrainBufs t;
+  t.L.resize(layers);
+  for (int i = 0; i < layers; ++i) {
+    t.L[i].x_in = a.take(M * d * xs);
+    t.L[i].h1 = a.take(M * d * e);
+    t.L[i].qkv = a.take(M * 3 * d * e);
+    t.L[i].attn = a.take(M * d * e);
+    t.L[i].x_mid = a.take(M * d * xs);
+    t.L[i].h2 = a.take(M * d * e);
+    t.L[i].pre = a.take(M * 4 * d * e);
+  }
+  t.x_last = a.take(M * d * xs);
+  t.patches = a.take(g2rows * pk * e);
+  t.x_pre = a.take<float>(g2rows ? M * d * 4 : 0);
+  t.patch_out = a.take<float>(g2rows * d * 4);
+  t.rows = a.take<int32_t>(B * 4);
+  t.pool = a.take(B * d * e);
+  t.dx = a.take<float>(M * d * 4);
+  t.dx2 = a.take<float>(M * d * 4);
+  t.dxe = a.take(M * d * e);
+  t.mlp = a.take(M * 4 * d * e);
+  t.dpre = a.take(M * 4 * d * e);
+  t.dh = a.take(M * d * e);
+  t.dqkv = a.take(M * 3 * d * e);
+  const size_t rmax = 4 * d > pk ? 4 * d : pk;
+  const size_t mp = pad64(M > g2rows ? M : g2rows);
+  t.tAB_bytes = rmax * mp * e;
+  t.tA = a.take(t.tAB_bytes);
+  t.tB = a.take(t.tAB_bytes);
+  t.wT = a.take(rmax * d * e);
+  const size_t wide = d > embed ? d : embed;
+  t.small = a.take<float>(2 * B * wide * 4);
+  size_t rb = cmh_layernorm_backward_workspace_bytes(static_cast<int>(M), static_cast<int>(d));
+  const size_t cands[] = {cmh_colsum_workspace_bytes(static_cast<int>(M), static_cast<int>(4 * d)),
+                          cmh_colsum_workspace_bytes(static_cast<int>(B), static_cast<int>((M / B) * d))};
+  for (size_t c : cands) rb = c > rb ? c : rb;
+  t.red_bytes = rb;
+  t.red = a.take(rb);
+  t.total = a.off;
+  return t;
+}
+
+int xkind(int xh) { return xh ? kF16 : kF32; }
+int ekind(int dt) { return dt == CMH_BF16 ? kBF16 : kF32; }
+
+// training runs keep the fp16 residual stream rule of the inference path (bf16 mode, width % 256 == 0, CMH_RESID_F16 != 0)
+int train_xh(int dt, int d) {
+  static const bool off = []() { const char* e = getenv("CMH_RESID_F16"); return e && !strcmp(e, "0"); }();
+  return dt == CMH_BF16 && d % 256 == 0 && !off;
+}
+
+// x [M,d] f32 -> GEMM dtype copy (bf16 mode) or the same pointer (f32 mode)
+int as_gemm_operand(int dt, const float* x, void* scratch, size_t n, hipStream_t st, const void** out) {
+  if (dt == CMH_F32) { *out = x; return CMH_OK; }
+  *out = scratch;
+  return cmh_cast_f32_to_bf16(x, scratch, static_cast<int64_t>(n), st);
+}
+
+struct BlockGradPtrs { float *in_w, *in_b, *out_w, *out_b, *ln1_w, *ln1_b, *ln2_w, *ln2_b, *fc_w, *fc_b, *proj_w, *proj_b; };
+
+int block_forward_train(const cmh_block_weights& w, int dt, int xh, const LayerTape& L, void* x_next, void* mlp, int B, int T,
+                        int d, int causal, const uint8_t* kpm, hipStream_t st) {
+  const int M = B * T;
+  const int obf = dt == CMH_BF16 ? EPI_OUT_BF16 : 0;
+  const int rx = EPI_BIAS | EPI_RESIDUAL | (xh ? EPI_RES_F16 | EPI_OUT_F16 : 0);
+  int rc;
+  if ((rc = launch_layernorm_x(L.x_in, xh, nullptr, w.ln1_w, w.ln1_b, L.h1, dt == CMH_BF16, M, d, st))) return rc;
+  if ((rc = launch_gemm(dt, L.h1, w.in_proj_w, w.in_proj_b, nullptr, L.qkv, M, 3 * d, d, EPI_BIAS | obf, st))) return rc;
+  if ((rc = launch_attention(L.qkv, L.attn, dt, B, T, d, causal, kpm, st))) return rc;
+  if ((rc = launch_gemm(dt, L.attn, w.out_proj_w, w.out_proj_b, static_cast<const float*>(L.x_in), L.x_mid, M, d, d, rx, st))) return rc;
+  if ((rc = launch_layernorm_x(L.x_mid, xh, nullptr, w.ln2_w, w.ln2_b, L.h2, dt == CMH_BF16, M, d, st))) return rc;
+  if ((rc = launch_gemm(dt, L.h2, w.fc_w, w.fc_b, nullptr, L.pre, M, 4 * d, d, EPI_BIAS | obf, st))) return rc;
+  if ((rc = cmh_quick_gelu(L.pre, mlp, static_cast<int64_t>(M) * 4 * d, ekind(dt), st))) return rc;
+  if ((rc = launch_gemm(dt, mlp, w.proj_w, w.proj_b, static_cast<const float*>(L.x_mid), x_next, M, d, 4 * d, rx, st))) return rc;
+  return CMH_OK;
+}
+
+// dW[O, I] = dY^T X with dY [M, O] (kind ky) and X [M, I] (kind kx); db[O] = column sums of dY
+int wgrad(int dt, const void* dY, int ky, int O, const void* X, int kx, int I, int M, float* dW, float* db, TrainBufs& t,
+          hipStream_t st) {
+  const int mp = static_cast<int>(pad64(M));
+  int rc;
+  if ((rc = launch_transpose(dY, ky, t.tA, ekind(dt), M, O, mp, st))) return rc;
+  if ((rc = launch_transpose(X, kx, t.tB, ekind(dt), M, I, mp, st))) return rc;
+  if ((rc = launch_gemm(dt, t.tA, t.tB, nullptr, nullptr, dW, O, I, mp, 0, st))) return rc;
+  if (db && (rc = cmh_colsum(dY, ky, M, O, db, t.red, t.red_bytes, st))) return rc;
+  return CMH_OK;
+}
+
+// dX[M, I] = dY[M, O] . W[O, I]  (W in the GEMM dtype, row-major [O, I]); out typed by `epi`
+int dgrad(int dt, const void* dYe, const void* W, int O, int I, int M, const void* aux, void* dX, int epi, TrainBufs& t,
+          hipStream_t st) {
+  int rc;
+  if ((rc = launch_transpose(W, ekind(dt), t.wT, ekind(dt), O, I, O, st))) return rc;      // W^T [I, O]
+  return launch_gemm(dt, dYe, t.wT, nullptr, static_cast<const float*>(aux), dX, M, I, O, epi, st);
+}
+
+int block_backward(const cmh_block_weights& w, const BlockGradPtrs& g, int dt, int xh, const LayerTape& L, TrainBufs& t, int B,
+                   int T, int d, int causal, const uint8_t* kpm, hipStream_t st) {
+  const int M = B * T;
+  const int obf = dt == CMH_BF16 ? EPI_OUT_BF16 : 0;
+  const int ek = ekind(dt), xk = xkind(xh);
+  const size_t md = static_cast<size_t>(M) * d;
+  const void* dxe = nullptr;
+  int rc;
+  // 1. MLP projection
+  if ((rc = as_gemm_operand(dt, t.dx, t.dxe, md, st, &dxe))) return rc;
+  if ((rc = dgrad(dt, dxe, w.proj_w, d, 4 * d, M, L.pre, t.dpre, EPI_MUL_DQGELU | obf, t, st))) return rc;
+  if ((rc = cmh_quick_gelu(L.pre, t.mlp, static_cast<int64_t>(M) * 4 * d, ek, st))) return rc;
+  if ((rc = wgrad(dt, t.dx, kF32, d, t.mlp, ek, 4 * d, M, g.proj_w, g.proj_b, t, st))) return rc;
+  // 2. c_fc
+  if ((rc = dgrad(dt, t.dpre, w.fc_w, 4 * d, d, M, nullptr, t.dh, obf, t, st))) return rc;
+  if ((rc = wgrad(dt, t.dpre, ek, 4 * d, L.h2, ek, d, M, g.fc_w, g.fc_b, t, st))) return rc;
+  // 3. ln_2
+  if ((rc = launch_layernorm_backward(L.x_mid, xk, t.dh, ek, w.ln2_w, nullptr, M, d, t.dx, 1, g.ln2_w, g.ln2_b, t.red, t.red_bytes, st))) return rc;
+  // 4. out_proj
+  if ((rc = as_gemm_operand(dt, t.dx, t.dxe, md, st, &dxe))) return rc;
+  if ((rc = dgrad(dt, dxe, w.out_proj_w, d, d, M, nullptr, t.dh, obf, t, st))) return rc;
+  if ((rc = wgrad(dt, t.dx, kF32, d, L.attn, ek, d, M, g.out_w, g.out_b, t, st))) return rc;
+  // 5. attention
+  if ((rc = cmh_attention_backward(dt, L.qkv, L.attn, t.dh, t.dqkv, B, T, d, causal, kpm, st))) return rc;
+  // 6. in_proj
+  if ((rc = dgrad(dt, t.dqkv, w.in_proj_w, 3 * d, d, M, nullptr, t.dh, obf, t, st))) return rc;
+  if ((rc = wgrad(dt, t.dqkv, ek, 3 * d, L.h1, ek, d, M, g.in_w, g.in_b, t, st))) return rc;
+  // 7. ln_1
+  return launch_layernorm_backward(L.x_in, xk, t.dh, ek, w.ln1_w, nullptr, M, d, t.dx, 1, g.ln1_w, g.ln1_b, t.red, t.red_bytes, st);
+}
+
+BlockGradPtrs grads_of(const cmh_block_grads& g) {
+  return BlockGradPtrs{g.in_proj_w, g.in_proj_b, g.out_proj_w, g.out_proj_b, g.ln1_w, g.ln1_b, g.ln2_w, g.ln2_b,
+                       g.fc_w, g.fc_b, g.proj_w, g.proj_b};
+}
+int check_block_grads(const cmh_block_grads* g, int layers) {
+  for (int i = 0; i < layers; ++i) {
+    const BlockGradPtrs p = grads_of(g[i]);
+    CMH_CHECK_ARG(p.in_w && p.in_b && p.out_w && p.out_b && p.ln1_w && p.ln1_b && p.ln2_w && p.ln2_b && p.fc_w && p.fc_b &&
+                  p.proj_w && p.proj_b, "backward: block %d has a null gradient pointer", i);
+  }
+  return CMH_OK;
+}
+
+// ---- pooled rows: feat = LN(x_last[rows]) . proj ------------------------------------------------------------------------------
+// dpool[b, i] = sum_j dfeat[b, j] * proj_t[j, i]
+template <typename T>
+__global__ __launch_bounds__(256) void pool_dgrad_kernel(const float* __restrict__ dfeat, const T* __restrict__ proj_t,
+                                                         float* __restrict__ dpool, int B, int d, int E) {
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < d; i += 256) {
+    float acc = 0.f;
+    for (int j = 0; j < E; ++j) acc += dfeat[static_cast<size_t>(b) * E + j] * load_as_f32(proj_t, static_cast<size_t>(j) * d + i, sizeof(T) == 4 ? kF32 : kBF16);
+    dpool[static_cast<size_t>(b) * d + i] = acc;
+  }
+}
+// dproj[i, j] = sum_b pool[b, i] * dfeat[b, j]      (the reference's [width, embed_dim] parameter layout)
+template <typename T>
+__global__ __launch_bounds__(256) void pool_wgrad_kernel(const T* __restrict__ pool, const float* __restrict__ dfeat,
+                                                         float* __restrict__ dproj, int B, int d, int E) {
+  const int i = blockIdx.x;
+  for (int j = threadIdx.x; j < E; j += 256) {
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b)
+      acc += load_as_f32(pool, static_cast<size_t>(b) * d + i, sizeof(T) == 4 ? kF32 : kBF16) * dfeat[static_cast<size_t>(b) * E + j];
+    dproj[static_cast<size_t>(i) * E + j] = acc;
+  }
+}
+
+int pooled_backward(int dt, int xh, const void* x_last, const int32_t* rows, const void* pool, const void* proj_t,
+                    const float* ln_w, const float* dfeat, float* dproj, float* dln_w, float* dln_b, TrainBufs& t, int B, int M,
+                    int d, int E, hipStream_t st) {
+  float* dpool = t.small;
+  if (dt == CMH_F32) {
+    hipLaunchKernelGGL(pool_dgrad_kernel<float>, dim3(B), dim3(256), 0, st, dfeat, static_cast<const float*>(proj_t), dpool, B, d, E);
+    hipLaunchKernelGGL(pool_wgrad_kernel<float>, dim3(d), dim3(256), 0, st, static_cast<const float*>(pool), dfeat, dproj, B, d, E);
+  } else {
+    hipLaunchKernelGGL(pool_dgrad_kernel<bf16_t>, dim3(B), dim3(256), 0, st, dfeat, static_cast<const bf16_t*>(proj_t), dpool, B, d, E);
+    hipLaunchKernelGGL(pool_wgrad_kernel<bf16_t>, dim3(d), dim3(256), 0, st, static_cast<const bf16_t*>(pool), dfeat, dproj, B, d, E);
+  }
+  CMH_CHECK_LAUNCH("pooled projection backward");
+  if (hipMemsetAsync(t.dx, 0, static_cast<size_t>(M) * d * 4, st) != hipSuccess) return fail(CMH_ERR_LAUNCH, "backward: memset failed");
+  return launch_layernorm_backward(x_last, xkind(xh), dpool, kF32, ln_w, rows, B, d, t.dx, 0, dln_w, dln_b, t.red, t.red_bytes, st);
+}
+
+// token embedding: dE[token[r], :] += dx[r, :]
+__global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ dx,
+                                                            float* __restrict__ dE, int rows, int d, int vocab) {
+  const int r = blockIdx.x;
+  int64_t id = tokens[r];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  for (int c = threadIdx.x; c < d; c += 256) atomicAdd(dE + static_cast<size_t>(id) * d + c, dx[static_cast<size_t>(r) * d + c]);
+}
+
+int zero_pad_buffers(TrainBufs& t, size_t M, hipStream_t st) {
+  if (pad64(M) == M) return CMH_OK;     // no padding columns: nothing to clear
+  if (hipMemsetAsync(t.tA, 0, t.tAB_bytes, st) != hipSuccess || hipMemsetAsync(t.tB, 0, t.tAB_bytes, st) != hipSuccess)
+    return fail(CMH_ERR_LAUNCH, "backward: memset failed");
+  return CMH_OK;
+}
+
+int check_train_tower(int dt, int width, int layers, int embed, const cmh_block_weights* blocks) {
+  CMH_CHECK_ARG(dt == CMH_F32 || dt == CMH_BF16, "bad gemm_dtype %d", dt);
+  CMH_CHECK_ARG(width > 0 && width % 128 == 0 && width <= 1024, "width %d must be a multiple of 128, <= 1024", width);
+  CMH_CHECK_ARG(layers >= 0 && embed > 0 && embed % 4 == 0, "bad layers/embed_dim");
+  CMH_CHECK_ARG(layers == 0 || blocks, "blocks is null");
+  return CMH_OK;
+}
+
+}  // namespace
+}  // namespace cmh
+
+using namespace cmh;
+
+// ================================================================================================================ vision
+extern "C" size_t cmh_vit_train_bytes(const cmh_vit_weights* w, int32_t batch) {
+  if (!w || batch <= 0 || w->patch <= 0) return 0;
+  const size_t g = w->resolution / w->patch, g2 = g * g, T = g2 + 1, d = w->width, B = batch;
+  const size_t e = w->gemm_dtype == CMH_BF16 ? 2 : 4, xs = train_xh(w->gemm_dtype, w->width) ? 2 : 4;
+  return carve_train(nullptr, B * T, B, d, e, xs, w->layers, B * g2, 3ull * w->patch * w->patch, w->embed_dim).total;
+}
+
+extern "C" int cmh_vit_forward_train(const cmh_vit_weights* w, const float* image, int32_t batch, float* feat, void* tape,
+                                     size_t tape_bytes, void* stream) {
+  CMH_CHECK_ARG(w && image && feat && tape && batch > 0, "vit_forward_train: bad arguments");
+  int rc = check_train_tower(w->gemm_dtype, w->width, w->layers, w->embed_dim, w->blocks);
+  if (rc) return rc;
+  CMH_CHECK_ARG(w->layers > 0, "vit_forward_train: no layers");
+  CMH_CHECK_ARG(w->patch > 0 && w->resolution % w->patch == 0 && w->patch % 4 == 0, "vit_forward_train: resolution / patch");
+  const int dt = w->gemm_dtype, d = w->width, B = batch;
+  const int g = w->resolution / w->patch, g2 = g * g, T = g2 + 1, M = B * T, pk = 3 * w->patch * w->patch;
+  CMH_CHECK_ARG(pk % (dt == CMH_F32 ? 32 : 64) == 0, "vit_forward_train: 3*patch^2 = %d not a multiple of the GEMM K-step", pk);
+  if (tape_bytes < cmh_vit_train_bytes(w, batch)) return fail(CMH_ERR_WORKSPACE, "vit_forward_train: tape too small");
+  CMH_CHECK_ARG((reinterpret_cast<uintptr_t>(tape) & 255) == 0, "vit_forward_train: tape must be 256-byte aligned");
+  const int xh = train_xh(dt, d);
+  const size_t e = dt == CMH_BF16 ? 2 : 4;
+  hipStream_t st = as_stream(stream);
+  TrainBufs t = carve_train(tape, static_cast<size_t>(M), B, d, e, xh ? 2 : 4, w->layers, static_cast<size_t>(B) * g2, pk, w->embed_dim);
+  if ((rc = launch_patchify(image, t.patches, dt, B, w->resolution, w->patch, st))) return rc;
+  if ((rc = launch_gemm(dt, t.patches, w->conv1_w, nullptr, nullptr, t.patch_out, B * g2, d, pk, 0, st))) return rc;
+  // x_pre = [cls ; patches] + positional (kept for ln_pre's backward), x_0 = ln_pre(x_pre)
+  if ((rc = launch_vit_assemble(t.patch_out, w->class_embedding, w->positional_embedding, t.x_pre, B, g2, d, st))) return rc;
+  if ((rc = launch_layernorm_any(t.x_pre, kF32, nullptr, w->ln_pre_w, w->ln_pre_b, t.L[0].x_in, xkind(xh), M, d, st))) return rc;
+  for (int i = 0; i < w->layers; ++i) {
+    void* nxt = i + 1 < w->layers ? t.L[i + 1].x_in : t.x_last;
+    if ((rc = block_forward_train(w->blocks[i], dt, xh, t.L[i], nxt, t.mlp, B, T, d, 0, nullptr, st))) return rc;
+  }
+  if ((rc = launch_iota_rows(t.rows, B, T, st))) return rc;
+  if ((rc = launch_layernorm_x(t.x_last, xh, t.rows, w->ln_post_w, w->ln_post_b, t.pool, dt == CMH_BF16, B, d, st))) return rc;
+  const int bk = dt == CMH_F32 ? 32 : 64;
+  if (w->embed_dim % 128 == 0 && d % bk == 0) return launch_gemm(dt, t.pool, w->proj_t, nullptr, nullptr, feat, B, w->embed_dim, d, 0, st);
+  return launch_small_linear(dt, t.pool, w->proj_t, nullptr, nullptr, 1.f, CMH_ACT_NONE, feat, B, w->embed_dim, d, st);
+}
+
+extern "C" int cmh_vit_backward(const cmh_vit_weights* w, int32_t batch, const float* dfeat, const cmh_vit_grads* gr, void* tape,
+                                size_t tape_bytes, void* stream) {
+  CMH_CHECK_ARG(w && dfeat && gr && tape && batch > 0, "vit_backward: bad arguments");
+  int rc = check_train_tower(w->gemm_dtype, w->width, w->layers, w->embed_dim, w->blocks);
+  if (rc) return rc;
+  CMH_CHECK_ARG(gr->conv1_w && gr->class_embedding && gr->positional_embedding && gr->ln_pre_w && gr->ln_pre_b && gr->ln_post_w &&
+                gr->ln_post_b && gr->proj && gr->blocks, "vit_backward: null gradient pointer");
+  if ((rc = check_block_grads(gr->blocks, w->layers))) return rc;
+  if (tape_bytes < cmh_vit_train_bytes(w, batch)) return fail(CMH_ERR_WORKSPACE, "vit_backward: tape too small");
+  const int dt = w->gemm_dtype, d = w->width, B = batch, E = w->embed_dim;
+  const int g = w->resolution / w->patch, g2 = g * g, T = g2 + 1, M = B * T, pk = 3 * w->patch * w->patch;
+  const int xh = train_xh(dt, d);
+  const size_t e = dt == CMH_BF16 ? 2 : 4;
+  hipStream_t st = as_stream(stream);
+  TrainBufs t = carve_train(tape, static_cast<size_t>(M), B, d, e, xh ? 2 : 4, w->layers, static_cast<size_t>(B) * g2, pk, E);
+  if ((rc = zero_pad_buffers(t, static_cast<size_t>(M), st))) return rc;
+  if ((rc = pooled_backward(dt, xh, t.x_last, t.rows, t.pool, w->proj_t, w->ln_post_w, dfeat, gr->proj, gr->ln_post_w, gr->ln_post_b,
+                            t, B, M, d, E, st))) return rc;
+  for (int i = w->layers - 1; i >= 0; --i)
+    if ((rc = block_backward(w->blocks[i], grads_of(gr->blocks[i]), dt, xh, t.L[i], t, B, T, d, 0, nullptr, st))) return rc;
+  // ln_pre, then the embeddings: x_pre[b,0] = cls + pos[0], x_pre[b,1+i] = patch_out[b*g2+i] + pos[1+i]
+  if ((rc = launch_layernorm_backward(t.x_pre, kF32, t.dx, kF32, w->ln_pre_w, nullptr, M, d, t.dx2, 0, gr->ln_pre_w, gr->ln_pre_b,
+                                      t.red, t.red_bytes, st))) return rc;
+  if ((rc = cmh_colsum(t.dx2, kF32, B, T * d, gr->positional_embedding, t.red, t.red_bytes, st))) return rc;
+  if (hipMemcpyAsync(gr->class_embedding, gr->positional_embedding, static_cast<size_t>(d) * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return fail(CMH_ERR_LAUNCH, "vit_backward: copy failed");
+  // conv1: dW[d, pk] = dpatch_out^T patches, dpatch_out = the non-class rows of dx2 (compacted into dx)
+  if (hipMemcpy2DAsync(t.dx, static_cast<size_t>(g2) * d * 4, t.dx2 + d, static_cast<size_t>(T) * d * 4, static_cast<size_t>(g2) * d * 4,
+                       B, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(CMH_ERR_LAUNCH, "vit_backward: compaction failed");
+  if ((rc = zero_pad_buffers(t, static_cast<size_t>(B) * g2, st))) return rc;
+  return wgrad(dt, t.dx, kF32, d, t.patches, ekind(dt), pk, B * g2, gr->conv1_w, nullptr, t, st);
+}
+
+// ================================================================================================================ text
+extern "C" size_t cmh_text_train_bytes(const cmh_text_weights* w, int32_t batch, int32_t seq_len) {
+  if (!w || batch <= 0 || seq_len <= 0) return 0;
+  const size_t e = w->gemm_dtype == CMH_BF16 ? 2 : 4, xs = train_xh(w->gemm_dtype, w->width) ? 2 : 4;
+  return carve_train(nullptr, static_cast<size_t>(batch) * seq_len, batch, w->width, e, xs, w->layers, 0, 0, w->embed_dim).total;
+}
+
+extern "C" int cmh_text_forward_train(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
+                                      const uint8_t* key_padding_mask, float* feat, void* tape, size_t tape_bytes, void* stream) {
+  CMH_CHECK_ARG(w && tokens && feat && tape && batch > 0 && seq_len > 0, "text_forward_train: bad arguments");
+  int rc = check_train_tower(w->gemm_dtype, w->width, w->layers, w->embed_dim, w->blocks);
+  if (rc) return rc;
+  CMH_CHECK_ARG(w->layers > 0 && seq_len <= w->context_length, "text_forward_train: layers / seq_len");
+  if (tape_bytes < cmh_text_train_bytes(w, batch, seq_len)) return fail(CMH_ERR_WORKSPACE, "text_forward_train: tape too small");
+  CMH_CHECK_ARG((reinterpret_cast<uintptr_t>(tape) & 255) == 0, "text_forward_train: tape must be 256-byte aligned");
+  const int dt = w->gemm_dtype, d = w->width, B = batch, L = seq_len, M = B * L;
+  const int xh = train_xh(dt, d);
+  const size_t e = dt == CMH_BF16 ? 2 : 4;
+  hipStream_t st = as_stream(stream);
+  TrainBufs t = carve_train(tape, static_cast<size_t>(M), B, d, e, xh ? 2 : 4, w->layers, 0, 0, w->embed_dim);
+  if ((rc = launch_text_embed(tokens, w->token_embedding, w->positional_embedding, t.L[0].x_in, xh, t.rows, B, L, d, w->vocab_size, st))) return rc;
+  for (int i = 0; i < w->layers; ++i) {
+    void* nxt = i + 1 < w->layers ? t.L[i + 1].x_in : t.x_last;
+    if ((rc = block_forward_train(w->blocks[i], dt, xh, t.L[i], nxt, t.mlp, B, L, d, 1, key_padding_mask, st))) return rc;
+  }
+  if ((rc = launch_layernorm_x(t.x_last, xh, t.rows, w->ln_final_w, w->ln_final_b, t.pool, dt == CMH_BF16, B, d, st))) return rc;
+  const int bk = dt == CMH_F32 ? 32 : 64;
+  if (w->embed_dim % 128 == 0 && d % bk == 0)
+    return launch_gemm(dt, t.pool, w->text_projection_t, nullptr, nullptr, feat, B, w->embed_dim, d, 0, st);
+  return launch_small_linear(dt, t.pool, w->text_projection_t, nullptr, nullptr, 1.f, CMH_ACT_NONE, feat, B, w->embed_dim, d, st);
+}
+
+extern "C" int cmh_text_backward(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
+                                 const uint8_t* key_padding_mask, const float* dfeat, const cmh_text_grads* gr, void* tape,
+                                 size_t tape_bytes, void* stream) {
+  CMH_CHECK_ARG(w && tokens && dfeat && gr && tape && batch > 0 && seq_len > 0, "text_backward: bad arguments");
+  int rc = check_train_tower(w->gemm_dtype, w->width, w->layers, w->embed_dim, w->blocks);
+  if (rc) return rc;
+  CMH_CHECK_ARG(gr->token_embedding && gr->positional_embedding && gr->ln_final_w && gr->ln_final_b && gr->text_projection &&
+                gr->blocks, "text_backward: null gradient pointer");
+  if ((rc = check_block_grads(gr->blocks, w->layers))) return rc;
+  if (tape_bytes < cmh_text_train_bytes(w, batch, seq_len)) return fail(CMH_ERR_WORKSPACE, "text_backward: tape too small");
+  const int dt = w->gemm_dtype, d = w->width, B = batch, L = seq_len, M = B * L, E = w->embed_dim;
+  const int xh = train_xh(dt, d);
+  const size_t e = dt == CMH_BF16 ? 2 : 4;
+  hipStream_t st = as_stream(stream);
+  TrainBufs t = carve_train(tape, static_cast<size_t>(M), B, d, e, xh ? 2 : 4, w->layers, 0, 0, E);
+  if ((rc = zero_pad_buffers(t, static_cast<size_t>(M), st))) return rc;
+  if ((rc = pooled_backward(dt, xh, t.x_last, t.rows, t.pool, w->text_projection_t, w->ln_final_w, dfeat, gr->text_projection,
+                            gr->ln_final_w, gr->ln_final_b, t, B, M, d, E, st))) return rc;
+  for (int i = w->layers - 1; i >= 0; --i)
+    if ((rc = block_backward(w->blocks[i], grads_of(gr->blocks[i]), dt, xh, t.L[i], t, B, L, d, 1, key_padding_mask, st))) return rc;
+  // x_0[b, t] = token_embedding[tokens[b, t]] + positional_embedding[t]
+  if (hipMemsetAsync(gr->positional_embedding, 0, static_cast<size_t>(w->context_length) * d * 4, st) != hipSuccess ||
+      hipMemsetAsync(gr->token_embedding, 0, static_cast<size_t>(w->vocab_size) * d * 4, st) != hipSuccess)
+    return fail(CMH_ERR_LAUNCH, "text_backward: memset failed");
+  if ((rc = cmh_colsum(t.dx, kF32, B, L * d, gr->positional_embedding, t.red, t.red_bytes, st))) return rc;
+  hipLaunchKernelGGL(embed_scatter_kernel, dim3(M), dim3(256), 0, st, tokens, t.dx, gr->token_embedding, M, d, w->vocab_size);
+  CMH_CHECK_LAUNCH("embedding scatter");
+  return CMH_OK;
+}

@@ -70,7 +70,7 @@ __device__ __forceinline__ float4 load_x4(const void* row, int e0) {
 template <bool XH>
 __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ x, const int32_t* __restrict__ row_index,
                                                         const float* __restrict__ w, const float* __restrict__ b,
-                                                        void* __restrict__ out, int out_bf16, int M, int d) {
+                                                        void* __restrict__ out, int out_kind, int M, int d) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
     const int e0 = lane * 4 + 256 * j;
     v[j] = (j < nv && e0 < d) ? load_x4<XH>(xr, e0) : float4{0.f, 0.f, 0.f, 0.f};
   }
-  char* orow = static_cast<char*>(out) + static_cast<size_t>(row) * d * (out_bf16 ? 2 : 4);
-  ln_row(v, nv, d, lane, w, b, orow, out_bf16 ? kOutBf16 : kOutF32);
+  char* orow = static_cast<char*>(out) + static_cast<size_t>(row) * d * (out_kind == kOutF32 ? 4 : 2);
+  ln_row(v, nv, d, lane, w, b, orow, out_kind);     // 0 f32, 1 bf16, 2 fp16 (the values of the old out_bf16 flag still hold)
 }
 
 // The bf16 mode's LayerNorm: fp16 row in, bf16 row out, d a multiple of 256.  HALF a wave per row: a lane owns 8 consecutive
@@ -169,6 +169,46 @@ int launch_layernorm_x(const void* x, int x_f16, const int32_t* row_index, const
 int launch_layernorm(const float* x, const int32_t* row_index, const float* w, const float* b, void* out,
                      int out_bf16, int M, int d, hipStream_t st) {
   return launch_layernorm_x(x, 0, row_index, w, b, out, out_bf16, M, d, st);
+}
+
+// any input kind (f32 / fp16) to any output kind (f32 / bf16 / fp16): the training forward's ln_pre writes the stream's type
+int launch_layernorm_any(const void* x, int x_kind, const int32_t* row_index, const float* w, const float* b, void* out,
+                         int out_kind, int M, int d, hipStream_t st) {
+  CMH_CHECK_ARG(d % 4 == 0 && d <= 256 * kMaxVec, "layernorm: d=%d must be a multiple of 4 and <= 1024", d);
+  CMH_CHECK_ARG((x_kind == 0 || x_kind == 2) && out_kind >= 0 && out_kind <= 2, "layernorm: bad kinds %d -> %d", x_kind, out_kind);
+  if (x_kind == 2)
+    hipLaunchKernelGGL(layernorm_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, x, row_index, w, b, out, out_kind, M, d);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, x, row_index, w, b, out, out_kind, M, d);
+  CMH_CHECK_LAUNCH("layernorm");
+  return CMH_OK;
+}
+
+// x_pre[b,0] = cls + pos[0]; x_pre[b,1+i] = patch_out[b*g2+i] + pos[1+i]   (f32; the training forward keeps it for ln_pre's backward)
+__global__ __launch_bounds__(256) void vit_assemble_kernel(const float* __restrict__ patch_out, const float* __restrict__ cls,
+                                                           const float* __restrict__ pos, float* __restrict__ x, int B, int g2,
+                                                           int d) {
+  const int T = g2 + 1;
+  const size_t total4 = static_cast<size_t>(B) * T * d / 4;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < total4; i += static_cast<size_t>(gridDim.x) * 256) {
+    const size_t e = i * 4;
+    const int c = static_cast<int>(e % d);
+    const size_t row = e / d;
+    const int b = static_cast<int>(row / T), t = static_cast<int>(row - static_cast<size_t>(b) * T);
+    const float4 a = *reinterpret_cast<const float4*>(t == 0 ? cls + c : patch_out + (static_cast<size_t>(b) * g2 + (t - 1)) * d + c);
+    const float4 q = *reinterpret_cast<const float4*>(pos + static_cast<size_t>(t) * d + c);
+    *reinterpret_cast<float4*>(x + e) = float4{a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w};
+  }
+}
+
+int launch_vit_assemble(const float* patch_out, const float* cls, const float* pos, float* x, int B, int g2, int d, hipStream_t st) {
+  CMH_CHECK_ARG(d % 4 == 0, "vit_assemble: width %d unsupported", d);
+  const size_t total4 = static_cast<size_t>(B) * (g2 + 1) * d / 4;
+  const size_t blocks = (total4 + 255) / 256;
+  hipLaunchKernelGGL(vit_assemble_kernel, dim3(static_cast<unsigned>(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st, patch_out, cls,
+                     pos, x, B, g2, d);
+  CMH_CHECK_LAUNCH("vit_assemble");
+  return CMH_OK;
 }
 
 // ---- conv1 as GEMM: patch extraction -----------------------------------------------------------

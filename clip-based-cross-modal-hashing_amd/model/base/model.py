@@ -283,6 +283,11 @@ class CLIP(nn.Module):
         B = image.shape[0]
         if tuple(image.shape[1:]) != (3, s.resolution, s.resolution):
             raise N.NativeError(f"encode_image: expected [B,3,{s.resolution},{s.resolution}], got {tuple(image.shape)}")
+        if taps is None and not self.assume_frozen:
+            from model.base import train_ops as T            # training: tape-keeping forward with a real backward
+            params = T.vit_params(self.visual)
+            if T.wants_grad(params):
+                return T.VitTrain.apply(self, image, *params)
         feat = torch.empty(B, s.embed_dim, dtype=torch.float32, device=image.device)
         need = N.lib().cmh_vit_workspace_bytes(C.byref(s), B)
         ws = N.workspace(need, image.device, "vit")
@@ -298,10 +303,15 @@ class CLIP(nn.Module):
         text = text.to(torch.int64).contiguous()
         s = self._text_struct()
         B, L = text.shape
+        kpm = None if key_padding_mask is None else key_padding_mask.to(torch.uint8).contiguous()
+        if taps is None and not self.assume_frozen:
+            from model.base import train_ops as T
+            params = T.text_params(self)
+            if T.wants_grad(params):
+                return T.TextTrain.apply(self, text, kpm, *params)
         feat = torch.empty(B, s.embed_dim, dtype=torch.float32, device=text.device)
         need = N.lib().cmh_text_workspace_bytes(C.byref(s), B, L)
         ws = N.workspace(need, text.device, "text")
-        kpm = None if key_padding_mask is None else key_padding_mask.to(torch.uint8).contiguous()
         tp, _arr = self._taps(taps)
         N.check(N.lib().cmh_text_encode(C.byref(s), N.ptr(text), B, L, N.ptr(kpm), N.ptr(feat), N.ptr(ws), ws.numel(),
                                         None if tp is None else C.byref(tp), N.stream_ptr(text.device)),

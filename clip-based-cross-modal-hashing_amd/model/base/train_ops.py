@@ -1,0 +1,103 @@
+"""Autograd bridges of the two towers: forward = cmh_*_forward_train (keeps a tape), backward = cmh_*_backward, which
+writes one f32 gradient per parameter (include/cmh.h "Training forward ... and backward").  Used by CLIP.encode_image /
+encode_text whenever gradients are enabled and a tower parameter requires them; under torch.no_grad() the plain encode
+entry points run instead."""
+import ctypes as C
+
+import torch
+
+import cmh_native as N
+
+_BLOCK_FIELDS = ("in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "ln1_w", "ln1_b", "ln2_w", "ln2_b",
+                 "fc_w", "fc_b", "proj_w", "proj_b")
+
+
+def block_params(blk):
+    """the 12 parameters of one ResidualAttentionBlock in cmh_block_weights order"""
+    return [blk.attn.in_proj_weight, blk.attn.in_proj_bias, blk.attn.out_proj.weight, blk.attn.out_proj.bias,
+            blk.ln_1.weight, blk.ln_1.bias, blk.ln_2.weight, blk.ln_2.bias,
+            blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias]
+
+
+def vit_params(v):
+    head = [v.conv1.weight, v.class_embedding, v.positional_embedding, v.ln_pre.weight, v.ln_pre.bias,
+            v.ln_post.weight, v.ln_post.bias, v.proj]
+    return head + [p for blk in v.transformer.resblocks for p in block_params(blk)]
+
+
+def text_params(clip):
+    head = [clip.token_embedding.weight, clip.positional_embedding, clip.ln_final.weight, clip.ln_final.bias,
+            clip.text_projection]
+    return head + [p for blk in clip.transformer.resblocks for p in block_params(blk)]
+
+
+def _grad_buffers(params):
+    for p in params:
+        if p.dtype != torch.float32 or not p.is_contiguous():
+            raise N.NativeError("training needs contiguous float32 parameters (model.float())")
+    return [torch.empty_like(p) for p in params]
+
+
+def _block_grads(grads, nhead):
+    layers = (len(grads) - nhead) // 12
+    arr = (N.BlockGrads * layers)()
+    for i in range(layers):
+        for j, f in enumerate(_BLOCK_FIELDS):
+            setattr(arr[i], f, grads[nhead + 12 * i + j].data_ptr())
+    return arr
+
+
+class VitTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, clip, image, *params):
+        s = clip._vit_struct()
+        B = image.shape[0]
+        feat = torch.empty(B, s.embed_dim, dtype=torch.float32, device=image.device)
+        tape = torch.empty(N.lib().cmh_vit_train_bytes(C.byref(s), B), dtype=torch.uint8, device=image.device)
+        N.check(N.lib().cmh_vit_forward_train(C.byref(s), N.ptr(image), B, N.ptr(feat), N.ptr(tape), tape.numel(),
+                                              N.stream_ptr(image.device)), "cmh_vit_forward_train")
+        ctx.clip, ctx.tape, ctx.B, ctx.struct = clip, tape, B, s
+        ctx.params = params
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        s, params = ctx.struct, ctx.params
+        grads = _grad_buffers(params)
+        blocks = _block_grads(grads, 8)
+        g = N.VitGrads(*[t.data_ptr() for t in grads[:8]], C.cast(blocks, C.POINTER(N.BlockGrads)))
+        dfeat = N.f32c(dfeat)
+        N.check(N.lib().cmh_vit_backward(C.byref(s), ctx.B, N.ptr(dfeat), C.byref(g), N.ptr(ctx.tape), ctx.tape.numel(),
+                                         N.stream_ptr(dfeat.device)), "cmh_vit_backward")
+        ctx.tape = None
+        return (None, None) + tuple(grads)
+
+
+class TextTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, clip, text, kpm, *params):
+        s = clip._text_struct()
+        B, L = text.shape
+        feat = torch.empty(B, s.embed_dim, dtype=torch.float32, device=text.device)
+        tape = torch.empty(N.lib().cmh_text_train_bytes(C.byref(s), B, L), dtype=torch.uint8, device=text.device)
+        N.check(N.lib().cmh_text_forward_train(C.byref(s), N.ptr(text), B, L, N.ptr(kpm), N.ptr(feat), N.ptr(tape), tape.numel(),
+                                               N.stream_ptr(text.device)), "cmh_text_forward_train")
+        ctx.tape, ctx.struct, ctx.text, ctx.kpm, ctx.params = tape, s, text, kpm, params
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        s, params, text = ctx.struct, ctx.params, ctx.text
+        grads = _grad_buffers(params)
+        blocks = _block_grads(grads, 5)
+        g = N.TextGrads(*[t.data_ptr() for t in grads[:5]], C.cast(blocks, C.POINTER(N.BlockGrads)))
+        dfeat = N.f32c(dfeat)
+        B, L = text.shape
+        N.check(N.lib().cmh_text_backward(C.byref(s), N.ptr(text), B, L, N.ptr(ctx.kpm), N.ptr(dfeat), C.byref(g), N.ptr(ctx.tape),
+                                          ctx.tape.numel(), N.stream_ptr(dfeat.device)), "cmh_text_backward")
+        ctx.tape = None
+        return (None, None, None) + tuple(grads)
+
+
+def wants_grad(params):
+    return torch.is_grad_enabled() and any(p.requires_grad for p in params)

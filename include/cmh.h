@@ -370,6 +370,43 @@ int cmh_attention_backward(int32_t dtype, const void* qkv, const void* o, const 
 /* out = pre * sigmoid(1.702 pre) element-wise from a saved pre-activation (model/base/model.py:162-164). */
 int cmh_quick_gelu(const void* pre, void* out, int64_t n, int32_t kind, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training forward (keeps a tape of activations) and backward of the two towers.  Gradients are WRITTEN (not accumulated) into
+ * caller-owned f32 buffers shaped like the reference's parameters (model/base/model.py; note `proj` / `text_projection` are in
+ * the parameter's own [width, embed_dim] layout, not transposed).  `tape` (cmh_*_train_bytes) holds the activations between
+ * the forward and the backward call plus all scratch, so one tape serves one (forward, backward) pair at a time.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct cmh_block_grads {
+  float *in_proj_w, *in_proj_b, *out_proj_w, *out_proj_b, *ln1_w, *ln1_b, *ln2_w, *ln2_b, *fc_w, *fc_b, *proj_w, *proj_b;
+} cmh_block_grads;
+typedef struct cmh_vit_grads {
+  float* conv1_w;               /* [width, 3*patch*patch] */
+  float* class_embedding;       /* [width] */
+  float* positional_embedding;  /* [grid*grid+1, width] */
+  float *ln_pre_w, *ln_pre_b, *ln_post_w, *ln_post_b;
+  float* proj;                  /* [width, embed_dim] */
+  const cmh_block_grads* blocks;   /* host array [layers] */
+} cmh_vit_grads;
+typedef struct cmh_text_grads {
+  float* token_embedding;       /* [vocab, width]  (zeroed, then scatter-added) */
+  float* positional_embedding;  /* [context_length, width] */
+  float *ln_final_w, *ln_final_b;
+  float* text_projection;       /* [width, embed_dim] */
+  const cmh_block_grads* blocks;
+} cmh_text_grads;
+size_t cmh_vit_train_bytes(const cmh_vit_weights* w, int32_t batch);
+/* same `feat` as cmh_vit_encode (c_fc's QuickGELU runs as a separate pass over the stored pre-activation) */
+int cmh_vit_forward_train(const cmh_vit_weights* w, const float* image, int32_t batch, float* feat, void* tape, size_t tape_bytes,
+                          void* stream);
+int cmh_vit_backward(const cmh_vit_weights* w, int32_t batch, const float* dfeat, const cmh_vit_grads* grads, void* tape,
+                     size_t tape_bytes, void* stream);
+size_t cmh_text_train_bytes(const cmh_text_weights* w, int32_t batch, int32_t seq_len);
+int cmh_text_forward_train(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
+                           const uint8_t* key_padding_mask, float* feat, void* tape, size_t tape_bytes, void* stream);
+int cmh_text_backward(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
+                      const uint8_t* key_padding_mask, const float* dfeat, const cmh_text_grads* grads, void* tape,
+                      size_t tape_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

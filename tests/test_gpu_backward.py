@@ -112,3 +112,36 @@ def test_gemm_epilogue_mul_dquickgelu(M, N, K, mode):
                                       M, N, K, epi, Nn.stream_ptr(xd.device)), "gemm")
     tol = dict(rtol=1e-2, atol=1e-2) if mode == "bf16" else dict(rtol=1e-4, atol=2e-5)
     torch.testing.assert_close(out.cpu().double(), ref, **tol)
+
+
+def test_tower_gradients_match_reference_autograd(golden):
+    """L = sum(encode_image * Gi) + sum(encode_text * Gt): every parameter gradient of both towers against the gradients
+    torch autograd produced on the REFERENCE's CLIP (tests/golden/make_golden5.py), f32 mode."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden5 as mg
+    import recipe
+    from test_gpu_clip import _clip
+    g = golden("clip_tiny_grads.npz")
+    cfg, seed, B, L = recipe.CLIP_TINY, 7, 3, 16
+    clip = _clip(cfg, seed, "f32")          # same weights as the reference model of make_golden5.py (no fp16 round trip)
+    image = torch.from_numpy(recipe.images(B, cfg["image_resolution"], seed)).to(DEV)
+    text = torch.from_numpy(recipe.captions(B, L, cfg["vocab_size"], seed)).to(DEV)
+    gi, gt = mg.cotangents(B, cfg["embed_dim"], 23)
+    fi = clip.encode_image(image)
+    ft = clip.encode_text(text)
+    np.testing.assert_allclose(fi.detach().cpu().numpy(), g["img_feat"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(ft.detach().cpu().numpy(), g["txt_feat"], rtol=1e-4, atol=1e-4)
+    ((fi * gi.to(DEV)).sum() + (ft * gt.to(DEV)).sum()).backward()
+    params = dict(clip.named_parameters())
+    worst = 0.0
+    for name in [str(n) for n in g["names"]]:
+        got = params[name].grad
+        assert got is not None, name
+        ref, norm = g["g_" + name], float(g["n_" + name])
+        a = mg.cut(got.cpu().numpy())
+        assert abs(float(got.double().norm()) - norm) <= 2e-4 * max(norm, 1e-3), (name, float(got.double().norm()), norm)
+        err = np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-6)
+        worst = max(worst, err)
+        assert err < 5e-4, (name, err)
+    print(f"tower gradients: worst relative-to-max error {worst:.2e} over {len(g['names'])} tensors")
