@@ -66,3 +66,52 @@ def attention_backward(qkv, o, dout, B, T, causal, key_padding_mask=None):
     N.check(N.lib().cmh_attention_backward(dt, N.ptr(qkv), N.ptr(o), N.ptr(dout), N.ptr(dqkv), B, T, d, int(causal), N.ptr(kpm),
                                            N.stream_ptr(qkv.device)), "cmh_attention_backward")
     return dqkv
+
+
+# ------------------------------------------------------------------------------------------ heads / loss (autograd bridges)
+class LinearAct(torch.autograd.Function):
+    """cmh_linear_act with its backward (LinearHash: fc -> dropout -> tanh, model/modelbase.py:25-35)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, drop_mask, p):
+        y = N.linear_act(x, w, b, act, drop_mask, p)
+        ctx.save_for_backward(N.f32c(x), N.f32c(w), y, None if drop_mask is None else N.f32c(drop_mask))
+        ctx.act, ctx.keep = act, 1.0 / (1.0 - p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y, mask = ctx.saved_tensors
+        dy = N.f32c(dy)
+        M, K = x.shape
+        Nn = w.shape[0]
+        dx, dw, db = torch.empty_like(x), torch.empty_like(w), torch.empty(Nn, dtype=torch.float32, device=x.device)
+        ws = N.workspace(M * Nn * 4 + 256, x.device, "bwd")
+        N.check(N.lib().cmh_linear_act_backward(N.ptr(x), N.ptr(w), N.ptr(y), N.ptr(dy), N.ptr(mask), ctx.keep, ctx.act, N.ptr(dx),
+                                                N.ptr(dw), N.ptr(db), M, Nn, K, N.ptr(ws), ws.numel(), N.stream_ptr(x.device)),
+                "cmh_linear_act_backward")
+        return dx, dw, db, None, None, None
+
+
+class HypLoss(torch.autograd.Function):
+    """cmh_dsph_hyp_loss with its backward (train/DSPH/loss.py:22-72)."""
+
+    @staticmethod
+    def forward(ctx, x, y, label, proxies, threshold, alpha):
+        x, y, label, proxies = N.f32c(x), N.f32c(y), N.f32c(label), N.f32c(proxies)
+        ctx.save_for_backward(x, y, label, proxies)
+        ctx.threshold, ctx.alpha = float(threshold), float(alpha)
+        return N.dsph_hyp_loss(x, y, label, proxies, threshold, alpha)
+
+    @staticmethod
+    def backward(ctx, dloss):
+        x, y, label, proxies = ctx.saved_tensors
+        B, K = x.shape
+        Cn = label.shape[1]
+        dx, dy, dp = torch.empty_like(x), torch.empty_like(y), torch.empty_like(proxies)
+        dl = N.f32c(dloss).reshape(1)
+        ws = N.workspace(N.lib().cmh_head_backward_workspace_bytes(B, K, Cn), x.device, "bwd")
+        N.check(N.lib().cmh_dsph_hyp_loss_backward(N.ptr(x), N.ptr(y), N.ptr(label), N.ptr(proxies), B, K, Cn, ctx.threshold, ctx.alpha,
+                                                   N.ptr(dl), N.ptr(dx), N.ptr(dy), N.ptr(dp), N.ptr(ws), ws.numel(),
+                                                   N.stream_ptr(x.device)), "cmh_dsph_hyp_loss_backward")
+        return dx, dy, None, dp, None, None

@@ -1,0 +1,266 @@
+// Backward of the DSPH training step's small pieces (SURVEY §8f "next" #2): the hash head and the HyP proxy loss.
+//   cmh_linear_act_backward    LinearHash: y = act((x W^T + b) * mask * keep_scale)            (model/modelbase.py:25-35)
+//   cmh_dsph_hyp_loss_backward HyP.forward (train/DSPH/loss.py:22-72): d loss / d(x, y, proxies)
+// All f32, launch-latency bound (B = 256, K = 64, C <= ~100): a handful of launches, one wave per row.
+#include "cmh_common.h"
+
+namespace cmh {
+namespace {
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---- LinearHash ----------------------------------------------------------------------------------------------------------
+// dz[m,n] = dy[m,n] * act'(.) * (mask ? mask*keep_scale : 1);   act' from the OUTPUT y: tanh -> 1 - y^2, relu -> y > 0
+__global__ __launch_bounds__(256) void la_dz_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                    const float* __restrict__ mask, float keep_scale, int act, float* __restrict__ dz,
+                                                    int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float g = dy[i];
+  if (act == CMH_ACT_TANH) g *= 1.0f - y[i] * y[i];
+  else if (act == CMH_ACT_RELU) g = y[i] > 0.f ? g : 0.f;
+  if (mask) g *= mask[i] * keep_scale;
+  dz[i] = g;
+}
+// dx[m,k] = sum_n dz[m,n] W[n,k]
+__global__ __launch_bounds__(256) void la_dx_kernel(const float* __restrict__ dz, const float* __restrict__ w, float* __restrict__ dx,
+                                                    int M, int N, int K) {
+  const int m = blockIdx.x;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) acc = fmaf(dz[static_cast<size_t>(m) * N + n], w[static_cast<size_t>(n) * K + k], acc);
+    dx[static_cast<size_t>(m) * K + k] = acc;
+  }
+}
+// dW[n,k] = sum_m dz[m,n] x[m,k];  db[n] = sum_m dz[m,n]
+__global__ __launch_bounds__(256) void la_dw_kernel(const float* __restrict__ dz, const float* __restrict__ x, float* __restrict__ dw,
+                                                    float* __restrict__ db, int M, int N, int K) {
+  const int n = blockIdx.x;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    float acc = 0.f;
+    for (int m = 0; m < M; ++m) acc = fmaf(dz[static_cast<size_t>(m) * N + n], x[static_cast<size_t>(m) * K + k], acc);
+    dw[static_cast<size_t>(n) * K + k] = acc;
+  }
+  if (threadIdx.x == 0) {
+    float acc = 0.f;
+    for (int m = 0; m < M; ++m) acc += dz[static_cast<size_t>(m) * N + n];
+    db[n] = acc;
+  }
+}
+
+// ---- HyP ---------------------------------------------------------------------------------------------------------------------
+// rows -> unit vectors (F.normalize, eps 1e-12) + the divisor used
+__global__ __launch_bounds__(256) void hyp_normalize_kernel(const float* __restrict__ a, float* __restrict__ an, float* __restrict__ nrm,
+                                                            int R, int K) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  float ss = 0.f;
+  for (int k = lane; k < K; k += 64) { const float v = a[static_cast<size_t>(row) * K + k]; ss = fmaf(v, v, ss); }
+  const float n = fmaxf(sqrtf(wsum(ss)), 1e-12f);
+  for (int k = lane; k < K; k += 64) an[static_cast<size_t>(row) * K + k] = a[static_cast<size_t>(row) * K + k] / n;
+  if (lane == 0) nrm[row] = n;
+}
+
+// cnt[0] = #(label != 0) (P_num), cnt[1] = #(label == 0) (N_num), cnt[2] = #pairs (i,j) of multi-label rows with label_i . label_j == 0;
+// multi[b] = label[b].sum() > 1.  One workgroup.
+__global__ __launch_bounds__(256) void hyp_counts_kernel(const float* __restrict__ label, int B, int C, int* __restrict__ multi,
+                                                         float* __restrict__ cnt) {
+  __shared__ float sh[3][4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float p = 0.f, n = 0.f, z = 0.f;
+  for (int i = threadIdx.x; i < B * C; i += 256) { if (label[i] != 0.f) p += 1.f; else n += 1.f; }
+  for (int b = threadIdx.x; b < B; b += 256) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += label[static_cast<size_t>(b) * C + c];
+    multi[b] = s > 1.f;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < B * B; idx += 256) {
+    const int i = idx / B, j = idx - i * B;
+    if (multi[i] && multi[j]) {
+      float ll = 0.f;
+      for (int c = 0; c < C; ++c) ll = fmaf(label[static_cast<size_t>(i) * C + c], label[static_cast<size_t>(j) * C + c], ll);
+      if (ll == 0.f) z += 1.f;
+    }
+  }
+  p = wsum(p); n = wsum(n); z = wsum(z);
+  if (lane == 0) { sh[0][wid] = p; sh[1][wid] = n; sh[2][wid] = z; }
+  __syncthreads();
+  if (threadIdx.x < 3) cnt[threadIdx.x] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+}
+
+// One wave per sample b: gradients w.r.t. the NORMALISED rows xn[b], yn[b], then through the normalisation.
+//   proxy terms : G[b,c] = -1/P (label == 1) | (cos > thr)/N (label == 0)          (loss.py:25-40; `label == 1` / `== 0` literally)
+//   pair terms  : rows i, j both multi-label with label_i . label_j == 0, weight alpha / Z         (loss.py:42-64)
+//     x_sim[i,j] (counted at (i,j) and (j,i)) -> dxn_i += 2 w [x_sim > thr] xn_j;   t_sim likewise for yn;
+//     xt_sim[i,j] = xn_i . yn_j -> dxn_i += w [.] yn_j;   xt_sim[j,i] = xn_j . yn_i -> dyn_i += w [.] xn_j
+__global__ __launch_bounds__(64) void hyp_rows_kernel(const float* __restrict__ xn, const float* __restrict__ yn,
+                                                      const float* __restrict__ pn, const float* __restrict__ nx,
+                                                      const float* __restrict__ ny, const float* __restrict__ label,
+                                                      const int* __restrict__ multi, const float* __restrict__ cnt, int B, int K,
+                                                      int C, float thr, float alpha, const float* __restrict__ dloss,
+                                                      float* __restrict__ dx, float* __restrict__ dy) {
+  constexpr int KV = 8;                                 // K <= 512
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float up = dloss ? dloss[0] : 1.f;
+  const float invP = 1.f / cnt[0], invN = 1.f / cnt[1];
+  float xi[KV], yi[KV], gx[KV], gy[KV];
+#pragma unroll
+  for (int v = 0; v < KV; ++v) {
+    const int k = lane + 64 * v;
+    xi[v] = k < K ? xn[static_cast<size_t>(b) * K + k] : 0.f;
+    yi[v] = k < K ? yn[static_cast<size_t>(b) * K + k] : 0.f;
+    gx[v] = 0.f; gy[v] = 0.f;
+  }
+  for (int c = 0; c < C; ++c) {
+    float px[KV], cx = 0.f, ct = 0.f;
+#pragma unroll
+    for (int v = 0; v < KV; ++v) {
+      const int k = lane + 64 * v;
+      px[v] = k < K ? pn[static_cast<size_t>(c) * K + k] : 0.f;
+      cx = fmaf(xi[v], px[v], cx); ct = fmaf(yi[v], px[v], ct);
+    }
+    cx = wsum(cx); ct = wsum(ct);
+    const float l = label[static_cast<size_t>(b) * C + c];
+    float wx = 0.f, wt = 0.f;
+    if (l == 1.f) { wx = -invP; wt = -invP; }
+    else if (l == 0.f) { wx = cx > thr ? invN : 0.f; wt = ct > thr ? invN : 0.f; }
+#pragma unroll
+    for (int v = 0; v < KV; ++v) { gx[v] = fmaf(wx, px[v], gx[v]); gy[v] = fmaf(wt, px[v], gy[v]); }
+  }
+  if (alpha > 0.f && cnt[2] > 0.f && multi[b]) {
+    const float w = alpha / cnt[2];
+    for (int j = 0; j < B; ++j) {
+      if (!multi[j]) continue;
+      float ll = 0.f;
+      for (int c = lane; c < C; c += 64) ll = fmaf(label[static_cast<size_t>(b) * C + c], label[static_cast<size_t>(j) * C + c], ll);
+      if (wsum(ll) != 0.f) continue;
+      float xj[KV], yj[KV], sx = 0.f, st = 0.f, sxt = 0.f, stx = 0.f;
+#pragma unroll
+      for (int v = 0; v < KV; ++v) {
+        const int k = lane + 64 * v;
+        xj[v] = k < K ? xn[static_cast<size_t>(j) * K + k] : 0.f;
+        yj[v] = k < K ? yn[static_cast<size_t>(j) * K + k] : 0.f;
+        sx = fmaf(xi[v], xj[v], sx); st = fmaf(yi[v], yj[v], st); sxt = fmaf(xi[v], yj[v], sxt); stx = fmaf(xj[v], yi[v], stx);
+      }
+      sx = wsum(sx); st = wsum(st); sxt = wsum(sxt); stx = wsum(stx);
+      const float a = sx > thr ? 2.f * w : 0.f, bq = st > thr ? 2.f * w : 0.f, cq = sxt > thr ? w : 0.f, dq = stx > thr ? w : 0.f;
+#pragma unroll
+      for (int v = 0; v < KV; ++v) {
+        gx[v] = fmaf(a, xj[v], fmaf(cq, yj[v], gx[v]));
+        gy[v] = fmaf(bq, yj[v], fmaf(dq, xj[v], gy[v]));
+      }
+    }
+  }
+  // through F.normalize: d a = (g - an (an . g)) / max(||a||, eps)
+  float dxg = 0.f, dyg = 0.f;
+#pragma unroll
+  for (int v = 0; v < KV; ++v) { dxg = fmaf(xi[v], gx[v], dxg); dyg = fmaf(yi[v], gy[v], dyg); }
+  dxg = wsum(dxg); dyg = wsum(dyg);
+  const float rx = up / nx[b], ry = up / ny[b];
+#pragma unroll
+  for (int v = 0; v < KV; ++v) {
+    const int k = lane + 64 * v;
+    if (k < K) {
+      dx[static_cast<size_t>(b) * K + k] = (gx[v] - xi[v] * dxg) * rx;
+      dy[static_cast<size_t>(b) * K + k] = (gy[v] - yi[v] * dyg) * ry;
+    }
+  }
+}
+
+// One wave per proxy c: dpn[c] = sum_b G_x[b,c] xn[b] + G_t[b,c] yn[b], then through the normalisation
+__global__ __launch_bounds__(64) void hyp_proxy_kernel(const float* __restrict__ xn, const float* __restrict__ yn,
+                                                       const float* __restrict__ pn, const float* __restrict__ np_,
+                                                       const float* __restrict__ label, const float* __restrict__ cnt, int B, int K,
+                                                       int C, float thr, const float* __restrict__ dloss, float* __restrict__ dp) {
+  constexpr int KV = 8;
+  const int c = blockIdx.x, lane = threadIdx.x;
+  const float up = dloss ? dloss[0] : 1.f;
+  const float invP = 1.f / cnt[0], invN = 1.f / cnt[1];
+  float pc[KV], g[KV];
+#pragma unroll
+  for (int v = 0; v < KV; ++v) { const int k = lane + 64 * v; pc[v] = k < K ? pn[static_cast<size_t>(c) * K + k] : 0.f; g[v] = 0.f; }
+  for (int b = 0; b < B; ++b) {
+    float xb[KV], yb[KV], cx = 0.f, ct = 0.f;
+#pragma unroll
+    for (int v = 0; v < KV; ++v) {
+      const int k = lane + 64 * v;
+      xb[v] = k < K ? xn[static_cast<size_t>(b) * K + k] : 0.f;
+      yb[v] = k < K ? yn[static_cast<size_t>(b) * K + k] : 0.f;
+      cx = fmaf(xb[v], pc[v], cx); ct = fmaf(yb[v], pc[v], ct);
+    }
+    cx = wsum(cx); ct = wsum(ct);
+    const float l = label[static_cast<size_t>(b) * C + c];
+    float wx = 0.f, wt = 0.f;
+    if (l == 1.f) { wx = -invP; wt = -invP; }
+    else if (l == 0.f) { wx = cx > thr ? invN : 0.f; wt = ct > thr ? invN : 0.f; }
+#pragma unroll
+    for (int v = 0; v < KV; ++v) g[v] = fmaf(wx, xb[v], fmaf(wt, yb[v], g[v]));
+  }
+  float pg = 0.f;
+#pragma unroll
+  for (int v = 0; v < KV; ++v) pg = fmaf(pc[v], g[v], pg);
+  pg = wsum(pg);
+  const float r = up / np_[c];
+#pragma unroll
+  for (int v = 0; v < KV; ++v) { const int k = lane + 64 * v; if (k < K) dp[static_cast<size_t>(c) * K + k] = (g[v] - pc[v] * pg) * r; }
+}
+
+}  // namespace
+}  // namespace cmh
+
+using namespace cmh;
+
+extern "C" size_t cmh_head_backward_workspace_bytes(int32_t B, int32_t K, int32_t C) {
+  if (B <= 0 || K <= 0 || C <= 0) return 0;
+  const size_t bk = align_up(static_cast<size_t>(B) * K * 4, 256), ck = align_up(static_cast<size_t>(C) * K * 4, 256);
+  return 2 * bk + ck + 3 * align_up(static_cast<size_t>(B > C ? B : C) * 4, 256) + align_up(static_cast<size_t>(B) * 4, 256) + 512;
+}
+
+extern "C" int cmh_linear_act_backward(const float* x, const float* w, const float* y, const float* dy, const float* drop_mask,
+                                       float keep_scale, int32_t act, float* dx, float* dw, float* db, int32_t M, int32_t N,
+                                       int32_t K, void* workspace, size_t workspace_bytes, void* stream) {
+  CMH_CHECK_ARG(x && w && y && dy && dx && dw && db && workspace && M > 0 && N > 0 && K > 0, "linear_act_backward: bad arguments");
+  CMH_CHECK_ARG(act == CMH_ACT_NONE || act == CMH_ACT_TANH || act == CMH_ACT_RELU, "linear_act_backward: bad act %d", act);
+  if (workspace_bytes < static_cast<size_t>(M) * N * 4 + 256) return fail(CMH_ERR_WORKSPACE, "linear_act_backward: workspace too small");
+  float* dz = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(la_dz_kernel, dim3((M * N + 255) / 256), dim3(256), 0, st, y, dy, drop_mask, keep_scale, act, dz, M * N);
+  hipLaunchKernelGGL(la_dx_kernel, dim3(M), dim3(256), 0, st, dz, w, dx, M, N, K);
+  hipLaunchKernelGGL(la_dw_kernel, dim3(N), dim3(256), 0, st, dz, x, dw, db, M, N, K);
+  CMH_CHECK_LAUNCH("linear_act_backward");
+  return CMH_OK;
+}
+
+extern "C" int cmh_dsph_hyp_loss_backward(const float* x, const float* y, const float* label, const float* proxies, int32_t B,
+                                          int32_t K, int32_t C, float threshold, float alpha, const float* dloss, float* dx,
+                                          float* dy, float* dproxies, void* workspace, size_t workspace_bytes, void* stream) {
+  CMH_CHECK_ARG(x && y && label && proxies && dx && dy && dproxies && workspace, "dsph_hyp_loss_backward: null pointer");
+  CMH_CHECK_ARG(B > 0 && K > 0 && K <= 512 && C > 0 && B <= 32768, "dsph_hyp_loss_backward: bad shape B=%d K=%d C=%d", B, K, C);
+  if (workspace_bytes < cmh_head_backward_workspace_bytes(B, K, C)) return fail(CMH_ERR_WORKSPACE, "dsph_hyp_loss_backward: workspace too small");
+  char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+  const size_t bk = align_up(static_cast<size_t>(B) * K * 4, 256), ck = align_up(static_cast<size_t>(C) * K * 4, 256);
+  const size_t v = align_up(static_cast<size_t>(B > C ? B : C) * 4, 256);
+  float* xn = reinterpret_cast<float*>(ws);
+  float* yn = reinterpret_cast<float*>(ws + bk);
+  float* pn = reinterpret_cast<float*>(ws + 2 * bk);
+  float* nx = reinterpret_cast<float*>(ws + 2 * bk + ck);
+  float* ny = reinterpret_cast<float*>(ws + 2 * bk + ck + v);
+  float* np_ = reinterpret_cast<float*>(ws + 2 * bk + ck + 2 * v);
+  int* multi = reinterpret_cast<int*>(ws + 2 * bk + ck + 3 * v);
+  float* cnt = reinterpret_cast<float*>(ws + 2 * bk + ck + 3 * v + align_up(static_cast<size_t>(B) * 4, 256));
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(hyp_normalize_kernel, dim3((B + 3) / 4), dim3(256), 0, st, x, xn, nx, B, K);
+  hipLaunchKernelGGL(hyp_normalize_kernel, dim3((B + 3) / 4), dim3(256), 0, st, y, yn, ny, B, K);
+  hipLaunchKernelGGL(hyp_normalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, proxies, pn, np_, C, K);
+  hipLaunchKernelGGL(hyp_counts_kernel, dim3(1), dim3(256), 0, st, label, B, C, multi, cnt);
+  hipLaunchKernelGGL(hyp_rows_kernel, dim3(B), dim3(64), 0, st, xn, yn, pn, nx, ny, label, multi, cnt, B, K, C, threshold, alpha, dloss,
+                     dx, dy);
+  hipLaunchKernelGGL(hyp_proxy_kernel, dim3(C), dim3(64), 0, st, xn, yn, pn, np_, label, cnt, B, K, C, threshold, dloss, dproxies);
+  CMH_CHECK_LAUNCH("dsph_hyp_loss_backward");
+  return CMH_OK;
+}

@@ -102,4 +102,6 @@ class BertAdam(Optimizer):
                 state["step"] += 1
         for (b1, b2, e), entries in batches.items():
             N.bert_adam_step(entries, b1, b2, e)
+            # the kernel wrote through raw pointers: tell autograd / the weight caches (model/base/model.py::_key)
+            torch._C._increment_version([t for p, g, *_ in entries for t in (p, g)])
         return loss

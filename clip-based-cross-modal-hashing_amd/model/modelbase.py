@@ -47,8 +47,10 @@ class LinearHash(nn.Module):
         if self.training and drop_mask is None and self.drop_out.p > 0:
             drop_mask = (torch.rand(data.shape[0], self.fc.out_features, device=data.device)
                          >= self.drop_out.p).float()
-        out = N.linear_act(data, self.fc.weight, self.fc.bias, N.ACT_TANH, drop_mask, self.drop_out.p)
-        return no_backward(out, self.fc.weight)
+        if torch.is_grad_enabled() and (data.requires_grad or self.fc.weight.requires_grad):
+            from backward_ops import LinearAct
+            return LinearAct.apply(data, self.fc.weight, self.fc.bias, N.ACT_TANH, drop_mask, self.drop_out.p)
+        return N.linear_act(data, self.fc.weight, self.fc.bias, N.ACT_TANH, drop_mask, self.drop_out.p)
 
 
 class Baseclip(nn.Module):

@@ -38,5 +38,8 @@ class HyP(torch.nn.Module):
         self.threshold = code_threshold(output_dim, numclass)
 
     def forward(self, x=None, y=None, label=None):
-        loss = N.dsph_hyp_loss(x, y, label.to(x.device), self.proxies, self.threshold, self.alpha)
-        return no_backward(loss, self.proxies)
+        label = label.to(x.device)
+        if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad or self.proxies.requires_grad):
+            from backward_ops import HypLoss
+            return HypLoss.apply(x, y, label, self.proxies, self.threshold, self.alpha)
+        return N.dsph_hyp_loss(x, y, label, self.proxies, self.threshold, self.alpha)

@@ -394,6 +394,17 @@ typedef struct cmh_text_grads {
   float* text_projection;       /* [width, embed_dim] */
   const cmh_block_grads* blocks;
 } cmh_text_grads;
+/* Backward of cmh_linear_act (LinearHash, model/modelbase.py:25-35): y = the forward output, dy its gradient, drop_mask /
+ * keep_scale / act as in the forward call -> dx [M,K], dw [N,K], db [N].  workspace >= M*N*4 + 256 bytes. */
+int cmh_linear_act_backward(const float* x, const float* w, const float* y, const float* dy, const float* drop_mask,
+                            float keep_scale, int32_t act, float* dx, float* dw, float* db, int32_t M, int32_t N, int32_t K,
+                            void* workspace, size_t workspace_bytes, void* stream);
+/* Backward of cmh_dsph_hyp_loss (train/DSPH/loss.py:22-72): dloss = optional device scalar (NULL = 1) ->
+ * dx, dy [B,K], dproxies [C,K].  K <= 512. */
+size_t cmh_head_backward_workspace_bytes(int32_t B, int32_t K, int32_t C);
+int cmh_dsph_hyp_loss_backward(const float* x, const float* y, const float* label, const float* proxies, int32_t B, int32_t K,
+                               int32_t C, float threshold, float alpha, const float* dloss, float* dx, float* dy,
+                               float* dproxies, void* workspace, size_t workspace_bytes, void* stream);
 size_t cmh_vit_train_bytes(const cmh_vit_weights* w, int32_t batch);
 /* same `feat` as cmh_vit_encode (c_fc's QuickGELU runs as a separate pass over the stored pre-activation) */
 int cmh_vit_forward_train(const cmh_vit_weights* w, const float* image, int32_t batch, float* feat, void* tape, size_t tape_bytes,

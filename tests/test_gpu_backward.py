@@ -145,3 +145,85 @@ def test_tower_gradients_match_reference_autograd(golden):
         worst = max(worst, err)
         assert err < 5e-4, (name, err)
     print(f"tower gradients: worst relative-to-max error {worst:.2e} over {len(g['names'])} tensors")
+
+
+@pytest.mark.parametrize("B,K,C,alpha", [(8, 16, 5, 0.8), (64, 64, 24, 0.8), (256, 64, 80, 0.8), (32, 128, 10, 0.0)])
+def test_hyp_loss_backward(B, K, C, alpha):
+    """d HyP / d(x, y, proxies) against torch autograd (fp64) of the reference formula (train/DSPH/loss.py:22-72)."""
+    import torch.nn.functional as F
+    from backward_ops import HypLoss
+    g = torch.Generator().manual_seed(B + K + C)
+    x = torch.tanh(torch.randn(B, K, generator=g))
+    y = torch.tanh(torch.randn(B, K, generator=g))
+    label = (torch.rand(B, C, generator=g) < 0.15).float()
+    label[0] = 0
+    label[1, :3] = 1
+    prox = torch.randn(C, K, generator=g)
+    thr = 0.05
+
+    def ref(x, y, p):
+        cos = F.normalize(x, dim=1) @ F.normalize(p, dim=1).T
+        cos_t = F.normalize(y, dim=1) @ F.normalize(p, dim=1).T
+        lab = label.double()
+        P, Nn = (lab != 0).sum(), (lab == 0).sum()
+        tot = ((1 - cos)[lab == 1].sum() + (1 - cos_t)[lab == 1].sum()) / P + (F.relu(cos - thr)[lab == 0].sum() + F.relu(cos_t - thr)[lab == 0].sum()) / Nn
+        if alpha > 0:
+            idx = lab.sum(1) > 1
+            l_ = lab[idx]
+            cs = l_ @ l_.T
+            if (cs == 0).sum() > 0:
+                xn, tn = F.normalize(x[idx], dim=1), F.normalize(y[idx], dim=1)
+                Z = (cs == 0).sum()
+                for s in (xn @ xn.T, tn @ tn.T, xn @ tn.T):
+                    tot = tot + (alpha * F.relu(s - thr))[cs == 0].sum() / Z
+        return tot
+    xr, yr, pr = (t.double().requires_grad_(True) for t in (x, y, prox))
+    (ref(xr, yr, pr) * 1.7).backward()
+    xd, yd, pd = (t.to(DEV).requires_grad_(True) for t in (x, y, prox))
+    loss = HypLoss.apply(xd, yd, label.to(DEV), pd, thr, alpha)
+    (loss * 1.7).backward()
+    assert abs(float(loss) - float(ref(x.double(), y.double(), prox.double()))) < 1e-5
+    for a, r in ((xd.grad, xr.grad), (yd.grad, yr.grad), (pd.grad, pr.grad)):
+        torch.testing.assert_close(a.cpu().double(), r, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+@pytest.mark.parametrize("use_mask", [False, True])
+def test_linear_act_backward(act, use_mask):
+    from backward_ops import LinearAct
+    g = torch.Generator().manual_seed(act * 2 + use_mask)
+    M, Nn, K = 37, 64, 512
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(Nn, K, generator=g) * 0.05, torch.randn(Nn, generator=g)
+    mask = (torch.rand(M, Nn, generator=g) >= 0.2).float() if use_mask else None
+    dy = torch.randn(M, Nn, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    z = xr @ wr.T + br
+    if mask is not None:
+        z = z * mask.double() / 0.8
+    yref = torch.tanh(z) if act == 1 else (torch.relu(z) if act == 2 else z)
+    yref.backward(dy.double())
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    out = LinearAct.apply(xd, wd, bd, act, None if mask is None else mask.to(DEV), 0.2)
+    out.backward(dy.to(DEV))
+    torch.testing.assert_close(out.detach().cpu().double(), yref.detach(), rtol=1e-4, atol=1e-5)
+    for a, r in ((xd.grad, xr.grad), (wd.grad, wr.grad), (bd.grad, br.grad)):
+        torch.testing.assert_close(a.cpu().double(), r, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,K,C,alpha,p", [(32, 64, 24, 0.8, 0.15), (48, 16, 80, 0.8, 0.05), (16, 128, 21, 0.0, 0.2), (8, 32, 24, 0.8, 0.04)])
+def test_hyp_loss_gradients_match_reference_goldens(golden, B, K, C, alpha, p):
+    """The gradients the REFERENCE's HyP produced (tests/golden/make_golden.py::gen_loss_dsph)."""
+    import recipe
+    from backward_ops import HypLoss
+    g = golden("loss_dsph.npz")
+    tag, seed = f"B{B}_K{K}_C{C}", 21
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    x = torch.tanh(t(recipe.features(B, K, seed, f"dsph_x_{tag}"))).requires_grad_()
+    y = torch.tanh(t(recipe.features(B, K, seed, f"dsph_y_{tag}"))).requires_grad_()
+    prox = t(recipe.features(C, K, seed, f"dsph_prox_{tag}")).requires_grad_()
+    lab = t(recipe.labels(B, C, seed, p=p, tag=f"dsph_lab_{tag}"))
+    loss = HypLoss.apply(x, y, lab, prox, float(g[f"{tag}_threshold"]), alpha)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g[f"{tag}_loss"])) < 1e-4
+    for a, name in ((x.grad, "gx"), (y.grad, "gy"), (prox.grad, "gprox")):
+        np.testing.assert_allclose(a.cpu().numpy(), g[f"{tag}_{name}"], rtol=1e-4, atol=1e-6)
