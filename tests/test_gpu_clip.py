@@ -101,10 +101,17 @@ def test_large_batch_matches_small_batches():
     np.testing.assert_allclose(full, part, rtol=1e-5, atol=1e-6)
 
 
-def test_backward_fails_loudly():
+def test_backward_is_native_or_fails_loudly():
+    """encode_* under grad mode run the tape-keeping forward and a real backward (tests/test_gpu_backward.py pins the values);
+    a frozen model stays inference-only and refuses to differentiate."""
     cfg, seed = recipe.CLIP_TINY, 7
     m = _clip(cfg, seed, "f32")
-    out = m.encode_text(torch.from_numpy(recipe.captions(2, 16, cfg["vocab_size"], 3)).to(DEV))
+    txt = torch.from_numpy(recipe.captions(2, 16, cfg["vocab_size"], 3)).to(DEV)
+    out = m.encode_text(txt)
     assert out.requires_grad
+    out.sum().backward()
+    assert m.text_projection.grad is not None and torch.isfinite(m.text_projection.grad).all()
+    assert m.visual.proj.grad is None
+    m.assume_frozen = True
     with pytest.raises(NotImplementedError):
-        out.sum().backward()
+        m.encode_text(txt).sum().backward()

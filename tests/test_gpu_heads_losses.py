@@ -159,5 +159,13 @@ def test_trainer_valid_end_to_end(tmp_path, monkeypatch):
     maps = tr.valid(0)
     m_ref, _, _ = oracle.map_k(q_img.cpu().numpy(), r_txt.cpu().numpy(), tr.query_labels.numpy(), tr.retrieval_labels.numpy())
     assert abs(float(maps[0]) - float(m_ref)) < 2e-6
-    with pytest.raises(NotImplementedError):
-        tr.train_epoch(0)
+    # two real epochs: forward (tape) -> HyP loss -> backward through heads and both towers -> fused BertAdam + SGD on the proxies
+    for grp in tr.optimizer.param_groups:
+        grp["t_total"] = 8                       # the trainer was built with --epochs 0
+    before = {n: p.detach().clone() for n, p in tr.model.named_parameters()}
+    prox0 = tr.hyp.proxies.detach().clone()
+    tr.train_epoch(0)
+    tr.train_epoch(1)
+    changed = [n for n, p in tr.model.named_parameters() if not torch.equal(p.detach(), before[n])]
+    assert set(before) - set(changed) == {"clip.logit_scale"}, sorted(set(before) - set(changed))[:5]   # unused by DSPH, as upstream
+    assert all(torch.isfinite(p).all() for p in tr.model.parameters()) and not torch.equal(prox0, tr.hyp.proxies.detach())
