@@ -115,3 +115,18 @@ class HypLoss(torch.autograd.Function):
                                                    N.ptr(dl), N.ptr(dx), N.ptr(dy), N.ptr(dp), N.ptr(ws), ws.numel(),
                                                    N.stream_ptr(x.device)), "cmh_dsph_hyp_loss_backward")
         return dx, dy, None, dp, None, None
+
+
+def linear_wgrad(dy, x, gemm_dtype="bf16", want_bias=True):
+    """dW [O,I] = dy^T x (+ db = column sums of dy) on the encoder GEMM (split over K = M rows when that pays)."""
+    N.require_gpu(dy, x)
+    dy, x = dy.contiguous(), x.contiguous()
+    M, O = dy.shape
+    I = x.shape[1]
+    dt = N.BF16 if gemm_dtype == "bf16" else N.F32
+    dw = torch.empty(O, I, dtype=torch.float32, device=x.device)
+    db = torch.empty(O, dtype=torch.float32, device=x.device) if want_bias else None
+    ws = N.workspace(N.lib().cmh_linear_wgrad_workspace_bytes(dt, M, O, I), x.device, "wgrad")
+    N.check(N.lib().cmh_linear_wgrad(dt, N.ptr(dy), KIND[dy.dtype], N.ptr(x), KIND[x.dtype], M, O, I, N.ptr(dw), N.ptr(db), N.ptr(ws),
+                                     ws.numel(), N.stream_ptr(x.device)), "cmh_linear_wgrad")
+    return dw, db

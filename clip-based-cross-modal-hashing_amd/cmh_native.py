@@ -129,6 +129,8 @@ SIGNATURES = {
     "cmh_layernorm_backward": (C.c_int, [_p, _i32, _p, _i32, _p, _i32, _i32, _p, _i32, _p, _p, _p, _sz, _p]),
     "cmh_quick_gelu": (C.c_int, [_p, _p, _i64, _i32, _p]),
     "cmh_attention_backward": (C.c_int, [_i32, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
+    "cmh_linear_wgrad_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "cmh_linear_wgrad": (C.c_int, [_i32, _p, _i32, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _sz, _p]),
     "cmh_linear_act_backward": (C.c_int, [_p, _p, _p, _p, _p, _f, _i32, _p, _p, _p, _i32, _i32, _i32, _p, _sz, _p]),
     "cmh_head_backward_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "cmh_dsph_hyp_loss_backward": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _f, _f, _p, _p, _p, _p, _p, _sz, _p]),

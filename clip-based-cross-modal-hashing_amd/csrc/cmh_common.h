@@ -123,6 +123,10 @@ int launch_text_embed(const int64_t* tokens, const float* tok_emb, const float* 
                       int32_t* eot_row, int B, int L, int d, int vocab, hipStream_t st);
 // cls_row[b] = b*T
 int launch_iota_rows(int32_t* rows, int B, int T, hipStream_t st);
+// gemm_wide.hip: split-K for few-tile / long-K products (wgrad); plan returns S (1 = do not split), partials = S*M*N floats
+int gemm_wide_splitk_plan(int dt, int M, int N, int K);
+int launch_gemm_wide_splitk(int dt, const void* A, const void* W, float* out, float* partials, int S, int M, int N, int K,
+                            hipStream_t st);
 // norm_embed.hip (training forward): LayerNorm between any stream kinds; token assembly without ln_pre
 int launch_layernorm_any(const void* x, int x_kind, const int32_t* row_index, const float* w, const float* b, void* out,
                          int out_kind, int M, int d, hipStream_t st);

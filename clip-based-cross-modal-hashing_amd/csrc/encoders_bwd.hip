@@ -55,6 +55,8 @@ struct TrainBufs {
   void* dxe;           // [M,d] e
   void* mlp;           // [M,4d] e   gelu(pre)
   void* dpre;          // [M,4d] e
+  float* part;         // split-K partial planes of the wgrad GEMMs
+  size_t part_bytes;
   void* dh;            // [M,d] e
   void* dqkv;          // [M,3d] e
   void* tA;            // [rmax, Mpad] e   dY^T
@@ -94,6 +96,8 @@ TrainBufs carve_train(void* ws, size_t M, size_t B, size_t d, size_t e, size_t x
   t.dxe = a.take(M * d * e);
   t.mlp = a.take(M * 4 * d * e);
   t.dpre = a.take(M * 4 * d * e);
+  t.part_bytes = static_cast<size_t>(256 + 64) * 160 * 256 * 4;      // <= one round of 160x256 f32 tiles (kPartBytes)
+  t.part = a.take<float>(t.part_bytes);
   t.dh = a.take(M * d * e);
   t.dqkv = a.take(M * 3 * d * e);
   const size_t rmax = 4 * d > pk ? 4 * d : pk;
@@ -150,15 +154,26 @@ int block_forward_train(const cmh_block_weights& w, int dt, int xh, const LayerT
 }
 
 // dW[O, I] = dY^T X with dY [M, O] (kind ky) and X [M, I] (kind kx); db[O] = column sums of dY
-int wgrad(int dt, const void* dY, int ky, int O, const void* X, int kx, int I, int M, float* dW, float* db, TrainBufs& t,
-          hipStream_t st) {
+struct WgradScratch { void* tA; void* tB; float* part; size_t part_bytes; void* red; size_t red_bytes; };
+
+int wgrad_core(int dt, const void* dY, int ky, int O, const void* X, int kx, int I, int M, float* dW, float* db,
+               const WgradScratch& w, hipStream_t st) {
   const int mp = static_cast<int>(pad64(M));
   int rc;
-  if ((rc = launch_transpose(dY, ky, t.tA, ekind(dt), M, O, mp, st))) return rc;
-  if ((rc = launch_transpose(X, kx, t.tB, ekind(dt), M, I, mp, st))) return rc;
-  if ((rc = launch_gemm(dt, t.tA, t.tB, nullptr, nullptr, dW, O, I, mp, 0, st))) return rc;
-  if (db && (rc = cmh_colsum(dY, ky, M, O, db, t.red, t.red_bytes, st))) return rc;
+  if ((rc = launch_transpose(dY, ky, w.tA, ekind(dt), M, O, mp, st))) return rc;
+  if ((rc = launch_transpose(X, kx, w.tB, ekind(dt), M, I, mp, st))) return rc;
+  const int S = gemm_wide_splitk_plan(dt, O, I, mp);
+  if (S > 1 && static_cast<size_t>(S) * O * I * 4 <= w.part_bytes) {
+    // few output tiles, K = M rows: split K over S groups of workgroups, partial planes summed afterwards
+    if ((rc = launch_gemm_wide_splitk(dt, w.tA, w.tB, dW, w.part, S, O, I, mp, st))) return rc;
+  } else if ((rc = launch_gemm(dt, w.tA, w.tB, nullptr, nullptr, dW, O, I, mp, 0, st))) return rc;
+  if (db && (rc = cmh_colsum(dY, ky, M, O, db, w.red, w.red_bytes, st))) return rc;
   return CMH_OK;
+}
+
+int wgrad(int dt, const void* dY, int ky, int O, const void* X, int kx, int I, int M, float* dW, float* db, TrainBufs& t,
+          hipStream_t st) {
+  return wgrad_core(dt, dY, ky, O, X, kx, I, M, dW, db, WgradScratch{t.tA, t.tB, t.part, t.part_bytes, t.red, t.red_bytes}, st);
 }
 
 // dX[M, I] = dY[M, O] . W[O, I]  (W in the GEMM dtype, row-major [O, I]); out typed by `epi`
@@ -282,6 +297,35 @@ int check_train_tower(int dt, int width, int layers, int embed, const cmh_block_
 }  // namespace cmh
 
 using namespace cmh;
+
+// ================================================================================================================ wgrad
+static constexpr size_t kPartBytes = static_cast<size_t>(256 + 64) * 160 * 256 * 4;      // <= one round of 160x256 f32 tiles
+
+extern "C" size_t cmh_linear_wgrad_workspace_bytes(int32_t dtype, int32_t M, int32_t O, int32_t I) {
+  if (M <= 0 || O <= 0 || I <= 0) return 0;
+  const size_t e = dtype == CMH_BF16 ? 2 : 4, mp = pad64(static_cast<size_t>(M));
+  return align_up(static_cast<size_t>(O) * mp * e, 256) + align_up(static_cast<size_t>(I) * mp * e, 256) + kPartBytes +
+         align_up(cmh_colsum_workspace_bytes(M, O), 256) + 256;
+}
+
+extern "C" int cmh_linear_wgrad(int32_t dtype, const void* dy, int32_t dy_kind, const void* x, int32_t x_kind, int32_t M, int32_t O,
+                                int32_t I, float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream) {
+  CMH_CHECK_ARG(dy && x && dw && workspace && M > 0 && O > 0 && I > 0, "linear_wgrad: bad arguments");
+  CMH_CHECK_ARG(dtype == CMH_F32 || dtype == CMH_BF16, "linear_wgrad: bad dtype");
+  if (workspace_bytes < cmh_linear_wgrad_workspace_bytes(dtype, M, O, I)) return fail(CMH_ERR_WORKSPACE, "linear_wgrad: workspace too small");
+  const size_t e = dtype == CMH_BF16 ? 2 : 4, mp = pad64(static_cast<size_t>(M));
+  char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+  WgradScratch w;
+  w.tA = ws; ws += align_up(static_cast<size_t>(O) * mp * e, 256);
+  w.tB = ws; ws += align_up(static_cast<size_t>(I) * mp * e, 256);
+  w.part = reinterpret_cast<float*>(ws); w.part_bytes = kPartBytes; ws += kPartBytes;
+  w.red = ws; w.red_bytes = cmh_colsum_workspace_bytes(M, O);
+  hipStream_t st = as_stream(stream);
+  if (mp != static_cast<size_t>(M) &&
+      (hipMemsetAsync(w.tA, 0, static_cast<size_t>(O) * mp * e, st) != hipSuccess || hipMemsetAsync(w.tB, 0, static_cast<size_t>(I) * mp * e, st) != hipSuccess))
+    return fail(CMH_ERR_LAUNCH, "linear_wgrad: memset failed");
+  return wgrad_core(dtype, dy, dy_kind, O, x, x_kind, I, M, dw, db, w, st);
+}
 
 // ================================================================================================================ vision
 extern "C" size_t cmh_vit_train_bytes(const cmh_vit_weights* w, int32_t batch) {

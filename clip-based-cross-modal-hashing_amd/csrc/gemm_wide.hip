@@ -57,7 +57,7 @@ __device__ unsigned g_wide_stamps[256 * 8 * 4];
 template <bool F32, bool OUTBF>
 __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__ X, const char* __restrict__ W,
                                                         const float* __restrict__ bias, const float* residual,
-                                                        void* out, int M, int N, int K, int epi) {
+                                                        void* out, int M, int N, int K, int epi, int ksplit) {
   __shared__ __attribute__((aligned(1024))) char lds[3 * wStageBytes];
 
   constexpr int ELT = F32 ? 4 : 2;
@@ -75,7 +75,10 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   // ---- this workgroup's tiles: XCD x = blockIdx%8 owns a contiguous range of the n-fastest tile order ----
   const int tiles_n = N / wBN;
   const int tiles_m = (M + wBM - 1) / wBM;
-  const int total = tiles_n * tiles_m;
+  // split-K (wgrad: few output tiles, very long K): virtual tile v = split * base_total + tile computes K-steps
+  // [split * nk, (split + 1) * nk) into the f32 partial plane out + split * M * N (summed by splitk_reduce_kernel)
+  const int base_total = tiles_n * tiles_m;
+  const int total = base_total * ksplit;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd_blocks = gridDim.x >> 3;
   const int q = total >> 3, r = total & 7;
   const int range_lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   const int my_tiles = slot < range_len ? (range_len - slot + per_xcd_blocks - 1) / per_xcd_blocks : 0;
   if (my_tiles == 0) return;
 
-  const int nk = K / BK;
+  const int nk = K / BK / ksplit;   // K-steps per (virtual) tile
   const uint32_t row_stride = static_cast<uint32_t>(K) * ELT;
 
   // ---- issue side.  DMA source = uniform tile base (SGPRs) + 32-bit per-lane offset (one VGPR per piece):
@@ -94,12 +97,16 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
     const int row = (wid * 4 + i) * 8 + sub;
     offW[i] = static_cast<uint32_t>(row) * row_stride + (((lane & 7) ^ (row & 7)) << 4);
   }
-  const char* Wt = W;   // W + n0*row_stride of the tile being staged
+  const char* Wt = W;   // W + n0*row_stride (+ the split's K offset) of the tile being staged
+  const char* Xt = X;   // X (+ the split's K offset)
   auto set_issue_tile = [&](int ti) {
-    const int logical = range_lo + slot + ti * per_xcd_blocks;
+    const int virt = range_lo + slot + ti * per_xcd_blocks;
+    const int split = virt / base_total, logical = virt - split * base_total;
     const int tm = logical / tiles_n, tn = logical - tm * tiles_n;
     const int m0 = tm * wBM, n0 = tn * wBN;
-    Wt = W + static_cast<size_t>(n0) * row_stride;
+    const size_t kbase = static_cast<size_t>(split) * nk * wRowBytes;
+    Wt = W + static_cast<size_t>(n0) * row_stride + kbase;
+    Xt = X + kbase;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int row = (wid + 8 * i) * 8 + sub;
@@ -115,10 +122,10 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
     if (p < 4)
       __builtin_amdgcn_global_load_lds((w_gptr_t)(Wt + koff + offW[p]), (w_lptr_t)(base + (wid * 4 + p) * 1024), 16, 0, 0);
     else if (p < 6)
-      __builtin_amdgcn_global_load_lds((w_gptr_t)(X + koff + offX[p - 4]),
+      __builtin_amdgcn_global_load_lds((w_gptr_t)(Xt + koff + offX[p - 4]),
                                        (w_lptr_t)(base + wWBytes + (wid + 8 * (p - 4)) * 1024), 16, 0, 0);
     else if (three)
-      __builtin_amdgcn_global_load_lds((w_gptr_t)(X + koff + offX[2]), (w_lptr_t)(base + wWBytes + (wid + 16) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((w_gptr_t)(Xt + koff + offX[2]), (w_lptr_t)(base + wWBytes + (wid + 16) * 1024), 16, 0, 0);
   };
   // The K loop below is ONE straight-line steady state: it issues a stage in every K-step.  The three stages issued past
   // the workgroup's last one re-stage its last tile into buffers nobody reads any more (drained before the kernel ends).
@@ -362,7 +369,8 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
     pend_valid = false;   // sps * nk >= 10: every deferred store of the previous tile has been issued
 
     // ---- epilogue of tile ti (the next tile's first stages are already in flight) ----------------------------
-    const int logical = range_lo + slot + ti * per_xcd_blocks;
+    const int virt = range_lo + slot + ti * per_xcd_blocks;
+    const int split = virt / base_total, logical = virt - split * base_total;
     const int tm = logical / tiles_n, tn = logical - tm * tiles_n;
     const int m0 = tm * wBM, n0 = tn * wBN;
     // All loads first, then all stores: a load issued behind a store (or waited for with DMA in flight) would wait for
@@ -480,7 +488,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           const int n = n0 + wn * 64 + a * 16 + fq * 4;
-          *reinterpret_cast<w_f32x4_t*>(static_cast<float*>(out) + static_cast<size_t>(m) * N + n) = acc[a][b];
+          *reinterpret_cast<w_f32x4_t*>(static_cast<float*>(out) + (static_cast<size_t>(split) * M + m) * N + n) = acc[a][b];
         }
       }
     }
@@ -499,13 +507,17 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
 
 bool gemm_wide_supported(int N) { return N % wBN == 0; }
 
-int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out,
-                     int M, int N, int K, int epi, hipStream_t st) {
-  const size_t esz = dt == CMH_F32 ? 4 : 2;
-  if (static_cast<size_t>(M) * K * esz >= (1ull << 32) || static_cast<size_t>(wBN) * K * esz >= (1ull << 32))
-    return fail(CMH_ERR_INVALID, "gemm: operand of %zu bytes exceeds the 32-bit offset range of the wide kernel",
-                static_cast<size_t>(M) * K * esz);
-  const int total = (N / wBN) * ((M + wBM - 1) / wBM);
+// out[i] = sum_s partial[s * n + i]
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int S, size_t n, float* __restrict__ out) {
+  const size_t n4 = n / 4;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < n4; i += static_cast<size_t>(gridDim.x) * 256) {
+    w_f32x4_t a = *reinterpret_cast<const w_f32x4_t*>(partial + i * 4);
+    for (int s = 1; s < S; ++s) a += *reinterpret_cast<const w_f32x4_t*>(partial + static_cast<size_t>(s) * n + i * 4);
+    *reinterpret_cast<w_f32x4_t*>(out + i * 4) = a;
+  }
+}
+
+static int wide_cus() {
   static int cus = 0;
   if (!cus) {
     int dev = 0;
@@ -514,10 +526,51 @@ int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, co
     if (cus < 8) cus = 256;
     cus &= ~7;   // whole groups of 8: blockIdx % 8 names the XCD share
   }
+  return cus;
+}
+
+// Split-K plan for out[M,N] f32 = A.W^T with few tiles and a long K (the wgrad GEMMs): the largest S that divides the K-steps
+// and keeps tiles * S within one round of workgroups.  Returns 1 when splitting does not pay.
+int gemm_wide_splitk_plan(int dt, int M, int N, int K) {
+  if (N % wBN != 0) return 1;
+  const int nk = K / (dt == CMH_F32 ? 32 : 64);
+  const int tiles = (N / wBN) * ((M + wBM - 1) / wBM);
+  int best = 1;
+  for (int s = 2; s <= 64 && tiles * s <= wide_cus(); ++s)
+    if (nk % s == 0 && nk / s >= 8) best = s;
+  return best;
+}
+
+// partial planes [S, M, N] f32 in `partials` (S*M*N*4 bytes), reduced into out
+int launch_gemm_wide_splitk(int dt, const void* A, const void* W, float* out, float* partials, int S, int M, int N, int K,
+                            hipStream_t st) {
+  const int total = (N / wBN) * ((M + wBM - 1) / wBM) * S;
+  const int cus = wide_cus();
+  const int grid = total < cus ? ((total + 7) & ~7) : cus;
+  if (dt == CMH_F32)
+    hipLaunchKernelGGL((gemm_wide_kernel<true, false>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),
+                       static_cast<const char*>(W), nullptr, nullptr, partials, M, N, K, 0, S);
+  else
+    hipLaunchKernelGGL((gemm_wide_kernel<false, false>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),
+                       static_cast<const char*>(W), nullptr, nullptr, partials, M, N, K, 0, S);
+  const size_t n = static_cast<size_t>(M) * N;
+  const size_t blocks = (n / 4 + 255) / 256;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, partials, S, n, out);
+  return 0;
+}
+
+int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out,
+                     int M, int N, int K, int epi, hipStream_t st) {
+  const size_t esz = dt == CMH_F32 ? 4 : 2;
+  if (static_cast<size_t>(M) * K * esz >= (1ull << 32) || static_cast<size_t>(wBN) * K * esz >= (1ull << 32))
+    return fail(CMH_ERR_INVALID, "gemm: operand of %zu bytes exceeds the 32-bit offset range of the wide kernel",
+                static_cast<size_t>(M) * K * esz);
+  const int total = (N / wBN) * ((M + wBM - 1) / wBM);
+  const int cus = wide_cus();
   int grid = total < cus ? ((total + 7) & ~7) : cus;
 #define W_LAUNCH(F32, OUTBF)                                                                                   \
   hipLaunchKernelGGL((gemm_wide_kernel<F32, OUTBF>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A), \
-                     static_cast<const char*>(W), bias, residual, out, M, N, K, epi)
+                     static_cast<const char*>(W), bias, residual, out, M, N, K, epi, 1)
   const bool obf = epi & (EPI_OUT_BF16 | EPI_OUT_F16);   // 16-bit outputs share the packed store path
   if (dt == CMH_F32) { if (obf) W_LAUNCH(true, true); else W_LAUNCH(true, false); }
   else { if (obf) W_LAUNCH(false, true); else W_LAUNCH(false, false); }

@@ -394,6 +394,12 @@ typedef struct cmh_text_grads {
   float* text_projection;       /* [width, embed_dim] */
   const cmh_block_grads* blocks;
 } cmh_text_grads;
+/* Weight / bias gradient of y = x W^T + b: dw[O,I] f32 = dy^T x, db[O] f32 = column sums of dy (db may be NULL).  dy [M,O]
+ * and x [M,I] are given in CMH_KIND_* element types and are transposed + cast to `dtype` (the GEMM arithmetic) internally;
+ * the product runs on the encoder's GEMM kernel, split over K = M when the output has few tiles. */
+size_t cmh_linear_wgrad_workspace_bytes(int32_t dtype, int32_t M, int32_t O, int32_t I);
+int cmh_linear_wgrad(int32_t dtype, const void* dy, int32_t dy_kind, const void* x, int32_t x_kind, int32_t M, int32_t O,
+                     int32_t I, float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream);
 /* Backward of cmh_linear_act (LinearHash, model/modelbase.py:25-35): y = the forward output, dy its gradient, drop_mask /
  * keep_scale / act as in the forward call -> dx [M,K], dw [N,K], db [N].  workspace >= M*N*4 + 256 bytes. */
 int cmh_linear_act_backward(const float* x, const float* w, const float* y, const float* dy, const float* drop_mask,

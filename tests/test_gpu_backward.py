@@ -227,3 +227,24 @@ def test_hyp_loss_gradients_match_reference_goldens(golden, B, K, C, alpha, p):
     assert abs(float(loss.detach()) - float(g[f"{tag}_loss"])) < 1e-4
     for a, name in ((x.grad, "gx"), (y.grad, "gy"), (prox.grad, "gprox")):
         np.testing.assert_allclose(a.cpu().numpy(), g[f"{tag}_{name}"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("M,O,I", [(15, 128, 128), (1000, 256, 128), (4096, 768, 768), (12800, 3072, 768), (19712, 512, 2048)])
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_linear_wgrad(M, O, I, mode):
+    """dW = dY^T X, db = sum dY: padded K (M not a multiple of 64), plain and split-K launches."""
+    import backward_ops as B
+    g = torch.Generator().manual_seed(M + O + I)
+    dy = torch.randn(M, O, generator=g)
+    x = torch.randn(M, I, generator=g)
+    if mode == "bf16":
+        dyd, xd = dy.to(DEV), x.bfloat16().to(DEV)             # f32 gradient stream x bf16 activation, as the towers call it
+        ref_w = dy.bfloat16().double().t() @ x.bfloat16().double()
+        tol = dict(rtol=2e-2, atol=2e-2 * M ** 0.5)
+    else:
+        dyd, xd = dy.to(DEV), x.to(DEV)
+        ref_w = dy.double().t() @ x.double()
+        tol = dict(rtol=1e-4, atol=1e-4 * M ** 0.5)
+    dw, db = B.linear_wgrad(dyd, xd, mode)
+    torch.testing.assert_close(dw.cpu().double(), ref_w, **tol)
+    torch.testing.assert_close(db.cpu().double(), dy.double().sum(0), rtol=1e-5, atol=1e-4 * M ** 0.5)
