@@ -30,6 +30,29 @@ __global__ __launch_bounds__(256) void transpose_kernel(const void* __restrict__
   }
 }
 
+// fast path (R, C, dst_ld multiples of 4): 8/16-byte reads along c and writes along r
+__global__ __launch_bounds__(256) void transpose4_kernel(const void* __restrict__ src, void* __restrict__ dst, int R, int C,
+                                                         int dst_ld, int skind, int dkind) {
+  __shared__ float tile[64][65];
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+  const int q = threadIdx.x & 15, p = threadIdx.x >> 4;      // 16 quads per 64-wide row, 16 rows per pass
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int i = pass * 16 + p, r = r0 + i, c = c0 + q * 4;
+    float4 v = float4{0.f, 0.f, 0.f, 0.f};
+    if (r < R && c < C) v = load4_as_f32(src, static_cast<size_t>(r) * C + c, skind);
+    tile[i][q * 4 + 0] = v.x; tile[i][q * 4 + 1] = v.y; tile[i][q * 4 + 2] = v.z; tile[i][q * 4 + 3] = v.w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int i = pass * 16 + p, c = c0 + i, r = r0 + q * 4;
+    if (c < C && r < R)
+      store4_from_f32(dst, static_cast<size_t>(c) * dst_ld + r, dkind,
+                      float4{tile[q * 4 + 0][i], tile[q * 4 + 1][i], tile[q * 4 + 2][i], tile[q * 4 + 3][i]});
+  }
+}
+
 // ---- column sums: partial[b, c] = sum over the block's rows; then a second pass over the partials ------------------------
 constexpr int kColRows = 128;   // rows per workgroup
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const void* __restrict__ x, int kind, int R, int C,
@@ -42,6 +65,30 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const void* __restr
   for (int r = r0; r < r1; ++r) s += load_as_f32(x, static_cast<size_t>(r) * C + c, kind);
   partial[static_cast<size_t>(blockIdx.y) * C + c] = s;
 }
+// fast path (C % 4 == 0): 64 column quads x 4 row lanes per workgroup
+__global__ __launch_bounds__(256) void colsum_partial4_kernel(const void* __restrict__ x, int kind, int R, int C,
+                                                              float* __restrict__ partial) {
+  __shared__ float4 red[4][64];
+  const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + cg * 4;
+  const int r0 = blockIdx.y * kColRows;
+  const int r1 = r0 + kColRows < R ? r0 + kColRows : R;
+  float4 s = float4{0.f, 0.f, 0.f, 0.f};
+  if (c < C)
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const float4 v = load4_as_f32(x, static_cast<size_t>(r) * C + c, kind);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  red[rl][cg] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    float4 t = red[0][cg];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) { t.x += red[k][cg].x; t.y += red[k][cg].y; t.z += red[k][cg].z; t.w += red[k][cg].w; }
+    *reinterpret_cast<float4*>(partial + static_cast<size_t>(blockIdx.y) * C + c) = t;
+  }
+}
+
 // 32 columns x 8 row-slices per workgroup: slice s adds partial rows s, s+8, ... in f64 (a serial walk over several hundred
 // partial rows per column measured 79 us); fixed order -> deterministic.
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nb, int C,
@@ -93,15 +140,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
     float xv[4][4], dv[4][4];
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int e = lane * 4 + 256 * j + k;
-        const bool ok = j < nv && e < d;
-        xv[j][k] = ok ? load_as_f32(x, xrow * d + e, xkind) : 0.f;
-        dv[j][k] = ok ? load_as_f32(dy, static_cast<size_t>(row) * d + e, dykind) : 0.f;
-        s += xv[j][k];
-      }
+    for (int j = 0; j < 4; ++j) {
+      const int e0 = lane * 4 + 256 * j;
+      const bool ok = j < nv && e0 < d;
+      const float4 xa = ok ? load4_as_f32(x, xrow * d + e0, xkind) : float4{0.f, 0.f, 0.f, 0.f};
+      const float4 da = ok ? load4_as_f32(dy, static_cast<size_t>(row) * d + e0, dykind) : float4{0.f, 0.f, 0.f, 0.f};
+      xv[j][0] = xa.x; xv[j][1] = xa.y; xv[j][2] = xa.z; xv[j][3] = xa.w;
+      dv[j][0] = da.x; dv[j][1] = da.y; dv[j][2] = da.z; dv[j][3] = da.w;
+      s += (xa.x + xa.y) + (xa.z + xa.w);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     const float mean = s / static_cast<float>(d);
@@ -136,16 +183,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
     for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); sax += __shfl_xor(sax, o, 64); }
     const float ma = sa / static_cast<float>(d), max_ = sax / static_cast<float>(d);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int e = lane * 4 + 256 * j + k;
-        if (j < nv && e < d) {
-          const float v = rstd * (dv[j][k] - ma - xv[j][k] * max_);
-          float* o = dx + xrow * d + e;
-          *o = accumulate ? *o + v : v;
-        }
+    for (int j = 0; j < 4; ++j) {
+      const int e0 = lane * 4 + 256 * j;
+      if (j < nv && e0 < d) {
+        float4* o = reinterpret_cast<float4*>(dx + xrow * d + e0);
+        float4 v = float4{rstd * (dv[j][0] - ma - xv[j][0] * max_), rstd * (dv[j][1] - ma - xv[j][1] * max_),
+                          rstd * (dv[j][2] - ma - xv[j][2] * max_), rstd * (dv[j][3] - ma - xv[j][3] * max_)};
+        if (accumulate) { const float4 c = *o; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
+        *o = v;
       }
+    }
   }
   // combine the 4 waves' dg / db columns, one partial row per workgroup
 #pragma unroll
@@ -165,7 +212,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
 // ---- QuickGELU forward from the saved pre-activation -----------------------------------------------------------------------
 __global__ __launch_bounds__(256) void quick_gelu_kernel(const void* __restrict__ pre, void* __restrict__ out, int64_t n, int kind) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+  const bool vec = (reinterpret_cast<uintptr_t>(pre) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+  const int64_t n4 = vec ? n / 4 : 0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 v = load4_as_f32(pre, static_cast<size_t>(i) * 4, kind);
+    v.x *= __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v.x)); v.y *= __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v.y));
+    v.z *= __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v.z)); v.w *= __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v.w));
+    store4_from_f32(out, static_cast<size_t>(i) * 4, kind, v);
+  }
+  for (int64_t i = n4 * 4 + static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
     const float v = load_as_f32(pre, i, kind);
     store_from_f32(out, i, kind, v / (1.0f + __expf(-1.702f * v)));
   }
@@ -181,8 +236,14 @@ namespace cmh {
 int launch_transpose(const void* src, int skind, void* dst, int dkind, int rows, int cols, int dst_ld, hipStream_t st) {
   CMH_CHECK_ARG(src && dst && rows > 0 && cols > 0 && dst_ld >= rows, "transpose: bad arguments");
   CMH_CHECK_ARG(kind_ok(skind) && kind_ok(dkind), "transpose: bad element kind %d / %d", skind, dkind);
-  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, st, src, dst, rows, cols, dst_ld,
-                     skind, dkind);
+  const bool vec = rows % 4 == 0 && cols % 4 == 0 && dst_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL(transpose4_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, st, src, dst, rows, cols, dst_ld,
+                       skind, dkind);
+  else
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, st, src, dst, rows, cols, dst_ld,
+                       skind, dkind);
   CMH_CHECK_LAUNCH("transpose");
   return CMH_OK;
 }
@@ -205,7 +266,10 @@ extern "C" int cmh_colsum(const void* x, int32_t kind, int32_t rows, int32_t col
   float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
   const int nb = (rows + kColRows - 1) / kColRows;
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 255) / 256, nb), dim3(256), 0, st, x, kind, rows, cols, partial);
+  if (cols % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+    hipLaunchKernelGGL(colsum_partial4_kernel, dim3((cols + 255) / 256, nb), dim3(256), 0, st, x, kind, rows, cols, partial);
+  else
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 255) / 256, nb), dim3(256), 0, st, x, kind, rows, cols, partial);
   CMH_CHECK_LAUNCH("colsum_partial");
   hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, partial, nb, cols, out);
   CMH_CHECK_LAUNCH("colsum_final");
@@ -248,7 +312,7 @@ extern "C" int cmh_layernorm_backward(const void* x, int32_t x_kind, const void*
 
 extern "C" int cmh_quick_gelu(const void* pre, void* out, int64_t n, int32_t kind, void* stream) {
   CMH_CHECK_ARG(pre && out && n > 0 && kind_ok(kind), "quick_gelu: bad arguments");
-  const int64_t blocks = (n + 255) / 256;
+  const int64_t blocks = (n / 4 + 255) / 256 + 1;
   hipLaunchKernelGGL(quick_gelu_kernel, dim3(static_cast<unsigned>(blocks < 8192 ? blocks : 8192)), dim3(256), 0, as_stream(stream),
                      pre, out, n, kind);
   CMH_CHECK_LAUNCH("quick_gelu");

@@ -83,6 +83,19 @@ __device__ __forceinline__ void store_from_f32(void* p, size_t i, int kind, floa
   else static_cast<uint16_t*>(p)[i] = __builtin_bit_cast(uint16_t, static_cast<_Float16>(v));
 }
 
+// 4 consecutive elements (i % 4 == 0, 8/16-byte aligned)
+__device__ __forceinline__ float4 load4_as_f32(const void* p, size_t i, int kind) {
+  if (kind == kF32) return *reinterpret_cast<const float4*>(static_cast<const float*>(p) + i);
+  const uint2 u = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(p) + i);
+  if (kind == kBF16) return float4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                                   __uint_as_float(u.y & 0xffff0000u)};
+  return float4{f16lo_to_f32(u.x), f16hi_to_f32(u.x), f16lo_to_f32(u.y), f16hi_to_f32(u.y)};
+}
+__device__ __forceinline__ void store4_from_f32(void* p, size_t i, int kind, float4 v) {
+  if (kind == kF32) *reinterpret_cast<float4*>(static_cast<float*>(p) + i) = v;
+  else if (kind == kBF16) *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p) + i) = uint2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+  else *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p) + i) = uint2{pack_f16x2(v.x, v.y), pack_f16x2(v.z, v.w)};
+}
 
 // ---- epilogue flags of the GEMM ---------------------------------------------------------------
 enum : int {
