@@ -6,6 +6,8 @@
 // First version: fp32 VALU, one 256-thread workgroup per (batch, head), T <= 128, everything staged in LDS
 // (two [T][65] operand buffers + one [T][T+1] score buffer, <= 132 KB).  Inputs f32 or bf16, accumulation f32, outputs in the
 // input type.  An MFMA version for the bf16 mode is the next step (this one costs ~0.2-0.3 ms per layer at batch 256).
+#include <cstdlib>
+
 #include "cmh_common.h"
 
 namespace cmh {
@@ -127,6 +129,200 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const T* __restrict_
 
 }  // namespace cmh
 
+// ============================================================================================================================
+// bf16 MFMA version (T <= 128): one 256-thread workgroup per (batch, head), every operand a plain row-major [rows][k] bf16 matrix
+// in LDS so that each of the five products is  out[i][j] = sum_k A[i][k] B[j][k]  on v_mfma_f32_16x16x32_bf16:
+//   S  [q][key] = Q . K^T          (A = Q,    B = K,    k = head dim)      dP [q][key] = dO . V^T     (A = dO,   B = V)
+//   dV^T[hd][key] = dO^T . P^T^T   (A = dO^T, B = P^T,  k = queries)       dK^T[hd][key] = Q^T . dS^T^T (A = Q^T, B = dS^T)
+//   dQ^T[hd][q]   = K^T . dS^T     (A = K^T,  B = dS,   k = keys)
+// Q, K, dO are staged twice (row-major and transposed), V once; a wave owns query tiles: it keeps the S and dP accumulators of
+// its 16 queries against all keys in registers, does the row softmax, D_q = sum_key P dP and dS = P (dP - D) / 8 there
+// (reductions across the 16 lanes of a row), and writes P^T, dS, dS^T (bf16) back to LDS for the second phase.
+// The three output products write 4 consecutive head-dim values per lane (8-byte stores), like the forward kernel.
+namespace cmh {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 ab_bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float ab_f32x4_t;
+
+__device__ __forceinline__ ab_f32x4_t ab_mma(const bf16_t* A, int lda, int arow0, const bf16_t* Bm, int ldb, int brow0, int ksteps,
+                                             int g, int c) {
+  ab_f32x4_t acc = ab_f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int ks = 0; ks < ksteps; ++ks) {
+    const ab_bf16x8_t a = *reinterpret_cast<const ab_bf16x8_t*>(A + static_cast<size_t>(arow0 + c) * lda + ks * 32 + g * 8);
+    const ab_bf16x8_t b = *reinterpret_cast<const ab_bf16x8_t*>(Bm + static_cast<size_t>(brow0 + c) * ldb + ks * 32 + g * 8);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+__device__ __forceinline__ float ab_row_max(float v) {      // over the 16 lanes c of a lane group g
+  v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64));
+  v = fmaxf(v, __shfl_xor(v, 4, 64)); v = fmaxf(v, __shfl_xor(v, 8, 64));
+  return v;
+}
+__device__ __forceinline__ float ab_row_sum(float v) {
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+template <int NT>    // row tiles: TR = 16 * NT rows, contraction over rows padded to KP = 32 * ceil(NT / 2)
+__global__ __launch_bounds__(256) void attention_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                                 bf16_t* __restrict__ dqkv, int B, int Tn, int d, int causal,
+                                                                 const uint8_t* __restrict__ kpm) {
+  constexpr int TR = NT * 16, KP = ((NT + 1) / 2) * 32;
+  constexpr int LR = 72;            // leading dimension of the [rows][64] matrices (144 B rows)
+  constexpr int LT = KP + 8;        // leading dimension of the [..][KP] matrices
+  extern __shared__ __attribute__((aligned(16))) bf16_t sm[];
+  bf16_t* sQ = sm;                   // [TR][LR]
+  bf16_t* sK = sQ + TR * LR;
+  bf16_t* sV = sK + TR * LR;
+  bf16_t* sDO = sV + TR * LR;
+  bf16_t* sQT = sDO + TR * LR;       // [64][LT]   Q^T
+  bf16_t* sKT = sQT + 64 * LT;
+  bf16_t* sDOT = sKT + 64 * LT;
+  bf16_t* sPT = sDOT + 64 * LT;      // [TR][LT]   P^T  [key][q]
+  bf16_t* sDS = sPT + TR * LT;       // [TR][LT]   dS   [q][key]
+  bf16_t* sDST = sDS + TR * LT;      // [TR][LT]   dS^T [key][q]
+  constexpr int kTotal = 4 * TR * LR + 3 * 64 * LT + 3 * TR * LT;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, c = lane & 15;
+  const int heads = d / HDB;
+  const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+  const size_t ld = static_cast<size_t>(3) * d;
+  const size_t row0 = static_cast<size_t>(b) * Tn;
+  const bf16_t* qb = qkv + row0 * ld + h * HDB;
+  const bf16_t* dob = dout + row0 * d + h * HDB;
+  bf16_t* dqb = dqkv + row0 * ld + h * HDB;
+
+  // ---- stage: zero everything (padding rows / columns must be exact zeros), then the real rows ------------------------
+  for (int i = tid; i < kTotal / 2; i += 256) reinterpret_cast<uint32_t*>(sm)[i] = 0u;
+  __syncthreads();
+  for (int slot = tid; slot < Tn * 8; slot += 256) {
+    const int r = slot >> 3, ch = slot & 7;
+    const uint4 q = *reinterpret_cast<const uint4*>(qb + static_cast<size_t>(r) * ld + ch * 8);
+    const uint4 k = *reinterpret_cast<const uint4*>(qb + d + static_cast<size_t>(r) * ld + ch * 8);
+    const uint4 v = *reinterpret_cast<const uint4*>(qb + 2 * d + static_cast<size_t>(r) * ld + ch * 8);
+    const uint4 o = *reinterpret_cast<const uint4*>(dob + static_cast<size_t>(r) * d + ch * 8);
+    *reinterpret_cast<uint4*>(sQ + r * LR + ch * 8) = q;
+    *reinterpret_cast<uint4*>(sK + r * LR + ch * 8) = k;
+    *reinterpret_cast<uint4*>(sV + r * LR + ch * 8) = v;
+    *reinterpret_cast<uint4*>(sDO + r * LR + ch * 8) = o;
+    const uint32_t qw[4] = {q.x, q.y, q.z, q.w}, kw[4] = {k.x, k.y, k.z, k.w}, ow[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int hd = ch * 8 + e, sh = (e & 1) * 16;
+      sQT[hd * LT + r] = static_cast<bf16_t>(qw[e >> 1] >> sh);
+      sKT[hd * LT + r] = static_cast<bf16_t>(kw[e >> 1] >> sh);
+      sDOT[hd * LT + r] = static_cast<bf16_t>(ow[e >> 1] >> sh);
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 1: per query tile: S, dP, softmax, D, dS -> P^T, dS, dS^T ------------------------------------------------------
+  const int nrt = (Tn + 15) >> 4;        // row tiles that hold real rows
+  for (int ti = wid; ti < nrt; ti += 4) {
+    ab_f32x4_t s[NT], dp[NT];
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj) {
+      if (tj < nrt) {
+        s[tj] = ab_mma(sQ, LR, ti * 16, sK, LR, tj * 16, 2, g, c);       // [q = 16ti + 4g + r][key = 16tj + c]
+        dp[tj] = ab_mma(sDO, LR, ti * 16, sV, LR, tj * 16, 2, g, c);
+      } else {
+        s[tj] = ab_f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[tj] = s[tj];
+      }
+    }
+    float m[4] = {-1e30f, -1e30f, -1e30f, -1e30f};
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj) {
+      const int key = tj * 16 + c;
+      bool kok = key < Tn;
+      if (kok && kpm) kok = kpm[static_cast<size_t>(b) * Tn + key] == 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = ti * 16 + 4 * g + r;
+        const bool ok = kok && !(causal && key > q);
+        s[tj][r] = ok ? s[tj][r] * 0.125f : -1e30f;
+        m[r] = fmaxf(m[r], s[tj][r]);
+      }
+    }
+    float l[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m[r] = ab_row_max(m[r]);
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = s[tj][r] > -1e29f ? __expf(s[tj][r] - m[r]) : 0.f;
+        s[tj][r] = p;
+        l[r] += p;
+      }
+    float dsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) l[r] = 1.0f / ab_row_sum(l[r]);
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s[tj][r] *= l[r]; dsum[r] += s[tj][r] * dp[tj][r]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dsum[r] = ab_row_sum(dsum[r]);
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj) {
+      if (tj >= nrt) break;
+      const int key = tj * 16 + c, q0 = ti * 16 + 4 * g;
+      float dsv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dsv[r] = s[tj][r] * (dp[tj][r] - dsum[r]) * 0.125f;
+      *reinterpret_cast<uint2*>(sPT + key * LT + q0) = uint2{pack_bf16x2(s[tj][0], s[tj][1]), pack_bf16x2(s[tj][2], s[tj][3])};
+      *reinterpret_cast<uint2*>(sDST + key * LT + q0) = uint2{pack_bf16x2(dsv[0], dsv[1]), pack_bf16x2(dsv[2], dsv[3])};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sDS[(q0 + r) * LT + key] = f32_to_bf16(dsv[r]);
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: dV, dK (contraction over queries), dQ (over keys); out[hd = 16th + 4g + r][row = 16tr + c] --------------------
+  constexpr int KS = KP / 32;
+  for (int job = wid; job < 3 * nrt * 4; job += 4) {
+    const int prod = job / (nrt * 4), rem = job - prod * nrt * 4, tr = rem >> 2, th = rem & 3;
+    const bf16_t* A = prod == 0 ? sDOT : (prod == 1 ? sQT : sKT);
+    const bf16_t* Bm = prod == 0 ? sPT : (prod == 1 ? sDST : sDS);
+    const ab_f32x4_t acc = ab_mma(A, LT, th * 16, Bm, LT, tr * 16, KS, g, c);
+    const int row = tr * 16 + c;
+    if (row < Tn) {
+      bf16_t* op = dqb + (prod == 0 ? 2 * d : (prod == 1 ? d : 0)) + static_cast<size_t>(row) * ld + th * 16 + 4 * g;
+      *reinterpret_cast<uint2*>(op) = uint2{pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3])};
+    }
+  }
+}
+
+template <int NT>
+static int launch_attention_bwd_mfma(const void* qkv, const void* dout, void* dqkv, int B, int T, int d, int causal,
+                                     const uint8_t* kpm, hipStream_t st) {
+  constexpr int TR = NT * 16, KP = ((NT + 1) / 2) * 32;
+  const size_t lds = (static_cast<size_t>(4) * TR * 72 + 3 * 64 * (KP + 8) + 3 * TR * (KP + 8)) * 2;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_mfma_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          static_cast<int>(lds)) != hipSuccess) return fail(CMH_ERR_LAUNCH, "attention_backward: cannot reserve %zu bytes of LDS", lds);
+  hipLaunchKernelGGL(attention_bwd_mfma_kernel<NT>, dim3(B * (d / HDB)), dim3(256), lds, st, static_cast<const bf16_t*>(qkv),
+                     static_cast<const bf16_t*>(dout), static_cast<bf16_t*>(dqkv), B, T, d, causal, kpm);
+  return CMH_OK;
+}
+
+int launch_attention_bwd_bf16(const void* qkv, const void* dout, void* dqkv, int B, int T, int d, int causal, const uint8_t* kpm,
+                              hipStream_t st) {
+  const int nt = (T + 15) / 16;
+  switch (nt) {
+    case 1: return launch_attention_bwd_mfma<1>(qkv, dout, dqkv, B, T, d, causal, kpm, st);
+    case 2: return launch_attention_bwd_mfma<2>(qkv, dout, dqkv, B, T, d, causal, kpm, st);
+    case 3: return launch_attention_bwd_mfma<3>(qkv, dout, dqkv, B, T, d, causal, kpm, st);
+    case 4: return launch_attention_bwd_mfma<4>(qkv, dout, dqkv, B, T, d, causal, kpm, st);
+    case 5: return launch_attention_bwd_mfma<5>(qkv, dout, dqkv, B, T, d, causal, kpm, st);
+    case 6: return launch_attention_bwd_mfma<6>(qkv, dout, dqkv, B, T, d, causal, kpm, st);
+    default: return 1;       // T > 96: the LDS image (208 / 230 KB) does not fit -> caller uses the fp32 VALU kernel
+  }
+}
+
+}  // namespace cmh
+
 using namespace cmh;
 
 extern "C" int cmh_attention_backward(int32_t dtype, const void* qkv, const void* o, const void* dout, void* dqkv, int32_t B,
@@ -144,6 +340,9 @@ extern "C" int cmh_attention_backward(int32_t dtype, const void* qkv, const void
     hipLaunchKernelGGL(attention_bwd_kernel<float>, grid, dim3(256), lds, st, static_cast<const float*>(qkv),
                        static_cast<const float*>(o), static_cast<const float*>(dout), static_cast<float*>(dqkv), B, T, d, causal,
                        key_padding_mask);
+  } else if (T <= 96 && !getenv("CMH_ATTN_BWD_VALU")) {
+    const int rc = launch_attention_bwd_bf16(qkv, dout, dqkv, B, T, d, causal, key_padding_mask, st);
+    if (rc) return rc;
   } else {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             static_cast<int>(lds)) != hipSuccess) return fail(CMH_ERR_LAUNCH, "attention_backward: LDS");
@@ -154,3 +353,4 @@ extern "C" int cmh_attention_backward(int32_t dtype, const void* qkv, const void
   CMH_CHECK_LAUNCH("attention_backward");
   return CMH_OK;
 }
+
