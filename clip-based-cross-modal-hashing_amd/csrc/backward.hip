@@ -92,8 +92,10 @@ __global__ __launch_bounds__(256) void colsum_partial4_kernel(const void* __rest
 // 32 columns x 8 row-slices per workgroup: slice s adds partial rows s, s+8, ... in f64 (a serial walk over several hundred
 // partial rows per column measured 79 us); fixed order -> deterministic.
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nb, int C,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, const float* __restrict__ partial2 = nullptr,
+                                                           float* __restrict__ out2 = nullptr) {
   __shared__ double red[8][33];
+  if (blockIdx.y == 1) { partial = partial2; out = out2; }      // second (partial, out) pair in the same launch
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   double s = 0.0;
@@ -271,7 +273,7 @@ extern "C" int cmh_colsum(const void* x, int32_t kind, int32_t rows, int32_t col
   else
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 255) / 256, nb), dim3(256), 0, st, x, kind, rows, cols, partial);
   CMH_CHECK_LAUNCH("colsum_partial");
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, partial, nb, cols, out);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, partial, nb, cols, out, nullptr, nullptr);
   CMH_CHECK_LAUNCH("colsum_final");
   return CMH_OK;
 }
@@ -295,10 +297,8 @@ int launch_layernorm_backward(const void* x, int x_kind, const void* dy, int dy_
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, st, x, x_kind, dy, dy_kind, gamma, dx, accumulate, M, d, pg, pb,
                      row_index);
   CMH_CHECK_LAUNCH("layernorm_backward");
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 31) / 32), dim3(256), 0, st, pg, nb, d, dgamma);
-  CMH_CHECK_LAUNCH("layernorm_backward dgamma");
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 31) / 32), dim3(256), 0, st, pb, nb, d, dbeta);
-  CMH_CHECK_LAUNCH("layernorm_backward dbeta");
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 31) / 32, 2), dim3(256), 0, st, pg, nb, d, dgamma, pb, dbeta);
+  CMH_CHECK_LAUNCH("layernorm_backward dgamma/dbeta");
   return CMH_OK;
 }
 }  // namespace cmh

@@ -229,15 +229,23 @@ int check_block_grads(const cmh_block_grads* g, int layers) {
 }
 
 // ---- pooled rows: feat = LN(x_last[rows]) . proj ------------------------------------------------------------------------------
-// dpool[b, i] = sum_j dfeat[b, j] * proj_t[j, i]
+// dpool[b, i] = sum_j dfeat[b, j] * proj_t[j, i]   (dfeat row in LDS, 8 independent partial sums per thread)
 template <typename T>
 __global__ __launch_bounds__(256) void pool_dgrad_kernel(const float* __restrict__ dfeat, const T* __restrict__ proj_t,
                                                          float* __restrict__ dpool, int B, int d, int E) {
+  __shared__ float row[2048];
   const int b = blockIdx.x;
+  constexpr int kind = sizeof(T) == 4 ? kF32 : kBF16;
+  for (int j = threadIdx.x; j < E; j += 256) row[j] = dfeat[static_cast<size_t>(b) * E + j];
+  __syncthreads();
   for (int i = threadIdx.x; i < d; i += 256) {
-    float acc = 0.f;
-    for (int j = 0; j < E; ++j) acc += dfeat[static_cast<size_t>(b) * E + j] * load_as_f32(proj_t, static_cast<size_t>(j) * d + i, sizeof(T) == 4 ? kF32 : kBF16);
-    dpool[static_cast<size_t>(b) * d + i] = acc;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int j = 0;
+    for (; j + 8 <= E; j += 8)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] = fmaf(row[j + u], load_as_f32(proj_t, static_cast<size_t>(j + u) * d + i, kind), acc[u]);
+    for (; j < E; ++j) acc[0] = fmaf(row[j], load_as_f32(proj_t, static_cast<size_t>(j) * d + i, kind), acc[0]);
+    dpool[static_cast<size_t>(b) * d + i] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   }
 }
 // dproj[i, j] = sum_b pool[b, i] * dfeat[b, j]      (the reference's [width, embed_dim] parameter layout)

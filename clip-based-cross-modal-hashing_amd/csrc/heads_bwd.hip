@@ -65,32 +65,38 @@ __global__ __launch_bounds__(256) void hyp_normalize_kernel(const float* __restr
   if (lane == 0) nrm[row] = n;
 }
 
-// cnt[0] = #(label != 0) (P_num), cnt[1] = #(label == 0) (N_num), cnt[2] = #pairs (i,j) of multi-label rows with label_i . label_j == 0;
-// multi[b] = label[b].sum() > 1.  One workgroup.
+// cnt[0] = #(label != 0) (P_num), cnt[1] = #(label == 0) (N_num); multi[b] = label[b].sum() > 1.  One workgroup.
 __global__ __launch_bounds__(256) void hyp_counts_kernel(const float* __restrict__ label, int B, int C, int* __restrict__ multi,
                                                          float* __restrict__ cnt) {
-  __shared__ float sh[3][4];
+  __shared__ float sh[2][4];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  float p = 0.f, n = 0.f, z = 0.f;
+  float p = 0.f, n = 0.f;
   for (int i = threadIdx.x; i < B * C; i += 256) { if (label[i] != 0.f) p += 1.f; else n += 1.f; }
   for (int b = threadIdx.x; b < B; b += 256) {
     float s = 0.f;
     for (int c = 0; c < C; ++c) s += label[static_cast<size_t>(b) * C + c];
     multi[b] = s > 1.f;
   }
+  p = wsum(p); n = wsum(n);
+  if (lane == 0) { sh[0][wid] = p; sh[1][wid] = n; }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < B * B; idx += 256) {
-    const int i = idx / B, j = idx - i * B;
-    if (multi[i] && multi[j]) {
-      float ll = 0.f;
-      for (int c = 0; c < C; ++c) ll = fmaf(label[static_cast<size_t>(i) * C + c], label[static_cast<size_t>(j) * C + c], ll);
-      if (ll == 0.f) z += 1.f;
-    }
+  if (threadIdx.x < 2) cnt[threadIdx.x] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+  if (threadIdx.x == 2) cnt[2] = 0.f;
+}
+// cnt[2] += #{j : multi[i] && multi[j] && label_i . label_j == 0}   (integers below 2^24: the float atomics are exact)
+__global__ __launch_bounds__(64) void hyp_pairs_kernel(const float* __restrict__ label, const int* __restrict__ multi, int B, int C,
+                                                       float* __restrict__ cnt) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  if (!multi[i]) return;
+  float z = 0.f;
+  for (int j = lane; j < B; j += 64) {
+    if (!multi[j]) continue;
+    float ll = 0.f;
+    for (int c = 0; c < C; ++c) ll = fmaf(label[static_cast<size_t>(i) * C + c], label[static_cast<size_t>(j) * C + c], ll);
+    if (ll == 0.f) z += 1.f;
   }
-  p = wsum(p); n = wsum(n); z = wsum(z);
-  if (lane == 0) { sh[0][wid] = p; sh[1][wid] = n; sh[2][wid] = z; }
-  __syncthreads();
-  if (threadIdx.x < 3) cnt[threadIdx.x] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+  z = wsum(z);
+  if (lane == 0 && z != 0.f) atomicAdd(cnt + 2, z);
 }
 
 // One wave per sample b: gradients w.r.t. the NORMALISED rows xn[b], yn[b], then through the normalisation.
@@ -258,6 +264,7 @@ extern "C" int cmh_dsph_hyp_loss_backward(const float* x, const float* y, const 
   hipLaunchKernelGGL(hyp_normalize_kernel, dim3((B + 3) / 4), dim3(256), 0, st, y, yn, ny, B, K);
   hipLaunchKernelGGL(hyp_normalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, proxies, pn, np_, C, K);
   hipLaunchKernelGGL(hyp_counts_kernel, dim3(1), dim3(256), 0, st, label, B, C, multi, cnt);
+  if (alpha > 0.f) hipLaunchKernelGGL(hyp_pairs_kernel, dim3(B), dim3(64), 0, st, label, multi, B, C, cnt);
   hipLaunchKernelGGL(hyp_rows_kernel, dim3(B), dim3(64), 0, st, xn, yn, pn, nx, ny, label, multi, cnt, B, K, C, threshold, alpha, dloss,
                      dx, dy);
   hipLaunchKernelGGL(hyp_proxy_kernel, dim3(C), dim3(64), 0, st, xn, yn, pn, np_, label, cnt, B, K, C, threshold, dloss, dproxies);
