@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-map-eval", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true")
     ap.add_argument("--no-overlap-towers", action="store_true", help="run the text tower after the image tower on one stream")
     ap.add_argument("--map-queries", type=int, default=5000)
     ap.add_argument("--map-db", type=int, default=15015)
@@ -247,6 +248,50 @@ def main():
                            "tie_order": "reference (libstdc++ introsort)", "mAP_i2t": round(float(maps[0]), 6),
                            "stable_tie_order": {"ms": round(ms_st, 3), "mAP_i2t": round(float(maps_st[0]), 6),
                                                 "note": "CMH_TIE_STABLE (ties by index): not the reference's ranking"}}
+
+    if not a.no_train_step:
+        try:
+            # secondary metric: the reference's actual inner loop (train/DSPH/hash_train.py:49-73) - tape-keeping forward of both
+            # towers, heads, HyP loss, backward through everything, fused BertAdam + SGD on the proxies; same batch, weights not frozen
+            from model.base.optimization import BertAdam
+            clip.assume_frozen = False
+            img_head.train(); txt_head.train()
+            params = [p for n, p in clip.named_parameters() if n != "logit_scale"]
+            opt = BertAdam([{"params": params, "lr": 1e-5}, {"params": list(img_head.parameters()) + list(txt_head.parameters())}],
+                           lr=1e-3, warmup=0.1, schedule="warmup_cosine", b1=0.9, b2=0.98, e=1e-6, t_total=1000, weight_decay=0.2,
+                           max_grad_norm=1.0)
+            sgd = torch.optim.SGD(hyp.parameters(), lr=0.02, momentum=0.9, weight_decay=0.0005)
+
+            def train_step():
+                fi, ft = overlapped(lambda: clip.encode_image(image), lambda: clip.encode_text(text))
+                hi, ht = img_head(fi), txt_head(ft)
+                if world > 1:
+                    fused, widths = du.fuse_columns(hi.detach(), ht.detach(), label)
+                    du.all_gather_rows(fused)            # the exchange step; gradients flow through the local rows only
+                loss = hyp(hi, ht, label)
+                opt.zero_grad(); sgd.zero_grad()
+                loss.backward()
+                if world > 1:                            # data-parallel gradient averaging in flat buckets (dist_utils.py)
+                    du.allreduce_mean_([p.grad for p in params + list(img_head.parameters()) + list(txt_head.parameters()) +
+                                        list(hyp.parameters()) if p.grad is not None])
+                opt.step(); sgd.step()
+                return loss
+            for _ in range(2):
+                train_step()
+            barrier()
+            t0 = time.perf_counter()
+            nts = 5
+            for _ in range(nts):
+                tl = train_step()
+            barrier()
+            tms = (time.perf_counter() - t0) / nts * 1e3
+            out["train_step"] = {"ms": round(tms, 3), "pairs_per_s": round(B * world / tms * 1e3, 1), "steps": nts,
+                                 "what": "DSPH step: forward with tape + HyP loss + backward (heads, both towers) + fused BertAdam",
+                                 "loss": round(float(tl.detach()), 5)}
+            clip.assume_frozen = True
+        except Exception as exc:      # the secondary metric must never take the headline line down
+            out["train_step"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            clip.assume_frozen = True
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cb = cpu_baseline(L, K)

@@ -97,3 +97,34 @@ def scatter_by_index(buffer: torch.Tensor, index: torch.Tensor, rows: torch.Tens
     """buffer[index] = rows for the gathered (index, rows) of all ranks — the reference's code buffers and the
     MITH memory bank are indexed by dataset position (train/base.py:145-146, train/MITH/hash_train.py:72-78)."""
     buffer[index.long()] = rows.to(buffer.dtype)
+
+
+def allreduce_mean_(tensors: list[torch.Tensor], bucket_bytes: int = 256 << 20) -> None:
+    """Data-parallel gradient synchronisation: average `tensors` over the ranks in place.  Gradients are
+    packed into flat buckets of ~bucket_bytes so that a step is a handful of large ring all-reduces (xGMI rings are per-link
+    bound: few big messages, not 302 small ones), one bucket in flight while the next is being packed."""
+    world = world_size()
+    if world == 1 or not tensors:
+        return
+    buckets, cur, cur_bytes = [], [], 0
+    for t in tensors:
+        nbytes = t.numel() * t.element_size()
+        if cur and cur_bytes + nbytes > bucket_bytes:
+            buckets.append(cur)
+            cur, cur_bytes = [], 0
+        cur.append(t)
+        cur_bytes += nbytes
+    if cur:
+        buckets.append(cur)
+    pending = []
+    for group in buckets:
+        flat = torch.cat([t.reshape(-1) for t in group])
+        pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, group))
+    for work, flat, group in pending:
+        work.wait()
+        flat.div_(world)
+        off = 0
+        for t in group:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n

@@ -1,11 +1,12 @@
 """DSPH trainer (reference train/DSPH/hash_train.py:16-73; paper: Deep Semantic-aware Proxy Hashing,
 TCSVT 2023).  Forward, loss and validation run on libcmh, and so does the optimiser (fused BertAdam, SURVEY §8f "next"
-#1); encoder backward is "next" #2, so train_epoch still stops loudly at `loss.backward()`."""
+#1) and the backward through heads and both towers (#2): train_epoch is a complete training loop."""
 import os
 import time
 
 import torch
 
+import dist_utils as du
 from model.DSPH import MDSPH
 from model.base.optimization import BertAdam
 from train.base import TrainBase
@@ -61,7 +62,10 @@ class DSPHTrainer(TrainBase):
             all_loss += loss
             self.optimizer.zero_grad()
             self.optimizer_loss.zero_grad()
-            loss.backward()      # raises NotImplementedError: backward kernels are the next scope row
+            loss.backward()
+            if du.world_size() > 1:   # one process per GPU: average the gradients over the ranks (flat buckets over RCCL)
+                du.allreduce_mean_([p.grad for p in list(self.model.parameters()) + list(self.hyp.parameters())
+                                    if p.grad is not None])
             self.optimizer.step()
             self.optimizer_loss.step()
             self.total_time += time.time() - start_time

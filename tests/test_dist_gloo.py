@@ -45,6 +45,11 @@ def _worker(rank, world, port, out_dir):
     # equal shards take the single-collective path
     eq = du.all_gather_rows(codes_i[rank * 10:(rank + 1) * 10])
     assert torch.equal(eq, codes_i[:20])
+    # gradient averaging in flat buckets (ragged tensor sizes, several buckets)
+    gs = [torch.full((5, 3), float(rank + 1)), torch.arange(7, dtype=torch.float32) * (rank + 1), torch.full((1,), 10.0 * rank)]
+    du.allreduce_mean_(gs, bucket_bytes=64)
+    assert torch.equal(gs[0], torch.full((5, 3), 1.5)) and torch.equal(gs[1], torch.arange(7, dtype=torch.float32) * 1.5)
+    assert torch.equal(gs[2], torch.full((1,), 5.0))
     # query-sharded AP, gathered in query order, summed like the reference
     ap = torch.rand(n, generator=g)
     full = du.gather_query_sharded_ap(ap[lo:hi], n)

@@ -248,3 +248,33 @@ def test_linear_wgrad(M, O, I, mode):
     dw, db = B.linear_wgrad(dyd, xd, mode)
     torch.testing.assert_close(dw.cpu().double(), ref_w, **tol)
     torch.testing.assert_close(db.cpu().double(), dy.double().sum(0), rtol=1e-5, atol=1e-4 * M ** 0.5)
+
+
+def test_bf16_mode_gradients_track_f32_mode():
+    """The bf16 training path (bf16 GEMM operands, fp16 residual stream, MFMA attention backward, split-K wgrad) against the
+    f32 path on the same weights: per-tensor cosine > 0.99 and norms within 5 % (width 256 so that every bf16-only code path
+    is taken; 64 samples x 50 / 16 tokens so that the wgrad contraction is long enough to be split)."""
+    from model.base.model import CLIP
+    cfg = dict(embed_dim=128, image_resolution=224, vision_layers=2, vision_width=256, vision_patch_size=32, context_length=16,
+               vocab_size=512, transformer_width=256, transformer_heads=4, transformer_layers=2)
+    torch.manual_seed(3)
+    m = CLIP(**cfg).to(DEV).float()
+    B = 64
+    img = torch.randn(B, 3, 224, 224, device=DEV)
+    txt = torch.randint(1, 500, (B, 16), device=DEV)
+    txt[:, -1] = 511
+    gi, gt = torch.randn(B, 128, device=DEV), torch.randn(B, 128, device=DEV)
+    grads = {}
+    for mode in ("f32", "bf16"):
+        m.set_gemm_dtype(mode)
+        m.zero_grad(set_to_none=True)
+        ((m.encode_image(img) * gi).sum() + (m.encode_text(txt) * gt).sum()).backward()
+        grads[mode] = {n: p.grad.detach().double().flatten().cpu() for n, p in m.named_parameters() if p.grad is not None}
+    worst = (1.0, "")
+    for n, a in grads["f32"].items():
+        b = grads["bf16"][n]
+        cos = float(a @ b / (a.norm() * b.norm() + 1e-30))
+        worst = min(worst, (cos, n))
+        assert cos > 0.99, (n, cos)
+        assert abs(float(b.norm() / (a.norm() + 1e-30)) - 1.0) < 0.05, (n, float(a.norm()), float(b.norm()))
+    print(f"bf16 vs f32 gradients: worst cosine {worst[0]:.5f} ({worst[1]})")
