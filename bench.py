@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-map-eval", action="store_true")
     ap.add_argument("--no-train-step", action="store_true")
+    ap.add_argument("--train-step", action="store_true",
+                    help="also time the training step when --gpus > 1 (default: single-GPU runs only, so that the secondary "
+                         "metric's gradient all-reduce can never stall the headline scaling line)")
     ap.add_argument("--no-overlap-towers", action="store_true", help="run the text tower after the image tower on one stream")
     ap.add_argument("--map-queries", type=int, default=5000)
     ap.add_argument("--map-db", type=int, default=15015)
@@ -249,7 +252,7 @@ def main():
                            "stable_tie_order": {"ms": round(ms_st, 3), "mAP_i2t": round(float(maps_st[0]), 6),
                                                 "note": "CMH_TIE_STABLE (ties by index): not the reference's ranking"}}
 
-    if not a.no_train_step:
+    if not a.no_train_step and (world == 1 or a.train_step):
         try:
             # secondary metric: the reference's actual inner loop (train/DSPH/hash_train.py:49-73) - tape-keeping forward of both
             # towers, heads, HyP loss, backward through everything, fused BertAdam + SGD on the proxies; same batch, weights not frozen
