@@ -130,3 +130,48 @@ def linear_wgrad(dy, x, gemm_dtype="bf16", want_bias=True):
     N.check(N.lib().cmh_linear_wgrad(dt, N.ptr(dy), KIND[dy.dtype], N.ptr(x), KIND[x.dtype], M, O, I, N.ptr(dw), N.ptr(db), N.ptr(ws),
                                      ws.numel(), N.stream_ptr(x.device)), "cmh_linear_wgrad")
     return dw, db
+
+
+class PairSoftmax(torch.autograd.Function):
+    """cmh_pair_softmax with its backward (DCHMT select head, model/DCHMT.py:24)."""
+
+    @staticmethod
+    def forward(ctx, z):
+        p = N.pair_softmax(z)
+        ctx.save_for_backward(p)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        (p,) = ctx.saved_tensors
+        dp = N.f32c(dp)
+        dz = torch.empty_like(p)
+        N.check(N.lib().cmh_pair_softmax_backward(N.ptr(p), N.ptr(dp), N.ptr(dz), p.shape[0], p.shape[1] // 2,
+                                                  N.stream_ptr(p.device)), "cmh_pair_softmax_backward")
+        return dz
+
+
+class DchmtLoss(torch.autograd.Function):
+    """cmh_dchmt_loss with its backward (similarity_loss x3 + our_loss, train/DCHMT/hash_train.py:82-150)."""
+
+    @staticmethod
+    def forward(ctx, img, txt, label, output_dim, similarity, loss_type, vartheta, sim_threshold):
+        img, txt, label = N.f32c(img), N.f32c(txt), N.f32c(label)
+        ctx.save_for_backward(img, txt, label)
+        ctx.cfg = (int(output_dim), similarity, loss_type, float(vartheta), float(sim_threshold))
+        return N.dchmt_loss(img, txt, label, output_dim, similarity, loss_type, vartheta, sim_threshold)
+
+    @staticmethod
+    def backward(ctx, dloss):
+        img, txt, label = ctx.saved_tensors
+        K, similarity, loss_type, vartheta, thr = ctx.cfg
+        B, D = img.shape
+        Cn = label.shape[1]
+        di, dt = torch.empty_like(img), torch.empty_like(txt)
+        dl = N.f32c(dloss).reshape(1)
+        ws = N.workspace(N.lib().cmh_head_backward_workspace_bytes(B, D, Cn), img.device, "bwd")
+        N.check(N.lib().cmh_dchmt_loss_backward(N.ptr(img), N.ptr(txt), N.ptr(label), B, D, Cn, K,
+                                                {"euclidean": 0, "cosine": 1}[similarity], {"l1": 1, "l2": 2}[loss_type], vartheta, thr,
+                                                N.ptr(dl), N.ptr(di), N.ptr(dt), N.ptr(ws), ws.numel(), N.stream_ptr(img.device)),
+                "cmh_dchmt_loss_backward")
+        return di, dt, None, None, None, None, None, None

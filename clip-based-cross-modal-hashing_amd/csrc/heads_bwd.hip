@@ -216,10 +216,160 @@ __global__ __launch_bounds__(64) void hyp_proxy_kernel(const float* __restrict__
   for (int v = 0; v < KV; ++v) { const int k = lane + 64 * v; if (k < K) dp[static_cast<size_t>(c) * K + k] = (g[v] - pc[v] * pg) * r; }
 }
 
+// ---- DCHMT ------------------------------------------------------------------------------------------------------------------
+// pair softmax backward: dz = p o (dp - (p0 dp0 + p1 dp1)) per adjacent pair
+__global__ __launch_bounds__(256) void pair_softmax_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp,
+                                                               float* __restrict__ dz, int64_t npairs) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= npairs) return;
+  const float2 pv = *reinterpret_cast<const float2*>(p + 2 * i), dv = *reinterpret_cast<const float2*>(dp + 2 * i);
+  const float s = pv.x * dv.x + pv.y * dv.y;
+  *reinterpret_cast<float2*>(dz + 2 * i) = float2{pv.x * (dv.x - s), pv.y * (dv.y - s)};
+}
+
+// d loss / d similarity of ONE similarity_loss term (train/DCHMT/hash_train.py:82-114), n = B*B elements per mean.
+// torch.clamp's backward passes the gradient where min <= x <= max.
+__device__ __forceinline__ float dchmt_dsim(float s, bool same, int cosine, int l2, float thr, float maxv, float inv_n) {
+  if (cosine) {
+    if (same) { if (s < thr) return 0.f; return (l2 ? 2.f * (s - thr) : 1.f) * inv_n; }       // clip(min=thr) - thr
+    if (s > 1.f) return 0.f;                                                                 // 1 - clip(max=1)
+    return -(l2 ? 2.f * (1.f - s) : 1.f) * inv_n;
+  }
+  if (same) return (l2 ? 2.f * s : 1.f) * inv_n;
+  if (s > maxv) return 0.f;
+  return -(l2 ? 2.f * (maxv - s) : 1.f) * inv_n;
+}
+
+// One wave per sample i: d loss / d img_i and d txt_i of  L = sl(img,txt) + sl(img,img) + sl(txt,txt)   (our_loss, :116-125).
+// A / T are the rows the similarities were taken on (raw for euclidean, unit rows for cosine); na / nt their norms (cosine).
+//   euclidean: sim = |a - b| (torch.cdist; zero distance -> zero gradient), d sim / d a = (a - b) / sim
+//   cosine   : sim = 1 - an . bn,  d sim / d an = -bn, then through an = a / |a|
+// img_i appears as `a` of (img_i, txt_j), as `a` of (img_i, img_j) and as `b` of (img_j, img_i) (equal by symmetry -> factor 2).
+__global__ __launch_bounds__(64) void dchmt_rows_kernel(const float* __restrict__ A, const float* __restrict__ T,
+                                                        const float* __restrict__ na, const float* __restrict__ nt,
+                                                        const float* __restrict__ label, int B, int D, int C, int cosine, int l2,
+                                                        float thr, float maxv, const float* __restrict__ dloss,
+                                                        float* __restrict__ dimg, float* __restrict__ dtxt) {
+  constexpr int DV = 8;                                 // D <= 512
+  const int i = blockIdx.x, lane = threadIdx.x;
+  const float up = dloss ? dloss[0] : 1.f;
+  const float inv_n = 1.f / (static_cast<float>(B) * static_cast<float>(B));
+  float ai[DV], ti[DV], ga[DV], gt[DV];
+#pragma unroll
+  for (int v = 0; v < DV; ++v) {
+    const int k = lane + 64 * v;
+    ai[v] = k < D ? A[static_cast<size_t>(i) * D + k] : 0.f;
+    ti[v] = k < D ? T[static_cast<size_t>(i) * D + k] : 0.f;
+    ga[v] = 0.f; gt[v] = 0.f;
+  }
+  for (int j = 0; j < B; ++j) {
+    float ll = 0.f;
+    for (int c = lane; c < C; c += 64) ll = fmaf(label[static_cast<size_t>(i) * C + c], label[static_cast<size_t>(j) * C + c], ll);
+    const bool same = wsum(ll) > 0.f;                    // calc_neighbor
+    float aj[DV], tj[DV], s_it = 0.f, s_ti = 0.f, s_ii = 0.f, s_tt = 0.f;
+#pragma unroll
+    for (int v = 0; v < DV; ++v) {
+      const int k = lane + 64 * v;
+      aj[v] = k < D ? A[static_cast<size_t>(j) * D + k] : 0.f;
+      tj[v] = k < D ? T[static_cast<size_t>(j) * D + k] : 0.f;
+      if (cosine) {
+        s_it = fmaf(ai[v], tj[v], s_it); s_ti = fmaf(aj[v], ti[v], s_ti); s_ii = fmaf(ai[v], aj[v], s_ii); s_tt = fmaf(ti[v], tj[v], s_tt);
+      } else {
+        const float d1 = ai[v] - tj[v], d2 = aj[v] - ti[v], d3 = ai[v] - aj[v], d4 = ti[v] - tj[v];
+        s_it = fmaf(d1, d1, s_it); s_ti = fmaf(d2, d2, s_ti); s_ii = fmaf(d3, d3, s_ii); s_tt = fmaf(d4, d4, s_tt);
+      }
+    }
+    s_it = wsum(s_it); s_ti = wsum(s_ti); s_ii = wsum(s_ii); s_tt = wsum(s_tt);
+    if (cosine) { s_it = 1.f - s_it; s_ti = 1.f - s_ti; s_ii = 1.f - s_ii; s_tt = 1.f - s_tt; }
+    else { s_it = sqrtf(s_it); s_ti = sqrtf(s_ti); s_ii = sqrtf(s_ii); s_tt = sqrtf(s_tt); }
+    const float w_it = dchmt_dsim(s_it, same, cosine, l2, thr, maxv, inv_n), w_ti = dchmt_dsim(s_ti, same, cosine, l2, thr, maxv, inv_n);
+    const float w_ii = 2.f * dchmt_dsim(s_ii, same, cosine, l2, thr, maxv, inv_n), w_tt = 2.f * dchmt_dsim(s_tt, same, cosine, l2, thr, maxv, inv_n);
+    if (cosine) {
+#pragma unroll
+      for (int v = 0; v < DV; ++v) {
+        ga[v] -= w_it * tj[v] + w_ii * aj[v];
+        gt[v] -= w_ti * aj[v] + w_tt * tj[v];
+      }
+    } else {
+      const float r_it = s_it > 0.f ? w_it / s_it : 0.f, r_ti = s_ti > 0.f ? w_ti / s_ti : 0.f;
+      const float r_ii = s_ii > 0.f ? w_ii / s_ii : 0.f, r_tt = s_tt > 0.f ? w_tt / s_tt : 0.f;
+#pragma unroll
+      for (int v = 0; v < DV; ++v) {
+        ga[v] += r_it * (ai[v] - tj[v]) + r_ii * (ai[v] - aj[v]);
+        gt[v] += r_ti * (ti[v] - aj[v]) + r_tt * (ti[v] - tj[v]);
+      }
+    }
+  }
+  float pa = 0.f, pt = 0.f;
+  if (cosine) {                                          // through a / |a| (no eps: utils/utils.py:61-62)
+#pragma unroll
+    for (int v = 0; v < DV; ++v) { pa = fmaf(ai[v], ga[v], pa); pt = fmaf(ti[v], gt[v], pt); }
+    pa = wsum(pa); pt = wsum(pt);
+  }
+#pragma unroll
+  for (int v = 0; v < DV; ++v) {
+    const int k = lane + 64 * v;
+    if (k < D) {
+      dimg[static_cast<size_t>(i) * D + k] = cosine ? (ga[v] - ai[v] * pa) * up / na[i] : ga[v] * up;
+      dtxt[static_cast<size_t>(i) * D + k] = cosine ? (gt[v] - ti[v] * pt) * up / nt[i] : gt[v] * up;
+    }
+  }
+}
+
+// rows / |row| (no eps) and the norms
+__global__ __launch_bounds__(256) void plain_normalize_kernel(const float* __restrict__ a, float* __restrict__ an, float* __restrict__ nrm,
+                                                              int R, int K) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  float ss = 0.f;
+  for (int k = lane; k < K; k += 64) { const float v = a[static_cast<size_t>(row) * K + k]; ss = fmaf(v, v, ss); }
+  const float n = sqrtf(wsum(ss));
+  for (int k = lane; k < K; k += 64) an[static_cast<size_t>(row) * K + k] = a[static_cast<size_t>(row) * K + k] / n;
+  if (lane == 0) nrm[row] = n;
+}
+
 }  // namespace
 }  // namespace cmh
 
 using namespace cmh;
+
+extern "C" int cmh_pair_softmax_backward(const float* p, const float* dp, float* dz, int32_t M, int32_t K, void* stream) {
+  CMH_CHECK_ARG(p && dp && dz && M > 0 && K > 0, "pair_softmax_backward: bad arguments");
+  const int64_t np = static_cast<int64_t>(M) * K;
+  hipLaunchKernelGGL(pair_softmax_bwd_kernel, dim3(static_cast<unsigned>((np + 255) / 256)), dim3(256), 0, as_stream(stream), p, dp, dz, np);
+  CMH_CHECK_LAUNCH("pair_softmax_backward");
+  return CMH_OK;
+}
+
+extern "C" int cmh_dchmt_loss_backward(const float* img, const float* txt, const float* label, int32_t B, int32_t D, int32_t C,
+                                       int32_t output_dim, int32_t similarity, int32_t loss_type, float vartheta,
+                                       float sim_threshold, const float* dloss, float* dimg, float* dtxt, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+  CMH_CHECK_ARG(img && txt && label && dimg && dtxt && workspace, "dchmt_loss_backward: null pointer");
+  CMH_CHECK_ARG(B > 0 && D > 0 && D <= 512 && C > 0 && B <= 32768, "dchmt_loss_backward: bad shape");
+  CMH_CHECK_ARG((similarity == 0 || similarity == 1) && (loss_type == 1 || loss_type == 2), "dchmt_loss_backward: bad similarity / loss_type");
+  if (workspace_bytes < cmh_head_backward_workspace_bytes(B, D, C)) return fail(CMH_ERR_WORKSPACE, "dchmt_loss_backward: workspace too small");
+  char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+  const size_t bk = align_up(static_cast<size_t>(B) * D * 4, 256), v = align_up(static_cast<size_t>(B > C ? B : C) * 4, 256);
+  float* an = reinterpret_cast<float*>(ws);
+  float* tn = reinterpret_cast<float*>(ws + bk);
+  float* na = reinterpret_cast<float*>(ws + 2 * bk);
+  float* nt = reinterpret_cast<float*>(ws + 2 * bk + v);
+  hipStream_t st = as_stream(stream);
+  const float* A = img;
+  const float* T = txt;
+  if (similarity == 1) {   // the forward normalises unless a matrix is identically zero (pair probabilities never are)
+    hipLaunchKernelGGL(plain_normalize_kernel, dim3((B + 3) / 4), dim3(256), 0, st, img, an, na, B, D);
+    hipLaunchKernelGGL(plain_normalize_kernel, dim3((B + 3) / 4), dim3(256), 0, st, txt, tn, nt, B, D);
+    A = an; T = tn;
+  }
+  const float thr = sim_threshold != 0.f ? sim_threshold : 0.05f;
+  const float maxv = sqrtf(static_cast<float>(output_dim) * 2.f * vartheta);
+  hipLaunchKernelGGL(dchmt_rows_kernel, dim3(B), dim3(64), 0, st, A, T, na, nt, label, B, D, C, similarity, loss_type == 2, thr, maxv,
+                     dloss, dimg, dtxt);
+  CMH_CHECK_LAUNCH("dchmt_loss_backward");
+  return CMH_OK;
+}
 
 extern "C" size_t cmh_head_backward_workspace_bytes(int32_t B, int32_t K, int32_t C) {
   if (B <= 0 || K <= 0 || C <= 0) return 0;

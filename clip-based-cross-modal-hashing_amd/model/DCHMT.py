@@ -28,11 +28,15 @@ class HashLayer(nn.Module):
 
     def pair_probs(self, data):
         """[B, 2K] pair probabilities (the trainer's torch.cat(list, -1), train/DCHMT/hash_train.py:55-57)."""
-        embed = N.linear_act(data, self.fc.weight, self.fc.bias, N.ACT_RELU)
         w = torch.cat([l.weight for l in self.hash_list], 0)
         b = torch.cat([l.bias for l in self.hash_list], 0)
+        if torch.is_grad_enabled() and (data.requires_grad or self.fc.weight.requires_grad):
+            from backward_ops import LinearAct, PairSoftmax      # training: the same three launches, each with its backward
+            embed = LinearAct.apply(data, self.fc.weight, self.fc.bias, N.ACT_RELU, None, 0.0)
+            return PairSoftmax.apply(LinearAct.apply(embed, w, b, N.ACT_NONE, None, 0.0))
+        embed = N.linear_act(data, self.fc.weight, self.fc.bias, N.ACT_RELU)
         z = N.linear_act(embed, w, b, N.ACT_NONE)
-        return no_backward(N.pair_softmax(z), self.fc.weight)
+        return N.pair_softmax(z)
 
     def forward(self, data):
         p = self.pair_probs(data)

@@ -1,12 +1,15 @@
 """DCHMT trainer (reference train/DCHMT/hash_train.py:14-158; paper: Differentiable Cross-modal
 Hashing via Multimodal Transformers, ACM MM 2022).  similarity_loss x3 + our_loss are ONE native
-call (cmh_dchmt_loss); as for DSPH the backward/optimiser half of the step is not built yet."""
+call (cmh_dchmt_loss); its backward, the select head's and both towers' are native too, the optimiser is the fused
+BertAdam: train_epoch is the reference's loop (hash_train.py:44-68)."""
 import os
 
 import torch
 
 import cmh_native as N
+import dist_utils as du
 from model.DCHMT import MDCMHT
+from model.base.optimization import BertAdam
 from model.base.model import no_backward
 from train.base import TrainBase
 from .get_args import get_args
@@ -30,16 +33,24 @@ class DCHMTTrainer(TrainBase):
             self.model.load_state_dict(torch.load(self.args.pretrained, map_location=f"cuda:{self.rank}"))
         self.model.float()
         self.model.clip.set_gemm_dtype(self.args.gemm_dtype)
-        self.optimizer = None
+        self.optimizer = BertAdam([
+            {"params": self.model.clip.parameters(), "lr": self.args.clip_lr},
+            {"params": self.model.image_hash.parameters(), "lr": self.args.lr},
+            {"params": self.model.text_hash.parameters(), "lr": self.args.lr}],
+            lr=self.args.lr, warmup=self.args.warmup_proportion, schedule="warmup_cosine", b1=0.9, b2=0.98, e=1e-6,
+            t_total=len(self.train_loader) * self.args.epochs, weight_decay=self.args.weight_decay, max_grad_norm=1.0)
 
     def our_loss(self, image, text, label, epoch=0, times=0):
         """image/text: [B, 2K] pair probabilities (hash_layer == 'select'); label [B,C]."""
         if self.args.hash_layer != "select":
             raise NotImplementedError("hash_layer='linear' calls an undefined self.hash_loss upstream (hash_train.py:131)")
-        loss = N.dchmt_loss(image, text, label.to(image.device), self.args.output_dim,
-                            self.args.similarity_function, self.args.loss_type, self.args.vartheta,
-                            self.args.sim_threshold)
-        return no_backward(loss, self.model.image_hash.fc.weight)
+        label = label.to(image.device)
+        if torch.is_grad_enabled() and (image.requires_grad or text.requires_grad):
+            from backward_ops import DchmtLoss
+            return DchmtLoss.apply(image, text, label, self.args.output_dim, self.args.similarity_function, self.args.loss_type,
+                                   self.args.vartheta, self.args.sim_threshold)
+        return N.dchmt_loss(image, text, label, self.args.output_dim, self.args.similarity_function, self.args.loss_type,
+                            self.args.vartheta, self.args.sim_threshold)
 
     def compute_loss(self, image, text, label, epoch=0, times=0):
         return self.our_loss(image, text, label, epoch, times)
@@ -58,6 +69,10 @@ class DCHMTTrainer(TrainBase):
             hash_img = torch.cat(hash_img, dim=-1) if isinstance(hash_img, list) else hash_img.view(hash_img.shape[0], -1)
             hash_text = torch.cat(hash_text, dim=-1) if isinstance(hash_text, list) else hash_text.view(hash_text.shape[0], -1)
             loss = self.compute_loss(hash_img, hash_text, label, epoch, times)
-            all_loss += loss
-            loss.backward()      # raises NotImplementedError: backward kernels are the next scope row
+            all_loss += loss.detach()
+            self.optimizer.zero_grad()
+            loss.backward()
+            if du.world_size() > 1:   # one process per GPU: average the gradients over the ranks (flat buckets over RCCL)
+                du.allreduce_mean_([p.grad for p in self.model.parameters() if p.grad is not None])
+            self.optimizer.step()
         self.logger.info(f">>>>>> [{epoch}/{self.args.epochs}] loss: {all_loss.data / (len(self.train_loader))}")

@@ -411,6 +411,13 @@ size_t cmh_head_backward_workspace_bytes(int32_t B, int32_t K, int32_t C);
 int cmh_dsph_hyp_loss_backward(const float* x, const float* y, const float* label, const float* proxies, int32_t B, int32_t K,
                                int32_t C, float threshold, float alpha, const float* dloss, float* dx, float* dy,
                                float* dproxies, void* workspace, size_t workspace_bytes, void* stream);
+/* Backward of cmh_pair_softmax (DCHMT select head): p = the forward output [M,2K], dp its gradient -> dz [M,2K]. */
+int cmh_pair_softmax_backward(const float* p, const float* dp, float* dz, int32_t M, int32_t K, void* stream);
+/* Backward of cmh_dchmt_loss (train/DCHMT/hash_train.py:82-150): same arguments, dloss = optional device scalar (NULL = 1)
+ * -> dimg, dtxt [B,D].  D <= 512; workspace >= cmh_head_backward_workspace_bytes(B, D, C). */
+int cmh_dchmt_loss_backward(const float* img, const float* txt, const float* label, int32_t B, int32_t D, int32_t C,
+                            int32_t output_dim, int32_t similarity, int32_t loss_type, float vartheta, float sim_threshold,
+                            const float* dloss, float* dimg, float* dtxt, void* workspace, size_t workspace_bytes, void* stream);
 size_t cmh_vit_train_bytes(const cmh_vit_weights* w, int32_t batch);
 /* same `feat` as cmh_vit_encode (c_fc's QuickGELU runs as a separate pass over the stored pre-activation) */
 int cmh_vit_forward_train(const cmh_vit_weights* w, const float* image, int32_t batch, float* feat, void* tape, size_t tape_bytes,

@@ -278,3 +278,74 @@ def test_bf16_mode_gradients_track_f32_mode():
         assert cos > 0.99, (n, cos)
         assert abs(float(b.norm() / (a.norm() + 1e-30)) - 1.0) < 0.05, (n, float(a.norm()), float(b.norm()))
     print(f"bf16 vs f32 gradients: worst cosine {worst[0]:.5f} ({worst[1]})")
+
+
+@pytest.mark.parametrize("B,K,C,fn,lt", [(32, 16, 24, "euclidean", "l2"), (32, 16, 24, "cosine", "l2"), (24, 64, 24, "euclidean", "l1"),
+                                         (24, 64, 80, "cosine", "l1")])
+def test_dchmt_loss_gradients_match_reference_goldens(golden, B, K, C, fn, lt):
+    """d our_loss / d(pair probabilities) as the REFERENCE's autograd produced them (make_golden.py::gen_loss_dchmt), through
+    the pair softmax as well (chain: z -> softmax pairs -> loss)."""
+    import recipe
+    from backward_ops import DchmtLoss, PairSoftmax
+    g = golden("loss_dchmt.npz")
+    tag, seed = f"B{B}_K{K}_C{C}_{fn}_{lt}", 31
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    zi = (2 * t(recipe.features(B, 2 * K, seed, f"dchmt_zi_{tag}"))).requires_grad_()
+    zt = (2 * t(recipe.features(B, 2 * K, seed, f"dchmt_zt_{tag}"))).requires_grad_()
+    lab = t(recipe.labels(B, C, seed, tag=f"dchmt_lab_{tag}"))
+    hi, ht = PairSoftmax.apply(zi), PairSoftmax.apply(zt)
+    hi.retain_grad(); ht.retain_grad()
+    loss = DchmtLoss.apply(hi, ht, lab, K, fn, lt, 0.5, 0.1)
+    loss.backward()
+    ref = float(g[f"{tag}_loss"])
+    assert abs(float(loss.detach()) - ref) < 1e-4 * max(1.0, abs(ref))
+    np.testing.assert_allclose(hi.grad.cpu().numpy(), g[f"{tag}_gi"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(ht.grad.cpu().numpy(), g[f"{tag}_gt"], rtol=1e-4, atol=1e-7)
+    # pair softmax backward against fp64 autograd
+    zr = zi.detach().cpu().double().requires_grad_(True)
+    torch.softmax(zr.view(B, K, 2), -1).reshape(B, 2 * K).backward(hi.grad.cpu().double())
+    torch.testing.assert_close(zi.grad.cpu().double(), zr.grad, rtol=1e-5, atol=1e-9)
+
+
+def test_dchmt_training_trajectory_matches_reference(golden):
+    """BASELINE configs[0] in miniature: 4 steps of the DCHMT loop (tape forward -> select heads -> our_loss -> backward through
+    heads and towers -> fused BertAdam), loss of every step and the final parameters against the REFERENCE's own run on the CPU
+    (tests/golden/make_golden6.py)."""
+    import dchmtutil as du
+    from backward_ops import DchmtLoss
+    from model.DCHMT import HashLayer
+    from model.base.optimization import BertAdam
+    from test_gpu_clip import _clip
+    g = golden("dchmt_traj.npz")
+    clip = _clip(du.CFG, du.SEED, "f32")
+    ih, th = HashLayer(du.CFG["embed_dim"], du.K), HashLayer(du.CFG["embed_dim"], du.K)
+    du.fill_head(ih, 1)
+    du.fill_head(th, 2)
+    ih, th = ih.to(DEV), th.to(DEV)
+    opt = BertAdam([{"params": [p for _, p in clip.named_parameters()], "lr": du.CLIP_LR}, {"params": ih.parameters(), "lr": du.OPT["lr"]},
+                    {"params": th.parameters(), "lr": du.OPT["lr"]}], **du.OPT)
+    losses = []
+    for step in range(du.STEPS):
+        img, txt, lab = du.batch(step)
+        hi = ih.pair_probs(clip.encode_image(img.to(DEV)))
+        ht = th.pair_probs(clip.encode_text(txt.to(DEV)))
+        loss = DchmtLoss.apply(hi, ht, lab.to(DEV), du.K, du.LOSS["similarity_function"], du.LOSS["loss_type"], du.LOSS["vartheta"],
+                               du.LOSS["sim_threshold"])
+        losses.append(float(loss.detach()))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    np.testing.assert_allclose(np.array(losses), g["losses"], rtol=1e-4)
+    named = dict(clip.named_parameters())
+    named.update({"image_hash." + n: p for n, p in ih.named_parameters()})
+    named.update({"text_hash." + n: p for n, p in th.named_parameters()})
+    worst = 0.0
+    for key in g.files:
+        if not key.startswith("p_"):
+            continue
+        ref = g[key]
+        a = du.cut(named[key[2:]].detach().cpu().numpy())
+        err = np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-6)
+        worst = max(worst, err)
+        assert err < 1e-4, (key, err)
+    print(f"DCHMT trajectory: losses {losses}, worst parameter error {worst:.2e} of max")
