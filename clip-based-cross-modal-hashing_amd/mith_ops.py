@@ -8,16 +8,33 @@ import cmh_native as N
 EPI_BIAS, EPI_QUICKGELU, EPI_RESIDUAL, EPI_OUT_BF16, EPI_GELU, EPI_RELU = 1, 2, 4, 8, 16, 32
 
 
-def gemm(x, w, bias=None, residual=None, act=None):
-    """f32 out = act(x @ w.T + bias) (+ residual); x,w f32 (exact-fp32 MFMA path). act in {None,'gelu','relu','quickgelu'}."""
-    x, w = N.f32c(x), N.f32c(w)
+_bf16_weights = {}
+
+
+def weight_bf16(w):
+    """bf16 copy of a GEMM weight, re-cast when the parameter changes (data_ptr / _version)"""
+    key = id(w)
+    hit = _bf16_weights.get(key)
+    if hit is None or hit[0] != (w.data_ptr(), w._version):
+        hit = ((w.data_ptr(), w._version), N.cast_bf16(w.detach()))
+        _bf16_weights[key] = hit
+    return hit[1]
+
+
+def gemm(x, w, bias=None, residual=None, act=None, dtype=N.F32):
+    """f32 out = act(x @ w.T + bias) (+ residual); act in {None,'gelu','relu','quickgelu'}.  dtype F32: exact-fp32 MFMA path on the
+    f32 tensors; BF16: the operands are cast to bf16 (weights cached), accumulation / bias / residual / output stay f32."""
     N.require_gpu(x, w, bias, residual)
+    if dtype == N.BF16:
+        x, w = N.cast_bf16(x), weight_bf16(w)
+    else:
+        x, w = N.f32c(x), N.f32c(w)
     M, K = x.shape
     Nn = w.shape[0]
     out = torch.empty(M, Nn, dtype=torch.float32, device=x.device)
     epi = (EPI_BIAS if bias is not None else 0) | (EPI_RESIDUAL if residual is not None else 0)
     epi |= {None: 0, "gelu": EPI_GELU, "relu": EPI_RELU, "quickgelu": EPI_QUICKGELU}[act]
-    N.check(N.lib().cmh_linear_gemm(N.F32, N.ptr(x), N.ptr(w), N.ptr(None if bias is None else N.f32c(bias)),
+    N.check(N.lib().cmh_linear_gemm(dtype, N.ptr(x), N.ptr(w), N.ptr(None if bias is None else N.f32c(bias)),
                                     N.ptr(None if residual is None else N.f32c(residual)), N.ptr(out), M, Nn, K, epi,
                                     N.stream_ptr(x.device)), "cmh_linear_gemm")
     return out
@@ -50,12 +67,12 @@ def text_encode_tokens(clip, text, key_padding_mask):
     return out.view(B, L, s.embed_dim), rows
 
 
-def transformer_blocks(block_array, layers, x, B, T):
-    """x f32 [B*T, d] -> same shape, after `layers` ResidualAttentionBlocks (no mask)."""
+def transformer_blocks(block_array, layers, x, B, T, dtype=N.F32):
+    """x f32 [B*T, d] -> same shape, after `layers` ResidualAttentionBlocks (no mask); block_array's GEMM weights in `dtype`."""
     x = N.f32c(x).clone()
     d = x.shape[1]
-    ws = N.workspace(N.lib().cmh_blocks_workspace_bytes(N.F32, B, T, d), x.device, "blocks")
-    N.check(N.lib().cmh_transformer_blocks(C.cast(block_array, C.POINTER(N.BlockWeights)), layers, N.F32, N.ptr(x), B, T,
+    ws = N.workspace(N.lib().cmh_blocks_workspace_bytes(dtype, B, T, d), x.device, "blocks")
+    N.check(N.lib().cmh_transformer_blocks(C.cast(block_array, C.POINTER(N.BlockWeights)), layers, dtype, N.ptr(x), B, T,
                                            d, 0, None, N.ptr(ws), ws.numel(), N.stream_ptr(x.device)),
             "cmh_transformer_blocks")
     return x

@@ -88,8 +88,9 @@ class ResidualMLPs(nn.Module):
         x = N.f32c(x).reshape(-1, shape[-1])
         for i in range(self.num_layers):
             h = N.layernorm(x, self.lns[i].weight, self.lns[i].bias)
-            u = M.gemm(h, self.mlps[i][0].weight, self.mlps[i][0].bias, act=self.activation)
-            x = M.gemm(u, self.mlps[i][3].weight, self.mlps[i][3].bias, residual=x)
+            dt = getattr(self, "_gemm_dt", N.F32)
+            u = M.gemm(h, self.mlps[i][0].weight, self.mlps[i][0].bias, act=self.activation, dtype=dt)
+            x = M.gemm(u, self.mlps[i][3].weight, self.mlps[i][3].bias, residual=x, dtype=dt)
         return x.reshape(shape)
 
 
@@ -157,8 +158,9 @@ class LocalConceptTransforming(nn.Module):
         x = self.position(x)
         Nb, K, D = x.shape
         keep = []
-        arr = _fill_blocks(self.transformer.resblocks, N.F32, keep)
-        y = M.transformer_blocks(arr, len(self.transformer.resblocks), x.reshape(Nb * K, D), Nb, K).reshape(Nb, K, D)
+        dt = getattr(self, "_gemm_dt", N.F32)
+        arr = _fill_blocks(self.transformer.resblocks, dt, keep)
+        y = M.transformer_blocks(arr, len(self.transformer.resblocks), x.reshape(Nb * K, D), Nb, K, dt).reshape(Nb, K, D)
         del keep
         return self.hashing(y), y
 
@@ -173,6 +175,14 @@ class HashingModel(nn.Module):
         self.lct_t = LocalConceptTransforming(clip_embed_dim, k_bits, args.transformer_layers, 0, args.top_k_label)
         self.img_concept_proj = nn.Linear(clip_embed_dim, clip_embed_dim)
         self.txt_concept_proj = nn.Linear(clip_embed_dim, clip_embed_dim)
+
+    def set_gemm_dtype(self, name: str):
+        """"f32": exact-fp32 MFMA GEMMs (parity mode); "bf16": bf16 operands / f32 accumulate for the ResidualMLPs, the concept
+        transformer and the concept projections - the GEMMs are 3/4 of the f32 HashingModel's time (tools/mith_bench.py)."""
+        dt = {"f32": N.F32, "fp32": N.F32, "bf16": N.BF16, "bfloat16": N.BF16}[name.lower()]
+        for m in self.modules():
+            m._gemm_dt = dt
+        return self
 
     def forward(self, img_tokens, txt_tokens, img_cls, txt_eos, key_padding_mask):
         """Reference layouts in (img_tokens [49,N,D], txt_tokens [L,N,D]) and out (trans_tokens_* [K,N,D])."""
@@ -191,8 +201,9 @@ class HashingModel(nn.Module):
         hash_t, trans_t = self.lct_t(tt, sim_t, 0, tt.shape[1], key_padding_mask)
         out['img_tokens_hash'], out['txt_tokens_hash'] = nb(hash_i), nb(hash_t)
         Nb, K, D = trans_i.shape
-        pi = M.gemm(trans_i.reshape(Nb * K, D), self.img_concept_proj.weight, self.img_concept_proj.bias)
-        pt = M.gemm(trans_t.reshape(Nb * K, D), self.txt_concept_proj.weight, self.txt_concept_proj.bias)
+        dt = getattr(self, "_gemm_dt", N.F32)
+        pi = M.gemm(trans_i.reshape(Nb * K, D), self.img_concept_proj.weight, self.img_concept_proj.bias, dtype=dt)
+        pt = M.gemm(trans_t.reshape(Nb * K, D), self.txt_concept_proj.weight, self.txt_concept_proj.bias, dtype=dt)
         out['trans_tokens_i'] = nb(M.l2_normalize_rows(pi).reshape(Nb, K, D).permute(1, 0, 2))
         out['trans_tokens_t'] = nb(M.l2_normalize_rows(pt).reshape(Nb, K, D).permute(1, 0, 2))
         return out

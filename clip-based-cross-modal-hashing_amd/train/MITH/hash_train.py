@@ -30,6 +30,7 @@ class MITHTrainer(TrainBase):
             self.model.load_state_dict(torch.load(self.args.pretrained, map_location=f"cuda:{self.rank}"))
         self.model.float()
         self.model.clip.set_gemm_dtype(self.args.gemm_dtype)
+        self.model.hash.set_gemm_dtype(self.args.gemm_dtype)
         self.optimizer = None
         self.k_bits = self.args.output_dim
         n = len(self.train_loader.dataset)
