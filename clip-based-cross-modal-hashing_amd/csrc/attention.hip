@@ -44,19 +44,23 @@ __device__ __forceinline__ void load_row64<bf16_t>(const bf16_t* __restrict__ p,
 }
 
 template <typename T>
-__global__ __launch_bounds__(64) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ o, int B, int Tn,
-                                                       int d, int causal, const uint8_t* __restrict__ kpm) {
+__global__ __launch_bounds__(64) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ o, int B, int Tmax,
+                                                       int d, int causal, const uint8_t* __restrict__ kpm,
+                                                       const int32_t* __restrict__ seq_off) {
   __shared__ __attribute__((aligned(16))) float sK[KT][HD];
   __shared__ __attribute__((aligned(16))) float sV[KT][HD];
 
   const int lane = threadIdx.x;
   const int heads = d / HD;
   const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+  // packed variable-length sequences (encode_text without its padding): sequence b = rows [seq_off[b], seq_off[b+1])
+  const int Tn = seq_off ? seq_off[b + 1] - seq_off[b] : Tmax;
+  const size_t srow = seq_off ? static_cast<size_t>(seq_off[b]) : static_cast<size_t>(b) * Tmax;
   const int q0 = blockIdx.y * 64;
   const int row = q0 + lane;
   const bool active = row < Tn;
   const size_t ld = static_cast<size_t>(3) * d;
-  const T* base = qkv + static_cast<size_t>(b) * Tn * ld + h * HD;
+  const T* base = qkv + srow * ld + h * HD;
 
   float q[HD], acc[HD];
 #pragma unroll
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(64) void attention_kernel(const T* __restrict__ qkv
       }
       const int kg = k0 + j;
       bool ok = kg < Tn && (!causal || kg <= row);
-      if (kpm && kg < Tn) ok = ok && (kpm[static_cast<size_t>(b) * Tn + kg] == 0);
+      if (kpm && kg < Tn) ok = ok && (kpm[srow + kg] == 0);
       s[j] = ok ? (a0 + a1) + (a2 + a3) : -1e30f;
       tmax = fmaxf(tmax, s[j]);
     }
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(64) void attention_kernel(const T* __restrict__ qkv
 
   if (!active) return;
   const float inv = 1.0f / l;
-  T* op = o + (static_cast<size_t>(b) * Tn + row) * d + h * HD;
+  T* op = o + (srow + row) * d + h * HD;
   if constexpr (sizeof(T) == 4) {
 #pragma unroll
     for (int i = 0; i < HD / 4; ++i)
@@ -175,8 +179,9 @@ typedef __attribute__((ext_vector_type(4))) float af32x4_t;
 
 template <int NKT>
 __global__ __launch_bounds__(64) void attention_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
-                                                            int B, int Tn, int d, int causal,
-                                                            const uint8_t* __restrict__ kpm) {
+                                                            int B, int Tmax, int d, int causal,
+                                                            const uint8_t* __restrict__ kpm,
+                                                            const int32_t* __restrict__ seq_off) {
   constexpr int NKS = NKT / 2;
   constexpr int TP = NKT * 16;
   constexpr int VST = 66;   // LDS row stride in bf16 elements (132 B): the 4 lane groups land on different banks
@@ -185,8 +190,10 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const bf16_t* __rest
   const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
   const int heads = d / HD;
   const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+  const int Tn = seq_off ? seq_off[b + 1] - seq_off[b] : Tmax;
+  const size_t srow = seq_off ? static_cast<size_t>(seq_off[b]) : static_cast<size_t>(b) * Tmax;
   const size_t ld = static_cast<size_t>(3) * d;
-  const bf16_t* base = qkv + static_cast<size_t>(b) * Tn * ld + h * HD;
+  const bf16_t* base = qkv + srow * ld + h * HD;
 
   // V -> LDS (rows >= T zeroed so that 0 * garbage can never be NaN)
   for (int slot = lane; slot < TP * 8; slot += 64) {
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const bf16_t* __rest
     for (int r = 0; r < 4; ++r) {
       const int key = kt * 16 + 4 * g + r;
       bool ok = key < Tn;
-      if (ok && kpm) ok = kpm[static_cast<size_t>(b) * Tn + key] == 0;
+      if (ok && kpm) ok = kpm[srow + key] == 0;
       keyok |= (ok ? 1u : 0u) << (kt * 4 + r);
     }
   __syncthreads();
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const bf16_t* __rest
     }
     if (qrow < Tn) {
       const float inv = 1.0f / l;
-      bf16_t* op = o + (static_cast<size_t>(b) * Tn + qrow) * d + h * HD + 4 * g;
+      bf16_t* op = o + (srow + qrow) * d + h * HD + 4 * g;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         uint2 pk;
@@ -300,30 +307,36 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const bf16_t* __rest
 
 template <int NKT>
 static void launch_attention_mfma(const void* qkv, void* o, int B, int T, int d, int causal, const uint8_t* kpm,
-                                  hipStream_t st) {
+                                  const int32_t* seq_off, hipStream_t st) {
   hipLaunchKernelGGL(attention_mfma_kernel<NKT>, dim3(B * (d / HD)), dim3(64), 0, st, static_cast<const bf16_t*>(qkv),
-                     static_cast<bf16_t*>(o), B, T, d, causal, kpm);
+                     static_cast<bf16_t*>(o), B, T, d, causal, kpm, seq_off);
 }
 
 int launch_attention(const void* qkv, void* o, int dt, int B, int T, int d, int causal,
                      const uint8_t* key_padding_mask, hipStream_t st) {
+  return launch_attention_varlen(qkv, o, dt, B, T, d, causal, key_padding_mask, nullptr, st);
+}
+
+// seq_off (device int32 [B+1], may be NULL): packed variable-length sequences, T = the longest
+int launch_attention_varlen(const void* qkv, void* o, int dt, int B, int T, int d, int causal,
+                            const uint8_t* key_padding_mask, const int32_t* seq_off, hipStream_t st) {
   CMH_CHECK_ARG(d % HD == 0, "attention: width %d is not a multiple of 64", d);
   CMH_CHECK_ARG(B > 0 && T > 0, "attention: empty batch");
   const dim3 grid(B * (d / HD), (T + 63) / 64);
   if (dt == CMH_BF16 && T <= 128) {
-    if (T <= 32) launch_attention_mfma<2>(qkv, o, B, T, d, causal, key_padding_mask, st);
-    else if (T <= 64) launch_attention_mfma<4>(qkv, o, B, T, d, causal, key_padding_mask, st);
-    else if (T <= 96) launch_attention_mfma<6>(qkv, o, B, T, d, causal, key_padding_mask, st);
-    else launch_attention_mfma<8>(qkv, o, B, T, d, causal, key_padding_mask, st);
+    if (T <= 32) launch_attention_mfma<2>(qkv, o, B, T, d, causal, key_padding_mask, seq_off, st);
+    else if (T <= 64) launch_attention_mfma<4>(qkv, o, B, T, d, causal, key_padding_mask, seq_off, st);
+    else if (T <= 96) launch_attention_mfma<6>(qkv, o, B, T, d, causal, key_padding_mask, seq_off, st);
+    else launch_attention_mfma<8>(qkv, o, B, T, d, causal, key_padding_mask, seq_off, st);
     CMH_CHECK_LAUNCH("attention_mfma");
     return CMH_OK;
   }
   if (dt == CMH_F32)
     hipLaunchKernelGGL(attention_kernel<float>, grid, dim3(64), 0, st, static_cast<const float*>(qkv),
-                       static_cast<float*>(o), B, T, d, causal, key_padding_mask);
+                       static_cast<float*>(o), B, T, d, causal, key_padding_mask, seq_off);
   else
     hipLaunchKernelGGL(attention_kernel<bf16_t>, grid, dim3(64), 0, st, static_cast<const bf16_t*>(qkv),
-                       static_cast<bf16_t*>(o), B, T, d, causal, key_padding_mask);
+                       static_cast<bf16_t*>(o), B, T, d, causal, key_padding_mask, seq_off);
   CMH_CHECK_LAUNCH("attention");
   return CMH_OK;
 }

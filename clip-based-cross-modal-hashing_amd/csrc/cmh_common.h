@@ -134,6 +134,10 @@ int launch_vit_assemble_lnpre(const float* patch_out, const float* cls, const fl
 // x[b,t] = tok_emb[tokens[b,t]] + pos[t]; eot_row[b] = b*L + argmax_t tokens[b,t]
 int launch_text_embed(const int64_t* tokens, const float* tok_emb, const float* pos, void* x, int x_f16,
                       int32_t* eot_row, int B, int L, int d, int vocab, hipStream_t st);
+// packed text rows (tokens up to the EOT only): offsets plan and the embedding into packed rows
+int launch_text_pack_plan(const int64_t* tokens, int B, int L, int32_t* seq_off, hipStream_t st);
+int launch_text_embed_packed(const int64_t* tokens, const float* tok_emb, const float* pos, void* x, int x_f16, int32_t* eot_row,
+                             int B, int L, int d, int vocab, const int32_t* seq_off, hipStream_t st);
 // cls_row[b] = b*T
 int launch_iota_rows(int32_t* rows, int B, int T, hipStream_t st);
 // gemm_wide.hip: split-K for few-tile / long-K products (wgrad); plan returns S (1 = do not split), partials = S*M*N floats
@@ -153,6 +157,8 @@ int launch_layernorm_backward(const void* x, int x_kind, const void* dy, int dy_
 // attention over qkv [B*T, 3d] (dt) -> o [B*T, d] (dt); heads = d/64; causal adds the -inf triu mask
 int launch_attention(const void* qkv, void* o, int dt, int B, int T, int d, int causal,
                      const uint8_t* key_padding_mask, hipStream_t st);
+int launch_attention_varlen(const void* qkv, void* o, int dt, int B, int T, int d, int causal,
+                            const uint8_t* key_padding_mask, const int32_t* seq_off, hipStream_t st);
 
 // y[M,N] f32 = act((x[M,K] . w[N,K]^T + bias) * mask*keep_scale); x,w dtype dt; any N, K%4==0, K<=4096
 int launch_small_linear(int dt, const void* x, const void* w, const float* bias, const float* mask,

@@ -76,14 +76,14 @@ static int tap(const cmh_taps* taps, int idx, const float* x, size_t bytes, hipS
 // One ResidualAttentionBlock (model/base/model.py:191-196):
 //   x += out_proj(attn(in_proj(ln_1(x))));  x += c_proj(QuickGELU(c_fc(ln_2(x))))
 static int run_block(const cmh_block_weights& w, int dt, const TowerBufs& t, int B, int T, int d, int causal,
-                     const uint8_t* kpm, hipStream_t st) {
-  const int M = B * T;
+                     const uint8_t* kpm, hipStream_t st, int rows = -1, const int32_t* seq_off = nullptr) {
+  const int M = rows >= 0 ? rows : B * T;      // packed variable-length text: `rows` real rows, T = the longest sequence
   const int obf = dt == CMH_BF16 ? EPI_OUT_BF16 : 0;
   const int rx = EPI_BIAS | EPI_RESIDUAL | (t.xh ? EPI_RES_F16 | EPI_OUT_F16 : 0);
   int rc;
   if ((rc = launch_layernorm_x(t.x, t.xh, nullptr, w.ln1_w, w.ln1_b, t.h, dt == CMH_BF16, M, d, st))) return rc;
   if ((rc = launch_gemm(dt, t.h, w.in_proj_w, w.in_proj_b, nullptr, t.qkv, M, 3 * d, d, EPI_BIAS | obf, st))) return rc;
-  if ((rc = launch_attention(t.qkv, t.h, dt, B, T, d, causal, kpm, st))) return rc;
+  if ((rc = launch_attention_varlen(t.qkv, t.h, dt, B, T, d, causal, kpm, seq_off, st))) return rc;
   if ((rc = launch_gemm(dt, t.h, w.out_proj_w, w.out_proj_b, t.x, t.x, M, d, d, rx, st))) return rc;
   if ((rc = launch_layernorm_x(t.x, t.xh, nullptr, w.ln2_w, w.ln2_b, t.h, dt == CMH_BF16, M, d, st))) return rc;
   if ((rc = launch_gemm(dt, t.h, w.fc_w, w.fc_b, nullptr, t.mlp, M, 4 * d, d, EPI_BIAS | EPI_QUICKGELU | obf, st))) return rc;
@@ -195,7 +195,8 @@ extern "C" size_t cmh_text_workspace_bytes(const cmh_text_weights* w, int32_t ba
 
 static int text_encode_impl(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
                             const uint8_t* key_padding_mask, float* feat, float* tokens_out, int32_t* eot_rows_out,
-                            void* workspace, size_t workspace_bytes, const cmh_taps* taps, void* stream) {
+                            void* workspace, size_t workspace_bytes, const cmh_taps* taps, void* stream,
+                            int32_t* packed_rows_out = nullptr) {
   CMH_CHECK_ARG(w && tokens && (feat || tokens_out) && workspace, "text_encode: null pointer");
   CMH_CHECK_ARG(batch > 0 && seq_len > 0, "text_encode: batch %d seq_len %d", batch, seq_len);
   int rc = check_tower(w->gemm_dtype, w->width, w->layers, w->embed_dim, w->blocks);
@@ -210,11 +211,39 @@ static int text_encode_impl(const cmh_text_weights* w, const int64_t* tokens, in
   TowerBufs t = carve(workspace, static_cast<size_t>(M), B, d, e, 0, 0);
   t.xh = resid_f16(dt, d, taps);
 
+  // Packed mode (pooled output only): under the causal mask nothing after a caption's EOT can reach the EOT row that
+  // encode_text returns (model.py:366-370), so only the tokens 0..EOT of every caption are embedded and run through the
+  // blocks - rows [seq_off[b], seq_off[b+1]) of one packed matrix; every kept row goes through exactly the arithmetic of
+  // the dense path (row-wise kernels, per-row dot products, attention over the same key tiles), so the features are
+  // bit-identical.  The row count is read back once (the GEMM grids need it on the host).
+  const int32_t* seq_off = nullptr;
+  int rows = M;
+  if (packed_rows_out) {
+    CMH_CHECK_ARG(!key_padding_mask && !tokens_out && !taps, "text_encode_packed: pooled features only, no mask / taps");
+    int32_t* so = static_cast<int32_t*>(t.pool) ;   // pool [B,d] e is free until the final LayerNorm: B+1 ints fit (d >= 128)
+    if ((rc = launch_text_pack_plan(tokens, B, L, so, st))) return rc;
+    int32_t total = 0;
+    if (hipMemcpyAsync(&total, so + B, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+      return fail(CMH_ERR_LAUNCH, "text_encode_packed: reading the packed row count failed");
+    // the offsets must outlive the pool buffer's reuse: keep them at the tail of the mlp scratch (M*4d*e bytes, rows*4d*e used)
+    int32_t* keep = reinterpret_cast<int32_t*>(static_cast<char*>(t.mlp) + static_cast<size_t>(M) * 4 * d * e - align_up(static_cast<size_t>(B + 1) * 4, 256));
+    CMH_CHECK_ARG(total > 0 && total <= M, "text_encode_packed: bad packed row count %d", total);
+    if (static_cast<size_t>(total) * 4 * d * e + align_up(static_cast<size_t>(B + 1) * 4, 256) > static_cast<size_t>(M) * 4 * d * e) {
+      seq_off = nullptr;                    // (almost) nothing to skip: run dense
+    } else {
+      if (hipMemcpyAsync(keep, so, static_cast<size_t>(B + 1) * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return fail(CMH_ERR_LAUNCH, "text_encode_packed: copy failed");
+      seq_off = keep;
+      rows = total;
+    }
+    *packed_rows_out = rows;
+  }
+
   // token_embedding gather + positional_embedding[:L]; EOT row = argmax(tokens)  (model.py:360-362,370)
-  if ((rc = launch_text_embed(tokens, w->token_embedding, w->positional_embedding, t.x, t.xh, t.rows, B, L, d,
-                              w->vocab_size, st))) return rc;
+  if ((rc = launch_text_embed_packed(tokens, w->token_embedding, w->positional_embedding, t.x, t.xh, t.rows, B, L, d,
+                                     w->vocab_size, seq_off, st))) return rc;
   for (int i = 0; i < w->layers; ++i) {
-    if ((rc = run_block(w->blocks[i], dt, t, B, L, d, /*causal=*/1, key_padding_mask, st))) return rc;
+    if ((rc = run_block(w->blocks[i], dt, t, B, L, d, /*causal=*/1, key_padding_mask, st, rows, seq_off))) return rc;
     if ((rc = tap(taps, 1 + i, t.x, static_cast<size_t>(M) * d * 4, st))) return rc;
   }
   if (tokens_out) {
@@ -239,6 +268,13 @@ extern "C" int cmh_text_encode(const cmh_text_weights* w, const int64_t* tokens,
   CMH_CHECK_ARG(feat, "text_encode: null pointer");
   return text_encode_impl(w, tokens, batch, seq_len, key_padding_mask, feat, nullptr, nullptr, workspace,
                           workspace_bytes, taps, stream);
+}
+
+extern "C" int cmh_text_encode_packed(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len, float* feat,
+                                      int32_t* rows_computed, void* workspace, size_t workspace_bytes, void* stream) {
+  CMH_CHECK_ARG(feat && rows_computed, "text_encode_packed: null pointer");
+  return text_encode_impl(w, tokens, batch, seq_len, nullptr, feat, nullptr, nullptr, workspace, workspace_bytes, nullptr, stream,
+                          rows_computed);
 }
 
 extern "C" int cmh_text_encode_tokens(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,

@@ -296,16 +296,21 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int64_t* __restri
                                                          const float* __restrict__ tok_emb,
                                                          const float* __restrict__ pos, void* __restrict__ x,
                                                          int x_f16, int32_t* __restrict__ eot_row, int B, int L, int d,
-                                                         int vocab) {
+                                                         int vocab, const int32_t* __restrict__ seq_off) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= B * L) return;
   const int b = row / L, t = row - b * L;
+  if (seq_off) {                           // packed: only the tokens up to the EOT exist, sequence b = rows [seq_off[b], seq_off[b+1])
+    if (t >= seq_off[b + 1] - seq_off[b]) return;
+    if (t == 0 && lane == 0) eot_row[b] = seq_off[b + 1] - 1;
+  }
+  const int orow = seq_off ? seq_off[b] + t : row;
   int64_t id = tokens[row];
   id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);   // out-of-vocabulary ids would fault; clamp
   const float* er = tok_emb + static_cast<size_t>(id) * d;
   const float* pr = pos + static_cast<size_t>(t) * d;
-  char* xr = static_cast<char*>(x) + static_cast<size_t>(row) * d * (x_f16 ? 2 : 4);
+  char* xr = static_cast<char*>(x) + static_cast<size_t>(orow) * d * (x_f16 ? 2 : 4);
   for (int e0 = lane * 4; e0 < d; e0 += 256) {
     const float4 a = *reinterpret_cast<const float4*>(er + e0);
     const float4 q = *reinterpret_cast<const float4*>(pr + e0);
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int64_t* __restri
     else
       *reinterpret_cast<float4*>(reinterpret_cast<float*>(xr) + e0) = y;
   }
-  if (t == 0) {   // this wave also finds argmax over the caption (first maximum, like torch.argmax)
+  if (t == 0 && !seq_off) {   // this wave also finds argmax over the caption (first maximum, like torch.argmax)
     int64_t best = INT64_MIN;
     int besti = 0;
     for (int i = lane; i < L; i += 64) {
@@ -332,12 +337,49 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int64_t* __restri
   }
 }
 
+// seq_off[b] = sum_{b' < b} (argmax(tokens[b']) + 1): the packed row offsets of encode_text without padding.  One workgroup.
+__global__ __launch_bounds__(256) void text_pack_plan_kernel(const int64_t* __restrict__ tokens, int B, int L,
+                                                             int32_t* __restrict__ seq_off) {
+  __shared__ int part[256];
+  // thread i owns the contiguous captions [i*per, (i+1)*per)
+  const int per = (B + 255) / 256;
+  const int b0 = threadIdx.x * per, b1 = b0 + per < B ? b0 + per : B;
+  int sum = 0;
+  for (int b = b0; b < b1; ++b) {
+    int64_t best = INT64_MIN; int besti = 0;
+    for (int i = 0; i < L; ++i) { const int64_t v = tokens[static_cast<size_t>(b) * L + i]; if (v > best) { best = v; besti = i; } }
+    seq_off[b + 1] = besti + 1;           // length, turned into an offset below
+    sum += besti + 1;
+  }
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int i = 0; i < 256; ++i) { const int v = part[i]; part[i] = run; run += v; }
+    seq_off[0] = 0;
+  }
+  __syncthreads();
+  int run = part[threadIdx.x];
+  for (int b = b0; b < b1; ++b) { run += seq_off[b + 1]; seq_off[b + 1] = run; }
+}
+
+int launch_text_pack_plan(const int64_t* tokens, int B, int L, int32_t* seq_off, hipStream_t st) {
+  hipLaunchKernelGGL(text_pack_plan_kernel, dim3(1), dim3(256), 0, st, tokens, B, L, seq_off);
+  CMH_CHECK_LAUNCH("text_pack_plan");
+  return CMH_OK;
+}
+
 int launch_text_embed(const int64_t* tokens, const float* tok_emb, const float* pos, void* x, int x_f16, int32_t* eot_row,
                       int B, int L, int d, int vocab, hipStream_t st) {
+  return launch_text_embed_packed(tokens, tok_emb, pos, x, x_f16, eot_row, B, L, d, vocab, nullptr, st);
+}
+
+int launch_text_embed_packed(const int64_t* tokens, const float* tok_emb, const float* pos, void* x, int x_f16, int32_t* eot_row,
+                             int B, int L, int d, int vocab, const int32_t* seq_off, hipStream_t st) {
   CMH_CHECK_ARG(d % 4 == 0, "text_embed: width %d unsupported", d);
   const int rows = B * L;
   hipLaunchKernelGGL(text_embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, tokens, tok_emb, pos, x, x_f16,
-                     eot_row, B, L, d, vocab);
+                     eot_row, B, L, d, vocab, seq_off);
   CMH_CHECK_LAUNCH("text_embed");
   return CMH_OK;
 }

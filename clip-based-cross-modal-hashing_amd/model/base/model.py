@@ -207,6 +207,11 @@ class CLIP(nn.Module):
         self._gemm_dtype = _DT[name.lower()]
         return self
 
+    # encode_text skips the padding after each caption's EOT (bit-identical pooled features, cmh_text_encode_packed);
+    # CMH_TEXT_PACK=0 or `clip.pack_text = False` computes all context_length positions like the reference
+    pack_text = os.environ.get("CMH_TEXT_PACK", "1") != "0"
+    last_text_rows = None
+
     @property
     def gemm_dtype(self) -> str:
         return "bf16" if self._gemm_dtype == N.BF16 else "f32"
@@ -312,6 +317,13 @@ class CLIP(nn.Module):
         feat = torch.empty(B, s.embed_dim, dtype=torch.float32, device=text.device)
         need = N.lib().cmh_text_workspace_bytes(C.byref(s), B, L)
         ws = N.workspace(need, text.device, "text")
+        if kpm is None and taps is None and self.pack_text:
+            # only the tokens up to each caption's EOT can reach the pooled row under the causal mask: skip the padding
+            rows = C.c_int32(0)
+            N.check(N.lib().cmh_text_encode_packed(C.byref(s), N.ptr(text), B, L, N.ptr(feat), C.byref(rows), N.ptr(ws), ws.numel(),
+                                                   N.stream_ptr(text.device)), "cmh_text_encode_packed")
+            self.last_text_rows = (rows.value, B * L)
+            return no_backward(feat, self.text_projection)
         tp, _arr = self._taps(taps)
         N.check(N.lib().cmh_text_encode(C.byref(s), N.ptr(text), B, L, N.ptr(kpm), N.ptr(feat), N.ptr(ws), ws.numel(),
                                         None if tp is None else C.byref(tp), N.stream_ptr(text.device)),

@@ -126,6 +126,13 @@ int cmh_text_encode(const cmh_text_weights* w, const int64_t* tokens, int32_t ba
                     const uint8_t* key_padding_mask, float* feat, void* workspace,
                     size_t workspace_bytes, const cmh_taps* taps, void* stream);
 
+/* encode_text without the padding: under the causal mask (model/base/model.py:340-346) no token after a caption's EOT can
+ * influence the EOT row that encode_text returns (:366-370), so only the tokens 0..EOT of every caption are computed, packed
+ * into one matrix of rows_computed <= batch*seq_len rows.  `feat` is bit-identical to cmh_text_encode's.  Synchronises the
+ * stream once (the packed row count sizes the GEMM grids).  Same workspace as cmh_text_encode. */
+int cmh_text_encode_packed(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len, float* feat,
+                           int32_t* rows_computed, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Building blocks of the towers, exported for unit-level parity tests and for heads that want them.
  * ------------------------------------------------------------------------------------------- */

@@ -115,3 +115,26 @@ def test_backward_is_native_or_fails_loudly():
     m.assume_frozen = True
     with pytest.raises(NotImplementedError):
         m.encode_text(txt).sum().backward()
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_packed_text_encode_is_bit_identical(mode):
+    """cmh_text_encode_packed (no padding rows) == cmh_text_encode, bit for bit, ViT-B/32-sized text tower, ragged captions
+    (one full-length, one of 3 tokens)."""
+    cfg = recipe.CLIP_VITB32
+    torch.manual_seed(9)
+    from model.base.model import CLIP
+    m = CLIP(**cfg).to(DEV).float().set_gemm_dtype(mode)
+    m.assume_frozen = True
+    txt = recipe.captions(12, 77, cfg["vocab_size"], 5)
+    txt[1] = 0
+    txt[1, 0], txt[1, 1], txt[1, 2] = cfg["vocab_size"] - 2, 17, cfg["vocab_size"] - 1      # shortest possible caption
+    t = torch.from_numpy(txt).to(DEV)
+    with torch.no_grad():
+        m.pack_text = False
+        dense = m.encode_text(t)
+        m.pack_text = True
+        packed = m.encode_text(t)
+    rows, total = m.last_text_rows
+    assert rows == int((txt.argmax(1) + 1).sum()) and total == 12 * 77 and rows < total
+    assert torch.equal(dense, packed)
