@@ -23,9 +23,13 @@ template <> __device__ __forceinline__ void ab_st<bf16_t>(bf16_t* p, size_t i, f
 
 template <typename T>
 __global__ __launch_bounds__(256) void attention_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
-                                                            const T* __restrict__ dout, T* __restrict__ dqkv, int B, int Tn,
-                                                            int d, int causal, const uint8_t* __restrict__ kpm) {
+                                                            const T* __restrict__ dout, T* __restrict__ dqkv, int B, int Tmax,
+                                                            int d, int causal, const uint8_t* __restrict__ kpm,
+                                                            const int32_t* __restrict__ seq_off) {
   extern __shared__ float smem[];
+  // packed variable-length sequences: sequence b = rows [seq_off[b], seq_off[b+1]) (LDS is sized for Tmax)
+  const int heads0 = d / HDB, b0 = blockIdx.x / heads0;
+  const int Tn = seq_off ? seq_off[b0 + 1] - seq_off[b0] : Tmax;
   float* bufA = smem;                       // [Tn][65]
   float* bufB = bufA + Tn * 65;             // [Tn][65]
   float* S = bufB + Tn * 65;                // [Tn][Tn+1]
@@ -34,7 +38,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const T* __restrict_
   const int heads = d / HDB;
   const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
   const size_t ld = static_cast<size_t>(3) * d;
-  const size_t rowq = static_cast<size_t>(b) * Tn;
+  const size_t rowq = seq_off ? static_cast<size_t>(seq_off[b]) : static_cast<size_t>(b) * Tmax;
   const T* qb = qkv + rowq * ld + h * HDB;            // q: +0, k: +d, v: +2d
   const T* ob = o + rowq * d + h * HDB;
   const T* dob = dout + rowq * d + h * HDB;
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const T* __restrict_
 #pragma unroll 16
     for (int c = 0; c < HDB; ++c) acc += bufA[i * 65 + c] * bufB[j * 65 + c];
     bool ok = !(causal && j > i);
-    if (ok && kpm) ok = kpm[static_cast<size_t>(b) * Tn + j] == 0;
+    if (ok && kpm) ok = kpm[rowq + j] == 0;
     S[i * ST + j] = ok ? acc * 0.125f : -1e30f;
   }
   __syncthreads();
@@ -167,8 +171,8 @@ __device__ __forceinline__ float ab_row_sum(float v) {
 
 template <int NT>    // row tiles: TR = 16 * NT rows, contraction over rows padded to KP = 32 * ceil(NT / 2)
 __global__ __launch_bounds__(256) void attention_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                                 bf16_t* __restrict__ dqkv, int B, int Tn, int d, int causal,
-                                                                 const uint8_t* __restrict__ kpm) {
+                                                                 bf16_t* __restrict__ dqkv, int B, int Tmax, int d, int causal,
+                                                                 const uint8_t* __restrict__ kpm, const int32_t* __restrict__ seq_off) {
   constexpr int TR = NT * 16, KP = ((NT + 1) / 2) * 32;
   constexpr int LR = 72;            // leading dimension of the [rows][64] matrices (144 B rows)
   constexpr int LT = KP + 8;        // leading dimension of the [..][KP] matrices
@@ -189,7 +193,8 @@ __global__ __launch_bounds__(256) void attention_bwd_mfma_kernel(const bf16_t* _
   const int heads = d / HDB;
   const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
   const size_t ld = static_cast<size_t>(3) * d;
-  const size_t row0 = static_cast<size_t>(b) * Tn;
+  const int Tn = seq_off ? seq_off[b + 1] - seq_off[b] : Tmax;
+  const size_t row0 = seq_off ? static_cast<size_t>(seq_off[b]) : static_cast<size_t>(b) * Tmax;
   const bf16_t* qb = qkv + row0 * ld + h * HDB;
   const bf16_t* dob = dout + row0 * d + h * HDB;
   bf16_t* dqb = dqkv + row0 * ld + h * HDB;
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(256) void attention_bwd_mfma_kernel(const bf16_t* _
     for (int tj = 0; tj < NT; ++tj) {
       const int key = tj * 16 + c;
       bool kok = key < Tn;
-      if (kok && kpm) kok = kpm[static_cast<size_t>(b) * Tn + key] == 0;
+      if (kok && kpm) kok = kpm[row0 + key] == 0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int q = ti * 16 + 4 * g + r;
@@ -297,26 +302,26 @@ __global__ __launch_bounds__(256) void attention_bwd_mfma_kernel(const bf16_t* _
 
 template <int NT>
 static int launch_attention_bwd_mfma(const void* qkv, const void* dout, void* dqkv, int B, int T, int d, int causal,
-                                     const uint8_t* kpm, hipStream_t st) {
+                                     const uint8_t* kpm, const int32_t* seq_off, hipStream_t st) {
   constexpr int TR = NT * 16, KP = ((NT + 1) / 2) * 32;
   const size_t lds = (static_cast<size_t>(4) * TR * 72 + 3 * 64 * (KP + 8) + 3 * TR * (KP + 8)) * 2;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_mfma_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           static_cast<int>(lds)) != hipSuccess) return fail(CMH_ERR_LAUNCH, "attention_backward: cannot reserve %zu bytes of LDS", lds);
   hipLaunchKernelGGL(attention_bwd_mfma_kernel<NT>, dim3(B * (d / HDB)), dim3(256), lds, st, static_cast<const bf16_t*>(qkv),
-                     static_cast<const bf16_t*>(dout), static_cast<bf16_t*>(dqkv), B, T, d, causal, kpm);
+                     static_cast<const bf16_t*>(dout), static_cast<bf16_t*>(dqkv), B, T, d, causal, kpm, seq_off);
   return CMH_OK;
 }
 
 int launch_attention_bwd_bf16(const void* qkv, const void* dout, void* dqkv, int B, int T, int d, int causal, const uint8_t* kpm,
-                              hipStream_t st) {
+                              const int32_t* seq_off, hipStream_t st) {
   const int nt = (T + 15) / 16;
   switch (nt) {
-    case 1: return launch_attention_bwd_mfma<1>(qkv, dout, dqkv, B, T, d, causal, kpm, st);
-    case 2: return launch_attention_bwd_mfma<2>(qkv, dout, dqkv, B, T, d, causal, kpm, st);
-    case 3: return launch_attention_bwd_mfma<3>(qkv, dout, dqkv, B, T, d, causal, kpm, st);
-    case 4: return launch_attention_bwd_mfma<4>(qkv, dout, dqkv, B, T, d, causal, kpm, st);
-    case 5: return launch_attention_bwd_mfma<5>(qkv, dout, dqkv, B, T, d, causal, kpm, st);
-    case 6: return launch_attention_bwd_mfma<6>(qkv, dout, dqkv, B, T, d, causal, kpm, st);
+    case 1: return launch_attention_bwd_mfma<1>(qkv, dout, dqkv, B, T, d, causal, kpm, seq_off, st);
+    case 2: return launch_attention_bwd_mfma<2>(qkv, dout, dqkv, B, T, d, causal, kpm, seq_off, st);
+    case 3: return launch_attention_bwd_mfma<3>(qkv, dout, dqkv, B, T, d, causal, kpm, seq_off, st);
+    case 4: return launch_attention_bwd_mfma<4>(qkv, dout, dqkv, B, T, d, causal, kpm, seq_off, st);
+    case 5: return launch_attention_bwd_mfma<5>(qkv, dout, dqkv, B, T, d, causal, kpm, seq_off, st);
+    case 6: return launch_attention_bwd_mfma<6>(qkv, dout, dqkv, B, T, d, causal, kpm, seq_off, st);
     default: return 1;       // T > 96: the LDS image (208 / 230 KB) does not fit -> caller uses the fp32 VALU kernel
   }
 }
@@ -325,32 +330,37 @@ int launch_attention_bwd_bf16(const void* qkv, const void* dout, void* dqkv, int
 
 using namespace cmh;
 
-extern "C" int cmh_attention_backward(int32_t dtype, const void* qkv, const void* o, const void* dout, void* dqkv, int32_t B,
-                                      int32_t T, int32_t d, int32_t causal, const uint8_t* key_padding_mask, void* stream) {
+namespace cmh {
+int launch_attention_backward(int dtype, const void* qkv, const void* o, const void* dout, void* dqkv, int B, int T, int d, int causal,
+                              const uint8_t* key_padding_mask, const int32_t* seq_off, hipStream_t st) {
   CMH_CHECK_ARG(qkv && o && dout && dqkv && B > 0 && T > 0, "attention_backward: bad arguments");
   CMH_CHECK_ARG(dtype == CMH_F32 || dtype == CMH_BF16, "attention_backward: bad dtype");
   CMH_CHECK_ARG(d % HDB == 0, "attention_backward: width %d is not a multiple of 64", d);
   CMH_CHECK_ARG(T <= 128, "attention_backward: T=%d > 128 is not built (both CLIP towers have T <= 77)", T);
   const size_t lds = (static_cast<size_t>(2) * T * 65 + static_cast<size_t>(T) * (T + 1) + T) * 4;
   const dim3 grid(B * (d / HDB));
-  hipStream_t st = as_stream(stream);
   if (dtype == CMH_F32) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             static_cast<int>(lds)) != hipSuccess) return fail(CMH_ERR_LAUNCH, "attention_backward: LDS");
     hipLaunchKernelGGL(attention_bwd_kernel<float>, grid, dim3(256), lds, st, static_cast<const float*>(qkv),
                        static_cast<const float*>(o), static_cast<const float*>(dout), static_cast<float*>(dqkv), B, T, d, causal,
-                       key_padding_mask);
+                       key_padding_mask, seq_off);
   } else if (T <= 96 && !getenv("CMH_ATTN_BWD_VALU")) {
-    const int rc = launch_attention_bwd_bf16(qkv, dout, dqkv, B, T, d, causal, key_padding_mask, st);
+    const int rc = launch_attention_bwd_bf16(qkv, dout, dqkv, B, T, d, causal, key_padding_mask, seq_off, st);
     if (rc) return rc;
   } else {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             static_cast<int>(lds)) != hipSuccess) return fail(CMH_ERR_LAUNCH, "attention_backward: LDS");
     hipLaunchKernelGGL(attention_bwd_kernel<bf16_t>, grid, dim3(256), lds, st, static_cast<const bf16_t*>(qkv),
                        static_cast<const bf16_t*>(o), static_cast<const bf16_t*>(dout), static_cast<bf16_t*>(dqkv), B, T, d,
-                       causal, key_padding_mask);
+                       causal, key_padding_mask, seq_off);
   }
   CMH_CHECK_LAUNCH("attention_backward");
   return CMH_OK;
 }
+}  // namespace cmh
 
+extern "C" int cmh_attention_backward(int32_t dtype, const void* qkv, const void* o, const void* dout, void* dqkv, int32_t B,
+                                      int32_t T, int32_t d, int32_t causal, const uint8_t* key_padding_mask, void* stream) {
+  return cmh::launch_attention_backward(dtype, qkv, o, dout, dqkv, B, T, d, causal, key_padding_mask, nullptr, as_stream(stream));
+}

@@ -148,6 +148,9 @@ int launch_gemm_wide_splitk(int dt, const void* A, const void* W, float* out, fl
 int launch_layernorm_any(const void* x, int x_kind, const int32_t* row_index, const float* w, const float* b, void* out,
                          int out_kind, int M, int d, hipStream_t st);
 int launch_vit_assemble(const float* patch_out, const float* cls, const float* pos, float* x, int B, int g2, int d, hipStream_t st);
+// attention_bwd.hip: backward of launch_attention_varlen (seq_off may be NULL)
+int launch_attention_backward(int dtype, const void* qkv, const void* o, const void* dout, void* dqkv, int B, int T, int d, int causal,
+                              const uint8_t* key_padding_mask, const int32_t* seq_off, hipStream_t st);
 // backward.hip: dst[c*dst_ld + r] = cast(src[r*cols + c]); LayerNorm backward with optional gathered rows (x / dx rows = row_index[r])
 int launch_transpose(const void* src, int skind, void* dst, int dkind, int rows, int cols, int dst_ld, hipStream_t st);
 int launch_layernorm_backward(const void* x, int x_kind, const void* dy, int dy_kind, const float* gamma, const int32_t* row_index,

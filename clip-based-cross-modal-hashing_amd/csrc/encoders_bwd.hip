@@ -48,6 +48,7 @@ struct TrainBufs {
   float* x_pre;        // vision: [M,d] f32 tokens + positional before ln_pre;   text: unused
   float* patch_out;    // vision: [B*g2, d] f32
   int32_t* rows;       // [B] pooled row of every sample
+  int32_t* seq_off;    // [B+1] packed text: row offsets of the captions (tokens 0..EOT only)
   void* pool;          // [B,d] e    ln_post / ln_final of the pooled rows
   // scratch
   float* dx;           // [M,d] f32 gradient stream
@@ -90,6 +91,7 @@ TrainBufs carve_train(void* ws, size_t M, size_t B, size_t d, size_t e, size_t x
   t.x_pre = a.take<float>(g2rows ? M * d * 4 : 0);
   t.patch_out = a.take<float>(g2rows * d * 4);
   t.rows = a.take<int32_t>(B * 4);
+  t.seq_off = a.take<int32_t>((B + 1) * 4);
   t.pool = a.take(B * d * e);
   t.dx = a.take<float>(M * d * 4);
   t.dx2 = a.take<float>(M * d * 4);
@@ -137,14 +139,14 @@ int as_gemm_operand(int dt, const float* x, void* scratch, size_t n, hipStream_t
 struct BlockGradPtrs { float *in_w, *in_b, *out_w, *out_b, *ln1_w, *ln1_b, *ln2_w, *ln2_b, *fc_w, *fc_b, *proj_w, *proj_b; };
 
 int block_forward_train(const cmh_block_weights& w, int dt, int xh, const LayerTape& L, void* x_next, void* mlp, int B, int T,
-                        int d, int causal, const uint8_t* kpm, hipStream_t st) {
-  const int M = B * T;
+                        int d, int causal, const uint8_t* kpm, hipStream_t st, int rows = -1, const int32_t* seq_off = nullptr) {
+  const int M = rows >= 0 ? rows : B * T;
   const int obf = dt == CMH_BF16 ? EPI_OUT_BF16 : 0;
   const int rx = EPI_BIAS | EPI_RESIDUAL | (xh ? EPI_RES_F16 | EPI_OUT_F16 : 0);
   int rc;
   if ((rc = launch_layernorm_x(L.x_in, xh, nullptr, w.ln1_w, w.ln1_b, L.h1, dt == CMH_BF16, M, d, st))) return rc;
   if ((rc = launch_gemm(dt, L.h1, w.in_proj_w, w.in_proj_b, nullptr, L.qkv, M, 3 * d, d, EPI_BIAS | obf, st))) return rc;
-  if ((rc = launch_attention(L.qkv, L.attn, dt, B, T, d, causal, kpm, st))) return rc;
+  if ((rc = launch_attention_varlen(L.qkv, L.attn, dt, B, T, d, causal, kpm, seq_off, st))) return rc;
   if ((rc = launch_gemm(dt, L.attn, w.out_proj_w, w.out_proj_b, static_cast<const float*>(L.x_in), L.x_mid, M, d, d, rx, st))) return rc;
   if ((rc = launch_layernorm_x(L.x_mid, xh, nullptr, w.ln2_w, w.ln2_b, L.h2, dt == CMH_BF16, M, d, st))) return rc;
   if ((rc = launch_gemm(dt, L.h2, w.fc_w, w.fc_b, nullptr, L.pre, M, 4 * d, d, EPI_BIAS | obf, st))) return rc;
@@ -185,8 +187,8 @@ int dgrad(int dt, const void* dYe, const void* W, int O, int I, int M, const voi
 }
 
 int block_backward(const cmh_block_weights& w, const BlockGradPtrs& g, int dt, int xh, const LayerTape& L, TrainBufs& t, int B,
-                   int T, int d, int causal, const uint8_t* kpm, hipStream_t st) {
-  const int M = B * T;
+                   int T, int d, int causal, const uint8_t* kpm, hipStream_t st, int rows = -1, const int32_t* seq_off = nullptr) {
+  const int M = rows >= 0 ? rows : B * T;
   const int obf = dt == CMH_BF16 ? EPI_OUT_BF16 : 0;
   const int ek = ekind(dt), xk = xkind(xh);
   const size_t md = static_cast<size_t>(M) * d;
@@ -207,7 +209,7 @@ int block_backward(const cmh_block_weights& w, const BlockGradPtrs& g, int dt, i
   if ((rc = dgrad(dt, dxe, w.out_proj_w, d, d, M, nullptr, t.dh, obf, t, st))) return rc;
   if ((rc = wgrad(dt, t.dx, kF32, d, L.attn, ek, d, M, g.out_w, g.out_b, t, st))) return rc;
   // 5. attention
-  if ((rc = cmh_attention_backward(dt, L.qkv, L.attn, t.dh, t.dqkv, B, T, d, causal, kpm, st))) return rc;
+  if ((rc = launch_attention_backward(dt, L.qkv, L.attn, t.dh, t.dqkv, B, T, d, causal, kpm, seq_off, st))) return rc;
   // 6. in_proj
   if ((rc = dgrad(dt, t.dqkv, w.in_proj_w, 3 * d, d, M, nullptr, t.dh, obf, t, st))) return rc;
   if ((rc = wgrad(dt, t.dqkv, ek, 3 * d, L.h1, ek, d, M, g.in_w, g.in_b, t, st))) return rc;
@@ -284,6 +286,37 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __res
   int64_t id = tokens[r];
   id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
   for (int c = threadIdx.x; c < d; c += 256) atomicAdd(dE + static_cast<size_t>(id) * d + c, dx[static_cast<size_t>(r) * d + c]);
+}
+
+// packed text: the training tower follows encode_text's packing rule (no mask, CMH_TEXT_PACK != 0)
+bool text_packing(const uint8_t* kpm) {
+  static const bool off = []() { const char* e = getenv("CMH_TEXT_PACK"); return e && !strcmp(e, "0"); }();
+  return !kpm && !off;
+}
+
+// dpos[t, :] = sum over the captions that have a token t of dx[seq_off[b] + t, :]   (deterministic: fixed caption order)
+__global__ __launch_bounds__(256) void packed_dpos_kernel(const float* __restrict__ dx, const int32_t* __restrict__ seq_off, int B, int d,
+                                                          float* __restrict__ dpos) {
+  const int t = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= d) return;
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const int o = seq_off[b];
+    if (t < seq_off[b + 1] - o) acc += dx[static_cast<size_t>(o + t) * d + c];
+  }
+  dpos[static_cast<size_t>(t) * d + c] = acc;
+}
+
+// token embedding from packed rows: dE[tokens[b, t], :] += dx[seq_off[b] + t, :]
+__global__ __launch_bounds__(256) void packed_embed_scatter_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ dx,
+                                                                   const int32_t* __restrict__ seq_off, float* __restrict__ dE, int B,
+                                                                   int L, int d, int vocab) {
+  const int b = blockIdx.x / L, t = blockIdx.x - b * L;
+  if (t >= seq_off[b + 1] - seq_off[b]) return;
+  int64_t id = tokens[blockIdx.x];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const size_t r = static_cast<size_t>(seq_off[b] + t);
+  for (int c = threadIdx.x; c < d; c += 256) atomicAdd(dE + static_cast<size_t>(id) * d + c, dx[r * d + c]);
 }
 
 int zero_pad_buffers(TrainBufs& t, size_t M, hipStream_t st) {
@@ -428,10 +461,23 @@ extern "C" int cmh_text_forward_train(const cmh_text_weights* w, const int64_t* 
   const size_t e = dt == CMH_BF16 ? 2 : 4;
   hipStream_t st = as_stream(stream);
   TrainBufs t = carve_train(tape, static_cast<size_t>(M), B, d, e, xh ? 2 : 4, w->layers, 0, 0, w->embed_dim);
-  if ((rc = launch_text_embed(tokens, w->token_embedding, w->positional_embedding, t.L[0].x_in, xh, t.rows, B, L, d, w->vocab_size, st))) return rc;
+  // packed like encode_text (encoders.hip): only the tokens 0..EOT of every caption are run through the blocks
+  const int32_t* seq_off = nullptr;
+  int rows = M;
+  if (text_packing(key_padding_mask)) {
+    if ((rc = launch_text_pack_plan(tokens, B, L, t.seq_off, st))) return rc;
+    int32_t total = 0;
+    if (hipMemcpyAsync(&total, t.seq_off + B, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+      return fail(CMH_ERR_LAUNCH, "text_forward_train: reading the packed row count failed");
+    CMH_CHECK_ARG(total > 0 && total <= M, "text_forward_train: bad packed row count %d", total);
+    seq_off = t.seq_off;
+    rows = total;
+  }
+  if ((rc = launch_text_embed_packed(tokens, w->token_embedding, w->positional_embedding, t.L[0].x_in, xh, t.rows, B, L, d,
+                                     w->vocab_size, seq_off, st))) return rc;
   for (int i = 0; i < w->layers; ++i) {
     void* nxt = i + 1 < w->layers ? t.L[i + 1].x_in : t.x_last;
-    if ((rc = block_forward_train(w->blocks[i], dt, xh, t.L[i], nxt, t.mlp, B, L, d, 1, key_padding_mask, st))) return rc;
+    if ((rc = block_forward_train(w->blocks[i], dt, xh, t.L[i], nxt, t.mlp, B, L, d, 1, key_padding_mask, st, rows, seq_off))) return rc;
   }
   if ((rc = launch_layernorm_x(t.x_last, xh, t.rows, w->ln_final_w, w->ln_final_b, t.pool, dt == CMH_BF16, B, d, st))) return rc;
   const int bk = dt == CMH_F32 ? 32 : 64;
@@ -455,17 +501,33 @@ extern "C" int cmh_text_backward(const cmh_text_weights* w, const int64_t* token
   const size_t e = dt == CMH_BF16 ? 2 : 4;
   hipStream_t st = as_stream(stream);
   TrainBufs t = carve_train(tape, static_cast<size_t>(M), B, d, e, xh ? 2 : 4, w->layers, 0, 0, E);
-  if ((rc = zero_pad_buffers(t, static_cast<size_t>(M), st))) return rc;
+  const int32_t* seq_off = nullptr;
+  int rows = M;
+  if (text_packing(key_padding_mask)) {       // same rule as the forward call that filled this tape
+    int32_t total = 0;
+    if (hipMemcpyAsync(&total, t.seq_off + B, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+      return fail(CMH_ERR_LAUNCH, "text_backward: reading the packed row count failed");
+    CMH_CHECK_ARG(total > 0 && total <= M, "text_backward: the tape holds no packed plan (row count %d)", total);
+    seq_off = t.seq_off;
+    rows = total;
+  }
+  if ((rc = zero_pad_buffers(t, static_cast<size_t>(rows), st))) return rc;
   if ((rc = pooled_backward(dt, xh, t.x_last, t.rows, t.pool, w->text_projection_t, w->ln_final_w, dfeat, gr->text_projection,
-                            gr->ln_final_w, gr->ln_final_b, t, B, M, d, E, st))) return rc;
+                            gr->ln_final_w, gr->ln_final_b, t, B, rows, d, E, st))) return rc;
   for (int i = w->layers - 1; i >= 0; --i)
-    if ((rc = block_backward(w->blocks[i], grads_of(gr->blocks[i]), dt, xh, t.L[i], t, B, L, d, 1, key_padding_mask, st))) return rc;
+    if ((rc = block_backward(w->blocks[i], grads_of(gr->blocks[i]), dt, xh, t.L[i], t, B, L, d, 1, key_padding_mask, st, rows, seq_off))) return rc;
   // x_0[b, t] = token_embedding[tokens[b, t]] + positional_embedding[t]
   if (hipMemsetAsync(gr->positional_embedding, 0, static_cast<size_t>(w->context_length) * d * 4, st) != hipSuccess ||
       hipMemsetAsync(gr->token_embedding, 0, static_cast<size_t>(w->vocab_size) * d * 4, st) != hipSuccess)
     return fail(CMH_ERR_LAUNCH, "text_backward: memset failed");
-  if ((rc = cmh_colsum(t.dx, kF32, B, L * d, gr->positional_embedding, t.red, t.red_bytes, st))) return rc;
-  hipLaunchKernelGGL(embed_scatter_kernel, dim3(M), dim3(256), 0, st, tokens, t.dx, gr->token_embedding, M, d, w->vocab_size);
+  if (seq_off) {
+    hipLaunchKernelGGL(packed_dpos_kernel, dim3(L, (d + 255) / 256), dim3(256), 0, st, t.dx, seq_off, B, d, gr->positional_embedding);
+    hipLaunchKernelGGL(packed_embed_scatter_kernel, dim3(M), dim3(256), 0, st, tokens, t.dx, seq_off, gr->token_embedding, B, L, d,
+                       w->vocab_size);
+  } else {
+    if ((rc = cmh_colsum(t.dx, kF32, B, L * d, gr->positional_embedding, t.red, t.red_bytes, st))) return rc;
+    hipLaunchKernelGGL(embed_scatter_kernel, dim3(M), dim3(256), 0, st, tokens, t.dx, gr->token_embedding, M, d, w->vocab_size);
+  }
   CMH_CHECK_LAUNCH("embedding scatter");
   return CMH_OK;
 }
