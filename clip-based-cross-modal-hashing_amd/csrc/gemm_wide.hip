@@ -21,6 +21,8 @@
 // Everything else as in gemm_glds.hip: W rows feed the MFMA A operand (lane owns 4 consecutive n), lane-linear LDS
 // image with the XOR swizzle on the DMA source chunk and on the ds_read_b128, fused epilogue, XCD-aware tile order
 // (workgroups with equal blockIdx%8 share an XCD and take neighbouring tiles of one contiguous range, n fastest).
+#include <cstdlib>
+
 #include "cmh_common.h"
 
 #include <type_traits>
@@ -54,11 +56,18 @@ typedef __attribute__((address_space(3))) void* w_lptr_t;
 __device__ unsigned g_wide_stamps[256 * 8 * 4];
 #endif
 
-template <bool F32, bool OUTBF>
+template <bool F32, bool OUTBF, int MF>   // MF = 16-row m-fragments per wave: tile rows = 32*MF (160, or 128 when that quantises better)
 __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__ X, const char* __restrict__ W,
                                                         const float* __restrict__ bias, const float* residual,
                                                         void* out, int M, int N, int K, int epi, int ksplit) {
-  __shared__ __attribute__((aligned(1024))) char lds[3 * wStageBytes];
+  constexpr int BMt = 32 * MF;                       // tile rows
+  constexpr int WR = 16 * MF;                        // rows per wave
+  constexpr int STG = wWBytes + BMt * wRowBytes;     // bytes per stage: 52 KB (MF = 5) or 48 KB (MF = 4)
+  constexpr int XP = BMt / 8;                        // X pieces of 1 KiB per stage: 20 or 16
+  constexpr int NPEND = 2 * MF;                      // deferred 16-byte stores per lane per tile
+  constexpr int NM = 4 * MF;                         // MFMAs per 32-deep half-step
+  static_assert(MF == 4 || MF == 5, "wave layout: 2(m) x 4(n) waves of MF x 4 fragments");
+  __shared__ __attribute__((aligned(1024))) char lds[3 * STG];
 
   constexpr int ELT = F32 ? 4 : 2;
   constexpr int BK = wRowBytes / ELT;
@@ -70,11 +79,11 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   const int sub = lane >> 3;
   const int frow = lane & 15;
   const int fq = lane >> 4;
-  const bool three = wid < wXPieces - 16;   // waves 0..3 move a third X piece per stage
+  const bool three = wid < XP - 16;   // waves 0..3 move a third X piece per stage
 
   // ---- this workgroup's tiles: XCD x = blockIdx%8 owns a contiguous range of the n-fastest tile order ----
   const int tiles_n = N / wBN;
-  const int tiles_m = (M + wBM - 1) / wBM;
+  const int tiles_m = (M + BMt - 1) / BMt;
   // split-K (wgrad: few output tiles, very long K): virtual tile v = split * base_total + tile computes K-steps
   // [split * nk, (split + 1) * nk) into the f32 partial plane out + split * M * N (summed by splitk_reduce_kernel)
   const int base_total = tiles_n * tiles_m;
@@ -103,7 +112,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
     const int virt = range_lo + slot + ti * per_xcd_blocks;
     const int split = virt / base_total, logical = virt - split * base_total;
     const int tm = logical / tiles_n, tn = logical - tm * tiles_n;
-    const int m0 = tm * wBM, n0 = tn * wBN;
+    const int m0 = tm * BMt, n0 = tn * wBN;
     const size_t kbase = static_cast<size_t>(split) * nk * wRowBytes;
     Wt = W + static_cast<size_t>(n0) * row_stride + kbase;
     Xt = X + kbase;
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   };
   int issue_kt = 0, issue_tile = 0, issue_buf = 0;
   auto issue_piece = [&](int p) {   // p is a compile-time constant at every call site
-    char* base = lds + issue_buf * wStageBytes;
+    char* base = lds + issue_buf * STG;
     const size_t koff = static_cast<size_t>(issue_kt) * wRowBytes;
     if (p < 4)
       __builtin_amdgcn_global_load_lds((w_gptr_t)(Wt + koff + offW[p]), (w_lptr_t)(base + (wid * 4 + p) * 1024), 16, 0, 0);
@@ -146,34 +155,44 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   // tiles of one operand sit 2048 bytes apart, the second 32-deep half is the first one's address XOR 64.
   const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((w_lptr_t)lds));
   const uint32_t aW = lds_base + w_swz(wn * 64 + frow, fq);
-  const uint32_t aX = lds_base + wWBytes + w_swz(wm * 80 + frow, fq);
+  const uint32_t aX = lds_base + wWBytes + w_swz(wm * WR + frow, fq);
 #ifdef W_STAMPS   // timing build only (tools/wide_stamps.py): per-wave cycle sums of the K loop's segments
 #define W_STAMP(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); st_sum[k] += static_cast<unsigned>(t_ - st_last); st_last = t_; } while (0)
 #else
 #define W_STAMP(k) do { } while (0)
 #endif
 #define W_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
-  auto load_frags = [&](w_u32x4_t (&fw)[4], w_u32x4_t (&fx)[5], int buf, int ks) {
-    const uint32_t bo = static_cast<uint32_t>(buf) * wStageBytes;
+  auto load_frags = [&](w_u32x4_t (&fw)[4], w_u32x4_t (&fx)[MF], int buf, int ks) {
+    const uint32_t bo = static_cast<uint32_t>(buf) * STG;
     const uint32_t w = (aW + bo) ^ (ks ? 64u : 0u), x = (aX + bo) ^ (ks ? 64u : 0u);
     W_READ(fw[0], w, 0); W_READ(fw[1], w, 2048); W_READ(fw[2], w, 4096); W_READ(fw[3], w, 6144);
-    W_READ(fx[0], x, 0); W_READ(fx[1], x, 2048); W_READ(fx[2], x, 4096); W_READ(fx[3], x, 6144); W_READ(fx[4], x, 8192);
+    W_READ(fx[0], x, 0); W_READ(fx[1], x, 2048); W_READ(fx[2], x, 4096); W_READ(fx[3], x, 6144);
+    if constexpr (MF == 5) W_READ(fx[4], x, 8192);
   };
-#define W_WAIT_FRAGS(cnt, fw, fx)                                                                              \
-  asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                                   \
-               : "+v"(fw[0]), "+v"(fw[1]), "+v"(fw[2]), "+v"(fw[3]), "+v"(fx[0]), "+v"(fx[1]), "+v"(fx[2]),    \
-                 "+v"(fx[3]), "+v"(fx[4])::"memory")
+#define W_WAIT_FRAGS(cnt, fw, fx)                                                                                \
+  do {                                                                                                           \
+    if constexpr (MF == 5)                                                                                       \
+      asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                                 \
+                   : "+v"(fw[0]), "+v"(fw[1]), "+v"(fw[2]), "+v"(fw[3]), "+v"(fx[0]), "+v"(fx[1]), "+v"(fx[2]),  \
+                     "+v"(fx[3]), "+v"(fx[MF - 1])::"memory");                                                   \
+    else                                                                                                         \
+      asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                                 \
+                   : "+v"(fw[0]), "+v"(fw[1]), "+v"(fw[2]), "+v"(fw[3]), "+v"(fx[0]), "+v"(fx[1]), "+v"(fx[2]),  \
+                     "+v"(fx[3])::"memory");                                                                     \
+  } while (0)
 
   // ---- deferred stores of the previous tile (bf16 outputs only) --------------------------------------------
-  w_u32x4_t pend[wPend];
+  w_u32x4_t pend[NPEND];
   bool pend_valid = false;
   bf16_t* pend_ptr = nullptr;          // &out[(m0 + wm*80 + frow) * N + col] of the pending tile
   const size_t row16 = static_cast<size_t>(16) * N;
-  const int sps = (wPend + nk - 1) / nk;   // stores per K-step so that all 10 leave within one tile's K loop
+  const int sps = (NPEND + nk - 1) / nk;   // stores per K-step so that all 10 leave within one tile's K loop
   auto store_pending = [&](int idx) {
     switch (idx) {   // compile-time register choice per case: no dynamically indexed vector arrays (they would go to scratch)
 #define W_ST(j) case j: *reinterpret_cast<w_u32x4_t*>(pend_ptr + (j / 2) * row16 + (j % 2) * 32) = pend[j]; break;
-      W_ST(0) W_ST(1) W_ST(2) W_ST(3) W_ST(4) W_ST(5) W_ST(6) W_ST(7) W_ST(8) W_ST(9)
+      W_ST(0) W_ST(1) W_ST(2) W_ST(3) W_ST(4) W_ST(5) W_ST(6) W_ST(7)
+      case 8: if constexpr (MF == 5) *reinterpret_cast<w_u32x4_t*>(pend_ptr + 4 * row16) = pend[NPEND - 2]; break;
+      case 9: if constexpr (MF == 5) *reinterpret_cast<w_u32x4_t*>(pend_ptr + 4 * row16 + 32) = pend[NPEND - 1]; break;
 #undef W_ST
       default: break;
     }
@@ -217,24 +236,24 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
 #endif
   auto run = [&](auto gb) {
   constexpr bool GB = decltype(gb)::value;
-  w_f32x4_t acc[4][5];   // [n-tile][m-tile]
+  w_f32x4_t acc[4][MF];   // [n-tile][m-tile]
   // acc += residual tile at (m0, n0): f32 rows, or (EPI_RES_F16) fp16 rows read in the 16-byte layout of the packed output
   // (lane = one row x 8 consecutive n) and brought back to the accumulator layout by the same v_permlane16_swap.
   auto add_residual = [&](int m0, int n0) __attribute__((always_inline)) {
     if (epi & EPI_RES_F16) {
       const uint16_t* res16 = reinterpret_cast<const uint16_t*>(residual);
       const int col = n0 + wn * 64 + (fq & 1) * 16 + (fq & 2) * 4;    // + 32*pair
-      w_u32x4_t r[wPend];
+      w_u32x4_t r[NPEND];
 #pragma unroll
-      for (int b = 0; b < 5; ++b) {
-        int m = m0 + wm * 80 + b * 16 + frow;
+      for (int b = 0; b < MF; ++b) {
+        int m = m0 + wm * WR + b * 16 + frow;
         m = m < M ? m : M - 1;
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr)
           r[b * 2 + pr] = *reinterpret_cast<const w_u32x4_t*>(res16 + static_cast<size_t>(m) * N + col + 32 * pr);
       }
 #pragma unroll
-      for (int b = 0; b < 5; ++b) {
+      for (int b = 0; b < MF; ++b) {
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
           const w_u32x4_t q = r[b * 2 + pr];
@@ -247,10 +266,10 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
         }
       }
     } else {
-      w_f32x4_t rv[4][5];
+      w_f32x4_t rv[4][MF];
 #pragma unroll
-      for (int b = 0; b < 5; ++b) {
-        int m = m0 + wm * 80 + b * 16 + frow;
+      for (int b = 0; b < MF; ++b) {
+        int m = m0 + wm * WR + b * 16 + frow;
         m = m < M ? m : M - 1;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -259,17 +278,17 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 5; ++b) acc[a][b] += rv[a][b];
+        for (int b = 0; b < MF; ++b) acc[a][b] += rv[a][b];
     }
   };
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 5; ++b) acc[a][b] = w_f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < MF; ++b) acc[a][b] = w_f32x4_t{0.f, 0.f, 0.f, 0.f};
   if (res_first) {
     const int logical = range_lo + slot;
     const int tm = logical / tiles_n, tn = logical - tm * tiles_n;
-    add_residual(tm * wBM, tn * wBN);
+    add_residual(tm * BMt, tn * wBN);
   }
   set_issue_tile(0);
   issue_stage();
@@ -284,14 +303,14 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
 
   int cur = 0;
   int ns = 0;                   // deferred stores issued since the last counted wait
-  w_u32x4_t f0w[4], f0x[5], f1w[4], f1x[5];
+  w_u32x4_t f0w[4], f0x[MF], f1w[4], f1x[MF];
   load_frags(f0w, f0x, 0, 0);   // from here on F0 of K-step s+1 (also across tiles) is fetched in the second half of s
   for (int ti = 0; ti < my_tiles; ++ti) {
     if (ti > 0) {
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 5; ++b) acc[a][b] = w_f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < MF; ++b) acc[a][b] = w_f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
 
     for (int kt = 0; kt < nk; ++kt) {
@@ -306,7 +325,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
           if (pend_valid) {
             for (int j = 0; j < sps; ++j) {
               const int idx = kt * sps + j;
-              if (idx < wPend) { store_pending(idx); ++ns; }
+              if (idx < NPEND) { store_pending(idx); ++ns; }
             }
           }
         }
@@ -314,11 +333,11 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
       if constexpr (!GB) deferred_stores();
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < 20; ++i) {                                  // 2
+      for (int i = 0; i < NM; ++i) {                                  // 2
 #ifndef W_ABL_NODMA
         if constexpr (GB) { if (i % 3 == 0) issue_piece(i / 3); }
 #endif
-        mfma(f0w[i / 5], f0x[i % 5], acc[i / 5][i % 5]);
+        mfma(f0w[i / MF], f0x[i % MF], acc[i / MF][i % MF]);
         if constexpr (GB) { if (i % 3 == 2) __builtin_amdgcn_sched_barrier(0); }
       }
       if constexpr (GB) issue_done();
@@ -338,12 +357,12 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
       W_STAMP(3);   // barrier
       const int nxt = cur == 2 ? 0 : cur + 1;
       {                                                               // 4-6: no branches between the MFMAs
-        const uint32_t bo = static_cast<uint32_t>(nxt) * wStageBytes;
+        const uint32_t bo = static_cast<uint32_t>(nxt) * STG;
         const uint32_t nW = aW + bo, nX = aX + bo;
         if constexpr (GB) deferred_stores();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 20; ++i) {
+        for (int i = 0; i < NM; ++i) {
 #ifndef W_ABL_NODMA
           if constexpr (!GB) { if (i % 3 == 0) issue_piece(i / 3); }
 #endif
@@ -356,9 +375,9 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
           if (i == 6) W_READ(f0x[1], nX, 2048);
           if (i == 7) W_READ(f0x[2], nX, 4096);
           if (i == 8) W_READ(f0x[3], nX, 6144);
-          if (i == 9) W_READ(f0x[4], nX, 8192);
+          if constexpr (MF == 5) { if (i == 9) W_READ(f0x[MF - 1], nX, 8192); }
 #endif
-          mfma(f1w[i / 5], f1x[i % 5], acc[i / 5][i % 5]);
+          mfma(f1w[i / MF], f1x[i % MF], acc[i / MF][i % MF]);
           if (i % 3 == 2) __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (!GB) issue_done();
@@ -372,7 +391,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
     const int virt = range_lo + slot + ti * per_xcd_blocks;
     const int split = virt / base_total, logical = virt - split * base_total;
     const int tm = logical / tiles_n, tn = logical - tm * tiles_n;
-    const int m0 = tm * wBM, n0 = tn * wBN;
+    const int m0 = tm * BMt, n0 = tn * wBN;
     // All loads first, then all stores: a load issued behind a store (or waited for with DMA in flight) would wait for
     // every older store to be acknowledged.
     if (epi & EPI_BIAS) {
@@ -382,13 +401,13 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 5; ++b) acc[a][b] += bv[a];
+        for (int b = 0; b < MF; ++b) acc[a][b] += bv[a];
     }
     if (epi & EPI_QUICKGELU) {
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 5; ++b)
+        for (int b = 0; b < MF; ++b)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[a][b][j] = w_quick_gelu(acc[a][b][j]);
     }
@@ -396,7 +415,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 5; ++b)
+        for (int b = 0; b < MF; ++b)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             acc[a][b][j] = (epi & EPI_GELU) ? gelu_erf(acc[a][b][j]) : fmaxf(acc[a][b][j], 0.f);
@@ -413,8 +432,8 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
         const uint16_t* aux = reinterpret_cast<const uint16_t*>(residual);
         const int col = n0 + wn * 64 + (fq & 1) * 16 + (fq & 2) * 4;
 #pragma unroll
-        for (int b = 0; b < 5; ++b) {
-          int m = m0 + wm * 80 + b * 16 + frow;
+        for (int b = 0; b < MF; ++b) {
+          int m = m0 + wm * WR + b * 16 + frow;
           m = m < M ? m : M - 1;
 #pragma unroll
           for (int pr = 0; pr < 2; ++pr) {
@@ -431,8 +450,8 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
         }
       } else {
 #pragma unroll
-        for (int b = 0; b < 5; ++b) {
-          int m = m0 + wm * 80 + b * 16 + frow;
+        for (int b = 0; b < MF; ++b) {
+          int m = m0 + wm * WR + b * 16 + frow;
           m = m < M ? m : M - 1;
 #pragma unroll
           for (int a = 0; a < 4; ++a) {
@@ -443,13 +462,13 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
         }
       }
     }
-    const bool full = m0 + wBM <= M;
+    const bool full = m0 + BMt <= M;
     if constexpr (OUTBF) {
       // v_permlane16_swap exchanges, between the lane pairs (l, l+16), the packed words of two neighbouring n-tiles: an even
       // lane-row then owns 8 consecutive n of tile a and an odd lane-row 8 consecutive n of tile a+1 -> 16-byte stores.
       const int col = n0 + wn * 64 + (fq & 1) * 16 + (fq & 2) * 4;    // + 32*pair
 #pragma unroll
-      for (int b = 0; b < 5; ++b) {
+      for (int b = 0; b < MF; ++b) {
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
           uint32_t lo[2], hi[2];   // packed words of tiles a = 2pr (lo) and 2pr+1 (hi)
@@ -471,19 +490,19 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
           pend[b * 2 + pr][0] = s0[0]; pend[b * 2 + pr][1] = s1[0]; pend[b * 2 + pr][2] = s0[1]; pend[b * 2 + pr][3] = s1[1];
         }
       }
-      pend_ptr = static_cast<bf16_t*>(out) + static_cast<size_t>(m0 + wm * 80 + frow) * N + col;
+      pend_ptr = static_cast<bf16_t*>(out) + static_cast<size_t>(m0 + wm * WR + frow) * N + col;
       if (full && ti + 1 < my_tiles && !(epi & (256 | 512))) {   // 512 = ablation: store from the epilogue
         pend_valid = true;                       // leave under the next tile's MFMAs
       } else if (!(epi & 256)) {                 // 256 = timing-only ablation: skip stores
 #pragma unroll
-        for (int j = 0; j < wPend; ++j)
-          if (m0 + wm * 80 + (j / 2) * 16 + frow < M)
+        for (int j = 0; j < NPEND; ++j)
+          if (m0 + wm * WR + (j / 2) * 16 + frow < M)
             *reinterpret_cast<w_u32x4_t*>(pend_ptr + (j / 2) * row16 + (j % 2) * 32) = pend[j];
       }
     } else if (!(epi & 256)) {
 #pragma unroll
-      for (int b = 0; b < 5; ++b) {
-        const int m = m0 + wm * 80 + b * 16 + frow;
+      for (int b = 0; b < MF; ++b) {
+        const int m = m0 + wm * WR + b * 16 + frow;
         if (m >= M) continue;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -548,10 +567,10 @@ int launch_gemm_wide_splitk(int dt, const void* A, const void* W, float* out, fl
   const int cus = wide_cus();
   const int grid = total < cus ? ((total + 7) & ~7) : cus;
   if (dt == CMH_F32)
-    hipLaunchKernelGGL((gemm_wide_kernel<true, false>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),
+    hipLaunchKernelGGL((gemm_wide_kernel<true, false, 5>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),
                        static_cast<const char*>(W), nullptr, nullptr, partials, M, N, K, 0, S);
   else
-    hipLaunchKernelGGL((gemm_wide_kernel<false, false>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),
+    hipLaunchKernelGGL((gemm_wide_kernel<false, false, 5>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),
                        static_cast<const char*>(W), nullptr, nullptr, partials, M, N, K, 0, S);
   const size_t n = static_cast<size_t>(M) * N;
   const size_t blocks = (n / 4 + 255) / 256;
@@ -565,12 +584,28 @@ int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, co
   if (static_cast<size_t>(M) * K * esz >= (1ull << 32) || static_cast<size_t>(wBN) * K * esz >= (1ull << 32))
     return fail(CMH_ERR_INVALID, "gemm: operand of %zu bytes exceeds the 32-bit offset range of the wide kernel",
                 static_cast<size_t>(M) * K * esz);
-  const int total = (N / wBN) * ((M + wBM - 1) / wBM);
+  // Tile rows: 160 (MF = 5) or 128 (MF = 4), whichever needs less time for this M on the chip's CUs: rounds of workgroups x
+  // (K-steps + ~4 K-steps of per-tile overhead) x rows.  M = 12 800 / 19 712 (the dense towers) take 160; the packed text
+  // rows (M ~ 10 k and odd) quantise 20 % better with 128 (N = 512: 132 -> 166 tiles on 256 CUs).  CMH_GEMM_BM=128|160 forces one.
   const int cus = wide_cus();
+  const int nk = K / (dt == CMH_F32 ? 32 : 64);
+  auto cost = [&](int mf) {
+    const int tiles = (N / wBN) * ((M + 32 * mf - 1) / (32 * mf));
+    return static_cast<long long>((tiles + cus - 1) / cus) * mf * (nk + 4);
+  };
+  static const int forced = []() { const char* e = getenv("CMH_GEMM_BM"); return e ? atoi(e) : 0; }();
+  const int mf = forced == 128 ? 4 : (forced == 160 ? 5 : (cost(4) < cost(5) ? 4 : 5));
+  const int total = (N / wBN) * ((M + 32 * mf - 1) / (32 * mf));
   int grid = total < cus ? ((total + 7) & ~7) : cus;
-#define W_LAUNCH(F32, OUTBF)                                                                                   \
-  hipLaunchKernelGGL((gemm_wide_kernel<F32, OUTBF>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A), \
-                     static_cast<const char*>(W), bias, residual, out, M, N, K, epi, 1)
+#define W_LAUNCH(F32, OUTBF)                                                                                              \
+  do {                                                                                                                    \
+    if (mf == 4)                                                                                                          \
+      hipLaunchKernelGGL((gemm_wide_kernel<F32, OUTBF, 4>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),    \
+                         static_cast<const char*>(W), bias, residual, out, M, N, K, epi, 1);                              \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((gemm_wide_kernel<F32, OUTBF, 5>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),    \
+                         static_cast<const char*>(W), bias, residual, out, M, N, K, epi, 1);                              \
+  } while (0)
   const bool obf = epi & (EPI_OUT_BF16 | EPI_OUT_F16);   // 16-bit outputs share the packed store path
   if (dt == CMH_F32) { if (obf) W_LAUNCH(true, true); else W_LAUNCH(true, false); }
   else { if (obf) W_LAUNCH(false, true); else W_LAUNCH(false, false); }
