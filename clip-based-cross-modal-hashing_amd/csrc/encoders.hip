@@ -4,9 +4,10 @@
 // graph-capturable.
 //
 // Data layout in HBM (per call, M = B*T rows, d = width, e = GEMM element size 4|2):
-//   x    f32 [M, d]    residual stream.  f32 mode: fp32.  bf16 mode: IEEE fp16 - the precision the reference
-//                      itself keeps it in on a GPU (convert_weights casts the towers to fp16, model/base/model.py:375-395):
-//                      halves the bytes of the 4 read-modify-write passes per layer (2 LayerNorms, 2 residual GEMMs).
+//   x    f32 [M, d]    residual stream.  f32 mode: fp32 (the parity mode for the trainers' model.float()).
+//                      bf16 mode (throughput): IEEE fp16, as a raw build_model CLIP keeps it on a GPU (convert_weights,
+//                      model/base/model.py:391-412): halves the bytes of the 4 read-modify-write passes per layer
+//                      (2 LayerNorms, 2 residual GEMMs).
 //                      CMH_RESID_F16=0, widths that are not a multiple of 256 or a taps request keep it fp32.
 //   h    e   [M, d]    LayerNorm output / attention output (GEMM A operand)
 //   qkv  e   [M, 3d]   packed in_proj output            (vision: patch_out f32 [B*g2, d] aliases it)
