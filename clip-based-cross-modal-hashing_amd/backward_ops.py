@@ -117,6 +117,35 @@ class HypLoss(torch.autograd.Function):
         return dx, dy, None, dp, None, None
 
 
+class DnphLoss(torch.autograd.Function):
+    """cmh_dnph_loss with its backward (DNPH_out, train/DNPH_TOMM/loss.py:14-32, plus the `- 0.1 * noise_loss` term of
+    train/DNPH_TOMM/hash_train.py:65-81 when the noise rows are given).  Returns loss1 without noise rows, else the step loss."""
+
+    @staticmethod
+    def forward(ctx, f1, f2, p1, p2, label, proxies, noise_1, noise_2, mrg, noise_weight):
+        ts = [N.f32c(t) for t in (f1, f2, p1, p2, label, proxies)]
+        n1 = None if noise_1 is None else N.f32c(noise_1)
+        n2 = None if noise_2 is None else N.f32c(noise_2)
+        ctx.save_for_backward(*ts, n1, n2)
+        ctx.mrg, ctx.nw = float(mrg), float(noise_weight)
+        total, loss1, _ = N.dnph_loss(*ts, n1, n2, mrg, noise_weight)
+        return (loss1 if n1 is None else total).clone()
+
+    @staticmethod
+    def backward(ctx, dloss):
+        f1, f2, p1, p2, label, proxies, n1, n2 = ctx.saved_tensors
+        B, K = f1.shape
+        Cn = label.shape[1]
+        d1, d2, dp1, dp2, dpx = (torch.empty_like(t) for t in (f1, f2, p1, p2, proxies))
+        dl = N.f32c(dloss).reshape(1)
+        ws = N.workspace(N.lib().cmh_dnph_backward_workspace_bytes(B, K, Cn), f1.device, "bwd")
+        N.check(N.lib().cmh_dnph_loss_backward(N.ptr(f1), N.ptr(f2), N.ptr(p1), N.ptr(p2), N.ptr(label), N.ptr(proxies), N.ptr(n1),
+                                               N.ptr(n2), B, K, Cn, ctx.mrg, ctx.nw, N.ptr(dl), N.ptr(d1), N.ptr(d2), N.ptr(dp1),
+                                               N.ptr(dp2), N.ptr(dpx), N.ptr(ws), ws.numel(), N.stream_ptr(f1.device)),
+                "cmh_dnph_loss_backward")
+        return d1, d2, dp1, dp2, None, dpx, None, None, None, None
+
+
 def linear_wgrad(dy, x, gemm_dtype="bf16", want_bias=True):
     """dW [O,I] = dy^T x (+ db = column sums of dy) on the encoder GEMM (split over K = M rows when that pays)."""
     N.require_gpu(dy, x)

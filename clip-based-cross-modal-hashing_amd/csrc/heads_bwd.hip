@@ -316,6 +316,124 @@ __global__ __launch_bounds__(64) void dchmt_rows_kernel(const float* __restrict_
   }
 }
 
+// ---- DNPH (TOMM) ---------------------------------------------------------------------------------------------------------------
+// DNPH_out.forward (train/DNPH_TOMM/loss.py:14-32) + the noise term of the step (hash_train.py:65-81):
+//   f = normalize(cat(img, txt)), p = normalize(proxies), D = |f - p|^2 + mrg [label == 1]
+//   p_loss = mean_r sum_c -label[r,c] log_softmax(-D)[r,c];   d_loss = CE(pre_img, argmax label) + CE(pre_txt, argmax label)
+//   loss = p_loss + d_loss - noise_weight * (mean_r img_r . noise_img_r + mean_r txt_r . noise_txt_r)
+// One wave per row r of cat(img, txt): dz = (softmax(-D) * sum_c label - label) / (2B), dD = -dz (kept in G for the proxy
+// pass), df_n = sum_c dD 2 (f_n - p_c), then through the normalisation, plus the noise term.
+__global__ __launch_bounds__(64) void dnph_rows_bwd_kernel(const float* __restrict__ fn, const float* __restrict__ nf,
+                                                           const float* __restrict__ pn, const float* __restrict__ label,
+                                                           const float* __restrict__ noise_img, const float* __restrict__ noise_txt,
+                                                           int B, int K, int C, float mrg, float noise_weight,
+                                                           const float* __restrict__ dloss, float* __restrict__ G,
+                                                           float* __restrict__ dimg, float* __restrict__ dtxt) {
+  constexpr int KV = 8;                                  // K <= 512
+  extern __shared__ float zs[];                          // [C] -D of this row
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const int lb = r < B ? r : r - B;                      // label row (label_all = cat(label, label))
+  const float up = dloss ? dloss[0] : 1.f;
+  float fi[KV], g[KV];
+#pragma unroll
+  for (int v = 0; v < KV; ++v) { const int k = lane + 64 * v; fi[v] = k < K ? fn[static_cast<size_t>(r) * K + k] : 0.f; g[v] = 0.f; }
+  float lsum = 0.f;
+  for (int c = lane; c < C; c += 64) lsum += label[static_cast<size_t>(lb) * C + c];
+  lsum = wsum(lsum);
+  float m = -1e30f;
+  for (int c = 0; c < C; ++c) {
+    float dd = 0.f;
+#pragma unroll
+    for (int v = 0; v < KV; ++v) { const int k = lane + 64 * v; const float d = k < K ? fi[v] - pn[static_cast<size_t>(c) * K + k] : 0.f; dd = fmaf(d, d, dd); }
+    dd = wsum(dd);
+    const float z = -(dd + (label[static_cast<size_t>(lb) * C + c] == 1.f ? mrg : 0.f));
+    if (lane == 0) zs[c] = z;
+    m = fmaxf(m, z);
+  }
+  __syncthreads();
+  float se = 0.f;
+  for (int c = lane; c < C; c += 64) se += expf(zs[c] - m);
+  se = wsum(se);
+  const float inv2b = 1.f / (2.f * static_cast<float>(B));
+  for (int c = 0; c < C; ++c) {
+    const float sm = expf(zs[c] - m) / se;
+    const float dz = (sm * lsum - label[static_cast<size_t>(lb) * C + c]) * inv2b;
+    const float dD = -dz;
+    if (lane == 0) G[static_cast<size_t>(r) * C + c] = dD;
+#pragma unroll
+    for (int v = 0; v < KV; ++v) {
+      const int k = lane + 64 * v;
+      if (k < K) g[v] = fmaf(2.f * dD, fi[v] - pn[static_cast<size_t>(c) * K + k], g[v]);
+    }
+  }
+  float pg = 0.f;
+#pragma unroll
+  for (int v = 0; v < KV; ++v) pg = fmaf(fi[v], g[v], pg);
+  pg = wsum(pg);
+  const float rn = 1.f / nf[r];
+  const float* noise = r < B ? noise_img : noise_txt;
+  float* out = r < B ? dimg : dtxt;
+#pragma unroll
+  for (int v = 0; v < KV; ++v) {
+    const int k = lane + 64 * v;
+    if (k < K) {
+      float val = (g[v] - fi[v] * pg) * rn;
+      if (noise) val -= noise_weight * noise[static_cast<size_t>(lb) * K + k] / static_cast<float>(B);
+      out[static_cast<size_t>(lb) * K + k] = val * up;
+    }
+  }
+}
+
+// One wave per proxy c: dp_n = sum_r G[r,c] 2 (p_c - f_r), then through the normalisation
+__global__ __launch_bounds__(64) void dnph_proxy_bwd_kernel(const float* __restrict__ fn, const float* __restrict__ pn,
+                                                            const float* __restrict__ np_, const float* __restrict__ G, int R, int K,
+                                                            int C, const float* __restrict__ dloss, float* __restrict__ dp) {
+  constexpr int KV = 8;
+  const int c = blockIdx.x, lane = threadIdx.x;
+  const float up = dloss ? dloss[0] : 1.f;
+  float pc[KV], g[KV];
+#pragma unroll
+  for (int v = 0; v < KV; ++v) { const int k = lane + 64 * v; pc[v] = k < K ? pn[static_cast<size_t>(c) * K + k] : 0.f; g[v] = 0.f; }
+  for (int r = 0; r < R; ++r) {
+    const float w = 2.f * G[static_cast<size_t>(r) * C + c];
+#pragma unroll
+    for (int v = 0; v < KV; ++v) { const int k = lane + 64 * v; if (k < K) g[v] = fmaf(w, pc[v] - fn[static_cast<size_t>(r) * K + k], g[v]); }
+  }
+  float pg = 0.f;
+#pragma unroll
+  for (int v = 0; v < KV; ++v) pg = fmaf(pc[v], g[v], pg);
+  pg = wsum(pg);
+  const float rn = up / np_[c];
+#pragma unroll
+  for (int v = 0; v < KV; ++v) { const int k = lane + 64 * v; if (k < K) dp[static_cast<size_t>(c) * K + k] = (g[v] - pc[v] * pg) * rn; }
+}
+
+// CrossEntropyLoss(pre, argmax(label)) mean over the batch: dpre = (softmax(pre) - onehot) / B   (first maximum, like torch.argmax)
+__global__ __launch_bounds__(64) void ce_argmax_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ label, int B, int C,
+                                                           const float* __restrict__ dloss, float* __restrict__ dpre) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const float up = dloss ? dloss[0] : 1.f;
+  float m = -1e30f, lbest = -1e30f;
+  int li = 0;
+  for (int c = lane; c < C; c += 64) {
+    m = fmaxf(m, pre[static_cast<size_t>(r) * C + c]);
+    const float l = label[static_cast<size_t>(r) * C + c];
+    if (l > lbest) { lbest = l; li = c; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    m = fmaxf(m, __shfl_xor(m, o, 64));
+    const float ol = __shfl_xor(lbest, o, 64);
+    const int oi = __shfl_xor(li, o, 64);
+    if (ol > lbest || (ol == lbest && oi < li)) { lbest = ol; li = oi; }
+  }
+  float se = 0.f;
+  for (int c = lane; c < C; c += 64) se += expf(pre[static_cast<size_t>(r) * C + c] - m);
+  se = wsum(se);
+  for (int c = lane; c < C; c += 64)
+    dpre[static_cast<size_t>(r) * C + c] = (expf(pre[static_cast<size_t>(r) * C + c] - m) / se - (c == li ? 1.f : 0.f)) * up / static_cast<float>(B);
+}
+
 // rows / |row| (no eps) and the norms
 __global__ __launch_bounds__(256) void plain_normalize_kernel(const float* __restrict__ a, float* __restrict__ an, float* __restrict__ nrm,
                                                               int R, int K) {
@@ -332,6 +450,42 @@ __global__ __launch_bounds__(256) void plain_normalize_kernel(const float* __res
 }  // namespace cmh
 
 using namespace cmh;
+
+extern "C" size_t cmh_dnph_backward_workspace_bytes(int32_t B, int32_t K, int32_t C) {
+  if (B <= 0 || K <= 0 || C <= 0) return 0;
+  return align_up(static_cast<size_t>(2) * B * K * 4, 256) + align_up(static_cast<size_t>(C) * K * 4, 256) +
+         align_up(static_cast<size_t>(2) * B * 4, 256) + align_up(static_cast<size_t>(C) * 4, 256) +
+         align_up(static_cast<size_t>(2) * B * C * 4, 256) + 512;
+}
+
+extern "C" int cmh_dnph_loss_backward(const float* hash_img, const float* hash_txt, const float* pre_img, const float* pre_txt,
+                                      const float* label, const float* proxies, const float* noise_img, const float* noise_txt,
+                                      int32_t B, int32_t K, int32_t C, float margin, float noise_weight, const float* dloss,
+                                      float* dhash_img, float* dhash_txt, float* dpre_img, float* dpre_txt, float* dproxies,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  CMH_CHECK_ARG(hash_img && hash_txt && pre_img && pre_txt && label && proxies && dhash_img && dhash_txt && dpre_img && dpre_txt &&
+                dproxies && workspace, "dnph_loss_backward: null pointer");
+  CMH_CHECK_ARG((noise_img == nullptr) == (noise_txt == nullptr), "dnph_loss_backward: give both noise matrices or none");
+  CMH_CHECK_ARG(B > 0 && K > 0 && K <= 512 && C > 0 && C <= 4096, "dnph_loss_backward: bad shape B=%d K=%d C=%d", B, K, C);
+  if (workspace_bytes < cmh_dnph_backward_workspace_bytes(B, K, C)) return fail(CMH_ERR_WORKSPACE, "dnph_loss_backward: workspace too small");
+  char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+  float* fn = reinterpret_cast<float*>(ws); ws += align_up(static_cast<size_t>(2) * B * K * 4, 256);
+  float* pn = reinterpret_cast<float*>(ws); ws += align_up(static_cast<size_t>(C) * K * 4, 256);
+  float* nf = reinterpret_cast<float*>(ws); ws += align_up(static_cast<size_t>(2) * B * 4, 256);
+  float* np_ = reinterpret_cast<float*>(ws); ws += align_up(static_cast<size_t>(C) * 4, 256);
+  float* G = reinterpret_cast<float*>(ws);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(hyp_normalize_kernel, dim3((B + 3) / 4), dim3(256), 0, st, hash_img, fn, nf, B, K);
+  hipLaunchKernelGGL(hyp_normalize_kernel, dim3((B + 3) / 4), dim3(256), 0, st, hash_txt, fn + static_cast<size_t>(B) * K, nf + B, B, K);
+  hipLaunchKernelGGL(hyp_normalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, proxies, pn, np_, C, K);
+  hipLaunchKernelGGL(dnph_rows_bwd_kernel, dim3(2 * B), dim3(64), static_cast<size_t>(C) * 4, st, fn, nf, pn, label, noise_img, noise_txt, B, K,
+                     C, margin, noise_img ? noise_weight : 0.f, dloss, G, dhash_img, dhash_txt);
+  hipLaunchKernelGGL(dnph_proxy_bwd_kernel, dim3(C), dim3(64), 0, st, fn, pn, np_, G, 2 * B, K, C, dloss, dproxies);
+  hipLaunchKernelGGL(ce_argmax_bwd_kernel, dim3(B), dim3(64), 0, st, pre_img, label, B, C, dloss, dpre_img);
+  hipLaunchKernelGGL(ce_argmax_bwd_kernel, dim3(B), dim3(64), 0, st, pre_txt, label, B, C, dloss, dpre_txt);
+  CMH_CHECK_LAUNCH("dnph_loss_backward");
+  return CMH_OK;
+}
 
 extern "C" int cmh_pair_softmax_backward(const float* p, const float* dp, float* dz, int32_t M, int32_t K, void* stream) {
   CMH_CHECK_ARG(p && dp && dz && M > 0 && K > 0, "pair_softmax_backward: bad arguments");

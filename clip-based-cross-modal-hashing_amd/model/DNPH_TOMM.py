@@ -1,10 +1,10 @@
 """DNPH (TOMM) model (reference model/DNPH_TOMM.py:7-51): LinearHash + a classifier on the same features."""
 import logging
 
+import torch
 import torch.nn as nn
 
 import cmh_native as N
-from model.base.model import no_backward
 from model.modelbase import Baseclip
 from streams import overlapped
 
@@ -15,7 +15,10 @@ class Pre_Layer(nn.Module):
         self.fc = nn.Linear(inputdim, nb_class)
 
     def forward(self, data):
-        return no_backward(N.linear_act(data, self.fc.weight, self.fc.bias, N.ACT_NONE), self.fc.weight)
+        if torch.is_grad_enabled() and (data.requires_grad or self.fc.weight.requires_grad):
+            from backward_ops import LinearAct
+            return LinearAct.apply(data, self.fc.weight, self.fc.bias, N.ACT_NONE, None, 0.0)
+        return N.linear_act(data, self.fc.weight, self.fc.bias, N.ACT_NONE)
 
 
 class MDNPH(Baseclip):

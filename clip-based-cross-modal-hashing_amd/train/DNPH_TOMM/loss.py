@@ -16,6 +16,10 @@ class DNPH_out(torch.nn.Module):
                 noise_weight=0.1):
         """label_1 must equal label_2 (the trainer passes the same tensor twice).  With noise rows the returned value
         is the full step loss `loss1 - 0.1*noise_loss` (hash_train.py:76-81), otherwise DNPH_out's loss1."""
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (feature_1, feature_2, predict_1, predict_2, self.proxies)):
+            from backward_ops import DnphLoss
+            return DnphLoss.apply(feature_1, feature_2, predict_1, predict_2, label_1, self.proxies, noise_1, noise_2, self.mrg,
+                                  noise_weight)
         total, loss1, _ = N.dnph_loss(feature_1, feature_2, predict_1, predict_2, label_1, self.proxies, noise_1, noise_2,
                                       self.mrg, noise_weight)
         return no_backward(loss1 if noise_1 is None else total, self.proxies)

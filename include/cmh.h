@@ -425,6 +425,14 @@ int cmh_pair_softmax_backward(const float* p, const float* dp, float* dz, int32_
 int cmh_dchmt_loss_backward(const float* img, const float* txt, const float* label, int32_t B, int32_t D, int32_t C,
                             int32_t output_dim, int32_t similarity, int32_t loss_type, float vartheta, float sim_threshold,
                             const float* dloss, float* dimg, float* dtxt, void* workspace, size_t workspace_bytes, void* stream);
+/* Backward of cmh_dnph_loss (train/DNPH_TOMM/loss.py:14-32 + the noise term of hash_train.py:65-81; pass NULL noises for
+ * DNPH_out alone): gradients w.r.t. both hash outputs [B,K], both classifier outputs [B,C] and the proxies [C,K]. */
+size_t cmh_dnph_backward_workspace_bytes(int32_t B, int32_t K, int32_t C);
+int cmh_dnph_loss_backward(const float* hash_img, const float* hash_txt, const float* pre_img, const float* pre_txt,
+                           const float* label, const float* proxies, const float* noise_img, const float* noise_txt, int32_t B,
+                           int32_t K, int32_t C, float margin, float noise_weight, const float* dloss, float* dhash_img,
+                           float* dhash_txt, float* dpre_img, float* dpre_txt, float* dproxies, void* workspace,
+                           size_t workspace_bytes, void* stream);
 size_t cmh_vit_train_bytes(const cmh_vit_weights* w, int32_t batch);
 /* same `feat` as cmh_vit_encode (c_fc's QuickGELU runs as a separate pass over the stored pre-activation) */
 int cmh_vit_forward_train(const cmh_vit_weights* w, const float* image, int32_t batch, float* feat, void* tape, size_t tape_bytes,

@@ -349,3 +349,38 @@ def test_dchmt_training_trajectory_matches_reference(golden):
         worst = max(worst, err)
         assert err < 1e-4, (key, err)
     print(f"DCHMT trajectory: losses {losses}, worst parameter error {worst:.2e} of max")
+
+
+@pytest.mark.parametrize("B,K,C", [(16, 16, 21), (40, 128, 24)])
+@pytest.mark.parametrize("with_noise", [True, False])
+def test_dnph_loss_gradients_match_reference_goldens(golden, B, K, C, with_noise):
+    """The gradients the REFERENCE's DNPH_out (+ the trainer's noise term) produced (tests/golden/make_golden7.py); without the
+    noise rows, fp64 autograd of the same formula (train/DNPH_TOMM/loss.py:14-32)."""
+    import torch.nn.functional as F
+    from heads2util import dnph_case
+    from backward_ops import DnphLoss
+    c = dnph_case(B, K, C)
+    tag = c["tag"]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+    hi, ht, pi, pt, prox = (t(c[k]).requires_grad_() for k in ("hi", "ht", "pi", "pt", "prox"))
+    lab = t(c["lab"])
+    if with_noise:
+        g, gn = golden("dnph_grads.npz"), golden("dnph.npz")
+        loss = DnphLoss.apply(hi, ht, pi, pt, lab, prox, t(gn[f"{tag}_noise_i"]), t(gn[f"{tag}_noise_t"]), 1.0, 0.1)
+        (3.0 * loss).backward()                                  # exercises the upstream-gradient scaling too
+        assert abs(float(loss.detach()) - float(g[f"{tag}_step_loss"])) < 1e-4 * max(1.0, abs(float(loss.detach())))
+        want = {n: 3.0 * g[f"{tag}_{n}"] for n in ("ghi", "ght", "gpi", "gpt", "gprox")}
+    else:
+        loss = DnphLoss.apply(hi, ht, pi, pt, lab, prox, None, None, 1.0, 0.1)
+        loss.backward()
+        d = [torch.from_numpy(np.asarray(c[k], dtype=np.float64)).requires_grad_() for k in ("hi", "ht", "pi", "pt", "prox")]
+        labd = torch.from_numpy(c["lab"]).double()
+        la = torch.cat((labd, labd))
+        D = torch.cdist(F.normalize(torch.cat((d[0], d[1])), p=2, dim=-1), F.normalize(d[4], p=2, dim=-1)) ** 2
+        pl = torch.sum(-la * F.log_softmax(-(D + (la == 1).double()), 1), -1).mean()
+        ce = F.cross_entropy(d[2], labd.argmax(-1)) + F.cross_entropy(d[3], labd.argmax(-1))
+        (pl + ce).backward()
+        assert abs(float(loss.detach()) - float((pl + ce).detach())) < 1e-4
+        want = dict(zip(("ghi", "ght", "gpi", "gpt", "gprox"), (x.grad.numpy() for x in d)))
+    for a, name in ((hi, "ghi"), (ht, "ght"), (pi, "gpi"), (pt, "gpt"), (prox, "gprox")):
+        np.testing.assert_allclose(a.grad.cpu().numpy(), want[name], rtol=2e-4, atol=2e-6, err_msg=name)

@@ -97,3 +97,14 @@ def test_twdh_and_dnph_trainers_end_to_end(tmp_path, monkeypatch):
                 hi, pi, ht, pt = outs
                 loss = tr.compute_loss(hi, pi, ht, pt, label.to(DEV).float())
         assert torch.isfinite(loss).item()
+        if method == "DNPH":
+            # one real epoch: tape forward -> DNPH_out + noise term -> backward through heads, classifiers and both towers -> BertAdam
+            for grp in tr.optimizer.param_groups:
+                grp["t_total"] = 4
+            before = {n: p.detach().clone() for n, p in tr.model.named_parameters()}
+            prox0 = tr.DNPH.proxies.detach().clone()
+            tr.train_epoch(0)
+            same = {n for n, p in tr.model.named_parameters() if torch.equal(p.detach(), before[n])}
+            assert same == {"clip.logit_scale"}, sorted(same)[:5]
+            assert all(torch.isfinite(p).all() for p in tr.model.parameters())
+            assert torch.equal(prox0, tr.DNPH.proxies.detach())        # upstream never steps its proxy SGD
