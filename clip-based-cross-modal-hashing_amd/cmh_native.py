@@ -139,6 +139,9 @@ SIGNATURES = {
     "cmh_dsph_hyp_loss_backward": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _f, _f, _p, _p, _p, _p, _p, _sz, _p]),
     "cmh_dnph_backward_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "cmh_dnph_loss_backward": (C.c_int, [_p] * 8 + [_i32, _i32, _i32, _f, _f, _p] + [_p] * 5 + [_p, _sz, _p]),
+    "cmh_image_preprocess_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "cmh_image_preprocess": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                       _p, _p, _p, _sz, _p]),
     "cmh_vit_train_bytes": (_sz, [C.POINTER(VitWeights), _i32]),
     "cmh_vit_forward_train": (C.c_int, [C.POINTER(VitWeights), _p, _i32, _p, _p, _sz, _p]),
     "cmh_vit_backward": (C.c_int, [C.POINTER(VitWeights), _i32, _p, C.POINTER(VitGrads), _p, _sz, _p]),

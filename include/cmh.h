@@ -433,6 +433,19 @@ int cmh_dnph_loss_backward(const float* hash_img, const float* hash_txt, const f
                            int32_t K, int32_t C, float margin, float noise_weight, const float* dloss, float* dhash_img,
                            float* dhash_txt, float* dpre_img, float* dpre_txt, float* dproxies, void* workspace,
                            size_t workspace_bytes, void* stream);
+/* ---- input pipeline, image side ---------------------------------------------------------------------
+ * dataset/base.py:35-44 (the two transform chains) and :55-64 (_load_image) for a whole batch of DECODED images:
+ * train != 0: Resize(R, BICUBIC) -> CenterCrop(R) -> ToTensor -> Normalize(mean, std); train == 0: Resize((R, R), BICUBIC) -> ...
+ * Bit-identical to Pillow's Image.resize + torchvision's rules (tests/golden/preprocess.npz).
+ *   pixels  device, uint8 RGB HWC images back to back;  offsets device int64 [batch] byte offset of each image;
+ *   hw      device int32 [batch, 2] = (height, width);  max_h / max_w >= every image's size (sizes the launch and the workspace);
+ *   mean / stdv  HOST float[3];  out device f32 [batch, 3, R, R] and/or out_u8 device uint8 [batch, R, R, 3] (the image that
+ *   reaches ToTensor; either may be NULL). */
+size_t cmh_image_preprocess_workspace_bytes(int32_t batch, int32_t max_h, int32_t max_w, int32_t R);
+int cmh_image_preprocess(const uint8_t* pixels, const int64_t* offsets, const int32_t* hw, int32_t batch, int32_t max_h,
+                         int32_t max_w, int32_t R, int32_t train, const float* mean, const float* stdv, float* out,
+                         uint8_t* out_u8, void* workspace, size_t workspace_bytes, void* stream);
+
 size_t cmh_vit_train_bytes(const cmh_vit_weights* w, int32_t batch);
 /* same `feat` as cmh_vit_encode (c_fc's QuickGELU runs as a separate pass over the stored pre-activation) */
 int cmh_vit_forward_train(const cmh_vit_weights* w, const float* image, int32_t batch, float* feat, void* tape, size_t tape_bytes,
