@@ -6,7 +6,7 @@
 // 22-bit fixed point; horizontal pass into a uint8 intermediate, vertical pass from it.  Only the pixels of the centre crop
 // (and the rows the vertical pass will read) are produced.  Three HBM-bound launches per batch:
 //   1. prep_coeffs_kernel   one thread per output index per axis: window + integer weights   (double, every operation rounded once)
-//   2. prep_horizontal_kernel   one workgroup per source row: row -> LDS (coalesced), R x 3 weighted sums -> uint8 [H, R, 3]
+//   2. prep_horizontal_kernel   one workgroup per 8 source rows: rows -> LDS (a word per pixel), R x 3 weighted sums -> uint8 [H, R, 3]
 //   3. prep_vertical_kernel     one workgroup per output row: weighted sums down the columns -> uint8 -> (x / 255 - mean) / std, CHW f32
 #include "cmh_common.h"
 
@@ -94,75 +94,112 @@ __device__ __forceinline__ int prep_clip8(int v) {
   return v < 0 ? 0 : (v > 255 ? 255 : v);
 }
 
-// grid (max_h, B), block 256: source row y of image b -> tmp[b][y][j][c], j < R
+constexpr int kPrepRows = 8;   // source rows per workgroup of the horizontal pass
+
+// grid (ceil(max_h / 8), B), block 256: source rows 8*blockIdx.x .. +7 of image b -> tmp[b][y][j][c], j < R.
+// The rows are staged in LDS as one 32-bit word per pixel (R | G << 8 | B << 16): a tap is one ds_read_b32 instead of three
+// byte reads, and every weight (loaded once per tap) serves 8 rows x 3 channels = 24 independent accumulators.
 __global__ __launch_bounds__(256) void prep_horizontal_kernel(const uint8_t* __restrict__ pixels, const int64_t* __restrict__ offsets,
                                                               const int32_t* __restrict__ hw, int R, int KS,
                                                               const int32_t* __restrict__ coef, const int32_t* __restrict__ bounds,
                                                               const PrepImage* __restrict__ info, uint8_t* __restrict__ tmp,
-                                                              size_t tmp_stride) {
-  extern __shared__ uint8_t row[];
-  const int b = blockIdx.y, y = blockIdx.x;
+                                                              size_t tmp_stride, int pitch) {
+  extern __shared__ uint32_t rows[];   // [8][pitch]
+  const int b = blockIdx.y, y0 = blockIdx.x * kPrepRows;
   const int h = hw[2 * b], w = hw[2 * b + 1];
-  if (y >= h || y < info[b].row_lo || y >= info[b].row_hi) return;
-  const uint8_t* src = pixels + offsets[b] + static_cast<size_t>(y) * w * 3;
-  const int nbytes = w * 3;
-  // coalesced copy of the row: 4-byte words once the source is aligned
-  const int head = static_cast<int>((4 - (reinterpret_cast<uintptr_t>(src) & 3)) & 3);
-  for (int i = threadIdx.x; i < head && i < nbytes; i += blockDim.x) row[i] = src[i];
-  const int words = nbytes > head ? (nbytes - head) >> 2 : 0;
-  // row[] is filled at byte offset `head` + 4k, which is not 4-aligned in LDS unless head == 0: write bytes
-  for (int i = threadIdx.x; i < words; i += blockDim.x) {
-    const uint32_t v = *reinterpret_cast<const uint32_t*>(src + head + 4 * i);
-    uint8_t* d = row + head + 4 * i;
-    d[0] = v & 255; d[1] = (v >> 8) & 255; d[2] = (v >> 16) & 255; d[3] = v >> 24;
+  const int lo = info[b].row_lo, hi = info[b].row_hi < h ? info[b].row_hi : h;
+  if (y0 >= hi || y0 + kPrepRows <= lo) return;
+  const uint8_t* img = pixels + offsets[b];
+  for (int r = 0; r < kPrepRows; ++r) {
+    int y = y0 + r;
+    y = y < h ? y : h - 1;                       // rows past the image repeat the last one (never stored)
+    const uint8_t* src = img + static_cast<size_t>(y) * w * 3;
+    for (int x = threadIdx.x; x < w; x += blockDim.x)
+      rows[r * pitch + x] = static_cast<uint32_t>(src[3 * x]) | (static_cast<uint32_t>(src[3 * x + 1]) << 8) |
+                            (static_cast<uint32_t>(src[3 * x + 2]) << 16);
   }
-  for (int i = head + 4 * words + threadIdx.x; i < nbytes; i += blockDim.x) row[i] = src[i];
   __syncthreads();
   const int32_t* kc = coef + (static_cast<size_t>(b) * 2 + 1) * KS * R;
   const int32_t* bd = bounds + (static_cast<size_t>(b) * 2 + 1) * R * 2;
-  uint8_t* dst = tmp + static_cast<size_t>(b) * tmp_stride + static_cast<size_t>(y) * R * 3;
   for (int j = threadIdx.x; j < R; j += blockDim.x) {
     const int xmin = bd[2 * j], n = bd[2 * j + 1];
-    int s0 = 1 << (kPrecisionBits - 1), s1 = s0, s2 = s0;
-    const uint8_t* p = row + xmin * 3;
+    int acc[kPrepRows][3];
+#pragma unroll
+    for (int r = 0; r < kPrepRows; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 1 << (kPrecisionBits - 1);
     for (int x = 0; x < n; ++x) {
       const int k = kc[static_cast<size_t>(x) * R + j];
-      s0 += p[3 * x] * k; s1 += p[3 * x + 1] * k; s2 += p[3 * x + 2] * k;
+#pragma unroll
+      for (int r = 0; r < kPrepRows; ++r) {
+        const uint32_t v = rows[r * pitch + xmin + x];
+        acc[r][0] += static_cast<int>(v & 255u) * k;
+        acc[r][1] += static_cast<int>((v >> 8) & 255u) * k;
+        acc[r][2] += static_cast<int>(v >> 16) * k;
+      }
     }
-    dst[3 * j] = static_cast<uint8_t>(prep_clip8(s0));
-    dst[3 * j + 1] = static_cast<uint8_t>(prep_clip8(s1));
-    dst[3 * j + 2] = static_cast<uint8_t>(prep_clip8(s2));
+#pragma unroll
+    for (int r = 0; r < kPrepRows; ++r) {
+      const int y = y0 + r;
+      if (y >= lo && y < hi) {
+        uint8_t* dst = tmp + static_cast<size_t>(b) * tmp_stride + (static_cast<size_t>(y) * R + j) * 3;
+        dst[0] = static_cast<uint8_t>(prep_clip8(acc[r][0]));
+        dst[1] = static_cast<uint8_t>(prep_clip8(acc[r][1]));
+        dst[2] = static_cast<uint8_t>(prep_clip8(acc[r][2]));
+      }
+    }
   }
 }
 
-// grid (R, B), block 256: output row i of image b
+// grid (R, B), block 256: output row i of image b.  The pass is element-wise along the row, so a thread takes 4 consecutive
+// BYTES of the interleaved row (one 32-bit load per tap; R*3 is padded to words by the row pitch), the finished uint8 row goes
+// through LDS and leaves as three coalesced float planes.
 __global__ __launch_bounds__(256) void prep_vertical_kernel(const uint8_t* __restrict__ tmp, size_t tmp_stride, int R, int KS,
                                                             const int32_t* __restrict__ coef, const int32_t* __restrict__ bounds,
                                                             float m0, float m1, float m2, float d0, float d1, float d2,
                                                             float* __restrict__ out, uint8_t* __restrict__ out_u8) {
+  __shared__ uint32_t line[(1024 * 3 + 3) / 4];
   const int b = blockIdx.y, i = blockIdx.x;
   const int32_t* kc = coef + (static_cast<size_t>(b) * 2 + 0) * KS * R;
   const int32_t* bd = bounds + (static_cast<size_t>(b) * 2 + 0) * R * 2;
   const int ymin = bd[2 * i], n = bd[2 * i + 1];
-  const uint8_t* src = tmp + static_cast<size_t>(b) * tmp_stride + static_cast<size_t>(ymin) * R * 3;
-  const size_t plane = static_cast<size_t>(R) * R;
-  for (int j = threadIdx.x; j < R; j += blockDim.x) {
-    int s0 = 1 << (kPrecisionBits - 1), s1 = s0, s2 = s0;
+  const int row_bytes = R * 3, words = (row_bytes + 3) >> 2;
+  const uint8_t* src = tmp + static_cast<size_t>(b) * tmp_stride + static_cast<size_t>(ymin) * row_bytes;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(src) | static_cast<uintptr_t>(row_bytes)) & 3) == 0;
+  for (int q = threadIdx.x; q < words; q += blockDim.x) {
+    int s0 = 1 << (kPrecisionBits - 1), s1 = s0, s2 = s0, s3 = s0;
     for (int y = 0; y < n; ++y) {
       const int k = kc[static_cast<size_t>(y) * R + i];
-      const uint8_t* p = src + (static_cast<size_t>(y) * R + j) * 3;
-      s0 += p[0] * k; s1 += p[1] * k; s2 += p[2] * k;
+      const uint8_t* p = src + static_cast<size_t>(y) * row_bytes + 4 * q;
+      uint32_t v;
+      if (aligned) v = *reinterpret_cast<const uint32_t*>(p);
+      else {                                   // bytes past the row's end belong to the next row / the padding: never stored
+        const int left = row_bytes - 4 * q;
+        v = p[0] | (left > 1 ? static_cast<uint32_t>(p[1]) << 8 : 0u) | (left > 2 ? static_cast<uint32_t>(p[2]) << 16 : 0u) |
+            (left > 3 ? static_cast<uint32_t>(p[3]) << 24 : 0u);
+      }
+      s0 += static_cast<int>(v & 255u) * k; s1 += static_cast<int>((v >> 8) & 255u) * k;
+      s2 += static_cast<int>((v >> 16) & 255u) * k; s3 += static_cast<int>(v >> 24) * k;
     }
-    const int c0 = prep_clip8(s0), c1 = prep_clip8(s1), c2 = prep_clip8(s2);
-    if (out_u8) {
-      uint8_t* q = out_u8 + ((static_cast<size_t>(b) * R + i) * R + j) * 3;
-      q[0] = static_cast<uint8_t>(c0); q[1] = static_cast<uint8_t>(c1); q[2] = static_cast<uint8_t>(c2);
-    }
-    if (out) {
+    // hipcc (ROCm 7.2) fuses shift + clamp + pack of two values into v_ashr_pk_u8_i32, which writes only the low 16 bits of
+    // its destination, and then ORs the other bytes into the stale upper half.  The explicit masks keep each pair clean.
+    uint32_t lo = static_cast<uint32_t>(prep_clip8(s0)) | (static_cast<uint32_t>(prep_clip8(s1)) << 8);
+    uint32_t hi = static_cast<uint32_t>(prep_clip8(s2)) | (static_cast<uint32_t>(prep_clip8(s3)) << 8);
+    asm volatile("v_and_b32 %0, 0xffff, %0" : "+v"(lo));
+    asm volatile("v_and_b32 %0, 0xffff, %0" : "+v"(hi));
+    line[q] = lo | (hi << 16);
+  }
+  __syncthreads();
+  const uint8_t* lb = reinterpret_cast<const uint8_t*>(line);
+  const size_t plane = static_cast<size_t>(R) * R;
+  if (out_u8) {
+    uint8_t* q8 = out_u8 + (static_cast<size_t>(b) * R + i) * row_bytes;
+    for (int q = threadIdx.x; q < row_bytes; q += blockDim.x) q8[q] = lb[q];
+  }
+  if (out) {
+    for (int j = threadIdx.x; j < R; j += blockDim.x) {
       float* o = out + static_cast<size_t>(b) * 3 * plane + static_cast<size_t>(i) * R + j;
-      o[0] = __fdiv_rn(__fsub_rn(__fdiv_rn(static_cast<float>(c0), 255.0f), m0), d0);
-      o[plane] = __fdiv_rn(__fsub_rn(__fdiv_rn(static_cast<float>(c1), 255.0f), m1), d1);
-      o[2 * plane] = __fdiv_rn(__fsub_rn(__fdiv_rn(static_cast<float>(c2), 255.0f), m2), d2);
+      o[0] = __fdiv_rn(__fsub_rn(__fdiv_rn(static_cast<float>(lb[3 * j]), 255.0f), m0), d0);
+      o[plane] = __fdiv_rn(__fsub_rn(__fdiv_rn(static_cast<float>(lb[3 * j + 1]), 255.0f), m1), d1);
+      o[2 * plane] = __fdiv_rn(__fsub_rn(__fdiv_rn(static_cast<float>(lb[3 * j + 2]), 255.0f), m2), d2);
     }
   }
 }
@@ -190,7 +227,7 @@ extern "C" int cmh_image_preprocess(const uint8_t* pixels, const int64_t* offset
                                     uint8_t* out_u8, void* workspace, size_t workspace_bytes, void* stream) {
   CMH_CHECK_ARG(pixels && offsets && hw && mean && stdv && workspace && (out || out_u8), "image_preprocess: null pointer");
   CMH_CHECK_ARG(batch > 0 && batch <= 65535 && R > 0 && R <= 1024, "image_preprocess: bad batch %d / resolution %d", batch, R);
-  CMH_CHECK_ARG(max_h > 0 && max_w > 0 && max_h <= 16384 && max_w <= 16384, "image_preprocess: bad max size %dx%d", max_h, max_w);
+  CMH_CHECK_ARG(max_h > 0 && max_w > 0 && max_h <= 16384 && max_w <= 4096, "image_preprocess: bad max size %dx%d (width <= 4096)", max_h, max_w);
   const size_t need = cmh_image_preprocess_workspace_bytes(batch, max_h, max_w, R);
   if (workspace_bytes < need) return fail(CMH_ERR_WORKSPACE, "image_preprocess: workspace %zu < %zu bytes", workspace_bytes, need);
   const int KS = prep_ksize(max_h, max_w, R);
@@ -202,8 +239,12 @@ extern "C" int cmh_image_preprocess(const uint8_t* pixels, const int64_t* offset
   const size_t tmp_stride = static_cast<size_t>(max_h) * R * 3;
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(prep_coeffs_kernel, dim3(batch, 2), dim3(256), 0, st, hw, R, train ? 1 : 0, KS, coef, bounds, info);
-  hipLaunchKernelGGL(prep_horizontal_kernel, dim3(max_h, batch), dim3(256), align_up(static_cast<size_t>(max_w) * 3 + 8, 16), st, pixels,
-                     offsets, hw, R, KS, coef, bounds, info, tmp, tmp_stride);
+  static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(prep_horizontal_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) == hipSuccess;
+  if (!lds_ok) return fail(CMH_ERR_LAUNCH, "image_preprocess: cannot raise the dynamic LDS limit");
+  const int pitch = max_w + 1;   // odd-ish pitch: the 8 rows of a tap land on different banks
+  hipLaunchKernelGGL(prep_horizontal_kernel, dim3((max_h + kPrepRows - 1) / kPrepRows, batch), dim3(256),
+                     static_cast<size_t>(kPrepRows) * pitch * 4, st, pixels, offsets, hw, R, KS, coef, bounds, info, tmp, tmp_stride, pitch);
   hipLaunchKernelGGL(prep_vertical_kernel, dim3(R, batch), dim3(256), 0, st, tmp, tmp_stride, R, KS, coef, bounds, mean[0], mean[1], mean[2],
                      stdv[0], stdv[1], stdv[2], out, out_u8);
   CMH_CHECK_LAUNCH("image_preprocess");
