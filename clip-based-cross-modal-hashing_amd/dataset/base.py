@@ -1,0 +1,109 @@
+"""BaseDataset with the reference's constructor and item contract (dataset/base.py:14-106), re-cut for a GPU-side input pipeline.
+
+Upstream `__getitem__` does everything per item on the CPU: PIL decode -> bicubic resize / crop / normalise -> float32
+[3, R, R], and the Python BPE tokenizer.  Here an item carries the DECODED uint8 image and the chosen caption STRING; the
+batch is finished by `collate` (native batch tokenizer -> int64 [B, maxWords], images packed into one ragged uint8 buffer)
+and by `DeviceLoader`, which uploads the raw pixels and runs `cmh_image_preprocess` on the GPU.  What the trainer iterates
+over is unchanged: (image f32 [B, 3, R, R] on the device, caption int64 [B, maxWords], label, index) — bit-identical images
+(tests/test_gpu_preprocess.py) and identical token ids (tests/test_tokenizer.py)."""
+import random
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Dataset
+
+from dataset.gpu_transform import RaggedImages, preprocess
+
+_TOKENIZER = {}
+
+
+def shared_tokenizer(bpe_path=None):
+    """One SimpleTokenizer per process and merges file (DataLoader workers build their own after the fork)."""
+    import os
+    key = (os.getpid(), bpe_path)
+    if key not in _TOKENIZER:
+        from model.base.simple_tokenizer import SimpleTokenizer
+        _TOKENIZER[key] = SimpleTokenizer(bpe_path)
+    return _TOKENIZER[key]
+
+
+class BaseDataset(Dataset):
+
+    def __init__(self, captions, indexs, labels, is_train=True, tokenizer=None, maxWords=32, imageResolution=224, npy=False,
+                 bpe_path=None):
+        self.captions, self.indexs, self.labels, self.npy = captions, indexs, labels, npy
+        self.maxWords, self.imageResolution, self.is_train = maxWords, imageResolution, is_train
+        self._tokenizer, self.bpe_path = tokenizer, bpe_path
+        self.SPECIAL_TOKEN = {"CLS_TOKEN": "<|startoftext|>", "SEP_TOKEN": "<|endoftext|>",
+                              "MASK_TOKEN": "[MASK]", "UNK_TOKEN": "[UNK]", "PAD_TOKEN": "[PAD]"}
+        self.__length = len(self.indexs)
+
+    @property
+    def tokenizer(self):
+        return self._tokenizer if self._tokenizer is not None else shared_tokenizer(self.bpe_path)
+
+    def __len__(self):
+        return self.__length
+
+    def _load_image(self, index: int) -> torch.Tensor:
+        """-> uint8 [H, W, 3]: what `Image.open(path).convert("RGB")` / `Image.fromarray(a).convert("RGB")` hold (base.py:55-62)."""
+        if not self.npy:
+            from PIL import Image
+            arr = np.asarray(Image.open(str(self.indexs[index]).strip()).convert("RGB"))
+        else:
+            arr = np.asarray(self.indexs[index])
+            if arr.dtype != np.uint8 or arr.ndim != 3 or arr.shape[2] != 3:
+                from PIL import Image
+                arr = np.asarray(Image.fromarray(arr).convert("RGB"))
+        return torch.from_numpy(np.ascontiguousarray(arr))
+
+    def _choose_caption(self, index: int) -> str:
+        captions = self.captions[index]
+        return str(captions[random.randint(0, len(captions) - 1)])            # base.py:67-68
+
+    def _load_text(self, index: int):
+        """One caption's ids (upstream's per-item path; the loader uses the batch call in `collate`)."""
+        return self.tokenizer.encode_captions([self._choose_caption(index)], self.maxWords)[0]
+
+    def _load_label(self, index: int) -> torch.Tensor:
+        return torch.from_numpy(np.asarray(self.labels[index]))
+
+    def get_all_label(self):
+        labels = torch.zeros([self.__length, len(self.labels[0])], dtype=torch.float32)
+        for i, item in enumerate(self.labels):
+            labels[i] = torch.from_numpy(np.asarray(item))
+        return labels
+
+    def __getitem__(self, index):
+        return self._load_image(index), self._choose_caption(index), self._load_label(index), index
+
+    # ---- batch side ----------------------------------------------------------------------------------------------------------
+    def collate(self, items):
+        images, captions, labels, index = zip(*items)
+        return (RaggedImages.from_arrays(images, pin=False), self.tokenizer.encode_captions(list(captions), self.maxWords),
+                torch.stack(labels), torch.tensor(index))
+
+    def finish(self, batch, device):
+        """collated batch -> the tuple upstream's loader yields, image already preprocessed on `device`."""
+        ragged, caption, label, index = batch
+        return preprocess(ragged.to(device), self.imageResolution, self.is_train), caption, label, index
+
+
+class DeviceLoader:
+    """DataLoader over a BaseDataset whose batches leave as upstream's (image, caption, label, index) with the image
+    transform done on the GPU.  `len`, `dataset`, iteration: like the DataLoader the trainers hold."""
+
+    def __init__(self, dataset, device, **loader_kwargs):
+        self.dataset, self.device = dataset, device
+        loader_kwargs.pop("pin_memory", None)                  # the ragged buffer is pinned here, after the workers' pickling
+        self.loader = DataLoader(dataset=dataset, collate_fn=dataset.collate, **loader_kwargs)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for batch in self.loader:
+            ragged = batch[0]
+            if torch.cuda.is_available() and not ragged.pixels.is_pinned():
+                ragged.pixels = ragged.pixels.pin_memory()
+            yield self.dataset.finish(batch, self.device)

@@ -8,8 +8,8 @@ Differences from upstream, all deliberate:
   * valid() dispatches get_code_DNPH on 'DNPH' (upstream tests 'DNPH-TOMM', which never matches);
   * code generation runs under no_grad (upstream builds and discards an autograd graph);
   * codes are sign()/argmax'd by libcmh kernels and ranked on the GPU (utils/calc_utils.py).
-Real `.mat` datasets are the host input pipeline (out of scope); `--dataset synthetic`
-exercises the same contract."""
+Real datasets (`--data-dir` with index.mat / caption.mat|txt / label.mat, dataset/dataloader.py) go through the GPU-side
+input pipeline of dataset/base.py; `--dataset synthetic` exercises the same contract without files."""
 import os
 import time
 
@@ -55,10 +55,23 @@ class TrainBase(object):
                 imageResolution=self.args.resolution, query_num=self.args.query_num,
                 train_num=self.args.train_num, seed=self.args.seed)
         else:
-            raise NotImplementedError(
-                "real .mat datasets (index.mat / caption.mat / label.mat + PIL/BPE preprocessing) are the host "
-                "input pipeline, out of scope this round; use --dataset synthetic or feed tensors honouring the "
-                "input contract (image f32 [B,3,224,224], caption i64 [B,maxWords], label [B,C], index)")
+            # reference train/base.py:39-88: <data dir>/index.mat, caption.mat (caption.txt for nuswide), label.mat.  Upstream
+            # hard-codes the directory ('YOUR-FLIE-DIR'); here it is --data-dir.  Items carry raw pixels and caption strings,
+            # the batch is tokenised natively and the image transform runs on the GPU (dataset/base.py).
+            data_dir = self.args.data_dir
+            if not data_dir or not os.path.isdir(data_dir):
+                raise FileNotFoundError(f"--data-dir {data_dir!r}: directory with index.mat / caption.mat|txt / label.mat expected")
+            self.index_file = os.path.join(data_dir, "index.mat")
+            self.caption_file = os.path.join(data_dir, "caption.txt" if 'nuswide' in self.args.dataset else "caption.mat")
+            self.label_file = os.path.join(data_dir, "label.mat")
+            if self.args.method == 'MITH':
+                from train.MITH.data import generate_dataset as dataloader
+            else:
+                from dataset.dataloader import dataloader
+            train_data, query_data, retrieval_data = dataloader(
+                captionFile=self.caption_file, indexFile=self.index_file, labelFile=self.label_file,
+                maxWords=self.args.max_words, imageResolution=self.args.resolution, query_num=self.args.query_num,
+                train_num=self.args.train_num, seed=self.args.seed)
         self.train_labels = train_data.get_all_label().to(self.rank)
         self.query_labels = query_data.get_all_label()
         self.retrieval_labels = retrieval_data.get_all_label()
@@ -66,8 +79,13 @@ class TrainBase(object):
         self.args.query_num = len(self.query_labels)
         self.logger.info(f"query shape: {self.query_labels.shape}")
         self.logger.info(f"retrieval shape: {self.retrieval_labels.shape}")
-        mk = lambda d: DataLoader(dataset=d, batch_size=self.args.batch_size, num_workers=self.args.num_workers,
-                                  pin_memory=True, shuffle=True)
+        if self.args.dataset == 'synthetic':
+            mk = lambda d: DataLoader(dataset=d, batch_size=self.args.batch_size, num_workers=self.args.num_workers,
+                                      pin_memory=True, shuffle=True)
+        else:
+            from dataset.base import DeviceLoader
+            mk = lambda d: DeviceLoader(d, self.rank, batch_size=self.args.batch_size, num_workers=self.args.num_workers,
+                                        shuffle=True)
         self.train_loader, self.query_loader, self.retrieval_loader = mk(train_data), mk(query_data), mk(retrieval_data)
 
     def _init_model(self):

@@ -446,6 +446,19 @@ int cmh_image_preprocess(const uint8_t* pixels, const int64_t* offsets, const in
                          int32_t max_w, int32_t R, int32_t train, const float* mean, const float* stdv, float* out,
                          uint8_t* out_u8, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- input pipeline, text side: host code, no GPU involved ------------------------------------------------
+ * model/base/simple_tokenizer.py:62-79 (tables from the merges text: pass the gunzipped bpe_simple_vocab_16e6.txt) and
+ * dataset/base.py:66-83 (_load_text) for n captions at once: clean -> lower -> split -> BPE -> [SOT] ids [EOT] cut to
+ * max_words, zero padded, int64 [n, max_words].  texts = the captions' UTF-8 bytes back to back, offsets int64 [n + 1].
+ * status[i] = 0: row i is filled; 1: caption i holds bytes outside printable ASCII / tab / CR / LF, or '&' — ftfy / html.unescape
+ * territory — and must go through the Python path (row i is zeroed).  threads <= 0: one per hardware thread (at most 64). */
+typedef struct cmh_bpe cmh_bpe;
+int cmh_bpe_create(const char* merges_utf8, size_t bytes, cmh_bpe** out);
+void cmh_bpe_destroy(cmh_bpe* tokenizer);
+int32_t cmh_bpe_vocab_size(const cmh_bpe* tokenizer);
+int cmh_bpe_encode_captions(const cmh_bpe* tokenizer, const char* texts, const int64_t* offsets, int32_t n, int32_t max_words,
+                            int64_t* out, uint8_t* status, int32_t threads);
+
 size_t cmh_vit_train_bytes(const cmh_vit_weights* w, int32_t batch);
 /* same `feat` as cmh_vit_encode (c_fc's QuickGELU runs as a separate pass over the stored pre-activation) */
 int cmh_vit_forward_train(const cmh_vit_weights* w, const float* image, int32_t batch, float* feat, void* tape, size_t tape_bytes,
