@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-map-eval", action="store_true")
     ap.add_argument("--no-train-step", action="store_true")
+    ap.add_argument("--no-input-pipeline", action="store_true")
     ap.add_argument("--no-dense-text", action="store_true", help="skip the extra timed pass with all text positions computed")
     ap.add_argument("--train-step", action="store_true",
                     help="also time the training step when --gpus > 1 (default: single-GPU runs only, so that the secondary "
@@ -318,6 +319,48 @@ def main():
         except Exception as exc:      # the secondary metric must never take the headline line down
             out["train_step"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
             clip.assume_frozen = True
+
+    if rank == 0 and not a.no_input_pipeline:
+        try:
+            # secondary metric: the input pipeline that feeds the step — image transform of a raw batch on the GPU
+            # (500x375 / 375x500 decoded images -> 224x224 normalised floats, bit-identical to Pillow + torchvision) and the
+            # native batch tokenizer.  The tokenizer needs the CLIP merges file (data, not shipped): reported when it is found.
+            import numpy as np
+            from dataset.gpu_transform import RaggedImages, preprocess
+            rng = np.random.default_rng(0)
+            raw = RaggedImages.from_arrays([rng.integers(0, 256, ((375, 500) if i % 3 else (500, 375)) + (3,), dtype=np.uint8)
+                                            for i in range(B)])
+            on_dev = raw.to(dev)
+            for _ in range(3):
+                preprocess(on_dev, 224, True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                preprocess(on_dev, 224, True)
+            torch.cuda.synchronize()
+            ms_res = (time.perf_counter() - t0) / 10 * 1e3
+            t0 = time.perf_counter()
+            for _ in range(5):
+                preprocess(raw.to(dev), 224, True)
+            torch.cuda.synchronize()
+            ms_h2d = (time.perf_counter() - t0) / 5 * 1e3
+            out["input_pipeline"] = {"image_transform_ms": round(ms_res, 3), "images_per_s": round(B / ms_res * 1e3, 1),
+                                     "with_pinned_h2d_ms": round(ms_h2d, 3), "images_per_s_with_h2d": round(B / ms_h2d * 1e3, 1),
+                                     "GBps_in_plus_out": round((raw.pixels.numel() + B * 3 * 224 * 224 * 4) / ms_res / 1e6, 1),
+                                     "what": f"{B} decoded RGB images (500x375 mix) -> Resize(224, BICUBIC) + CenterCrop + ToTensor + Normalize on the GPU"}
+            try:
+                from model.base.simple_tokenizer import SimpleTokenizer
+                tok = SimpleTokenizer()
+                words = "a man riding a wave on top of a surfboard while two dogs play in the snow near the old red barn".split()
+                caps = [" ".join(rng.choice(words, size=int(rng.integers(8, 25)))) for _ in range(20000)]
+                tok.encode_captions(caps[:2000], 32)
+                t0 = time.perf_counter()
+                tok.encode_captions(caps, 32)
+                out["input_pipeline"]["captions_per_s"] = round(len(caps) / (time.perf_counter() - t0), 1)
+            except FileNotFoundError:
+                out["input_pipeline"]["captions_per_s"] = None
+        except Exception as exc:
+            out["input_pipeline"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cb = cpu_baseline(L, K)
