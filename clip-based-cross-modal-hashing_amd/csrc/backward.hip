@@ -30,9 +30,11 @@ __global__ __launch_bounds__(256) void transpose_kernel(const void* __restrict__
   }
 }
 
-// fast path (R, C, dst_ld multiples of 4): 8/16-byte reads along c and writes along r
+// fast path (C, dst_ld multiples of 4, dst_ld >= R rounded up to 4): 8/16-byte reads along c and writes along r (the last quad
+// of a row writes zeros into the padding).  With `colsum` the workgroup also leaves the column sums of its 64 source rows in
+// colsum[blockIdx.y][c] (the bias gradient's first stage, for free: the tile is in LDS anyway).
 __global__ __launch_bounds__(256) void transpose4_kernel(const void* __restrict__ src, void* __restrict__ dst, int R, int C,
-                                                         int dst_ld, int skind, int dkind) {
+                                                         int dst_ld, int skind, int dkind, float* __restrict__ colsum) {
   __shared__ float tile[64][65];
   const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
   const int q = threadIdx.x & 15, p = threadIdx.x >> 4;      // 16 quads per 64-wide row, 16 rows per pass
@@ -51,10 +53,16 @@ __global__ __launch_bounds__(256) void transpose4_kernel(const void* __restrict_
       store4_from_f32(dst, static_cast<size_t>(c) * dst_ld + r, dkind,
                       float4{tile[q * 4 + 0][i], tile[q * 4 + 1][i], tile[q * 4 + 2][i], tile[q * 4 + 3][i]});
   }
+  if (colsum && threadIdx.x < 64 && c0 + static_cast<int>(threadIdx.x) < C) {
+    float s = 0.f;
+#pragma unroll 16
+    for (int i = 0; i < 64; ++i) s += tile[i][threadIdx.x];
+    colsum[static_cast<size_t>(blockIdx.y) * C + c0 + threadIdx.x] = s;
+  }
 }
 
 // ---- column sums: partial[b, c] = sum over the block's rows; then a second pass over the partials ------------------------
-constexpr int kColRows = 128;   // rows per workgroup
+constexpr int kColRows = 64;    // rows per workgroup (= the transpose tile, whose fused column sums share the layout)
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const void* __restrict__ x, int kind, int R, int C,
                                                              float* __restrict__ partial) {
   const int c = blockIdx.x * 256 + threadIdx.x;
@@ -235,14 +243,21 @@ static int kind_ok(int k) { return k == kF32 || k == kBF16 || k == kF16; }
 using namespace cmh;
 
 namespace cmh {
-int launch_transpose(const void* src, int skind, void* dst, int dkind, int rows, int cols, int dst_ld, hipStream_t st) {
+bool transpose_is_vectorised(const void* src, const void* dst, int rows, int cols, int dst_ld) {
+  return cols % 4 == 0 && dst_ld % 4 == 0 && dst_ld >= (rows + 3) / 4 * 4 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 &&
+         (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+}
+
+// colsum_partial (optional, vectorised path only — check transpose_is_vectorised first): [ceil(rows / 64), cols] partial column sums
+int launch_transpose(const void* src, int skind, void* dst, int dkind, int rows, int cols, int dst_ld, hipStream_t st,
+                     float* colsum_partial) {
   CMH_CHECK_ARG(src && dst && rows > 0 && cols > 0 && dst_ld >= rows, "transpose: bad arguments");
   CMH_CHECK_ARG(kind_ok(skind) && kind_ok(dkind), "transpose: bad element kind %d / %d", skind, dkind);
-  const bool vec = rows % 4 == 0 && cols % 4 == 0 && dst_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 &&
-                   (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+  const bool vec = transpose_is_vectorised(src, dst, rows, cols, dst_ld);
+  CMH_CHECK_ARG(vec || !colsum_partial, "transpose: fused column sums need the vectorised path");
   if (vec)
     hipLaunchKernelGGL(transpose4_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, st, src, dst, rows, cols, dst_ld,
-                       skind, dkind);
+                       skind, dkind, colsum_partial);
   else
     hipLaunchKernelGGL(transpose_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, st, src, dst, rows, cols, dst_ld,
                        skind, dkind);
@@ -253,8 +268,16 @@ int launch_transpose(const void* src, int skind, void* dst, int dkind, int rows,
 
 extern "C" int cmh_transpose(const void* src, int32_t src_kind, void* dst, int32_t dst_kind, int32_t rows, int32_t cols,
                              void* stream) {
-  return launch_transpose(src, src_kind, dst, dst_kind, rows, cols, rows, as_stream(stream));
+  return launch_transpose(src, src_kind, dst, dst_kind, rows, cols, rows, as_stream(stream), nullptr);
 }
+
+namespace cmh {
+int launch_colsum_final(const float* partial, int slices, int cols, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, partial, slices, cols, out, nullptr, nullptr);
+  CMH_CHECK_LAUNCH("colsum_final");
+  return CMH_OK;
+}
+}  // namespace cmh
 
 extern "C" size_t cmh_colsum_workspace_bytes(int32_t rows, int32_t cols) {
   if (rows <= 0 || cols <= 0) return 0;

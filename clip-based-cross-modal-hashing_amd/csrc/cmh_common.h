@@ -152,7 +152,10 @@ int launch_vit_assemble(const float* patch_out, const float* cls, const float* p
 int launch_attention_backward(int dtype, const void* qkv, const void* o, const void* dout, void* dqkv, int B, int T, int d, int causal,
                               const uint8_t* key_padding_mask, const int32_t* seq_off, hipStream_t st);
 // backward.hip: dst[c*dst_ld + r] = cast(src[r*cols + c]); LayerNorm backward with optional gathered rows (x / dx rows = row_index[r])
-int launch_transpose(const void* src, int skind, void* dst, int dkind, int rows, int cols, int dst_ld, hipStream_t st);
+int launch_transpose(const void* src, int skind, void* dst, int dkind, int rows, int cols, int dst_ld, hipStream_t st,
+                     float* colsum_partial = nullptr);   // + [ceil(rows/64), cols] partial column sums (vectorised path only)
+bool transpose_is_vectorised(const void* src, const void* dst, int rows, int cols, int dst_ld);
+int launch_colsum_final(const float* partial, int slices, int cols, float* out, hipStream_t st);
 int launch_layernorm_backward(const void* x, int x_kind, const void* dy, int dy_kind, const float* gamma, const int32_t* row_index,
                               int M, int d, float* dx, int accumulate, float* dgamma, float* dbeta, void* workspace,
                               size_t workspace_bytes, hipStream_t st);

@@ -162,14 +162,18 @@ int wgrad_core(int dt, const void* dY, int ky, int O, const void* X, int kx, int
                const WgradScratch& w, hipStream_t st) {
   const int mp = static_cast<int>(pad64(M));
   int rc;
-  if ((rc = launch_transpose(dY, ky, w.tA, ekind(dt), M, O, mp, st))) return rc;
+  // db = column sums of dY: their first stage rides on the transpose of dY when that takes the tiled path
+  const bool fuse_db = db && transpose_is_vectorised(dY, w.tA, M, O, mp) && w.red_bytes >= static_cast<size_t>((M + 63) / 64) * O * 4 + 256;
+  float* dbp = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(w.red) + 255) & ~static_cast<uintptr_t>(255));
+  if ((rc = launch_transpose(dY, ky, w.tA, ekind(dt), M, O, mp, st, fuse_db ? dbp : nullptr))) return rc;
+  if (fuse_db && (rc = launch_colsum_final(dbp, (M + 63) / 64, O, db, st))) return rc;
   if ((rc = launch_transpose(X, kx, w.tB, ekind(dt), M, I, mp, st))) return rc;
   const int S = gemm_wide_splitk_plan(dt, O, I, mp);
   if (S > 1 && static_cast<size_t>(S) * O * I * 4 <= w.part_bytes) {
     // few output tiles, K = M rows: split K over S groups of workgroups, partial planes summed afterwards
     if ((rc = launch_gemm_wide_splitk(dt, w.tA, w.tB, dW, w.part, S, O, I, mp, st))) return rc;
   } else if ((rc = launch_gemm(dt, w.tA, w.tB, nullptr, nullptr, dW, O, I, mp, 0, st))) return rc;
-  if (db && (rc = cmh_colsum(dY, ky, M, O, db, w.red, w.red_bytes, st))) return rc;
+  if (db && !fuse_db && (rc = cmh_colsum(dY, ky, M, O, db, w.red, w.red_bytes, st))) return rc;
   return CMH_OK;
 }
 

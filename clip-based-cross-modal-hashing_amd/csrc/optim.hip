@@ -171,22 +171,42 @@ extern "C" int cmh_bert_adam_step(const cmh_adam_tensor* tensors, int32_t count,
   AdamChunk* dC = reinterpret_cast<AdamChunk*>(ws + align_up(sizeof(AdamTensorDev) * count, 256));
   float* dP = reinterpret_cast<float*>(reinterpret_cast<char*>(dC) + align_up(sizeof(AdamChunk) * chunks, 256));
   float* dK = reinterpret_cast<float*>(reinterpret_cast<char*>(dP) + align_up(4 * chunks, 256));
-  // host tables (thread-local staging so the async copies read stable memory until the next call on this thread)
-  static thread_local std::vector<AdamTensorDev> hT;
-  static thread_local std::vector<AdamChunk> hC;
+  // Host tables go through two pinned staging buffers used in turn: a buffer is rewritten only after the event recorded behind
+  // its previous upload (two calls ago) has passed, so the call never waits for the stream — the tables are built and queued
+  // while the GPU is still busy with the backward pass.
+  struct Staging {
+    void* buf[2] = {nullptr, nullptr};
+    size_t cap[2] = {0, 0};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int cur = 0;
+  };
+  static thread_local Staging sg;
   hipStream_t st = as_stream(stream);
-  if (hipStreamSynchronize(st) != hipSuccess) return fail(CMH_ERR_LAUNCH, "bert_adam_step: stream sync failed");   // staging reuse
-  hT.resize(count);
-  hC.resize(chunks);
+  sg.cur ^= 1;
+  const int k = sg.cur;
+  if (sg.ev[k] && hipEventSynchronize(sg.ev[k]) != hipSuccess) return fail(CMH_ERR_LAUNCH, "bert_adam_step: staging event wait failed");
+  const size_t tb = align_up(sizeof(AdamTensorDev) * count, 256), cb = sizeof(AdamChunk) * chunks;
+  if (sg.cap[k] < tb + cb) {
+    if (sg.buf[k]) (void)hipHostFree(sg.buf[k]);
+    sg.cap[k] = (tb + cb) * 5 / 4;
+    if (hipHostMalloc(&sg.buf[k], sg.cap[k], hipHostMallocDefault) != hipSuccess) {
+      sg.buf[k] = nullptr; sg.cap[k] = 0;
+      return fail(CMH_ERR_LAUNCH, "bert_adam_step: pinned staging allocation failed");
+    }
+  }
+  if (!sg.ev[k] && hipEventCreateWithFlags(&sg.ev[k], hipEventDisableTiming) != hipSuccess)
+    return fail(CMH_ERR_LAUNCH, "bert_adam_step: event creation failed");
+  AdamTensorDev* hT = reinterpret_cast<AdamTensorDev*>(sg.buf[k]);
+  AdamChunk* hC = reinterpret_cast<AdamChunk*>(static_cast<char*>(sg.buf[k]) + tb);
   size_t ci = 0;
   for (int i = 0; i < count; ++i) {
     hT[i] = AdamTensorDev{tensors[i].p, tensors[i].g, tensors[i].m, tensors[i].v, tensors[i].n, tensors[i].lr,
                           tensors[i].weight_decay, tensors[i].max_grad_norm, static_cast<int>(ci)};
     const int nch = static_cast<int>((tensors[i].n + kAdamChunk - 1) / kAdamChunk);
-    for (int k = 0; k < nch; ++k) hC[ci++] = AdamChunk{i, k};
+    for (int c = 0; c < nch; ++c) hC[ci++] = AdamChunk{i, c};
   }
-  if (hipMemcpyAsync(dT, hT.data(), sizeof(AdamTensorDev) * count, hipMemcpyHostToDevice, st) != hipSuccess ||
-      hipMemcpyAsync(dC, hC.data(), sizeof(AdamChunk) * chunks, hipMemcpyHostToDevice, st) != hipSuccess)
+  if (hipMemcpyAsync(dT, hT, sizeof(AdamTensorDev) * count, hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(dC, hC, cb, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(sg.ev[k], st) != hipSuccess)
     return fail(CMH_ERR_LAUNCH, "bert_adam_step: table upload failed");
   // the reference forms 1 - beta in python doubles and ATen rounds each scalar to f32 once (optimization.py:141,143)
   const float omb1 = static_cast<float>(1.0 - b1), omb2 = static_cast<float>(1.0 - b2);
