@@ -81,32 +81,83 @@ __global__ __launch_bounds__(256) void dsph_multi_kernel(const float* __restrict
   multi[b] = s > 1.f;
 }
 
+// Pair term of HyP (train/DSPH/loss.py:43-63) over all ordered pairs (i, j) of multi-label rows with disjoint labels.
+// One workgroup per 64 x 64 tile of pairs, a thread owns 4 x 4 of them: rows and labels are staged through LDS in chunks of 32
+// columns (every global element is read once per tile instead of once per pair), and each pair keeps the same ascending-k fma
+// chain as a straightforward loop.  O(B^2 K) work: this is the part of a data-parallel step that grows with the GLOBAL batch.
+template <int PT>   // pairs per thread and side: tile = 16 * PT rows (64, or 32 while the grid would not fill the chip)
 __global__ __launch_bounds__(256) void dsph_pair_kernel(const float* __restrict__ xn, const float* __restrict__ yn,
                                                         const float* __restrict__ label, const int* __restrict__ multi,
                                                         int B, int K, int C, float thr, double* __restrict__ acc) {
+  constexpr int TS = 16 * PT, CH = 32;
+  __shared__ float sXi[TS][CH + 1], sTi[TS][CH + 1], sXj[TS][CH + 1], sTj[TS][CH + 1];
   __shared__ double sh[4];
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ int any_i, any_j;
+  const int i0 = blockIdx.y * TS, j0 = blockIdx.x * TS;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  if (threadIdx.x == 0) { any_i = 0; any_j = 0; }
+  __syncthreads();
+  if (threadIdx.x < TS) {
+    if (i0 + threadIdx.x < B && multi[i0 + threadIdx.x]) any_i = 1;
+    if (j0 + threadIdx.x < B && multi[j0 + threadIdx.x]) any_j = 1;
+  }
+  __syncthreads();
   double v[4] = {0, 0, 0, 0};
-  if (idx < B * B) {
-    const int i = idx / B, j = idx - i * B;
-    if (multi[i] && multi[j]) {
-      float ll = 0.f;
-      for (int c = 0; c < C; ++c) ll = fmaf(label[static_cast<size_t>(i) * C + c], label[static_cast<size_t>(j) * C + c], ll);
-      if (ll == 0.f) {
-        float sx = 0.f, st = 0.f, sxt = 0.f;
-        for (int k = 0; k < K; ++k) {
-          const float xi = xn[static_cast<size_t>(i) * K + k], xj = xn[static_cast<size_t>(j) * K + k];
-          const float ti = yn[static_cast<size_t>(i) * K + k], tj = yn[static_cast<size_t>(j) * K + k];
-          sx = fmaf(xi, xj, sx);
-          st = fmaf(ti, tj, st);
-          sxt = fmaf(xi, tj, sxt);
-        }
-        v[0] = fmaxf(sx - thr, 0.f);
-        v[1] = fmaxf(st - thr, 0.f);
-        v[2] = fmaxf(sxt - thr, 0.f);
-        v[3] = 1.0;
+  if (any_i && any_j) {                      // uniform: a tile without multi-label rows on one side has no pair
+    auto stage = [&](const float* src, int r0, int c0, int ncol, float (*dst)[CH + 1]) {
+      for (int e = threadIdx.x; e < TS * CH; e += 256) {
+        const int r = e / CH, c = e - r * CH;
+        dst[r][c] = (r0 + r < B && c0 + c < ncol) ? src[static_cast<size_t>(r0 + r) * ncol + c0 + c] : 0.f;
+      }
+    };
+    float ll[PT][PT], sx[PT][PT], st[PT][PT], sxt[PT][PT];
+#pragma unroll
+    for (int a = 0; a < PT; ++a)
+#pragma unroll
+      for (int b = 0; b < PT; ++b) { ll[a][b] = 0.f; sx[a][b] = 0.f; st[a][b] = 0.f; sxt[a][b] = 0.f; }
+    for (int c0 = 0; c0 < C; c0 += CH) {
+      __syncthreads();
+      stage(label, i0, c0, C, sXi);
+      stage(label, j0, c0, C, sXj);
+      __syncthreads();
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int a = 0; a < PT; ++a)
+#pragma unroll
+          for (int b = 0; b < PT; ++b) ll[a][b] = fmaf(sXi[ty * PT + a][c], sXj[tx * PT + b][c], ll[a][b]);
+    }
+    for (int k0 = 0; k0 < K; k0 += CH) {
+      __syncthreads();
+      stage(xn, i0, k0, K, sXi); stage(yn, i0, k0, K, sTi);
+      stage(xn, j0, k0, K, sXj); stage(yn, j0, k0, K, sTj);
+      __syncthreads();
+      const int kc = K - k0 < CH ? K - k0 : CH;
+      for (int k = 0; k < kc; ++k) {
+        float xi[PT], ti[PT], xj[PT], tj[PT];
+#pragma unroll
+        for (int a = 0; a < PT; ++a) { xi[a] = sXi[ty * PT + a][k]; ti[a] = sTi[ty * PT + a][k]; xj[a] = sXj[tx * PT + a][k]; tj[a] = sTj[tx * PT + a][k]; }
+#pragma unroll
+        for (int a = 0; a < PT; ++a)
+#pragma unroll
+          for (int b = 0; b < PT; ++b) {
+            sx[a][b] = fmaf(xi[a], xj[b], sx[a][b]);
+            st[a][b] = fmaf(ti[a], tj[b], st[a][b]);
+            sxt[a][b] = fmaf(xi[a], tj[b], sxt[a][b]);
+          }
       }
     }
+#pragma unroll
+    for (int a = 0; a < PT; ++a)
+#pragma unroll
+      for (int b = 0; b < PT; ++b) {
+        const int i = i0 + ty * PT + a, j = j0 + tx * PT + b;
+        if (i < B && j < B && multi[i] && multi[j] && ll[a][b] == 0.f) {
+          v[0] += fmaxf(sx[a][b] - thr, 0.f);
+          v[1] += fmaxf(st[a][b] - thr, 0.f);
+          v[2] += fmaxf(sxt[a][b] - thr, 0.f);
+          v[3] += 1.0;
+        }
+      }
   }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -208,7 +259,10 @@ extern "C" int cmh_dsph_hyp_loss(const float* x, const float* y, const float* la
   hipLaunchKernelGGL(dsph_proxy_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, xn, yn, pn, label, B, K, C, threshold, acc);
   if (alpha > 0.f) {
     hipLaunchKernelGGL(dsph_multi_kernel, dim3((B + 255) / 256), dim3(256), 0, st, label, B, C, multi);
-    hipLaunchKernelGGL(dsph_pair_kernel, dim3((B * B + 255) / 256), dim3(256), 0, st, xn, yn, label, multi, B, K, C, threshold, acc);
+    if (B > 1024)
+      hipLaunchKernelGGL(dsph_pair_kernel<4>, dim3((B + 63) / 64, (B + 63) / 64), dim3(256), 0, st, xn, yn, label, multi, B, K, C, threshold, acc);
+    else
+      hipLaunchKernelGGL(dsph_pair_kernel<2>, dim3((B + 31) / 32, (B + 31) / 32), dim3(256), 0, st, xn, yn, label, multi, B, K, C, threshold, acc);
   }
   hipLaunchKernelGGL(dsph_finalize_kernel, dim3(1), dim3(1), 0, st, acc, alpha, loss);
   CMH_CHECK_LAUNCH("dsph_hyp_loss");
