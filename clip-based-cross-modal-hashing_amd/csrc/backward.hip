@@ -129,7 +129,8 @@ constexpr int kLnRows = 32;
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ x, int xkind, const void* __restrict__ dy,
                                                             int dykind, const float* __restrict__ g, float* __restrict__ dx,
                                                             int accumulate, int M, int d, float* __restrict__ pg,
-                                                            float* __restrict__ pb, const int32_t* __restrict__ row_index) {
+                                                            float* __restrict__ pb, const int32_t* __restrict__ row_index,
+                                                            bf16_t* __restrict__ dx_bf16) {
   __shared__ float red[2][4][1024];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int nv = (d + 255) / 256;
@@ -201,6 +202,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
                           rstd * (dv[j][2] - ma - xv[j][2] * max_), rstd * (dv[j][3] - ma - xv[j][3] * max_)};
         if (accumulate) { const float4 c = *o; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
         *o = v;
+        // the next GEMMs take this gradient as a bf16 operand: write it here instead of a cast pass over the f32 stream
+        if (dx_bf16) *reinterpret_cast<uint2*>(dx_bf16 + xrow * d + e0) = uint2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
       }
     }
   }
@@ -309,7 +312,7 @@ extern "C" size_t cmh_layernorm_backward_workspace_bytes(int32_t M, int32_t d) {
 namespace cmh {
 int launch_layernorm_backward(const void* x, int x_kind, const void* dy, int dy_kind, const float* gamma, const int32_t* row_index,
                               int M, int d, float* dx, int accumulate, float* dgamma, float* dbeta, void* workspace,
-                              size_t workspace_bytes, hipStream_t st) {
+                              size_t workspace_bytes, hipStream_t st, void* dx_bf16) {
   CMH_CHECK_ARG(x && dy && gamma && dx && dgamma && dbeta && workspace && M > 0, "layernorm_backward: bad arguments");
   CMH_CHECK_ARG(d % 4 == 0 && d <= 1024, "layernorm_backward: d=%d must be a multiple of 4 and <= 1024", d);
   CMH_CHECK_ARG((x_kind == kF32 || x_kind == kF16) && (dy_kind == kF32 || dy_kind == kBF16), "layernorm_backward: bad kinds");
@@ -318,7 +321,7 @@ int launch_layernorm_backward(const void* x, int x_kind, const void* dy, int dy_
   float* pg = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
   float* pb = pg + static_cast<size_t>(nb) * d;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, st, x, x_kind, dy, dy_kind, gamma, dx, accumulate, M, d, pg, pb,
-                     row_index);
+                     row_index, static_cast<bf16_t*>(dx_bf16));
   CMH_CHECK_LAUNCH("layernorm_backward");
   hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 31) / 32, 2), dim3(256), 0, st, pg, nb, d, dgamma, pb, dbeta);
   CMH_CHECK_LAUNCH("layernorm_backward dgamma/dbeta");

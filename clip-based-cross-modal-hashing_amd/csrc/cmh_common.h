@@ -158,7 +158,7 @@ bool transpose_is_vectorised(const void* src, const void* dst, int rows, int col
 int launch_colsum_final(const float* partial, int slices, int cols, float* out, hipStream_t st);
 int launch_layernorm_backward(const void* x, int x_kind, const void* dy, int dy_kind, const float* gamma, const int32_t* row_index,
                               int M, int d, float* dx, int accumulate, float* dgamma, float* dbeta, void* workspace,
-                              size_t workspace_bytes, hipStream_t st);
+                              size_t workspace_bytes, hipStream_t st, void* dx_bf16 = nullptr);   // + a bf16 copy of the new dx
 
 // attention over qkv [B*T, 3d] (dt) -> o [B*T, d] (dt); heads = d/64; causal adds the -inf triu mask
 int launch_attention(const void* qkv, void* o, int dt, int B, int T, int d, int causal,

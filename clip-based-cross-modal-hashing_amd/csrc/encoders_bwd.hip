@@ -39,7 +39,7 @@ struct Carver {
   }
 };
 
-struct LayerTape { void *x_in, *h1, *qkv, *attn, *x_mid, *h2, *pre; };
+struct LayerTape { void *x_in, *h1, *qkv, *attn, *x_mid, *h2, *pre, *act; };   // act = QuickGELU(pre): c_proj's operand, kept for its wgrad
 
 struct TrainBufs {
   std::vector<LayerTape> L;
@@ -54,7 +54,6 @@ struct TrainBufs {
   float* dx;           // [M,d] f32 gradient stream
   float* dx2;          // [M,d] f32
   void* dxe;           // [M,d] e
-  void* mlp;           // [M,4d] e   gelu(pre)
   void* dpre;          // [M,4d] e
   float* part;         // split-K partial planes of the wgrad GEMMs
   size_t part_bytes;
@@ -85,6 +84,7 @@ TrainBufs carve_train(void* ws, size_t M, size_t B, size_t d, size_t e, size_t x
     t.L[i].x_mid = a.take(M * d * xs);
     t.L[i].h2 = a.take(M * d * e);
     t.L[i].pre = a.take(M * 4 * d * e);
+    t.L[i].act = a.take(M * 4 * d * e);
   }
   t.x_last = a.take(M * d * xs);
   t.patches = a.take(g2rows * pk * e);
@@ -96,7 +96,6 @@ TrainBufs carve_train(void* ws, size_t M, size_t B, size_t d, size_t e, size_t x
   t.dx = a.take<float>(M * d * 4);
   t.dx2 = a.take<float>(M * d * 4);
   t.dxe = a.take(M * d * e);
-  t.mlp = a.take(M * 4 * d * e);
   t.dpre = a.take(M * 4 * d * e);
   t.part_bytes = static_cast<size_t>(256 + 64) * 160 * 256 * 4;      // <= one round of 160x256 f32 tiles (kPartBytes)
   t.part = a.take<float>(t.part_bytes);
@@ -138,7 +137,7 @@ int as_gemm_operand(int dt, const float* x, void* scratch, size_t n, hipStream_t
 
 struct BlockGradPtrs { float *in_w, *in_b, *out_w, *out_b, *ln1_w, *ln1_b, *ln2_w, *ln2_b, *fc_w, *fc_b, *proj_w, *proj_b; };
 
-int block_forward_train(const cmh_block_weights& w, int dt, int xh, const LayerTape& L, void* x_next, void* mlp, int B, int T,
+int block_forward_train(const cmh_block_weights& w, int dt, int xh, const LayerTape& L, void* x_next, int B, int T,
                         int d, int causal, const uint8_t* kpm, hipStream_t st, int rows = -1, const int32_t* seq_off = nullptr) {
   const int M = rows >= 0 ? rows : B * T;
   const int obf = dt == CMH_BF16 ? EPI_OUT_BF16 : 0;
@@ -150,8 +149,8 @@ int block_forward_train(const cmh_block_weights& w, int dt, int xh, const LayerT
   if ((rc = launch_gemm(dt, L.attn, w.out_proj_w, w.out_proj_b, static_cast<const float*>(L.x_in), L.x_mid, M, d, d, rx, st))) return rc;
   if ((rc = launch_layernorm_x(L.x_mid, xh, nullptr, w.ln2_w, w.ln2_b, L.h2, dt == CMH_BF16, M, d, st))) return rc;
   if ((rc = launch_gemm(dt, L.h2, w.fc_w, w.fc_b, nullptr, L.pre, M, 4 * d, d, EPI_BIAS | obf, st))) return rc;
-  if ((rc = cmh_quick_gelu(L.pre, mlp, static_cast<int64_t>(M) * 4 * d, ekind(dt), st))) return rc;
-  if ((rc = launch_gemm(dt, mlp, w.proj_w, w.proj_b, static_cast<const float*>(L.x_mid), x_next, M, d, 4 * d, rx, st))) return rc;
+  if ((rc = cmh_quick_gelu(L.pre, L.act, static_cast<int64_t>(M) * 4 * d, ekind(dt), st))) return rc;
+  if ((rc = launch_gemm(dt, L.act, w.proj_w, w.proj_b, static_cast<const float*>(L.x_mid), x_next, M, d, 4 * d, rx, st))) return rc;
   return CMH_OK;
 }
 
@@ -191,25 +190,29 @@ int dgrad(int dt, const void* dYe, const void* W, int O, int I, int M, const voi
 }
 
 int block_backward(const cmh_block_weights& w, const BlockGradPtrs& g, int dt, int xh, const LayerTape& L, TrainBufs& t, int B,
-                   int T, int d, int causal, const uint8_t* kpm, hipStream_t st, int rows = -1, const int32_t* seq_off = nullptr) {
+                   int T, int d, int causal, const uint8_t* kpm, hipStream_t st, bool dxe_ready, int rows = -1,
+                   const int32_t* seq_off = nullptr) {
   const int M = rows >= 0 ? rows : B * T;
   const int obf = dt == CMH_BF16 ? EPI_OUT_BF16 : 0;
   const int ek = ekind(dt), xk = xkind(xh);
   const size_t md = static_cast<size_t>(M) * d;
   const void* dxe = nullptr;
+  // bf16 mode: the LayerNorm backward kernels also leave the new dx as the bf16 GEMM operand (t.dxe)
+  void* dx_copy = dt == CMH_BF16 ? t.dxe : nullptr;
   int rc;
-  // 1. MLP projection
-  if ((rc = as_gemm_operand(dt, t.dx, t.dxe, md, st, &dxe))) return rc;
+  // 1. MLP projection (dxe_ready: the previous block's ln_1 backward already wrote t.dxe)
+  if (dxe_ready && dx_copy) dxe = t.dxe;
+  else if ((rc = as_gemm_operand(dt, t.dx, t.dxe, md, st, &dxe))) return rc;
   if ((rc = dgrad(dt, dxe, w.proj_w, d, 4 * d, M, L.pre, t.dpre, EPI_MUL_DQGELU | obf, t, st))) return rc;
-  if ((rc = cmh_quick_gelu(L.pre, t.mlp, static_cast<int64_t>(M) * 4 * d, ek, st))) return rc;
-  if ((rc = wgrad(dt, t.dx, kF32, d, t.mlp, ek, 4 * d, M, g.proj_w, g.proj_b, t, st))) return rc;
+  if ((rc = wgrad(dt, t.dx, kF32, d, L.act, ek, 4 * d, M, g.proj_w, g.proj_b, t, st))) return rc;
   // 2. c_fc
   if ((rc = dgrad(dt, t.dpre, w.fc_w, 4 * d, d, M, nullptr, t.dh, obf, t, st))) return rc;
   if ((rc = wgrad(dt, t.dpre, ek, 4 * d, L.h2, ek, d, M, g.fc_w, g.fc_b, t, st))) return rc;
   // 3. ln_2
-  if ((rc = launch_layernorm_backward(L.x_mid, xk, t.dh, ek, w.ln2_w, nullptr, M, d, t.dx, 1, g.ln2_w, g.ln2_b, t.red, t.red_bytes, st))) return rc;
+  if ((rc = launch_layernorm_backward(L.x_mid, xk, t.dh, ek, w.ln2_w, nullptr, M, d, t.dx, 1, g.ln2_w, g.ln2_b, t.red, t.red_bytes, st, dx_copy))) return rc;
   // 4. out_proj
-  if ((rc = as_gemm_operand(dt, t.dx, t.dxe, md, st, &dxe))) return rc;
+  if (dx_copy) dxe = t.dxe;
+  else if ((rc = as_gemm_operand(dt, t.dx, t.dxe, md, st, &dxe))) return rc;
   if ((rc = dgrad(dt, dxe, w.out_proj_w, d, d, M, nullptr, t.dh, obf, t, st))) return rc;
   if ((rc = wgrad(dt, t.dx, kF32, d, L.attn, ek, d, M, g.out_w, g.out_b, t, st))) return rc;
   // 5. attention
@@ -218,7 +221,7 @@ int block_backward(const cmh_block_weights& w, const BlockGradPtrs& g, int dt, i
   if ((rc = dgrad(dt, t.dqkv, w.in_proj_w, 3 * d, d, M, nullptr, t.dh, obf, t, st))) return rc;
   if ((rc = wgrad(dt, t.dqkv, ek, 3 * d, L.h1, ek, d, M, g.in_w, g.in_b, t, st))) return rc;
   // 7. ln_1
-  return launch_layernorm_backward(L.x_in, xk, t.dh, ek, w.ln1_w, nullptr, M, d, t.dx, 1, g.ln1_w, g.ln1_b, t.red, t.red_bytes, st);
+  return launch_layernorm_backward(L.x_in, xk, t.dh, ek, w.ln1_w, nullptr, M, d, t.dx, 1, g.ln1_w, g.ln1_b, t.red, t.red_bytes, st, dx_copy);
 }
 
 BlockGradPtrs grads_of(const cmh_block_grads& g) {
@@ -403,7 +406,7 @@ extern "C" int cmh_vit_forward_train(const cmh_vit_weights* w, const float* imag
   if ((rc = launch_layernorm_any(t.x_pre, kF32, nullptr, w->ln_pre_w, w->ln_pre_b, t.L[0].x_in, xkind(xh), M, d, st))) return rc;
   for (int i = 0; i < w->layers; ++i) {
     void* nxt = i + 1 < w->layers ? t.L[i + 1].x_in : t.x_last;
-    if ((rc = block_forward_train(w->blocks[i], dt, xh, t.L[i], nxt, t.mlp, B, T, d, 0, nullptr, st))) return rc;
+    if ((rc = block_forward_train(w->blocks[i], dt, xh, t.L[i], nxt, B, T, d, 0, nullptr, st))) return rc;
   }
   if ((rc = launch_iota_rows(t.rows, B, T, st))) return rc;
   if ((rc = launch_layernorm_x(t.x_last, xh, t.rows, w->ln_post_w, w->ln_post_b, t.pool, dt == CMH_BF16, B, d, st))) return rc;
@@ -431,7 +434,7 @@ extern "C" int cmh_vit_backward(const cmh_vit_weights* w, int32_t batch, const f
   if ((rc = pooled_backward(dt, xh, t.x_last, t.rows, t.pool, w->proj_t, w->ln_post_w, dfeat, gr->proj, gr->ln_post_w, gr->ln_post_b,
                             t, B, M, d, E, st))) return rc;
   for (int i = w->layers - 1; i >= 0; --i)
-    if ((rc = block_backward(w->blocks[i], grads_of(gr->blocks[i]), dt, xh, t.L[i], t, B, T, d, 0, nullptr, st))) return rc;
+    if ((rc = block_backward(w->blocks[i], grads_of(gr->blocks[i]), dt, xh, t.L[i], t, B, T, d, 0, nullptr, st, i != w->layers - 1))) return rc;
   // ln_pre, then the embeddings: x_pre[b,0] = cls + pos[0], x_pre[b,1+i] = patch_out[b*g2+i] + pos[1+i]
   if ((rc = launch_layernorm_backward(t.x_pre, kF32, t.dx, kF32, w->ln_pre_w, nullptr, M, d, t.dx2, 0, gr->ln_pre_w, gr->ln_pre_b,
                                       t.red, t.red_bytes, st))) return rc;
@@ -481,7 +484,7 @@ extern "C" int cmh_text_forward_train(const cmh_text_weights* w, const int64_t* 
                                      w->vocab_size, seq_off, st))) return rc;
   for (int i = 0; i < w->layers; ++i) {
     void* nxt = i + 1 < w->layers ? t.L[i + 1].x_in : t.x_last;
-    if ((rc = block_forward_train(w->blocks[i], dt, xh, t.L[i], nxt, t.mlp, B, L, d, 1, key_padding_mask, st, rows, seq_off))) return rc;
+    if ((rc = block_forward_train(w->blocks[i], dt, xh, t.L[i], nxt, B, L, d, 1, key_padding_mask, st, rows, seq_off))) return rc;
   }
   if ((rc = launch_layernorm_x(t.x_last, xh, t.rows, w->ln_final_w, w->ln_final_b, t.pool, dt == CMH_BF16, B, d, st))) return rc;
   const int bk = dt == CMH_F32 ? 32 : 64;
@@ -519,7 +522,7 @@ extern "C" int cmh_text_backward(const cmh_text_weights* w, const int64_t* token
   if ((rc = pooled_backward(dt, xh, t.x_last, t.rows, t.pool, w->text_projection_t, w->ln_final_w, dfeat, gr->text_projection,
                             gr->ln_final_w, gr->ln_final_b, t, B, rows, d, E, st))) return rc;
   for (int i = w->layers - 1; i >= 0; --i)
-    if ((rc = block_backward(w->blocks[i], grads_of(gr->blocks[i]), dt, xh, t.L[i], t, B, L, d, 1, key_padding_mask, st, rows, seq_off))) return rc;
+    if ((rc = block_backward(w->blocks[i], grads_of(gr->blocks[i]), dt, xh, t.L[i], t, B, L, d, 1, key_padding_mask, st, i != w->layers - 1, rows, seq_off))) return rc;
   // x_0[b, t] = token_embedding[tokens[b, t]] + positional_embedding[t]
   if (hipMemsetAsync(gr->positional_embedding, 0, static_cast<size_t>(w->context_length) * d * 4, st) != hipSuccess ||
       hipMemsetAsync(gr->token_embedding, 0, static_cast<size_t>(w->vocab_size) * d * 4, st) != hipSuccess)

@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--forward-only", action="store_true", help="tape forward + loss only (for profiling)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -38,6 +39,11 @@ def step(timers=None):
     fi, ft = overlapped(lambda: clip.encode_image(img), lambda: clip.encode_text(txt))
     loss = hyp(hi(fi), ht(ft), lab)
     ev[1].record()
+    if a.forward_only:
+        torch.cuda.synchronize()
+        if timers is not None:
+            timers[0] += ev[0].elapsed_time(ev[1])
+        return float(loss)
     opt.zero_grad(); sgd.zero_grad()
     loss.backward()
     ev[2].record()
