@@ -184,10 +184,15 @@ __global__ __launch_bounds__(256) void attention_bwd_mfma_kernel(const bf16_t* _
   bf16_t* sQT = sDO + TR * LR;       // [64][LT]   Q^T
   bf16_t* sKT = sQT + 64 * LT;
   bf16_t* sDOT = sKT + 64 * LT;
-  bf16_t* sPT = sDOT + 64 * LT;      // [TR][LT]   P^T  [key][q]
-  bf16_t* sDS = sPT + TR * LT;       // [TR][LT]   dS   [q][key]
-  bf16_t* sDST = sDS + TR * LT;      // [TR][LT]   dS^T [key][q]
-  constexpr int kTotal = 4 * TR * LR + 3 * 64 * LT + 3 * TR * LT;
+  // Up to 4 row tiles (T <= 64, the image tower) every wave owns at most one query tile, so phase 1 can finish reading Q, K, V
+  // before anything is written back: P^T, dS, dS^T then take over the Q, K, V slots and the image shrinks from 92 to 65 KB —
+  // two workgroups per CU, which is what this latency-bound kernel needs (one workgroup's loads hide behind the other's MFMAs).
+  constexpr bool ALIAS = NT <= 4;
+  static_assert(!ALIAS || LT <= LR, "aliased operands must fit the row-major slots");
+  bf16_t* sPT = ALIAS ? sQ : sDOT + 64 * LT;       // [TR][LT]   P^T  [key][q]
+  bf16_t* sDS = ALIAS ? sK : sPT + TR * LT;        // [TR][LT]   dS   [q][key]
+  bf16_t* sDST = ALIAS ? sV : sDS + TR * LT;       // [TR][LT]   dS^T [key][q]
+  constexpr int kTotal = 4 * TR * LR + 3 * 64 * LT + (ALIAS ? 0 : 3 * TR * LT);
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, c = lane & 15;
   const int heads = d / HDB;
@@ -225,8 +230,7 @@ __global__ __launch_bounds__(256) void attention_bwd_mfma_kernel(const bf16_t* _
 
   // ---- phase 1: per query tile: S, dP, softmax, D, dS -> P^T, dS, dS^T ------------------------------------------------------
   const int nrt = (Tn + 15) >> 4;        // row tiles that hold real rows
-  for (int ti = wid; ti < nrt; ti += 4) {
-    ab_f32x4_t s[NT], dp[NT];
+  auto phase1_compute = [&](int ti, ab_f32x4_t (&s)[NT], ab_f32x4_t (&dp)[NT], float (&dsum)[4]) __attribute__((always_inline)) {
 #pragma unroll
     for (int tj = 0; tj < NT; ++tj) {
       if (tj < nrt) {
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(256) void attention_bwd_mfma_kernel(const bf16_t* _
         s[tj][r] = p;
         l[r] += p;
       }
-    float dsum[4] = {0.f, 0.f, 0.f, 0.f};
+    dsum[0] = dsum[1] = dsum[2] = dsum[3] = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) l[r] = 1.0f / ab_row_sum(l[r]);
 #pragma unroll
@@ -270,6 +274,8 @@ __global__ __launch_bounds__(256) void attention_bwd_mfma_kernel(const bf16_t* _
       for (int r = 0; r < 4; ++r) { s[tj][r] *= l[r]; dsum[r] += s[tj][r] * dp[tj][r]; }
 #pragma unroll
     for (int r = 0; r < 4; ++r) dsum[r] = ab_row_sum(dsum[r]);
+  };
+  auto phase1_write = [&](int ti, ab_f32x4_t (&s)[NT], ab_f32x4_t (&dp)[NT], float (&dsum)[4]) __attribute__((always_inline)) {
 #pragma unroll
     for (int tj = 0; tj < NT; ++tj) {
       if (tj >= nrt) break;
@@ -281,6 +287,23 @@ __global__ __launch_bounds__(256) void attention_bwd_mfma_kernel(const bf16_t* _
       *reinterpret_cast<uint2*>(sDST + key * LT + q0) = uint2{pack_bf16x2(dsv[0], dsv[1]), pack_bf16x2(dsv[2], dsv[3])};
 #pragma unroll
       for (int r = 0; r < 4; ++r) sDS[(q0 + r) * LT + key] = f32_to_bf16(dsv[r]);
+    }
+  };
+  if constexpr (ALIAS) {
+    ab_f32x4_t s[NT], dp[NT];
+    float dsum[4];
+    if (wid < nrt) phase1_compute(wid, s, dp, dsum);
+    __syncthreads();                      // every wave is done with Q, K, V: their slots become P^T, dS, dS^T
+    // the padding of the new matrices must be exact zeros where phase 2 reads it: rows >= Tn and columns >= Tn
+    for (int i = tid; i < 3 * TR * LR / 2; i += 256) reinterpret_cast<uint32_t*>(sQ)[i] = 0u;
+    __syncthreads();
+    if (wid < nrt) phase1_write(wid, s, dp, dsum);
+  } else {
+    for (int ti = wid; ti < nrt; ti += 4) {
+      ab_f32x4_t s[NT], dp[NT];
+      float dsum[4];
+      phase1_compute(ti, s, dp, dsum);
+      phase1_write(ti, s, dp, dsum);
     }
   }
   __syncthreads();
@@ -304,7 +327,7 @@ template <int NT>
 static int launch_attention_bwd_mfma(const void* qkv, const void* dout, void* dqkv, int B, int T, int d, int causal,
                                      const uint8_t* kpm, const int32_t* seq_off, hipStream_t st) {
   constexpr int TR = NT * 16, KP = ((NT + 1) / 2) * 32;
-  const size_t lds = (static_cast<size_t>(4) * TR * 72 + 3 * 64 * (KP + 8) + 3 * TR * (KP + 8)) * 2;
+  const size_t lds = (static_cast<size_t>(4) * TR * 72 + 3 * 64 * (KP + 8) + (NT <= 4 ? 0 : 3 * TR * (KP + 8))) * 2;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_mfma_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           static_cast<int>(lds)) != hipSuccess) return fail(CMH_ERR_LAUNCH, "attention_backward: cannot reserve %zu bytes of LDS", lds);
   hipLaunchKernelGGL(attention_bwd_mfma_kernel<NT>, dim3(B * (d / HDB)), dim3(256), lds, st, static_cast<const bf16_t*>(qkv),
