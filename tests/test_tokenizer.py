@@ -83,3 +83,20 @@ def test_missing_vocabulary_fails_loudly(tmp_path):
     from model.base.simple_tokenizer import SimpleTokenizer
     with pytest.raises(FileNotFoundError):
         SimpleTokenizer(str(tmp_path / "nope.txt.gz"))
+
+
+def test_random_ascii_agrees_with_the_python_path(mini):
+    """Fuzz: random printable-ASCII strings (heavy on apostrophes, angle brackets, digits, blanks) through the native splitter
+    and BPE against the regex-based Python path, which is pinned to the reference above."""
+    rng = np.random.default_rng(11)
+    alphabet = list("abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ") + list("0123456789") * 2 + list("'''  \t\n<|>|.,!?-_/\\\"#$%()*+:;=@[]^`{}~")
+    pieces = ["<|startoftext|>", "<|endoftext|>", "'s", "'re", "'ll", "n't", " ", "the", "ing", "'", "<|"]
+    caps = []
+    for _ in range(4000):
+        n = int(rng.integers(0, 60))
+        s = "".join(rng.choice(pieces) if rng.random() < 0.12 else rng.choice(alphabet) for _ in range(n))
+        caps.append(s)
+    ids, native = mini.encode_captions(caps, 40, return_native_mask=True)
+    assert native.all()
+    for i, c in enumerate(caps):
+        assert ids[i].tolist() == mini.caption_ids(c, 40), repr(c)
