@@ -348,6 +348,19 @@ def main():
                                      "with_pinned_h2d_ms": round(ms_h2d, 3), "images_per_s_with_h2d": round(B / ms_h2d * 1e3, 1),
                                      "GBps_in_plus_out": round((raw.pixels.numel() + B * 3 * 224 * 224 * 4) / ms_res / 1e6, 1),
                                      "what": f"{B} decoded RGB images (500x375 mix) -> Resize(224, BICUBIC) + CenterCrop + ToTensor + Normalize on the GPU"}
+            from dataset.gpu_transform import normalize_u8
+            cache = torch.randint(0, 256, (4 * B, 224, 224, 3), dtype=torch.uint8, device=dev)     # device-resident resized images
+            pick = torch.randperm(4 * B, device=dev)[:B]
+            for _ in range(3):
+                normalize_u8(cache, pick)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                normalize_u8(cache, pick)
+            torch.cuda.synchronize()
+            ms_c = (time.perf_counter() - t0) / 10 * 1e3
+            out["input_pipeline"]["cached_epoch_batch_ms"] = round(ms_c, 3)
+            out["input_pipeline"]["cached_images_per_s"] = round(B / ms_c * 1e3, 1)
             try:
                 from model.base.simple_tokenizer import SimpleTokenizer
                 tok = SimpleTokenizer()

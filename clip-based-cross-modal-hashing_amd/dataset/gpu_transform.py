@@ -64,6 +64,20 @@ def preprocess(batch: RaggedImages, resolution=224, train=True, mean=MEAN, std=S
     return (out, u8) if want_u8 else out
 
 
+def normalize_u8(u8, rows=None, mean=MEAN, std=STD):
+    """ToTensor + Normalize of resized uint8 images on the device: u8 [N, R, R, 3]; rows (int64 device tensor) gathers a batch."""
+    N.require_gpu(u8, rows)
+    if u8.dtype != torch.uint8 or u8.dim() != 4 or u8.shape[1] != u8.shape[2] or u8.shape[3] != 3 or not u8.is_contiguous():
+        raise ValueError("uint8 [N, R, R, 3] contiguous expected")
+    B, R = (u8.shape[0] if rows is None else rows.numel()), u8.shape[1]
+    if rows is not None:
+        rows = rows.to(torch.int64).contiguous()
+    out = torch.empty(B, 3, R, R, dtype=torch.float32, device=u8.device)
+    m, s = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    N.check(N.lib().cmh_image_normalize(N.ptr(u8), N.ptr(rows), B, R, m, s, N.ptr(out), N.stream_ptr(u8.device)), "cmh_image_normalize")
+    return out
+
+
 class GpuTransform:
     """Drop-in for the Compose([...]) of dataset/base.py:35-44, applied per batch: `GpuTransform(224, is_train)(list_of_arrays, device)`."""
 

@@ -15,6 +15,10 @@ class BasDataset(BaseDataset):
         return image, caption, mask, label, index
 
 
+    def cached_batch(self, image, caption, label, index):
+        return image, caption, caption == 0, label, index
+
+
 def generate_dataset(captionFile: str, indexFile: str, labelFile: str, maxWords=32, imageResolution=224, query_num=2000,
                      train_num=10000, seed=None, bpe_path=None):
     return dataloader(captionFile, indexFile, labelFile, maxWords, imageResolution, query_num, train_num, seed,

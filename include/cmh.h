@@ -446,6 +446,12 @@ int cmh_image_preprocess(const uint8_t* pixels, const int64_t* offsets, const in
                          int32_t max_w, int32_t R, int32_t train, const float* mean, const float* stdv, float* out,
                          uint8_t* out_u8, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ToTensor + Normalize of resized images that already live on the device (dataset/base.py:38-39 / :43-44 alone): u8 uint8
+ * [N, R, R, 3]; rows (optional, device int64 [batch]) picks the images, else the first `batch`; out f32 [batch, 3, R, R].
+ * Serves a device-resident cache of the resized dataset: identical floats to cmh_image_preprocess's, no decode / resize / PCIe. */
+int cmh_image_normalize(const uint8_t* u8, const int64_t* rows, int32_t batch, int32_t R, const float* mean, const float* stdv,
+                        float* out, void* stream);
+
 /* ---- input pipeline, text side: host code, no GPU involved ------------------------------------------------
  * model/base/simple_tokenizer.py:62-79 (tables from the merges text: pass the gunzipped bpe_simple_vocab_16e6.txt) and
  * dataset/base.py:66-83 (_load_text) for n captions at once: clean -> lower -> split -> BPE -> [SOT] ids [EOT] cut to

@@ -66,7 +66,8 @@ def test_real_dataset_trainer_end_to_end(tmp_path, monkeypatch):
     order = np.random.permutation(range(n))
     assert torch.equal(tr.query_labels, torch.from_numpy(lab[order[:24]]))
     tok = st.SimpleTokenizer(str(gz))
-    for loader, ids, train in ((tr.train_loader, order[24:56], True), (tr.query_loader, order[:24], False)):
+    # second pass over each loader: served from the device-resident cache of resized images (no decode / resize), same batches
+    for loader, ids, train in ((tr.train_loader, order[24:56], True), (tr.query_loader, order[:24], False)) * 2:
         seen = 0
         for image, caption, label, index in loader:
             assert image.is_cuda and image.dtype == torch.float32 and image.shape[1:] == (3, 64, 64) and caption.shape[1] == 16
@@ -78,6 +79,7 @@ def test_real_dataset_trainer_end_to_end(tmp_path, monkeypatch):
                 assert np.array_equal(label[k].numpy(), lab[src])
             seen += len(index)
         assert seen == len(ids)
+    assert tr.train_loader.cached_epochs == 1 and tr.query_loader.cached_epochs == 1 and tr.retrieval_loader.cached_epochs == 0
     tr.change_state(mode="valid")
     maps = tr.valid(0)
     assert all(0.0 <= float(m) <= 1.0 for m in maps[:4])
@@ -101,5 +103,13 @@ def test_mith_dataset_carries_the_padding_mask(tmp_path, monkeypatch):
     _write_dataset(data, 30, 24)
     trn, q, r = generate_dataset(str(data / "caption.txt"), str(data / "index.mat"), str(data / "label.mat"), maxWords=16,
                                  imageResolution=32, query_num=10, train_num=12, seed=1, bpe_path=str(gz))
-    image, caption, mask, label, index = next(iter(DeviceLoader(trn, DEV, batch_size=6, shuffle=False)))
+    loader = DeviceLoader(trn, DEV, batch_size=6, shuffle=False)
+    first = [b for b in loader]
+    image, caption, mask, label, index = first[0]
     assert image.shape == (6, 3, 32, 32) and torch.equal(mask, caption == 0) and label.shape == (6, 24)
+    again = [b for b in loader]                                 # from the cache: same images, same order (no shuffle)
+    assert loader.cached_epochs == 1 and len(again) == len(first) == 2
+    for a, b in zip(first, again):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4]) and torch.equal(b[2], b[1] == 0)
+    plain = DeviceLoader(trn, DEV, cache_images=False, batch_size=6, shuffle=False)
+    assert torch.equal(next(iter(plain))[0], first[0][0]) and plain.cached_epochs == 0
