@@ -170,7 +170,7 @@ __device__ __forceinline__ float ab_row_sum(float v) {
 }
 
 template <int NT>    // row tiles: TR = 16 * NT rows, contraction over rows padded to KP = 32 * ceil(NT / 2)
-__global__ __launch_bounds__(256) void attention_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(NT <= 4 ? 256 : 512) void attention_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                                  bf16_t* __restrict__ dqkv, int B, int Tmax, int d, int causal,
                                                                  const uint8_t* __restrict__ kpm, const int32_t* __restrict__ seq_off) {
   constexpr int TR = NT * 16, KP = ((NT + 1) / 2) * 32;
@@ -194,6 +194,8 @@ __global__ __launch_bounds__(256) void attention_bwd_mfma_kernel(const bf16_t* _
   bf16_t* sDST = ALIAS ? sV : sDS + TR * LT;       // [TR][LT]   dS^T [key][q]
   constexpr int kTotal = 4 * TR * LR + 3 * 64 * LT + (ALIAS ? 0 : 3 * TR * LT);
 
+  // NT > 4 (captions longer than 64 tokens): the 136 KB image allows one workgroup per CU, so it gets 8 waves instead of 4
+  constexpr int NW = NT <= 4 ? 4 : 8, NTH = 64 * NW;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, c = lane & 15;
   const int heads = d / HDB;
   const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
@@ -205,9 +207,9 @@ __global__ __launch_bounds__(256) void attention_bwd_mfma_kernel(const bf16_t* _
   bf16_t* dqb = dqkv + row0 * ld + h * HDB;
 
   // ---- stage: zero everything (padding rows / columns must be exact zeros), then the real rows ------------------------
-  for (int i = tid; i < kTotal / 2; i += 256) reinterpret_cast<uint32_t*>(sm)[i] = 0u;
+  for (int i = tid; i < kTotal / 2; i += NTH) reinterpret_cast<uint32_t*>(sm)[i] = 0u;
   __syncthreads();
-  for (int slot = tid; slot < Tn * 8; slot += 256) {
+  for (int slot = tid; slot < Tn * 8; slot += NTH) {
     const int r = slot >> 3, ch = slot & 7;
     const uint4 q = *reinterpret_cast<const uint4*>(qb + static_cast<size_t>(r) * ld + ch * 8);
     const uint4 k = *reinterpret_cast<const uint4*>(qb + d + static_cast<size_t>(r) * ld + ch * 8);
@@ -295,11 +297,11 @@ __global__ __launch_bounds__(256) void attention_bwd_mfma_kernel(const bf16_t* _
     if (wid < nrt) phase1_compute(wid, s, dp, dsum);
     __syncthreads();                      // every wave is done with Q, K, V: their slots become P^T, dS, dS^T
     // the padding of the new matrices must be exact zeros where phase 2 reads it: rows >= Tn and columns >= Tn
-    for (int i = tid; i < 3 * TR * LR / 2; i += 256) reinterpret_cast<uint32_t*>(sQ)[i] = 0u;
+    for (int i = tid; i < 3 * TR * LR / 2; i += NTH) reinterpret_cast<uint32_t*>(sQ)[i] = 0u;
     __syncthreads();
     if (wid < nrt) phase1_write(wid, s, dp, dsum);
   } else {
-    for (int ti = wid; ti < nrt; ti += 4) {
+    for (int ti = wid; ti < nrt; ti += NW) {
       ab_f32x4_t s[NT], dp[NT];
       float dsum[4];
       phase1_compute(ti, s, dp, dsum);
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(256) void attention_bwd_mfma_kernel(const bf16_t* _
 
   // ---- phase 2: dV, dK (contraction over queries), dQ (over keys); out[hd = 16th + 4g + r][row = 16tr + c] --------------------
   constexpr int KS = KP / 32;
-  for (int job = wid; job < 3 * nrt * 4; job += 4) {
+  for (int job = wid; job < 3 * nrt * 4; job += NW) {
     const int prod = job / (nrt * 4), rem = job - prod * nrt * 4, tr = rem >> 2, th = rem & 3;
     const bf16_t* A = prod == 0 ? sDOT : (prod == 1 ? sQT : sKT);
     const bf16_t* Bm = prod == 0 ? sPT : (prod == 1 ? sDST : sDS);
@@ -330,7 +332,7 @@ static int launch_attention_bwd_mfma(const void* qkv, const void* dout, void* dq
   const size_t lds = (static_cast<size_t>(4) * TR * 72 + 3 * 64 * (KP + 8) + (NT <= 4 ? 0 : 3 * TR * (KP + 8))) * 2;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_mfma_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           static_cast<int>(lds)) != hipSuccess) return fail(CMH_ERR_LAUNCH, "attention_backward: cannot reserve %zu bytes of LDS", lds);
-  hipLaunchKernelGGL(attention_bwd_mfma_kernel<NT>, dim3(B * (d / HDB)), dim3(256), lds, st, static_cast<const bf16_t*>(qkv),
+  hipLaunchKernelGGL(attention_bwd_mfma_kernel<NT>, dim3(B * (d / HDB)), dim3(NT <= 4 ? 256 : 512), lds, st, static_cast<const bf16_t*>(qkv),
                      static_cast<const bf16_t*>(dout), static_cast<bf16_t*>(dqkv), B, T, d, causal, kpm, seq_off);
   return CMH_OK;
 }
