@@ -169,3 +169,47 @@ def test_trainer_valid_end_to_end(tmp_path, monkeypatch):
     changed = [n for n, p in tr.model.named_parameters() if not torch.equal(p.detach(), before[n])]
     assert set(before) - set(changed) == {"clip.logit_scale"}, sorted(set(before) - set(changed))[:5]   # unused by DSPH, as upstream
     assert all(torch.isfinite(p).all() for p in tr.model.parameters()) and not torch.equal(prox0, tr.hyp.proxies.detach())
+
+
+def test_cli_train_then_test_roundtrip(tmp_path, monkeypatch):
+    """The reference's whole user flow (main.py -> trainer.run()): 2 epochs of train_epoch -> valid -> save_model, the PR-curve
+    .mat files, then `--is-train false --pretrained model-1.pth` reproduces the last validation's mAPs from the checkpoint."""
+    import argparse
+    import sys
+    import scipy.io as scio
+    import main
+    import dataset.synthetic as ds
+    ck = tmp_path / "clip.pt"
+    torch.save(_state(), ck)
+    monkeypatch.setattr(ds, "SOT", 510); monkeypatch.setattr(ds, "EOT", 511)
+    out = tmp_path / "run"
+    common = ["main.py", "-clip-path", str(ck), "--save-dir", str(out), "--batch-size", "16", "--num-workers", "0", "--resolution", "64",
+              "--max-words", "16", "--query-num", "24", "--train-num", "32", "--synthetic-size", "120", "--gemm-dtype", "f32"]
+    monkeypatch.setattr(sys, "argv", common + ["--epochs", "2"])
+    tr = main.trainers["DSPH"](argparse.Namespace(method="DSPH", dataset="synthetic", output_dim=16, is_train=True), 0)
+    out = out / "DSPH" / "synthetic" / "16"                       # get_args: <save-dir>/<method>/<dataset>/<bits>, as upstream
+    assert (out / "model-0.pth").exists() and (out / "model-1.pth").exists()
+    mats = sorted(p.name for p in (out / "PR_cruve").glob("*.mat"))
+    assert "16-ours-synthetic-i2t.mat" in mats
+    m = scio.loadmat(out / "PR_cruve" / "16-ours-synthetic-i2t.mat")
+    assert m["q_img"].shape == (24, 16) and m["r_txt"].shape == (96, 16) and m["q_l"].shape == (24, 24) and m["r_l"].shape == (96, 24)
+    assert set(np.unique(m["q_img"])) <= {-1.0, 0.0, 1.0}
+    tr.change_state(mode="valid")
+    want = [float(v) for v in tr._four_maps(*tr._codes_for_eval()[:4])]
+    common[common.index("--save-dir") + 1] = str(tmp_path / "run2")
+    monkeypatch.setattr(sys, "argv", common + ["--epochs", "2", "--pretrained", str(out / "model-1.pth")])
+    te = main.trainers["DSPH"](argparse.Namespace(method="DSPH", dataset="synthetic", output_dim=16, is_train=False), 0)
+    # upstream quirk kept: the checkpoint is loaded while the CLIP weights are still fp16 (build_model's convert_weights), i.e.
+    # BEFORE model.float() (train/base.py / hash_train.py _init_model), so those tensors come back rounded to fp16
+    rounded = 0
+    for (ka, a), (kb, b) in zip(tr.model.state_dict().items(), te.model.state_dict().items()):
+        assert ka == kb
+        if not torch.equal(a, b):
+            assert torch.equal(a.half().float(), b), ka
+            rounded += 1
+    assert rounded > 0
+    ca, cb = tr._codes_for_eval()[:4], te._codes_for_eval()[:4]
+    for a, b in zip(ca, cb):
+        assert float((a != b).float().mean()) < 0.02
+    got = [float(v) for v in te._four_maps(*cb)]
+    assert all(abs(g - w) < 0.03 for g, w in zip(got, want)), (got, want)
