@@ -331,6 +331,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
         }
       };
       if constexpr (!GB) deferred_stores();
+      __builtin_amdgcn_s_setprio(GB ? 0 : 1);   // the wave of a SIMD that is NOT issuing LDS-DMA in this half goes first (+1 % on the mix)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < NM; ++i) {                                  // 2
@@ -360,6 +361,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
         const uint32_t bo = static_cast<uint32_t>(nxt) * STG;
         const uint32_t nW = aW + bo, nX = aX + bo;
         if constexpr (GB) deferred_stores();
+        __builtin_amdgcn_s_setprio(GB ? 1 : 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
