@@ -271,10 +271,30 @@ def main():
             return (time.perf_counter() - t0) * 1e3, maps
         ms, maps = timed(N.TIE_REFERENCE)
         ms_st, maps_st = timed(N.TIE_STABLE)
+        alg_bytes = 4 * ((Q + Nn) * K // 8 + (Q + Nn) * ((C + 7) // 8) + 4 * Q)      # packed inputs once + per-query AP
         out["map_eval"] = {"ms": round(ms, 3), "directions": 4, "Q": Q, "N": Nn, "bits": K,
+                           "code_pairs_per_s": round(4.0 * Q * Nn / (ms * 1e-3), 1),
+                           "algorithmic_GBps": round(alg_bytes / (ms * 1e-3) / 1e9, 3),
+                           "bound": "ranking (emulated introsort per query), not HBM: the packed inputs are %.2f MB" % (alg_bytes / 1e6),
                            "tie_order": "reference (libstdc++ introsort)", "mAP_i2t": round(float(maps[0]), 6),
                            "stable_tie_order": {"ms": round(ms_st, 3), "mAP_i2t": round(float(maps_st[0]), 6),
                                                 "note": "CMH_TIE_STABLE (ties by index): not the reference's ranking"}}
+
+    if rank == 0:
+        # SURVEY 8(d), N x N loss kernels: time per step and share of the step (HyP on the rank's batch; tools/loss_scale_bench.py
+        # has the global-batch sizes of an N-GPU step)
+        with torch.no_grad():
+            hi_l, ht_l = img_head(torch.randn(B, 512, device=dev)), txt_head(torch.randn(B, 512, device=dev))
+            for _ in range(3):
+                hyp(hi_l, ht_l, label)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                hyp(hi_l, ht_l, label)
+            e1.record()
+            torch.cuda.synchronize()
+            lus = e0.elapsed_time(e1) / 20 * 1e3
+        out["loss_fwd"] = {"us": round(lus, 1), "share_of_step": round(lus * 1e-3 / out["ms_per_step"], 4), "what": f"HyP forward, batch {B}, {K} bits, {C} classes"}
 
     if not a.no_train_step and (world == 1 or a.train_step):
         try:
