@@ -12,6 +12,11 @@ SOT, EOT = 49406, 49407
 
 
 class SyntheticPairs(Dataset):
+    """signal = 0: image and caption are independent noise (throughput / contract tests).  signal > 0: every class owns a fixed
+    image pattern and a few caption tokens, an item shows the patterns / tokens of its labels plus noise — something a model can
+    learn, so a few epochs must raise the mAP (tests/test_gpu_heads_losses.py::test_training_learns)."""
+    signal = 0.0
+
     def __init__(self, ids, labels, max_words, resolution, seed):
         self.ids, self.labels = ids, labels
         self.max_words, self.resolution, self.seed = max_words, resolution, seed
@@ -24,13 +29,21 @@ class SyntheticPairs(Dataset):
 
     def __getitem__(self, index):
         rng = np.random.default_rng([self.seed, int(self.ids[index])])
-        image = torch.from_numpy(rng.standard_normal((3, self.resolution, self.resolution)).astype(np.float32))
+        image = rng.standard_normal((3, self.resolution, self.resolution)).astype(np.float32)
         cap = np.zeros(self.max_words, np.int64)
         n = int(rng.integers(2, self.max_words))
         cap[0] = SOT
         cap[1:n] = rng.integers(1, SOT, size=n - 1)
         cap[n] = EOT
-        return image, torch.from_numpy(cap), torch.from_numpy(self.labels[index]), index
+        if self.signal > 0:
+            classes = np.nonzero(self.labels[index])[0]
+            for c in classes:
+                proto = np.random.default_rng([self.seed, 7919, int(c)])
+                image += self.signal * proto.standard_normal(image.shape).astype(np.float32)
+                words = proto.integers(1, SOT, size=3)                       # the class's caption tokens
+                for w in words:
+                    cap[int(rng.integers(1, max(n, 2)))] = w
+        return torch.from_numpy(image), torch.from_numpy(cap), torch.from_numpy(self.labels[index]), index
 
 
 def dataloader(total, nclass, maxWords=32, imageResolution=224, query_num=5000, train_num=10000, seed=None):

@@ -213,3 +213,30 @@ def test_cli_train_then_test_roundtrip(tmp_path, monkeypatch):
         assert float((a != b).float().mean()) < 0.02
     got = [float(v) for v in te._four_maps(*cb)]
     assert all(abs(g - w) < 0.03 for g, w in zip(got, want)), (got, want)
+
+
+def test_training_learns(tmp_path, monkeypatch):
+    """The whole stack as a learner: on a synthetic set whose images and captions carry their labels (class patterns / class
+    tokens under noise) eight short DSPH epochs — tape forward, HyP, backward through heads and towers, fused BertAdam — must
+    lift the mAPs well above their random-weights starting point (measured: i->t 0.42 -> 0.55, i->i 0.48 -> 0.70)."""
+    import argparse
+    import sys
+    import main
+    import dataset.synthetic as ds
+    ck = tmp_path / "clip.pt"
+    torch.save(_state(), ck)
+    monkeypatch.setattr(ds, "SOT", 510); monkeypatch.setattr(ds, "EOT", 511)
+    monkeypatch.setattr(ds.SyntheticPairs, "signal", 2.0)
+    monkeypatch.setattr(sys, "argv", ["main.py", "-clip-path", str(ck), "--save-dir", str(tmp_path / "run"), "--batch-size", "32",
+                                      "--num-workers", "0", "--resolution", "64", "--max-words", "16", "--query-num", "100",
+                                      "--train-num", "400", "--synthetic-size", "600", "--epochs", "0", "--gemm-dtype", "f32",
+                                      "--lr", "0.001", "--clip-lr", "0.0003"])
+    tr = main.trainers["DSPH"](argparse.Namespace(method="DSPH", dataset="synthetic", output_dim=32, is_train=True), 0)
+    epochs = 8
+    for grp in tr.optimizer.param_groups:
+        grp["t_total"] = epochs * len(tr.train_loader)
+    before = [float(v) for v in tr.valid(0)]
+    for epoch in range(epochs):
+        tr.train_epoch(epoch)
+    after = [float(v) for v in tr.valid(epochs)]
+    assert after[0] > before[0] + 0.06 and after[1] > before[1] + 0.04 and after[2] > before[2] + 0.12, (before, after)
