@@ -117,6 +117,65 @@ class HypLoss(torch.autograd.Function):
         return dx, dy, None, dp, None, None
 
 
+class LayerNormFn(torch.autograd.Function):
+    """cmh_layernorm (f32 rows) with cmh_layernorm_backward: the TwDH text head's `norm` (model/TwDH.py:61,78)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = N.f32c(x)
+        ctx.save_for_backward(x, N.f32c(w))
+        return N.layernorm(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx, dg, db = layernorm_backward(x, N.f32c(dy), w)
+        return dx, dg, db
+
+
+class BatchNorm1dTrain(torch.autograd.Function):
+    """cmh_batchnorm1d_train (batch statistics) with its backward: the TwDH image head's `norm`."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        x, w = N.f32c(x), N.f32c(w)
+        ctx.save_for_backward(x, w)
+        ctx.eps = float(eps)
+        return N.batchnorm1d_train(x, w, b, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = N.f32c(dy)
+        B, d = x.shape
+        dx, dw, db = torch.empty_like(x), torch.empty_like(w), torch.empty_like(w)
+        N.check(N.lib().cmh_batchnorm1d_backward(N.ptr(x), N.ptr(w), ctx.eps, N.ptr(dy), N.ptr(dx), N.ptr(dw), N.ptr(db), B, d,
+                                                 N.stream_ptr(x.device)), "cmh_batchnorm1d_backward")
+        return dx, dw, db, None
+
+
+class TwdhLoss(torch.autograd.Function):
+    """cmh_twdh_loss -> (nce, quan) for one code length with its backward (train/TwDH/hash_train.py:117-139)."""
+
+    @staticmethod
+    def forward(ctx, p_img, p_txt, target):
+        p_img, p_txt, target = N.f32c(p_img), N.f32c(p_txt), N.f32c(target)
+        ctx.save_for_backward(p_img, p_txt, target)
+        nce, quan = N.twdh_loss(p_img, p_txt, target)
+        return nce.clone(), quan.clone()
+
+    @staticmethod
+    def backward(ctx, d_nce, d_quan):
+        p_img, p_txt, target = ctx.saved_tensors
+        B, K = target.shape
+        di, dt = torch.empty_like(p_img), torch.empty_like(p_txt)
+        gn = None if d_nce is None else N.f32c(d_nce).reshape(1)
+        gq = None if d_quan is None else N.f32c(d_quan).reshape(1)
+        N.check(N.lib().cmh_twdh_loss_backward(N.ptr(p_img), N.ptr(p_txt), N.ptr(target), B, K, N.ptr(gn), N.ptr(gq), N.ptr(di), N.ptr(dt),
+                                               N.stream_ptr(p_img.device)), "cmh_twdh_loss_backward")
+        return di, dt, None
+
+
 class DnphLoss(torch.autograd.Function):
     """cmh_dnph_loss with its backward (DNPH_out, train/DNPH_TOMM/loss.py:14-32, plus the `- 0.1 * noise_loss` term of
     train/DNPH_TOMM/hash_train.py:65-81 when the noise rows are given).  Returns loss1 without noise rows, else the step loss."""

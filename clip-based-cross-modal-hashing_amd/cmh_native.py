@@ -142,6 +142,9 @@ SIGNATURES = {
     "cmh_image_preprocess_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "cmh_image_preprocess": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                        _p, _p, _p, _sz, _p]),
+    "cmh_batchnorm1d_update_running": (C.c_int, [_p, _f, _p, _p, _i32, _i32, _p]),
+    "cmh_batchnorm1d_backward": (C.c_int, [_p, _p, _f, _p, _p, _p, _p, _i32, _i32, _p]),
+    "cmh_twdh_loss_backward": (C.c_int, [_p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p]),
     "cmh_image_normalize": (C.c_int, [_p, _p, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float), _p, _p]),
     "cmh_bpe_create": (C.c_int, [C.c_char_p, _sz, C.POINTER(_p)]),
     "cmh_bpe_destroy": (None, [_p]),

@@ -47,6 +47,80 @@ __global__ __launch_bounds__(256) void batchnorm_train_kernel(const float* __res
     y[static_cast<size_t>(r) * d + col] = (x[static_cast<size_t>(r) * d + col] - mean) * rstd * g + bb;
 }
 
+// The same with the module's side effect: running_mean / running_var <- (1 - momentum) * old + momentum * batch statistic, the
+// variance UNBIASED (B / (B - 1)) as nn.BatchNorm1d stores it.  The reference's image head is never put in eval mode, so every
+// forward — validation included — moves these buffers, and they are part of the checkpoint.
+__global__ __launch_bounds__(256) void batchnorm_running_kernel(const float* __restrict__ x, float momentum,
+                                                                float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                int B, int d) {
+  const int lane = threadIdx.x & 63;
+  const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (col >= d) return;
+  float s = 0.f;
+  for (int r = lane; r < B; r += 64) s += x[static_cast<size_t>(r) * d + col];
+  const float mean = h2_wave_sum(s) / static_cast<float>(B);
+  float ss = 0.f;
+  for (int r = lane; r < B; r += 64) {
+    const float c = x[static_cast<size_t>(r) * d + col] - mean;
+    ss = fmaf(c, c, ss);
+  }
+  ss = h2_wave_sum(ss);
+  if (lane == 0) {
+    const float unbiased = B > 1 ? ss / static_cast<float>(B - 1) : ss;
+    running_mean[col] = (1.f - momentum) * running_mean[col] + momentum * mean;
+    running_var[col] = (1.f - momentum) * running_var[col] + momentum * unbiased;
+  }
+}
+
+// backward of batchnorm_train_kernel: xh = (x - mean) rstd;  dg = sum dy xh, db = sum dy,  dx = g rstd (dy - db / B - xh dg / B)
+__global__ __launch_bounds__(256) void batchnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float eps,
+                                                            const float* __restrict__ dy, float* __restrict__ dx,
+                                                            float* __restrict__ dw, float* __restrict__ db, int B, int d) {
+  const int lane = threadIdx.x & 63;
+  const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (col >= d) return;
+  float s = 0.f;
+  for (int r = lane; r < B; r += 64) s += x[static_cast<size_t>(r) * d + col];
+  const float mean = h2_wave_sum(s) / static_cast<float>(B);
+  float ss = 0.f;
+  for (int r = lane; r < B; r += 64) {
+    const float c = x[static_cast<size_t>(r) * d + col] - mean;
+    ss = fmaf(c, c, ss);
+  }
+  const float rstd = 1.0f / sqrtf(h2_wave_sum(ss) / static_cast<float>(B) + eps);
+  float sg = 0.f, sb = 0.f;
+  for (int r = lane; r < B; r += 64) {
+    const float g = dy[static_cast<size_t>(r) * d + col];
+    sg = fmaf(g, (x[static_cast<size_t>(r) * d + col] - mean) * rstd, sg);
+    sb += g;
+  }
+  sg = h2_wave_sum(sg); sb = h2_wave_sum(sb);
+  if (lane == 0) { dw[col] = sg; db[col] = sb; }
+  const float k = w[col] * rstd, inv = 1.0f / static_cast<float>(B);
+  for (int r = lane; r < B; r += 64) {
+    const float xh = (x[static_cast<size_t>(r) * d + col] - mean) * rstd;
+    dx[static_cast<size_t>(r) * d + col] = k * (dy[static_cast<size_t>(r) * d + col] - sb * inv - xh * sg * inv);
+  }
+}
+
+// backward of twdh_loss_kernel's two terms for one element of p (train/TwDH/hash_train.py:117-139):
+//   nce  = (BCE(p_img, t) + BCE(p_txt, t)) / 2, BCELoss mean over the n2 = B * 2K elements; ATen's backward is
+//          (p - t) / max((1 - p) p, 1e-12) / n2;      quan = ((1 - mean((2p - 1)^2))_img + (...)_txt) / 2  ->  -4 (2p - 1) / n2
+__global__ __launch_bounds__(256) void twdh_loss_bwd_kernel(const float* __restrict__ p_img, const float* __restrict__ p_txt,
+                                                            const float* __restrict__ target, int64_t n2,
+                                                            const float* __restrict__ d_nce, const float* __restrict__ d_quan,
+                                                            float* __restrict__ dp_img, float* __restrict__ dp_txt) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n2) return;
+  const float gn = (d_nce ? d_nce[0] : 0.f) * 0.5f / static_cast<float>(n2);
+  const float gq = (d_quan ? d_quan[0] : 0.f) * 0.5f / static_cast<float>(n2);
+  const float code = target[i >> 1];
+  const float t = ((i & 1) != 0) == (code > 0.f) ? 1.f : 0.f;         // hash_convert: code > 0 -> pair (0, 1), else (1, 0)
+  const float a = p_img[i], b = p_txt[i];
+  dp_img[i] = gn * (a - t) / fmaxf((1.f - a) * a, 1e-12f) - gq * 4.f * (2.f * a - 1.f);
+  dp_txt[i] = gn * (b - t) / fmaxf((1.f - b) * b, 1e-12f) - gq * 4.f * (2.f * b - 1.f);
+}
+
 // hash_center_multilables: code[b,k] = sign(mean_{c: label[b,c]==1} center[c,k]), exact zeros replaced by
 // random_center[k] (a +-1 vector the caller draws once per call, like the reference's torch.randint_like).
 // Rows without any label give NaN means upstream, which hash_convert maps to "bit 0" == -1.
@@ -214,6 +288,33 @@ extern "C" int cmh_batchnorm1d_train(const float* x, const float* w, const float
   CMH_CHECK_ARG(x && w && b && y && B > 0 && d > 0, "batchnorm1d_train: bad arguments");
   hipLaunchKernelGGL(batchnorm_train_kernel, dim3((d + 3) / 4), dim3(256), 0, as_stream(stream), x, w, b, eps, y, B, d);
   CMH_CHECK_LAUNCH("batchnorm1d_train");
+  return CMH_OK;
+}
+
+extern "C" int cmh_batchnorm1d_update_running(const float* x, float momentum, float* running_mean, float* running_var,
+                                              int32_t B, int32_t d, void* stream) {
+  CMH_CHECK_ARG(x && running_mean && running_var && B > 0 && d > 0, "batchnorm1d_update_running: bad arguments");
+  hipLaunchKernelGGL(batchnorm_running_kernel, dim3((d + 3) / 4), dim3(256), 0, as_stream(stream), x, momentum, running_mean,
+                     running_var, B, d);
+  CMH_CHECK_LAUNCH("batchnorm1d_update_running");
+  return CMH_OK;
+}
+
+extern "C" int cmh_batchnorm1d_backward(const float* x, const float* w, float eps, const float* dy, float* dx, float* dw,
+                                        float* db, int32_t B, int32_t d, void* stream) {
+  CMH_CHECK_ARG(x && w && dy && dx && dw && db && B > 0 && d > 0, "batchnorm1d_backward: bad arguments");
+  hipLaunchKernelGGL(batchnorm_bwd_kernel, dim3((d + 3) / 4), dim3(256), 0, as_stream(stream), x, w, eps, dy, dx, dw, db, B, d);
+  CMH_CHECK_LAUNCH("batchnorm1d_backward");
+  return CMH_OK;
+}
+
+extern "C" int cmh_twdh_loss_backward(const float* p_img, const float* p_txt, const float* target, int32_t B, int32_t K,
+                                      const float* d_nce, const float* d_quan, float* dp_img, float* dp_txt, void* stream) {
+  CMH_CHECK_ARG(p_img && p_txt && target && dp_img && dp_txt && B > 0 && K > 0, "twdh_loss_backward: bad arguments");
+  const int64_t n2 = static_cast<int64_t>(B) * K * 2;
+  hipLaunchKernelGGL(twdh_loss_bwd_kernel, dim3(static_cast<unsigned>((n2 + 255) / 256)), dim3(256), 0, as_stream(stream), p_img,
+                     p_txt, target, n2, d_nce, d_quan, dp_img, dp_txt);
+  CMH_CHECK_LAUNCH("twdh_loss_backward");
   return CMH_OK;
 }
 

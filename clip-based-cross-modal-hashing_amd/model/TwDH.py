@@ -4,7 +4,7 @@ ModalityHash keeps the reference's parameters (`atten` = nn.MultiheadAttention o
 `fc2`) so checkpoints load strict.  With one key the softmax is 1, so attention == out_proj(v_proj(x)): two GEMMs.
 The image head's BatchNorm1d runs with BATCH statistics even at eval time, exactly like upstream (Baseclip.eval()
 only toggles image_hash/text_hash, never img_hash/txt_hash) — codes therefore depend on batch
-composition.  Running statistics are not updated (they are never read).
+composition.  Its running statistics move on every forward, as upstream's do (they are never read, but they are part of the checkpoint).
 Centres / transition matrices: `long_center` [C,K] +-1, `short_center` {S: [C,S]}, `trans` {S: [2K,2S]} as tensors or
 paths to the reference's .pkl assets (train/TwDH/center/<dataset>/...)."""
 import logging
@@ -14,7 +14,6 @@ import torch
 import torch.nn as nn
 
 import cmh_native as N
-from model.base.model import no_backward
 from model.modelbase import Baseclip, weights_init_kaiming
 from streams import overlapped
 
@@ -45,17 +44,46 @@ class ModalityHash(nn.Module):
     def quantization(self, code):
         return softmax_hash(code)
 
+    def _update_running(self, embed):
+        """nn.BatchNorm1d's side effect in training mode (upstream never leaves it): move the running statistics."""
+        n = self.norm
+        if n.track_running_stats and n.running_mean is not None:
+            n.num_batches_tracked += 1
+            mom = n.momentum if n.momentum is not None else 1.0 / float(n.num_batches_tracked)
+            N.check(N.lib().cmh_batchnorm1d_update_running(N.ptr(embed), float(mom), N.ptr(n.running_mean), N.ptr(n.running_var),
+                                                           embed.shape[0], embed.shape[1], N.stream_ptr(embed.device)),
+                    "cmh_batchnorm1d_update_running")
+
+    def _forward_train(self, data):
+        """The same chain through autograd Functions (each a libcmh forward + backward): v_proj -> out_proj -> norm -> fc2 + ReLU
+        -> pair softmax.  The Q / K rows of in_proj receive zero gradients (one key: the softmax is constant), as upstream."""
+        from backward_ops import BatchNorm1dTrain, LayerNormFn, LinearAct, PairSoftmax
+        d = data.shape[1]
+        w_in, b_in = self.atten.in_proj_weight, self.atten.in_proj_bias
+        v = LinearAct.apply(data, w_in[2 * d:], b_in[2 * d:], N.ACT_NONE, None, 0.0)
+        embed = LinearAct.apply(v, self.atten.out_proj.weight, self.atten.out_proj.bias, N.ACT_NONE, None, 0.0)
+        if isinstance(self.norm, nn.BatchNorm1d):
+            self._update_running(embed.detach())
+            embed = BatchNorm1dTrain.apply(embed, self.norm.weight, self.norm.bias, self.norm.eps)
+        else:
+            embed = LayerNormFn.apply(embed, self.norm.weight, self.norm.bias)
+        embed = LinearAct.apply(embed, self.fc2.weight, self.fc2.bias, N.ACT_RELU, None, 0.0)
+        return PairSoftmax.apply(embed)
+
     def forward(self, data):
+        if torch.is_grad_enabled() and (data.requires_grad or self.fc2.weight.requires_grad):
+            return self._forward_train(data)
         d = data.shape[1]
         w_in, b_in = self.atten.in_proj_weight, self.atten.in_proj_bias
         v = N.linear_act(data, w_in[2 * d:], b_in[2 * d:], N.ACT_NONE)                  # v_proj
         embed = N.linear_act(v, self.atten.out_proj.weight, self.atten.out_proj.bias, N.ACT_NONE)
         if isinstance(self.norm, nn.BatchNorm1d):
+            self._update_running(embed)
             embed = N.batchnorm1d_train(embed, self.norm.weight, self.norm.bias, self.norm.eps)
         else:
             embed = N.layernorm(embed, self.norm.weight, self.norm.bias)
         embed = N.linear_act(embed, self.fc2.weight, self.fc2.bias, N.ACT_RELU)
-        return no_backward(N.pair_softmax(embed), self.fc2.weight)
+        return N.pair_softmax(embed)
 
 
 def _load_tensor(x):
@@ -105,8 +133,14 @@ class MTwDH(Baseclip):
             key = (k, str(long_hash.device))
             if key not in self._trans_t:                       # [2K,2S] -> Linear layout [2S,2K], once per device
                 self._trans_t[key] = v.to(long_hash.device).t().contiguous()
-            z = N.linear_act(long_hash.detach(), self._trans_t[key], None, N.ACT_NONE)
-            out[k] = no_backward(head.quantization(z), head.fc2.weight)
+            if torch.is_grad_enabled() and long_hash.requires_grad:
+                from backward_ops import LinearAct, PairSoftmax
+                w = self._trans_t[key]
+                zero_b = torch.zeros(w.shape[0], device=w.device)
+                out[k] = PairSoftmax.apply(LinearAct.apply(long_hash, w, zero_b, N.ACT_NONE, None, 0.0))
+            else:
+                z = N.linear_act(long_hash.detach(), self._trans_t[key], None, N.ACT_NONE)
+                out[k] = head.quantization(z)
         return out
 
     def encode_image(self, image):

@@ -1,13 +1,14 @@
 """TwDH trainer (reference train/TwDH/hash_train.py; paper: Two-Step Discrete Hashing, TOMM 2024): long codes from
-the two ModalityHash heads, short codes by long_hash @ trans, targets from per-class hash centres.  Forward, loss
-and the long+short validation run on libcmh; backward/optimiser are the next scope row."""
+the two ModalityHash heads, short codes by long_hash @ trans, targets from per-class hash centres.  Forward, loss,
+backward (heads, both towers), the fused BertAdam step and the long+short validation run on libcmh."""
 import os
 
 import torch
 
 import cmh_native as N
+import dist_utils as du
 from model.TwDH import MTwDH
-from model.base.model import no_backward
+from model.base.optimization import BertAdam
 from train.base import TrainBase
 from utils.calc_utils import calc_map_k_matrix as calc_map_k
 from .get_args import get_args
@@ -44,7 +45,12 @@ class TwDHTrainer(TrainBase):
             self.model.load_state_dict(torch.load(self.args.pretrained, map_location=f"cuda:{self.rank}"))
         self.model.float()
         self.model.clip.set_gemm_dtype(self.args.gemm_dtype)
-        self.optimizer = None
+        self.optimizer = BertAdam([
+            {"params": self.model.clip.parameters(), "lr": self.args.clip_lr},
+            {"params": self.model.img_hash.parameters(), "lr": self.args.lr},
+            {"params": self.model.txt_hash.parameters(), "lr": self.args.lr}],
+            lr=self.args.lr, warmup=self.args.warmup_proportion, schedule="warmup_cosine", b1=0.9, b2=0.98, e=1e-6,
+            t_total=len(self.train_loader) * self.args.epochs, weight_decay=self.args.weight_decay, max_grad_norm=1.0)
         self.distributed = False
         self.max_short, self.best_epoch_short = {}, {}
         for item in self.model.get_short_dims():
@@ -71,16 +77,22 @@ class TwDHTrainer(TrainBase):
     def compute_loss(self, long_img_hash, long_txt_hash, short_img_hash, short_txt_hash, labels, indexs, long_center,
                      short_center, random_centers=None):
         rc = random_centers or {}
+        if torch.is_grad_enabled() and (long_img_hash.requires_grad or long_txt_hash.requires_grad):
+            from backward_ops import TwdhLoss
+            terms = TwdhLoss.apply
+        else:
+            terms = N.twdh_loss
         target = self.hash_center_multilables(labels, long_center, rc.get("long"))
-        nce, quan = N.twdh_loss(long_img_hash, long_txt_hash, target)
+        nce, quan = terms(long_img_hash, long_txt_hash, target)
         loss = nce + self.args.quan_alpha * quan
         for k, v in short_center.items():
             t_k = self.hash_center_multilables(labels, v, rc.get(k))
-            nce_k, quan_k = N.twdh_loss(short_img_hash[k], short_txt_hash[k], t_k)
+            nce_k, quan_k = terms(short_img_hash[k], short_txt_hash[k], t_k)
             loss = loss + self.args.low_rate * nce_k + self.args.low_rate * quan_k
-        return no_backward(loss, self.model.img_hash.fc2.weight)
+        return loss
 
     def train_epoch(self, epoch):
+        self.change_state(mode="train")
         self.logger.info(">>>>>> epochs: %d/%d" % (epoch, self.args.epochs))
         all_loss = 0
         for image, text, label, index in self.train_loader:
@@ -90,7 +102,11 @@ class TwDHTrainer(TrainBase):
             il, ish, tl, tsh, lc, sc = self.model(image, text)
             loss = self.compute_loss(il, tl, ish, tsh, label, index.numpy(), lc, sc)
             all_loss += loss
-            loss.backward()      # raises NotImplementedError: backward kernels are the next scope row
+            self.optimizer.zero_grad()
+            loss.backward()
+            if du.world_size() > 1:
+                du.allreduce_mean_([p.grad for p in self.model.parameters() if p.grad is not None])
+            self.optimizer.step()
         self.logger.info(f">>>>>> [{epoch}/{self.args.epochs}] loss: {all_loss.data / (len(self.train_loader))}")
 
     def make_hash_code(self, code):

@@ -256,6 +256,17 @@ int cmh_dchmt_loss(const float* img, const float* txt, const float* label, int32
 int cmh_batchnorm1d_train(const float* x, const float* w, const float* b, float eps, float* y, int32_t B,
                           int32_t d, void* stream);
 
+/* The module side effect of that forward: running_mean / running_var (momentum 0.1, unbiased variance), part of the checkpoint. */
+int cmh_batchnorm1d_update_running(const float* x, float momentum, float* running_mean, float* running_var, int32_t B,
+                                   int32_t d, void* stream);
+/* Backward of cmh_batchnorm1d_train: dx [B,d], dw [d], db [d] from dy [B,d] (statistics recomputed from x). */
+int cmh_batchnorm1d_backward(const float* x, const float* w, float eps, const float* dy, float* dx, float* dw, float* db,
+                             int32_t B, int32_t d, void* stream);
+/* Backward of cmh_twdh_loss: dp_img / dp_txt f32 [B,2K] from the upstream gradients of the two scalars (device pointers to one
+ * float each; NULL = 0).  BCELoss as ATen differentiates it: (p - t) / max((1 - p) p, 1e-12) / numel. */
+int cmh_twdh_loss_backward(const float* p_img, const float* p_txt, const float* target, int32_t B, int32_t K,
+                           const float* d_nce, const float* d_quan, float* dp_img, float* dp_txt, void* stream);
+
 /* hash_center_multilables (train/TwDH/hash_train.py:93-115): code[b,k] = sign(mean of the centers of b's
  * classes), exact zeros replaced by random_center[k] (a +-1 vector drawn once per call by the caller).
  * label f32 [B,C], center f32 [C,K] (+-1), code f32 [B,K]. */
