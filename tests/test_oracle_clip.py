@@ -80,3 +80,17 @@ def test_dnph_heads_match_reference(golden):
     np.testing.assert_allclose(co.linear_hash(fi, w, b), g["dnph_img"], **TOL)
     w, b = recipe.head_linear(cfg["embed_dim"], 21, seed, "dnph_image_pre")
     np.testing.assert_allclose(co.pre_layer(fi, w, b), g["dnph_img_pre"], **TOL)
+
+
+def test_torch_cpu_port_matches_the_numpy_oracle():
+    """oracle/torch_cpu.py (the timed CPU baseline's second form) against clip_oracle on the tiny configuration."""
+    import recipe
+    from oracle import clip_oracle as co
+    from oracle.torch_cpu import TorchClip
+    cfg = recipe.CLIP_TINY
+    sd = recipe.clip_state_dict(cfg, 5)
+    img = recipe.images(3, cfg["image_resolution"], 2)
+    txt = recipe.captions(3, cfg["context_length"], cfg["vocab_size"], 2)
+    tc = TorchClip(sd)
+    np.testing.assert_allclose(tc.encode_image(img).numpy(), co.encode_image(sd, img), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(tc.encode_text(txt).numpy(), co.encode_text(sd, txt), rtol=2e-4, atol=2e-4)
