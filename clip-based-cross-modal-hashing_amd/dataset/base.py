@@ -57,9 +57,21 @@ class BaseDataset(Dataset):
                 arr = np.asarray(Image.fromarray(arr).convert("RGB"))
         return torch.from_numpy(np.ascontiguousarray(arr))
 
+    @staticmethod
+    def _caption_list(entry):
+        """The captions of one item as a list of str.  Upstream indexes `captions[index]` directly, which works for string
+        matrices ([N, n_captions] '<U', blank padded) and for caption.txt ([N, 1]); MATLAB cell arrays come back from
+        scipy.io.loadmat as nested object arrays ([[array(['a dog']), array(['two cats'])]]) — those are flattened here."""
+        if isinstance(entry, (str, bytes, np.str_)):
+            return [entry.decode() if isinstance(entry, bytes) else str(entry)]
+        out = []
+        for e in (entry.ravel() if isinstance(entry, np.ndarray) else entry):
+            out.extend(BaseDataset._caption_list(e))
+        return out
+
     def _choose_caption(self, index: int) -> str:
-        captions = self.captions[index]
-        return str(captions[random.randint(0, len(captions) - 1)])            # base.py:67-68
+        captions = self._caption_list(self.captions[index])
+        return captions[random.randint(0, len(captions) - 1)]                  # base.py:67-68
 
     def _load_text(self, index: int):
         """One caption's ids (upstream's per-item path; the loader uses the batch call in `collate`)."""

@@ -90,3 +90,42 @@ def test_synthetic_split_rule():
     img, cap, lab, idx = r[0]
     assert img.shape == (3, 64, 64) and cap.shape == (32,) and cap[0] == 49406 and cap.max() == 49407
     assert lab.shape == (24,) and r.get_all_label().shape == (250, 24)
+
+
+def test_dataset_files_and_caption_layouts(tmp_path):
+    """dataset/dataloader.py on the three caption layouts (string matrix, caption.txt, MATLAB cell array), the reference's split
+    rule and the label / index plumbing — host logic only, no GPU."""
+    import random
+    import scipy.io as scio
+    from dataset.base import BaseDataset
+    from dataset.dataloader import load_files, split_data
+    n = 12
+    paths = np.array([f"/data/im{i:02d}.jpg" for i in range(n)] + ["/data/long_name_image.jpg"])[:n]
+    scio.savemat(tmp_path / "index.mat", {"index": paths})
+    lab = (np.arange(n * 5).reshape(n, 5) % 3 == 0).astype(np.int8)
+    scio.savemat(tmp_path / "label.mat", {"category": lab})
+    mat = np.array([[f"caption {i} a", f"second caption of {i}"] for i in range(n)])
+    scio.savemat(tmp_path / "caption.mat", {"caption": mat})
+    caps, idx, labels = load_files(str(tmp_path / "caption.mat"), str(tmp_path / "index.mat"), str(tmp_path / "label.mat"))
+    assert caps.shape == (n, 2) and idx.shape == (n,) and labels.shape == (n, 5)
+    assert idx[3].strip() == "/data/im03.jpg"
+    ds = BaseDataset(caps, idx, labels, tokenizer=object())
+    random.seed(0)
+    assert {ds._choose_caption(4).strip() for _ in range(40)} == {"caption 4 a", "second caption of 4"}
+    assert torch.equal(ds.get_all_label(), torch.from_numpy(lab).float())
+    (tmp_path / "caption.txt").write_text("".join("only caption %d\n" % i for i in range(n)))
+    caps_t, _, _ = load_files(str(tmp_path / "caption.txt"), str(tmp_path / "index.mat"), str(tmp_path / "label.mat"))
+    assert caps_t.shape == (n, 1) and BaseDataset(caps_t, idx, labels, tokenizer=object())._choose_caption(7) == "only caption 7"
+    cell = np.empty((1, n), dtype=object)
+    for i in range(n):
+        cell[0, i] = np.array([f"cell {i} x", f"cell {i} y", f"cell {i} z"][: 1 + i % 3], dtype=object)
+    scio.savemat(tmp_path / "cell.mat", {"caption": cell})
+    caps_c, _, _ = load_files(str(tmp_path / "cell.mat"), str(tmp_path / "index.mat"), str(tmp_path / "label.mat"))
+    dc = BaseDataset(caps_c, idx, labels, tokenizer=object())
+    assert dc._caption_list(caps_c[5]) == ["cell 5 x", "cell 5 y", "cell 5 z"] and dc._caption_list(caps_c[3]) == ["cell 3 x"]
+    (qi, ti, ri), (qc, tc, rc), (ql, tl, rl) = split_data(caps, idx, labels, query_num=3, train_num=4, seed=9)
+    np.random.seed(9)
+    order = np.random.permutation(range(n))
+    assert list(qi) == list(idx[order[:3]]) and list(ti) == list(idx[order[3:7]]) and list(ri) == list(idx[order[3:]])
+    with pytest.raises(ValueError):
+        load_files(str(tmp_path / "caption.json"), str(tmp_path / "index.mat"), str(tmp_path / "label.mat"))
