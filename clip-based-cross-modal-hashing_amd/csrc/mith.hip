@@ -41,11 +41,14 @@ constexpr int kLtaMaxK = 128;    // concepts (= hash bits)
 constexpr int kTop = 8;          // compile-time bound of top_k_label (reference default 8)
 constexpr float kNegInf = -__builtin_huge_valf();
 
-// One workgroup per sample.  sim rows [row0 + l] (l < L) of a [B*Ltot, K] matrix, tokens rows likewise of [B*Ltot, D].
+// grid (B, ceil(D / 256)): a workgroup owns one sample and 256 columns of D (steps 1-3 are repeated per column block: they are
+// cheap next to the L x K x D aggregation, and two blocks per sample fill the chip at batch 128).  sim rows [row0 + l] (l < L)
+// of a [B*Ltot, K] matrix, tokens rows likewise of [B*Ltot, D].  The weights sit in LDS with a 16-byte aligned row pitch: the
+// aggregation reads them four concepts at a time (one ds_read_b128 per 4 FMAs instead of one ds_read_b32 per FMA).
 __global__ __launch_bounds__(256) void lta_kernel(const float* __restrict__ tokens, const float* __restrict__ sim,
                                                   const uint8_t* __restrict__ kpm, float* __restrict__ out, int Ltot,
                                                   int l0, int L, int K, int D, int top_k) {
-  __shared__ float w[kLtaMaxL][kLtaMaxK + 1];
+  __shared__ __attribute__((aligned(16))) float w[kLtaMaxL][kLtaMaxK + 4];
   const int b = blockIdx.x, tid = threadIdx.x;
   const size_t row0 = static_cast<size_t>(b) * Ltot + l0;
   // 1. load, key-padding -> -inf, non-positive -> -inf   (:350-361)
@@ -99,15 +102,20 @@ __global__ __launch_bounds__(256) void lta_kernel(const float* __restrict__ toke
   }
   __syncthreads();
   // 4. merge[b,k,:] = sum_l w[l,k] * tokens[b,l,:]   (:370-375)
-  for (int d = tid; d < D; d += 256) {
+  const int d = blockIdx.y * 256 + tid;
+  if (d < D) {
     float acc[kLtaMaxK];
 #pragma unroll
     for (int k = 0; k < kLtaMaxK; ++k) acc[k] = 0.f;
     for (int l = 0; l < L; ++l) {
       const float xv = tokens[(row0 + l) * D + d];
 #pragma unroll
-      for (int k = 0; k < kLtaMaxK; ++k)
-        if (k < K) acc[k] = fmaf(w[l][k], xv, acc[k]);
+      for (int k4 = 0; k4 < kLtaMaxK / 4; ++k4)
+        if (k4 * 4 < K) {                       // K % 4 == 0 (host-checked): whole quads; columns >= K hold zeros
+          const float4 wv = *reinterpret_cast<const float4*>(&w[l][k4 * 4]);
+          acc[k4 * 4 + 0] = fmaf(wv.x, xv, acc[k4 * 4 + 0]); acc[k4 * 4 + 1] = fmaf(wv.y, xv, acc[k4 * 4 + 1]);
+          acc[k4 * 4 + 2] = fmaf(wv.z, xv, acc[k4 * 4 + 2]); acc[k4 * 4 + 3] = fmaf(wv.w, xv, acc[k4 * 4 + 3]);
+        }
     }
 #pragma unroll
     for (int k = 0; k < kLtaMaxK; ++k)
@@ -252,8 +260,9 @@ extern "C" int cmh_mith_lta(const float* tokens, const float* sim, const uint8_t
   CMH_CHECK_ARG(B > 0 && L > 0 && L <= kLtaMaxL && l0 >= 0 && l0 + L <= Ltot, "mith_lta: token range (L <= %d)", kLtaMaxL);
   CMH_CHECK_ARG(K > 0 && K <= kLtaMaxK && D > 0, "mith_lta: K must be <= %d", kLtaMaxK);
   CMH_CHECK_ARG(top_k >= 1 && top_k <= kTop, "mith_lta: top_k must be in 1..%d", kTop);
-  hipLaunchKernelGGL(lta_kernel, dim3(B), dim3(256), 0, as_stream(stream), tokens, sim, key_padding_mask, out, Ltot, l0, L,
-                     K, D, top_k);
+  CMH_CHECK_ARG(K % 4 == 0, "mith_lta: K=%d must be a multiple of 4", K);
+  hipLaunchKernelGGL(lta_kernel, dim3(B, (D + 255) / 256), dim3(256), 0, as_stream(stream), tokens, sim, key_padding_mask, out, Ltot,
+                     l0, L, K, D, top_k);
   CMH_CHECK_LAUNCH("mith_lta");
   return CMH_OK;
 }
