@@ -100,3 +100,15 @@ def test_random_ascii_agrees_with_the_python_path(mini):
     assert native.all()
     for i, c in enumerate(caps):
         assert ids[i].tolist() == mini.caption_ids(c, 40), repr(c)
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+def test_tokenizer_under_address_sanitizer(tmp_path):
+    """The host-side C++ of the input pipeline, built with -fsanitize=address,undefined (CPU build: the pool offers no GPU
+    sanitizers), fed empty / huge / non-ASCII / NUL-containing / random captions on 1 and 4 threads, leak check on."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TMPDIR=str(tmp_path))
+    r = subprocess.run(["bash", os.path.join(root, "tools", "asan_bpe.sh"), bu.MINI_MERGES], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "asan_bpe ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
