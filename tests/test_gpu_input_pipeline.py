@@ -113,3 +113,6 @@ def test_mith_dataset_carries_the_padding_mask(tmp_path, monkeypatch):
         assert torch.equal(a[0], b[0]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4]) and torch.equal(b[2], b[1] == 0)
     plain = DeviceLoader(trn, DEV, cache_images=False, batch_size=6, shuffle=False)
     assert torch.equal(next(iter(plain))[0], first[0][0]) and plain.cached_epochs == 0
+    # decoding + native tokenisation inside forked DataLoader workers (they never touch the GPU), batches finished here
+    forked = [b for b in DeviceLoader(trn, DEV, cache_images=False, batch_size=6, shuffle=False, num_workers=2)]
+    assert len(forked) == 2 and all(torch.equal(a[0], b[0]) and torch.equal(a[4], b[4]) for a, b in zip(first, forked))
