@@ -142,6 +142,10 @@ SIGNATURES = {
     "cmh_image_preprocess_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "cmh_image_preprocess": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                        _p, _p, _p, _sz, _p]),
+    "cmh_vit_forward_train_tokens": (C.c_int, [C.POINTER(VitWeights), _p, _i32, _p, _p, _sz, _p]),
+    "cmh_vit_backward_tokens": (C.c_int, [C.POINTER(VitWeights), _i32, _p, C.POINTER(VitGrads), _p, _sz, _p]),
+    "cmh_text_forward_train_tokens": (C.c_int, [C.POINTER(TextWeights), _p, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
+    "cmh_text_backward_tokens": (C.c_int, [C.POINTER(TextWeights), _p, _i32, _i32, _p, _p, C.POINTER(TextGrads), _p, _sz, _p]),
     "cmh_batchnorm1d_update_running": (C.c_int, [_p, _f, _p, _p, _i32, _i32, _p]),
     "cmh_batchnorm1d_backward": (C.c_int, [_p, _p, _f, _p, _p, _p, _p, _i32, _i32, _p]),
     "cmh_twdh_loss_backward": (C.c_int, [_p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p]),

@@ -62,6 +62,8 @@ struct TrainBufs {
   void* tA;            // [rmax, Mpad] e   dY^T
   void* tB;            // [rmax, Mpad] e   X^T
   void* wT;            // [rmax * d] e     W^T
+  void* tokE;          // [M, embed] e
+  float* projT;        // [embed, d] f32
   float* small;        // [2*B*max(d,E)] f32
   void* red;           // reduction workspace
   size_t red_bytes;
@@ -101,12 +103,15 @@ TrainBufs carve_train(void* ws, size_t M, size_t B, size_t d, size_t e, size_t x
   t.part = a.take<float>(t.part_bytes);
   t.dh = a.take(M * d * e);
   t.dqkv = a.take(M * 3 * d * e);
-  const size_t rmax = 4 * d > pk ? 4 * d : pk;
+  size_t rmax = 4 * d > pk ? 4 * d : pk;
+  rmax = rmax > embed ? rmax : embed;                       // the all-token head's wgrad / dgrad have `embed` rows
   const size_t mp = pad64(M > g2rows ? M : g2rows);
   t.tAB_bytes = rmax * mp * e;
   t.tA = a.take(t.tAB_bytes);
   t.tB = a.take(t.tAB_bytes);
   t.wT = a.take(rmax * d * e);
+  t.tokE = a.take(M * embed * e);                           // all-token head: dtokens as a GEMM operand
+  t.projT = a.take<float>(embed * d * 4);                   //                 d(proj^T) [embed, d] before its transpose
   const size_t wide = d > embed ? d : embed;
   t.small = a.take<float>(2 * B * wide * 4);
   size_t rb = cmh_layernorm_backward_workspace_bytes(static_cast<int>(M), static_cast<int>(d));
@@ -375,6 +380,33 @@ extern "C" int cmh_linear_wgrad(int32_t dtype, const void* dy, int32_t dy_kind, 
   return wgrad_core(dtype, dy, dy_kind, O, x, x_kind, I, M, dw, db, w, st);
 }
 
+// ---- all-token head (MITH trunk, model/MITH.py:70-80,136-139): tokens = LN(x_last, every row) . proj ---------------------------
+// forward: the normalised rows go through t.dxe (free during the forward pass)
+int tokens_head_forward(int dt, int xh, const TrainBufs& t, const float* ln_w, const float* ln_b, const void* proj_t, float* tokens_out,
+                        int M, int d, int E, hipStream_t st) {
+  int rc;
+  if ((rc = launch_layernorm_x(t.x_last, xh, nullptr, ln_w, ln_b, t.dxe, dt == CMH_BF16, M, d, st))) return rc;
+  const int bk = dt == CMH_F32 ? 32 : 64;
+  if (E % 128 == 0 && d % bk == 0) return launch_gemm(dt, t.dxe, proj_t, nullptr, nullptr, tokens_out, M, E, d, 0, st);
+  return launch_small_linear(dt, t.dxe, proj_t, nullptr, nullptr, 1.f, CMH_ACT_NONE, tokens_out, M, E, d, st);
+}
+// backward: dproj (reference layout [d, E]) = (dtok^T h)^T, dh = dtok . proj_t, then LayerNorm backward over every row into t.dx
+// (+ its bf16 operand copy in t.dxe).  Scratch: h in t.dxe, dtok operand in t.tokE, dproj^T in t.projT.
+int tokens_head_backward(int dt, int xh, TrainBufs& t, const float* ln_w, const float* ln_b, const void* proj_t, const float* dtok,
+                         float* dproj, float* dln_w, float* dln_b, int M, int d, int E, hipStream_t st) {
+  int rc;
+  if ((rc = launch_layernorm_x(t.x_last, xh, nullptr, ln_w, ln_b, t.dxe, dt == CMH_BF16, M, d, st))) return rc;     // h again
+  float* dprojT = t.projT;
+  if ((rc = wgrad(dt, dtok, kF32, E, t.dxe, ekind(dt), d, M, dprojT, nullptr, t, st))) return rc;                     // [E, d]
+  if ((rc = launch_transpose(dprojT, kF32, dproj, kF32, E, d, E, st))) return rc;                                      // -> [d, E]
+  const void* dtok_e = nullptr;
+  if ((rc = as_gemm_operand(dt, dtok, t.tokE, static_cast<size_t>(M) * E, st, &dtok_e))) return rc;
+  const int obf = dt == CMH_BF16 ? EPI_OUT_BF16 : 0;
+  if ((rc = dgrad(dt, dtok_e, proj_t, E, d, M, nullptr, t.dh, obf, t, st))) return rc;
+  return launch_layernorm_backward(t.x_last, xkind(xh), t.dh, ekind(dt), ln_w, nullptr, M, d, t.dx, 0, dln_w, dln_b, t.red, t.red_bytes,
+                                   st, dt == CMH_BF16 ? t.dxe : nullptr);
+}
+
 // ================================================================================================================ vision
 extern "C" size_t cmh_vit_train_bytes(const cmh_vit_weights* w, int32_t batch) {
   if (!w || batch <= 0 || w->patch <= 0) return 0;
@@ -383,9 +415,9 @@ extern "C" size_t cmh_vit_train_bytes(const cmh_vit_weights* w, int32_t batch) {
   return carve_train(nullptr, B * T, B, d, e, xs, w->layers, B * g2, 3ull * w->patch * w->patch, w->embed_dim).total;
 }
 
-extern "C" int cmh_vit_forward_train(const cmh_vit_weights* w, const float* image, int32_t batch, float* feat, void* tape,
-                                     size_t tape_bytes, void* stream) {
-  CMH_CHECK_ARG(w && image && feat && tape && batch > 0, "vit_forward_train: bad arguments");
+static int vit_forward_train_impl(const cmh_vit_weights* w, const float* image, int32_t batch, float* feat, float* tokens_out,
+                                  void* tape, size_t tape_bytes, void* stream) {
+  CMH_CHECK_ARG(w && image && (feat || tokens_out) && tape && batch > 0, "vit_forward_train: bad arguments");
   int rc = check_train_tower(w->gemm_dtype, w->width, w->layers, w->embed_dim, w->blocks);
   if (rc) return rc;
   CMH_CHECK_ARG(w->layers > 0, "vit_forward_train: no layers");
@@ -409,15 +441,28 @@ extern "C" int cmh_vit_forward_train(const cmh_vit_weights* w, const float* imag
     if ((rc = block_forward_train(w->blocks[i], dt, xh, t.L[i], nxt, B, T, d, 0, nullptr, st))) return rc;
   }
   if ((rc = launch_iota_rows(t.rows, B, T, st))) return rc;
+  if (tokens_out) return tokens_head_forward(dt, xh, t, w->ln_post_w, w->ln_post_b, w->proj_t, tokens_out, M, d, w->embed_dim, st);
   if ((rc = launch_layernorm_x(t.x_last, xh, t.rows, w->ln_post_w, w->ln_post_b, t.pool, dt == CMH_BF16, B, d, st))) return rc;
   const int bk = dt == CMH_F32 ? 32 : 64;
   if (w->embed_dim % 128 == 0 && d % bk == 0) return launch_gemm(dt, t.pool, w->proj_t, nullptr, nullptr, feat, B, w->embed_dim, d, 0, st);
   return launch_small_linear(dt, t.pool, w->proj_t, nullptr, nullptr, 1.f, CMH_ACT_NONE, feat, B, w->embed_dim, d, st);
 }
 
-extern "C" int cmh_vit_backward(const cmh_vit_weights* w, int32_t batch, const float* dfeat, const cmh_vit_grads* gr, void* tape,
-                                size_t tape_bytes, void* stream) {
-  CMH_CHECK_ARG(w && dfeat && gr && tape && batch > 0, "vit_backward: bad arguments");
+extern "C" int cmh_vit_forward_train(const cmh_vit_weights* w, const float* image, int32_t batch, float* feat, void* tape,
+                                     size_t tape_bytes, void* stream) {
+  CMH_CHECK_ARG(feat, "vit_forward_train: null feature pointer");
+  return vit_forward_train_impl(w, image, batch, feat, nullptr, tape, tape_bytes, stream);
+}
+
+extern "C" int cmh_vit_forward_train_tokens(const cmh_vit_weights* w, const float* image, int32_t batch, float* tokens_out,
+                                            void* tape, size_t tape_bytes, void* stream) {
+  CMH_CHECK_ARG(tokens_out, "vit_forward_train_tokens: null output pointer");
+  return vit_forward_train_impl(w, image, batch, nullptr, tokens_out, tape, tape_bytes, stream);
+}
+
+static int vit_backward_impl(const cmh_vit_weights* w, int32_t batch, const float* dfeat, const float* dtokens, const cmh_vit_grads* gr,
+                             void* tape, size_t tape_bytes, void* stream) {
+  CMH_CHECK_ARG(w && (dfeat || dtokens) && gr && tape && batch > 0, "vit_backward: bad arguments");
   int rc = check_train_tower(w->gemm_dtype, w->width, w->layers, w->embed_dim, w->blocks);
   if (rc) return rc;
   CMH_CHECK_ARG(gr->conv1_w && gr->class_embedding && gr->positional_embedding && gr->ln_pre_w && gr->ln_pre_b && gr->ln_post_w &&
@@ -431,10 +476,14 @@ extern "C" int cmh_vit_backward(const cmh_vit_weights* w, int32_t batch, const f
   hipStream_t st = as_stream(stream);
   TrainBufs t = carve_train(tape, static_cast<size_t>(M), B, d, e, xh ? 2 : 4, w->layers, static_cast<size_t>(B) * g2, pk, E);
   if ((rc = zero_pad_buffers(t, static_cast<size_t>(M), st))) return rc;
-  if ((rc = pooled_backward(dt, xh, t.x_last, t.rows, t.pool, w->proj_t, w->ln_post_w, dfeat, gr->proj, gr->ln_post_w, gr->ln_post_b,
-                            t, B, M, d, E, st))) return rc;
+  if (dtokens) {
+    if ((rc = tokens_head_backward(dt, xh, t, w->ln_post_w, w->ln_post_b, w->proj_t, dtokens, gr->proj, gr->ln_post_w, gr->ln_post_b, M, d,
+                                   E, st))) return rc;
+  } else if ((rc = pooled_backward(dt, xh, t.x_last, t.rows, t.pool, w->proj_t, w->ln_post_w, dfeat, gr->proj, gr->ln_post_w,
+                                   gr->ln_post_b, t, B, M, d, E, st))) return rc;
   for (int i = w->layers - 1; i >= 0; --i)
-    if ((rc = block_backward(w->blocks[i], grads_of(gr->blocks[i]), dt, xh, t.L[i], t, B, T, d, 0, nullptr, st, i != w->layers - 1))) return rc;
+    if ((rc = block_backward(w->blocks[i], grads_of(gr->blocks[i]), dt, xh, t.L[i], t, B, T, d, 0, nullptr, st,
+                             i != w->layers - 1 || dtokens != nullptr))) return rc;
   // ln_pre, then the embeddings: x_pre[b,0] = cls + pos[0], x_pre[b,1+i] = patch_out[b*g2+i] + pos[1+i]
   if ((rc = launch_layernorm_backward(t.x_pre, kF32, t.dx, kF32, w->ln_pre_w, nullptr, M, d, t.dx2, 0, gr->ln_pre_w, gr->ln_pre_b,
                                       t.red, t.red_bytes, st))) return rc;
@@ -448,6 +497,18 @@ extern "C" int cmh_vit_backward(const cmh_vit_weights* w, int32_t batch, const f
   return wgrad(dt, t.dx, kF32, d, t.patches, ekind(dt), pk, B * g2, gr->conv1_w, nullptr, t, st);
 }
 
+extern "C" int cmh_vit_backward(const cmh_vit_weights* w, int32_t batch, const float* dfeat, const cmh_vit_grads* gr, void* tape,
+                                size_t tape_bytes, void* stream) {
+  CMH_CHECK_ARG(dfeat, "vit_backward: null gradient");
+  return vit_backward_impl(w, batch, dfeat, nullptr, gr, tape, tape_bytes, stream);
+}
+
+extern "C" int cmh_vit_backward_tokens(const cmh_vit_weights* w, int32_t batch, const float* dtokens, const cmh_vit_grads* gr,
+                                       void* tape, size_t tape_bytes, void* stream) {
+  CMH_CHECK_ARG(dtokens, "vit_backward_tokens: null gradient");
+  return vit_backward_impl(w, batch, nullptr, dtokens, gr, tape, tape_bytes, stream);
+}
+
 // ================================================================================================================ text
 extern "C" size_t cmh_text_train_bytes(const cmh_text_weights* w, int32_t batch, int32_t seq_len) {
   if (!w || batch <= 0 || seq_len <= 0) return 0;
@@ -455,9 +516,10 @@ extern "C" size_t cmh_text_train_bytes(const cmh_text_weights* w, int32_t batch,
   return carve_train(nullptr, static_cast<size_t>(batch) * seq_len, batch, w->width, e, xs, w->layers, 0, 0, w->embed_dim).total;
 }
 
-extern "C" int cmh_text_forward_train(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
-                                      const uint8_t* key_padding_mask, float* feat, void* tape, size_t tape_bytes, void* stream) {
-  CMH_CHECK_ARG(w && tokens && feat && tape && batch > 0 && seq_len > 0, "text_forward_train: bad arguments");
+static int text_forward_train_impl(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
+                                   const uint8_t* key_padding_mask, float* feat, float* tokens_out, int32_t* eot_rows_out, void* tape,
+                                   size_t tape_bytes, void* stream) {
+  CMH_CHECK_ARG(w && tokens && (feat || tokens_out) && tape && batch > 0 && seq_len > 0, "text_forward_train: bad arguments");
   int rc = check_train_tower(w->gemm_dtype, w->width, w->layers, w->embed_dim, w->blocks);
   if (rc) return rc;
   CMH_CHECK_ARG(w->layers > 0 && seq_len <= w->context_length, "text_forward_train: layers / seq_len");
@@ -471,7 +533,7 @@ extern "C" int cmh_text_forward_train(const cmh_text_weights* w, const int64_t* 
   // packed like encode_text (encoders.hip): only the tokens 0..EOT of every caption are run through the blocks
   const int32_t* seq_off = nullptr;
   int rows = M;
-  if (text_packing(key_padding_mask)) {
+  if (!tokens_out && text_packing(key_padding_mask)) {      // every token is an output of the MITH trunk: nothing to skip there
     if ((rc = launch_text_pack_plan(tokens, B, L, t.seq_off, st))) return rc;
     int32_t total = 0;
     if (hipMemcpyAsync(&total, t.seq_off + B, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
@@ -486,6 +548,12 @@ extern "C" int cmh_text_forward_train(const cmh_text_weights* w, const int64_t* 
     void* nxt = i + 1 < w->layers ? t.L[i + 1].x_in : t.x_last;
     if ((rc = block_forward_train(w->blocks[i], dt, xh, t.L[i], nxt, B, L, d, 1, key_padding_mask, st, rows, seq_off))) return rc;
   }
+  if (tokens_out) {
+    if (eot_rows_out && hipMemcpyAsync(eot_rows_out, t.rows, static_cast<size_t>(B) * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return fail(CMH_ERR_LAUNCH, "text_forward_train_tokens: eot row copy failed");
+    if (hipMemsetAsync(t.seq_off, 0, static_cast<size_t>(B + 1) * 4, st) != hipSuccess) return fail(CMH_ERR_LAUNCH, "text_forward_train_tokens: memset failed");
+    return tokens_head_forward(dt, xh, t, w->ln_final_w, w->ln_final_b, w->text_projection_t, tokens_out, M, d, w->embed_dim, st);
+  }
   if ((rc = launch_layernorm_x(t.x_last, xh, t.rows, w->ln_final_w, w->ln_final_b, t.pool, dt == CMH_BF16, B, d, st))) return rc;
   const int bk = dt == CMH_F32 ? 32 : 64;
   if (w->embed_dim % 128 == 0 && d % bk == 0)
@@ -493,10 +561,23 @@ extern "C" int cmh_text_forward_train(const cmh_text_weights* w, const int64_t* 
   return launch_small_linear(dt, t.pool, w->text_projection_t, nullptr, nullptr, 1.f, CMH_ACT_NONE, feat, B, w->embed_dim, d, st);
 }
 
-extern "C" int cmh_text_backward(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
-                                 const uint8_t* key_padding_mask, const float* dfeat, const cmh_text_grads* gr, void* tape,
-                                 size_t tape_bytes, void* stream) {
-  CMH_CHECK_ARG(w && tokens && dfeat && gr && tape && batch > 0 && seq_len > 0, "text_backward: bad arguments");
+extern "C" int cmh_text_forward_train(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
+                                      const uint8_t* key_padding_mask, float* feat, void* tape, size_t tape_bytes, void* stream) {
+  CMH_CHECK_ARG(feat, "text_forward_train: null feature pointer");
+  return text_forward_train_impl(w, tokens, batch, seq_len, key_padding_mask, feat, nullptr, nullptr, tape, tape_bytes, stream);
+}
+
+extern "C" int cmh_text_forward_train_tokens(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
+                                             const uint8_t* key_padding_mask, float* tokens_out, int32_t* eot_rows_out, void* tape,
+                                             size_t tape_bytes, void* stream) {
+  CMH_CHECK_ARG(tokens_out, "text_forward_train_tokens: null output pointer");
+  return text_forward_train_impl(w, tokens, batch, seq_len, key_padding_mask, nullptr, tokens_out, eot_rows_out, tape, tape_bytes, stream);
+}
+
+static int text_backward_impl(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
+                              const uint8_t* key_padding_mask, const float* dfeat, const float* dtokens, const cmh_text_grads* gr,
+                              void* tape, size_t tape_bytes, void* stream) {
+  CMH_CHECK_ARG(w && tokens && (dfeat || dtokens) && gr && tape && batch > 0 && seq_len > 0, "text_backward: bad arguments");
   int rc = check_train_tower(w->gemm_dtype, w->width, w->layers, w->embed_dim, w->blocks);
   if (rc) return rc;
   CMH_CHECK_ARG(gr->token_embedding && gr->positional_embedding && gr->ln_final_w && gr->ln_final_b && gr->text_projection &&
@@ -510,7 +591,7 @@ extern "C" int cmh_text_backward(const cmh_text_weights* w, const int64_t* token
   TrainBufs t = carve_train(tape, static_cast<size_t>(M), B, d, e, xh ? 2 : 4, w->layers, 0, 0, E);
   const int32_t* seq_off = nullptr;
   int rows = M;
-  if (text_packing(key_padding_mask)) {       // same rule as the forward call that filled this tape
+  if (!dtokens && text_packing(key_padding_mask)) {       // same rule as the forward call that filled this tape
     int32_t total = 0;
     if (hipMemcpyAsync(&total, t.seq_off + B, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
       return fail(CMH_ERR_LAUNCH, "text_backward: reading the packed row count failed");
@@ -519,10 +600,14 @@ extern "C" int cmh_text_backward(const cmh_text_weights* w, const int64_t* token
     rows = total;
   }
   if ((rc = zero_pad_buffers(t, static_cast<size_t>(rows), st))) return rc;
-  if ((rc = pooled_backward(dt, xh, t.x_last, t.rows, t.pool, w->text_projection_t, w->ln_final_w, dfeat, gr->text_projection,
-                            gr->ln_final_w, gr->ln_final_b, t, B, rows, d, E, st))) return rc;
+  if (dtokens) {
+    if ((rc = tokens_head_backward(dt, xh, t, w->ln_final_w, w->ln_final_b, w->text_projection_t, dtokens, gr->text_projection,
+                                   gr->ln_final_w, gr->ln_final_b, M, d, E, st))) return rc;
+  } else if ((rc = pooled_backward(dt, xh, t.x_last, t.rows, t.pool, w->text_projection_t, w->ln_final_w, dfeat, gr->text_projection,
+                                   gr->ln_final_w, gr->ln_final_b, t, B, rows, d, E, st))) return rc;
   for (int i = w->layers - 1; i >= 0; --i)
-    if ((rc = block_backward(w->blocks[i], grads_of(gr->blocks[i]), dt, xh, t.L[i], t, B, L, d, 1, key_padding_mask, st, i != w->layers - 1, rows, seq_off))) return rc;
+    if ((rc = block_backward(w->blocks[i], grads_of(gr->blocks[i]), dt, xh, t.L[i], t, B, L, d, 1, key_padding_mask, st,
+                             i != w->layers - 1 || dtokens != nullptr, rows, seq_off))) return rc;
   // x_0[b, t] = token_embedding[tokens[b, t]] + positional_embedding[t]
   if (hipMemsetAsync(gr->positional_embedding, 0, static_cast<size_t>(w->context_length) * d * 4, st) != hipSuccess ||
       hipMemsetAsync(gr->token_embedding, 0, static_cast<size_t>(w->vocab_size) * d * 4, st) != hipSuccess)
@@ -537,4 +622,18 @@ extern "C" int cmh_text_backward(const cmh_text_weights* w, const int64_t* token
   }
   CMH_CHECK_LAUNCH("embedding scatter");
   return CMH_OK;
+}
+
+extern "C" int cmh_text_backward(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
+                                 const uint8_t* key_padding_mask, const float* dfeat, const cmh_text_grads* gr, void* tape,
+                                 size_t tape_bytes, void* stream) {
+  CMH_CHECK_ARG(dfeat, "text_backward: null gradient");
+  return text_backward_impl(w, tokens, batch, seq_len, key_padding_mask, dfeat, nullptr, gr, tape, tape_bytes, stream);
+}
+
+extern "C" int cmh_text_backward_tokens(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
+                                        const uint8_t* key_padding_mask, const float* dtokens, const cmh_text_grads* gr, void* tape,
+                                        size_t tape_bytes, void* stream) {
+  CMH_CHECK_ARG(dtokens, "text_backward_tokens: null gradient");
+  return text_backward_impl(w, tokens, batch, seq_len, key_padding_mask, nullptr, dtokens, gr, tape, tape_bytes, stream);
 }

@@ -28,13 +28,26 @@ class ViT(VisionTransformer):
 
 class CLIP1(CLIP):
     def encode_image(self, image):
-        tok = M.vit_encode_tokens(self, image)                       # [B, T, E]
-        tok = no_backward(tok, self.visual.proj)
+        from model.base import train_ops as T
+        params = T.vit_params(self.visual)
+        if not self.assume_frozen and T.wants_grad(params):                 # training: tape-keeping forward, token gradients back
+            image = N.f32c(image)
+            s = self._vit_struct()
+            tok = T.VitTrainTokens.apply(self, image, *params).view(image.shape[0], -1, s.embed_dim)
+        else:
+            tok = M.vit_encode_tokens(self, image)                       # [B, T, E]
         return tok[:, 1:].permute(1, 0, 2), None, tok[:, 0]
 
     def encode_text(self, text, key_padding_mask):
-        tok, rows = M.text_encode_tokens(self, text, key_padding_mask)   # [B, L, E]
-        tok = no_backward(tok, self.text_projection)
+        from model.base import train_ops as T
+        params = T.text_params(self)
+        if not self.assume_frozen and T.wants_grad(params):
+            text = text.to(torch.int64).contiguous()
+            kpm = None if key_padding_mask is None else key_padding_mask.to(torch.uint8).contiguous()
+            tok, rows = T.TextTrainTokens.apply(self, text, kpm, *params)
+            tok = tok.view(text.shape[0], text.shape[1], -1)
+        else:
+            tok, rows = M.text_encode_tokens(self, text, key_padding_mask)   # [B, L, E]
         B, L, E = tok.shape
         new_kpm = key_padding_mask + (text == 49407)                 # model/MITH.py:134 (bool OR)
         eos = tok.reshape(B * L, E)[rows.long()]

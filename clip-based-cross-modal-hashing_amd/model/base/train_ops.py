@@ -99,5 +99,64 @@ class TextTrain(torch.autograd.Function):
         return (None, None, None) + tuple(grads)
 
 
+class VitTrainTokens(torch.autograd.Function):
+    """The MITH trunk's image tower under training: every token projected (model/MITH.py:56-82) -> [B*T, E]."""
+
+    @staticmethod
+    def forward(ctx, clip, image, *params):
+        s = clip._vit_struct()
+        B = image.shape[0]
+        T = (s.resolution // s.patch) ** 2 + 1
+        tok = torch.empty(B * T, s.embed_dim, dtype=torch.float32, device=image.device)
+        tape = torch.empty(N.lib().cmh_vit_train_bytes(C.byref(s), B), dtype=torch.uint8, device=image.device)
+        N.check(N.lib().cmh_vit_forward_train_tokens(C.byref(s), N.ptr(image), B, N.ptr(tok), N.ptr(tape), tape.numel(),
+                                                     N.stream_ptr(image.device)), "cmh_vit_forward_train_tokens")
+        ctx.tape, ctx.B, ctx.struct, ctx.params = tape, B, s, params
+        return tok
+
+    @staticmethod
+    def backward(ctx, dtok):
+        s, params = ctx.struct, ctx.params
+        grads = _grad_buffers(params)
+        blocks = _block_grads(grads, 8)
+        g = N.VitGrads(*[t.data_ptr() for t in grads[:8]], C.cast(blocks, C.POINTER(N.BlockGrads)))
+        dtok = N.f32c(dtok)
+        N.check(N.lib().cmh_vit_backward_tokens(C.byref(s), ctx.B, N.ptr(dtok), C.byref(g), N.ptr(ctx.tape), ctx.tape.numel(),
+                                                N.stream_ptr(dtok.device)), "cmh_vit_backward_tokens")
+        ctx.tape = None
+        return (None, None) + tuple(grads)
+
+
+class TextTrainTokens(torch.autograd.Function):
+    """The MITH trunk's text tower under training (model/MITH.py:120-144) -> ([B*L, E] tokens, eot rows i32 [B])."""
+
+    @staticmethod
+    def forward(ctx, clip, text, kpm, *params):
+        s = clip._text_struct()
+        B, L = text.shape
+        tok = torch.empty(B * L, s.embed_dim, dtype=torch.float32, device=text.device)
+        rows = torch.empty(B, dtype=torch.int32, device=text.device)
+        tape = torch.empty(N.lib().cmh_text_train_bytes(C.byref(s), B, L), dtype=torch.uint8, device=text.device)
+        N.check(N.lib().cmh_text_forward_train_tokens(C.byref(s), N.ptr(text), B, L, N.ptr(kpm), N.ptr(tok), N.ptr(rows), N.ptr(tape),
+                                                      tape.numel(), N.stream_ptr(text.device)), "cmh_text_forward_train_tokens")
+        ctx.tape, ctx.struct, ctx.text, ctx.kpm, ctx.params = tape, s, text, kpm, params
+        ctx.mark_non_differentiable(rows)
+        return tok, rows
+
+    @staticmethod
+    def backward(ctx, dtok, _drows):
+        s, params, text = ctx.struct, ctx.params, ctx.text
+        grads = _grad_buffers(params)
+        blocks = _block_grads(grads, 5)
+        g = N.TextGrads(*[t.data_ptr() for t in grads[:5]], C.cast(blocks, C.POINTER(N.BlockGrads)))
+        dtok = N.f32c(dtok)
+        B, L = text.shape
+        N.check(N.lib().cmh_text_backward_tokens(C.byref(s), N.ptr(text), B, L, N.ptr(ctx.kpm), N.ptr(dtok), C.byref(g),
+                                                 N.ptr(ctx.tape), ctx.tape.numel(), N.stream_ptr(dtok.device)),
+                "cmh_text_backward_tokens")
+        ctx.tape = None
+        return (None, None, None) + tuple(grads)
+
+
 def wants_grad(params):
     return torch.is_grad_enabled() and any(p.requires_grad for p in params)

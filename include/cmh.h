@@ -482,12 +482,28 @@ int cmh_vit_forward_train(const cmh_vit_weights* w, const float* image, int32_t 
                           void* stream);
 int cmh_vit_backward(const cmh_vit_weights* w, int32_t batch, const float* dfeat, const cmh_vit_grads* grads, void* tape,
                      size_t tape_bytes, void* stream);
+/* The same two calls for the MITH trunk (model/MITH.py:56-82): ln_post + proj on EVERY token.  tokens_out / dtokens f32
+ * [batch * (g*g + 1), embed_dim] (row b*(g*g+1) is the class token); tape as for cmh_vit_forward_train. */
+int cmh_vit_forward_train_tokens(const cmh_vit_weights* w, const float* image, int32_t batch, float* tokens_out, void* tape,
+                                 size_t tape_bytes, void* stream);
+int cmh_vit_backward_tokens(const cmh_vit_weights* w, int32_t batch, const float* dtokens, const cmh_vit_grads* grads, void* tape,
+                            size_t tape_bytes, void* stream);
 size_t cmh_text_train_bytes(const cmh_text_weights* w, int32_t batch, int32_t seq_len);
 int cmh_text_forward_train(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
                            const uint8_t* key_padding_mask, float* feat, void* tape, size_t tape_bytes, void* stream);
 int cmh_text_backward(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
                       const uint8_t* key_padding_mask, const float* dfeat, const cmh_text_grads* grads, void* tape,
                       size_t tape_bytes, void* stream);
+
+/* CLIP1.encode_text of the MITH trunk under training (model/MITH.py:120-144): causal mask + key_padding_mask, every position is
+ * run (no packing), ln_final + text_projection on every token.  tokens_out / dtokens f32 [batch * seq_len, embed_dim];
+ * eot_rows_out i32 [batch] = b * seq_len + argmax(tokens[b]) (may be NULL). */
+int cmh_text_forward_train_tokens(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
+                                  const uint8_t* key_padding_mask, float* tokens_out, int32_t* eot_rows_out, void* tape,
+                                  size_t tape_bytes, void* stream);
+int cmh_text_backward_tokens(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
+                             const uint8_t* key_padding_mask, const float* dtokens, const cmh_text_grads* grads, void* tape,
+                             size_t tape_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -128,3 +128,40 @@ def test_hashing_model_bf16_gemms_track_f32():
         local = "tokens" in k
         assert cos > (0.97 if local else 0.999), (k, cos)
         assert flips < (0.10 if local else 0.03), (k, flips)
+
+
+def test_trunk_token_gradients_match_reference_autograd(golden):
+    """The MITH trunk under training (every token projected, key_padding_mask in the text blocks): all parameter gradients of
+    L = sum(seq_i G1) + sum(cls_i G2) + sum(seq_t G3) + sum(eos_t G4) against torch autograd on the REFERENCE's CLIP1
+    (tests/golden/make_golden11.py), f32 mode."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_golden5 import cut
+    import recipe
+    from model.MITH import build_model
+    g = golden("mith_trunk_grads.npz")
+    cfg, seed = mu.CLIP_TINY512, 7
+    sd = {k: torch.from_numpy(v) for k, v in recipe.clip_state_dict(cfg, seed).items()}
+    clip = build_model(sd).to(DEV).float().set_gemm_dtype("f32")
+    image = torch.from_numpy(recipe.images(3, cfg["image_resolution"], seed)).to(DEV)
+    text_np = recipe.captions(3, 16, cfg["vocab_size"], seed)
+    text, kpm = torch.from_numpy(text_np).to(DEV), torch.from_numpy(text_np == 0).to(DEV)
+    seq_i, _, cls_i = clip.encode_image(image)
+    seq_t, _, new_kpm, eos_t = clip.encode_text(text, kpm)
+    for a, k in ((seq_i, "seq_i"), (cls_i, "cls_i"), (eos_t, "eos_t")):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), g[k], rtol=1e-3, atol=2e-4)
+    gen = torch.Generator().manual_seed(31)
+    G = [torch.randn(x.shape, generator=gen).to(DEV) for x in (seq_i, cls_i, seq_t, eos_t)]
+    ((seq_i * G[0]).sum() + (cls_i * G[1]).sum() + (seq_t * G[2]).sum() + (eos_t * G[3]).sum()).backward()
+    params = dict(clip.named_parameters())
+    worst = 0.0
+    for name in [str(n) for n in g["names"]]:
+        got = params[name].grad
+        assert got is not None, name
+        ref, norm = g["g_" + name], float(g["n_" + name])
+        assert abs(float(got.double().norm()) - norm) <= 5e-4 * max(norm, 1e-3), (name, float(got.double().norm()), norm)
+        err = np.abs(cut(got.cpu().numpy()) - ref).max() / max(np.abs(ref).max(), 1e-6)
+        worst = max(worst, err)
+        assert err < 1e-3, (name, err)
+    print(f"MITH trunk gradients: worst relative-to-max error {worst:.2e} over {len(g['names'])} tensors")
