@@ -146,6 +146,14 @@ SIGNATURES = {
     "cmh_vit_backward_tokens": (C.c_int, [C.POINTER(VitWeights), _i32, _p, C.POINTER(VitGrads), _p, _sz, _p]),
     "cmh_text_forward_train_tokens": (C.c_int, [C.POINTER(TextWeights), _p, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
     "cmh_text_backward_tokens": (C.c_int, [C.POINTER(TextWeights), _p, _i32, _i32, _p, _p, C.POINTER(TextGrads), _p, _sz, _p]),
+    "cmh_blocks_train_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
+    "cmh_blocks_forward_train": (C.c_int, [C.POINTER(BlockWeights), _i32, _i32, _p, _p, _i32, _i32, _i32, _p, _sz, _p]),
+    "cmh_blocks_backward": (C.c_int, [C.POINTER(BlockWeights), C.POINTER(BlockGrads), _i32, _i32, _p, _p, _i32, _i32, _i32, _p, _sz, _p]),
+    "cmh_mith_lta_backward": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    "cmh_gelu": (C.c_int, [_p, _p, C.c_int64, _p]),
+    "cmh_gelu_backward": (C.c_int, [_p, _p, _p, C.c_int64, _p]),
+    "cmh_l2_normalize_backward": (C.c_int, [_p, _p, _p, _i32, _i32, _p]),
+    "cmh_bitwise_hash_backward": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p]),
     "cmh_batchnorm1d_update_running": (C.c_int, [_p, _f, _p, _p, _i32, _i32, _p]),
     "cmh_batchnorm1d_backward": (C.c_int, [_p, _p, _f, _p, _p, _p, _p, _i32, _i32, _p]),
     "cmh_twdh_loss_backward": (C.c_int, [_p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p]),

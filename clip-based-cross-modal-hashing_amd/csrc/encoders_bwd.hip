@@ -637,3 +637,51 @@ extern "C" int cmh_text_backward_tokens(const cmh_text_weights* w, const int64_t
   CMH_CHECK_ARG(dtokens, "text_backward_tokens: null gradient");
   return text_backward_impl(w, tokens, batch, seq_len, key_padding_mask, nullptr, dtokens, gr, tape, tape_bytes, stream);
 }
+
+
+// ================================================================================================ a bare stack of blocks
+// MITH's concept transformer (model/MITH.py:379-396: 2 ResidualAttentionBlocks over the K "concept tokens" of every sample, no
+// mask) under training: f32 residual stream in and out, GEMM operands in `dtype`.
+extern "C" size_t cmh_blocks_train_bytes(int32_t dtype, int32_t B, int32_t T, int32_t d, int32_t layers) {
+  if (B <= 0 || T <= 0 || d <= 0 || layers <= 0) return 0;
+  const size_t e = dtype == CMH_BF16 ? 2 : 4;
+  return carve_train(nullptr, static_cast<size_t>(B) * T, B, d, e, 4, layers, 0, 0, 4).total;
+}
+
+extern "C" int cmh_blocks_forward_train(const cmh_block_weights* blocks, int32_t layers, int32_t dtype, const float* x, float* y,
+                                        int32_t B, int32_t T, int32_t d, void* tape, size_t tape_bytes, void* stream) {
+  CMH_CHECK_ARG(blocks && x && y && tape && layers > 0 && B > 0 && T > 0, "blocks_forward_train: bad arguments");
+  int rc = check_train_tower(dtype, d, layers, 4, blocks);
+  if (rc) return rc;
+  if (tape_bytes < cmh_blocks_train_bytes(dtype, B, T, d, layers)) return fail(CMH_ERR_WORKSPACE, "blocks_forward_train: tape too small");
+  CMH_CHECK_ARG((reinterpret_cast<uintptr_t>(tape) & 255) == 0, "blocks_forward_train: tape must be 256-byte aligned");
+  const size_t M = static_cast<size_t>(B) * T, e = dtype == CMH_BF16 ? 2 : 4;
+  hipStream_t st = as_stream(stream);
+  TrainBufs t = carve_train(tape, M, B, d, e, 4, layers, 0, 0, 4);
+  if (hipMemcpyAsync(t.L[0].x_in, x, M * d * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(CMH_ERR_LAUNCH, "blocks_forward_train: copy failed");
+  for (int i = 0; i < layers; ++i) {
+    void* nxt = i + 1 < layers ? t.L[i + 1].x_in : t.x_last;
+    if ((rc = block_forward_train(blocks[i], dtype, /*xh=*/0, t.L[i], nxt, B, T, d, 0, nullptr, st))) return rc;
+  }
+  if (hipMemcpyAsync(y, t.x_last, M * d * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(CMH_ERR_LAUNCH, "blocks_forward_train: copy failed");
+  return CMH_OK;
+}
+
+extern "C" int cmh_blocks_backward(const cmh_block_weights* blocks, const cmh_block_grads* grads, int32_t layers, int32_t dtype,
+                                   const float* dy, float* dx, int32_t B, int32_t T, int32_t d, void* tape, size_t tape_bytes,
+                                   void* stream) {
+  CMH_CHECK_ARG(blocks && grads && dy && dx && tape && layers > 0 && B > 0 && T > 0, "blocks_backward: bad arguments");
+  int rc = check_train_tower(dtype, d, layers, 4, blocks);
+  if (rc) return rc;
+  if ((rc = check_block_grads(grads, layers))) return rc;
+  if (tape_bytes < cmh_blocks_train_bytes(dtype, B, T, d, layers)) return fail(CMH_ERR_WORKSPACE, "blocks_backward: tape too small");
+  const size_t M = static_cast<size_t>(B) * T, e = dtype == CMH_BF16 ? 2 : 4;
+  hipStream_t st = as_stream(stream);
+  TrainBufs t = carve_train(tape, M, B, d, e, 4, layers, 0, 0, 4);
+  if ((rc = zero_pad_buffers(t, M, st))) return rc;
+  if (hipMemcpyAsync(t.dx, dy, M * d * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(CMH_ERR_LAUNCH, "blocks_backward: copy failed");
+  for (int i = layers - 1; i >= 0; --i)
+    if ((rc = block_backward(blocks[i], grads_of(grads[i]), dtype, /*xh=*/0, t.L[i], t, B, T, d, 0, nullptr, st, i != layers - 1))) return rc;
+  if (hipMemcpyAsync(dx, t.dx, M * d * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(CMH_ERR_LAUNCH, "blocks_backward: copy failed");
+  return CMH_OK;
+}

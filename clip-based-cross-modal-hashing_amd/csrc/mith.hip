@@ -45,12 +45,11 @@ constexpr float kNegInf = -__builtin_huge_valf();
 // cheap next to the L x K x D aggregation, and two blocks per sample fill the chip at batch 128).  sim rows [row0 + l] (l < L)
 // of a [B*Ltot, K] matrix, tokens rows likewise of [B*Ltot, D].  The weights sit in LDS with a 16-byte aligned row pitch: the
 // aggregation reads them four concepts at a time (one ds_read_b128 per 4 FMAs instead of one ds_read_b32 per FMA).
-__global__ __launch_bounds__(256) void lta_kernel(const float* __restrict__ tokens, const float* __restrict__ sim,
-                                                  const uint8_t* __restrict__ kpm, float* __restrict__ out, int Ltot,
-                                                  int l0, int L, int K, int D, int top_k) {
-  __shared__ __attribute__((aligned(16))) float w[kLtaMaxL][kLtaMaxK + 4];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const size_t row0 = static_cast<size_t>(b) * Ltot + l0;
+// steps 1-3 of LocalizedTokenAggregation for one sample: w[l][k] = the aggregation weights (softmax over the tokens of the
+// masked, positive, per-token top-k similarities); shared by the forward kernel and the gradient w.r.t. the tokens
+__device__ __forceinline__ void lta_build_weights(float (*w)[kLtaMaxK + 4], const float* __restrict__ sim,
+                                                  const uint8_t* __restrict__ kpm, int b, size_t row0, int L, int K, int top_k) {
+  const int tid = threadIdx.x;
   // 1. load, key-padding -> -inf, non-positive -> -inf   (:350-361)
   for (int i = tid; i < L * K; i += 256) {
     const int l = i / K, k = i - l * K;
@@ -101,6 +100,15 @@ __global__ __launch_bounds__(256) void lta_kernel(const float* __restrict__ toke
     }
   }
   __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void lta_kernel(const float* __restrict__ tokens, const float* __restrict__ sim,
+                                                  const uint8_t* __restrict__ kpm, float* __restrict__ out, int Ltot,
+                                                  int l0, int L, int K, int D, int top_k) {
+  __shared__ __attribute__((aligned(16))) float w[kLtaMaxL][kLtaMaxK + 4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const size_t row0 = static_cast<size_t>(b) * Ltot + l0;
+  lta_build_weights(w, sim, kpm, b, row0, L, K, top_k);
   // 4. merge[b,k,:] = sum_l w[l,k] * tokens[b,l,:]   (:370-375)
   const int d = blockIdx.y * 256 + tid;
   if (d < D) {
@@ -250,6 +258,93 @@ __global__ void read_acc_kernel(const double* __restrict__ acc, double scale, fl
   out[0] = static_cast<float>(acc[0] * scale);
 }
 
+// ---- backward pieces of the HashingModel (the similarities that steer the aggregation are detached upstream, model/MITH.py:345,
+// so the aggregation is linear in the tokens) ------------------------------------------------------------------------------------
+// dtokens[b, l0 + l, :] = sum_k w[l, k] * dmerge[b, k, :]; grid (B, ceil(D / 256))
+__global__ __launch_bounds__(256) void lta_bwd_kernel(const float* __restrict__ sim, const uint8_t* __restrict__ kpm,
+                                                      const float* __restrict__ dmerge, float* __restrict__ dtokens, int Ltot, int l0,
+                                                      int L, int K, int D, int top_k) {
+  __shared__ __attribute__((aligned(16))) float w[kLtaMaxL][kLtaMaxK + 4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const size_t row0 = static_cast<size_t>(b) * Ltot + l0;
+  lta_build_weights(w, sim, kpm, b, row0, L, K, top_k);
+  const int d = blockIdx.y * 256 + tid;
+  if (d >= D) return;
+  float g[kLtaMaxK];
+#pragma unroll
+  for (int k = 0; k < kLtaMaxK; ++k) g[k] = k < K ? dmerge[(static_cast<size_t>(b) * K + k) * D + d] : 0.f;
+  for (int l = 0; l < L; ++l) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k4 = 0; k4 < kLtaMaxK / 4; ++k4)
+      if (k4 * 4 < K) {
+        const float4 wv = *reinterpret_cast<const float4*>(&w[l][k4 * 4]);
+        acc = fmaf(wv.x, g[k4 * 4], acc); acc = fmaf(wv.y, g[k4 * 4 + 1], acc);
+        acc = fmaf(wv.z, g[k4 * 4 + 2], acc); acc = fmaf(wv.w, g[k4 * 4 + 3], acc);
+      }
+    dtokens[(row0 + l) * D + d] = acc;
+  }
+}
+
+// exact GELU (nn.GELU(): 0.5 x (1 + erf(x / sqrt 2))) and its derivative 0.5 (1 + erf(x / sqrt 2)) + x exp(-x^2 / 2) / sqrt(2 pi)
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = gelu_erf(x[i]);
+}
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                                       int64_t n) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = x[i];
+  dx[i] = dy[i] * (0.5f * (1.0f + erff(v * 0.70710678118654752f)) + v * expf(-0.5f * v * v) * 0.3989422804014327f);
+}
+
+// F.normalize(x, dim=-1) backward: y = x / max(|x|, 1e-12);  dx = (dy - y (y . dy)) / max(|x|, 1e-12).  One wave per row.
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         float* __restrict__ dx, int R, int D) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const float* xr = x + static_cast<size_t>(row) * D;
+  const float* gr = dy + static_cast<size_t>(row) * D;
+  float ss = 0.f, sg = 0.f;
+  for (int d = lane; d < D; d += 64) { ss = fmaf(xr[d], xr[d], ss); sg = fmaf(xr[d], gr[d], sg); }
+  ss = m_wave_sum(ss); sg = m_wave_sum(sg);
+  const float nrm = sqrtf(ss);
+  const float inv = 1.0f / fmaxf(nrm, 1e-12f);
+  // below the eps clamp y = x / eps is linear: dx = dy / eps
+  const float proj = nrm > 1e-12f ? sg * inv * inv : 0.f;          // (y . dy) / |x| = (x . dy) / |x|^2 ... times x / |x| below
+  for (int d = lane; d < D; d += 64) dx[static_cast<size_t>(row) * D + d] = (gr[d] - xr[d] * proj) * inv;
+}
+
+// BitwiseHashing backward: y[n,k] = tanh(x[n,k,:] . w[k,:] + b[k]).  dz = dy (1 - y^2);
+//   dx[n,k,:] = dz[n,k] w[k,:]  (grid (N*K) waves), dw[k,:] = sum_n dz[n,k] x[n,k,:], db[k] = sum_n dz[n,k]  (grid K workgroups)
+__global__ __launch_bounds__(256) void bithash_dx_kernel(const float* __restrict__ w, const float* __restrict__ y,
+                                                         const float* __restrict__ dy, float* __restrict__ dx, int NK, int K, int D) {
+  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= NK) return;
+  const int k = i % K;
+  const float dz = dy[i] * (1.0f - y[i] * y[i]);
+  for (int d = lane; d < D; d += 64) dx[static_cast<size_t>(i) * D + d] = dz * w[static_cast<size_t>(k) * D + d];
+}
+__global__ __launch_bounds__(256) void bithash_dw_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                         const float* __restrict__ dy, float* __restrict__ dw, float* __restrict__ db,
+                                                         int Nb, int K, int D) {
+  const int k = blockIdx.x;
+  float sb = 0.f;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float acc = 0.f;
+    for (int n = 0; n < Nb; ++n) {
+      const size_t i = static_cast<size_t>(n) * K + k;
+      acc = fmaf(dy[i] * (1.0f - y[i] * y[i]), x[i * D + d], acc);
+    }
+    dw[static_cast<size_t>(k) * D + d] = acc;
+  }
+  if (threadIdx.x == 0) {
+    for (int n = 0; n < Nb; ++n) { const size_t i = static_cast<size_t>(n) * K + k; sb += dy[i] * (1.0f - y[i] * y[i]); }
+    db[k] = sb;
+  }
+}
+
 }  // namespace cmh
 
 using namespace cmh;
@@ -340,5 +435,51 @@ extern "C" int cmh_info_nce(const float* a, const float* b, int32_t R, int32_t G
   hipLaunchKernelGGL(row_ce_kernel, dim3((R + 3) / 4), dim3(256), smem, st, b, a, R, G, D, 1.0f / temperature, acc);
   hipLaunchKernelGGL(read_acc_kernel, dim3(1), dim3(1), 0, st, acc, 0.5 / static_cast<double>(R), out);
   CMH_CHECK_LAUNCH("info_nce");
+  return CMH_OK;
+}
+
+extern "C" int cmh_mith_lta_backward(const float* sim, const uint8_t* key_padding_mask, const float* dmerge, float* dtokens, int32_t B,
+                                     int32_t Ltot, int32_t l0, int32_t L, int32_t K, int32_t D, int32_t top_k, void* stream) {
+  CMH_CHECK_ARG(sim && dmerge && dtokens, "mith_lta_backward: null pointer");
+  CMH_CHECK_ARG(B > 0 && L > 0 && L <= kLtaMaxL && l0 >= 0 && l0 + L <= Ltot, "mith_lta_backward: token range (L <= %d)", kLtaMaxL);
+  CMH_CHECK_ARG(K > 0 && K <= kLtaMaxK && K % 4 == 0 && D > 0, "mith_lta_backward: K must be a multiple of 4, <= %d", kLtaMaxK);
+  CMH_CHECK_ARG(top_k >= 1 && top_k <= kTop, "mith_lta_backward: top_k must be in 1..%d", kTop);
+  hipStream_t st = as_stream(stream);
+  if (L != Ltot && hipMemsetAsync(dtokens, 0, static_cast<size_t>(B) * Ltot * D * 4, st) != hipSuccess)
+    return fail(CMH_ERR_LAUNCH, "mith_lta_backward: memset failed");
+  hipLaunchKernelGGL(lta_bwd_kernel, dim3(B, (D + 255) / 256), dim3(256), 0, st, sim, key_padding_mask, dmerge, dtokens, Ltot, l0, L, K,
+                     D, top_k);
+  CMH_CHECK_LAUNCH("mith_lta_backward");
+  return CMH_OK;
+}
+
+extern "C" int cmh_gelu(const float* x, float* y, int64_t n, void* stream) {
+  CMH_CHECK_ARG(x && y && n > 0, "gelu: bad arguments");
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, as_stream(stream), x, y, n);
+  CMH_CHECK_LAUNCH("gelu");
+  return CMH_OK;
+}
+
+extern "C" int cmh_gelu_backward(const float* x, const float* dy, float* dx, int64_t n, void* stream) {
+  CMH_CHECK_ARG(x && dy && dx && n > 0, "gelu_backward: bad arguments");
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, as_stream(stream), x, dy, dx, n);
+  CMH_CHECK_LAUNCH("gelu_backward");
+  return CMH_OK;
+}
+
+extern "C" int cmh_l2_normalize_backward(const float* x, const float* dy, float* dx, int32_t R, int32_t D, void* stream) {
+  CMH_CHECK_ARG(x && dy && dx && R > 0 && D > 0, "l2_normalize_backward: bad arguments");
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, as_stream(stream), x, dy, dx, R, D);
+  CMH_CHECK_LAUNCH("l2_normalize_backward");
+  return CMH_OK;
+}
+
+extern "C" int cmh_bitwise_hash_backward(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw,
+                                         float* db, int32_t B, int32_t K, int32_t D, void* stream) {
+  CMH_CHECK_ARG(x && w && y && dy && dx && dw && db && B > 0 && K > 0 && D > 0, "bitwise_hash_backward: bad arguments");
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(bithash_dx_kernel, dim3((B * K + 3) / 4), dim3(256), 0, st, w, y, dy, dx, B * K, K, D);
+  hipLaunchKernelGGL(bithash_dw_kernel, dim3(K), dim3(256), 0, st, x, y, dy, dw, db, B, K, D);
+  CMH_CHECK_LAUNCH("bitwise_hash_backward");
   return CMH_OK;
 }

@@ -106,6 +106,19 @@ class ResidualMLPs(nn.Module):
             x = M.gemm(u, self.mlps[i][3].weight, self.mlps[i][3].bias, residual=x, dtype=dt)
         return x.reshape(shape)
 
+    def forward_train(self, x):
+        """The same layers through autograd Functions (mith_train_ops.py); x [R, D]."""
+        import mith_train_ops as T
+        from backward_ops import LayerNormFn
+        if self.activation != 'gelu':
+            raise NotImplementedError("MITH training: only the reference's default activation 'gelu' has a backward")
+        dt = getattr(self, "_gemm_dt", N.F32)
+        for i in range(self.num_layers):
+            h = LayerNormFn.apply(x, self.lns[i].weight, self.lns[i].bias)
+            u = T.GeluFn.apply(T.GemmLinear.apply(h, self.mlps[i][0].weight, self.mlps[i][0].bias, dt))
+            x = x + T.GemmLinear.apply(u, self.mlps[i][3].weight, self.mlps[i][3].bias, dt)
+        return x
+
 
 class PositionalEncoding(nn.Module):
     def __init__(self, d_model, dropout=0., max_len=128):
@@ -149,6 +162,14 @@ class GlobalConceptLearning(nn.Module):
         c = N.linear_act(flat, self.common_concept_embedding.weight, None, N.ACT_TANH)
         return x, c.reshape(*x.shape[:-1], -1)
 
+    def forward_train(self, x):
+        """x [R, D] with gradients: (residual-MLP features, tanh concept logits)."""
+        from backward_ops import LinearAct
+        x = self.mlp.forward_train(N.f32c(x)) if isinstance(self.mlp, ResidualMLPs) else x
+        w = self.common_concept_embedding.weight
+        c = LinearAct.apply(x, w, torch.zeros(w.shape[0], device=w.device), N.ACT_TANH, None, 0.0)
+        return x, c
+
 
 class LocalizedTokenAggregation(nn.Module):
     def __init__(self, top_k):
@@ -177,6 +198,21 @@ class LocalConceptTransforming(nn.Module):
         del keep
         return self.hashing(y), y
 
+    def forward_train(self, tokens_bm, sim_bm, l0, L, key_padding_mask=None):
+        """Same outputs with gradients w.r.t. the tokens and every parameter (the similarities stay detached, as upstream)."""
+        import mith_train_ops as T
+        x = T.LtaFn.apply(tokens_bm, sim_bm.detach(), key_padding_mask, l0, L, self.lta.top_k)
+        x = T.AddPosFn.apply(x, self.position.pe[:x.shape[1], 0, :])
+        Nb, K, D = x.shape
+        keep = []
+        dt = getattr(self, "_gemm_dt", N.F32)
+        arr = _fill_blocks(self.transformer.resblocks, dt, keep)
+        params = T.blocks_params(self.transformer.resblocks)
+        y = T.BlocksTrain.apply(x.reshape(Nb * K, D), Nb, K, dt, arr, keep, *params).reshape(Nb, K, D)
+        w = torch.cat([l.weight for l in self.hashing.fc_list], 0)
+        b = torch.cat([l.bias for l in self.hashing.fc_list], 0)
+        return T.BitHashFn.apply(y, w, b), y
+
 
 class HashingModel(nn.Module):
     def __init__(self, clip_embed_dim=512, args=None):
@@ -199,8 +235,10 @@ class HashingModel(nn.Module):
 
     def forward(self, img_tokens, txt_tokens, img_cls, txt_eos, key_padding_mask):
         """Reference layouts in (img_tokens [49,N,D], txt_tokens [L,N,D]) and out (trans_tokens_* [K,N,D])."""
+        if torch.is_grad_enabled() and (img_tokens.requires_grad or self.img_concept_proj.weight.requires_grad):
+            return self._forward_train(img_tokens, txt_tokens, img_cls, txt_eos, key_padding_mask)
         out = {}
-        nb = lambda t: no_backward(t, self.img_concept_proj.weight)
+        nb = lambda t: t
         res_img_cls, img_cls_hash = self.gcl_i(img_cls)
         res_txt_cls, txt_cls_hash = self.gcl_t(txt_eos)
         out['img_cls_hash'], out['txt_cls_hash'] = nb(img_cls_hash), nb(txt_cls_hash)
@@ -219,6 +257,30 @@ class HashingModel(nn.Module):
         pt = M.gemm(trans_t.reshape(Nb * K, D), self.txt_concept_proj.weight, self.txt_concept_proj.bias, dtype=dt)
         out['trans_tokens_i'] = nb(M.l2_normalize_rows(pi).reshape(Nb, K, D).permute(1, 0, 2))
         out['trans_tokens_t'] = nb(M.l2_normalize_rows(pt).reshape(Nb, K, D).permute(1, 0, 2))
+        return out
+
+
+    def _forward_train(self, img_tokens, txt_tokens, img_cls, txt_eos, key_padding_mask):
+        """forward() through autograd Functions; layouts as in forward()."""
+        import mith_train_ops as T
+        out = {}
+        res_img_cls, out['img_cls_hash'] = self.gcl_i.forward_train(img_cls)
+        res_txt_cls, out['txt_cls_hash'] = self.gcl_t.forward_train(txt_eos)
+        out['res_img_cls'] = T.L2NormFn.apply(res_img_cls)
+        out['res_txt_cls'] = T.L2NormFn.apply(res_txt_cls)
+        it = img_tokens.permute(1, 0, 2).contiguous()
+        tt = txt_tokens.permute(1, 0, 2).contiguous()
+        with torch.no_grad():                                        # gcl(tokens)[1].detach() upstream (:441-442)
+            sim_i = self.gcl_i(it)[1]
+            sim_t = self.gcl_t(tt)[1]
+        out['img_tokens_hash'], trans_i = self.lct_i.forward_train(it, sim_i, 0, it.shape[1], None)
+        out['txt_tokens_hash'], trans_t = self.lct_t.forward_train(tt, sim_t, 0, tt.shape[1], key_padding_mask)
+        Nb, K, D = trans_i.shape
+        dt = getattr(self, "_gemm_dt", N.F32)
+        pi = T.GemmLinear.apply(trans_i.reshape(Nb * K, D), self.img_concept_proj.weight, self.img_concept_proj.bias, dt)
+        pt = T.GemmLinear.apply(trans_t.reshape(Nb * K, D), self.txt_concept_proj.weight, self.txt_concept_proj.bias, dt)
+        out['trans_tokens_i'] = T.L2NormFn.apply(pi).reshape(Nb, K, D).permute(1, 0, 2)
+        out['trans_tokens_t'] = T.L2NormFn.apply(pt).reshape(Nb, K, D).permute(1, 0, 2)
         return out
 
 

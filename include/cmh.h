@@ -505,6 +505,24 @@ int cmh_text_backward_tokens(const cmh_text_weights* w, const int64_t* tokens, i
                              const uint8_t* key_padding_mask, const float* dtokens, const cmh_text_grads* grads, void* tape,
                              size_t tape_bytes, void* stream);
 
+/* ---- MITH HashingModel under training (model/MITH.py:217-453) -------------------------------------------------------------
+ * A bare stack of ResidualAttentionBlocks (the concept transformer, :379-396) with a tape: x / y / dy / dx f32 [B*T, d]. */
+size_t cmh_blocks_train_bytes(int32_t dtype, int32_t B, int32_t T, int32_t d, int32_t layers);
+int cmh_blocks_forward_train(const cmh_block_weights* blocks, int32_t layers, int32_t dtype, const float* x, float* y, int32_t B,
+                             int32_t T, int32_t d, void* tape, size_t tape_bytes, void* stream);
+int cmh_blocks_backward(const cmh_block_weights* blocks, const cmh_block_grads* grads, int32_t layers, int32_t dtype,
+                        const float* dy, float* dx, int32_t B, int32_t T, int32_t d, void* tape, size_t tape_bytes, void* stream);
+/* Gradient of cmh_mith_lta w.r.t. the tokens (the similarities are detached upstream, :345): dtokens f32 [B, Ltot, D]. */
+int cmh_mith_lta_backward(const float* sim, const uint8_t* key_padding_mask, const float* dmerge, float* dtokens, int32_t B,
+                          int32_t Ltot, int32_t l0, int32_t L, int32_t K, int32_t D, int32_t top_k, void* stream);
+/* nn.GELU() (exact, erf) and its backward, element-wise f32 (the ResidualMLPs' activation, :224-233). */
+int cmh_gelu(const float* x, float* y, int64_t n, void* stream);
+int cmh_gelu_backward(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+/* Backward of cmh_l2_normalize_rows (F.normalize, eps 1e-12) and of cmh_bitwise_hash (x [B,K,D], w [K,D], y = the forward output). */
+int cmh_l2_normalize_backward(const float* x, const float* dy, float* dx, int32_t R, int32_t D, void* stream);
+int cmh_bitwise_hash_backward(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw, float* db,
+                              int32_t B, int32_t K, int32_t D, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

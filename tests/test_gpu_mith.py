@@ -165,3 +165,45 @@ def test_trunk_token_gradients_match_reference_autograd(golden):
         worst = max(worst, err)
         assert err < 1e-3, (name, err)
     print(f"MITH trunk gradients: worst relative-to-max error {worst:.2e} over {len(g['names'])} tensors")
+
+
+def test_hashing_model_gradients_match_reference_autograd(golden):
+    """HashingModel under training (ResidualMLPs with exact GELU, concept logits, F.normalize, token aggregation with detached
+    similarities, positional encoding, the 2-layer concept transformer, bitwise hashing, concept projections): gradients w.r.t.
+    the four inputs and all 129 parameters of L = sum <output, cotangent> against torch autograd on the REFERENCE's module
+    (tests/golden/make_golden12.py), f32 mode."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden12 as mg
+    from model.MITH import HashingModel
+    g = golden("mith_hash_grads.npz")
+    Nb, L, K = 3, 12, 16
+    tag = f"N{Nb}_L{L}_K{K}"
+    hm = HashingModel(clip_embed_dim=512, args=SimpleNamespace(output_dim=K, **mu.ARGS))
+    st = mu.fill_state({k: tuple(v.shape) for k, v in hm.state_dict().items()}, 100 + K)
+    hm.load_state_dict({k: (torch.from_numpy(st[k]) if k in st else v) for k, v in hm.state_dict().items()})
+    hm = hm.to(DEV).train()
+    c = mu.hash_inputs(Nb, L, K)
+    ins = {k: tt(c[k]).requires_grad_() for k in ("img_tokens", "txt_tokens", "img_cls", "txt_eos")}
+    od = hm(ins["img_tokens"], ins["txt_tokens"], ins["img_cls"], ins["txt_eos"], tt(c["kpm"]))
+    G = mg.cotangents({k: v.detach().cpu() for k, v in od.items()})
+    sum((od[k] * G[k].to(DEV)).sum() for k in mg.KEYS).backward()
+    worst = 0.0
+
+    def check(name, got, key_g, key_n):
+        nonlocal worst
+        assert got is not None, name
+        ref, norm = g[key_g], float(g[key_n])
+        assert abs(float(got.double().norm()) - norm) <= 1e-3 * max(norm, 1e-3), (name, float(got.double().norm()), norm)
+        err = np.abs(mg.cut(got.cpu().numpy()) - ref).max() / max(np.abs(ref).max(), 1e-6)
+        worst = max(worst, err)
+        assert err < 2e-3, (name, err)
+    for k, v in ins.items():
+        check(k, v.grad, f"{tag}_d_{k}", f"{tag}_n_{k}")
+    params = dict(hm.named_parameters())
+    names = [str(n) for n in g[f"{tag}_names"]]
+    assert len(names) == 129
+    for name in names:
+        check(name, params[name].grad, f"{tag}_g_{name}", f"{tag}_n_{name}")
+    print(f"HashingModel gradients: worst relative-to-max error {worst:.2e} over {len(names) + 4} tensors")
