@@ -154,6 +154,10 @@ SIGNATURES = {
     "cmh_gelu_backward": (C.c_int, [_p, _p, _p, C.c_int64, _p]),
     "cmh_l2_normalize_backward": (C.c_int, [_p, _p, _p, _i32, _i32, _p]),
     "cmh_bitwise_hash_backward": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p]),
+    "cmh_mith_bayesian_backward_workspace_bytes": (_sz, [_i32, _i32]),
+    "cmh_mith_bayesian_loss_backward": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _sz, _p]),
+    "cmh_info_nce_backward": (C.c_int, [_p, _p, _i32, _i32, _i32, _f, _p, _p, _p, _p, _sz, _p]),
+    "cmh_sq_diff_sum_backward": (C.c_int, [_p, _p, C.c_int64, _p, _p, _p, _p]),
     "cmh_batchnorm1d_update_running": (C.c_int, [_p, _f, _p, _p, _i32, _i32, _p]),
     "cmh_batchnorm1d_backward": (C.c_int, [_p, _p, _f, _p, _p, _p, _p, _i32, _i32, _p]),
     "cmh_twdh_loss_backward": (C.c_int, [_p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p]),

@@ -258,6 +258,108 @@ __global__ void read_acc_kernel(const double* __restrict__ acc, double scale, fl
   out[0] = static_cast<float>(acc[0] * scale);
 }
 
+// ---- backward of the loss terms (train/MITH/hash_train.py:103-201) ---------------------------------------------------------------
+// bayesian_loss = -mean_{m,b}(ls s - log(1 + e^s)), s = .5 clamp(bank_m . batch_b, +-64):  d/d batch_b = -(1/(Mb B)) sum_m (ls - sigmoid(s))
+// * .5 bank_m where the clamp is inactive.  One workgroup per batch row: coefficients of all bank rows first, then one thread per bit.
+__global__ __launch_bounds__(256) void bayes_bwd_kernel(const float* __restrict__ bank, const float* __restrict__ batch,
+                                                        const float* __restrict__ bank_label, const float* __restrict__ label, int Mb,
+                                                        int B, int K, int C, const float* __restrict__ dloss, float* __restrict__ coef,
+                                                        float* __restrict__ dbatch) {
+  const int b = blockIdx.x;
+  float* cf = coef + static_cast<size_t>(b) * Mb;
+  const float g = -(dloss ? dloss[0] : 1.f) * 0.5f / (static_cast<float>(Mb) * static_cast<float>(B));
+  for (int m = threadIdx.x; m < Mb; m += 256) {
+    float dot = 0.f;
+    for (int k = 0; k < K; ++k) dot = fmaf(bank[static_cast<size_t>(m) * K + k], batch[static_cast<size_t>(b) * K + k], dot);
+    float ll = 0.f;
+    for (int c = 0; c < C; ++c) ll = fmaf(bank_label[static_cast<size_t>(m) * C + c], label[static_cast<size_t>(b) * C + c], ll);
+    const float s = 0.5f * fminf(fmaxf(dot, -64.f), 64.f);
+    const float sig = 1.0f / (1.0f + expf(-s));
+    cf[m] = (dot >= -64.f && dot <= 64.f) ? g * ((ll > 0.f ? 1.f : 0.f) - sig) : 0.f;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += 256) {
+    float acc = 0.f;
+    for (int m = 0; m < Mb; ++m) acc = fmaf(cf[m], bank[static_cast<size_t>(m) * K + k], acc);
+    dbatch[static_cast<size_t>(b) * K + k] = acc;
+  }
+}
+
+// InfoNCE: logsumexp of every row of a against its group of b rows (the forward's row_ce_kernel, keeping the value per row)
+__global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ a, const float* __restrict__ b, int R, int G, int D,
+                                                      float inv_temp, float* __restrict__ lse) {
+  extern __shared__ float sa[];   // 4 waves x D
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + wid;
+  if (i >= R) return;
+  const int g0 = (i / G) * G;
+  float* ar = sa + wid * D;
+  for (int d = lane; d < D; d += 64) ar[d] = a[static_cast<size_t>(i) * D + d];
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  float mx = -1e30f;
+  for (int j = lane; j < G; j += 64) {
+    const float* br = b + static_cast<size_t>(g0 + j) * D;
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) s = fmaf(ar[d], br[d], s);
+    mx = fmaxf(mx, s * inv_temp);
+  }
+  mx = m_wave_max(mx);
+  float se = 0.f;
+  for (int j = lane; j < G; j += 64) {
+    const float* br = b + static_cast<size_t>(g0 + j) * D;
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) s = fmaf(ar[d], br[d], s);
+    se += expf(s * inv_temp - mx);
+  }
+  se = m_wave_sum(se);
+  if (lane == 0) lse[i] = mx + logf(se);
+}
+// d/dx_i of 0.5/R [sum_i CE(x_i . y / T) + sum_i CE(y_i . x / T)] (diagonal targets inside the group):
+//   dx_i = scale [ sum_j (exp(s_ij - lse_x[i]) + exp(s_ij - lse_y[j])) y_j - 2 y_i ],  s_ij = x_i . y_j / T,  scale = g * 0.5 / (R T)
+// lse_x[i] = logsumexp_j s_ij, lse_y[j] = logsumexp_i s_ij (rows of y against x).  One wave per row, weights through LDS.
+__global__ __launch_bounds__(256) void info_nce_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ lse_x, const float* __restrict__ lse_y, int R,
+                                                           int G, int D, float inv_temp, const float* __restrict__ dloss,
+                                                           float* __restrict__ dx) {
+  extern __shared__ float sm[];   // 4 waves x (D + G)
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + wid;
+  if (i >= R) return;
+  const int g0 = (i / G) * G;
+  float* xr = sm + wid * (D + G);
+  float* wj = xr + D;
+  for (int d = lane; d < D; d += 64) xr[d] = x[static_cast<size_t>(i) * D + d];
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  const float li = lse_x[i];
+  for (int j = lane; j < G; j += 64) {
+    const float* yr = y + static_cast<size_t>(g0 + j) * D;
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) s = fmaf(xr[d], yr[d], s);
+    s *= inv_temp;
+    wj[j] = expf(s - li) + expf(s - lse_y[g0 + j]) - (g0 + j == i ? 2.f : 0.f);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  const float scale = (dloss ? dloss[0] : 1.f) * 0.5f * inv_temp / static_cast<float>(R);
+  for (int d = lane; d < D; d += 64) {
+    float acc = 0.f;
+    for (int j = 0; j < G; ++j) acc = fmaf(wj[j], y[static_cast<size_t>(g0 + j) * D + d], acc);
+    dx[static_cast<size_t>(i) * D + d] = acc * scale;
+  }
+}
+
+// sum (a - b)^2: da = 2 g (a - b), db = -da (either may be NULL)
+__global__ __launch_bounds__(256) void sq_diff_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+                                                          const float* __restrict__ dloss, float* __restrict__ da, float* __restrict__ db) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = 2.f * (dloss ? dloss[0] : 1.f) * (a[i] - b[i]);
+  if (da) da[i] = v;
+  if (db) db[i] = -v;
+}
+
 // ---- backward pieces of the HashingModel (the similarities that steer the aggregation are detached upstream, model/MITH.py:345,
 // so the aggregation is linear in the tokens) ------------------------------------------------------------------------------------
 // dtokens[b, l0 + l, :] = sum_k w[l, k] * dmerge[b, k, :]; grid (B, ceil(D / 256))
@@ -481,5 +583,47 @@ extern "C" int cmh_bitwise_hash_backward(const float* x, const float* w, const f
   hipLaunchKernelGGL(bithash_dx_kernel, dim3((B * K + 3) / 4), dim3(256), 0, st, w, y, dy, dx, B * K, K, D);
   hipLaunchKernelGGL(bithash_dw_kernel, dim3(K), dim3(256), 0, st, x, y, dy, dw, db, B, K, D);
   CMH_CHECK_LAUNCH("bitwise_hash_backward");
+  return CMH_OK;
+}
+
+extern "C" size_t cmh_mith_bayesian_backward_workspace_bytes(int32_t Mb, int32_t B) {
+  return Mb > 0 && B > 0 ? static_cast<size_t>(Mb) * B * 4 + 256 : 0;
+}
+
+extern "C" int cmh_mith_bayesian_loss_backward(const float* bank, const float* batch, const float* bank_label, const float* label,
+                                               int32_t Mb, int32_t B, int32_t K, int32_t C, const float* dloss, float* dbatch,
+                                               void* workspace, size_t workspace_bytes, void* stream) {
+  CMH_CHECK_ARG(bank && batch && bank_label && label && dbatch && workspace, "mith_bayesian_loss_backward: null pointer");
+  CMH_CHECK_ARG(Mb > 0 && B > 0 && K > 0 && C > 0, "mith_bayesian_loss_backward: bad shape");
+  if (workspace_bytes < cmh_mith_bayesian_backward_workspace_bytes(Mb, B)) return fail(CMH_ERR_WORKSPACE, "mith_bayesian_loss_backward: workspace too small");
+  float* coef = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+  hipLaunchKernelGGL(bayes_bwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), bank, batch, bank_label, label, Mb, B, K, C, dloss, coef, dbatch);
+  CMH_CHECK_LAUNCH("mith_bayesian_loss_backward");
+  return CMH_OK;
+}
+
+extern "C" int cmh_info_nce_backward(const float* a, const float* b, int32_t R, int32_t G, int32_t D, float temperature,
+                                     const float* dloss, float* da, float* db, void* workspace, size_t workspace_bytes, void* stream) {
+  CMH_CHECK_ARG(a && b && da && db && workspace, "info_nce_backward: null pointer");
+  CMH_CHECK_ARG(R > 0 && G > 0 && R % G == 0 && D > 0 && temperature > 0.f, "info_nce_backward: bad shape R=%d G=%d D=%d", R, G, D);
+  CMH_CHECK_ARG(static_cast<size_t>(4) * (D + G) * 4 <= 64 * 1024, "info_nce_backward: D + G = %d too large for the LDS rows", D + G);
+  if (workspace_bytes < static_cast<size_t>(2) * R * 4 + 256) return fail(CMH_ERR_WORKSPACE, "info_nce_backward: workspace must hold 2 R floats");
+  float* lse_a = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+  float* lse_b = lse_a + R;
+  hipStream_t st = as_stream(stream);
+  const float it = 1.0f / temperature;
+  const dim3 grid((R + 3) / 4);
+  hipLaunchKernelGGL(row_lse_kernel, grid, dim3(256), static_cast<size_t>(4) * D * 4, st, a, b, R, G, D, it, lse_a);
+  hipLaunchKernelGGL(row_lse_kernel, grid, dim3(256), static_cast<size_t>(4) * D * 4, st, b, a, R, G, D, it, lse_b);
+  hipLaunchKernelGGL(info_nce_bwd_kernel, grid, dim3(256), static_cast<size_t>(4) * (D + G) * 4, st, a, b, lse_a, lse_b, R, G, D, it, dloss, da);
+  hipLaunchKernelGGL(info_nce_bwd_kernel, grid, dim3(256), static_cast<size_t>(4) * (D + G) * 4, st, b, a, lse_b, lse_a, R, G, D, it, dloss, db);
+  CMH_CHECK_LAUNCH("info_nce_backward");
+  return CMH_OK;
+}
+
+extern "C" int cmh_sq_diff_sum_backward(const float* a, const float* b, int64_t n, const float* dloss, float* da, float* db, void* stream) {
+  CMH_CHECK_ARG(a && b && n > 0 && (da || db), "sq_diff_sum_backward: bad arguments");
+  hipLaunchKernelGGL(sq_diff_bwd_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, as_stream(stream), a, b, n, dloss, da, db);
+  CMH_CHECK_LAUNCH("sq_diff_sum_backward");
   return CMH_OK;
 }

@@ -161,3 +161,72 @@ class BlocksTrain(torch.autograd.Function):
 
 def blocks_params(resblocks):
     return [p for blk in resblocks for p in block_params(blk)]
+
+
+# ---- loss terms (train/MITH/hash_train.py:103-147) ----------------------------------------------------------------------------
+class BayesianLossFn(torch.autograd.Function):
+    """bayesian_loss(bank, batch, label_sim): the bank holds detached codes, so only the batch codes receive a gradient."""
+
+    @staticmethod
+    def forward(ctx, bank, batch, bank_label, label):
+        bank, batch, bank_label, label = (N.f32c(t) for t in (bank, batch, bank_label, label))
+        ctx.save_for_backward(bank.clone(), batch, bank_label, label)       # the trainer rewrites rows of the bank every step
+        return M.bayesian_loss(bank, batch, bank_label, label).clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        bank, batch, bank_label, label = ctx.saved_tensors
+        Mb, K = bank.shape
+        Bn, Cn = label.shape
+        db = torch.empty_like(batch)
+        g = N.f32c(g).reshape(1)
+        ws = N.workspace(N.lib().cmh_mith_bayesian_backward_workspace_bytes(Mb, Bn), bank.device, "bayes")
+        N.check(N.lib().cmh_mith_bayesian_loss_backward(N.ptr(bank), N.ptr(batch), N.ptr(bank_label), N.ptr(label), Mb, Bn, K, Cn, N.ptr(g),
+                                                        N.ptr(db), N.ptr(ws), ws.numel(), N.stream_ptr(bank.device)),
+                "cmh_mith_bayesian_loss_backward")
+        return None, db, None, None
+
+
+class InfoNceFn(torch.autograd.Function):
+    """Symmetric InfoNCE with diagonal targets inside groups of `group` consecutive rows (info_nce_loss / info_nce_loss_bmm)."""
+
+    @staticmethod
+    def forward(ctx, a, b, group, temperature):
+        a, b = N.f32c(a), N.f32c(b)
+        ctx.save_for_backward(a, b)
+        ctx.group, ctx.temperature = group, float(temperature)
+        return M.info_nce(a, b, group, temperature).clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        D = a.shape[-1]
+        R = a.numel() // D
+        G = R if ctx.group is None else ctx.group
+        da, db = torch.empty_like(a), torch.empty_like(b)
+        g = N.f32c(g).reshape(1)
+        ws = N.workspace(2 * R * 4 + 512, a.device, "nce")
+        N.check(N.lib().cmh_info_nce_backward(N.ptr(a), N.ptr(b), R, G, D, ctx.temperature, N.ptr(g), N.ptr(da), N.ptr(db), N.ptr(ws),
+                                              ws.numel(), N.stream_ptr(a.device)), "cmh_info_nce_backward")
+        return da, db, None, None
+
+
+class SqDiffSumFn(torch.autograd.Function):
+    """F.mse_loss(a, b, reduction='sum')."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = N.f32c(a), N.f32c(b)
+        ctx.save_for_backward(a, b)
+        return M.sq_diff_sum(a, b).clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        need_a, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        da = torch.empty_like(a) if need_a else None
+        db = torch.empty_like(b) if need_b else None
+        g = N.f32c(g).reshape(1)
+        N.check(N.lib().cmh_sq_diff_sum_backward(N.ptr(a), N.ptr(b), a.numel(), N.ptr(g), N.ptr(da), N.ptr(db), N.stream_ptr(a.device)),
+                "cmh_sq_diff_sum_backward")
+        return da, db

@@ -1,15 +1,16 @@
 """MITH trainer (reference train/MITH/hash_train.py; paper: Multi-Granularity Interactive Transformer Hashing, ACM MM 2023).
-Forward (token-returning trunk + HashingModel), the memory-bank update, all five loss groups and validation run on libcmh;
-backward/optimiser are the next scope row.  Under data parallelism the bank update needs every rank's (index, codes):
+Forward (token-returning trunk + HashingModel), the memory-bank update, all five loss groups, their backward through the
+HashingModel and both towers, the fused BertAdam step and validation run on libcmh.  Under data parallelism the bank update needs every rank's (index, codes):
 dist_utils.all_gather_rows + scatter_by_index."""
 import os
 
 import torch
 
 import cmh_native as N
+import dist_utils as du
 import mith_ops as M
 from model.MITH import MITH
-from model.base.model import no_backward
+from model.base.optimization import BertAdam
 from train.base import TrainBase
 from .get_args import get_args
 
@@ -31,7 +32,12 @@ class MITHTrainer(TrainBase):
         self.model.float()
         self.model.clip.set_gemm_dtype(self.args.gemm_dtype)
         self.model.hash.set_gemm_dtype(self.args.gemm_dtype)
-        self.optimizer = None
+        # reference train/MITH/hash_train.py:36-42: the trunk at clip_lr, the HashingModel at lr
+        self.optimizer = BertAdam([
+            {"params": self.model.clip.parameters(), "lr": self.args.clip_lr},
+            {"params": self.model.hash.parameters(), "lr": self.args.lr}],
+            lr=self.args.lr, warmup=self.args.warmup_proportion, schedule="warmup_cosine", b1=0.9, b2=0.98, e=1e-6,
+            t_total=len(self.train_loader) * self.args.epochs, weight_decay=self.args.weight_decay, max_grad_norm=1.0)
         self.k_bits = self.args.output_dim
         n = len(self.train_loader.dataset)
         mk = lambda: torch.randn(n, self.k_bits).to(self.rank, non_blocking=True)
@@ -42,20 +48,39 @@ class MITHTrainer(TrainBase):
         self.model.train() if mode == "train" else self.model.eval()
 
     # ---- reference loss helpers (:103-147), each ONE native call ---------------------------------------
+    @staticmethod
+    def _grad(*ts):
+        return torch.is_grad_enabled() and any(t.requires_grad for t in ts)
+
     def info_nce_loss(self, out_1, out_2, temperature=0.07):
+        if self._grad(out_1, out_2):
+            from mith_train_ops import InfoNceFn
+            return InfoNceFn.apply(out_1, out_2, None, temperature)
         return M.info_nce(out_1, out_2, None, temperature)
 
     def info_nce_loss_bmm(self, out_1, out_2, temperature=0.07):
         a = out_1.permute(1, 0, 2).contiguous()            # [K,N,D] -> [N,K,D]
         b = out_2.permute(1, 0, 2).contiguous()
+        if self._grad(a, b):
+            from mith_train_ops import InfoNceFn
+            return InfoNceFn.apply(a, b, a.shape[1], temperature)
         return M.info_nce(a, b, a.shape[1], temperature)
 
     def bayesian_loss(self, a, b, label_pair):
         """label_pair = (bank_labels [M,C], batch_labels [B,C]); the [M,B] label_sim is formed inside the kernel."""
+        if self._grad(b):
+            from mith_train_ops import BayesianLossFn
+            return BayesianLossFn.apply(a, b, label_pair[0], label_pair[1])
         return M.bayesian_loss(a, b, label_pair[0], label_pair[1])
 
+    def sq_diff(self, x, y):
+        if self._grad(x, y):
+            from mith_train_ops import SqDiffSumFn
+            return SqDiffSumFn.apply(x, y)
+        return M.sq_diff_sum(x, y)
+
     def quantization_loss_2(self, hash_feature, B):
-        return M.sq_diff_sum(hash_feature, B) / (hash_feature.shape[0]) / self.k_bits
+        return self.sq_diff(hash_feature, B) / (hash_feature.shape[0]) / self.k_bits
 
     def make_B(self, output_dict):
         ic, it = output_dict['img_cls_hash'].detach(), output_dict['img_tokens_hash'].detach()
@@ -70,6 +95,8 @@ class MITHTrainer(TrainBase):
         Bc, H_i, H_t = mixes if mixes is not None else self.make_B(output_dict)
         if B is not None:
             Bc = B
+        if self._grad(ic, it, tc, tt):                     # the hash features that carry gradients (:179-180)
+            H_i, H_t = ic * 0.5 + it * 0.5, tc * 0.5 + tt * 0.5
         L = {}
         L['tokens_intra_likelihood'] = a.hyper_tokens_intra * (self.bayesian_loss(self.img_buffer_tokens, it, pair) +
                                                                self.bayesian_loss(self.txt_buffer_tokens, tt, pair))
@@ -79,9 +106,11 @@ class MITHTrainer(TrainBase):
         L['infoNCE'] = a.hyper_info_nce * (self.info_nce_loss(output_dict['res_img_cls'], output_dict['res_txt_cls']) +
                                            a.hyper_alpha * self.info_nce_loss_bmm(output_dict['trans_tokens_i'],
                                                                                   output_dict['trans_tokens_t']))
-        item = M.sq_diff_sum(ic, it) + M.sq_diff_sum(tc, tt)       # value of item_1; item_2 = 0.1 * the same value
-        L['distillation'] = a.hyper_distill * (item + 0.1 * item) / ic.shape[0]
-        return {k: no_backward(v, self.model.hash.img_concept_proj.weight) for k, v in L.items()}
+        # item_1: full gradient to the student (token codes), item_2: a tenth of it to the teacher (cls codes)  (:193-200)
+        item_1 = self.sq_diff(ic.detach(), it) + self.sq_diff(tc.detach(), tt)
+        item_2 = 0.1 * (self.sq_diff(ic, it.detach()) + self.sq_diff(tc, tt.detach()))
+        L['distillation'] = a.hyper_distill * (item_1 + item_2) / ic.shape[0]
+        return L
 
     def train_epoch(self, epoch):
         self.change_state(mode="train")
@@ -99,7 +128,11 @@ class MITHTrainer(TrainBase):
             self.txt_buffer_tokens[index] = output_dict['txt_tokens_hash'].detach()
             losses = self.compute_loss(output_dict, label)
             loss = sum(losses.values())
-            loss.backward()      # raises NotImplementedError: backward kernels are the next scope row
+            self.optimizer.zero_grad()
+            loss.backward()
+            if du.world_size() > 1:
+                du.allreduce_mean_([p.grad for p in self.model.parameters() if p.grad is not None])
+            self.optimizer.step()
 
     def get_code_MITH(self, data_loader, length: int):
         img_buffer = torch.empty(length, self.args.output_dim, dtype=torch.float).to(self.rank)

@@ -68,8 +68,9 @@ def test_losses_match_reference(golden, Nb, K, C, Mb):
                            img_buffer_tokens=tt(banks["img_tokens"]), img_buffer_cls=tt(banks["img_cls"]),
                            txt_buffer_tokens=tt(banks["txt_tokens"]), txt_buffer_cls=tt(banks["txt_cls"]),
                            model=SimpleNamespace(hash=SimpleNamespace(img_concept_proj=SimpleNamespace(weight=torch.zeros(1)))))
-    for name in ("bayesian_loss", "info_nce_loss", "info_nce_loss_bmm", "quantization_loss_2", "make_B"):
+    for name in ("bayesian_loss", "info_nce_loss", "info_nce_loss_bmm", "quantization_loss_2", "make_B", "sq_diff"):
         setattr(self, name, (lambda n: (lambda *a, **k: getattr(MITHTrainer, n)(self, *a, **k)))(name))
+    self._grad = MITHTrainer._grad
     tod = {k: tt(v) for k, v in od.items()}
     with torch.no_grad():
         Bc, _, _ = self.make_B(tod)
@@ -98,8 +99,20 @@ def test_mith_trainer_end_to_end(tmp_path, monkeypatch):
         losses = tr.compute_loss(od, label)
     assert set(losses) == {"tokens_intra_likelihood", "cls_inter_likelihood", "quantization", "infoNCE", "distillation"}
     assert all(torch.isfinite(v).item() for v in losses.values())
-    with pytest.raises(NotImplementedError):
-        tr.train_epoch(0)
+    # two real epochs: token-returning trunk with tape -> HashingModel -> memory banks -> five loss groups -> backward through the
+    # HashingModel and both towers -> fused BertAdam
+    for grp in tr.optimizer.param_groups:
+        grp["t_total"] = 8
+    before = {n: p.detach().clone() for n, p in tr.model.named_parameters()}
+    banks0 = tr.img_buffer_cls.clone()
+    tr.train_epoch(0)
+    tr.train_epoch(1)
+    same = {n for n, p in tr.model.named_parameters() if torch.equal(p.detach(), before[n])}
+    assert same <= {"clip.logit_scale"}, sorted(same)[:8]
+    assert all(torch.isfinite(p).all() for p in tr.model.parameters())
+    assert not torch.equal(banks0, tr.img_buffer_cls)                 # the memory banks took this epoch's codes
+    maps = tr.valid(1)
+    assert all(0.0 <= float(m) <= 1.0 for m in maps)
 
 
 def test_hashing_model_bf16_gemms_track_f32():
@@ -207,3 +220,29 @@ def test_hashing_model_gradients_match_reference_autograd(golden):
     for name in names:
         check(name, params[name].grad, f"{tag}_g_{name}", f"{tag}_n_{name}")
     print(f"HashingModel gradients: worst relative-to-max error {worst:.2e} over {len(names) + 4} tensors")
+
+
+@pytest.mark.parametrize("Nb,K,C,Mb", [(8, 16, 24, 50), (16, 64, 80, 200)])
+def test_loss_gradients_match_reference_autograd(golden, Nb, K, C, Mb):
+    """The summed MITH step loss (bayesian x4 against the memory banks, quantisation, InfoNCE on cls and on concept tokens,
+    distillation with its detach pattern) differentiated on the GPU w.r.t. the eight HashingModel outputs, against torch
+    autograd on the REFERENCE's compute_loss (tests/golden/make_golden13.py)."""
+    from train.MITH.hash_train import MITHTrainer
+    g = golden("mith_loss_grads.npz")
+    tag = f"loss_N{Nb}_K{K}"
+    od, banks, label, train_labels = mu.loss_inputs(Nb, K, C, Mb)
+    self = SimpleNamespace(args=SimpleNamespace(**mu.HP), rank=0, k_bits=K, train_labels=tt(train_labels),
+                           img_buffer_tokens=tt(banks["img_tokens"]), img_buffer_cls=tt(banks["img_cls"]),
+                           txt_buffer_tokens=tt(banks["txt_tokens"]), txt_buffer_cls=tt(banks["txt_cls"]))
+    for name in ("bayesian_loss", "info_nce_loss", "info_nce_loss_bmm", "quantization_loss_2", "make_B", "sq_diff", "_grad"):
+        setattr(self, name, (lambda n: (lambda *a, **k: getattr(MITHTrainer, n)(self, *a, **k)))(name) if name != "_grad" else MITHTrainer._grad)
+    tod = {k: tt(v).requires_grad_() for k, v in od.items()}
+    L = MITHTrainer.compute_loss(self, tod, tt(label))
+    total = sum(L.values())
+    assert abs(float(total.detach()) - float(g[f"{tag}_total"])) < 1e-4 * max(1.0, abs(float(g[f"{tag}_total"])))
+    total.backward()
+    for k, v in tod.items():
+        want, got = g[f"{tag}_d_{k}"], v.grad.cpu().numpy()
+        if k.startswith("trans_tokens"):
+            got = got[::4, :, ::4]
+        np.testing.assert_allclose(got, want, rtol=1e-3, atol=2e-5 * max(np.abs(want).max(), 1e-30), err_msg=k)
