@@ -198,24 +198,40 @@ __global__ __launch_bounds__(256) void sq_diff_kernel(const float* __restrict__ 
 }
 
 // bayesian_loss(bank, batch, label_sim) partial: acc += sum_{m,b} (ls*s - log(1+e^s)), s = .5*clamp(bank_m.batch_b, +-64),
-// ls = (bank_label_m . label_b > 0).  One thread per (m,b).
+// ls = (bank_label_m . label_b > 0).  grid (B, 16 bank slices): a wave takes four bank rows at a time, lanes across the bits /
+// the classes (coalesced rows, wave reductions); the value of every (m, b) pair is formed exactly as a per-pair loop would.
 __global__ __launch_bounds__(256) void bayes_kernel(const float* __restrict__ bank, const float* __restrict__ batch,
                                                     const float* __restrict__ bank_label, const float* __restrict__ label,
                                                     int Mb, int B, int K, int C, double* __restrict__ acc) {
   __shared__ double sh[4];
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int b = blockIdx.x, sl = blockIdx.y, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int per_slice = (Mb + gridDim.y - 1) / gridDim.y;
+  const int s0 = sl * per_slice, s1 = s0 + per_slice < Mb ? s0 + per_slice : Mb;
+  const int n = s1 > s0 ? s1 - s0 : 0;
   double v = 0.0;
-  if (i < static_cast<int64_t>(Mb) * B) {
-    const int m = static_cast<int>(i / B), b = static_cast<int>(i - static_cast<int64_t>(m) * B);
-    float dot = 0.f;
-    for (int k = 0; k < K; ++k) dot = fmaf(bank[static_cast<size_t>(m) * K + k], batch[static_cast<size_t>(b) * K + k], dot);
-    float ll = 0.f;
-    for (int c = 0; c < C; ++c) ll = fmaf(bank_label[static_cast<size_t>(m) * C + c], label[static_cast<size_t>(b) * C + c], ll);
-    const float s = 0.5f * fminf(fmaxf(dot, -64.f), 64.f);
-    v = static_cast<double>((ll > 0.f ? s : 0.f) - logf(1.f + expf(s)));
+  for (int mb = wid * 4; mb < n; mb += 16) {
+    float dot[4], ll[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = s0 + (mb + u < n ? mb + u : n - 1);
+      float d = 0.f, l = 0.f;
+      for (int k = lane; k < K; k += 64) d = fmaf(bank[static_cast<size_t>(m) * K + k], batch[static_cast<size_t>(b) * K + k], d);
+      for (int c = lane; c < C; c += 64) l = fmaf(bank_label[static_cast<size_t>(m) * C + c], label[static_cast<size_t>(b) * C + c], l);
+      dot[u] = d; ll[u] = l;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { dot[u] += __shfl_xor(dot[u], o, 64); ll[u] += __shfl_xor(ll[u], o, 64); }
+    if (lane < 4 && mb + lane < n) {
+      const float d = lane == 0 ? dot[0] : (lane == 1 ? dot[1] : (lane == 2 ? dot[2] : dot[3]));
+      const float l = lane == 0 ? ll[0] : (lane == 1 ? ll[1] : (lane == 2 ? ll[2] : ll[3]));
+      const float s = 0.5f * fminf(fmaxf(d, -64.f), 64.f);
+      v += static_cast<double>((l > 0.f ? s : 0.f) - logf(1.f + expf(s)));
+    }
   }
-  const double s = m_block_sum(v, sh);
-  if (threadIdx.x == 0 && s != 0.0) atomicAdd(acc, s);
+  const double t = m_block_sum(v, sh);
+  if (threadIdx.x == 0 && t != 0.0) atomicAdd(acc, t);
 }
 
 // Grouped row cross-entropy with diagonal targets: row i (group g = i / G, index t = i % G) scores a_i . b_j / temp against
@@ -261,28 +277,73 @@ __global__ void read_acc_kernel(const double* __restrict__ acc, double scale, fl
 // ---- backward of the loss terms (train/MITH/hash_train.py:103-201) ---------------------------------------------------------------
 // bayesian_loss = -mean_{m,b}(ls s - log(1 + e^s)), s = .5 clamp(bank_m . batch_b, +-64):  d/d batch_b = -(1/(Mb B)) sum_m (ls - sigmoid(s))
 // * .5 bank_m where the clamp is inactive.  One workgroup per batch row: coefficients of all bank rows first, then one thread per bit.
+constexpr int kBayesSlices = 16;      // bank slices per batch row: 16 x B workgroups keep the chip busy at B = 128
+constexpr int kBayesMaxRows = 4096;   // bank rows per slice held in LDS
+
 __global__ __launch_bounds__(256) void bayes_bwd_kernel(const float* __restrict__ bank, const float* __restrict__ batch,
                                                         const float* __restrict__ bank_label, const float* __restrict__ label, int Mb,
-                                                        int B, int K, int C, const float* __restrict__ dloss, float* __restrict__ coef,
-                                                        float* __restrict__ dbatch) {
-  const int b = blockIdx.x;
-  float* cf = coef + static_cast<size_t>(b) * Mb;
+                                                        int B, int K, int C, const float* __restrict__ dloss, float* __restrict__ partial) {
+  __shared__ float cf[kBayesMaxRows];
+  __shared__ float red[4][128];
+  const int b = blockIdx.x, sl = blockIdx.y, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int per_slice = (Mb + kBayesSlices - 1) / kBayesSlices;
+  const int s0 = sl * per_slice, s1 = s0 + per_slice < Mb ? s0 + per_slice : Mb;
+  const int n = s1 > s0 ? s1 - s0 : 0;
   const float g = -(dloss ? dloss[0] : 1.f) * 0.5f / (static_cast<float>(Mb) * static_cast<float>(B));
-  for (int m = threadIdx.x; m < Mb; m += 256) {
-    float dot = 0.f;
-    for (int k = 0; k < K; ++k) dot = fmaf(bank[static_cast<size_t>(m) * K + k], batch[static_cast<size_t>(b) * K + k], dot);
-    float ll = 0.f;
-    for (int c = 0; c < C; ++c) ll = fmaf(bank_label[static_cast<size_t>(m) * C + c], label[static_cast<size_t>(b) * C + c], ll);
-    const float s = 0.5f * fminf(fmaxf(dot, -64.f), 64.f);
-    const float sig = 1.0f / (1.0f + expf(-s));
-    cf[m] = (dot >= -64.f && dot <= 64.f) ? g * ((ll > 0.f ? 1.f : 0.f) - sig) : 0.f;
+  // phase A: a wave takes four bank rows at a time (independent load / reduction chains), lanes across the bits / the classes
+  const float bk0 = lane < K ? batch[static_cast<size_t>(b) * K + lane] : 0.f;
+  const float bk1 = lane + 64 < K ? batch[static_cast<size_t>(b) * K + lane + 64] : 0.f;
+  const float lb0 = lane < C ? label[static_cast<size_t>(b) * C + lane] : 0.f;
+  for (int mb = wid * 4; mb < n; mb += 16) {
+    float dot[4], ll[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = s0 + (mb + u < n ? mb + u : n - 1);
+      const float* br = bank + static_cast<size_t>(m) * K;
+      const float* lr = bank_label + static_cast<size_t>(m) * C;
+      float d = lane < K ? br[lane] * bk0 : 0.f;
+      if (lane + 64 < K) d = fmaf(br[lane + 64], bk1, d);
+      float l = lane < C ? lr[lane] * lb0 : 0.f;
+      for (int c = lane + 64; c < C; c += 64) l = fmaf(lr[c], label[static_cast<size_t>(b) * C + c], l);
+      dot[u] = d; ll[u] = l;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { dot[u] += __shfl_xor(dot[u], o, 64); ll[u] += __shfl_xor(ll[u], o, 64); }
+    if (lane < 4 && mb + lane < n) {
+      const float d = lane == 0 ? dot[0] : (lane == 1 ? dot[1] : (lane == 2 ? dot[2] : dot[3]));
+      const float l = lane == 0 ? ll[0] : (lane == 1 ? ll[1] : (lane == 2 ? ll[2] : ll[3]));
+      const float sv = 0.5f * fminf(fmaxf(d, -64.f), 64.f);
+      const float sig = 1.0f / (1.0f + expf(-sv));
+      cf[mb + lane] = (d >= -64.f && d <= 64.f) ? g * ((l > 0.f ? 1.f : 0.f) - sig) : 0.f;
+    }
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < K; k += 256) {
-    float acc = 0.f;
-    for (int m = 0; m < Mb; ++m) acc = fmaf(cf[m], bank[static_cast<size_t>(m) * K + k], acc);
-    dbatch[static_cast<size_t>(b) * K + k] = acc;
+  // phase B: wave w sums its quarter of the slice for every bit (four rows in flight), the partial rows meet in LDS (K <= 128)
+  const int per = (n + 3) / 4, m0 = wid * per, m1 = m0 + per < n ? m0 + per : n;
+  for (int k = lane; k < K; k += 64) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int m = m0;
+    for (; m + 4 <= m1; m += 4) {
+      const float v0 = bank[static_cast<size_t>(s0 + m) * K + k], v1 = bank[static_cast<size_t>(s0 + m + 1) * K + k];
+      const float v2 = bank[static_cast<size_t>(s0 + m + 2) * K + k], v3 = bank[static_cast<size_t>(s0 + m + 3) * K + k];
+      a0 = fmaf(cf[m], v0, a0); a1 = fmaf(cf[m + 1], v1, a1); a2 = fmaf(cf[m + 2], v2, a2); a3 = fmaf(cf[m + 3], v3, a3);
+    }
+    for (; m < m1; ++m) a0 = fmaf(cf[m], bank[static_cast<size_t>(s0 + m) * K + k], a0);
+    red[wid][k] = (a0 + a1) + (a2 + a3);
   }
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += 256)
+    partial[(static_cast<size_t>(sl) * B + b) * K + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+}
+// dbatch[b,k] = sum over the slices, in slice order
+__global__ __launch_bounds__(256) void bayes_bwd_reduce_kernel(const float* __restrict__ partial, int n, float* __restrict__ dbatch) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float acc = 0.f;
+  for (int sl = 0; sl < kBayesSlices; ++sl) acc += partial[static_cast<size_t>(sl) * n + i];
+  dbatch[i] = acc;
 }
 
 // InfoNCE: logsumexp of every row of a against its group of b rows (the forward's row_ce_kernel, keeping the value per row)
@@ -518,8 +579,7 @@ extern "C" int cmh_mith_bayesian_loss(const float* bank, const float* batch, con
   double* acc = static_cast<double*>(workspace);
   if (hipMemsetAsync(acc, 0, 8, st) != hipSuccess) return fail(CMH_ERR_LAUNCH, "mith_bayesian_loss: memset failed");
   const int64_t n = static_cast<int64_t>(Mb) * B;
-  hipLaunchKernelGGL(bayes_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, bank, batch, bank_label,
-                     label, Mb, B, K, C, acc);
+  hipLaunchKernelGGL(bayes_kernel, dim3(B, Mb >= 1024 ? 16 : 1), dim3(256), 0, st, bank, batch, bank_label, label, Mb, B, K, C, acc);
   hipLaunchKernelGGL(read_acc_kernel, dim3(1), dim3(1), 0, st, acc, -1.0 / static_cast<double>(n), out);
   CMH_CHECK_LAUNCH("mith_bayesian_loss");
   return CMH_OK;
@@ -586,18 +646,21 @@ extern "C" int cmh_bitwise_hash_backward(const float* x, const float* w, const f
   return CMH_OK;
 }
 
-extern "C" size_t cmh_mith_bayesian_backward_workspace_bytes(int32_t Mb, int32_t B) {
-  return Mb > 0 && B > 0 ? static_cast<size_t>(Mb) * B * 4 + 256 : 0;
+extern "C" size_t cmh_mith_bayesian_backward_workspace_bytes(int32_t B, int32_t K) {
+  return B > 0 && K > 0 ? static_cast<size_t>(kBayesSlices) * B * K * 4 + 256 : 0;
 }
 
 extern "C" int cmh_mith_bayesian_loss_backward(const float* bank, const float* batch, const float* bank_label, const float* label,
                                                int32_t Mb, int32_t B, int32_t K, int32_t C, const float* dloss, float* dbatch,
                                                void* workspace, size_t workspace_bytes, void* stream) {
   CMH_CHECK_ARG(bank && batch && bank_label && label && dbatch && workspace, "mith_bayesian_loss_backward: null pointer");
-  CMH_CHECK_ARG(Mb > 0 && B > 0 && K > 0 && C > 0, "mith_bayesian_loss_backward: bad shape");
-  if (workspace_bytes < cmh_mith_bayesian_backward_workspace_bytes(Mb, B)) return fail(CMH_ERR_WORKSPACE, "mith_bayesian_loss_backward: workspace too small");
-  float* coef = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
-  hipLaunchKernelGGL(bayes_bwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), bank, batch, bank_label, label, Mb, B, K, C, dloss, coef, dbatch);
+  CMH_CHECK_ARG(Mb > 0 && B > 0 && K > 0 && K <= 128 && C > 0, "mith_bayesian_loss_backward: bad shape (K <= 128)");
+  CMH_CHECK_ARG((Mb + kBayesSlices - 1) / kBayesSlices <= kBayesMaxRows, "mith_bayesian_loss_backward: bank of %d rows is too large", Mb);
+  if (workspace_bytes < cmh_mith_bayesian_backward_workspace_bytes(B, K)) return fail(CMH_ERR_WORKSPACE, "mith_bayesian_loss_backward: workspace too small");
+  float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(bayes_bwd_kernel, dim3(B, kBayesSlices), dim3(256), 0, st, bank, batch, bank_label, label, Mb, B, K, C, dloss, partial);
+  hipLaunchKernelGGL(bayes_bwd_reduce_kernel, dim3((B * K + 255) / 256), dim3(256), 0, st, partial, B * K, dbatch);
   CMH_CHECK_LAUNCH("mith_bayesian_loss_backward");
   return CMH_OK;
 }

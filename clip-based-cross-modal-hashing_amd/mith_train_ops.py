@@ -180,7 +180,7 @@ class BayesianLossFn(torch.autograd.Function):
         Bn, Cn = label.shape
         db = torch.empty_like(batch)
         g = N.f32c(g).reshape(1)
-        ws = N.workspace(N.lib().cmh_mith_bayesian_backward_workspace_bytes(Mb, Bn), bank.device, "bayes")
+        ws = N.workspace(N.lib().cmh_mith_bayesian_backward_workspace_bytes(Bn, K), bank.device, "bayes")
         N.check(N.lib().cmh_mith_bayesian_loss_backward(N.ptr(bank), N.ptr(batch), N.ptr(bank_label), N.ptr(label), Mb, Bn, K, Cn, N.ptr(g),
                                                         N.ptr(db), N.ptr(ws), ws.numel(), N.stream_ptr(bank.device)),
                 "cmh_mith_bayesian_loss_backward")

@@ -526,7 +526,7 @@ int cmh_bitwise_hash_backward(const float* x, const float* w, const float* y, co
 /* Backward of the three MITH loss primitives (train/MITH/hash_train.py:103-147); dloss = device pointer to the upstream scalar
  * gradient (NULL = 1).  Bayesian: gradient w.r.t. the batch codes only (the bank holds detached codes).  InfoNCE: da, db f32
  * [R, D].  Squared difference: da / db f32 [n], either may be NULL. */
-size_t cmh_mith_bayesian_backward_workspace_bytes(int32_t Mb, int32_t B);
+size_t cmh_mith_bayesian_backward_workspace_bytes(int32_t B, int32_t K);
 int cmh_mith_bayesian_loss_backward(const float* bank, const float* batch, const float* bank_label, const float* label, int32_t Mb,
                                     int32_t B, int32_t K, int32_t C, const float* dloss, float* dbatch, void* workspace,
                                     size_t workspace_bytes, void* stream);
