@@ -75,6 +75,16 @@ def all_gather_rows(block: torch.Tensor, counts: list[int] | None = None) -> tor
     return torch.cat([out[r * mx:r * mx + counts[r]] for r in range(world)], dim=0)
 
 
+def row_counts(n_local: int, device) -> list[int] | None:
+    """Rows every rank contributes to a ragged all_gather_rows (the last batch of an epoch may differ between ranks)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return None
+    mine = torch.tensor([n_local], dtype=torch.int64, device=device)
+    every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, mine)
+    return [int(t.item()) for t in every]
+
+
 def gather_query_sharded_ap(ap_local: torch.Tensor, n_query: int) -> torch.Tensor:
     """Per-query APs computed on query shards -> the full [Q] vector in QUERY ORDER on every rank, so the final
     mean is accumulated in the same order as a single-GPU run (the reference sums in query order)."""

@@ -122,10 +122,14 @@ class MITHTrainer(TrainBase):
             key_padding_mask = key_padding_mask.to(self.rank, non_blocking=True)
             output_dict = self.model(image, text, key_padding_mask)
             index = index.to(self.rank)
-            self.img_buffer_cls[index] = output_dict['img_cls_hash'].detach()
-            self.txt_buffer_cls[index] = output_dict['txt_cls_hash'].detach()
-            self.img_buffer_tokens[index] = output_dict['img_tokens_hash'].detach()
-            self.txt_buffer_tokens[index] = output_dict['txt_tokens_hash'].detach()
+            codes = [output_dict[k].detach() for k in ('img_cls_hash', 'txt_cls_hash', 'img_tokens_hash', 'txt_tokens_hash')]
+            if du.world_size() > 1:
+                # every rank's memory bank takes every rank's (index, codes): one fused all-gather per step
+                fused, widths = du.fuse_columns(index.view(-1, 1).float(), *codes)
+                parts = du.split_columns(du.all_gather_rows(fused, du.row_counts(fused.shape[0], fused.device)), widths)
+                index, codes = parts[0].view(-1).long(), parts[1:]
+            for buf, rows in zip((self.img_buffer_cls, self.txt_buffer_cls, self.img_buffer_tokens, self.txt_buffer_tokens), codes):
+                du.scatter_by_index(buf, index, rows)
             losses = self.compute_loss(output_dict, label)
             loss = sum(losses.values())
             self.optimizer.zero_grad()

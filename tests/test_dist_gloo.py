@@ -42,6 +42,7 @@ def _worker(rank, world, port, out_dir):
     ref = torch.zeros(n, K)
     ref[index] = codes_i
     assert torch.equal(buf, ref)
+    assert du.row_counts(hi - lo, "cpu") == counts
     # equal shards take the single-collective path
     eq = du.all_gather_rows(codes_i[rank * 10:(rank + 1) * 10])
     assert torch.equal(eq, codes_i[:20])
