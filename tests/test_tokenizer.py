@@ -102,7 +102,11 @@ def test_random_ascii_agrees_with_the_python_path(mini):
         assert ids[i].tolist() == mini.caption_ids(c, 40), repr(c)
 
 
-@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+_ASAN_SCRIPT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "asan_bpe.sh")
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc") or not os.path.exists(_ASAN_SCRIPT),
+                    reason="hipcc or tools/asan_bpe.sh not available (the script is CPU-only and does not travel to the GPU box)")
 def test_tokenizer_under_address_sanitizer(tmp_path):
     """The host-side C++ of the input pipeline, built with -fsanitize=address,undefined (CPU build: the pool offers no GPU
     sanitizers), fed empty / huge / non-ASCII / NUL-containing / random captions on 1 and 4 threads, leak check on."""
