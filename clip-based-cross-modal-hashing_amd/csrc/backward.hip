@@ -119,6 +119,29 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
   }
 }
 
+// Several (partial, out) pairs in one launch: blockIdx.y names the job (a block of the backward pass queues the final stage of
+// its bias / LayerNorm-parameter gradients — six tiny reductions — and launches them once).
+__global__ __launch_bounds__(256) void colsum_final_multi_kernel(FinalJobs jobs) {
+  __shared__ double red[8][33];
+  const int job = blockIdx.y;
+  const float* __restrict__ partial = jobs.partial[job];
+  const int nb = jobs.slices[job], C = jobs.cols[job];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  if (blockIdx.x * 32 >= C) return;
+  double s = 0.0;
+  if (c < C)
+    for (int b = sl; b < nb; b += 8) s += static_cast<double>(partial[static_cast<size_t>(b) * C + c]);
+  red[sl][cl] = s;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cl];
+    jobs.out[job][c] = static_cast<float>(t);
+  }
+}
+
 // ---- LayerNorm backward ------------------------------------------------------------------------------------------------------
 // y = (x - mean) * rstd * g + b.  With xh = (x - mean) * rstd and a = dy * g:
 //   dx = rstd * (a - mean(a) - xh * mean(a * xh)),  dg = sum_rows dy * xh,  db = sum_rows dy.
@@ -312,7 +335,7 @@ extern "C" size_t cmh_layernorm_backward_workspace_bytes(int32_t M, int32_t d) {
 namespace cmh {
 int launch_layernorm_backward(const void* x, int x_kind, const void* dy, int dy_kind, const float* gamma, const int32_t* row_index,
                               int M, int d, float* dx, int accumulate, float* dgamma, float* dbeta, void* workspace,
-                              size_t workspace_bytes, hipStream_t st, void* dx_bf16) {
+                              size_t workspace_bytes, hipStream_t st, void* dx_bf16, FinalJobs* defer) {
   CMH_CHECK_ARG(x && dy && gamma && dx && dgamma && dbeta && workspace && M > 0, "layernorm_backward: bad arguments");
   CMH_CHECK_ARG(d % 4 == 0 && d <= 1024, "layernorm_backward: d=%d must be a multiple of 4 and <= 1024", d);
   CMH_CHECK_ARG((x_kind == kF32 || x_kind == kF16) && (dy_kind == kF32 || dy_kind == kBF16), "layernorm_backward: bad kinds");
@@ -323,8 +346,23 @@ int launch_layernorm_backward(const void* x, int x_kind, const void* dy, int dy_
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, st, x, x_kind, dy, dy_kind, gamma, dx, accumulate, M, d, pg, pb,
                      row_index, static_cast<bf16_t*>(dx_bf16));
   CMH_CHECK_LAUNCH("layernorm_backward");
+  if (defer && defer->n + 2 <= FinalJobs::kMax) {      // the caller launches the final stage later (the partials stay in `workspace`)
+    defer->add(pg, nb, d, dgamma);
+    defer->add(pb, nb, d, dbeta);
+    return CMH_OK;
+  }
   hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 31) / 32, 2), dim3(256), 0, st, pg, nb, d, dgamma, pb, dbeta);
   CMH_CHECK_LAUNCH("layernorm_backward dgamma/dbeta");
+  return CMH_OK;
+}
+
+int launch_final_jobs(FinalJobs& jobs, hipStream_t st) {
+  if (jobs.n == 0) return CMH_OK;
+  int maxc = 0;
+  for (int i = 0; i < jobs.n; ++i) maxc = jobs.cols[i] > maxc ? jobs.cols[i] : maxc;
+  hipLaunchKernelGGL(colsum_final_multi_kernel, dim3((maxc + 31) / 32, jobs.n), dim3(256), 0, st, jobs);
+  CMH_CHECK_LAUNCH("final reductions");
+  jobs.n = 0;
   return CMH_OK;
 }
 }  // namespace cmh

@@ -156,9 +156,21 @@ int launch_transpose(const void* src, int skind, void* dst, int dkind, int rows,
                      float* colsum_partial = nullptr);   // + [ceil(rows/64), cols] partial column sums (vectorised path only)
 bool transpose_is_vectorised(const void* src, const void* dst, int rows, int cols, int dst_ld);
 int launch_colsum_final(const float* partial, int slices, int cols, float* out, hipStream_t st);
+// deferred final stage of column reductions: up to kMax (partial [slices, cols] -> out [cols]) jobs for one launch
+struct FinalJobs {
+  static constexpr int kMax = 8;
+  int n = 0;
+  const float* partial[kMax];
+  int slices[kMax];
+  int cols[kMax];
+  float* out[kMax];
+  void add(const float* p, int s, int c, float* o) { partial[n] = p; slices[n] = s; cols[n] = c; out[n] = o; ++n; }
+};
+int launch_final_jobs(FinalJobs& jobs, hipStream_t st);
 int launch_layernorm_backward(const void* x, int x_kind, const void* dy, int dy_kind, const float* gamma, const int32_t* row_index,
                               int M, int d, float* dx, int accumulate, float* dgamma, float* dbeta, void* workspace,
-                              size_t workspace_bytes, hipStream_t st, void* dx_bf16 = nullptr);   // + a bf16 copy of the new dx
+                              size_t workspace_bytes, hipStream_t st, void* dx_bf16 = nullptr,   // + a bf16 copy of the new dx
+                              FinalJobs* defer = nullptr);                                        // queue dgamma / dbeta's final stage
 
 // attention over qkv [B*T, 3d] (dt) -> o [B*T, d] (dt); heads = d/64; causal adds the -inf triu mask
 int launch_attention(const void* qkv, void* o, int dt, int B, int T, int d, int causal,

@@ -118,6 +118,9 @@ TrainBufs carve_train(void* ws, size_t M, size_t B, size_t d, size_t e, size_t x
   const size_t cands[] = {cmh_colsum_workspace_bytes(static_cast<int>(M), static_cast<int>(4 * d)),
                           cmh_colsum_workspace_bytes(static_cast<int>(B), static_cast<int>((M / B) * d))};
   for (size_t c : cands) rb = c > rb ? c : rb;
+  // a block's six deferred reductions keep their partials side by side: 9 [M, d]-bias slices (proj 1, fc 4, out 1, in 3) + 2 LayerNorms
+  const size_t batched = 9 * align_up(((M + 63) / 64) * d * 4 + 256, 256) + 2 * align_up(cmh_layernorm_backward_workspace_bytes(static_cast<int>(M), static_cast<int>(d)), 256);
+  rb = batched > rb ? batched : rb;
   t.red_bytes = rb;
   t.red = a.take(rb);
   t.total = a.off;
@@ -160,7 +163,7 @@ int block_forward_train(const cmh_block_weights& w, int dt, int xh, const LayerT
 }
 
 // dW[O, I] = dY^T X with dY [M, O] (kind ky) and X [M, I] (kind kx); db[O] = column sums of dY
-struct WgradScratch { void* tA; void* tB; float* part; size_t part_bytes; void* red; size_t red_bytes; };
+struct WgradScratch { void* tA; void* tB; float* part; size_t part_bytes; void* red; size_t red_bytes; FinalJobs* defer = nullptr; };
 
 int wgrad_core(int dt, const void* dY, int ky, int O, const void* X, int kx, int I, int M, float* dW, float* db,
                const WgradScratch& w, hipStream_t st) {
@@ -170,7 +173,8 @@ int wgrad_core(int dt, const void* dY, int ky, int O, const void* X, int kx, int
   const bool fuse_db = db && transpose_is_vectorised(dY, w.tA, M, O, mp) && w.red_bytes >= static_cast<size_t>((M + 63) / 64) * O * 4 + 256;
   float* dbp = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(w.red) + 255) & ~static_cast<uintptr_t>(255));
   if ((rc = launch_transpose(dY, ky, w.tA, ekind(dt), M, O, mp, st, fuse_db ? dbp : nullptr))) return rc;
-  if (fuse_db && (rc = launch_colsum_final(dbp, (M + 63) / 64, O, db, st))) return rc;
+  if (fuse_db && w.defer && w.defer->n < FinalJobs::kMax) w.defer->add(dbp, (M + 63) / 64, O, db);     // final stage queued
+  else if (fuse_db && (rc = launch_colsum_final(dbp, (M + 63) / 64, O, db, st))) return rc;
   if ((rc = launch_transpose(X, kx, w.tB, ekind(dt), M, I, mp, st))) return rc;
   const int S = gemm_wide_splitk_plan(dt, O, I, mp);
   if (S > 1 && static_cast<size_t>(S) * O * I * 4 <= w.part_bytes) {
@@ -182,8 +186,9 @@ int wgrad_core(int dt, const void* dY, int ky, int O, const void* X, int kx, int
 }
 
 int wgrad(int dt, const void* dY, int ky, int O, const void* X, int kx, int I, int M, float* dW, float* db, TrainBufs& t,
-          hipStream_t st) {
-  return wgrad_core(dt, dY, ky, O, X, kx, I, M, dW, db, WgradScratch{t.tA, t.tB, t.part, t.part_bytes, t.red, t.red_bytes}, st);
+          hipStream_t st, FinalJobs* defer = nullptr, size_t red_off = 0) {
+  return wgrad_core(dt, dY, ky, O, X, kx, I, M, dW, db,
+                    WgradScratch{t.tA, t.tB, t.part, t.part_bytes, static_cast<char*>(t.red) + red_off, t.red_bytes - red_off, defer}, st);
 }
 
 // dX[M, I] = dY[M, O] . W[O, I]  (W in the GEMM dtype, row-major [O, I]); out typed by `epi`
@@ -205,28 +210,41 @@ int block_backward(const cmh_block_weights& w, const BlockGradPtrs& g, int dt, i
   // bf16 mode: the LayerNorm backward kernels also leave the new dx as the bf16 GEMM operand (t.dxe)
   void* dx_copy = dt == CMH_BF16 ? t.dxe : nullptr;
   int rc;
+  // The final stage of the block's six small reductions (four bias gradients, two LayerNorm parameter pairs) is queued and
+  // launched once at the end of the block; their partial sums live side by side in t.red (sized for that by carve_train).
+  FinalJobs jobs;
+  const size_t db_slice = align_up(static_cast<size_t>((M + 63) / 64) * d * 4 + 256, 256);       // partials of a [M, d] bias gradient
+  const size_t ln_ws = align_up(cmh_layernorm_backward_workspace_bytes(M, d), 256);
+  const size_t off_proj = 0, off_fc = db_slice, off_out = 5 * db_slice, off_in = 6 * db_slice, off_ln2 = 9 * db_slice,
+               off_ln1 = off_ln2 + ln_ws;
+  const bool batched = off_ln1 + ln_ws <= t.red_bytes;
+  FinalJobs* dj = batched ? &jobs : nullptr;
+  char* red = static_cast<char*>(t.red);
   // 1. MLP projection (dxe_ready: the previous block's ln_1 backward already wrote t.dxe)
   if (dxe_ready && dx_copy) dxe = t.dxe;
   else if ((rc = as_gemm_operand(dt, t.dx, t.dxe, md, st, &dxe))) return rc;
   if ((rc = dgrad(dt, dxe, w.proj_w, d, 4 * d, M, L.pre, t.dpre, EPI_MUL_DQGELU | obf, t, st))) return rc;
-  if ((rc = wgrad(dt, t.dx, kF32, d, L.act, ek, 4 * d, M, g.proj_w, g.proj_b, t, st))) return rc;
+  if ((rc = wgrad(dt, t.dx, kF32, d, L.act, ek, 4 * d, M, g.proj_w, g.proj_b, t, st, dj, batched ? off_proj : 0))) return rc;
   // 2. c_fc
   if ((rc = dgrad(dt, t.dpre, w.fc_w, 4 * d, d, M, nullptr, t.dh, obf, t, st))) return rc;
-  if ((rc = wgrad(dt, t.dpre, ek, 4 * d, L.h2, ek, d, M, g.fc_w, g.fc_b, t, st))) return rc;
+  if ((rc = wgrad(dt, t.dpre, ek, 4 * d, L.h2, ek, d, M, g.fc_w, g.fc_b, t, st, dj, batched ? off_fc : 0))) return rc;
   // 3. ln_2
-  if ((rc = launch_layernorm_backward(L.x_mid, xk, t.dh, ek, w.ln2_w, nullptr, M, d, t.dx, 1, g.ln2_w, g.ln2_b, t.red, t.red_bytes, st, dx_copy))) return rc;
+  if ((rc = launch_layernorm_backward(L.x_mid, xk, t.dh, ek, w.ln2_w, nullptr, M, d, t.dx, 1, g.ln2_w, g.ln2_b,
+                                      batched ? red + off_ln2 : red, batched ? ln_ws : t.red_bytes, st, dx_copy, dj))) return rc;
   // 4. out_proj
   if (dx_copy) dxe = t.dxe;
   else if ((rc = as_gemm_operand(dt, t.dx, t.dxe, md, st, &dxe))) return rc;
   if ((rc = dgrad(dt, dxe, w.out_proj_w, d, d, M, nullptr, t.dh, obf, t, st))) return rc;
-  if ((rc = wgrad(dt, t.dx, kF32, d, L.attn, ek, d, M, g.out_w, g.out_b, t, st))) return rc;
+  if ((rc = wgrad(dt, t.dx, kF32, d, L.attn, ek, d, M, g.out_w, g.out_b, t, st, dj, batched ? off_out : 0))) return rc;
   // 5. attention
   if ((rc = launch_attention_backward(dt, L.qkv, L.attn, t.dh, t.dqkv, B, T, d, causal, kpm, seq_off, st))) return rc;
   // 6. in_proj
   if ((rc = dgrad(dt, t.dqkv, w.in_proj_w, 3 * d, d, M, nullptr, t.dh, obf, t, st))) return rc;
-  if ((rc = wgrad(dt, t.dqkv, ek, 3 * d, L.h1, ek, d, M, g.in_w, g.in_b, t, st))) return rc;
+  if ((rc = wgrad(dt, t.dqkv, ek, 3 * d, L.h1, ek, d, M, g.in_w, g.in_b, t, st, dj, batched ? off_in : 0))) return rc;
   // 7. ln_1
-  return launch_layernorm_backward(L.x_in, xk, t.dh, ek, w.ln1_w, nullptr, M, d, t.dx, 1, g.ln1_w, g.ln1_b, t.red, t.red_bytes, st, dx_copy);
+  if ((rc = launch_layernorm_backward(L.x_in, xk, t.dh, ek, w.ln1_w, nullptr, M, d, t.dx, 1, g.ln1_w, g.ln1_b,
+                                      batched ? red + off_ln1 : red, batched ? ln_ws : t.red_bytes, st, dx_copy, dj))) return rc;
+  return launch_final_jobs(jobs, st);
 }
 
 BlockGradPtrs grads_of(const cmh_block_grads& g) {
