@@ -1,5 +1,6 @@
-"""Shared flags of every method — same names and defaults as the reference's argsbase.py:8-35."""
+"""Shared flags of every method — the names and defaults of the reference's argsbase.py:8-35, kept in one table."""
 import argparse
+import os
 
 
 def str2bool(v):
@@ -8,38 +9,36 @@ def str2bool(v):
     return str(v).lower() in ("1", "true", "yes", "y", "t")
 
 
-def get_baseargs():
-    parser = argparse.ArgumentParser()
-    parser.add_argument("--save-dir", type=str, default="./result/")
-    parser.add_argument("--save-mat", type=str2bool, default=True)
-    parser.add_argument("--save-model", type=str2bool, default=False)
-    parser.add_argument("--save_csv", type=str2bool, default=True)
-    parser.add_argument("--valid", default=True)
-    parser.add_argument("-vit-use", type=str2bool, default=True)
-    parser.add_argument("-clip-path", type=str, default="./ViT-B-32.pt")
-    parser.add_argument("--pretrained", type=str, default="")
-    parser.add_argument("--epochs", type=int, default=200)
-    parser.add_argument("--max-words", type=int, default=32)
-    parser.add_argument("--resolution", type=int, default=224)
-    parser.add_argument("--batch-size", type=int, default=300)
-    parser.add_argument("--num-workers", type=int, default=8)
-    parser.add_argument("--query-num", type=int, default=5000)
-    parser.add_argument("--train-num", type=int, default=10000)
-    parser.add_argument("--lr-decay-freq", type=int, default=5)
-    parser.add_argument("--display-step", type=int, default=50)
-    parser.add_argument("--seed", type=int, default=1814)
-    parser.add_argument("--lr", type=float, default=0.001)
-    parser.add_argument("--lr-decay", type=float, default=0.9)
-    parser.add_argument("--clip-lr", type=float, default=0.00001)
-    parser.add_argument("--weight-decay", type=float, default=0.2)
-    parser.add_argument("--warmup-proportion", type=float, default=0.1,
-                        help="Proportion of training to perform linear learning rate warmup for.")
-    # additions of this build (absent upstream)
-    parser.add_argument("--gemm-dtype", type=str, default="f32", choices=["f32", "bf16"],
-                        help="encoder GEMM arithmetic: f32 = reference parity, bf16 = throughput")
-    parser.add_argument("--data-dir", type=str, default="", help="directory with index/caption/label .mat files")
-    parser.add_argument("--synthetic-size", type=int, default=2000, help="items of the synthetic dataset")
+# (flag, type, default[, help]) — upstream's flags first, this build's additions last
+BASE_FLAGS = [
+    ("--save-dir", str, "./result/"), ("--save-mat", str2bool, True), ("--save-model", str2bool, False),
+    ("--save_csv", str2bool, True), ("--valid", None, True), ("-vit-use", str2bool, True), ("-clip-path", str, "./ViT-B-32.pt"),
+    ("--pretrained", str, ""), ("--epochs", int, 200), ("--max-words", int, 32), ("--resolution", int, 224),
+    ("--batch-size", int, 300), ("--num-workers", int, 8), ("--query-num", int, 5000), ("--train-num", int, 10000),
+    ("--lr-decay-freq", int, 5), ("--display-step", int, 50), ("--seed", int, 1814), ("--lr", float, 0.001),
+    ("--lr-decay", float, 0.9), ("--clip-lr", float, 0.00001), ("--weight-decay", float, 0.2),
+    ("--warmup-proportion", float, 0.1, "share of the training steps spent on the linear warm-up of the learning rate"),
+    ("--gemm-dtype", str, "f32", "encoder GEMM arithmetic: f32 = reference parity, bf16 = throughput (this build)"),
+    ("--data-dir", str, "", "directory with index.mat / caption.mat|txt / label.mat (this build; upstream hard-codes it)"),
+    ("--synthetic-size", int, 2000, "items of the synthetic dataset (this build)"),
+]
+
+
+def add_flags(parser, table):
+    for flag, typ, default, *doc in table:
+        kw = {"default": default}
+        if typ is not None:
+            kw["type"] = typ
+        if doc:
+            kw["help"] = doc[0]
+        if flag == "--gemm-dtype":
+            kw["choices"] = ["f32", "bf16"]
+        parser.add_argument(flag, **kw)
     return parser
+
+
+def get_baseargs():
+    return add_flags(argparse.ArgumentParser(), BASE_FLAGS)
 
 
 def merge(parser, main_args):
@@ -49,3 +48,11 @@ def merge(parser, main_args):
     merged = dict(vars(args))
     merged.update(vars(main_args))
     return argparse.Namespace(**merged)
+
+
+def method_args(main_args, table):
+    """Base flags + the method's own table, merged with main.py's arguments; save_dir = <save-dir>/<method>/<dataset>/<bits>
+    (what every upstream get_args.py ends with)."""
+    args = merge(add_flags(get_baseargs(), table), main_args)
+    args.save_dir = os.path.join(args.save_dir, args.method, args.dataset, str(args.output_dim))
+    return args

@@ -30,13 +30,15 @@ class MDNPH(Baseclip):
         self.image_pre = Pre_Layer(inputdim=self.embedDim, nb_class=num_classes)
         self.text_pre = Pre_Layer(inputdim=self.embedDim, nb_class=num_classes)
 
+    def _both(self, feature, hash_head, classifier):
+        """hash code and class logits from one tower feature (reference :33-51)"""
+        return hash_head(feature), classifier(feature)
+
     def encode_image(self, image):
-        image_fea = self.clip.encode_image(image)
-        return self.image_hash(image_fea), self.image_pre(image_fea)
+        return self._both(self.clip.encode_image(image), self.image_hash, self.image_pre)
 
     def encode_text(self, text):
-        text_fea = self.clip.encode_text(text)
-        return self.text_hash(text_fea), self.text_pre(text_fea)
+        return self._both(self.clip.encode_text(text), self.text_hash, self.text_pre)
 
     def forward(self, image, text):
         (image_embed, image_pre), (text_embed, text_pre) = overlapped(

@@ -19,18 +19,19 @@ from streams import overlapped
 
 
 def weights_init_kaiming(m):
-    classname = m.__class__.__name__
-    if classname.find('Linear') != -1:
+    """The reference's initialiser (model/modelbase.py:10-22), dispatched on the module's class name like upstream: Linear ->
+    kaiming-uniform fan_out + zero bias, Conv -> kaiming-normal fan_in (+ zero bias), affine BatchNorm -> weight 1 / bias 0."""
+    kind = type(m).__name__
+    if 'Linear' in kind:
         nn.init.kaiming_uniform_(m.weight, mode='fan_out')
-        nn.init.constant_(m.bias, 0.0)
-    elif classname.find('Conv') != -1:
+        nn.init.zeros_(m.bias)
+    elif 'Conv' in kind:
         nn.init.kaiming_normal_(m.weight, a=0, mode='fan_in')
         if m.bias is not None:
-            nn.init.constant_(m.bias, 0.0)
-    elif classname.find('BatchNorm') != -1:
-        if m.affine:
-            nn.init.constant_(m.weight, 1.0)
-            nn.init.constant_(m.bias, 0.0)
+            nn.init.zeros_(m.bias)
+    elif 'BatchNorm' in kind and m.affine:
+        nn.init.ones_(m.weight)
+        nn.init.zeros_(m.bias)
 
 
 class LinearHash(nn.Module):
@@ -54,58 +55,46 @@ class LinearHash(nn.Module):
 
 
 class Baseclip(nn.Module):
+    """CLIP trunk + one LinearHash per modality.  Constructor signature, attribute names and state_dict keys are the reference's."""
 
-    def __init__(self,
-                 outputDim=64,
-                 clipPath="./ViT-B-32.pt",
-                 writer=None,
-                 saveDir="./result/log",
-                 logger: logging.Logger = None,
-                 is_train=True):
-        super(Baseclip, self).__init__()
-
+    def __init__(self, outputDim=64, clipPath="./ViT-B-32.pt", writer=None, saveDir="./result/log",
+                 logger: logging.Logger = None, is_train=True):
+        super().__init__()
         os.makedirs(saveDir, exist_ok=True)
-        self.logger = logger if logger is not None else get_logger(
-            os.path.join(saveDir, "train.log" if is_train else "test.log"))
-        self.writer = writer if writer is not None and is_train else get_summary_writer(
-            os.path.join(saveDir, "tensorboard"))
-
+        if logger is None:
+            logger = get_logger(os.path.join(saveDir, "train.log" if is_train else "test.log"))
+        if writer is None or not is_train:
+            writer = get_summary_writer(os.path.join(saveDir, "tensorboard"))
+        self.logger, self.writer = logger, writer
         self.embedDim, self.clip = self.load_clip(clipPath)
-
-        self.image_hash = LinearHash(inputDim=self.embedDim, outputDim=outputDim)
-        self.text_hash = LinearHash(inputDim=self.embedDim, outputDim=outputDim)
+        self.image_hash, self.text_hash = (LinearHash(inputDim=self.embedDim, outputDim=outputDim) for _ in range(2))
 
     def load_clip(self, clipPath) -> tuple:
-        """OpenAI JIT archive or plain state_dict file; a dict is accepted too (random-init runs)."""
+        """-> (embed_dim, CLIP) from an OpenAI JIT archive, a plain state_dict file, or a state_dict (random-init runs)."""
         if isinstance(clipPath, dict):
             state_dict = dict(clipPath)
         else:
             try:
-                model = torch.jit.load(clipPath, map_location="cpu").eval()
-                state_dict = model.state_dict()
-            except RuntimeError:
+                state_dict = torch.jit.load(clipPath, map_location="cpu").eval().state_dict()
+            except RuntimeError:                       # not a TorchScript archive
                 state_dict = torch.load(clipPath, map_location="cpu")
         return state_dict["text_projection"].shape[1], build_model(state_dict)
 
-    def encode_image(self, image):
-        image_embed = self.clip.encode_image(image)
-        image_embed = self.image_hash(image_embed)
-        return image_embed
-
+    # upstream's eval() / train() toggle the two heads only (the trunk has no mode-dependent layers) and return None
     def eval(self):
-        self.image_hash.eval()
-        self.text_hash.eval()
+        for head in (self.image_hash, self.text_hash):
+            head.eval()
 
     def train(self):
-        self.image_hash.train()
-        self.text_hash.train()
+        for head in (self.image_hash, self.text_hash):
+            head.train()
+
+    def encode_image(self, image):
+        return self.image_hash(self.clip.encode_image(image))
 
     def encode_text(self, text):
-        text_embed = self.clip.encode_text(text)
-        text_embed = self.text_hash(text_embed)
-        return text_embed
+        return self.text_hash(self.clip.encode_text(text))
 
     def forward(self, image, text):
-        # the two towers are independent: one HIP stream each (streams.py)
-        image_embed, text_embed = overlapped(lambda: self.encode_image(image), lambda: self.encode_text(text))
-        return image_embed, text_embed
+        # the two towers are independent until the loss: one HIP stream each (streams.py)
+        return overlapped(lambda: self.encode_image(image), lambda: self.encode_text(text))

@@ -1,11 +1,6 @@
-"""DNPH flags (reference train/DNPH_TOMM/get_args.py)."""
-import os
-
-from argsbase import get_baseargs, merge
+"""DNPH flags (reference train/DNPH_TOMM/get_args.py): the base flags only."""
+from argsbase import method_args
 
 
 def get_args(main_args):
-    parser = get_baseargs()
-    args = merge(parser, main_args)
-    args.save_dir = os.path.join(args.save_dir, args.method, args.dataset, str(args.output_dim))
-    return args
+    return method_args(main_args, [])

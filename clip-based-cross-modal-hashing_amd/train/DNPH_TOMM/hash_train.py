@@ -44,29 +44,36 @@ class DNPHTOMMTrainer(TrainBase):
         # upstream builds this SGD for the proxies but never steps it (hash_train.py:48, :83-85): the proxies stay at their seed
         self.optimizer_loss = torch.optim.SGD(params=self.DNPH.parameters(), lr=1e-4)
 
-    def compute_loss(self, hash_img, pre_img, hash_text, pre_text, label):
+    def noise_rows(self, hash_img, hash_text):
+        """The uniform-distribution regulariser's targets (b_reg.py): one random +-1 matrix per step, assigned to the samples of
+        each modality by the Hungarian method on the host (numpy / scipy, as upstream)."""
         s_vector = rand_unit_rect(*hash_img.shape)
-        i_noises = torch.from_numpy(gene_noise(hash_img.cpu().detach().numpy(), s_vector)).float().to(self.rank)
-        t_noises = torch.from_numpy(gene_noise(hash_text.cpu().detach().numpy(), s_vector)).float().to(self.rank)
+        on_host = lambda h: h.cpu().detach().numpy()
+        to_dev = lambda a: torch.from_numpy(a).float().to(self.rank)
+        return to_dev(gene_noise(on_host(hash_img), s_vector)), to_dev(gene_noise(on_host(hash_text), s_vector))
+
+    def compute_loss(self, hash_img, pre_img, hash_text, pre_text, label):
+        i_noises, t_noises = self.noise_rows(hash_img, hash_text)
         return self.DNPH(hash_img, hash_text, pre_img, pre_text, label, label, i_noises, t_noises)
+
+    def _step(self, image, text, label):
+        image, text = image.to(self.rank, non_blocking=True), text.to(self.rank, non_blocking=True)
+        label = label.to(self.rank, non_blocking=True).float()
+        loss = self.compute_loss(*self.model(image, text), label)
+        self.optimizer.zero_grad()
+        loss.backward()
+        if du.world_size() > 1:
+            du.allreduce_mean_([p.grad for p in self.model.parameters() if p.grad is not None])
+        self.optimizer.step()
+        return loss
 
     def train_epoch(self, epoch):
         self.change_state(mode="train")
         self.logger.info(">>>>>> epochs: %d/%d" % (epoch, self.args.epochs))
         all_loss = 0
         for image, text, label, index in self.train_loader:
-            start_time = time.time()
+            began = time.time()
             self.global_step += 1
-            image = image.to(self.rank, non_blocking=True)
-            text = text.to(self.rank, non_blocking=True)
-            label = label.to(self.rank, non_blocking=True).float()
-            hash_img, pre_img, hash_text, pre_text = self.model(image, text)
-            loss = self.compute_loss(hash_img, pre_img, hash_text, pre_text, label)
-            all_loss += loss
-            self.optimizer.zero_grad()
-            loss.backward()
-            if du.world_size() > 1:
-                du.allreduce_mean_([p.grad for p in self.model.parameters() if p.grad is not None])
-            self.optimizer.step()
-            self.total_time += time.time() - start_time
+            all_loss += self._step(image, text, label)
+            self.total_time += time.time() - began
         self.logger.info(f">>>>>> [{epoch}/{self.args.epochs}] loss: {all_loss.data / (len(self.train_loader))}, time: {self.total_time}")

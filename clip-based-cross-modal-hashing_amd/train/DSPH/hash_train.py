@@ -47,26 +47,28 @@ class DSPHTrainer(TrainBase):
     def compute_loss(self, hash_img, hash_text, label):
         return self.hyp(hash_img, hash_text, label)
 
+    def _step(self, image, text, label):
+        """One optimisation step (reference :52-70): forward, HyP loss, backward, BertAdam on the model + SGD on the proxies."""
+        dev = self.rank
+        image, text, label = (t.to(dev, non_blocking=True) for t in (image, text, label))
+        loss = self.compute_loss(*self.model(image, text), label)
+        for opt in (self.optimizer, self.optimizer_loss):
+            opt.zero_grad()
+        loss.backward()
+        if du.world_size() > 1:   # one process per GPU: average the gradients over the ranks (flat buckets over RCCL)
+            params = list(self.model.parameters()) + list(self.hyp.parameters())
+            du.allreduce_mean_([p.grad for p in params if p.grad is not None])
+        for opt in (self.optimizer, self.optimizer_loss):
+            opt.step()
+        return loss
+
     def train_epoch(self, epoch):
         self.change_state(mode="train")
         self.logger.info(">>>>>> epochs: %d/%d" % (epoch, self.args.epochs))
         all_loss = 0
         for image, text, label, index in self.train_loader:
-            start_time = time.time()
+            began = time.time()
             self.global_step += 1
-            image = image.to(self.rank, non_blocking=True)
-            text = text.to(self.rank, non_blocking=True)
-            label = label.to(self.rank, non_blocking=True)
-            hash_img, hash_text = self.model(image, text)
-            loss = self.compute_loss(hash_img, hash_text, label)
-            all_loss += loss
-            self.optimizer.zero_grad()
-            self.optimizer_loss.zero_grad()
-            loss.backward()
-            if du.world_size() > 1:   # one process per GPU: average the gradients over the ranks (flat buckets over RCCL)
-                du.allreduce_mean_([p.grad for p in list(self.model.parameters()) + list(self.hyp.parameters())
-                                    if p.grad is not None])
-            self.optimizer.step()
-            self.optimizer_loss.step()
-            self.total_time += time.time() - start_time
+            all_loss += self._step(image, text, label)
+            self.total_time += time.time() - began
         self.logger.info(f">>>>>> [{epoch}/{self.args.epochs}] loss: {all_loss.data / (len(self.train_loader))}, time: {self.total_time}")

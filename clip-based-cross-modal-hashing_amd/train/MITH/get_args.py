@@ -1,23 +1,11 @@
 """MITH flags (reference train/MITH/get_args.py:11-22)."""
-import os
+from argsbase import method_args
 
-from argsbase import get_baseargs, merge
+FLAGS = [("--dropout", float, 0), ("--transformer-layers", int, 2), ("--activation", str, "gelu"), ("--top-k-label", int, 8),
+         ("--res-mlp-layers", int, 2), ("--hyper-lambda", float, 0.99), ("--hyper-tokens-intra", float, 1),
+         ("--hyper-cls-inter", float, 10), ("--hyper-quan", float, 8), ("--hyper-info-nce", float, 50),
+         ("--hyper-alpha", float, 0.01), ("--hyper-distill", float, 1)]
 
 
 def get_args(main_args):
-    parser = get_baseargs()
-    parser.add_argument("--dropout", type=float, default=0)
-    parser.add_argument("--transformer-layers", type=int, default=2)
-    parser.add_argument("--activation", type=str, default="gelu")
-    parser.add_argument("--top-k-label", type=int, default=8)
-    parser.add_argument("--res-mlp-layers", type=int, default=2)
-    parser.add_argument("--hyper-lambda", type=float, default=0.99)
-    parser.add_argument("--hyper-tokens-intra", type=float, default=1)
-    parser.add_argument("--hyper-cls-inter", type=float, default=10)
-    parser.add_argument("--hyper-quan", type=float, default=8)
-    parser.add_argument("--hyper-info-nce", type=float, default=50)
-    parser.add_argument("--hyper-alpha", type=float, default=0.01)
-    parser.add_argument("--hyper-distill", type=float, default=1)
-    args = merge(parser, main_args)
-    args.save_dir = os.path.join(args.save_dir, args.method, args.dataset, str(args.output_dim))
-    return args
+    return method_args(main_args, FLAGS)
