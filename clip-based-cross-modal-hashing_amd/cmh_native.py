@@ -270,6 +270,9 @@ def linear_gemm(x, w, bias=None, residual=None, quickgelu=False, out_bf16=False,
     x, w = x.contiguous(), w.contiguous()
     M, K = x.shape
     Nn = w.shape[0]
+    if w.dim() != 2 or w.shape[1] != K or (bias is not None and bias.numel() != Nn) or \
+            (residual is not None and tuple(residual.shape) != (M, Nn)):
+        raise NativeError(f"linear_gemm: x {tuple(x.shape)}, w {tuple(w.shape)}, bias / residual shapes do not fit together")
     odt = torch.bfloat16 if out_bf16 else (torch.float16 if out_f16 else torch.float32)
     out = torch.empty(M, Nn, dtype=odt, device=x.device)
     res_f16 = residual is not None and residual.dtype == torch.float16
@@ -287,6 +290,8 @@ def layernorm(x, w, b, out_bf16=False):
     x, w, b = f32c(x), f32c(w), f32c(b)
     require_gpu(x, w, b)
     M, d = x.shape
+    if w.numel() != d or b.numel() != d:
+        raise NativeError(f"layernorm: rows of {d} elements, weight {tuple(w.shape)}, bias {tuple(b.shape)}")
     out = torch.empty(M, d, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
     check(lib().cmh_layernorm(ptr(x), ptr(w), ptr(b), ptr(out), BF16 if out_bf16 else F32, M, d, stream_ptr(x.device)),
           "cmh_layernorm")

@@ -31,6 +31,10 @@ def gemm(x, w, bias=None, residual=None, act=None, dtype=N.F32):
         x, w = N.f32c(x), N.f32c(w)
     M, K = x.shape
     Nn = w.shape[0]
+    if w.dim() != 2 or w.shape[1] != K or (bias is not None and bias.numel() != Nn) or \
+            (residual is not None and tuple(residual.shape) != (M, Nn)):
+        raise N.NativeError(f"gemm: x {tuple(x.shape)}, w {tuple(w.shape)}, bias {None if bias is None else tuple(bias.shape)}, "
+                            f"residual {None if residual is None else tuple(residual.shape)} do not fit together")
     out = torch.empty(M, Nn, dtype=torch.float32, device=x.device)
     epi = (EPI_BIAS if bias is not None else 0) | (EPI_RESIDUAL if residual is not None else 0)
     epi |= {None: 0, "gelu": EPI_GELU, "relu": EPI_RELU, "quickgelu": EPI_QUICKGELU}[act]

@@ -235,6 +235,10 @@ class HashingModel(nn.Module):
 
     def forward(self, img_tokens, txt_tokens, img_cls, txt_eos, key_padding_mask):
         """Reference layouts in (img_tokens [49,N,D], txt_tokens [L,N,D]) and out (trans_tokens_* [K,N,D])."""
+        D = self.img_concept_proj.in_features
+        for name, t in (("img_tokens", img_tokens), ("txt_tokens", txt_tokens), ("img_cls", img_cls), ("txt_eos", txt_eos)):
+            if t.shape[-1] != D:
+                raise ValueError(f"HashingModel was built for {D}-d CLIP features, {name} has {t.shape[-1]}")
         if torch.is_grad_enabled() and (img_tokens.requires_grad or self.img_concept_proj.weight.requires_grad):
             return self._forward_train(img_tokens, txt_tokens, img_cls, txt_eos, key_padding_mask)
         out = {}
