@@ -246,3 +246,21 @@ def test_loss_gradients_match_reference_autograd(golden, Nb, K, C, Mb):
         if k.startswith("trans_tokens"):
             got = got[::4, :, ::4]
         np.testing.assert_allclose(got, want, rtol=1e-3, atol=2e-5 * max(np.abs(want).max(), 1e-30), err_msg=k)
+
+
+def test_mismatched_feature_width_fails_loudly():
+    """A HashingModel built for 512-d features refuses narrower ones before any kernel runs, and the GEMM / LayerNorm wrappers
+    refuse operands whose shapes do not fit (a residual of the wrong width would otherwise be read out of bounds)."""
+    import cmh_native as N
+    import mith_ops as M
+    from model.MITH import HashingModel
+    hm = HashingModel(clip_embed_dim=512, args=SimpleNamespace(output_dim=16, **mu.ARGS)).to(DEV).eval()
+    z = lambda *s: torch.zeros(*s, device=DEV)
+    with pytest.raises(ValueError):
+        hm(z(49, 2, 64), z(8, 2, 64), z(2, 64), z(2, 64), torch.zeros(2, 8, dtype=torch.bool, device=DEV))
+    with pytest.raises(N.NativeError):
+        M.gemm(z(4, 64), z(128, 512), None)
+    with pytest.raises(N.NativeError):
+        M.gemm(z(4, 512), z(128, 512), None, residual=z(4, 64))
+    with pytest.raises(N.NativeError):
+        N.layernorm(z(4, 64), z(512), z(512))
