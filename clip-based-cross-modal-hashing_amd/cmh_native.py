@@ -385,6 +385,8 @@ def pack_labels(labels):
 def hamming_dist(q_planes, r_planes, bits):
     (qs, qn), (rs, rn) = q_planes, r_planes
     Q, N = qs.shape[0], rs.shape[0]
+    W = (bits + 31) // 32
+    fit("hamming_dist", (qs, (Q, W)), (qn, (Q, W)), (rs, (N, W)), (rn, (N, W)))
     out = torch.empty(Q, N, dtype=torch.float32, device=qs.device)
     check(lib().cmh_hamming_dist(ptr(qs), ptr(qn), ptr(rs), ptr(rn), Q, N, bits, ptr(out), stream_ptr(qs.device)),
           "cmh_hamming_dist")
@@ -393,6 +395,7 @@ def hamming_dist(q_planes, r_planes, bits):
 
 def calc_neighbor(la, lb, classes):
     A, B = la.shape[0], lb.shape[0]
+    fit("calc_neighbor", (la, (A, (classes + 31) // 32)), (lb, (B, (classes + 31) // 32)))
     out = torch.empty(A, B, dtype=torch.float32, device=la.device)
     check(lib().cmh_calc_neighbor(ptr(la), ptr(lb), A, B, classes, ptr(out), stream_ptr(la.device)), "cmh_calc_neighbor")
     return out
@@ -404,6 +407,8 @@ def hamming_map(q_planes, q_lab, r_planes, r_lab, bits, classes, topk=None, tie_
     (qs, qn), (rs, rn) = q_planes, r_planes
     dev = qs.device
     Q, N = qs.shape[0], rs.shape[0]
+    W, LW = (bits + 31) // 32, (classes + 31) // 32
+    fit("hamming_map", (qs, (Q, W)), (qn, (Q, W)), (rs, (N, W)), (rn, (N, W)), (q_lab, (Q, LW)), (r_lab, (N, LW)))
     ap = torch.empty(Q, dtype=torch.float32, device=dev)
     mp = torch.empty(1, dtype=torch.float32, device=dev)
     perm = torch.empty(Q, N, dtype=torch.int32, device=dev) if want_perm else None
@@ -416,11 +421,20 @@ def hamming_map(q_planes, q_lab, r_planes, r_lab, bits, classes, topk=None, tie_
 
 
 # ------------------------------------------------------------------------------------------ losses
+def fit(what, *pairs):
+    """pairs of (tensor, expected shape): the kernels take their sizes from ONE operand, so every other operand is checked here
+    (a mismatched operand would be read out of bounds)."""
+    for t, shape in pairs:
+        if t is not None and tuple(t.shape) != tuple(shape):
+            raise NativeError(f"{what}: operand of shape {tuple(t.shape)} where {tuple(shape)} is expected")
+
+
 def dsph_hyp_loss(x, y, label, proxies, threshold, alpha):
     x, y, label, proxies = f32c(x), f32c(y), f32c(label), f32c(proxies)
     require_gpu(x, y, label, proxies)
     B, K = x.shape
     Cn = label.shape[1]
+    fit("dsph_hyp_loss", (y, (B, K)), (label, (B, Cn)), (proxies, (Cn, K)))
     out = torch.empty(1, dtype=torch.float32, device=x.device)
     ws = workspace(lib().cmh_loss_workspace_bytes(B, K, Cn), x.device, "loss")
     check(lib().cmh_dsph_hyp_loss(ptr(x), ptr(y), ptr(label), ptr(proxies), B, K, Cn, float(threshold), float(alpha),
@@ -433,6 +447,7 @@ def dchmt_loss(img, txt, label, output_dim, similarity="euclidean", loss_type="l
     require_gpu(img, txt, label)
     B, D = img.shape
     Cn = label.shape[1]
+    fit("dchmt_loss", (txt, (B, D)), (label, (B, Cn)))
     out = torch.empty(1, dtype=torch.float32, device=img.device)
     ws = workspace(lib().cmh_loss_workspace_bytes(B, D, Cn), img.device, "loss")
     sim = {"euclidean": 0, "cosine": 1}[similarity]
@@ -448,6 +463,7 @@ def batchnorm1d_train(x, w, b, eps=1e-5):
     x, w, b = f32c(x), f32c(w), f32c(b)
     require_gpu(x, w, b)
     B, d = x.shape
+    fit("batchnorm1d_train", (w, (d,)), (b, (d,)))
     y = torch.empty_like(x)
     check(lib().cmh_batchnorm1d_train(ptr(x), ptr(w), ptr(b), float(eps), ptr(y), B, d, stream_ptr(x.device)),
           "cmh_batchnorm1d_train")
@@ -459,6 +475,7 @@ def twdh_targets(label, center, random_center):
     require_gpu(label, center, random_center)
     B, Cn = label.shape
     K = center.shape[1]
+    fit("twdh_targets", (center, (Cn, K)), (random_center, (K,)))
     code = torch.empty(B, K, dtype=torch.float32, device=label.device)
     check(lib().cmh_twdh_targets(ptr(label), ptr(center), ptr(random_center), ptr(code), B, Cn, K,
                                  stream_ptr(label.device)), "cmh_twdh_targets")
@@ -470,6 +487,7 @@ def twdh_loss(p_img, p_txt, target):
     p_img, p_txt, target = f32c(p_img), f32c(p_txt), f32c(target)
     require_gpu(p_img, p_txt, target)
     B, K = target.shape
+    fit("twdh_loss", (p_img, (B, 2 * K)), (p_txt, (B, 2 * K)))
     out = torch.empty(2, dtype=torch.float32, device=p_img.device)
     ws = workspace(256, p_img.device, "loss")
     check(lib().cmh_twdh_loss(ptr(p_img), ptr(p_txt), ptr(target), B, K, ptr(out), ptr(ws), ws.numel(),
@@ -486,6 +504,7 @@ def dnph_loss(hash_img, hash_txt, pre_img, pre_txt, label, proxies, noise_img=No
     require_gpu(*ts, ni, nt)
     B, K = ts[0].shape
     Cn = ts[4].shape[1]
+    fit("dnph_loss", (ts[1], (B, K)), (ts[2], (B, Cn)), (ts[3], (B, Cn)), (ts[4], (B, Cn)), (ts[5], (Cn, K)), (ni, (B, K)), (nt, (B, K)))
     out = torch.empty(3, dtype=torch.float32, device=ts[0].device)
     ws = workspace(256, ts[0].device, "loss")
     check(lib().cmh_dnph_loss(*[ptr(t) for t in ts], ptr(ni), ptr(nt), B, K, Cn, float(margin), float(noise_weight),

@@ -87,6 +87,7 @@ def lta(tokens, sim, key_padding_mask, l0, L, top_k):
     tokens, sim = N.f32c(tokens), N.f32c(sim)
     B, Ltot, D = tokens.shape
     K = sim.shape[2]
+    N.fit("lta", (sim, (B, Ltot, K)), (key_padding_mask, (B, L)))
     out = torch.empty(B, K, D, dtype=torch.float32, device=tokens.device)
     kpm = None if key_padding_mask is None else key_padding_mask.to(torch.uint8).contiguous()
     N.check(N.lib().cmh_mith_lta(N.ptr(tokens), N.ptr(sim), N.ptr(kpm), N.ptr(out), B, Ltot, l0, L, K, D, top_k,
@@ -104,6 +105,7 @@ def add_positional(x, pe):
 def bitwise_hash(x, w, bias):
     x = N.f32c(x)
     B, K, D = x.shape
+    N.fit("bitwise_hash", (w, (K, D)), (bias, (K,)))
     out = torch.empty(B, K, dtype=torch.float32, device=x.device)
     N.check(N.lib().cmh_bitwise_hash(N.ptr(x), N.ptr(N.f32c(w)), N.ptr(N.f32c(bias)), N.ptr(out), B, K, D,
                                      N.stream_ptr(x.device)), "cmh_bitwise_hash")
@@ -120,6 +122,7 @@ def l2_normalize_rows(x):
 
 def mith_mix(ic, it, tc, tt, lam):
     ic, it, tc, tt = (N.f32c(t) for t in (ic, it, tc, tt))
+    N.fit("mith_mix", (it, ic.shape), (tc, ic.shape), (tt, ic.shape))
     Bc, Hi, Ht = torch.empty_like(ic), torch.empty_like(ic), torch.empty_like(ic)
     N.check(N.lib().cmh_mith_mix(N.ptr(ic), N.ptr(it), N.ptr(tc), N.ptr(tt), float(lam), N.ptr(Bc), N.ptr(Hi), N.ptr(Ht),
                                  ic.numel(), N.stream_ptr(ic.device)), "cmh_mith_mix")
@@ -132,6 +135,7 @@ def _scalar(dev):
 
 def sq_diff_sum(a, b):
     a, b = N.f32c(a), N.f32c(b)
+    N.fit("sq_diff_sum", (b, a.shape))
     out, ws = _scalar(a.device), N.workspace(256, a.device, "loss")
     N.check(N.lib().cmh_sq_diff_sum(N.ptr(a), N.ptr(b), a.numel(), N.ptr(out), N.ptr(ws), ws.numel(), N.stream_ptr(a.device)),
             "cmh_sq_diff_sum")
@@ -140,6 +144,8 @@ def sq_diff_sum(a, b):
 
 def bayesian_loss(bank, batch, bank_label, label):
     bank, batch, bank_label, label = (N.f32c(t) for t in (bank, batch, bank_label, label))
+    N.fit("bayesian_loss", (batch, (batch.shape[0], bank.shape[1])), (bank_label, (bank.shape[0], label.shape[1])),
+          (label, (batch.shape[0], label.shape[1])))
     out, ws = _scalar(bank.device), N.workspace(256, bank.device, "loss")
     N.check(N.lib().cmh_mith_bayesian_loss(N.ptr(bank), N.ptr(batch), N.ptr(bank_label), N.ptr(label), bank.shape[0],
                                            batch.shape[0], bank.shape[1], label.shape[1], N.ptr(out), N.ptr(ws), ws.numel(),
@@ -149,6 +155,7 @@ def bayesian_loss(bank, batch, bank_label, label):
 
 def info_nce(a, b, group=None, temperature=0.07):
     a, b = N.f32c(a), N.f32c(b)
+    N.fit("info_nce", (b, a.shape))
     D = a.shape[-1]
     R = a.numel() // D
     G = R if group is None else group
