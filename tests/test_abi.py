@@ -58,3 +58,43 @@ def test_product_never_imports_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "oracle/" in txt:
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_argument_validation_of_the_later_entry_points():
+    """Null pointers and impossible sizes come back as negative status codes with a message — nothing is launched, so this runs
+    without a GPU (input pipeline, optimiser, backward building blocks, MITH training entry points, host tokenizer)."""
+    import ctypes as C
+    import cmh_native as N
+    lib = N.lib()
+    three = (C.c_float * 3)(0, 0, 0)
+    calls = [
+        lambda: lib.cmh_image_preprocess(None, None, None, 4, 10, 10, 16, 1, three, three, None, None, None, 0, None),
+        lambda: lib.cmh_image_normalize(None, None, 4, 16, three, three, None, None),
+        lambda: lib.cmh_bert_adam_step(None, 0, 0.9, 0.98, 1e-6, None, 0, None),
+        lambda: lib.cmh_transpose(None, 0, None, 0, 4, 4, None),
+        lambda: lib.cmh_layernorm_backward(None, 0, None, 0, None, 4, 8, None, 0, None, None, None, 0, None),
+        lambda: lib.cmh_attention_backward(1, None, None, None, None, 1, 8, 64, 0, None, None),
+        lambda: lib.cmh_linear_wgrad(1, None, 0, None, 0, 64, 64, 64, None, None, None, 0, None),
+        lambda: lib.cmh_dnph_loss_backward(*([None] * 8), 4, 16, 8, 1.0, 0.1, None, *([None] * 5), None, 0, None),
+        lambda: lib.cmh_twdh_loss_backward(None, None, None, 4, 8, None, None, None, None, None),
+        lambda: lib.cmh_batchnorm1d_backward(None, None, 1e-5, None, None, None, None, 4, 8, None),
+        lambda: lib.cmh_mith_lta_backward(None, None, None, None, 2, 8, 0, 8, 16, 64, 8, None),
+        lambda: lib.cmh_blocks_forward_train(None, 2, 0, None, None, 2, 8, 128, None, 0, None),
+        lambda: lib.cmh_blocks_backward(None, None, 2, 0, None, None, 2, 8, 128, None, 0, None),
+        lambda: lib.cmh_mith_bayesian_loss_backward(None, None, None, None, 10, 4, 16, 8, None, None, None, 0, None),
+        lambda: lib.cmh_info_nce_backward(None, None, 8, 4, 64, 0.07, None, None, None, None, 0, None),
+        lambda: lib.cmh_sq_diff_sum_backward(None, None, 16, None, None, None, None),
+        lambda: lib.cmh_gelu(None, None, 16, None),
+        lambda: lib.cmh_l2_normalize_backward(None, None, None, 4, 8, None),
+        lambda: lib.cmh_bitwise_hash_backward(*([None] * 7), 2, 4, 8, None),
+        lambda: lib.cmh_vit_forward_train_tokens(None, None, 2, None, None, 0, None),
+        lambda: lib.cmh_text_backward_tokens(None, None, 2, 8, None, None, None, None, 0, None),
+        lambda: lib.cmh_bpe_create(None, 0, None),
+        lambda: lib.cmh_bpe_encode_captions(None, None, None, 1, 8, None, None, 1),
+    ]
+    for k, call in enumerate(calls):
+        rc = call()
+        assert rc < 0, (k, rc)
+        assert len(lib.cmh_last_error()) > 0
+    assert lib.cmh_image_preprocess_workspace_bytes(0, 10, 10, 16) == 0 and lib.cmh_blocks_train_bytes(0, 0, 8, 128, 2) == 0
+    assert lib.cmh_bpe_vocab_size(None) == 0
