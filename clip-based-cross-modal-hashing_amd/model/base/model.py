@@ -77,7 +77,8 @@ class VisionTransformer(nn.Module):
 
 
 class _NoBackward(torch.autograd.Function):
-    """Attaches a grad_fn to native outputs so that a backward pass fails loudly."""
+    """Attaches a grad_fn to outputs of the inference-only entry points so that a backward pass through them fails loudly
+    instead of silently stopping (the training entry points keep a tape and are used whenever gradients are wanted)."""
 
     @staticmethod
     def forward(ctx, out, anchor):
@@ -86,8 +87,8 @@ class _NoBackward(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         raise NotImplementedError(
-            "backward through the libcmh CLIP towers / hash heads is not implemented yet "
-            "(SURVEY.md §8f next #2); this build covers encode -> hash -> loss(forward) -> mAP")
+            "this output came from an inference-only call (per-block taps, `assume_frozen`, or an operand that did not ask for "
+            "gradients when it was produced): it carries no tape, so nothing can be propagated through it")
 
 
 def no_backward(out: torch.Tensor, anchor: torch.Tensor) -> torch.Tensor:
