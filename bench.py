@@ -334,6 +334,11 @@ def main():
                            max_grad_norm=1.0)
             sgd = torch.optim.SGD(hyp.parameters(), lr=0.02, momentum=0.9, weight_decay=0.0005)
 
+            # gradient means over the ranks, each tower's all-reduce queued from inside backward (dist_utils.GradSync)
+            vis_ids = {id(p) for p in clip.visual.parameters()}
+            sync = du.GradSync([[p for p in params if id(p) not in vis_ids], list(clip.visual.parameters()),
+                                list(img_head.parameters()) + list(txt_head.parameters()) + list(hyp.parameters())])
+
             def train_step():
                 fi, ft = overlapped(lambda: clip.encode_image(image), lambda: clip.encode_text(text))
                 hi, ht = img_head(fi), txt_head(ft)
@@ -343,9 +348,7 @@ def main():
                 loss = hyp(hi, ht, label)
                 opt.zero_grad(); sgd.zero_grad()
                 loss.backward()
-                if world > 1:                            # data-parallel gradient averaging in flat buckets (dist_utils.py)
-                    du.allreduce_mean_([p.grad for p in params + list(img_head.parameters()) + list(txt_head.parameters()) +
-                                        list(hyp.parameters()) if p.grad is not None])
+                sync.finish()                            # no-op on one GPU
                 opt.step(); sgd.step()
                 return loss
             for _ in range(2):
@@ -361,6 +364,7 @@ def main():
                                  "what": "DSPH step: forward with tape + HyP loss + backward (heads, both towers) + fused BertAdam",
                                  "loss": round(float(tl.detach()), 5)}
             clip.assume_frozen = True
+            sync.remove()
         except Exception as exc:      # the secondary metric must never take the headline line down
             out["train_step"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
             clip.assume_frozen = True

@@ -119,8 +119,6 @@ class DeviceLoader:
         self.dataset, self.device = dataset, device
         loader_kwargs.pop("pin_memory", None)                  # the ragged buffer is pinned here, after the workers' pickling
         self.batch_size = loader_kwargs.get("batch_size", 1)
-        self.shuffle = loader_kwargs.get("shuffle", False)
-        self.drop_last = loader_kwargs.get("drop_last", False)
         self.loader = DataLoader(dataset=dataset, collate_fn=dataset.collate, **loader_kwargs)
         self.cache_images = cache_images
         self._cache = None                                      # uint8 [N, R, R, 3] on the device
@@ -146,13 +144,11 @@ class DeviceLoader:
         return (image,) + tuple(batch[1:])
 
     def _cached_epoch(self):
-        ds, n = self.dataset, len(self.dataset)
+        ds = self.dataset
         if self._labels is None:
             self._labels = ds.get_all_label()
-        order = torch.randperm(n) if self.shuffle else torch.arange(n)
-        stop = n - n % self.batch_size if self.drop_last else n
-        for lo in range(0, stop, self.batch_size):
-            index = order[lo:lo + self.batch_size]
+        for batch_index in self.loader.batch_sampler:            # the DataLoader's own order: shuffle / sampler / drop_last as given
+            index = torch.as_tensor(batch_index, dtype=torch.int64)
             caption = ds.tokenizer.encode_captions([ds._choose_caption(int(i)) for i in index], ds.maxWords)
             label = torch.stack([ds._load_label(int(i)) for i in index])
             image = normalize_u8(self._cache, index.to(self.device))

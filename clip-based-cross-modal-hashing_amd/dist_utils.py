@@ -35,6 +35,10 @@ def init_from_env(backend: str | None = None):
     return rank, world, local
 
 
+def dist_rank() -> int:
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
 def world_size() -> int:
     return dist.get_world_size() if dist.is_initialized() else 1
 
@@ -109,6 +113,26 @@ def scatter_by_index(buffer: torch.Tensor, index: torch.Tensor, rows: torch.Tens
     buffer[index.long()] = rows.to(buffer.dtype)
 
 
+def broadcast_modules_(modules, src: int = 0) -> None:
+    """Parameters and buffers of `modules` on every rank := rank `src`'s, in flat per-dtype messages."""
+    if world_size() == 1:
+        return
+    seen, by_dtype = set(), {}
+    for m in modules:
+        for t in list(m.parameters()) + list(m.buffers()):
+            if id(t) not in seen:
+                seen.add(id(t))
+                by_dtype.setdefault(t.dtype, []).append(t)
+    for group in by_dtype.values():
+        with torch.no_grad():
+            flat = torch.cat([t.reshape(-1) for t in group])
+            dist.broadcast(flat, src=src)
+            off = 0
+            for t in group:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+
+
 def allreduce_mean_(tensors: list[torch.Tensor], bucket_bytes: int = 256 << 20) -> None:
     """Data-parallel gradient synchronisation: average `tensors` over the ranks in place.  Gradients are
     packed into flat buckets of ~bucket_bytes so that a step is a handful of large ring all-reduces (xGMI rings are per-link
@@ -138,3 +162,89 @@ def allreduce_mean_(tensors: list[torch.Tensor], bucket_bytes: int = 256 << 20) 
             n = t.numel()
             t.copy_(flat[off:off + n].view_as(t))
             off += n
+
+
+class GradSync:
+    """allreduce_mean_ started from inside the backward pass ("overlapped with backward").
+
+    The parameters are cut into groups in the order their gradients complete — the text tower, the image tower, the rest
+    (hash heads, loss parameters) — and a post-accumulate hook on every parameter counts its group down; the moment a group
+    is complete its gradients are packed into one flat buffer and an asynchronous ring all-reduce is queued, so the text
+    tower's 254 MB travel over xGMI while the image tower's backward kernels are still running.  `finish()` (after
+    `loss.backward()`, before the optimiser) sends whatever did not go out early, waits, and writes the means back.
+
+    Which parameters receive a gradient is learnt from the previous step (the first step sends everything from `finish()`);
+    a gradient that shows up after its group was sent goes out in `finish()`; one that stays away only delays its group
+    until `finish()`.  The result is the same as allreduce_mean_ over the same gradients: same sums, same division."""
+
+    def __init__(self, groups):
+        self.world = world_size()
+        self.groups = [[p for p in g if p.requires_grad] for g in groups]
+        self.groups = [g for g in self.groups if g]
+        self._group_of = {id(p): gi for gi, g in enumerate(self.groups) for p in g}
+        self._expected = [None] * len(self.groups)            # ids of the parameters that had a gradient last step
+        self._arrived = [[] for _ in self.groups]
+        self._sent = [False] * len(self.groups)
+        self._late, self._pending, self._handles = [], [], []
+        if self.world > 1:
+            for g in self.groups:
+                for p in g:
+                    self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    @staticmethod
+    def for_model(model, *extra_modules):
+        """[text tower], [image tower], [everything else] of a Baseclip-style model (+ loss modules holding parameters)."""
+        clip = getattr(model, "clip", None)
+        visual = list(clip.visual.parameters()) if clip is not None and hasattr(clip, "visual") else []
+        vis_ids = {id(p) for p in visual}
+        text = [p for p in clip.parameters() if id(p) not in vis_ids] if clip is not None else []
+        seen = vis_ids | {id(p) for p in text}
+        rest = [p for m in (model,) + extra_modules for p in m.parameters() if id(p) not in seen]
+        return GradSync([text, visual, rest])
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+    def _send(self, params):
+        flat = torch.cat([p.grad.reshape(-1) for p in params])
+        self._pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, params))
+
+    def _on_grad(self, p):
+        gi = self._group_of[id(p)]
+        if self._sent[gi]:
+            self._late.append(p)
+            return
+        self._arrived[gi].append(p)
+        exp = self._expected[gi]
+        if exp is not None and len(self._arrived[gi]) == len(exp) and {id(q) for q in self._arrived[gi]} == exp:
+            self._send(self._arrived[gi])
+            self._sent[gi] = True
+
+    def finish(self):
+        if self.world == 1:
+            return
+        for gi in range(len(self.groups)):
+            if not self._sent[gi] and self._arrived[gi]:
+                self._send(self._arrived[gi])
+        if self._late:
+            self._send(self._late)
+        on_gpu = torch.cuda.is_available()
+        for work, flat, params in self._pending:
+            work.wait()
+            if on_gpu and flat.is_cuda:
+                flat.record_stream(torch.cuda.current_stream(flat.device))
+            flat.div_(self.world)
+            off = 0
+            for p in params:
+                n = p.grad.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                off += n
+        late_ids = {id(p) for p in self._late}
+        for gi in range(len(self.groups)):
+            got = {id(p) for p in self._arrived[gi]} | {i for i in late_ids if self._group_of[i] == gi}
+            self._expected[gi] = got if got else None
+        self._arrived = [[] for _ in self.groups]
+        self._sent = [False] * len(self.groups)
+        self._late, self._pending = [], []

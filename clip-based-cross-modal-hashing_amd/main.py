@@ -43,5 +43,15 @@ if __name__ == "__main__":
     parser.add_argument("--is-train", type=str2bool, default=True)
     args, _ = parser.parse_known_args()
 
+    # under `python -m torch.distributed.run --nproc-per-node N main.py ...` this is one process per GPU: the trainer's `rank`
+    # argument is the GPU id, as upstream; batches, evaluation sets and gradients are sharded / averaged in train/base.py
+    import torch
+    import dist_utils as du
+    _, world, local = du.init_from_env()
+    gpu = local % max(torch.cuda.device_count(), 1) if world > 1 else 0
+    if world > 1 and torch.cuda.is_available():
+        torch.cuda.set_device(gpu)
     trainer = trainers.get(args.method)
-    trainer(args, 0)
+    trainer(args, gpu)
+    if world > 1:
+        torch.distributed.destroy_process_group()

@@ -7,7 +7,6 @@ import os
 import torch
 
 import cmh_native as N
-import dist_utils as du
 from model.DCHMT import MDCMHT
 from model.base.optimization import BertAdam
 from model.base.model import no_backward
@@ -71,8 +70,6 @@ class DCHMTTrainer(TrainBase):
             loss = self.compute_loss(hash_img, hash_text, label, epoch, times)
             all_loss += loss.detach()
             self.optimizer.zero_grad()
-            loss.backward()
-            if du.world_size() > 1:   # one process per GPU: average the gradients over the ranks (flat buckets over RCCL)
-                du.allreduce_mean_([p.grad for p in self.model.parameters() if p.grad is not None])
+            self.backward(loss)                   # + the gradient means over the ranks when there are several
             self.optimizer.step()
         self.logger.info(f">>>>>> [{epoch}/{self.args.epochs}] loss: {all_loss.data / (len(self.train_loader))}")

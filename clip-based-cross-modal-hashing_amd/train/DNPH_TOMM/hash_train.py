@@ -5,7 +5,6 @@ import time
 
 import torch
 
-import dist_utils as du
 from model.DNPH_TOMM import MDNPH
 from model.base.optimization import BertAdam
 from train.base import TrainBase
@@ -61,9 +60,7 @@ class DNPHTOMMTrainer(TrainBase):
         label = label.to(self.rank, non_blocking=True).float()
         loss = self.compute_loss(*self.model(image, text), label)
         self.optimizer.zero_grad()
-        loss.backward()
-        if du.world_size() > 1:
-            du.allreduce_mean_([p.grad for p in self.model.parameters() if p.grad is not None])
+        self.backward(loss)
         self.optimizer.step()
         return loss
 

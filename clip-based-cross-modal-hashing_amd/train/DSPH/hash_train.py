@@ -6,7 +6,6 @@ import time
 
 import torch
 
-import dist_utils as du
 from model.DSPH import MDSPH
 from model.base.optimization import BertAdam
 from train.base import TrainBase
@@ -54,10 +53,7 @@ class DSPHTrainer(TrainBase):
         loss = self.compute_loss(*self.model(image, text), label)
         for opt in (self.optimizer, self.optimizer_loss):
             opt.zero_grad()
-        loss.backward()
-        if du.world_size() > 1:   # one process per GPU: average the gradients over the ranks (flat buckets over RCCL)
-            params = list(self.model.parameters()) + list(self.hyp.parameters())
-            du.allreduce_mean_([p.grad for p in params if p.grad is not None])
+        self.backward(loss, self.hyp)             # + the gradient means over the ranks when there are several
         for opt in (self.optimizer, self.optimizer_loss):
             opt.step()
         return loss

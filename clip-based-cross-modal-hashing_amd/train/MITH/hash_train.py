@@ -133,14 +133,13 @@ class MITHTrainer(TrainBase):
             losses = self.compute_loss(output_dict, label)
             loss = sum(losses.values())
             self.optimizer.zero_grad()
-            loss.backward()
-            if du.world_size() > 1:
-                du.allreduce_mean_([p.grad for p in self.model.parameters() if p.grad is not None])
+            self.backward(loss)
             self.optimizer.step()
 
     def get_code_MITH(self, data_loader, length: int):
         img_buffer = torch.empty(length, self.args.output_dim, dtype=torch.float).to(self.rank)
         text_buffer = torch.empty(length, self.args.output_dim, dtype=torch.float).to(self.rank)
+        seen = []
         with torch.no_grad():
             for image, text, key_padding_mask, label, index in data_loader:
                 image = image.to(self.rank, non_blocking=True)
@@ -150,6 +149,8 @@ class MITHTrainer(TrainBase):
                 index = index.to(self.rank)
                 img_buffer[index, :] = N.sign_codes(od['img_tokens_hash'] + od['img_cls_hash'])
                 text_buffer[index, :] = N.sign_codes(od['txt_tokens_hash'] + od['txt_cls_hash'])
+                seen.append(index)
+        self._gather_code_shards(seen, img_buffer, text_buffer)
         return img_buffer, text_buffer, 0
 
     def _codes_for_eval(self):

@@ -6,7 +6,6 @@ import os
 import torch
 
 import cmh_native as N
-import dist_utils as du
 from model.TwDH import MTwDH
 from model.base.optimization import BertAdam
 from train.base import TrainBase
@@ -103,9 +102,7 @@ class TwDHTrainer(TrainBase):
             loss = self.compute_loss(il, tl, ish, tsh, label, index.numpy(), lc, sc)
             all_loss += loss
             self.optimizer.zero_grad()
-            loss.backward()
-            if du.world_size() > 1:
-                du.allreduce_mean_([p.grad for p in self.model.parameters() if p.grad is not None])
+            self.backward(loss)
             self.optimizer.step()
         self.logger.info(f">>>>>> [{epoch}/{self.args.epochs}] loss: {all_loss.data / (len(self.train_loader))}")
 
@@ -120,11 +117,13 @@ class TwDHTrainer(TrainBase):
         long_img, long_txt = mk(self.args.output_dim), mk(self.args.output_dim)
         s_img = {str(d): mk(d) for d in short_dims}
         s_txt = {str(d): mk(d) for d in short_dims}
+        seen = []
         with torch.no_grad():
             for image, text, label, index in data_loader:
                 image = image.to(self.rank, non_blocking=True)
                 text = text.to(self.rank, non_blocking=True)
                 index = index.to(self.rank)
+                seen.append(index)
                 li, si = self.model.encode_image(image)
                 lt, st = self.model.encode_text(text)
                 long_img[index, :] = self.make_hash_code(li)
@@ -133,6 +132,7 @@ class TwDHTrainer(TrainBase):
                     s_img[k][index, :] = self.make_hash_code(v)
                 for k, v in st.items():
                     s_txt[k][index, :] = self.make_hash_code(v)
+        self._gather_code_shards(seen, long_img, long_txt, *s_img.values(), *s_txt.values())
         return long_img, long_txt, s_img, s_txt
 
     def valid(self, epoch, k=None):

@@ -17,6 +17,7 @@ import torch
 from torch.utils.data import DataLoader
 
 import cmh_native as N
+import dist_utils as du
 from utils import get_logger, get_summary_writer
 from utils.calc_utils import calc_map_k_matrix as calc_map_k
 
@@ -33,6 +34,8 @@ class TrainBase(object):
         self.rank = getattr(args, "rank", rank)   # GPU ID
         self._init_dataset()
         self._init_model()
+        if du.world_size() > 1:          # replicas start from rank 0's weights (heads and loss parameters are drawn at random)
+            du.broadcast_modules_([m for m in vars(self).values() if isinstance(m, torch.nn.Module)])
         self.global_step = 0
         self.max_mapi2t = 0
         self.max_mapt2i = 0
@@ -79,22 +82,34 @@ class TrainBase(object):
         self.args.query_num = len(self.query_labels)
         self.logger.info(f"query shape: {self.query_labels.shape}")
         self.logger.info(f"retrieval shape: {self.retrieval_labels.shape}")
+        self.train_sampler, self.train_loader = self._loader(train_data, train=True)
+        _, self.query_loader = self._loader(query_data, train=False)
+        _, self.retrieval_loader = self._loader(retrieval_data, train=False)
+
+    def _loader(self, data, train):
+        """Upstream: DataLoader(batch_size, num_workers, pin_memory=True, shuffle=True) for all three sets (train/base.py:90-113).
+        With one process per GPU each rank draws its share of every epoch from a DistributedSampler (the short tail is
+        padded by repeats, so all ranks run the same number of steps); evaluation sets are cut the same way, unshuffled."""
+        sampler = None
+        if du.world_size() > 1:
+            from torch.utils.data.distributed import DistributedSampler
+            sampler = DistributedSampler(data, shuffle=train, seed=int(getattr(self.args, "seed", 0) or 0))
+        kw = dict(batch_size=self.args.batch_size, num_workers=self.args.num_workers, sampler=sampler, shuffle=sampler is None)
         if self.args.dataset == 'synthetic':
-            mk = lambda d: DataLoader(dataset=d, batch_size=self.args.batch_size, num_workers=self.args.num_workers,
-                                      pin_memory=True, shuffle=True)
-        else:
-            from dataset.base import DeviceLoader
-            mk = lambda d: DeviceLoader(d, self.rank, batch_size=self.args.batch_size, num_workers=self.args.num_workers,
-                                        shuffle=True)
-        self.train_loader, self.query_loader, self.retrieval_loader = mk(train_data), mk(query_data), mk(retrieval_data)
+            return sampler, DataLoader(dataset=data, pin_memory=True, **kw)
+        from dataset.base import DeviceLoader
+        return sampler, DeviceLoader(data, self.rank, **kw)
 
     def _init_model(self):
         self.model = None
         self.model_ddp = None
 
     def _init_writer(self):
-        self.logger = get_logger(os.path.join(self.args.save_dir, "train.log" if self.args.is_train else "test.log"))
-        self.writer = get_summary_writer(os.path.join(self.args.save_dir, "tensorboard"))
+        r = du.dist_rank()
+        self.is_main = r == 0                     # checkpoints, .mat files and the tensorboard directory come from rank 0 only
+        tag = "" if self.is_main else f".rank{r}"
+        self.logger = get_logger(os.path.join(self.args.save_dir, ("train" if self.args.is_train else "test") + tag + ".log"))
+        self.writer = get_summary_writer(os.path.join(self.args.save_dir, "tensorboard" + tag))
 
     def run(self):
         if self.args.is_train:
@@ -113,6 +128,7 @@ class TrainBase(object):
         img_buffer = torch.empty(length, self.args.output_dim, dtype=torch.float).to(self.rank)
         text_buffer = torch.empty(length, self.args.output_dim, dtype=torch.float).to(self.rank)
         encoder_time = 0
+        seen = []
         with torch.no_grad():
             for batch in data_loader:
                 start_encoder_time = time.time()
@@ -124,7 +140,20 @@ class TrainBase(object):
                 encoder_time = time.time() - start_encoder_time
                 img_buffer[index, :] = image_hash
                 text_buffer[index, :] = text_hash
+                seen.append(index)
+        self._gather_code_shards(seen, img_buffer, text_buffer)
         return img_buffer, text_buffer, encoder_time
+
+    def _gather_code_shards(self, seen, *buffers):
+        """With one process per GPU every rank has encoded its share of the set (rows `seen` of each buffer): ONE fused all-gather
+        of (position, codes...) rows fills the rest, so all ranks hold the whole code matrices before ranking."""
+        if du.world_size() == 1 or not seen:
+            return
+        mine = torch.cat(seen)
+        fused, widths = du.fuse_columns(mine.unsqueeze(1), *[b[mine] for b in buffers])      # f32: positions < 2^24 stay exact
+        parts = du.split_columns(du.all_gather_rows(fused, du.row_counts(mine.numel(), fused.device)), widths)
+        for buf, rows in zip(buffers, parts[1:]):
+            du.scatter_by_index(buf, parts[0].view(-1), rows)
 
     def get_code(self, data_loader, length: int):
         return self._code_loop(data_loader, length, lambda i, t, b: (
@@ -143,7 +172,18 @@ class TrainBase(object):
         return self._code_loop(data_loader, length, lambda i, t, b: (
             N.sign_codes(self.model.encode_image(i)[0]), N.sign_codes(self.model.encode_text(t)[0])))
 
+    def backward(self, loss, *loss_modules):
+        """loss.backward(); with one process per GPU also the gradient means over the ranks, each tower's all-reduce queued from
+        inside the backward pass as soon as its last gradient is written (dist_utils.GradSync)."""
+        if du.world_size() > 1 and getattr(self, "_grad_sync", None) is None:
+            self._grad_sync = du.GradSync.for_model(self.model, *loss_modules)
+        loss.backward()
+        if getattr(self, "_grad_sync", None) is not None:
+            self._grad_sync.finish()
+
     def save_model(self, epoch):
+        if not getattr(self, "is_main", True):
+            return
         torch.save(self.model.state_dict(), os.path.join(self.args.save_dir, "model-" + str(epoch) + ".pth"))
         self.logger.info("save mode to {}".format(os.path.join(self.args.save_dir, "model-" + str(epoch) + ".pth")))
 
@@ -153,7 +193,13 @@ class TrainBase(object):
     def train(self):
         self.logger.info("Start train.")
         for epoch in range(self.args.epochs):
+            if getattr(self, "train_sampler", None) is not None:
+                self.train_sampler.set_epoch(epoch)
             self.train_epoch(epoch)
+            if du.world_size() > 1:     # replicas must hold identical weights after every epoch: log a checksum per rank
+                with torch.no_grad():
+                    total = sum(p.double().sum() for p in self.model.parameters())
+                self.logger.info(f">>>>>> [{epoch}/{self.args.epochs}] replica checksum: {float(total)!r}")
             self.valid(epoch)
             self.save_model(epoch)
         self.logger.info(
@@ -211,7 +257,7 @@ class TrainBase(object):
 
     def save_mat(self, query_img, query_txt, retrieval_img, retrieval_txt, mode_name="i2t"):
         """PR_cruve/<bits>-ours-<dataset>-<mode>.mat with q_img q_txt r_img r_txt q_l r_l (train/base.py:328-349)."""
-        if not getattr(self.args, "save_mat", True):
+        if not getattr(self.args, "save_mat", True) or not getattr(self, "is_main", True):
             return
         import scipy.io as scio
         save_dir = os.path.join(self.args.save_dir, "PR_cruve")

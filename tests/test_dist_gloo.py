@@ -51,6 +51,56 @@ def _worker(rank, world, port, out_dir):
     du.allreduce_mean_(gs, bucket_bytes=64)
     assert torch.equal(gs[0], torch.full((5, 3), 1.5)) and torch.equal(gs[1], torch.arange(7, dtype=torch.float32) * 1.5)
     assert torch.equal(gs[2], torch.full((1,), 5.0))
+    # the same means from inside backward: three groups, a parameter that never gets a gradient, one that appears late
+    class Clip(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.visual = torch.nn.Linear(4, 3)
+            self.txt = torch.nn.Linear(4, 3)
+            self.logit_scale = torch.nn.Parameter(torch.ones([]))          # never used: no gradient, like upstream's
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.clip = Clip()
+            self.head = torch.nn.Linear(3, 2)
+            self.sometimes = torch.nn.Parameter(torch.ones(2))
+
+    torch.manual_seed(3 + rank)                               # replicas drawn differently, then made equal to rank 0's
+    model, twin = Model(), Model()
+    model.register_buffer("steps", torch.tensor([rank + 5]))
+    du.broadcast_modules_([model])
+    mine = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    both = [torch.zeros_like(mine) for _ in range(world)]
+    torch.distributed.all_gather(both, mine)
+    assert torch.equal(both[0], both[1]) and int(model.steps) == 5
+    del model.steps
+    twin.load_state_dict(model.state_dict())
+    sync = du.GradSync.for_model(model)
+    assert [len(g) for g in sync.groups] == [3, 2, 3]
+    sent_early = []
+    for step in range(4):
+        x = torch.randn(6, 4, generator=g) * (rank + 1)
+        for m in (model, twin):
+            m.zero_grad()
+            y = m.head(m.clip.visual(x) + m.clip.txt(x)).sum(0)
+            if step >= 2:
+                y = y * m.sometimes
+            y.sum().backward()
+            if m is model:
+                sent_early.append(sum(sync._sent))
+                sync.finish()
+            else:
+                du.allreduce_mean_([p.grad for p in m.parameters() if p.grad is not None])
+        for (name, p), q in zip(model.named_parameters(), twin.parameters()):
+            assert (p.grad is None) == (q.grad is None), name
+            if p.grad is not None:
+                assert torch.equal(p.grad, q.grad), (step, name)
+    # step 0 learns the pattern; steps 1 and 3 send all three groups from the hooks; in step 2 `sometimes` is new, so its
+    # group no longer matches what was learnt and leaves from finish()
+    assert sent_early == [0, 3, 2, 3], sent_early
+    assert model.clip.logit_scale.grad is None
+    sync.remove()
     # query-sharded AP, gathered in query order, summed like the reference
     ap = torch.rand(n, generator=g)
     full = du.gather_query_sharded_ap(ap[lo:hi], n)
