@@ -143,11 +143,11 @@ class DeviceLoader:
         # the subclass may carry extra fields (MITH: key_padding_mask); swap a finished image into its tuple
         return (image,) + tuple(batch[1:])
 
-    def _cached_epoch(self):
+    def _cached_epoch(self, batches):
         ds = self.dataset
         if self._labels is None:
             self._labels = ds.get_all_label()
-        for batch_index in self.loader.batch_sampler:            # the DataLoader's own order: shuffle / sampler / drop_last as given
+        for batch_index in batches:
             index = torch.as_tensor(batch_index, dtype=torch.int64)
             caption = ds.tokenizer.encode_captions([ds._choose_caption(int(i)) for i in index], ds.maxWords)
             label = torch.stack([ds._load_label(int(i)) for i in index])
@@ -155,10 +155,14 @@ class DeviceLoader:
             yield ds.cached_batch(image, caption, label, index)
 
     def __iter__(self):
-        if self.cache_images and self._filled.all():
-            self.cached_epochs += 1
-            yield from self._cached_epoch()
-            return
+        if self.cache_images:
+            # this epoch's batches in the DataLoader's own order (shuffle / sampler / drop_last as given); when every image they
+            # name is already resident the epoch is served from HBM — under a DistributedSampler a rank's share, not the whole set
+            batches = list(self.loader.batch_sampler)
+            if batches and self._filled[np.concatenate([np.asarray(b, dtype=np.int64) for b in batches])].all():
+                self.cached_epochs += 1
+                yield from self._cached_epoch(batches)
+                return
         for batch in self.loader:
             ragged = batch[0]
             if torch.cuda.is_available() and not ragged.pixels.is_pinned():

@@ -111,6 +111,12 @@ def test_mith_dataset_carries_the_padding_mask(tmp_path, monkeypatch):
     assert loader.cached_epochs == 1 and len(again) == len(first) == 2
     for a, b in zip(first, again):
         assert torch.equal(a[0], b[0]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4]) and torch.equal(b[2], b[1] == 0)
+    # a rank's share under a DistributedSampler is served from the cache once THAT share is resident
+    from torch.utils.data.distributed import DistributedSampler
+    share = DeviceLoader(trn, DEV, batch_size=4, sampler=DistributedSampler(trn, num_replicas=2, rank=1, shuffle=False))
+    one, two = [b for b in share], [b for b in share]
+    assert share.cached_epochs == 1 and [b[4].tolist() for b in one] == [b[4].tolist() for b in two] == [[1, 3, 5, 7], [9, 11]]
+    assert all(torch.equal(a[0], b[0]) for a, b in zip(one, two)) and torch.equal(one[0][0][0], first[0][0][1])
     plain = DeviceLoader(trn, DEV, cache_images=False, batch_size=6, shuffle=False)
     assert torch.equal(next(iter(plain))[0], first[0][0]) and plain.cached_epochs == 0
     # decoding + native tokenisation inside forked DataLoader workers (they never touch the GPU), batches finished here
