@@ -239,11 +239,11 @@ def main():
     # HBM-side bytes per GEMM launch cannot be counted from inside this process: they come from the two rocprofv3 --pmc
     # passes of this same command (tools/pmc_bench_traffic.sh), committed under profiles/; null if absent / other dtype.
     traffic, traffic_src = None, None
-    tfile = os.path.join(ROOT, "profiles", "r01_e_gemm_traffic.json")
+    tfile = os.path.join(ROOT, "profiles", "r01_h_gemm_traffic.json")
     if a.dtype == "bf16" and os.path.exists(tfile):
         with open(tfile) as fh:
             traffic = json.load(fh)["traffic_bytes_per_launch"]
-        traffic_src = "profiles/r01_e_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, (2*FETCH+WRITE)*1024)"
+        traffic_src = "profiles/r01_h_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, (2*FETCH+WRITE)*1024)"
     out = {
         "metric": "image+text pairs/s encoded+hashed per GPU; mAP@K eval wallclock (64-bit)",
         "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
