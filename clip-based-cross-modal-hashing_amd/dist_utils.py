@@ -175,7 +175,9 @@ class GradSync:
 
     Which parameters receive a gradient is learnt from the previous step (the first step sends everything from `finish()`);
     a gradient that shows up after its group was sent goes out in `finish()`; one that stays away only delays its group
-    until `finish()`.  The result is the same as allreduce_mean_ over the same gradients: same sums, same division."""
+    until `finish()`.  The result is the same as allreduce_mean_ over the same gradients: same sums, same division.
+    Contract (as for allreduce_mean_): in a given step every rank produces gradients for the same parameters, one backward
+    pass per `finish()`; the messages then have the same composition and order on all ranks."""
 
     def __init__(self, groups):
         self.world = world_size()
