@@ -113,6 +113,58 @@ def cpu_baseline(L, bits, budget_s=10.0):
                       f"numpy restatement: {n_np} pairs in {dt_np:.1f} s (batches of {B}) = {v_np:.1f} pairs/s; 224x224 + {L} tokens, ViT-B/32 fp32"}
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` (N > 1) without a launcher around it: start N ranks of this same command under
+    torch.distributed.run (one process per GPU, RCCL) and pass rank 0's JSON line through.  This parent process never touches
+    the GPU (nothing here initialises HIP); children are fresh processes, and a failed group is replaced by a fresh group once,
+    on a new port, before giving up with a non-zero exit code."""
+    import socket
+    import subprocess
+    last = None
+    for attempt in range(2):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CMH_BENCH_CHILD="1")
+        last = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        lines = [ln for ln in last.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+        if last.returncode == 0 and lines:
+            print(lines[-1], flush=True)
+            return 0
+        print(f"bench.py: {n_gpus}-rank group exited with code {last.returncode} (attempt {attempt + 1})", file=sys.stderr, flush=True)
+    return last.returncode or 1
+
+
+def flip_rates(clip, heads, image, text):
+    """Sign-bit disagreement of the K-bit codes between the benchmarked arithmetic mode and the f32 parity mode (the reference's
+    model.float() arithmetic) on the bench batch, per tower: the number behind "bit-exact sign()" for a low-precision
+    mode.  Also the cosine of the 512-d features."""
+    import cmh_native as N
+    mode = clip.gemm_dtype
+    out = {}
+    with torch.no_grad():
+        feats = {}
+        for m in (mode, "f32"):
+            clip.set_gemm_dtype(m)
+            feats[m] = (clip.encode_image(image).float(), clip.encode_text(text).float())
+        clip.set_gemm_dtype(mode)
+        tot_flip = tot_bits = 0
+        for side, head, k in (("image", heads[0], 0), ("text", heads[1], 1)):
+            ca, cb = N.sign_codes(head(feats[mode][k])), N.sign_codes(head(feats["f32"][k]))
+            flips = int((ca != cb).sum().item())
+            tot_flip += flips
+            tot_bits += ca.numel()
+            cos = torch.nn.functional.cosine_similarity(feats[mode][k], feats["f32"][k], dim=1)
+            out[side] = {"flip_rate": round(flips / ca.numel(), 6), "flipped_bits": flips, "bits": ca.numel(),
+                         "feature_cosine_min": round(float(cos.min()), 6), "feature_cosine_mean": round(float(cos.mean()), 6)}
+        out["both_towers"] = round(tot_flip / tot_bits, 6)
+        out["samples"] = int(image.shape[0])
+        out["what"] = f"{heads[0].fc.weight.shape[0]}-bit sign() codes of the bench batch, {mode} mode vs f32 mode, random-init weights"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,9 +184,12 @@ def main():
                     help="also time the training step when --gpus > 1 (default: single-GPU runs only, so that the secondary "
                          "metric's gradient all-reduce can never stall the headline scaling line)")
     ap.add_argument("--no-overlap-towers", action="store_true", help="run the text tower after the image tower on one stream")
+    ap.add_argument("--no-precision-legs", action="store_true", help="skip flip_rate_vs_f32 and the timed f32-mode leg")
     ap.add_argument("--map-queries", type=int, default=5000)
     ap.add_argument("--map-db", type=int, default=15015)
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:     # started bare: become the launcher of N ranks (before any GPU call)
+        sys.exit(self_launch(a.gpus))
 
     import cmh_native as N
     import dist_utils as du
@@ -146,7 +201,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     rank, world, _ = du.init_from_env()
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local)
     B, L, K, C = a.batch, a.seq_len, a.bits, a.classes
 
@@ -249,6 +304,9 @@ def main():
         "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "residual_stream": ("fp16" if a.dtype == "bf16" and os.environ.get("CMH_RESID_F16", "1") != "0" else "f32"),
+        "arithmetic": ("bf16 MFMA operands, f32 accumulate, f32 LayerNorm statistics / softmax, fp16 residual stream" if a.dtype == "bf16"
+                       else "f32 operands on the f32 MFMA (exact fma chain), f32 everywhere: the reference's model.float() arithmetic"),
         "config": {"workload": "configs[1]: DSPH flickr25k output-dim 64, ViT-B/32, batch 256/GPU, 224x224 + "
                                f"{L}-token captions: encode_image+encode_text -> LinearHash -> sign -> pack -> "
                                "[all-gather] -> HyP loss fwd", "per_gpu_batch": B, "global_batch": B * world,
@@ -270,6 +328,37 @@ def main():
                                      "overlap when the towers share the GPU); value/ms_per_step are from the overlapped region"),
                      "gemm_ms_per_step_serialized": round(gemm_ms / a.steps, 4)},
     }
+
+    if rank == 0 and a.dtype != "f32" and not a.no_precision_legs:
+        try:
+            # the precision story of the benchmarked mode: sign flips against the f32 parity mode on this very batch, and the same
+            # step timed in f32 mode (towers serialized so that the per-launch events time the kernels)
+            out["flip_rate_vs_f32"] = flip_rates(clip, (img_head, txt_head), image, text)
+            clip.set_gemm_dtype("f32")
+            nf = max(2, min(a.steps, 5))
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            tf0 = time.perf_counter()
+            for _ in range(nf):
+                step()
+            torch.cuda.synchronize()
+            f32_ms = (time.perf_counter() - tf0) / nf * 1e3
+            N.prof_gemm_begin(nf * 128)
+            for _ in range(nf):
+                step(overlap=False)
+            torch.cuda.synchronize()
+            g_ms, g_fl, g_n = N.prof_gemm_end()
+            f32_tf = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+            out["f32_mode"] = {"pairs_per_s": round(B / f32_ms * 1e3, 2), "ms_per_step": round(f32_ms, 3), "steps": nf,
+                               "roofline": {"bound": "mfma", "achieved": round(f32_tf, 2), "peak": PEAK_TFLOPS["f32"], "unit": "TFLOP/s",
+                                            "frac": round(f32_tf / PEAK_TFLOPS["f32"], 4), "launches": int(g_n)},
+                               "what": "the same step with set_gemm_dtype('f32'): the parity mode (v_mfma_f32_16x16x4_f32, f32 residual stream)"}
+            clip.set_gemm_dtype(a.dtype)
+            step()
+        except Exception as exc:
+            out["f32_mode"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            clip.set_gemm_dtype(a.dtype)
 
     if not a.no_map_eval:
         # secondary metric: 4 x calc_map_k at MIRFlickr scale, 64-bit, codes resident; queries sharded over ranks

@@ -90,6 +90,7 @@ SIGNATURES = {
     "cmh_linear_gemm": (C.c_int, [_i32, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "cmh_layernorm": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _p]),
     "cmh_attention": (C.c_int, [_i32, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
+    "cmh_gemm_tuning": (C.c_int, [_i32, _i32]),
     "cmh_prof_gemm_begin": (C.c_int, [_i32]),
     "cmh_prof_gemm_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "cmh_cast_f32_to_bf16": (C.c_int, [_p, _p, _i64, _p]),
@@ -240,6 +241,11 @@ def cast_bf16(src: torch.Tensor) -> torch.Tensor:
     dst = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
     check(lib().cmh_cast_f32_to_bf16(ptr(src), ptr(dst), src.numel(), stream_ptr(src.device)), "cmh_cast_f32_to_bf16")
     return dst
+
+
+def gemm_tuning(tile_rows: int = -1, order_group: int = -1):
+    """Pin the wide GEMM's tile height (96 / 128 / 160) and tile-order group (0 = n-fastest); -1 = automatic."""
+    check(lib().cmh_gemm_tuning(int(tile_rows), int(order_group)), "cmh_gemm_tuning")
 
 
 def prof_gemm_begin(max_launches: int):

@@ -55,31 +55,42 @@ typedef __attribute__((address_space(3))) void* w_lptr_t;
 #ifdef W_STAMPS
 __device__ unsigned g_wide_stamps[256 * 8 * 4];
 #endif
+#ifdef W_TIMELINE   // diagnostic build only (tools/wide_timeline.py): wall-clock (100 MHz) stamps of each workgroup's phases
+__device__ unsigned long long g_wide_tl[256 * 8];
+#define W_TL(k) do { if (threadIdx.x == 0) g_wide_tl[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define W_TL(k) do { } while (0)
+#endif
 
 template <bool F32, bool OUTBF, int MF>   // MF = 16-row m-fragments per wave: tile rows = 32*MF (160, or 128 when that quantises better)
 __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__ X, const char* __restrict__ W,
                                                         const float* __restrict__ bias, const float* residual,
-                                                        void* out, int M, int N, int K, int epi, int ksplit) {
+                                                        void* out, int M, int N, int K, int epi, int ksplit, int ordG) {
   constexpr int BMt = 32 * MF;                       // tile rows
   constexpr int WR = 16 * MF;                        // rows per wave
   constexpr int STG = wWBytes + BMt * wRowBytes;     // bytes per stage: 52 KB (MF = 5) or 48 KB (MF = 4)
   constexpr int XP = BMt / 8;                        // X pieces of 1 KiB per stage: 20 or 16
   constexpr int NPEND = 2 * MF;                      // deferred 16-byte stores per lane per tile
   constexpr int NM = 4 * MF;                         // MFMAs per 32-deep half-step
-  static_assert(MF == 4 || MF == 5, "wave layout: 2(m) x 4(n) waves of MF x 4 fragments");
+  static_assert(MF >= 3 && MF <= 5, "wave layout: 2(m) x 4(n) waves of MF x 4 fragments");
+  constexpr int PSTEP = MF == 3 ? 2 : 3;             // one LDS-DMA piece per PSTEP MFMAs: 6 (MF = 3, 4) or 7 pieces in 4*MF MFMAs
   __shared__ __attribute__((aligned(1024))) char lds[3 * STG];
 
   constexpr int ELT = F32 ? 4 : 2;
   constexpr int BK = wRowBytes / ELT;
 
   const int tid = threadIdx.x;
+  W_TL(0);   // entry
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wid & 3, wm = wid >> 2;
   const int sub = lane >> 3;
   const int frow = lane & 15;
   const int fq = lane >> 4;
-  const bool three = wid < XP - 16;   // waves 0..3 move a third X piece per stage
+  const bool three = wid < XP - 16;   // waves 0..3 move a third X piece per stage (MF = 5)
+  // every wave issues >= 6 pieces per stage (the counted vmcnt waits rely on it): with 12 X pieces (MF = 3) waves 4..7 have no
+  // second X piece of their own and fetch their first one again (same bytes to the same LDS address)
+  const int xpiece1 = wid + 8 < XP ? wid + 8 : wid;
 
   // ---- this workgroup's tiles: XCD x = blockIdx%8 owns a contiguous range of the n-fastest tile order ----
   const int tiles_n = N / wBN;
@@ -96,6 +107,25 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   if (my_tiles == 0) return;
 
   const int nk = K / BK / ksplit;   // K-steps per (virtual) tile
+  // Tile order inside the n-fastest ranges above would sweep ALL of W (3.5 MB at N = 2304, K = 768) with every round of an XCD's
+  // 32 workgroups: more than its 4 MiB L2 holds next to the X tiles and the outputs passing through, so W came back from the
+  // Infinity Cache once per round (round 1: 4.4x read amplification on the QKV / c_fc shapes).  Order: bands of `band` m-tiles
+  // (one band ~ one XCD's share), inside a band groups of G n-panels, inside a group m-tile-major: an XCD's concurrent tiles share
+  // G W panels (<= 1.6 MB) and its band's X tiles (~2.5 MB), and the next group re-reads only the X tiles, still in L2.
+  // (ordG = n-panels per group, chosen by the host: wide_order_group(); 0 = the plain n-fastest order, for A/B runs)
+  const int band = (tiles_m + 7) >> 3;
+  auto tile_coords = [&](int logical, int& tm, int& tn) {
+    if (ordG == 0) { tm = logical / tiles_n; tn = logical - tm * tiles_n; return; }
+    const int b = logical / (band * tiles_n);
+    const int blen = tiles_m - b * band < band ? tiles_m - b * band : band;   // the last band may be shorter
+    const int rem = logical - b * band * tiles_n;
+    const int g = rem / (blen * ordG);
+    const int glen = tiles_n - g * ordG < ordG ? tiles_n - g * ordG : ordG;   // the last group may be narrower
+    const int rem2 = rem - g * blen * ordG;
+    const int mi = rem2 / glen;
+    tm = b * band + mi;
+    tn = g * ordG + (rem2 - mi * glen);
+  };
   const uint32_t row_stride = static_cast<uint32_t>(K) * ELT;
 
   // ---- issue side.  DMA source = uniform tile base (SGPRs) + 32-bit per-lane offset (one VGPR per piece):
@@ -111,14 +141,15 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   auto set_issue_tile = [&](int ti) {
     const int virt = range_lo + slot + ti * per_xcd_blocks;
     const int split = virt / base_total, logical = virt - split * base_total;
-    const int tm = logical / tiles_n, tn = logical - tm * tiles_n;
+    int tm, tn;
+    tile_coords(logical, tm, tn);
     const int m0 = tm * BMt, n0 = tn * wBN;
     const size_t kbase = static_cast<size_t>(split) * nk * wRowBytes;
     Wt = W + static_cast<size_t>(n0) * row_stride + kbase;
     Xt = X + kbase;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const int row = (wid + 8 * i) * 8 + sub;
+      const int row = (i == 1 ? xpiece1 : wid + 8 * i) * 8 + sub;
       int xr = m0 + row;
       xr = xr < M ? xr : M - 1;   // rows past M are computed on duplicated data and never stored
       offX[i] = static_cast<uint32_t>(xr) * row_stride + (((lane & 7) ^ (row & 7)) << 4);   // < 4 GiB: M*K*ELT checked on host
@@ -132,7 +163,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
       __builtin_amdgcn_global_load_lds((w_gptr_t)(Wt + koff + offW[p]), (w_lptr_t)(base + (wid * 4 + p) * 1024), 16, 0, 0);
     else if (p < 6)
       __builtin_amdgcn_global_load_lds((w_gptr_t)(Xt + koff + offX[p - 4]),
-                                       (w_lptr_t)(base + wWBytes + (wid + 8 * (p - 4)) * 1024), 16, 0, 0);
+                                       (w_lptr_t)(base + wWBytes + (p == 4 ? wid : xpiece1) * 1024), 16, 0, 0);
     else if (three)
       __builtin_amdgcn_global_load_lds((w_gptr_t)(Xt + koff + offX[2]), (w_lptr_t)(base + wWBytes + (wid + 16) * 1024), 16, 0, 0);
   };
@@ -166,7 +197,8 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
     const uint32_t bo = static_cast<uint32_t>(buf) * STG;
     const uint32_t w = (aW + bo) ^ (ks ? 64u : 0u), x = (aX + bo) ^ (ks ? 64u : 0u);
     W_READ(fw[0], w, 0); W_READ(fw[1], w, 2048); W_READ(fw[2], w, 4096); W_READ(fw[3], w, 6144);
-    W_READ(fx[0], x, 0); W_READ(fx[1], x, 2048); W_READ(fx[2], x, 4096); W_READ(fx[3], x, 6144);
+    W_READ(fx[0], x, 0); W_READ(fx[1], x, 2048); W_READ(fx[2], x, 4096);
+    if constexpr (MF >= 4) W_READ(fx[3], x, 6144);
     if constexpr (MF == 5) W_READ(fx[4], x, 8192);
   };
 #define W_WAIT_FRAGS(cnt, fw, fx)                                                                                \
@@ -175,10 +207,14 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
       asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                                 \
                    : "+v"(fw[0]), "+v"(fw[1]), "+v"(fw[2]), "+v"(fw[3]), "+v"(fx[0]), "+v"(fx[1]), "+v"(fx[2]),  \
                      "+v"(fx[3]), "+v"(fx[MF - 1])::"memory");                                                   \
-    else                                                                                                         \
+    else if constexpr (MF == 4)                                                                                  \
       asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                                 \
                    : "+v"(fw[0]), "+v"(fw[1]), "+v"(fw[2]), "+v"(fw[3]), "+v"(fx[0]), "+v"(fx[1]), "+v"(fx[2]),  \
                      "+v"(fx[3])::"memory");                                                                     \
+    else                                                                                                         \
+      asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                                 \
+                   : "+v"(fw[0]), "+v"(fw[1]), "+v"(fw[2]), "+v"(fw[3]), "+v"(fx[0]), "+v"(fx[1]), "+v"(fx[2])   \
+                   ::"memory");                                                                                  \
   } while (0)
 
   // ---- deferred stores of the previous tile (bf16 outputs only) --------------------------------------------
@@ -189,10 +225,8 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   const int sps = (NPEND + nk - 1) / nk;   // stores per K-step so that all 10 leave within one tile's K loop
   auto store_pending = [&](int idx) {
     switch (idx) {   // compile-time register choice per case: no dynamically indexed vector arrays (they would go to scratch)
-#define W_ST(j) case j: *reinterpret_cast<w_u32x4_t*>(pend_ptr + (j / 2) * row16 + (j % 2) * 32) = pend[j]; break;
-      W_ST(0) W_ST(1) W_ST(2) W_ST(3) W_ST(4) W_ST(5) W_ST(6) W_ST(7)
-      case 8: if constexpr (MF == 5) *reinterpret_cast<w_u32x4_t*>(pend_ptr + 4 * row16) = pend[NPEND - 2]; break;
-      case 9: if constexpr (MF == 5) *reinterpret_cast<w_u32x4_t*>(pend_ptr + 4 * row16 + 32) = pend[NPEND - 1]; break;
+#define W_ST(j) case j: if constexpr (j < NPEND) *reinterpret_cast<w_u32x4_t*>(pend_ptr + (j / 2) * row16 + (j % 2) * 32) = pend[j < NPEND ? j : 0]; break;
+      W_ST(0) W_ST(1) W_ST(2) W_ST(3) W_ST(4) W_ST(5) W_ST(6) W_ST(7) W_ST(8) W_ST(9)
 #undef W_ST
       default: break;
     }
@@ -286,8 +320,8 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
 #pragma unroll
     for (int b = 0; b < MF; ++b) acc[a][b] = w_f32x4_t{0.f, 0.f, 0.f, 0.f};
   if (res_first) {
-    const int logical = range_lo + slot;
-    const int tm = logical / tiles_n, tn = logical - tm * tiles_n;
+    int tm, tn;
+    tile_coords(range_lo + slot, tm, tn);
     add_residual(tm * BMt, tn * wBN);
   }
   set_issue_tile(0);
@@ -300,6 +334,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // group B issues stage 2 in the first half of K-step 0
   }
   __builtin_amdgcn_s_barrier();
+  W_TL(1);   // first stage landed
 
   int cur = 0;
   int ns = 0;                   // deferred stores issued since the last counted wait
@@ -318,7 +353,9 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
 #ifndef W_ABL_NOREAD
       load_frags(f1w, f1x, cur, 1);                                   // 1
 #endif
-      W_WAIT_FRAGS(9, f0w, f0x);                                      //    F0 (older than the 9 F1 reads) is in registers
+      if constexpr (MF == 5) W_WAIT_FRAGS(9, f0w, f0x);               //    F0 (older than the 4 + MF F1 reads) is in registers
+      else if constexpr (MF == 4) W_WAIT_FRAGS(8, f0w, f0x);
+      else W_WAIT_FRAGS(7, f0w, f0x);
       __builtin_amdgcn_sched_barrier(0);
       auto deferred_stores = [&]() {
         if constexpr (OUTBF) {
@@ -336,7 +373,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
 #pragma unroll
       for (int i = 0; i < NM; ++i) {                                  // 2
 #ifndef W_ABL_NODMA
-        if constexpr (GB) { if (i % 3 == 0) issue_piece(i / 3); }
+        if constexpr (GB) { if (i % PSTEP == 0) issue_piece(i / PSTEP); }
 #endif
         mfma(f0w[i / MF], f0x[i % MF], acc[i / MF][i % MF]);
         if constexpr (GB) { if (i % 3 == 2) __builtin_amdgcn_sched_barrier(0); }
@@ -366,7 +403,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
 #ifndef W_ABL_NODMA
-          if constexpr (!GB) { if (i % 3 == 0) issue_piece(i / 3); }
+          if constexpr (!GB) { if (i % PSTEP == 0) issue_piece(i / PSTEP); }
 #endif
 #ifndef W_ABL_NOREAD
           if (i == 1) W_READ(f0w[0], nW, 0);
@@ -376,7 +413,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
           if (i == 5) W_READ(f0x[0], nX, 0);
           if (i == 6) W_READ(f0x[1], nX, 2048);
           if (i == 7) W_READ(f0x[2], nX, 4096);
-          if (i == 8) W_READ(f0x[3], nX, 6144);
+          if constexpr (MF >= 4) { if (i == 8) W_READ(f0x[MF >= 4 ? 3 : 0], nX, 6144); }
           if constexpr (MF == 5) { if (i == 9) W_READ(f0x[MF - 1], nX, 8192); }
 #endif
           mfma(f1w[i / MF], f1x[i % MF], acc[i / MF][i % MF]);
@@ -388,11 +425,14 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
       cur = nxt;
     }
     pend_valid = false;   // sps * nk >= 10: every deferred store of the previous tile has been issued
+    if (ti == 0) W_TL(2);              // first tile's K loop done
+    if (ti == my_tiles - 1) W_TL(3);   // last tile's K loop done
 
     // ---- epilogue of tile ti (the next tile's first stages are already in flight) ----------------------------
     const int virt = range_lo + slot + ti * per_xcd_blocks;
     const int split = virt / base_total, logical = virt - split * base_total;
-    const int tm = logical / tiles_n, tn = logical - tm * tiles_n;
+    int tm, tn;
+    tile_coords(logical, tm, tn);
     const int m0 = tm * BMt, n0 = tn * wBN;
     // All loads first, then all stores: a load issued behind a store (or waited for with DMA in flight) would wait for
     // every older store to be acknowledged.
@@ -516,6 +556,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
     // Epilogue-issued stores are younger than every DMA in flight, so the next counted waits (P + ns outstanding) would
     // simply also retire the DMAs: safe, slightly conservative.  A partial tile may have skipped store instructions.
     if (!full) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ns = 0; }
+    if (ti == my_tiles - 1) W_TL(4);   // last epilogue's stores issued
   }
   };
   if (group_b) run(std::true_type{}); else run(std::false_type{});
@@ -524,6 +565,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
     for (int k = 0; k < 4; ++k) g_wide_stamps[(blockIdx.x * 8 + wid) * 4 + k] = st_sum[k];
 #endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the over-issued stages must land before the LDS is released
+  W_TL(5);   // everything this workgroup issued has completed
 }
 
 bool gemm_wide_supported(int N) { return N % wBN == 0; }
@@ -536,6 +578,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     for (int s = 1; s < S; ++s) a += *reinterpret_cast<const w_f32x4_t*>(partial + static_cast<size_t>(s) * n + i * 4);
     *reinterpret_cast<w_f32x4_t*>(out + i * 4) = a;
   }
+}
+
+// Tuning overrides (cmh_gemm_tuning; initial values from CMH_GEMM_BM / CMH_GEMM_ORDER): -1 = decided per launch
+static int g_force_rows = []() { const char* e = getenv("CMH_GEMM_BM"); return e ? atoi(e) : -1; }();
+static int g_force_order = []() { const char* e = getenv("CMH_GEMM_ORDER"); return e ? atoi(e) : -1; }();
+
+// n-panels per group of the tile order (see tile_coords in the kernel); 0 = the n-fastest order
+static int wide_order_group(int N) {
+  if (g_force_order >= 0) return g_force_order;
+  const int tiles_n = N / wBN;
+  return tiles_n <= 4 ? tiles_n : (tiles_n % 4 == 0 ? 4 : (tiles_n % 3 == 0 ? 3 : 4));
 }
 
 static int wide_cus() {
@@ -570,10 +623,10 @@ int launch_gemm_wide_splitk(int dt, const void* A, const void* W, float* out, fl
   const int grid = total < cus ? ((total + 7) & ~7) : cus;
   if (dt == CMH_F32)
     hipLaunchKernelGGL((gemm_wide_kernel<true, false, 5>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),
-                       static_cast<const char*>(W), nullptr, nullptr, partials, M, N, K, 0, S);
+                       static_cast<const char*>(W), nullptr, nullptr, partials, M, N, K, 0, S, wide_order_group(N));
   else
     hipLaunchKernelGGL((gemm_wide_kernel<false, false, 5>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),
-                       static_cast<const char*>(W), nullptr, nullptr, partials, M, N, K, 0, S);
+                       static_cast<const char*>(W), nullptr, nullptr, partials, M, N, K, 0, S, wide_order_group(N));
   const size_t n = static_cast<size_t>(M) * N;
   const size_t blocks = (n / 4 + 255) / 256;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, partials, S, n, out);
@@ -586,27 +639,35 @@ int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, co
   if (static_cast<size_t>(M) * K * esz >= (1ull << 32) || static_cast<size_t>(wBN) * K * esz >= (1ull << 32))
     return fail(CMH_ERR_INVALID, "gemm: operand of %zu bytes exceeds the 32-bit offset range of the wide kernel",
                 static_cast<size_t>(M) * K * esz);
-  // Tile rows: 160 (MF = 5) or 128 (MF = 4), whichever needs less time for this M on the chip's CUs: rounds of workgroups x
-  // (K-steps + ~4 K-steps of per-tile overhead) x rows.  M = 12 800 / 19 712 (the dense towers) take 160; the packed text
-  // rows (M ~ 10 k and odd) quantise 20 % better with 128 (N = 512: 132 -> 166 tiles on 256 CUs).  CMH_GEMM_BM=128|160 forces one.
+  // Tile rows: 160 (MF = 5), 128 (MF = 4) or 96 (MF = 3), whichever needs less time for this M on the chip's CUs: rounds of
+  // workgroups x (K-steps + ~4 K-steps of per-tile overhead) x (rows + a share that does not shrink with the tile).  M = 12 800 /
+  // 19 712 (the dense towers) take 160; the packed text rows (M ~ 10 k) take 128 at N = 1536 / 2048 and 96 at N = 512, where one
+  // round of 220 tiles keeps 86 % of the CUs busy instead of 65 % (166 tiles of 128 rows).  CMH_GEMM_BM=96|128|160 forces one.
   const int cus = wide_cus();
   const int nk = K / (dt == CMH_F32 ? 32 : 64);
-  auto cost = [&](int mf) {
+  auto cost = [&](int mf) {   // rounds x (rows + the per-K-step cost that does not shrink with the tile: W fragment reads, barrier) x K-steps
     const int tiles = (N / wBN) * ((M + 32 * mf - 1) / (32 * mf));
-    return static_cast<long long>((tiles + cus - 1) / cus) * mf * (nk + 4);
+    return static_cast<long long>((tiles + cus - 1) / cus) * (10 * mf + 6) * (nk + 4);
   };
-  static const int forced = []() { const char* e = getenv("CMH_GEMM_BM"); return e ? atoi(e) : 0; }();
-  const int mf = forced == 128 ? 4 : (forced == 160 ? 5 : (cost(4) < cost(5) ? 4 : 5));
+  const int forced = g_force_rows;
+  int mf = 5;
+  if (cost(4) < cost(mf)) mf = 4;
+  if (cost(3) < cost(mf)) mf = 3;
+  if (forced == 96 || forced == 128 || forced == 160) mf = forced / 32;
   const int total = (N / wBN) * ((M + 32 * mf - 1) / (32 * mf));
   int grid = total < cus ? ((total + 7) & ~7) : cus;
+  const int ordg = wide_order_group(N);
 #define W_LAUNCH(F32, OUTBF)                                                                                              \
   do {                                                                                                                    \
-    if (mf == 4)                                                                                                          \
+    if (mf == 3)                                                                                                          \
+      hipLaunchKernelGGL((gemm_wide_kernel<F32, OUTBF, 3>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),    \
+                         static_cast<const char*>(W), bias, residual, out, M, N, K, epi, 1, ordg);                            \
+    else if (mf == 4)                                                                                                     \
       hipLaunchKernelGGL((gemm_wide_kernel<F32, OUTBF, 4>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),    \
-                         static_cast<const char*>(W), bias, residual, out, M, N, K, epi, 1);                              \
+                         static_cast<const char*>(W), bias, residual, out, M, N, K, epi, 1, ordg);                            \
     else                                                                                                                  \
       hipLaunchKernelGGL((gemm_wide_kernel<F32, OUTBF, 5>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),    \
-                         static_cast<const char*>(W), bias, residual, out, M, N, K, epi, 1);                              \
+                         static_cast<const char*>(W), bias, residual, out, M, N, K, epi, 1, ordg);                            \
   } while (0)
   const bool obf = epi & (EPI_OUT_BF16 | EPI_OUT_F16);   // 16-bit outputs share the packed store path
   if (dt == CMH_F32) { if (obf) W_LAUNCH(true, true); else W_LAUNCH(true, false); }
@@ -617,6 +678,24 @@ int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, co
 
 }  // namespace cmh
 
+extern "C" int cmh_gemm_tuning(int32_t tile_rows, int32_t order_group) {
+  using namespace cmh;
+  CMH_CHECK_ARG(tile_rows == -1 || tile_rows == 96 || tile_rows == 128 || tile_rows == 160, "gemm_tuning: tile_rows %d (-1, 96, 128, 160)", tile_rows);
+  CMH_CHECK_ARG(order_group >= -1 && order_group <= 64, "gemm_tuning: order_group %d", order_group);
+  g_force_rows = tile_rows;
+  g_force_order = order_group;
+  return CMH_OK;
+}
+
+#ifdef W_TIMELINE
+extern "C" int cmh_debug_wide_timeline(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(cmh::g_wide_tl), sizeof(unsigned long long) * 256 * 8) == hipSuccess ? 0 : -1;
+}
+extern "C" int cmh_debug_wide_timeline_clear() {
+  static unsigned long long z[256 * 8];
+  return hipMemcpyToSymbol(HIP_SYMBOL(cmh::g_wide_tl), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef W_STAMPS
 extern "C" int cmh_debug_wide_stamps(unsigned* host_out) {
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(cmh::g_wide_stamps), sizeof(unsigned) * 256 * 8 * 4) == hipSuccess ? 0 : -1;

@@ -79,6 +79,52 @@ def all_gather_rows(block: torch.Tensor, counts: list[int] | None = None) -> tor
     return torch.cat([out[r * mx:r * mx + counts[r]] for r in range(world)], dim=0)
 
 
+class _GatherRowsFn(torch.autograd.Function):
+    """all_gather_rows with a backward: every rank computes the SAME loss on the gathered rows, so the gradient of that loss with
+    respect to rank r's block is rows [r*B, (r+1)*B) of the incoming gradient.  It is handed back times `world`: the parameter
+    gradients are then averaged over the ranks (GradSync / allreduce_mean_), and (1/world) * sum_r world * dL/d(rows of r)
+    is the gradient a single GPU would compute for the whole global batch."""
+
+    @staticmethod
+    def forward(ctx, block):
+        ctx.rows, ctx.rank, ctx.world = block.shape[0], dist_rank(), world_size()
+        return all_gather_rows(block)
+
+    @staticmethod
+    def backward(ctx, grad):
+        lo = ctx.rank * ctx.rows
+        return grad[lo:lo + ctx.rows] * float(ctx.world)
+
+
+def gather_loss_inputs(*blocks: torch.Tensor) -> list[torch.Tensor]:
+    """The exchange step of a training iteration (north_star "all-gather of hash codes ... for the pairwise loss"):
+    the per-rank [B_local, w_i] loss inputs (hash outputs, labels, ...) travel as ONE fused [B_local, sum w_i] all-gather and
+    come back as the global-batch tensors [world * B_local, w_i], rank-major, on every rank.  Differentiable (see
+    _GatherRowsFn); blocks that need no gradient (labels) ride along in the same message.  Every rank must contribute the same
+    number of rows (the trainers' DistributedSampler pads the epoch so that they do).  One rank: returned unchanged."""
+    if world_size() == 1:
+        return list(blocks)
+    widths = [b.shape[1] for b in blocks]
+    fused = torch.cat([b.float() for b in blocks], dim=1).contiguous()
+    if fused.requires_grad:
+        whole = _GatherRowsFn.apply(fused)
+    else:
+        whole = all_gather_rows(fused)
+    return list(torch.split(whole, widths, dim=1))
+
+
+def broadcast_tensor_(t: torch.Tensor, src: int = 0) -> torch.Tensor:
+    """t on every rank := rank `src`'s (a random draw that a single-GPU run would make once for the whole batch)."""
+    if world_size() > 1:
+        dist.broadcast(t, src=src)
+    return t
+
+
+def query_shard(n_query: int) -> tuple[int, int]:
+    """This rank's contiguous share [lo, hi) of the queries of an evaluation."""
+    return shard_range(n_query, dist_rank(), world_size())
+
+
 def row_counts(n_local: int, device) -> list[int] | None:
     """Rows every rank contributes to a ragged all_gather_rows (the last batch of an epoch may differ between ranks)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

@@ -54,6 +54,21 @@ class DCHMTTrainer(TrainBase):
     def compute_loss(self, image, text, label, epoch=0, times=0):
         return self.our_loss(image, text, label, epoch, times)
 
+    def _step(self, image, text, label, epoch=0, times=0):
+        """One optimisation step (reference hash_train.py:52-66)."""
+        image = image.to(self.rank, non_blocking=True)
+        text = text.to(self.rank, non_blocking=True)
+        hash_img, hash_text = self.model(image, text)
+        hash_img = torch.cat(hash_img, dim=-1) if isinstance(hash_img, list) else hash_img.view(hash_img.shape[0], -1)
+        hash_text = torch.cat(hash_text, dim=-1) if isinstance(hash_text, list) else hash_text.view(hash_text.shape[0], -1)
+        # several ranks: ONE fused all-gather of [B_local, 4K + C]; similarity_loss (reference :82-114) is O(B^2) in the global batch
+        hash_img, hash_text, label = self.loss_inputs(hash_img, hash_text, label.to(self.rank).float())
+        loss = self.compute_loss(hash_img, hash_text, label, epoch, times)
+        self.optimizer.zero_grad()
+        self.backward(loss)                   # + the gradient means over the ranks when there are several
+        self.optimizer.step()
+        return loss
+
     def train_epoch(self, epoch):
         self.change_state(mode="train")
         self.logger.info(">>>>>> epochs: %d/%d" % (epoch, self.args.epochs))
@@ -62,14 +77,5 @@ class DCHMTTrainer(TrainBase):
         for image, text, label, index in self.train_loader:
             self.global_step += 1
             times += 1
-            image = image.to(self.rank, non_blocking=True)
-            text = text.to(self.rank, non_blocking=True)
-            hash_img, hash_text = self.model(image, text)
-            hash_img = torch.cat(hash_img, dim=-1) if isinstance(hash_img, list) else hash_img.view(hash_img.shape[0], -1)
-            hash_text = torch.cat(hash_text, dim=-1) if isinstance(hash_text, list) else hash_text.view(hash_text.shape[0], -1)
-            loss = self.compute_loss(hash_img, hash_text, label, epoch, times)
-            all_loss += loss.detach()
-            self.optimizer.zero_grad()
-            self.backward(loss)                   # + the gradient means over the ranks when there are several
-            self.optimizer.step()
+            all_loss += self._step(image, text, label, epoch, times).detach()
         self.logger.info(f">>>>>> [{epoch}/{self.args.epochs}] loss: {all_loss.data / (len(self.train_loader))}")

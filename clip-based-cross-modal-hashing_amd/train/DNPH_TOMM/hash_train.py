@@ -52,7 +52,11 @@ class DNPHTOMMTrainer(TrainBase):
         return to_dev(gene_noise(on_host(hash_img), s_vector)), to_dev(gene_noise(on_host(hash_text), s_vector))
 
     def compute_loss(self, hash_img, pre_img, hash_text, pre_text, label):
-        i_noises, t_noises = self.noise_rows(hash_img, hash_text)
+        i_noises, t_noises = self.noise_rows(hash_img, hash_text)        # Hungarian assignment: host work on the rank's own batch
+        # several ranks: ONE fused all-gather of [B_local, 4K + 3C] (hashes, classifier outputs, labels, assigned noise rows);
+        # DNPH_out and the noise term are then evaluated on the global batch
+        hash_img, pre_img, hash_text, pre_text, label, i_noises, t_noises = self.loss_inputs(
+            hash_img, pre_img, hash_text, pre_text, label, i_noises, t_noises)
         return self.DNPH(hash_img, hash_text, pre_img, pre_text, label, label, i_noises, t_noises)
 
     def _step(self, image, text, label):

@@ -50,7 +50,10 @@ class DSPHTrainer(TrainBase):
         """One optimisation step (reference :52-70): forward, HyP loss, backward, BertAdam on the model + SGD on the proxies."""
         dev = self.rank
         image, text, label = (t.to(dev, non_blocking=True) for t in (image, text, label))
-        loss = self.compute_loss(*self.model(image, text), label)
+        hash_img, hash_text = self.model(image, text)
+        # several ranks: ONE fused all-gather of [B_local, 2K + C]; HyP's pairwise terms (loss.py:42-66) see the global batch
+        hash_img, hash_text, label = self.loss_inputs(hash_img, hash_text, label.float())
+        loss = self.compute_loss(hash_img, hash_text, label)
         for opt in (self.optimizer, self.optimizer_loss):
             opt.zero_grad()
         self.backward(loss, self.hyp)             # + the gradient means over the ranks when there are several

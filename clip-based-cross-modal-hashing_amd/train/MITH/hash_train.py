@@ -103,7 +103,11 @@ class MITHTrainer(TrainBase):
         L['cls_inter_likelihood'] = a.hyper_cls_inter * (self.bayesian_loss(self.img_buffer_cls, tc, pair) +
                                                          self.bayesian_loss(self.txt_buffer_cls, ic, pair))
         L['quantization'] = a.hyper_quan * (self.quantization_loss_2(H_i, Bc) + self.quantization_loss_2(H_t, Bc))
-        L['infoNCE'] = a.hyper_info_nce * (self.info_nce_loss(output_dict['res_img_cls'], output_dict['res_txt_cls']) +
+        # the cls-level InfoNCE is the one term that pairs samples WITH EACH OTHER ([B,B] logits, reference :103-118): with several
+        # ranks its inputs are all-gathered (differentiably) so the negatives are the global batch; every other term is a mean of
+        # per-sample values against the replicated memory bank, whose rank-local means average to the global one in GradSync
+        res_i, res_t = du.gather_loss_inputs(output_dict['res_img_cls'], output_dict['res_txt_cls'])
+        L['infoNCE'] = a.hyper_info_nce * (self.info_nce_loss(res_i, res_t) +
                                            a.hyper_alpha * self.info_nce_loss_bmm(output_dict['trans_tokens_i'],
                                                                                   output_dict['trans_tokens_t']))
         # item_1: full gradient to the student (token codes), item_2: a tenth of it to the teacher (cls codes)  (:193-200)

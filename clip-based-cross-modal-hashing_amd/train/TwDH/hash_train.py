@@ -6,6 +6,7 @@ import os
 import torch
 
 import cmh_native as N
+import dist_utils as du
 from model.TwDH import MTwDH
 from model.base.optimization import BertAdam
 from train.base import TrainBase
@@ -63,6 +64,8 @@ class TwDHTrainer(TrainBase):
         dev = torch.device("cuda", self.rank) if isinstance(self.rank, int) else torch.device(self.rank)
         if random_center is None:
             random_center = torch.randint(0, 2, (Hash_center.shape[1],)).float() * 2 - 1
+            if du.world_size() > 1:   # one draw per step for the whole (global) batch, as in a single-GPU run: rank 0's
+                random_center = du.broadcast_tensor_(random_center.to(dev), 0)
         return N.twdh_targets(labels.to(dev).float(), Hash_center.to(dev).float(), random_center.to(dev).float())
 
     def hash_convert(self, hash_label):
@@ -90,20 +93,32 @@ class TwDHTrainer(TrainBase):
             loss = loss + self.args.low_rate * nce_k + self.args.low_rate * quan_k
         return loss
 
+    def _step(self, image, text, label, index):
+        """One optimisation step (reference hash_train.py:49-75)."""
+        image = image.to(self.rank, non_blocking=True)
+        text = text.to(self.rank, non_blocking=True)
+        il, ish, tl, tsh, lc, sc = self.model(image, text)
+        if du.world_size() > 1:
+            # ONE fused all-gather of the long and short pair probabilities + labels: the BCE / quantisation means run over
+            # the global batch (BatchNorm1d of the image head keeps the rank's batch statistics, DESIGN 6)
+            keys = list(ish.keys())
+            parts = self.loss_inputs(il, tl, *[ish[k] for k in keys], *[tsh[k] for k in keys], label.to(self.rank).float())
+            il, tl, label = parts[0], parts[1], parts[-1]
+            ish = dict(zip(keys, parts[2:2 + len(keys)]))
+            tsh = dict(zip(keys, parts[2 + len(keys):2 + 2 * len(keys)]))
+        loss = self.compute_loss(il, tl, ish, tsh, label, index.numpy(), lc, sc)
+        self.optimizer.zero_grad()
+        self.backward(loss)
+        self.optimizer.step()
+        return loss
+
     def train_epoch(self, epoch):
         self.change_state(mode="train")
         self.logger.info(">>>>>> epochs: %d/%d" % (epoch, self.args.epochs))
         all_loss = 0
         for image, text, label, index in self.train_loader:
             self.global_step += 1
-            image = image.to(self.rank, non_blocking=True)
-            text = text.to(self.rank, non_blocking=True)
-            il, ish, tl, tsh, lc, sc = self.model(image, text)
-            loss = self.compute_loss(il, tl, ish, tsh, label, index.numpy(), lc, sc)
-            all_loss += loss
-            self.optimizer.zero_grad()
-            self.backward(loss)
-            self.optimizer.step()
+            all_loss += self._step(image, text, label, index)
         self.logger.info(f">>>>>> [{epoch}/{self.args.epochs}] loss: {all_loss.data / (len(self.train_loader))}")
 
     def make_hash_code(self, code):
@@ -145,10 +160,7 @@ class TwDHTrainer(TrainBase):
         return out
 
     def valid_each(self, epoch, query_img=None, query_txt=None, retrieval_img=None, retrieval_txt=None, k=None, short=None):
-        mAPi2t = calc_map_k(query_img, retrieval_txt, self.query_labels, self.retrieval_labels, k)
-        mAPt2i = calc_map_k(query_txt, retrieval_img, self.query_labels, self.retrieval_labels, k)
-        mAPi2i = calc_map_k(query_img, retrieval_img, self.query_labels, self.retrieval_labels, k)
-        mAPt2t = calc_map_k(query_txt, retrieval_txt, self.query_labels, self.retrieval_labels, k)
+        mAPi2t, mAPt2i, mAPi2i, mAPt2t = self._four_maps(query_img, query_txt, retrieval_img, retrieval_txt, k)   # queries sharded over the ranks
         if short is None:
             if self.max_mapi2t < mAPi2t:
                 self.best_epoch_i = epoch

@@ -216,12 +216,34 @@ class TrainBase(object):
         r_img, r_txt, r_t = gc(self.retrieval_loader, self.args.retrieval_num)
         return q_img, q_txt, r_img, r_txt, q_t, r_t
 
-    def _four_maps(self, query_img, query_txt, retrieval_img, retrieval_txt):
-        mAPi2t = calc_map_k(query_img, retrieval_txt, self.query_labels, self.retrieval_labels, None, self.rank)
-        mAPt2i = calc_map_k(query_txt, retrieval_img, self.query_labels, self.retrieval_labels, None, self.rank)
-        mAPi2i = calc_map_k(query_img, retrieval_img, self.query_labels, self.retrieval_labels, None, self.rank)
-        mAPt2t = calc_map_k(query_txt, retrieval_txt, self.query_labels, self.retrieval_labels, None, self.rank)
+    def _map(self, query_codes, retrieval_codes, k=None):
+        """calc_map_k for one direction.  With one process per GPU every rank holds the whole code matrices (_gather_code_shards),
+        ranks its own contiguous share of the QUERIES against the whole database, and the per-query APs are gathered in query
+        order and summed in f32 exactly like the kernel's own mean (reference utils/calc_utils.py:37-38), so the value is the
+        single-GPU one bit for bit (reference call sites train/base.py:259-262, :299-302)."""
+        if du.world_size() == 1:
+            return calc_map_k(query_codes, retrieval_codes, self.query_labels, self.retrieval_labels, k, self.rank)
+        n_query = query_codes.shape[0]
+        lo, hi = du.query_shard(n_query)
+        if hi > lo:
+            _, ap = calc_map_k(query_codes[lo:hi], retrieval_codes, self.query_labels[lo:hi], self.retrieval_labels, k, self.rank,
+                               return_ap=True)
+        else:
+            ap = torch.empty(0, dtype=torch.float32, device=query_codes.device)
+        return du.mean_in_query_order(du.gather_query_sharded_ap(ap, n_query))
+
+    def _four_maps(self, query_img, query_txt, retrieval_img, retrieval_txt, k=None):
+        mAPi2t = self._map(query_img, retrieval_txt, k)
+        mAPt2i = self._map(query_txt, retrieval_img, k)
+        mAPi2i = self._map(query_img, retrieval_img, k)
+        mAPt2t = self._map(query_txt, retrieval_txt, k)
         return mAPi2t, mAPt2i, mAPi2i, mAPt2t
+
+    def loss_inputs(self, *blocks):
+        """The per-rank loss inputs as global-batch tensors: ONE fused, differentiable all-gather per step (dist_utils.
+        gather_loss_inputs); the pairwise terms of the reference's losses are O(B^2) in the GLOBAL batch
+        (train/DSPH/loss.py:42-66, train/DCHMT/hash_train.py:82-114).  One rank: the blocks themselves."""
+        return du.gather_loss_inputs(*blocks)
 
     def valid(self, epoch):
         self.logger.info("Valid.")

@@ -158,6 +158,12 @@ int cmh_attention(int32_t dtype, const void* qkv, void* o, int32_t B, int32_t T,
 int cmh_prof_gemm_begin(int32_t max_launches);
 int cmh_prof_gemm_end(double* total_ms, double* total_flops, int64_t* launches);
 
+/* Tuning overrides of the N % 256 == 0 GEMM kernel, for A/B measurements and for tests that must reach every variant:
+ * tile_rows in {96, 128, 160} pins the tile height (-1: chosen per launch from M, N, K and the CU count); order_group = n-panels
+ * per group of the L2-aware tile order (0: plain n-fastest order, -1: chosen per launch).  Results do not depend on either.
+ * Process-wide, not thread-safe.  (No reference counterpart: upstream's GEMMs are ATen's, model/base/model.py:167-196.) */
+int cmh_gemm_tuning(int32_t tile_rows, int32_t order_group);
+
 /* f32 -> bf16 (round-to-nearest-even) copy used to prepare CMH_BF16 GEMM weights. */
 int cmh_cast_f32_to_bf16(const float* src, void* dst_bf16, int64_t n, void* stream);
 

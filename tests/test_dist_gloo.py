@@ -115,6 +115,69 @@ def _worker(rank, world, port, out_dir):
     open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
 
 
+def _pair_loss(hi, ht, lab, proxies):
+    """A stand-in with the structure of the reference's losses (HyP, train/DSPH/loss.py:33-66): a per-sample proxy term plus
+    pairwise terms over the whole batch, which is what makes the global batch matter."""
+    import torch.nn.functional as F
+    cos_p = F.normalize(hi, dim=1) @ F.normalize(proxies, dim=1).t()
+    pos = ((1 - cos_p) * lab).sum() / lab.sum().clamp(min=1)
+    sim = (lab @ lab.t() > 0).float()
+    cross = F.normalize(hi, dim=1) @ F.normalize(ht, dim=1).t()
+    neg = (torch.relu(cross) * (1 - sim)).sum() / (1 - sim).sum().clamp(min=1)
+    return pos + neg + (torch.cdist(hi, ht) * sim).mean()
+
+
+def _global_loss_worker(rank, world, port, out_dir):
+    from conftest import PKG  # noqa: F401
+    import dist_utils as du
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    du.init_from_env("gloo")
+    g = torch.Generator().manual_seed(5)
+    Bg, D, K, C = 12, 10, 8, 4
+    x_img, x_txt = torch.randn(Bg, D, generator=g), torch.randn(Bg, D, generator=g)
+    lab = (torch.rand(Bg, C, generator=g) < 0.4).float()
+
+    def build():
+        torch.manual_seed(11)
+        return torch.nn.Linear(D, K), torch.nn.Linear(D, K), torch.nn.Parameter(torch.randn(C, K))
+    # one process, whole batch
+    fi, ft, px = build()
+    ref = _pair_loss(torch.tanh(fi(x_img)), torch.tanh(ft(x_txt)), lab, px)
+    ref.backward()
+    # two ranks, half a batch each, loss on the gathered rows, gradient means over the ranks
+    gi, gt, gp = build()
+    n = Bg // world
+    sl = slice(rank * n, (rank + 1) * n)
+    sync = du.GradSync([list(gi.parameters()), list(gt.parameters()), [gp]])
+    hi, ht, lb = du.gather_loss_inputs(torch.tanh(gi(x_img[sl])), torch.tanh(gt(x_txt[sl])), lab[sl])
+    assert hi.shape == (Bg, K) and torch.equal(lb, lab)
+    loss = _pair_loss(hi, ht, lb, gp)
+    loss.backward()
+    sync.finish()
+    assert abs(float(loss) - float(ref)) <= 1e-6 * abs(float(ref)), (float(loss), float(ref))
+    for a, b in zip(list(gi.parameters()) + list(gt.parameters()) + [gp], list(fi.parameters()) + list(ft.parameters()) + [px]):
+        assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-6 * float(b.grad.abs().max())), (a.grad - b.grad).abs().max()
+    # without gradients the same call is a plain fused all-gather
+    with torch.no_grad():
+        h2, = du.gather_loss_inputs(torch.tanh(gi(x_img[sl])))
+    assert torch.allclose(h2, torch.tanh(gi(x_img)), atol=1e-7)
+    # a draw shared by the ranks
+    t = torch.full((3,), float(rank + 7))
+    assert torch.equal(du.broadcast_tensor_(t, 0), torch.full((3,), 7.0))
+    assert du.query_shard(11) == du.shard_range(11, rank, world)
+    sync.remove()
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+    open(os.path.join(out_dir, f"gl{rank}"), "w").write("ok")
+
+
+def test_world2_global_batch_loss_equals_single_process(tmp_path):
+    """gather_loss_inputs + GradSync: loss and every gradient of a 2-rank step equal a 1-process step on the concatenated batch."""
+    port = _free_port()
+    mp.spawn(_global_loss_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "gl0").exists() and (tmp_path / "gl1").exists()
+
+
 def test_world2_gloo_exchange(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)

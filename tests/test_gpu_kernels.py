@@ -43,6 +43,40 @@ def test_gemm_epilogues(M, N, K, mode):
     torch.testing.assert_close(out.cpu().double(), base + b.double() + r.double(), **tol)
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 2304, 768), (10499, 512, 512), (3000, 1536, 512), (777, 768, 3072)])
+def test_gemm_wide_tile_variants(M, N, K):
+    """Every tile height (96 / 128 / 160 rows) and both tile orders of the wide kernel give the SAME bits (an output element is
+    the same K-ordered MFMA chain whatever tile it falls in), and those bits match the fp64 statement of the op."""
+    import cmh_native as Nn
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16()
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g).half()
+    ref_q = x.double() @ w.double().t() + b.double()
+    ref_q = ref_q * torch.sigmoid(1.702 * ref_q)
+    ref_r = x.double() @ w.double().t() + b.double() + r.double()
+    xd, wd, bd, rd = (t.to(_dev()) for t in (x, w, b, r))
+    first = None
+    try:
+        for rows in (-1, 96, 128, 160):
+            for order in (-1, 0, 2):
+                Nn.gemm_tuning(rows, order)
+                oq = Nn.linear_gemm(xd, wd, bias=bd, quickgelu=True, out_bf16=True)
+                orr = Nn.linear_gemm(xd, wd, bias=bd, residual=rd, out_f16=True)
+                if first is None:
+                    first = (oq, orr)
+                    torch.testing.assert_close(oq.cpu().double(), ref_q, rtol=1e-2, atol=1e-2)
+                    torch.testing.assert_close(orr.cpu().double(), ref_r, rtol=1.5e-3, atol=2e-3)
+                else:
+                    assert torch.equal(oq, first[0]), (rows, order)
+                    assert torch.equal(orr, first[1]), (rows, order)
+    finally:
+        Nn.gemm_tuning(-1, -1)
+    with pytest.raises(Nn.NativeError):
+        Nn.gemm_tuning(100, -1)
+
+
 def test_gemm_asymmetric_identity():
     """A = I against an ASYMMETRIC W catches a transposed C write (cdna guide §3)."""
     import cmh_native as Nn

@@ -5,7 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "clip-based-cross-modal-hashing_amd"))
 import numpy as np, torch, cmh_native as N
 dev = torch.device("cuda:0")
-shapes = {"v_qkv": (12800, 2304, 768), "v_fc1": (12800, 3072, 768), "t_fc1": (19712, 2048, 512), "v_fc2": (12800, 768, 3072)}
+shapes = {"v_out": (12800, 768, 768), "v_qkv": (12800, 2304, 768), "v_fc1": (12800, 3072, 768), "v_fc2": (12800, 768, 3072),
+          "v_qkv_1round": (4480, 2304, 768), "t_fc1": (19712, 2048, 512)}
 for name, (M, Nn, K) in shapes.items():
     x = torch.randn(M, K, device=dev).bfloat16(); w = (torch.randn(Nn, K, device=dev) * K ** -0.5).bfloat16()
     b = torch.randn(Nn, device=dev); out = torch.empty(M, Nn, dtype=torch.bfloat16, device=dev)
