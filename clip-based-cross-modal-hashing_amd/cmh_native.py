@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CMH_LIB") or os.path.join(_HERE, "csrc", "build", "libcmh.so")   # CMH_LIB: A/B a kernel build
 
-F32, BF16 = 0, 1
+F32, BF16, FP8 = 0, 1, 2
 ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
 TIE_REFERENCE, TIE_STABLE = 0, 1
 
@@ -27,7 +27,8 @@ class NativeError(RuntimeError):
 class BlockWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "ln1_w", "ln1_b", "ln2_w", "ln2_b",
-        "fc_w", "fc_b", "proj_w", "proj_b")]
+        "fc_w", "fc_b", "proj_w", "proj_b",
+        "in_proj_cs", "out_proj_cs", "fc_cs", "proj_cs")] + [("act_scale", C.c_float * 4)]     # fp8 mode only
 
 
 class VitWeights(C.Structure):
@@ -87,10 +88,17 @@ SIGNATURES = {
     "cmh_vit_encode": (C.c_int, [C.POINTER(VitWeights), _p, _i32, _p, _p, _sz, C.POINTER(Taps), _p]),
     "cmh_text_encode": (C.c_int, [C.POINTER(TextWeights), _p, _i32, _i32, _p, _p, _p, _sz, C.POINTER(Taps), _p]),
     "cmh_text_encode_packed": (C.c_int, [C.POINTER(TextWeights), _p, _i32, _i32, _p, C.POINTER(C.c_int32), _p, _sz, _p]),
+    "cmh_vit_calibrate_fp8": (C.c_int, [C.POINTER(VitWeights), _p, _i32, _p, _p, _p, _sz, _p]),
+    "cmh_text_calibrate_fp8": (C.c_int, [C.POINTER(TextWeights), _p, _i32, _i32, _p, _p, _p, _sz, _p]),
     "cmh_linear_gemm": (C.c_int, [_i32, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "cmh_layernorm": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _p]),
     "cmh_attention": (C.c_int, [_i32, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "cmh_gemm_tuning": (C.c_int, [_i32, _i32]),
+    "cmh_fp8_quantize_weight": (C.c_int, [_p, _p, _p, _i32, _i32, _p]),
+    "cmh_fp8_quantize": (C.c_int, [_p, _i32, _p, _i64, _f, _p]),
+    "cmh_fp8_dequantize": (C.c_int, [_p, _p, _i64, _f, _p]),
+    "cmh_amax": (C.c_int, [_p, _i32, _i64, _p, _p]),
+    "cmh_linear_gemm_fp8": (C.c_int, [_p, _p, _p, _f, _p, _p, _p, _f, _i32, _i32, _i32, _i32, _p]),
     "cmh_prof_gemm_begin": (C.c_int, [_i32]),
     "cmh_prof_gemm_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "cmh_cast_f32_to_bf16": (C.c_int, [_p, _p, _i64, _p]),
@@ -241,6 +249,73 @@ def cast_bf16(src: torch.Tensor) -> torch.Tensor:
     dst = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
     check(lib().cmh_cast_f32_to_bf16(ptr(src), ptr(dst), src.numel(), stream_ptr(src.device)), "cmh_cast_f32_to_bf16")
     return dst
+
+
+def _kind(t: torch.Tensor) -> int:
+    return {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[t.dtype]
+
+
+def fp8_quantize_weight(w: torch.Tensor):
+    """w f32 [N,K] -> (e4m3 bytes [N,K] uint8, colscale f32 [N]) with w ~ fp8 * colscale[:, None]."""
+    w = f32c(w)
+    require_gpu(w)
+    Nn, K = w.shape
+    q = torch.empty(Nn, K, dtype=torch.uint8, device=w.device)
+    cs = torch.empty(Nn, dtype=torch.float32, device=w.device)
+    check(lib().cmh_fp8_quantize_weight(ptr(w), ptr(q), ptr(cs), Nn, K, stream_ptr(w.device)), "cmh_fp8_quantize_weight")
+    return q, cs
+
+
+def fp8_quantize(x: torch.Tensor, scale: float) -> torch.Tensor:
+    """x (f32 / bf16 / f16) -> e4m3 bytes of clamp(x / scale, +-448), same shape, uint8."""
+    require_gpu(x)
+    x = x.contiguous()
+    q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    check(lib().cmh_fp8_quantize(ptr(x), _kind(x), ptr(q), x.numel(), float(scale), stream_ptr(x.device)), "cmh_fp8_quantize")
+    return q
+
+
+def fp8_dequantize(q: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    require_gpu(q)
+    q = q.contiguous()
+    out = torch.empty(q.shape, dtype=torch.float32, device=q.device)
+    check(lib().cmh_fp8_dequantize(ptr(q), ptr(out), q.numel(), float(scale), stream_ptr(q.device)), "cmh_fp8_dequantize")
+    return out
+
+
+def amax(x: torch.Tensor, into: torch.Tensor | None = None) -> torch.Tensor:
+    """max |x| as a device scalar (accumulated into `into` when given)."""
+    require_gpu(x)
+    x = x.contiguous()
+    out = torch.zeros(1, dtype=torch.float32, device=x.device) if into is None else into
+    check(lib().cmh_amax(ptr(x), _kind(x), x.numel(), ptr(out), stream_ptr(x.device)), "cmh_amax")
+    return out
+
+
+EPI_OUT_FP8 = 4096
+
+
+def linear_gemm_fp8(x8, w8, colscale, alpha, bias=None, residual=None, quickgelu=False, out="f32", out_scale=1.0):
+    """epi(alpha * colscale[n] * (x8 @ w8.T)) on e4m3 operands (uint8 tensors); out in {"f32", "bf16", "f16", "fp8"}."""
+    require_gpu(x8, w8, colscale, bias, residual)
+    if x8.dtype != torch.uint8 or w8.dtype != torch.uint8:
+        raise NativeError("linear_gemm_fp8: operands are e4m3 bytes (uint8 tensors)")
+    x8, w8 = x8.contiguous(), w8.contiguous()
+    M, K = x8.shape
+    Nn = w8.shape[0]
+    if w8.shape[1] != K or colscale.numel() != Nn or (bias is not None and bias.numel() != Nn) or \
+            (residual is not None and tuple(residual.shape) != (M, Nn)):
+        raise NativeError(f"linear_gemm_fp8: x {tuple(x8.shape)}, w {tuple(w8.shape)}, colscale / bias / residual shapes do not fit together")
+    odt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16, "fp8": torch.uint8}[out]
+    o = torch.empty(M, Nn, dtype=odt, device=x8.device)
+    res_f16 = residual is not None and residual.dtype == torch.float16
+    if residual is not None:
+        residual = residual.contiguous() if res_f16 else f32c(residual)
+    epi = (EPI_BIAS if bias is not None else 0) | (EPI_QUICKGELU if quickgelu else 0) | (EPI_RESIDUAL if residual is not None else 0) | \
+          (EPI_RES_F16 if res_f16 else 0) | {"f32": 0, "bf16": EPI_OUT_BF16, "f16": EPI_OUT_F16, "fp8": EPI_OUT_FP8}[out]
+    check(lib().cmh_linear_gemm_fp8(ptr(x8), ptr(w8), ptr(f32c(colscale)), float(alpha), ptr(None if bias is None else f32c(bias)),
+                                    ptr(residual), ptr(o), float(out_scale), M, Nn, K, epi, stream_ptr(x8.device)), "cmh_linear_gemm_fp8")
+    return o
 
 
 def gemm_tuning(tile_rows: int = -1, order_group: int = -1):

@@ -181,7 +181,7 @@ template <int NKT>
 __global__ __launch_bounds__(64) void attention_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                             int B, int Tmax, int d, int causal,
                                                             const uint8_t* __restrict__ kpm,
-                                                            const int32_t* __restrict__ seq_off) {
+                                                            const int32_t* __restrict__ seq_off, float o8_inv_scale) {
   constexpr int NKS = NKT / 2;
   constexpr int TP = NKT * 16;
   constexpr int VST = 66;   // LDS row stride in bf16 elements (132 B): the 4 lane groups land on different banks
@@ -291,7 +291,18 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const bf16_t* __rest
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) oc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[s][dt], pb, oc[dt], 0, 0, 0);
     }
-    if (qrow < Tn) {
+    if (qrow < Tn && o8_inv_scale > 0.f) {
+      // fp8 mode: the out_proj GEMM's operand leaves as e4m3(o / act_scale), 4 bytes per lane and head-dim tile
+      const float inv = o8_inv_scale / l;
+      uint8_t* op8 = reinterpret_cast<uint8_t*>(o) + (srow + qrow) * d + h * HD + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        auto cl = [](float v) { return fminf(fmaxf(v, -448.f), 448.f); };
+        int w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(oc[dt][0] * inv), cl(oc[dt][1] * inv), 0, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(oc[dt][2] * inv), cl(oc[dt][3] * inv), w, true);
+        *reinterpret_cast<uint32_t*>(op8 + 16 * dt) = static_cast<uint32_t>(w);
+      }
+    } else if (qrow < Tn) {
       const float inv = 1.0f / l;
       bf16_t* op = o + (srow + qrow) * d + h * HD + 4 * g;
 #pragma unroll
@@ -307,27 +318,28 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const bf16_t* __rest
 
 template <int NKT>
 static void launch_attention_mfma(const void* qkv, void* o, int B, int T, int d, int causal, const uint8_t* kpm,
-                                  const int32_t* seq_off, hipStream_t st) {
+                                  const int32_t* seq_off, hipStream_t st, float o8_inv_scale) {
   hipLaunchKernelGGL(attention_mfma_kernel<NKT>, dim3(B * (d / HD)), dim3(64), 0, st, static_cast<const bf16_t*>(qkv),
-                     static_cast<bf16_t*>(o), B, T, d, causal, kpm, seq_off);
+                     static_cast<bf16_t*>(o), B, T, d, causal, kpm, seq_off, o8_inv_scale);
 }
 
 int launch_attention(const void* qkv, void* o, int dt, int B, int T, int d, int causal,
                      const uint8_t* key_padding_mask, hipStream_t st) {
-  return launch_attention_varlen(qkv, o, dt, B, T, d, causal, key_padding_mask, nullptr, st);
+  return launch_attention_varlen(qkv, o, dt, B, T, d, causal, key_padding_mask, nullptr, st, 0.f);
 }
 
 // seq_off (device int32 [B+1], may be NULL): packed variable-length sequences, T = the longest
 int launch_attention_varlen(const void* qkv, void* o, int dt, int B, int T, int d, int causal,
-                            const uint8_t* key_padding_mask, const int32_t* seq_off, hipStream_t st) {
+                            const uint8_t* key_padding_mask, const int32_t* seq_off, hipStream_t st, float o8_inv_scale) {
   CMH_CHECK_ARG(d % HD == 0, "attention: width %d is not a multiple of 64", d);
   CMH_CHECK_ARG(B > 0 && T > 0, "attention: empty batch");
+  CMH_CHECK_ARG(o8_inv_scale == 0.f || (dt == CMH_BF16 && T <= 128), "attention: e4m3 output needs bf16 qkv and T <= 128 (T=%d)", T);
   const dim3 grid(B * (d / HD), (T + 63) / 64);
   if (dt == CMH_BF16 && T <= 128) {
-    if (T <= 32) launch_attention_mfma<2>(qkv, o, B, T, d, causal, key_padding_mask, seq_off, st);
-    else if (T <= 64) launch_attention_mfma<4>(qkv, o, B, T, d, causal, key_padding_mask, seq_off, st);
-    else if (T <= 96) launch_attention_mfma<6>(qkv, o, B, T, d, causal, key_padding_mask, seq_off, st);
-    else launch_attention_mfma<8>(qkv, o, B, T, d, causal, key_padding_mask, seq_off, st);
+    if (T <= 32) launch_attention_mfma<2>(qkv, o, B, T, d, causal, key_padding_mask, seq_off, st, o8_inv_scale);
+    else if (T <= 64) launch_attention_mfma<4>(qkv, o, B, T, d, causal, key_padding_mask, seq_off, st, o8_inv_scale);
+    else if (T <= 96) launch_attention_mfma<6>(qkv, o, B, T, d, causal, key_padding_mask, seq_off, st, o8_inv_scale);
+    else launch_attention_mfma<8>(qkv, o, B, T, d, causal, key_padding_mask, seq_off, st, o8_inv_scale);
     CMH_CHECK_LAUNCH("attention_mfma");
     return CMH_OK;
   }

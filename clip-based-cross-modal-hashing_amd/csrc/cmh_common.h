@@ -107,8 +107,10 @@ enum : int {
   EPI_RELU = 32,      // max(x, 0)
   EPI_RES_F16 = 64,   // residual is IEEE fp16 (the bf16 mode's residual stream, see encoders.hip)
   EPI_OUT_F16 = 128,  // store fp16 instead of f32
-  EPI_MUL_DQGELU = 1024  // acc *= QuickGELU'(aux[m,n]); aux (in the residual slot) has the OUTPUT's type (bf16 with EPI_OUT_BF16,
+  EPI_MUL_DQGELU = 1024, // acc *= QuickGELU'(aux[m,n]); aux (in the residual slot) has the OUTPUT's type (bf16 with EPI_OUT_BF16,
                          // else f32): the dgrad through c_fc's activation.  N % 256 == 0 (wide kernel only); 256/512 are ablation bits
+  EPI_SCALE = 2048,      // acc *= alpha * colscale[n] before the bias: dequantisation of fp8 operands (launch_gemm_fp8)
+  EPI_OUT_FP8 = 4096     // store OCP e4m3 of clamp(v * oscale, +-448) (the next fp8 GEMM's operand)
 };
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
@@ -116,6 +118,10 @@ __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + e
 // C[M,N] = epilogue(A[M,K] . W[N,K]^T).  A/W dtype = dt (f32 or bf16); residual f32; out f32|bf16.
 int launch_gemm(int dt, const void* A, const void* W, const float* bias, const float* residual,
                 void* out, int M, int N, int K, int epi, hipStream_t st);
+// C = epilogue(alpha * colscale[n] * (A8 . W8^T)): OCP e4m3 operands [M,K] / [N,K] (K % 128 == 0, N % 256 == 0), f32 accumulate;
+// out f32 | bf16 | fp16 | (EPI_OUT_FP8) e4m3 of v * oscale.  EPI_SCALE is implied.
+int launch_gemm_fp8(const void* A8, const void* W8, const float* colscale, float alpha, const float* bias, const float* residual,
+                    void* out, float oscale, int M, int N, int K, int epi, hipStream_t st);
 
 // LayerNorm over rows of x[M,d] (f32) -> out (f32 or bf16 per out_bf16). rows optionally gathered:
 // row r reads x[row_index[r]] when row_index != null.
@@ -176,7 +182,11 @@ int launch_layernorm_backward(const void* x, int x_kind, const void* dy, int dy_
 int launch_attention(const void* qkv, void* o, int dt, int B, int T, int d, int causal,
                      const uint8_t* key_padding_mask, hipStream_t st);
 int launch_attention_varlen(const void* qkv, void* o, int dt, int B, int T, int d, int causal,
-                            const uint8_t* key_padding_mask, const int32_t* seq_off, hipStream_t st);
+                            const uint8_t* key_padding_mask, const int32_t* seq_off, hipStream_t st,
+                            float o8_inv_scale = 0.f);   // > 0 (bf16 qkv, T <= 128): o is e4m3 of o * o8_inv_scale (fp8 mode)
+// fp8.hip: LayerNorm of the fp16 residual stream straight to e4m3 (y * inv_scale); max |x| into a device scalar (running maximum)
+int launch_layernorm_q(const void* x_f16, const float* w, const float* b, void* out_fp8, float inv_scale, int M, int d, hipStream_t st);
+int launch_amax(const void* x, int kind, size_t n, float* out, hipStream_t st);
 
 // y[M,N] f32 = act((x[M,K] . w[N,K]^T + bias) * mask*keep_scale); x,w dtype dt; any N, K%4==0, K<=4096
 int launch_small_linear(int dt, const void* x, const void* w, const float* bias, const float* mask,

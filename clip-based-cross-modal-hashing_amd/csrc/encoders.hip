@@ -76,12 +76,51 @@ static int tap(const cmh_taps* taps, int idx, const float* x, size_t bytes, hipS
 
 // One ResidualAttentionBlock (model/base/model.py:191-196):
 //   x += out_proj(attn(in_proj(ln_1(x))));  x += c_proj(QuickGELU(c_fc(ln_2(x))))
+// fp8 mode (CMH_FP8): the four GEMMs on e4m3 operands.  Activations are quantised by their producers with the per-tensor
+// scales of cmh_block_weights.act_scale (LayerNorm -> launch_layernorm_q, attention -> its fp8 store, QuickGELU -> the c_fc
+// epilogue); the GEMM epilogues undo act_scale * colscale[n].  Residual stream fp16, qkv bf16 (attention is the bf16 kernel).
+static int run_block_fp8(const cmh_block_weights& w, const TowerBufs& t, int B, int T, int d, int causal, const uint8_t* kpm,
+                         hipStream_t st, int M, const int32_t* seq_off) {
+  const float* a = w.act_scale;
+  CMH_CHECK_ARG(t.xh, "fp8 mode runs on the fp16 residual stream (width %% 256 == 0, no taps)");
+  CMH_CHECK_ARG(w.in_proj_cs && w.out_proj_cs && w.fc_cs && w.proj_cs, "fp8 mode: weight scales missing");
+  CMH_CHECK_ARG(a[0] > 0.f && a[1] > 0.f && a[2] > 0.f && a[3] > 0.f, "fp8 mode: activation scales missing (run the calibration pass)");
+  const int rx = EPI_BIAS | EPI_RESIDUAL | EPI_RES_F16 | EPI_OUT_F16;
+  int rc;
+  if ((rc = launch_layernorm_q(t.x, w.ln1_w, w.ln1_b, t.h, 1.0f / a[0], M, d, st))) return rc;
+  if ((rc = launch_gemm_fp8(t.h, w.in_proj_w, w.in_proj_cs, a[0], w.in_proj_b, nullptr, t.qkv, 1.f, M, 3 * d, d, EPI_BIAS | EPI_OUT_BF16, st))) return rc;
+  if ((rc = launch_attention_varlen(t.qkv, t.h, CMH_BF16, B, T, d, causal, kpm, seq_off, st, 1.0f / a[1]))) return rc;
+  if ((rc = launch_gemm_fp8(t.h, w.out_proj_w, w.out_proj_cs, a[1], w.out_proj_b, t.x, t.x, 1.f, M, d, d, rx, st))) return rc;
+  if ((rc = launch_layernorm_q(t.x, w.ln2_w, w.ln2_b, t.h, 1.0f / a[2], M, d, st))) return rc;
+  if ((rc = launch_gemm_fp8(t.h, w.fc_w, w.fc_cs, a[2], w.fc_b, nullptr, t.mlp, 1.0f / a[3], M, 4 * d, d,
+                            EPI_BIAS | EPI_QUICKGELU | EPI_OUT_FP8, st))) return rc;
+  if ((rc = launch_gemm_fp8(t.mlp, w.proj_w, w.proj_cs, a[3], w.proj_b, t.x, t.x, 1.f, M, d, 4 * d, rx, st))) return rc;
+  return CMH_OK;
+}
+
 static int run_block(const cmh_block_weights& w, int dt, const TowerBufs& t, int B, int T, int d, int causal,
-                     const uint8_t* kpm, hipStream_t st, int rows = -1, const int32_t* seq_off = nullptr) {
+                     const uint8_t* kpm, hipStream_t st, int rows = -1, const int32_t* seq_off = nullptr,
+                     float* amax = nullptr) {   // amax [4] (bf16 mode): running maxima of the four GEMM inputs (fp8 calibration)
   const int M = rows >= 0 ? rows : B * T;      // packed variable-length text: `rows` real rows, T = the longest sequence
+  if (dt == CMH_FP8) return run_block_fp8(w, t, B, T, d, causal, kpm, st, M, seq_off);
   const int obf = dt == CMH_BF16 ? EPI_OUT_BF16 : 0;
   const int rx = EPI_BIAS | EPI_RESIDUAL | (t.xh ? EPI_RES_F16 | EPI_OUT_F16 : 0);
   int rc;
+  if (amax) {   // the calibration pass: the same kernels, with a reduction after each producer
+    CMH_CHECK_ARG(dt == CMH_BF16, "fp8 calibration runs in bf16 mode");
+    const size_t n = static_cast<size_t>(M) * d;
+    if ((rc = launch_layernorm_x(t.x, t.xh, nullptr, w.ln1_w, w.ln1_b, t.h, 1, M, d, st))) return rc;
+    if ((rc = launch_amax(t.h, kBF16, n, amax + 0, st))) return rc;
+    if ((rc = launch_gemm(dt, t.h, w.in_proj_w, w.in_proj_b, nullptr, t.qkv, M, 3 * d, d, EPI_BIAS | obf, st))) return rc;
+    if ((rc = launch_attention_varlen(t.qkv, t.h, dt, B, T, d, causal, kpm, seq_off, st))) return rc;
+    if ((rc = launch_amax(t.h, kBF16, n, amax + 1, st))) return rc;
+    if ((rc = launch_gemm(dt, t.h, w.out_proj_w, w.out_proj_b, t.x, t.x, M, d, d, rx, st))) return rc;
+    if ((rc = launch_layernorm_x(t.x, t.xh, nullptr, w.ln2_w, w.ln2_b, t.h, 1, M, d, st))) return rc;
+    if ((rc = launch_amax(t.h, kBF16, n, amax + 2, st))) return rc;
+    if ((rc = launch_gemm(dt, t.h, w.fc_w, w.fc_b, nullptr, t.mlp, M, 4 * d, d, EPI_BIAS | EPI_QUICKGELU | obf, st))) return rc;
+    if ((rc = launch_amax(t.mlp, kBF16, n * 4, amax + 3, st))) return rc;
+    return launch_gemm(dt, t.mlp, w.proj_w, w.proj_b, t.x, t.x, M, d, 4 * d, rx, st);
+  }
   if ((rc = launch_layernorm_x(t.x, t.xh, nullptr, w.ln1_w, w.ln1_b, t.h, dt == CMH_BF16, M, d, st))) return rc;
   if ((rc = launch_gemm(dt, t.h, w.in_proj_w, w.in_proj_b, nullptr, t.qkv, M, 3 * d, d, EPI_BIAS | obf, st))) return rc;
   if ((rc = launch_attention_varlen(t.qkv, t.h, dt, B, T, d, causal, kpm, seq_off, st))) return rc;
@@ -102,12 +141,14 @@ static int final_projection(int dt, const void* pool, const void* w_t, float* fe
 // fp16 residual stream?  (bf16 mode only; the residual GEMMs must take the wide kernel; taps are defined on an f32 stream)
 static int resid_f16(int dt, int d, const cmh_taps* taps) {
   static const bool off = []() { const char* e = getenv("CMH_RESID_F16"); return e && !strcmp(e, "0"); }();
+  if (dt == CMH_FP8) return d % 256 == 0 && !taps;
   return dt == CMH_BF16 && d % 256 == 0 && !taps && !off;
 }
 
 static int check_tower(int dt, int width, int layers, int embed, const cmh_block_weights* blocks) {
-  CMH_CHECK_ARG(dt == CMH_F32 || dt == CMH_BF16, "bad gemm_dtype %d", dt);
+  CMH_CHECK_ARG(dt == CMH_F32 || dt == CMH_BF16 || dt == CMH_FP8, "bad gemm_dtype %d", dt);
   CMH_CHECK_ARG(width > 0 && width % 128 == 0 && width <= 1024, "width %d must be a multiple of 128, <= 1024", width);
+  CMH_CHECK_ARG(dt != CMH_FP8 || width % 256 == 0, "fp8 mode needs width %% 256 == 0 (width %d)", width);
   CMH_CHECK_ARG(layers >= 0 && embed > 0 && embed % 4 == 0, "bad layers/embed_dim");
   CMH_CHECK_ARG(layers == 0 || blocks, "blocks is null");
   return CMH_OK;
@@ -123,23 +164,25 @@ extern "C" int cmh_version(void) { return CMH_VERSION; }
 extern "C" size_t cmh_vit_workspace_bytes(const cmh_vit_weights* w, int32_t batch) {
   if (!w || batch <= 0 || w->patch <= 0) return 0;
   const size_t g = w->resolution / w->patch, g2 = g * g, T = g2 + 1, d = w->width;
-  const size_t e = w->gemm_dtype == CMH_BF16 ? 2 : 4;
+  const size_t e = w->gemm_dtype == CMH_F32 ? 4 : 2;   // fp8 mode: sized like bf16 (conv1 and the stream are the bf16 mode's)
   const size_t B = batch, pk = 3ull * w->patch * w->patch;
   return carve(nullptr, B * T, B, d, e, B * g2 * d * 4, B * g2 * pk * e).total;
 }
 
 static int vit_encode_impl(const cmh_vit_weights* w, const float* image, int32_t batch, float* feat, float* tokens_out,
-                           void* workspace, size_t workspace_bytes, const cmh_taps* taps, void* stream) {
+                           void* workspace, size_t workspace_bytes, const cmh_taps* taps, void* stream, float* amax = nullptr) {
   CMH_CHECK_ARG(w && image && (feat || tokens_out) && workspace, "vit_encode: null pointer");
   CMH_CHECK_ARG(batch > 0, "vit_encode: batch %d", batch);
   int rc = check_tower(w->gemm_dtype, w->width, w->layers, w->embed_dim, w->blocks);
   if (rc) return rc;
   CMH_CHECK_ARG(w->patch > 0 && w->resolution % w->patch == 0 && w->patch % 4 == 0, "vit_encode: resolution %d / patch %d",
                 w->resolution, w->patch);
-  const int dt = w->gemm_dtype, d = w->width, B = batch;
+  const int dtb = w->gemm_dtype, d = w->width, B = batch;   // dtb: arithmetic of the blocks' GEMMs
+  const int dt = dtb == CMH_FP8 ? CMH_BF16 : dtb;             // everything outside the blocks (conv1, LayerNorms, projections)
   const int g = w->resolution / w->patch, g2 = g * g, T = g2 + 1, M = B * T;
   const int pk = 3 * w->patch * w->patch;
   const size_t e = dt == CMH_BF16 ? 2 : 4;
+  CMH_CHECK_ARG(!amax || dtb == CMH_BF16, "vit_calibrate_fp8: weights must be the bf16 mode's");
   CMH_CHECK_ARG(pk % (dt == CMH_F32 ? 32 : 64) == 0, "vit_encode: 3*patch^2 = %d not a multiple of the GEMM K-step", pk);
   const size_t need = cmh_vit_workspace_bytes(w, batch);
   if (workspace_bytes < need) return fail(CMH_ERR_WORKSPACE, "vit_encode: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -147,7 +190,7 @@ static int vit_encode_impl(const cmh_vit_weights* w, const float* image, int32_t
   hipStream_t st = as_stream(stream);
   TowerBufs t = carve(workspace, static_cast<size_t>(M), B, d, e, static_cast<size_t>(B) * g2 * d * 4,
                       static_cast<size_t>(B) * g2 * pk * e);
-  t.xh = resid_f16(dt, d, taps);
+  t.xh = resid_f16(dtb, d, taps);
   void* patches = t.mlp;
   float* patch_out = static_cast<float*>(t.qkv);
 
@@ -159,7 +202,7 @@ static int vit_encode_impl(const cmh_vit_weights* w, const float* image, int32_t
                                       w->ln_pre_b, t.x, t.xh, B, g2, d, st))) return rc;
   if ((rc = tap(taps, 0, t.x, static_cast<size_t>(M) * d * 4, st))) return rc;
   for (int i = 0; i < w->layers; ++i) {
-    if ((rc = run_block(w->blocks[i], dt, t, B, T, d, /*causal=*/0, nullptr, st))) return rc;
+    if ((rc = run_block(w->blocks[i], dtb, t, B, T, d, /*causal=*/0, nullptr, st, -1, nullptr, amax ? amax + 4 * i : nullptr))) return rc;
     if ((rc = tap(taps, 1 + i, t.x, static_cast<size_t>(M) * d * 4, st))) return rc;
   }
   if (tokens_out) {
@@ -190,27 +233,29 @@ extern "C" int cmh_vit_encode_tokens(const cmh_vit_weights* w, const float* imag
 
 extern "C" size_t cmh_text_workspace_bytes(const cmh_text_weights* w, int32_t batch, int32_t seq_len) {
   if (!w || batch <= 0 || seq_len <= 0) return 0;
-  const size_t e = w->gemm_dtype == CMH_BF16 ? 2 : 4;
+  const size_t e = w->gemm_dtype == CMH_F32 ? 4 : 2;
   return carve(nullptr, static_cast<size_t>(batch) * seq_len, batch, w->width, e, 0, 0).total;
 }
 
 static int text_encode_impl(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
                             const uint8_t* key_padding_mask, float* feat, float* tokens_out, int32_t* eot_rows_out,
                             void* workspace, size_t workspace_bytes, const cmh_taps* taps, void* stream,
-                            int32_t* packed_rows_out = nullptr) {
+                            int32_t* packed_rows_out = nullptr, float* amax = nullptr) {
   CMH_CHECK_ARG(w && tokens && (feat || tokens_out) && workspace, "text_encode: null pointer");
   CMH_CHECK_ARG(batch > 0 && seq_len > 0, "text_encode: batch %d seq_len %d", batch, seq_len);
   int rc = check_tower(w->gemm_dtype, w->width, w->layers, w->embed_dim, w->blocks);
   if (rc) return rc;
   CMH_CHECK_ARG(seq_len <= w->context_length, "text_encode: seq_len %d > context_length %d", seq_len, w->context_length);
-  const int dt = w->gemm_dtype, d = w->width, B = batch, L = seq_len, M = B * L;
+  const int dtb = w->gemm_dtype, d = w->width, B = batch, L = seq_len, M = B * L;
+  const int dt = dtb == CMH_FP8 ? CMH_BF16 : dtb;
   const size_t e = dt == CMH_BF16 ? 2 : 4;
+  CMH_CHECK_ARG(!amax || dtb == CMH_BF16, "text_calibrate_fp8: weights must be the bf16 mode's");
   const size_t need = cmh_text_workspace_bytes(w, batch, seq_len);
   if (workspace_bytes < need) return fail(CMH_ERR_WORKSPACE, "text_encode: workspace %zu < %zu bytes", workspace_bytes, need);
   CMH_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "text_encode: workspace must be 256-byte aligned");
   hipStream_t st = as_stream(stream);
   TowerBufs t = carve(workspace, static_cast<size_t>(M), B, d, e, 0, 0);
-  t.xh = resid_f16(dt, d, taps);
+  t.xh = resid_f16(dtb, d, taps);
 
   // Packed mode (pooled output only): under the causal mask nothing after a caption's EOT can reach the EOT row that
   // encode_text returns (model.py:366-370), so only the tokens 0..EOT of every caption are embedded and run through the
@@ -244,7 +289,7 @@ static int text_encode_impl(const cmh_text_weights* w, const int64_t* tokens, in
   if ((rc = launch_text_embed_packed(tokens, w->token_embedding, w->positional_embedding, t.x, t.xh, t.rows, B, L, d,
                                      w->vocab_size, seq_off, st))) return rc;
   for (int i = 0; i < w->layers; ++i) {
-    if ((rc = run_block(w->blocks[i], dt, t, B, L, d, /*causal=*/1, key_padding_mask, st, rows, seq_off))) return rc;
+    if ((rc = run_block(w->blocks[i], dtb, t, B, L, d, /*causal=*/1, key_padding_mask, st, rows, seq_off, amax ? amax + 4 * i : nullptr))) return rc;
     if ((rc = tap(taps, 1 + i, t.x, static_cast<size_t>(M) * d * 4, st))) return rc;
   }
   if (tokens_out) {
@@ -278,6 +323,20 @@ extern "C" int cmh_text_encode_packed(const cmh_text_weights* w, const int64_t* 
                           rows_computed);
 }
 
+extern "C" int cmh_vit_calibrate_fp8(const cmh_vit_weights* w, const float* image, int32_t batch, float* feat, float* amax,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  CMH_CHECK_ARG(feat && amax, "vit_calibrate_fp8: null pointer");
+  return vit_encode_impl(w, image, batch, feat, nullptr, workspace, workspace_bytes, nullptr, stream, amax);
+}
+
+extern "C" int cmh_text_calibrate_fp8(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len, float* feat,
+                                      float* amax, void* workspace, size_t workspace_bytes, void* stream) {
+  CMH_CHECK_ARG(feat && amax, "text_calibrate_fp8: null pointer");
+  int32_t rows = 0;   // the packed path: calibrate on the rows the fp8 mode will compute
+  return text_encode_impl(w, tokens, batch, seq_len, nullptr, feat, nullptr, nullptr, workspace, workspace_bytes, nullptr, stream, &rows,
+                          amax);
+}
+
 extern "C" int cmh_text_encode_tokens(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
                                       const uint8_t* key_padding_mask, float* tokens_out, int32_t* eot_rows_out,
                                       void* workspace, size_t workspace_bytes, void* stream) {
@@ -297,6 +356,7 @@ extern "C" int cmh_transformer_blocks(const cmh_block_weights* blocks, int32_t l
                                       int32_t T, int32_t d, int32_t causal, const uint8_t* key_padding_mask,
                                       void* workspace, size_t workspace_bytes, void* stream) {
   CMH_CHECK_ARG(blocks && x && workspace && layers > 0 && B > 0 && T > 0, "transformer_blocks: bad arguments");
+  CMH_CHECK_ARG(dtype != CMH_FP8, "transformer_blocks: f32 / bf16 only (the fp8 mode runs on the towers' fp16 residual stream)");
   int rc = check_tower(dtype, d, layers, 4, blocks);
   if (rc) return rc;
   if (workspace_bytes < cmh_blocks_workspace_bytes(dtype, B, T, d)) return fail(CMH_ERR_WORKSPACE, "transformer_blocks: workspace too small");

@@ -212,7 +212,8 @@ void launch_gemm_glds(int dt, const void* A, const void* W, const float* bias, c
                       int M, int N, int K, int epi, hipStream_t st);   // gemm_glds.hip
 bool gemm_wide_supported(int N);                                         // gemm_wide.hip
 int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out,
-                     int M, int N, int K, int epi, hipStream_t st);
+                     int M, int N, int K, int epi, hipStream_t st, const float* colscale = nullptr, float alpha = 1.f,
+                     float oscale = 1.f);
 
 // CMH_GEMM_IMPL=regstage selects the v1 register-staged kernel (A/B testing); default = LDS-DMA kernel.
 static int gemm_impl_from_env() {
@@ -257,6 +258,30 @@ int launch_gemm(int dt, const void* A, const void* W, const float* bias, const f
     g_prof.used += 2;
   }
   CMH_CHECK_LAUNCH("gemm");
+  return CMH_OK;
+}
+
+int launch_gemm_fp8(const void* A8, const void* W8, const float* colscale, float alpha, const float* bias, const float* residual,
+                    void* out, float oscale, int M, int N, int K, int epi, hipStream_t st) {
+  CMH_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm_fp8: empty problem M=%d N=%d K=%d", M, N, K);
+  CMH_CHECK_ARG(gemm_wide_supported(N) && K % 128 == 0, "gemm_fp8: N=%d must be a multiple of 256 and K=%d of 128", N, K);
+  CMH_CHECK_ARG(A8 && W8 && out && colscale, "gemm_fp8: null pointer");
+  CMH_CHECK_ARG(!(epi & EPI_BIAS) || bias, "gemm_fp8: EPI_BIAS without bias");
+  CMH_CHECK_ARG(!(epi & EPI_RESIDUAL) || residual, "gemm_fp8: EPI_RESIDUAL without residual");
+  CMH_CHECK_ARG(!(epi & EPI_MUL_DQGELU), "gemm_fp8: forward epilogues only");
+  const int okinds = ((epi & EPI_OUT_BF16) ? 1 : 0) + ((epi & EPI_OUT_F16) ? 1 : 0) + ((epi & EPI_OUT_FP8) ? 1 : 0);
+  CMH_CHECK_ARG(okinds <= 1, "gemm_fp8: one output type at a time");
+  const bool timed = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
+  if (timed) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
+  const int rc = launch_gemm_wide(CMH_FP8, A8, W8, bias, residual, out, M, N, K, epi | EPI_SCALE, st, colscale, alpha, oscale);
+  if (rc) return rc;
+  if (timed) {
+    (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
+    g_prof.flops.push_back(2.0 * M * static_cast<double>(N) * K);
+    g_prof.dims.push_back({M, N, K, epi | EPI_SCALE});
+    g_prof.used += 2;
+  }
+  CMH_CHECK_LAUNCH("gemm_fp8");
   return CMH_OK;
 }
 

@@ -62,21 +62,34 @@ __device__ unsigned long long g_wide_tl[256 * 8];
 #define W_TL(k) do { } while (0)
 #endif
 
-template <bool F32, bool OUTBF, int MF>   // MF = 16-row m-fragments per wave: tile rows = 32*MF (160, or 128 when that quantises better)
+// fp8 operands (DT = 2, the throughput mode of BASELINE configs[4]): OCP e4m3 rows of 128 bytes = 128 k per K-step, one
+// v_mfma_scale_f32_16x16x128_f8f6f4 per (n-tile, m-tile) and K-step (block scales fixed at 2^0; twice the bf16 MFMA's flops per
+// cycle), the dequantisation `acc * alpha * colscale[n]` (per-tensor activation scale x per-output-channel weight scale) fused
+// with the bias into one FMA of the epilogue, and optionally an e4m3 OUTPUT (`* oscale`, clamped to +-448) for the next GEMM.
+struct WideScales {
+  const float* colscale;   // [N] or null (EPI_SCALE)
+  float alpha;             // EPI_SCALE: acc *= alpha * colscale[n]
+  float oscale;            // EPI_OUT_FP8: out = e4m3(clamp(v * oscale))
+};
+
+template <int DT, int OK, int MF>   // DT: 0 f32, 1 bf16, 2 fp8 operands; OK: 0 f32, 1 16-bit (bf16 / fp16), 2 fp8 outputs;
+                                    // MF = 16-row m-fragments per wave: tile rows = 32*MF (160, 128 or 96)
 __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__ X, const char* __restrict__ W,
                                                         const float* __restrict__ bias, const float* residual,
-                                                        void* out, int M, int N, int K, int epi, int ksplit, int ordG) {
+                                                        void* out, int M, int N, int K, int epi, int ksplit, int ordG,
+                                                        WideScales sc) {
+  constexpr bool F32 = DT == 0, FP8 = DT == 2, OUTBF = OK == 1, OUT8 = OK == 2;
   constexpr int BMt = 32 * MF;                       // tile rows
   constexpr int WR = 16 * MF;                        // rows per wave
   constexpr int STG = wWBytes + BMt * wRowBytes;     // bytes per stage: 52 KB (MF = 5) or 48 KB (MF = 4)
   constexpr int XP = BMt / 8;                        // X pieces of 1 KiB per stage: 20 or 16
-  constexpr int NPEND = 2 * MF;                      // deferred 16-byte stores per lane per tile
+  constexpr int NPEND = OUT8 ? MF : 2 * MF;          // deferred 16-byte stores per lane per tile
   constexpr int NM = 4 * MF;                         // MFMAs per 32-deep half-step
   static_assert(MF >= 3 && MF <= 5, "wave layout: 2(m) x 4(n) waves of MF x 4 fragments");
   constexpr int PSTEP = MF == 3 ? 2 : 3;             // one LDS-DMA piece per PSTEP MFMAs: 6 (MF = 3, 4) or 7 pieces in 4*MF MFMAs
   __shared__ __attribute__((aligned(1024))) char lds[3 * STG];
 
-  constexpr int ELT = F32 ? 4 : 2;
+  constexpr int ELT = F32 ? 4 : (FP8 ? 1 : 2);
   constexpr int BK = wRowBytes / ELT;
 
   const int tid = threadIdx.x;
@@ -218,14 +231,16 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   } while (0)
 
   // ---- deferred stores of the previous tile (bf16 outputs only) --------------------------------------------
+  constexpr bool DEFER = true;
   w_u32x4_t pend[NPEND];
   bool pend_valid = false;
-  bf16_t* pend_ptr = nullptr;          // &out[(m0 + wm*80 + frow) * N + col] of the pending tile
-  const size_t row16 = static_cast<size_t>(16) * N;
+  char* pend_ptr = nullptr;            // &out[(m0 + wm*WR + frow) * N + col] of the pending tile
+  constexpr int OEL = OUT8 ? 1 : 2;    // bytes per output element of the packed store paths
+  const size_t row16 = static_cast<size_t>(16) * N * OEL;   // bytes between the 16-row fragments of a wave
   const int sps = (NPEND + nk - 1) / nk;   // stores per K-step so that all 10 leave within one tile's K loop
   auto store_pending = [&](int idx) {
     switch (idx) {   // compile-time register choice per case: no dynamically indexed vector arrays (they would go to scratch)
-#define W_ST(j) case j: if constexpr (j < NPEND) *reinterpret_cast<w_u32x4_t*>(pend_ptr + (j / 2) * row16 + (j % 2) * 32) = pend[j < NPEND ? j : 0]; break;
+#define W_ST(j) case j: if constexpr (j < NPEND) *reinterpret_cast<w_u32x4_t*>(pend_ptr + (OUT8 ? j : j / 2) * row16 + (OUT8 ? 0 : (j % 2) * 64)) = pend[j < NPEND ? j : 0]; break;
       W_ST(0) W_ST(1) W_ST(2) W_ST(3) W_ST(4) W_ST(5) W_ST(6) W_ST(7) W_ST(8) W_ST(9)
 #undef W_ST
       default: break;
@@ -252,9 +267,11 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   // the prologue instead of sitting exposed in the epilogue (residual GEMMs have <= 1 tile per workgroup: N = 512 / 768).
   // Measured inside the encoder: K = 512 / 768: -2.9 / -1.6 us per launch; K = 2048 / 3072: +0.3 / +2.3 us (the 40 MB burst
   // delays the first stage and a long K loop has no trouble hiding the epilogue's loads behind other workgroups) -> nk <= 16.
-  const bool res_first = (epi & EPI_RESIDUAL) && !(epi & (EPI_QUICKGELU | EPI_GELU | EPI_RELU)) && nk <= 16;
+  const bool res_first = (epi & EPI_RESIDUAL) && !(epi & (EPI_QUICKGELU | EPI_GELU | EPI_RELU | EPI_SCALE)) && nk <= 16;
   auto mfma = [&](const w_u32x4_t& fw, const w_u32x4_t& fx, w_f32x4_t& c) {
-    if constexpr (F32) {
+    if constexpr (FP8) {
+      (void)fw; (void)fx; (void)c;   // the fp8 K-step multiplies whole 128-k rows: mfma8 below
+    } else if constexpr (F32) {
 #pragma unroll
       for (int s = 0; s < 4; ++s)
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fw[s]), __uint_as_float(fx[s]), c, 0, 0, 0);
@@ -264,6 +281,18 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
     }
   };
 
+  // fp8: the two 16-byte halves of a lane's 32 k (chunks fq and fq+4 of the 128-byte row, the same for both operands, so the
+  // pairing inside the dot product is consistent whatever order the instruction gives its k) form one 8-register operand
+  typedef __attribute__((ext_vector_type(8))) int w_i32x8_t;
+  auto mfma8 = [&](const w_u32x4_t& w0, const w_u32x4_t& w1, const w_u32x4_t& x0, const w_u32x4_t& x1, w_f32x4_t& c) {
+    w_i32x8_t a, b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      a[j] = static_cast<int>(w0[j]); a[4 + j] = static_cast<int>(w1[j]);
+      b[j] = static_cast<int>(x0[j]); b[4 + j] = static_cast<int>(x1[j]);
+    }
+    c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);   // e4m3 x e4m3, block scales 2^0
+  };
 #ifdef W_STAMPS
   unsigned st_sum[4] = {0, 0, 0, 0};
   unsigned long long st_last = __builtin_readcyclecounter();
@@ -339,7 +368,37 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   int cur = 0;
   int ns = 0;                   // deferred stores issued since the last counted wait
   w_u32x4_t f0w[4], f0x[MF], f1w[4], f1x[MF];
-  load_frags(f0w, f0x, 0, 0);   // from here on F0 of K-step s+1 (also across tiles) is fetched in the second half of s
+  // every fragment register of the wave as an operand of a counted wait (fp8 K-step): nothing that reads them moves above it
+#define W_WAIT_ALL(cnt)                                                                                                   \
+  do {                                                                                                                    \
+    if constexpr (MF == 5)                                                                                                \
+      asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                                          \
+                   : "+v"(f0w[0]), "+v"(f0w[1]), "+v"(f0w[2]), "+v"(f0w[3]), "+v"(f1w[0]), "+v"(f1w[1]), "+v"(f1w[2]),    \
+                     "+v"(f1w[3]), "+v"(f0x[0]), "+v"(f0x[1]), "+v"(f0x[2]), "+v"(f0x[MF > 3 ? 3 : 0]),                   \
+                     "+v"(f0x[MF > 4 ? 4 : 0]), "+v"(f1x[0]), "+v"(f1x[1]), "+v"(f1x[2]), "+v"(f1x[MF > 3 ? 3 : 0]),      \
+                     "+v"(f1x[MF > 4 ? 4 : 0])::"memory");                                                                \
+    else if constexpr (MF == 4)                                                                                           \
+      asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                                          \
+                   : "+v"(f0w[0]), "+v"(f0w[1]), "+v"(f0w[2]), "+v"(f0w[3]), "+v"(f1w[0]), "+v"(f1w[1]), "+v"(f1w[2]),    \
+                     "+v"(f1w[3]), "+v"(f0x[0]), "+v"(f0x[1]), "+v"(f0x[2]), "+v"(f0x[MF > 3 ? 3 : 0]), "+v"(f1x[0]),     \
+                     "+v"(f1x[1]), "+v"(f1x[2]), "+v"(f1x[MF > 3 ? 3 : 0])::"memory");                                    \
+    else                                                                                                                  \
+      asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                                          \
+                   : "+v"(f0w[0]), "+v"(f0w[1]), "+v"(f0w[2]), "+v"(f0w[3]), "+v"(f1w[0]), "+v"(f1w[1]), "+v"(f1w[2]),    \
+                     "+v"(f1w[3]), "+v"(f0x[0]), "+v"(f0x[1]), "+v"(f0x[2]), "+v"(f1x[0]), "+v"(f1x[1]), "+v"(f1x[2])     \
+                   ::"memory");                                                                                           \
+  } while (0)
+  if constexpr (FP8) {
+    // fp8 K-step s starts with BOTH halves of W tiles 0,1 and of every X tile of stage s in (or on their way to) registers
+    const uint32_t w0 = aW, w1 = aW ^ 64u, x0 = aX, x1 = aX ^ 64u;
+    W_READ(f0w[0], w0, 0); W_READ(f1w[0], w1, 0); W_READ(f0w[1], w0, 2048); W_READ(f1w[1], w1, 2048);
+    W_READ(f0x[0], x0, 0); W_READ(f1x[0], x1, 0); W_READ(f0x[1], x0, 2048); W_READ(f1x[1], x1, 2048);
+    W_READ(f0x[2], x0, 4096); W_READ(f1x[2], x1, 4096);
+    if constexpr (MF >= 4) { W_READ(f0x[MF >= 4 ? 3 : 0], x0, 6144); W_READ(f1x[MF >= 4 ? 3 : 0], x1, 6144); }
+    if constexpr (MF == 5) { W_READ(f0x[MF - 1], x0, 8192); W_READ(f1x[MF - 1], x1, 8192); }
+  } else {
+    load_frags(f0w, f0x, 0, 0);   // from here on F0 of K-step s+1 (also across tiles) is fetched in the second half of s
+  }
   for (int ti = 0; ti < my_tiles; ++ti) {
     if (ti > 0) {
 #pragma unroll
@@ -349,6 +408,81 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
     }
 
     for (int kt = 0; kt < nk; ++kt) {
+      if constexpr (FP8) {
+        // ---- fp8 K-step: 4*MF scaled MFMAs of 128 k, 2*MF per half; same barrier / DMA / store protocol as below ---------
+        constexpr int NM2 = 2 * MF;                    // MFMAs per half
+        constexpr int NP = MF == 5 ? 7 : 6;            // LDS-DMA pieces per wave and stage
+        auto stores8 = [&]() {
+          if constexpr (OK != 0 && DEFER) {
+            if (pend_valid) {
+              for (int j = 0; j < sps; ++j) {
+                const int idx = kt * sps + j;
+                if (idx < NPEND) { store_pending(idx); ++ns; }
+              }
+            }
+          }
+        };
+        {   // first half: W tiles 2,3 of this stage arrive while tiles 0,1 multiply
+          const uint32_t bo = static_cast<uint32_t>(cur) * STG;
+          const uint32_t w0 = aW + bo, w1 = (aW + bo) ^ 64u;
+          W_READ(f0w[2], w0, 4096); W_READ(f1w[2], w1, 4096); W_READ(f0w[3], w0, 6144); W_READ(f1w[3], w1, 6144);
+        }
+        W_WAIT_ALL(6);   // all but these four and the last X tile's two reads (issued last in the previous half) have landed
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!GB) stores8();
+        __builtin_amdgcn_s_setprio(GB ? 0 : 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NM2; ++i) {
+          if constexpr (GB) {
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) if (i == pc * NM2 / NP) issue_piece(pc);
+          }
+          if (i == 2 * (MF - 1)) { W_WAIT_ALL(4); __builtin_amdgcn_sched_barrier(0); }
+          mfma8(f0w[i & 1], f1w[i & 1], f0x[i >> 1], f1x[i >> 1], acc[i & 1][i >> 1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (GB) issue_done();
+        __builtin_amdgcn_sched_barrier(0);
+        W_WAIT_ALL(0);
+        if (ns == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (ns == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        ns = 0;
+        __builtin_amdgcn_s_barrier();
+        const int nxt = cur == 2 ? 0 : cur + 1;
+        {   // second half: W tiles 2,3; the next stage's W tiles 0,1 and X tiles replace registers as they fall free
+          const uint32_t bo = static_cast<uint32_t>(nxt) * STG;
+          const uint32_t nW0 = aW + bo, nW1 = (aW + bo) ^ 64u, nX0 = aX + bo, nX1 = (aX + bo) ^ 64u;
+          if constexpr (GB) stores8();
+          __builtin_amdgcn_s_setprio(GB ? 1 : 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < NM2; ++i) {
+            if constexpr (!GB) {
+#pragma unroll
+              for (int pc = 0; pc < NP; ++pc) if (i == pc * NM2 / NP) issue_piece(pc);
+            }
+            if (i == 0) W_READ(f0w[0], nW0, 0);
+            if (i == 1) W_READ(f1w[0], nW1, 0);
+            if (i == 2) { W_READ(f0w[1], nW0, 2048); W_READ(f0x[0], nX0, 0); }
+            if (i == 3) { W_READ(f1w[1], nW1, 2048); W_READ(f1x[0], nX1, 0); }
+            if (i == 4) W_READ(f0x[1], nX0, 2048);
+            if (i == 5) W_READ(f1x[1], nX1, 2048);
+            if constexpr (MF >= 4) { if (i == 6) W_READ(f0x[2], nX0, 4096); if (i == 7) W_READ(f1x[2], nX1, 4096); }
+            if constexpr (MF == 5) { if (i == 8) W_READ(f0x[MF > 3 ? 3 : 0], nX0, 6144); if (i == 9) W_READ(f1x[MF > 3 ? 3 : 0], nX1, 6144); }
+            mfma8(f0w[2 + (i & 1)], f1w[2 + (i & 1)], f0x[i >> 1], f1x[i >> 1], acc[2 + (i & 1)][i >> 1]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          // the last X tile's registers are free only now
+          if constexpr (MF == 3) { W_READ(f0x[2], nX0, 4096); W_READ(f1x[2], nX1, 4096); }
+          if constexpr (MF == 4) { W_READ(f0x[MF > 3 ? 3 : 0], nX0, 6144); W_READ(f1x[MF > 3 ? 3 : 0], nX1, 6144); }
+          if constexpr (MF == 5) { W_READ(f0x[MF - 1], nX0, 8192); W_READ(f1x[MF - 1], nX1, 8192); }
+          if constexpr (!GB) issue_done();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+      } else {
       W_STAMP(0);   // second half of the previous K-step (+ epilogue at kt = 0)
 #ifndef W_ABL_NOREAD
       load_frags(f1w, f1x, cur, 1);                                   // 1
@@ -423,6 +557,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
       }
       __builtin_amdgcn_sched_barrier(0);
       cur = nxt;
+      }
     }
     pend_valid = false;   // sps * nk >= 10: every deferred store of the previous tile has been issued
     if (ti == 0) W_TL(2);              // first tile's K loop done
@@ -436,7 +571,17 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
     const int m0 = tm * BMt, n0 = tn * wBN;
     // All loads first, then all stores: a load issued behind a store (or waited for with DMA in flight) would wait for
     // every older store to be acknowledged.
-    if (epi & EPI_BIAS) {
+    if (FP8 && (epi & EPI_SCALE)) {   // dequantisation of fp8 operands, fused with the bias: acc * (alpha * colscale[n]) + bias[n]
+      // (fp8 instantiations only, one n-tile at a time: the 160-row variants have no registers to spare)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const w_f32x4_t cs = *reinterpret_cast<const w_f32x4_t*>(sc.colscale + n0 + wn * 64 + a * 16 + fq * 4) * sc.alpha;
+        const w_f32x4_t bv = (epi & EPI_BIAS) ? *reinterpret_cast<const w_f32x4_t*>(bias + n0 + wn * 64 + a * 16 + fq * 4)
+                                              : w_f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < MF; ++b) acc[a][b] = acc[a][b] * cs + bv;
+      }
+    } else if (epi & EPI_BIAS) {
       w_f32x4_t bv[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) bv[a] = *reinterpret_cast<const w_f32x4_t*>(bias + n0 + wn * 64 + a * 16 + fq * 4);
@@ -505,7 +650,37 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
       }
     }
     const bool full = m0 + BMt <= M;
-    if constexpr (OUTBF) {
+    if constexpr (OUT8) {
+      // e4m3 outputs: a lane's 4 consecutive n of n-tile a become one dword; a 4x4 transpose between the lane quarters (fq) and
+      // the n-tile index (v_permlane32_swap on tiles (0,2), (1,3), then v_permlane16_swap on (0,1), (2,3)) leaves quarter fq with
+      // 16 consecutive n of one row: n0 + wn*64 + fq*16 .. +15 -> one 16-byte store per 16-row fragment
+#pragma unroll
+      for (int b = 0; b < MF; ++b) {
+        uint32_t t[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fminf(fmaxf(acc[a][b][j] * sc.oscale, -448.f), 448.f);
+          int w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+          w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+          t[a] = static_cast<uint32_t>(w);
+        }
+        const w_u2_t p02 = __builtin_amdgcn_permlane32_swap(t[0], t[2], false, false);   // -> [t0.lo, t2.lo], [t0.hi, t2.hi]
+        const w_u2_t p13 = __builtin_amdgcn_permlane32_swap(t[1], t[3], false, false);
+        const w_u2_t q01 = __builtin_amdgcn_permlane16_swap(p02[0], p13[0], false, false);
+        const w_u2_t q23 = __builtin_amdgcn_permlane16_swap(p02[1], p13[1], false, false);
+        pend[b][0] = q01[0]; pend[b][1] = q01[1]; pend[b][2] = q23[0]; pend[b][3] = q23[1];
+      }
+      pend_ptr = static_cast<char*>(out) + static_cast<size_t>(m0 + wm * WR + frow) * N + n0 + wn * 64 + fq * 16;
+      if (full && ti + 1 < my_tiles && !(epi & (256 | 512))) {
+        pend_valid = true;
+      } else if (!(epi & 256)) {
+#pragma unroll
+        for (int j = 0; j < NPEND; ++j)
+          if (m0 + wm * WR + j * 16 + frow < M) *reinterpret_cast<w_u32x4_t*>(pend_ptr + j * row16) = pend[j];
+      }
+    } else if constexpr (OUTBF) {
       // v_permlane16_swap exchanges, between the lane pairs (l, l+16), the packed words of two neighbouring n-tiles: an even
       // lane-row then owns 8 consecutive n of tile a and an odd lane-row 8 consecutive n of tile a+1 -> 16-byte stores.
       const int col = n0 + wn * 64 + (fq & 1) * 16 + (fq & 2) * 4;    // + 32*pair
@@ -532,14 +707,14 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
           pend[b * 2 + pr][0] = s0[0]; pend[b * 2 + pr][1] = s1[0]; pend[b * 2 + pr][2] = s0[1]; pend[b * 2 + pr][3] = s1[1];
         }
       }
-      pend_ptr = static_cast<bf16_t*>(out) + static_cast<size_t>(m0 + wm * WR + frow) * N + col;
-      if (full && ti + 1 < my_tiles && !(epi & (256 | 512))) {   // 512 = ablation: store from the epilogue
+      pend_ptr = static_cast<char*>(out) + (static_cast<size_t>(m0 + wm * WR + frow) * N + col) * 2;
+      if (DEFER && full && ti + 1 < my_tiles && !(epi & (256 | 512))) {   // 512 = ablation: store from the epilogue
         pend_valid = true;                       // leave under the next tile's MFMAs
       } else if (!(epi & 256)) {                 // 256 = timing-only ablation: skip stores
 #pragma unroll
         for (int j = 0; j < NPEND; ++j)
           if (m0 + wm * WR + (j / 2) * 16 + frow < M)
-            *reinterpret_cast<w_u32x4_t*>(pend_ptr + (j / 2) * row16 + (j % 2) * 32) = pend[j];
+            *reinterpret_cast<w_u32x4_t*>(pend_ptr + (j / 2) * row16 + (j % 2) * 64) = pend[j];
       }
     } else if (!(epi & 256)) {
 #pragma unroll
@@ -586,9 +761,12 @@ static int g_force_order = []() { const char* e = getenv("CMH_GEMM_ORDER"); retu
 
 // n-panels per group of the tile order (see tile_coords in the kernel); 0 = the n-fastest order
 static int wide_order_group(int N) {
-  if (g_force_order >= 0) return g_force_order;
-  const int tiles_n = N / wBN;
-  return tiles_n <= 4 ? tiles_n : (tiles_n % 4 == 0 ? 4 : (tiles_n % 3 == 0 ? 3 : 4));
+  // Measured (round 2, tools/gemm_bench2.py + bench.py A/B on one box): groups of 3-4 panels are +6 % on a back-to-back chain
+  // of the four GEMMs of a block, but -6 ... -10 % on the QKV / c_fc launches INSIDE the encoder (their X operand was just
+  // written by the LayerNorm kernel and is shared by 9-12 concurrent tiles in the n-fastest order; grouped, it is re-read once
+  // per group after the outputs have passed through the L2).  Default: n-fastest.
+  (void)N;
+  return g_force_order >= 0 ? g_force_order : 0;
 }
 
 static int wide_cus() {
@@ -622,11 +800,11 @@ int launch_gemm_wide_splitk(int dt, const void* A, const void* W, float* out, fl
   const int cus = wide_cus();
   const int grid = total < cus ? ((total + 7) & ~7) : cus;
   if (dt == CMH_F32)
-    hipLaunchKernelGGL((gemm_wide_kernel<true, false, 5>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),
-                       static_cast<const char*>(W), nullptr, nullptr, partials, M, N, K, 0, S, wide_order_group(N));
+    hipLaunchKernelGGL((gemm_wide_kernel<0, 0, 5>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),
+                       static_cast<const char*>(W), nullptr, nullptr, partials, M, N, K, 0, S, wide_order_group(N), WideScales{nullptr, 1.f, 1.f});
   else
-    hipLaunchKernelGGL((gemm_wide_kernel<false, false, 5>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),
-                       static_cast<const char*>(W), nullptr, nullptr, partials, M, N, K, 0, S, wide_order_group(N));
+    hipLaunchKernelGGL((gemm_wide_kernel<1, 0, 5>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),
+                       static_cast<const char*>(W), nullptr, nullptr, partials, M, N, K, 0, S, wide_order_group(N), WideScales{nullptr, 1.f, 1.f});
   const size_t n = static_cast<size_t>(M) * N;
   const size_t blocks = (n / 4 + 255) / 256;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, partials, S, n, out);
@@ -634,8 +812,9 @@ int launch_gemm_wide_splitk(int dt, const void* A, const void* W, float* out, fl
 }
 
 int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out,
-                     int M, int N, int K, int epi, hipStream_t st) {
-  const size_t esz = dt == CMH_F32 ? 4 : 2;
+                     int M, int N, int K, int epi, hipStream_t st, const float* colscale, float alpha, float oscale) {
+  const WideScales sc{colscale, alpha, oscale};
+  const size_t esz = dt == CMH_F32 ? 4 : (dt == CMH_FP8 ? 1 : 2);
   if (static_cast<size_t>(M) * K * esz >= (1ull << 32) || static_cast<size_t>(wBN) * K * esz >= (1ull << 32))
     return fail(CMH_ERR_INVALID, "gemm: operand of %zu bytes exceeds the 32-bit offset range of the wide kernel",
                 static_cast<size_t>(M) * K * esz);
@@ -644,34 +823,51 @@ int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, co
   // 19 712 (the dense towers) take 160; the packed text rows (M ~ 10 k) take 128 at N = 1536 / 2048 and 96 at N = 512, where one
   // round of 220 tiles keeps 86 % of the CUs busy instead of 65 % (166 tiles of 128 rows).  CMH_GEMM_BM=96|128|160 forces one.
   const int cus = wide_cus();
-  const int nk = K / (dt == CMH_F32 ? 32 : 64);
+  const int nk = K / (dt == CMH_F32 ? 32 : (dt == CMH_FP8 ? 128 : 64));
   auto cost = [&](int mf) {   // rounds x (rows + the per-K-step cost that does not shrink with the tile: W fragment reads, barrier) x K-steps
     const int tiles = (N / wBN) * ((M + 32 * mf - 1) / (32 * mf));
     return static_cast<long long>((tiles + cus - 1) / cus) * (10 * mf + 6) * (nk + 4);
   };
   const int forced = g_force_rows;
-  int mf = 5;
-  if (cost(4) < cost(mf)) mf = 4;
+  // fp8: 128 rows at most.  The 160-row variant needs 56 fragment registers live across the epilogue (both 16-byte halves of
+  // the next K-step's operands, as aligned 8-register MFMA operands) next to 80 accumulators and the pending stores: hipcc
+  // spills inside the K loop (scratch reloads with vmcnt(0) drain the LDS-DMA pipeline: measured 64 us against bf16's 46 on QKV).
+  int mf = dt == CMH_FP8 ? 4 : 5;
+  if (mf == 5 && cost(4) < cost(mf)) mf = 4;
   if (cost(3) < cost(mf)) mf = 3;
-  if (forced == 96 || forced == 128 || forced == 160) mf = forced / 32;
+  if (forced == 96 || forced == 128 || (forced == 160 && dt != CMH_FP8)) mf = forced / 32;
   const int total = (N / wBN) * ((M + 32 * mf - 1) / (32 * mf));
   int grid = total < cus ? ((total + 7) & ~7) : cus;
   const int ordg = wide_order_group(N);
-#define W_LAUNCH(F32, OUTBF)                                                                                              \
+#define W_LAUNCH(DT, OK)                                                                                                  \
   do {                                                                                                                    \
     if (mf == 3)                                                                                                          \
-      hipLaunchKernelGGL((gemm_wide_kernel<F32, OUTBF, 3>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),    \
-                         static_cast<const char*>(W), bias, residual, out, M, N, K, epi, 1, ordg);                            \
+      hipLaunchKernelGGL((gemm_wide_kernel<DT, OK, 3>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),        \
+                         static_cast<const char*>(W), bias, residual, out, M, N, K, epi, 1, ordg, sc);                    \
     else if (mf == 4)                                                                                                     \
-      hipLaunchKernelGGL((gemm_wide_kernel<F32, OUTBF, 4>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),    \
-                         static_cast<const char*>(W), bias, residual, out, M, N, K, epi, 1, ordg);                            \
+      hipLaunchKernelGGL((gemm_wide_kernel<DT, OK, 4>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),        \
+                         static_cast<const char*>(W), bias, residual, out, M, N, K, epi, 1, ordg, sc);                    \
     else                                                                                                                  \
-      hipLaunchKernelGGL((gemm_wide_kernel<F32, OUTBF, 5>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),    \
-                         static_cast<const char*>(W), bias, residual, out, M, N, K, epi, 1, ordg);                            \
+      hipLaunchKernelGGL((gemm_wide_kernel<DT, OK, 5>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),        \
+                         static_cast<const char*>(W), bias, residual, out, M, N, K, epi, 1, ordg, sc);                    \
   } while (0)
   const bool obf = epi & (EPI_OUT_BF16 | EPI_OUT_F16);   // 16-bit outputs share the packed store path
-  if (dt == CMH_F32) { if (obf) W_LAUNCH(true, true); else W_LAUNCH(true, false); }
-  else { if (obf) W_LAUNCH(false, true); else W_LAUNCH(false, false); }
+  const bool o8 = epi & EPI_OUT_FP8;
+  if (dt == CMH_F32) { if (obf) W_LAUNCH(0, 1); else W_LAUNCH(0, 0); }
+  else if (dt == CMH_BF16) { if (obf) W_LAUNCH(1, 1); else W_LAUNCH(1, 0); }
+  else {
+#undef W_LAUNCH
+#define W_LAUNCH(DT, OK)                                                                                                  \
+  do {                                                                                                                    \
+    if (mf == 3)                                                                                                          \
+      hipLaunchKernelGGL((gemm_wide_kernel<DT, OK, 3>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),        \
+                         static_cast<const char*>(W), bias, residual, out, M, N, K, epi, 1, ordg, sc);                    \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((gemm_wide_kernel<DT, OK, 4>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),        \
+                         static_cast<const char*>(W), bias, residual, out, M, N, K, epi, 1, ordg, sc);                    \
+  } while (0)
+    if (o8) W_LAUNCH(2, 2); else if (obf) W_LAUNCH(2, 1); else W_LAUNCH(2, 0);
+  }
 #undef W_LAUNCH
   return 0;
 }

@@ -120,16 +120,40 @@ def _gemm_w(p: torch.Tensor, dt: int, keep: list, transpose: bool = False) -> to
     t = p.detach().float()
     t = t.t().contiguous() if transpose else t.contiguous()
     t = t.reshape(t.shape[0], -1)
-    if dt == N.BF16:
+    if dt in (N.BF16, N.FP8):       # outside the blocks the fp8 mode is the bf16 mode (conv1, the final projections)
         t = N.cast_bf16(t)
     keep.append(t)
     return t
 
 
-def _fill_blocks(resblocks, dt: int, keep: list):
+def _fp8_w(p: torch.Tensor, keep: list):
+    """Linear weight [out, in] -> (e4m3 bytes, per-output-channel scales): the tensors convert_weights lowers upstream."""
+    q, cs = N.fp8_quantize_weight(p.detach().float().contiguous())
+    keep.extend((q, cs))
+    return q.data_ptr(), cs.data_ptr()
+
+
+FP8_HEADROOM = 2.0     # act_scale = FP8_HEADROOM * amax(calibration batch) / 448: later batches may exceed the calibration maximum
+
+
+def _fill_blocks(resblocks, dt: int, keep: list, act_amax=None):
     arr = (N.BlockWeights * len(resblocks))()
     for i, blk in enumerate(resblocks):
         b = arr[i]
+        if dt == N.FP8:
+            if act_amax is None:
+                raise N.NativeError("fp8 mode needs activation scales: call clip.calibrate_fp8(images, texts) first")
+            b.in_proj_w, b.in_proj_cs = _fp8_w(blk.attn.in_proj_weight, keep)
+            b.out_proj_w, b.out_proj_cs = _fp8_w(blk.attn.out_proj.weight, keep)
+            b.fc_w, b.fc_cs = _fp8_w(blk.mlp.c_fc.weight, keep)
+            b.proj_w, b.proj_cs = _fp8_w(blk.mlp.c_proj.weight, keep)
+            for j in range(4):
+                b.act_scale[j] = max(float(act_amax[i][j]), 1e-6) * FP8_HEADROOM / 448.0
+            for name, src in (("in_proj_b", blk.attn.in_proj_bias), ("out_proj_b", blk.attn.out_proj.bias), ("ln1_w", blk.ln_1.weight),
+                              ("ln1_b", blk.ln_1.bias), ("ln2_w", blk.ln_2.weight), ("ln2_b", blk.ln_2.bias),
+                              ("fc_b", blk.mlp.c_fc.bias), ("proj_b", blk.mlp.c_proj.bias)):
+                setattr(b, name, _prep(src, keep).data_ptr())
+            continue
         b.in_proj_w = _gemm_w(blk.attn.in_proj_weight, dt, keep).data_ptr()
         b.in_proj_b = _prep(blk.attn.in_proj_bias, keep).data_ptr()
         b.out_proj_w = _gemm_w(blk.attn.out_proj.weight, dt, keep).data_ptr()
@@ -145,7 +169,7 @@ def _fill_blocks(resblocks, dt: int, keep: list):
     return arr
 
 
-_DT = {"f32": N.F32, "fp32": N.F32, "float32": N.F32, "bf16": N.BF16, "bfloat16": N.BF16}
+_DT = {"f32": N.F32, "fp32": N.F32, "float32": N.F32, "bf16": N.BF16, "bfloat16": N.BF16, "fp8": N.FP8, "e4m3": N.FP8}
 
 
 class CLIP(nn.Module):
@@ -173,6 +197,7 @@ class CLIP(nn.Module):
         self._vit_cache = _TowerCache()
         self._txt_cache = _TowerCache()
         self.assume_frozen = False     # True: skip the per-call parameter-version scan (pure inference)
+        self._fp8_amax = {"vit": None, "text": None}     # [layers, 4] calibration maxima of the four GEMM inputs per block
 
     # -- reference API ---------------------------------------------------------------------------
     def initialize_parameters(self):
@@ -205,8 +230,52 @@ class CLIP(nn.Module):
         return self.visual.conv1.weight.device
 
     def set_gemm_dtype(self, name: str):
+        """"f32" (parity mode), "bf16" (throughput mode) or "fp8" (BASELINE configs[4]: the blocks' four GEMMs on e4m3 operands;
+        inference only; activation scales come from `calibrate_fp8`, run on the first batch if it was not called)."""
         self._gemm_dtype = _DT[name.lower()]
         return self
+
+    def calibrate_fp8(self, image=None, text=None, reset=True):
+        """Calibration pass of the fp8 mode: runs the batch(es) in bf16 mode and records, per block, the largest magnitude of the
+        four GEMM inputs (ln_1 output, attention output, ln_2 output, QuickGELU(c_fc) output).  The per-tensor quantisation
+        scales are FP8_HEADROOM * amax / 448.  Call again with reset=False to widen the maxima with more batches.
+        Returns the bf16-mode features of the batches it was given."""
+        mode, self._gemm_dtype = self._gemm_dtype, N.BF16
+        out = []
+        try:
+            with torch.no_grad():
+                for tower, x in (("vit", image), ("text", text)):
+                    if x is None:
+                        continue
+                    s = self._vit_struct() if tower == "vit" else self._text_struct()
+                    dev = x.device
+                    N.require_gpu(x)
+                    prev = self._fp8_amax[tower]
+                    amax = torch.zeros(s.layers * 4, dtype=torch.float32, device=dev)
+                    if prev is not None and not reset:
+                        amax.copy_(torch.as_tensor(prev, dtype=torch.float32).reshape(-1))
+                    B = x.shape[0]
+                    feat = torch.empty(B, s.embed_dim, dtype=torch.float32, device=dev)
+                    if tower == "vit":
+                        x = N.f32c(x)
+                        ws = N.workspace(N.lib().cmh_vit_workspace_bytes(C.byref(s), B), dev, f"vit@{N.stream_ptr(dev)}")
+                        N.check(N.lib().cmh_vit_calibrate_fp8(C.byref(s), N.ptr(x), B, N.ptr(feat), N.ptr(amax), N.ptr(ws), ws.numel(),
+                                                              N.stream_ptr(dev)), "cmh_vit_calibrate_fp8")
+                    else:
+                        x = x.to(torch.int64).contiguous()
+                        L = x.shape[1]
+                        ws = N.workspace(N.lib().cmh_text_workspace_bytes(C.byref(s), B, L), dev, f"text@{N.stream_ptr(dev)}")
+                        N.check(N.lib().cmh_text_calibrate_fp8(C.byref(s), N.ptr(x), B, L, N.ptr(feat), N.ptr(amax), N.ptr(ws), ws.numel(),
+                                                               N.stream_ptr(dev)), "cmh_text_calibrate_fp8")
+                    vals = amax.cpu().reshape(s.layers, 4)
+                    if not bool(torch.isfinite(vals).all()):
+                        raise N.NativeError("calibrate_fp8: non-finite activations in the calibration batch")
+                    self._fp8_amax[tower] = vals.tolist()
+                    (self._vit_cache if tower == "vit" else self._txt_cache).key = None       # scales changed: rebuild the fp8 structs
+                    out.append(feat)
+        finally:
+            self._gemm_dtype = mode
+        return tuple(out)
 
     # encode_text skips the padding after each caption's EOT (bit-identical pooled features, cmh_text_encode_packed);
     # CMH_TEXT_PACK=0 or `clip.pack_text = False` computes all context_length positions like the reference
@@ -215,7 +284,7 @@ class CLIP(nn.Module):
 
     @property
     def gemm_dtype(self) -> str:
-        return "bf16" if self._gemm_dtype == N.BF16 else "f32"
+        return {N.BF16: "bf16", N.FP8: "fp8"}.get(self._gemm_dtype, "f32")
 
     # -- native weight structs -------------------------------------------------------------------
     def _key(self, params):
@@ -243,7 +312,7 @@ class CLIP(nn.Module):
             s.ln_post_w = _prep(v.ln_post.weight, keep).data_ptr()
             s.ln_post_b = _prep(v.ln_post.bias, keep).data_ptr()
             s.proj_t = _gemm_w(v.proj, dt, keep, transpose=True).data_ptr()
-            c.blocks = _fill_blocks(v.transformer.resblocks, dt, keep)
+            c.blocks = _fill_blocks(v.transformer.resblocks, dt, keep, self._fp8_amax["vit"])
             s.blocks = C.cast(c.blocks, C.POINTER(N.BlockWeights))
             c.struct, c.keep, c.key = s, keep, key
         return c.struct
@@ -267,7 +336,7 @@ class CLIP(nn.Module):
             s.ln_final_w = _prep(self.ln_final.weight, keep).data_ptr()
             s.ln_final_b = _prep(self.ln_final.bias, keep).data_ptr()
             s.text_projection_t = _gemm_w(self.text_projection, dt, keep, transpose=True).data_ptr()
-            c.blocks = _fill_blocks(self.transformer.resblocks, dt, keep)
+            c.blocks = _fill_blocks(self.transformer.resblocks, dt, keep, self._fp8_amax["text"])
             s.blocks = C.cast(c.blocks, C.POINTER(N.BlockWeights))
             c.struct, c.keep, c.key = s, keep, key
         return c.struct
@@ -285,6 +354,8 @@ class CLIP(nn.Module):
         """image f32 [B,3,R,R] -> [B, embed_dim] f32  (reference model/base/model.py:356-357,228-252)."""
         image = N.f32c(image)
         N.require_gpu(image, self.visual.proj)
+        if self._gemm_dtype == N.FP8 and self._fp8_amax["vit"] is None:
+            self.calibrate_fp8(image=image)              # first batch calibrates the activation scales
         s = self._vit_struct()
         B = image.shape[0]
         if tuple(image.shape[1:]) != (3, s.resolution, s.resolution):
@@ -293,10 +364,12 @@ class CLIP(nn.Module):
             from model.base import train_ops as T            # training: tape-keeping forward with a real backward
             params = T.vit_params(self.visual)
             if T.wants_grad(params):
+                if self._gemm_dtype == N.FP8:
+                    raise N.NativeError("the fp8 mode is inference-only: use torch.no_grad() or set_gemm_dtype('bf16' | 'f32') to train")
                 return T.VitTrain.apply(self, image, *params)
         feat = torch.empty(B, s.embed_dim, dtype=torch.float32, device=image.device)
         need = N.lib().cmh_vit_workspace_bytes(C.byref(s), B)
-        ws = N.workspace(need, image.device, "vit")
+        ws = N.workspace(need, image.device, f"vit@{N.stream_ptr(image.device)}")   # one scratch per stream: sub-batches may overlap
         tp, _arr = self._taps(taps)
         N.check(N.lib().cmh_vit_encode(C.byref(s), N.ptr(image), B, N.ptr(feat), N.ptr(ws), ws.numel(),
                                        None if tp is None else C.byref(tp), N.stream_ptr(image.device)),
@@ -307,6 +380,8 @@ class CLIP(nn.Module):
         """text i64 [B,L] -> [B, embed_dim] f32  (reference model/base/model.py:359-372)."""
         N.require_gpu(text, self.text_projection)
         text = text.to(torch.int64).contiguous()
+        if self._gemm_dtype == N.FP8 and self._fp8_amax["text"] is None:
+            self.calibrate_fp8(text=text)
         s = self._text_struct()
         B, L = text.shape
         kpm = None if key_padding_mask is None else key_padding_mask.to(torch.uint8).contiguous()
@@ -314,10 +389,12 @@ class CLIP(nn.Module):
             from model.base import train_ops as T
             params = T.text_params(self)
             if T.wants_grad(params):
+                if self._gemm_dtype == N.FP8:
+                    raise N.NativeError("the fp8 mode is inference-only: use torch.no_grad() or set_gemm_dtype('bf16' | 'f32') to train")
                 return T.TextTrain.apply(self, text, kpm, *params)
         feat = torch.empty(B, s.embed_dim, dtype=torch.float32, device=text.device)
         need = N.lib().cmh_text_workspace_bytes(C.byref(s), B, L)
-        ws = N.workspace(need, text.device, "text")
+        ws = N.workspace(need, text.device, f"text@{N.stream_ptr(text.device)}")
         if kpm is None and taps is None and self.pack_text:
             # only the tokens up to each caption's EOT can reach the pooled row under the causal mask: skip the padding
             rows = C.c_int32(0)

@@ -45,7 +45,11 @@ typedef enum cmh_status {
  * chain; the parity mode against the fp32 reference, train/.../hash_train.py `self.model.float()`).
  * CMH_BF16: bf16 operands, fp32 accumulate on v_mfma_f32_16x16x32_bf16; LayerNorm/softmax/residual
  * stream stay fp32. */
-typedef enum cmh_dtype { CMH_F32 = 0, CMH_BF16 = 1 } cmh_dtype;
+typedef enum cmh_dtype { CMH_F32 = 0, CMH_BF16 = 1, CMH_FP8 = 2 } cmh_dtype;
+/* CMH_FP8 (BASELINE configs[4] "fp8 MFMA CLIP encoders"): the four GEMMs of every block (QKV, out_proj, c_fc, c_proj) take OCP
+ * e4m3 operands on v_mfma_scale_f32_16x16x128_f8f6f4 (f32 accumulate): weights quantised per output channel, activations per
+ * tensor with scales from a calibration pass; everything else as CMH_BF16 (fp16 residual stream, f32 LayerNorm statistics and
+ * softmax; conv1 and the final projections stay bf16).  Needs width % 256 == 0.  See "fp8 encoder mode" below. */
 
 const char* cmh_last_error(void);
 int cmh_version(void);
@@ -69,6 +73,13 @@ typedef struct cmh_block_weights {
   const float* fc_b;        /* [4d] */
   const void* proj_w;       /* [d, 4d]  mlp.c_proj.weight */
   const float* proj_b;      /* [d] */
+  /* CMH_FP8 only (ignored otherwise): the four `*_w` above are e4m3 bytes from cmh_fp8_quantize_weight */
+  const float* in_proj_cs;  /* [3d] per-output-channel scales of in_proj_w */
+  const float* out_proj_cs; /* [d] */
+  const float* fc_cs;       /* [4d] */
+  const float* proj_cs;     /* [d] */
+  float act_scale[4];       /* per-tensor scales of the four GEMM inputs: ln_1 output, attention output, ln_2 output,
+                             * QuickGELU(c_fc) output; x_fp8 = e4m3(x / act_scale).  From cmh_*_calibrate_fp8: headroom * amax / 448 */
 } cmh_block_weights;
 
 /* Image tower = reference model/base/model.py:210-252 VisionTransformer. */
@@ -126,6 +137,15 @@ int cmh_text_encode(const cmh_text_weights* w, const int64_t* tokens, int32_t ba
                     const uint8_t* key_padding_mask, float* feat, void* workspace,
                     size_t workspace_bytes, const cmh_taps* taps, void* stream);
 
+/* Calibration pass of the fp8 mode: the CMH_BF16 encode of this batch (`w` holds bf16 weights; feat as cmh_vit_encode /
+ * cmh_text_encode_packed) which also records, per block i, the largest magnitude of the four GEMM inputs into
+ * amax[4*i + {0: ln_1 output, 1: attention output, 2: ln_2 output, 3: QuickGELU(c_fc) output}] (device f32 [4*layers], running
+ * maximum: zero it before the first batch).  The host turns it into cmh_block_weights.act_scale. */
+int cmh_vit_calibrate_fp8(const cmh_vit_weights* w, const float* image, int32_t batch, float* feat, float* amax, void* workspace,
+                          size_t workspace_bytes, void* stream);
+int cmh_text_calibrate_fp8(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len, float* feat,
+                           float* amax, void* workspace, size_t workspace_bytes, void* stream);
+
 /* encode_text without the padding: under the causal mask (model/base/model.py:340-346) no token after a caption's EOT can
  * influence the EOT row that encode_text returns (:366-370), so only the tokens 0..EOT of every caption are computed, packed
  * into one matrix of rows_computed <= batch*seq_len rows.  `feat` is bit-identical to cmh_text_encode's.  Synchronises the
@@ -163,6 +183,28 @@ int cmh_prof_gemm_end(double* total_ms, double* total_flops, int64_t* launches);
  * per group of the L2-aware tile order (0: plain n-fastest order, -1: chosen per launch).  Results do not depend on either.
  * Process-wide, not thread-safe.  (No reference counterpart: upstream's GEMMs are ATen's, model/base/model.py:167-196.) */
 int cmh_gemm_tuning(int32_t tile_rows, int32_t order_group);
+
+/* ---------------------------------------------------------------------------------------------
+ * fp8 encoder mode (CMH_FP8).  Mirrors the reference's precision hook convert_weights (model/base/model.py:391-412): the same
+ * tensors it lowers to fp16 - Linear / MultiheadAttention weights - go to e4m3 here, with the activations that feed them.
+ * ------------------------------------------------------------------------------------------- */
+#define CMH_EPI_OUT_FP8 4096  /* cmh_linear_gemm_fp8: out is e4m3 of clamp(v / out_scale, +-448) */
+#define CMH_FP8_MAX 448.0f
+
+/* w f32 [N,K] -> w_fp8 e4m3 [N,K] and colscale f32 [N] = amax_k|w[n,k]| / 448 (1 for an all-zero row): w ~ w_fp8 * colscale[n]. */
+int cmh_fp8_quantize_weight(const float* w, void* w_fp8, float* colscale, int32_t N, int32_t K, void* stream);
+/* x (kind 0 f32 / 1 bf16 / 2 fp16, n % 4 == 0 elements) -> x_fp8 = e4m3(clamp(x / scale)); and back: out = f32(x_fp8) * scale. */
+int cmh_fp8_quantize(const void* x, int32_t kind, void* x_fp8, int64_t n, float scale, void* stream);
+int cmh_fp8_dequantize(const void* x_fp8, float* out, int64_t n, float scale, void* stream);
+/* amax_inout[0] = max(amax_inout[0], max|x|) (device scalar, zero it first; a NaN in x reports +inf): calibration of the
+ * per-tensor activation scales. */
+int cmh_amax(const void* x, int32_t kind, int64_t n, float* amax_inout, void* stream);
+/* out[M,N] = epi( alpha * colscale[n] * (x_fp8[M,K] . w_fp8[N,K]^T) ), N % 256 == 0, K % 128 == 0.  `epilogue` takes CMH_EPI_BIAS,
+ * _QUICKGELU, _GELU, _RELU, _RESIDUAL (+ _RES_F16) and ONE of _OUT_BF16 / _OUT_F16 / _OUT_FP8 (default f32).  alpha = the
+ * activation tensor's scale, colscale = cmh_fp8_quantize_weight's. */
+int cmh_linear_gemm_fp8(const void* x_fp8, const void* w_fp8, const float* colscale, float alpha, const float* bias,
+                        const float* residual, void* out, float out_scale, int32_t M, int32_t N, int32_t K, int32_t epilogue,
+                        void* stream);
 
 /* f32 -> bf16 (round-to-nearest-even) copy used to prepare CMH_BF16 GEMM weights. */
 int cmh_cast_f32_to_bf16(const float* src, void* dst_bf16, int64_t n, void* stream);

@@ -19,6 +19,7 @@ ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--sets", default="vision,text,textdense")
 ap.add_argument("--text-rows", type=int, default=10499)
+ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"])
 ap.add_argument("--configs", default="-1:-1", help="comma list of tile_rows:order_group pairs for cmh_gemm_tuning (-1 = automatic)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -36,6 +37,14 @@ SETS = {"vision": block_shapes(12800, 768), "text": block_shapes(a.text_rows, 51
 
 
 def make(M, Nn, K, epi):
+    if a.dtype == "fp8":
+        x = N.fp8_quantize(torch.randn(M, K, device=dev), 4.0 / 448)
+        w, cs = N.fp8_quantize_weight(torch.randn(Nn, K, device=dev) * K ** -0.5)
+        b = torch.randn(Nn, device=dev)
+        res = torch.randn(M, Nn, device=dev).half() if epi & E["res"] else None
+        o8 = bool(epi & E["qgelu"])                      # c_fc feeds c_proj: e4m3 output
+        out = torch.empty(M, Nn, dtype=torch.uint8 if o8 else (torch.float16 if epi & E["of16"] else torch.bfloat16), device=dev)
+        return x, (w, cs), b, res, out
     x = torch.randn(M, K, device=dev).bfloat16()
     w = (torch.randn(Nn, K, device=dev) * K ** -0.5).bfloat16()
     b = torch.randn(Nn, device=dev)
@@ -46,6 +55,11 @@ def make(M, Nn, K, epi):
 
 def run(M, Nn, K, epi, bufs):
     x, w, b, res, out = bufs
+    if a.dtype == "fp8":
+        e = (epi & ~E["obf"] | 4096) if out.dtype == torch.uint8 else epi
+        N.check(N.lib().cmh_linear_gemm_fp8(N.ptr(x), N.ptr(w[0]), N.ptr(w[1]), 4.0 / 448, N.ptr(b), N.ptr(res), N.ptr(out), 0.05,
+                                            M, Nn, K, e, st), "gemm_fp8")
+        return
     N.check(N.lib().cmh_linear_gemm(N.BF16, N.ptr(x), N.ptr(w), N.ptr(b), N.ptr(res), N.ptr(out), M, Nn, K, epi, st), "gemm")
 
 

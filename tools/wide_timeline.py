@@ -12,6 +12,9 @@ rx = E["bias"] | E["res"] | E["rf16"] | E["of16"]
 T = int(os.environ.get("TEXT_ROWS", "10499"))
 shapes = {"v_qkv": (12800, 2304, 768, 9), "v_out": (12800, 768, 768, rx), "v_fc1": (12800, 3072, 768, 11), "v_fc2": (12800, 768, 3072, rx),
           "t_qkv": (T, 1536, 512, 9), "t_out": (T, 512, 512, rx), "t_fc1": (T, 2048, 512, 11), "t_fc2": (T, 512, 2048, rx)}
+if os.environ.get("VARIANTS"):   # epilogue ablations on one shape: gelu on/off, stores skipped (256) / issued from the epilogue (512)
+    shapes = {f"v_fc1 epi={e}": (12800, 3072, 768, e) for e in (11, 9, 11 | 256, 9 | 256, 11 | 512)}
+    shapes.update({f"v_qkv epi={e}": (12800, 2304, 768, e) for e in (9, 9 | 256, 9 | 512)})
 lib = N.lib()
 for name, (M, Nn, K, epi) in shapes.items():
     x = torch.randn(M, K, device=dev).bfloat16(); w = (torch.randn(Nn, K, device=dev) * K ** -0.5).bfloat16()
