@@ -33,7 +33,7 @@ for p in (ROOT, PKG, os.path.join(ROOT, "tests", "golden")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}      # /opt/skills/guides/MI355X_MICROARCH.md, dense
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "fp8": 5000.0}      # /opt/skills/guides/MI355X_MICROARCH.md, dense
 FLOP_IMG = 8.818e9                                  # BASELINE.md §3 (fwd, per image)
 VITB32 = dict(embed_dim=512, image_resolution=224, vision_layers=12, vision_width=768, vision_patch_size=32,
               context_length=77, vocab_size=49408, transformer_width=512, transformer_heads=8, transformer_layers=12)
@@ -184,7 +184,7 @@ def main():
                     help="also time the training step when --gpus > 1 (default: single-GPU runs only, so that the secondary "
                          "metric's gradient all-reduce can never stall the headline scaling line)")
     ap.add_argument("--no-overlap-towers", action="store_true", help="run the text tower after the image tower on one stream")
-    ap.add_argument("--no-precision-legs", action="store_true", help="skip flip_rate_vs_f32 and the timed f32-mode leg")
+    ap.add_argument("--no-precision-legs", action="store_true", help="skip flip_rate_vs_f32 and the timed f32-mode / fp8-mode legs")
     ap.add_argument("--map-queries", type=int, default=5000)
     ap.add_argument("--map-db", type=int, default=15015)
     a = ap.parse_args()
@@ -358,6 +358,42 @@ def main():
             step()
         except Exception as exc:
             out["f32_mode"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            clip.set_gemm_dtype(a.dtype)
+        try:
+            # BASELINE configs[4]'s encoder arithmetic on the same workload: the blocks' four GEMMs on e4m3 operands (fp8 MFMA),
+            # scales calibrated on this batch; timed like the headline (towers overlapped), roofline leg serialized
+            clip.set_gemm_dtype("fp8")
+            with torch.no_grad():
+                clip.calibrate_fp8(image=image, text=text)
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            t8 = time.perf_counter()
+            for _ in range(a.steps):
+                step()
+            torch.cuda.synchronize()
+            fp8_ms = (time.perf_counter() - t8) / a.steps * 1e3
+            N.prof_gemm_begin(a.steps * 128)
+            for _ in range(a.steps):
+                step(overlap=False)
+            torch.cuda.synchronize()
+            g_ms, g_fl, g_n = N.prof_gemm_end()
+            fp8_tf = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+            out["fp8_mode"] = {"pairs_per_s": round(B / fp8_ms * 1e3, 2), "ms_per_step": round(fp8_ms, 4), "steps": a.steps,
+                               "speedup_vs_headline": round(out["ms_per_step"] / fp8_ms, 3),
+                               "roofline": {"bound": "mfma", "kernel": "cmh::gemm_wide_kernel<2, *>", "achieved": round(fp8_tf, 2),
+                                            "peak": PEAK_TFLOPS["fp8"], "unit": "TFLOP/s", "frac": round(fp8_tf / PEAK_TFLOPS["fp8"], 4),
+                                            "launches": int(g_n), "gemm_ms_per_step_serialized": round(g_ms / a.steps, 4),
+                                            "note": "all GEMM launches of the step against the dense fp8 peak; conv1 and the two final "
+                                                    "projections (2 % of the FLOPs) stay bf16"},
+                               "flip_rate_vs_f32": flip_rates(clip, (img_head, txt_head), image, text),
+                               "what": "set_gemm_dtype('fp8'): QKV / out_proj / c_fc / c_proj on v_mfma_scale_f32_16x16x128_f8f6f4 "
+                                       "(e4m3 x e4m3, f32 accumulate), per-channel weight scales, per-tensor activation scales "
+                                       "calibrated on this batch; fp16 residual stream, bf16 attention"}
+            clip.set_gemm_dtype(a.dtype)
+            step()
+        except Exception as exc:
+            out["fp8_mode"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
             clip.set_gemm_dtype(a.dtype)
 
     if not a.no_map_eval:

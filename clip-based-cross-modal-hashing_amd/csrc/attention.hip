@@ -241,13 +241,20 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const bf16_t* __rest
     }
 
   const int nqt = (Tn + 15) >> 4;
-  for (int qt = 0; qt < nqt; ++qt) {
+  // the NEXT query tile's fragments are fetched while the current tile computes (8 more registers): loaded at the top of its
+  // own iteration, each tile's first MFMA waited a full L2 / Infinity-Cache round trip for them
+  auto load_q = [&](int qt, abf16x8_t (&q)[2]) {
     const int qrow = qt * 16 + c;
     const int qr = qrow < Tn ? qrow : Tn - 1;
-    abf16x8_t qf[2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-      qf[s] = *reinterpret_cast<const abf16x8_t*>(base + static_cast<size_t>(qr) * ld + s * 32 + g * 8);
+    for (int s = 0; s < 2; ++s) q[s] = *reinterpret_cast<const abf16x8_t*>(base + static_cast<size_t>(qr) * ld + s * 32 + g * 8);
+  };
+  abf16x8_t qn[2];
+  load_q(0, qn);
+  for (int qt = 0; qt < nqt; ++qt) {
+    const int qrow = qt * 16 + c;
+    abf16x8_t qf[2] = {qn[0], qn[1]};
+    load_q(qt + 1, qn);        // rows are clamped to the sequence: the read past the last tile stays in bounds and is never used
     af32x4_t sc[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {

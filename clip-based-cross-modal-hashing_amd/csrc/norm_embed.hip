@@ -337,34 +337,47 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int64_t* __restri
   }
 }
 
-// seq_off[b] = sum_{b' < b} (argmax(tokens[b']) + 1): the packed row offsets of encode_text without padding.  One workgroup.
-__global__ __launch_bounds__(256) void text_pack_plan_kernel(const int64_t* __restrict__ tokens, int B, int L,
-                                                             int32_t* __restrict__ seq_off) {
-  __shared__ int part[256];
-  // thread i owns the contiguous captions [i*per, (i+1)*per)
-  const int per = (B + 255) / 256;
-  const int b0 = threadIdx.x * per, b1 = b0 + per < B ? b0 + per : B;
-  int sum = 0;
-  for (int b = b0; b < b1; ++b) {
-    int64_t best = INT64_MIN; int besti = 0;
-    for (int i = 0; i < L; ++i) { const int64_t v = tokens[static_cast<size_t>(b) * L + i]; if (v > best) { best = v; besti = i; } }
-    seq_off[b + 1] = besti + 1;           // length, turned into an offset below
-    sum += besti + 1;
+// seq_off[b] = sum_{b' < b} (argmax(tokens[b']) + 1): the packed row offsets of encode_text without padding.  One workgroup of
+// 16 waves: a wave takes whole captions (coalesced row reads, first-maximum argmax by a butterfly on (value, index)), then wave 0
+// turns the lengths into offsets with 64-wide prefix scans.  (Round 1's one-thread-per-caption loop took 37 us at B = 256.)
+__global__ __launch_bounds__(1024) void text_pack_plan_kernel(const int64_t* __restrict__ tokens, int B, int L,
+                                                              int32_t* __restrict__ seq_off) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int b = wave; b < B; b += 16) {
+    long long best = INT64_MIN;
+    int besti = 0;
+    for (int i = lane; i < L; i += 64) {
+      const long long v = tokens[static_cast<size_t>(b) * L + i];
+      if (v > best) { best = v; besti = i; }      // a lane's indices ascend: strict > keeps its first maximum
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const long long ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(besti, o, 64);
+      if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+    }
+    if (lane == 0) seq_off[b + 1] = besti + 1;    // length, turned into an offset below
   }
-  part[threadIdx.x] = sum;
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (wave == 0) {
     int run = 0;
-    for (int i = 0; i < 256; ++i) { const int v = part[i]; part[i] = run; run += v; }
-    seq_off[0] = 0;
+    for (int base = 0; base < B; base += 64) {
+      const int idx = base + lane;
+      int v = idx < B ? seq_off[idx + 1] : 0;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+      }
+      if (idx < B) seq_off[idx + 1] = run + v;
+      run += __shfl(v, 63, 64);
+    }
+    if (lane == 0) seq_off[0] = 0;
   }
-  __syncthreads();
-  int run = part[threadIdx.x];
-  for (int b = b0; b < b1; ++b) { run += seq_off[b + 1]; seq_off[b + 1] = run; }
 }
 
 int launch_text_pack_plan(const int64_t* tokens, int B, int L, int32_t* seq_off, hipStream_t st) {
-  hipLaunchKernelGGL(text_pack_plan_kernel, dim3(1), dim3(256), 0, st, tokens, B, L, seq_off);
+  hipLaunchKernelGGL(text_pack_plan_kernel, dim3(1), dim3(1024), 0, st, tokens, B, L, seq_off);
   CMH_CHECK_LAUNCH("text_pack_plan");
   return CMH_OK;
 }

@@ -60,21 +60,30 @@ def test_vitb32_f32_matches_reference_goldens(golden):
 
 
 def test_vitb32_bf16_close_to_f32_and_flip_rate(golden):
-    """bf16 GEMM operands: features stay within bf16 noise of the fp32 reference; report sign-flip rate
-    of 64-bit codes (SURVEY hard part: 'bit-exact sign()' only holds away from 0)."""
+    """bf16 mode (bf16 MFMA operands, fp16 residual stream) against the f32 parity mode: features within bf16 noise of the
+    reference's own rows, and the sign-flip rate of 64-bit codes on 64 samples per tower.  "Bit-exact sign()" holds away from 0
+    only; measured on MI355X with these seeded random-init weights: 0.15 % (image) / 0.27 % (text) of the bits on the 256-pair
+    bench batch (bench.py `flip_rate_vs_f32`), hence the 1 % gate."""
     g = golden("clip_vitb32.npz")
     cfg, seed = recipe.CLIP_VITB32, int(g["seed"])
     m = _clip(cfg, seed, "bf16")
-    img = m.encode_image(torch.from_numpy(recipe.images(2, 224, seed)).to(DEV)).detach().cpu().numpy()
-    txt = m.encode_text(torch.from_numpy(recipe.captions(2, 77, cfg["vocab_size"], seed)).to(DEV)).detach().cpu().numpy()
-    for a, r in ((img, g["img_feat"]), (txt, g["txt_feat_L77"])):
-        cos = (a * r).sum(-1) / np.linalg.norm(a, axis=-1) / np.linalg.norm(r, axis=-1)
-        assert cos.min() > 0.999, cos
-        assert np.abs(a - r).max() < 0.05 * np.abs(r).max()
+    B = 64
+    images = torch.from_numpy(recipe.images(B, 224, seed)).to(DEV)
+    texts = torch.from_numpy(recipe.captions(B, 77, cfg["vocab_size"], seed)).to(DEV)
+    with torch.no_grad():
+        img, txt = m.encode_image(images).cpu().numpy(), m.encode_text(texts).cpu().numpy()
+        m.set_gemm_dtype("f32")
+        img32, txt32 = m.encode_image(images).cpu().numpy(), m.encode_text(texts).cpu().numpy()
+    np.testing.assert_allclose(img32[:2], g["img_feat"], rtol=1e-3, atol=1e-4)          # the f32 mode IS the reference (its golden rows)
+    np.testing.assert_allclose(txt32[:2], g["txt_feat_L77"], rtol=1e-3, atol=1e-4)
     w, b = recipe.head_linear(512, 64, seed, "flip")
-    flips = np.mean(np.sign(img @ w.T + b) != np.sign(g["img_feat"] @ w.T + b))
-    print(f"bf16 sign flip rate on 64-bit codes: {flips:.4f}")
-    assert flips < 0.05
+    for name, a, r in (("image", img, img32), ("text", txt, txt32)):
+        cos = (a * r).sum(-1) / np.linalg.norm(a, axis=-1) / np.linalg.norm(r, axis=-1)
+        assert cos.min() > 0.9995, cos.min()
+        assert np.abs(a - r).max() < 0.05 * np.abs(r).max()
+        flips = float(np.mean(np.sign(a @ w.T + b) != np.sign(r @ w.T + b)))
+        print(f"bf16 {name}: cosine min {cos.min():.6f}; sign flip rate of 64-bit codes on {B} samples: {flips:.4f}")
+        assert flips < 0.01, flips
 
 
 def test_eot_is_first_argmax_and_batch_independence():
