@@ -18,7 +18,7 @@ BASE_FLAGS = [
     ("--lr-decay-freq", int, 5), ("--display-step", int, 50), ("--seed", int, 1814), ("--lr", float, 0.001),
     ("--lr-decay", float, 0.9), ("--clip-lr", float, 0.00001), ("--weight-decay", float, 0.2),
     ("--warmup-proportion", float, 0.1, "share of the training steps spent on the linear warm-up of the learning rate"),
-    ("--gemm-dtype", str, "f32", "encoder GEMM arithmetic: f32 = reference parity, bf16 = throughput (this build)"),
+    ("--gemm-dtype", str, "f32", "encoder GEMM arithmetic: f32 = reference parity, bf16 = throughput, fp8 = e4m3 block GEMMs, inference only (this build)"),
     ("--data-dir", str, "", "directory with index.mat / caption.mat|txt / label.mat (this build; upstream hard-codes it)"),
     ("--synthetic-size", int, 2000, "items of the synthetic dataset (this build)"),
 ]
@@ -32,7 +32,7 @@ def add_flags(parser, table):
         if doc:
             kw["help"] = doc[0]
         if flag == "--gemm-dtype":
-            kw["choices"] = ["f32", "bf16"]
+            kw["choices"] = ["f32", "bf16", "fp8"]      # fp8: inference only (--is-train false)
         parser.add_argument(flag, **kw)
     return parser
 

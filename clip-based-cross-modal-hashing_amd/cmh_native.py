@@ -94,6 +94,9 @@ SIGNATURES = {
     "cmh_layernorm": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _p]),
     "cmh_attention": (C.c_int, [_i32, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "cmh_gemm_tuning": (C.c_int, [_i32, _i32]),
+    "cmh_qmi_workspace_bytes": (_sz, [_i32]),
+    "cmh_qmi_loss": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _f, _p, _p, _p, _sz, _p]),
+    "cmh_qmi_loss_backward": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _f, _p, _p, _p, _p, _p, _sz, _p]),
     "cmh_fp8_quantize_weight": (C.c_int, [_p, _p, _p, _i32, _i32, _p]),
     "cmh_fp8_quantize": (C.c_int, [_p, _i32, _p, _i64, _f, _p]),
     "cmh_fp8_dequantize": (C.c_int, [_p, _p, _i64, _f, _p]),
@@ -521,6 +524,31 @@ def dsph_hyp_loss(x, y, label, proxies, threshold, alpha):
     check(lib().cmh_dsph_hyp_loss(ptr(x), ptr(y), ptr(label), ptr(proxies), B, K, Cn, float(threshold), float(alpha),
                                   ptr(out), ptr(ws), ws.numel(), stream_ptr(x.device)), "cmh_dsph_hyp_loss")
     return out[0]
+
+
+def qmi_loss(img, txt, label, eps=1e-8):
+    """DNpH qmi_loss (train/DNpH_TMM/loss.py:5-72, defaults) -> (loss 0-dim, sum_d [1] for the backward, packed labels)"""
+    img, txt, label = f32c(img), f32c(txt), f32c(label)
+    require_gpu(img, txt, label)
+    B, K = img.shape
+    Cn = label.shape[1]
+    fit("qmi_loss", (txt, (B, K)), (label, (B, Cn)))
+    packed = pack_labels(label)
+    out = torch.empty(1, dtype=torch.float32, device=img.device)
+    sum_d = torch.empty(1, dtype=torch.float32, device=img.device)
+    ws = workspace(lib().cmh_qmi_workspace_bytes(B), img.device, "loss")
+    check(lib().cmh_qmi_loss(ptr(img), ptr(txt), ptr(packed), B, K, Cn, float(eps), ptr(out), ptr(sum_d), ptr(ws), ws.numel(),
+                             stream_ptr(img.device)), "cmh_qmi_loss")
+    return out[0], sum_d, packed
+
+
+def qmi_loss_backward(img, txt, packed, classes, sum_d, dloss, eps=1e-8):
+    B, K = img.shape
+    dimg, dtxt = torch.empty_like(img), torch.empty_like(txt)
+    ws = workspace(lib().cmh_qmi_workspace_bytes(B), img.device, "loss")
+    check(lib().cmh_qmi_loss_backward(ptr(img), ptr(txt), ptr(packed), B, K, int(classes), float(eps), ptr(sum_d), ptr(f32c(dloss).reshape(1)),
+                                      ptr(dimg), ptr(dtxt), ptr(ws), ws.numel(), stream_ptr(img.device)), "cmh_qmi_loss_backward")
+    return dimg, dtxt
 
 
 def dchmt_loss(img, txt, label, output_dim, similarity="euclidean", loss_type="l2", vartheta=0.5, sim_threshold=0.1):

@@ -12,8 +12,9 @@ _REGISTRY = {
     'TwDH': ("train.TwDH.hash_train", "TwDHTrainer"),
     'DNPH': ("train.DNPH_TOMM.hash_train", "DNPHTOMMTrainer"),
     'MITH': ("train.MITH.hash_train", "MITHTrainer"),
+    'DNpH': ("train.DNpH_TMM.hash_train", "DNpHTMMTrainer"),
 }
-_NOT_BUILT = ['DHaPH', 'DMsH_LN', 'DNpH', 'DPBE', 'DDWSH', 'DDBH', 'DScPH', 'DPSIH', 'DGHDGH']
+_NOT_BUILT = ['DHaPH', 'DMsH_LN', 'DPBE', 'DDWSH', 'DDBH', 'DScPH', 'DPSIH', 'DGHDGH']
 
 
 class _LazyTrainers(dict):

@@ -206,6 +206,17 @@ int cmh_linear_gemm_fp8(const void* x_fp8, const void* w_fp8, const float* colsc
                         const float* residual, void* out, float out_scale, int32_t M, int32_t N, int32_t K, int32_t epilogue,
                         void* stream);
 
+/* DNpH quadratic spherical mutual information loss, reference train/DNpH_TMM/loss.py:5-72 `qmi_loss(images, texts, targets)` in
+ * its default form (use_cosine, use_square_clamp, M = B^2 / sum(D)): img, txt f32 [B,K] hash outputs, labels bit-packed as by
+ * cmh_pack_labels ([B, ceil(C/32)] u32) -> loss f32 [1] and sum_d f32 [1] (the number of label-sharing pairs, kept for the
+ * backward).  Backward: dimg, dtxt f32 [B,K] = dloss[0] * d loss / d img, txt.  K <= 1024, C <= 512. */
+size_t cmh_qmi_workspace_bytes(int32_t B);
+int cmh_qmi_loss(const float* img, const float* txt, const uint32_t* labels_packed, int32_t B, int32_t K, int32_t C, float eps,
+                 float* loss, float* sum_d, void* workspace, size_t workspace_bytes, void* stream);
+int cmh_qmi_loss_backward(const float* img, const float* txt, const uint32_t* labels_packed, int32_t B, int32_t K, int32_t C,
+                          float eps, const float* sum_d, const float* dloss, float* dimg, float* dtxt, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
 /* f32 -> bf16 (round-to-nearest-even) copy used to prepare CMH_BF16 GEMM weights. */
 int cmh_cast_f32_to_bf16(const float* src, void* dst_bf16, int64_t n, void* stream);
 

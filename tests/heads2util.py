@@ -42,3 +42,9 @@ def dnph_case(B, K, C, seed=51):
                 hi=np.tanh(recipe.features(B, K, seed, f"dnph_hi_{tag}")), ht=np.tanh(recipe.features(B, K, seed, f"dnph_ht_{tag}")),
                 pi=recipe.features(B, C, seed, f"dnph_pi_{tag}"), pt=recipe.features(B, C, seed, f"dnph_pt_{tag}"),
                 lab=recipe.labels(B, C, seed, p=0.15, tag=f"dnph_lab_{tag}"))
+
+
+def dnph_noise(B, K, seed=51):
+    """+-1 noise rows for the real-size DNPH case (what b_reg.gene_noise hands out; which row goes to which sample is the host's
+    Hungarian step, tested apart)"""
+    return tuple(np.where(recipe.features(B, K, seed, f"dnph_real_noise_{s}") >= 0, 1.0, -1.0).astype(np.float32) for s in "it")

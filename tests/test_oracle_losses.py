@@ -44,3 +44,15 @@ def test_dchmt_our_loss(golden, B, K, C, fn, lt):
     lab = recipe.labels(B, C, seed, tag=f"dchmt_lab_{tag}")
     loss = co.dchmt_our_loss(hi, ht, lab, K, fn, lt)
     assert abs(float(loss) - float(g[f"{tag}_loss"])) < 1e-4 * max(1, abs(float(loss)))
+
+
+@pytest.mark.parametrize("B,K,C,p", [(8, 16, 24, 0.15), (48, 32, 80, 0.05), (256, 64, 24, 0.15), (16, 128, 21, 0.0)])
+def test_dnph_tmm_qmi_loss(golden, B, K, C, p):
+    """numpy restatement of train/DNpH_TMM/loss.py:5-72 against the reference's own values (tests/golden/make_golden15.py)."""
+    from qmiutil import qmi_case
+    from oracle.qmi_oracle import qmi_loss
+    g = golden("qmi.npz")
+    c = qmi_case(B, K, C, p)
+    loss = qmi_loss(c["x"], c["y"], c["lab"])
+    want = float(g[f"{c['tag']}_loss"])
+    assert abs(float(loss) - want) < 2e-5 * max(1.0, abs(want)), (float(loss), want)
