@@ -291,14 +291,29 @@ def main():
         clip.pack_text = True
     peak = PEAK_TFLOPS[a.dtype]
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+
+    def gemm_algorithmic_bytes(text_rows):
+        """operand + result bytes of the GEMM launches of one step, each tensor counted once (bf16 mode: bf16 operands and
+        QKV / c_fc outputs, fp16 residual stream read + written by out_proj / c_proj, f32 outputs of conv1 and the projections)"""
+        e = 2 if a.dtype == "bf16" else 4
+        xs = 2 if a.dtype == "bf16" else 4            # residual stream element
+        total, n = 0, 0
+        for M, d in ((B * 50, 768), (text_rows, 512)):
+            for (Nn, K, res, osz) in ((3 * d, d, 0, e), (d, d, 1, xs), (4 * d, d, 0, e), (d, 4 * d, 1, xs)):
+                total += 12 * (M * K * e + Nn * K * e + M * Nn * osz + res * M * Nn * xs)
+                n += 12
+        total += B * 49 * 3072 * e + 768 * 3072 * e + B * 49 * 768 * 4                         # conv1 as a GEMM
+        total += 2 * B * 512 * 4 + B * (768 + 512) * e + (768 + 512) * 512 * e                # the two final projections
+        return total, n + 3
     # HBM-side bytes per GEMM launch cannot be counted from inside this process: they come from the two rocprofv3 --pmc
     # passes of this same command (tools/pmc_bench_traffic.sh), committed under profiles/; null if absent / other dtype.
     traffic, traffic_src = None, None
-    tfile = os.path.join(ROOT, "profiles", "r01_h_gemm_traffic.json")
-    if a.dtype == "bf16" and os.path.exists(tfile):
-        with open(tfile) as fh:
+    import glob
+    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_traffic.json")))      # the latest round's passes
+    if a.dtype == "bf16" and tfiles:
+        with open(tfiles[-1]) as fh:
             traffic = json.load(fh)["traffic_bytes_per_launch"]
-        traffic_src = "profiles/r01_h_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, (2*FETCH+WRITE)*1024)"
+        traffic_src = f"profiles/{os.path.basename(tfiles[-1])} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, (2*FETCH+WRITE)*1024)"
     out = {
         "metric": "image+text pairs/s encoded+hashed per GPU; mAP@K eval wallclock (64-bit)",
         "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -321,6 +336,7 @@ def main():
         "roofline": {"bound": "mfma", "kernel": "cmh::gemm_wide_kernel<%s, *>" % ("true" if a.dtype == "f32" else "false"),
                      "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                      "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": round(gemm_algorithmic_bytes(rows_c)[0] / gemm_algorithmic_bytes(rows_c)[1]),
                      "launches": int(gemm_launches),
                      "avg_launch_us": round(gemm_ms * 1e3 / max(gemm_launches, 1), 2),
                      "measured_in": ("the timed region" if not overlap else
