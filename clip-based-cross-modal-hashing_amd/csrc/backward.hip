@@ -298,6 +298,16 @@ extern "C" int cmh_transpose(const void* src, int32_t src_kind, void* dst, int32
 }
 
 namespace cmh {
+// first stage only: partial [ceil(rows / 64), cols] column sums of 64-row slices (the layout launch_colsum_final / FinalJobs expect)
+int launch_colsum_partial(const void* x, int kind, int rows, int cols, float* partial, hipStream_t st) {
+  const int nb = (rows + kColRows - 1) / kColRows;
+  if (cols % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+    hipLaunchKernelGGL(colsum_partial4_kernel, dim3((cols + 255) / 256, nb), dim3(256), 0, st, x, kind, rows, cols, partial);
+  else
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 255) / 256, nb), dim3(256), 0, st, x, kind, rows, cols, partial);
+  CMH_CHECK_LAUNCH("colsum_partial");
+  return CMH_OK;
+}
 int launch_colsum_final(const float* partial, int slices, int cols, float* out, hipStream_t st) {
   hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, partial, slices, cols, out, nullptr, nullptr);
   CMH_CHECK_LAUNCH("colsum_final");

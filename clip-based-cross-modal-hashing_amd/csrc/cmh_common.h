@@ -123,6 +123,11 @@ int launch_gemm(int dt, const void* A, const void* W, const float* bias, const f
 int launch_gemm_fp8(const void* A8, const void* W8, const float* colscale, float alpha, const float* bias, const float* residual,
                     void* out, float oscale, int M, int N, int K, int epi, hipStream_t st);
 
+// gemm_wide.hip, TN form (wgrad): out[Mm, Nn] f32 = sum_k Xk[k, m] * Wk[k, n], bf16 operands [Kd, Mm] / [Kd, Nn] row-major
+bool gemm_wide_tn_supported(int Mm, int Nn, int Kd);
+int launch_gemm_wide_tn(const void* Xk, const void* Wk, float* out, float* partials, size_t part_bytes, int Mm, int Nn, int Kd,
+                        hipStream_t st);
+
 // LayerNorm over rows of x[M,d] (f32) -> out (f32 or bf16 per out_bf16). rows optionally gathered:
 // row r reads x[row_index[r]] when row_index != null.
 int launch_layernorm(const float* x, const int32_t* row_index, const float* w, const float* b,
@@ -173,6 +178,7 @@ struct FinalJobs {
   void add(const float* p, int s, int c, float* o) { partial[n] = p; slices[n] = s; cols[n] = c; out[n] = o; ++n; }
 };
 int launch_final_jobs(FinalJobs& jobs, hipStream_t st);
+int launch_colsum_partial(const void* x, int kind, int rows, int cols, float* partial, hipStream_t st);   // [ceil(rows/64), cols]
 int launch_layernorm_backward(const void* x, int x_kind, const void* dy, int dy_kind, const float* gamma, const int32_t* row_index,
                               int M, int d, float* dx, int accumulate, float* dgamma, float* dbeta, void* workspace,
                               size_t workspace_bytes, hipStream_t st, void* dx_bf16 = nullptr,   // + a bf16 copy of the new dx

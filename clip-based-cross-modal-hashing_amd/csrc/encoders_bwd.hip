@@ -165,10 +165,24 @@ int block_forward_train(const cmh_block_weights& w, int dt, int xh, const LayerT
 // dW[O, I] = dY^T X with dY [M, O] (kind ky) and X [M, I] (kind kx); db[O] = column sums of dY
 struct WgradScratch { void* tA; void* tB; float* part; size_t part_bytes; void* red; size_t red_bytes; FinalJobs* defer = nullptr; };
 
+// dYe (optional): dY as a bf16 GEMM operand when dY itself is f32 (the residual-stream gradient keeps both)
 int wgrad_core(int dt, const void* dY, int ky, int O, const void* X, int kx, int I, int M, float* dW, float* db,
-               const WgradScratch& w, hipStream_t st) {
+               const WgradScratch& w, hipStream_t st, const void* dYe = nullptr) {
   const int mp = static_cast<int>(pad64(M));
   int rc;
+  // bf16 mode: dW = dY^T X straight from the row-major operands (TN GEMM, transposing LDS reads): no transposed copies
+  const void* dYb = ky == kBF16 ? dY : dYe;
+  if (dt == CMH_BF16 && kx == kBF16 && dYb && gemm_wide_tn_supported(O, I, M)) {
+    if ((rc = launch_gemm_wide_tn(dYb, X, dW, w.part, w.part_bytes, O, I, M, st))) return rc;
+    if (db) {   // column sums of dY (from its most precise copy): first stage now, final stage with the block's other reductions
+      float* dbp = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(w.red) + 255) & ~static_cast<uintptr_t>(255));
+      if (w.red_bytes < static_cast<size_t>((M + 63) / 64) * O * 4 + 256) return fail(CMH_ERR_WORKSPACE, "wgrad: reduction scratch too small");
+      if ((rc = launch_colsum_partial(dY, ky, M, O, dbp, st))) return rc;
+      if (w.defer && w.defer->n < FinalJobs::kMax) w.defer->add(dbp, (M + 63) / 64, O, db);
+      else if ((rc = launch_colsum_final(dbp, (M + 63) / 64, O, db, st))) return rc;
+    }
+    return CMH_OK;
+  }
   // db = column sums of dY: their first stage rides on the transpose of dY when that takes the tiled path
   const bool fuse_db = db && transpose_is_vectorised(dY, w.tA, M, O, mp) && w.red_bytes >= static_cast<size_t>((M + 63) / 64) * O * 4 + 256;
   float* dbp = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(w.red) + 255) & ~static_cast<uintptr_t>(255));
@@ -186,9 +200,10 @@ int wgrad_core(int dt, const void* dY, int ky, int O, const void* X, int kx, int
 }
 
 int wgrad(int dt, const void* dY, int ky, int O, const void* X, int kx, int I, int M, float* dW, float* db, TrainBufs& t,
-          hipStream_t st, FinalJobs* defer = nullptr, size_t red_off = 0) {
+          hipStream_t st, FinalJobs* defer = nullptr, size_t red_off = 0, const void* dYe = nullptr) {
   return wgrad_core(dt, dY, ky, O, X, kx, I, M, dW, db,
-                    WgradScratch{t.tA, t.tB, t.part, t.part_bytes, static_cast<char*>(t.red) + red_off, t.red_bytes - red_off, defer}, st);
+                    WgradScratch{t.tA, t.tB, t.part, t.part_bytes, static_cast<char*>(t.red) + red_off, t.red_bytes - red_off, defer}, st,
+                    dYe);
 }
 
 // dX[M, I] = dY[M, O] . W[O, I]  (W in the GEMM dtype, row-major [O, I]); out typed by `epi`
@@ -224,7 +239,8 @@ int block_backward(const cmh_block_weights& w, const BlockGradPtrs& g, int dt, i
   if (dxe_ready && dx_copy) dxe = t.dxe;
   else if ((rc = as_gemm_operand(dt, t.dx, t.dxe, md, st, &dxe))) return rc;
   if ((rc = dgrad(dt, dxe, w.proj_w, d, 4 * d, M, L.pre, t.dpre, EPI_MUL_DQGELU | obf, t, st))) return rc;
-  if ((rc = wgrad(dt, t.dx, kF32, d, L.act, ek, 4 * d, M, g.proj_w, g.proj_b, t, st, dj, batched ? off_proj : 0))) return rc;
+  if ((rc = wgrad(dt, t.dx, kF32, d, L.act, ek, 4 * d, M, g.proj_w, g.proj_b, t, st, dj, batched ? off_proj : 0,
+                  dt == CMH_BF16 ? dxe : nullptr))) return rc;
   // 2. c_fc
   if ((rc = dgrad(dt, t.dpre, w.fc_w, 4 * d, d, M, nullptr, t.dh, obf, t, st))) return rc;
   if ((rc = wgrad(dt, t.dpre, ek, 4 * d, L.h2, ek, d, M, g.fc_w, g.fc_b, t, st, dj, batched ? off_fc : 0))) return rc;
@@ -235,7 +251,8 @@ int block_backward(const cmh_block_weights& w, const BlockGradPtrs& g, int dt, i
   if (dx_copy) dxe = t.dxe;
   else if ((rc = as_gemm_operand(dt, t.dx, t.dxe, md, st, &dxe))) return rc;
   if ((rc = dgrad(dt, dxe, w.out_proj_w, d, d, M, nullptr, t.dh, obf, t, st))) return rc;
-  if ((rc = wgrad(dt, t.dx, kF32, d, L.attn, ek, d, M, g.out_w, g.out_b, t, st, dj, batched ? off_out : 0))) return rc;
+  if ((rc = wgrad(dt, t.dx, kF32, d, L.attn, ek, d, M, g.out_w, g.out_b, t, st, dj, batched ? off_out : 0,
+                  dt == CMH_BF16 ? dxe : nullptr))) return rc;
   // 5. attention
   if ((rc = launch_attention_backward(dt, L.qkv, L.attn, t.dh, t.dqkv, B, T, d, causal, kpm, seq_off, st))) return rc;
   // 6. in_proj

@@ -70,10 +70,20 @@ struct WideScales {
   const float* colscale;   // [N] or null (EPI_SCALE)
   float alpha;             // EPI_SCALE: acc *= alpha * colscale[n]
   float oscale;            // EPI_OUT_FP8: out = e4m3(clamp(v * oscale))
+  int kreal;               // TN: rows of the K-major operands that exist (K is padded to whole K-steps)
 };
 
-template <int DT, int OK, int MF>   // DT: 0 f32, 1 bf16, 2 fp8 operands; OK: 0 f32, 1 16-bit (bf16 / fp16), 2 fp8 outputs;
-                                    // MF = 16-row m-fragments per wave: tile rows = 32*MF (160, 128 or 96)
+// TN operands (wgrad: dW[O,I] = dY^T X with dY [M,O] and X [M,I] as the backward pass has them, the reduction index m being the
+// SLOW axis of both): out[Mm,Nn] = sum_k Xk[k,m] Wk[k,n].  A stage holds 64 k-rows of both operands as they lie in memory (rows
+// of 512 B = this tile's 256 n, rows of 256 B = its 128 m; LDS-DMA pieces are whole rows, 16-byte chunks XOR-swizzled on the
+// source side), and the MFMA fragments - 8 consecutive k of one n or m per lane - come out of LDS through the transposing read
+// `ds_read_b64_tr_b16` (4 k-rows x 16 columns per 16-lane group, two reads per fragment).  No transposed copy of any operand is
+// ever written: round 1 spent 3.2 ms of the 23.6 ms training step in transpose kernels (11.6 GB of traffic per step).
+__device__ const uint4 g_wide_zero[16] = {};   // 256 zero bytes: the source of k-rows past the end of the Xk operand
+typedef __attribute__((ext_vector_type(2))) uint32_t w_u32x2_t;
+
+template <int DT, int OK, int MF, bool TN = false>   // DT: 0 f32, 1 bf16, 2 fp8 operands; OK: 0 f32, 1 16-bit (bf16 / fp16), 2 fp8
+                                    // outputs; MF = 16-row m-fragments per wave: tile rows = 32*MF (160, 128 or 96); TN: above
 __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__ X, const char* __restrict__ W,
                                                         const float* __restrict__ bias, const float* residual,
                                                         void* out, int M, int N, int K, int epi, int ksplit, int ordG,
@@ -86,6 +96,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   constexpr int NPEND = OUT8 ? MF : 2 * MF;          // deferred 16-byte stores per lane per tile
   constexpr int NM = 4 * MF;                         // MFMAs per 32-deep half-step
   static_assert(MF >= 3 && MF <= 5, "wave layout: 2(m) x 4(n) waves of MF x 4 fragments");
+  static_assert(!TN || (DT == 1 && OK == 0 && MF == 4), "TN: bf16 operands, f32 (split-K) output, 128-row tile");
   constexpr int PSTEP = MF == 3 ? 2 : 3;             // one LDS-DMA piece per PSTEP MFMAs: 6 (MF = 3, 4) or 7 pieces in 4*MF MFMAs
   __shared__ __attribute__((aligned(1024))) char lds[3 * STG];
 
@@ -144,11 +155,30 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   // ---- issue side.  DMA source = uniform tile base (SGPRs) + 32-bit per-lane offset (one VGPR per piece):
   // lane i of a 1-KiB piece fills LDS (row 8*piece + i/8, physical chunk i%8) and fetches logical chunk (i%8)^(row&7).
   uint32_t offW[4], offX[3];
+  // TN: k-row of the lane inside a stage and its (swizzled) 16-byte chunk offset inside the tile's row, per piece
+  uint32_t krW[4], krX[2];
+  const uint32_t ldw_b = static_cast<uint32_t>(N) * 2, ldx_b = static_cast<uint32_t>(M) * 2;   // TN: bytes per k-row of Wk / Xk
+  auto tn_f = [](int kr) { return ((kr & 3) << 2) | ((kr >> 2) & 3); };                       // chunk XOR of k-row kr (cdna guide T10 (b))
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int row = (wid * 4 + i) * 8 + sub;
-    offW[i] = static_cast<uint32_t>(row) * row_stride + (((lane & 7) ^ (row & 7)) << 4);
+    if constexpr (TN) {
+      const int kr = (wid * 4 + i) * 2 + (lane >> 5), pch = lane & 31;       // a 1-KiB piece = two 512-byte rows
+      krW[i] = kr;
+      offW[i] = static_cast<uint32_t>((pch & 16) | ((pch & 15) ^ tn_f(kr))) << 4;
+    } else {
+      const int row = (wid * 4 + i) * 8 + sub;
+      offW[i] = static_cast<uint32_t>(row) * row_stride + (((lane & 7) ^ (row & 7)) << 4);
+    }
   }
+  if constexpr (TN) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int kr = (wid + 8 * i) * 4 + (lane >> 4), pch = lane & 15;       // a piece = four 256-byte rows
+      krX[i] = kr;
+      offX[i] = static_cast<uint32_t>(pch ^ tn_f(kr)) << 4;
+    }
+  }
+  int issue_krow0 = 0;   // TN: first k-row of the (virtual) tile being staged
   const char* Wt = W;   // W + n0*row_stride (+ the split's K offset) of the tile being staged
   const char* Xt = X;   // X (+ the split's K offset)
   auto set_issue_tile = [&](int ti) {
@@ -157,6 +187,12 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
     int tm, tn;
     tile_coords(logical, tm, tn);
     const int m0 = tm * BMt, n0 = tn * wBN;
+    if constexpr (TN) {
+      Wt = W + static_cast<size_t>(n0) * 2;      // column origins; the k-rows are added per piece
+      Xt = X + static_cast<size_t>(m0) * 2;
+      issue_krow0 = split * nk * 64;
+      return;
+    }
     const size_t kbase = static_cast<size_t>(split) * nk * wRowBytes;
     Wt = W + static_cast<size_t>(n0) * row_stride + kbase;
     Xt = X + kbase;
@@ -171,6 +207,21 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   int issue_kt = 0, issue_tile = 0, issue_buf = 0;
   auto issue_piece = [&](int p) {   // p is a compile-time constant at every call site
     char* base = lds + issue_buf * STG;
+    if constexpr (TN) {
+      const int kr0 = issue_krow0 + issue_kt * 64;
+      if (p < 4) {          // Wk rows: past the end they repeat the last row (finite, and multiplied by the zeros below)
+        int kr = kr0 + static_cast<int>(krW[p]);
+        kr = kr < sc.kreal ? kr : sc.kreal - 1;
+        __builtin_amdgcn_global_load_lds((w_gptr_t)(Wt + (static_cast<uint32_t>(kr) * ldw_b + offW[p])),
+                                         (w_lptr_t)(base + (wid * 4 + p) * 1024), 16, 0, 0);
+      } else if (p < 6) {   // Xk rows: past the end they are zeros
+        const int kr = kr0 + static_cast<int>(krX[p - 4]);
+        const char* src = kr < sc.kreal ? Xt + (static_cast<uint32_t>(kr) * ldx_b + offX[p - 4])
+                                        : reinterpret_cast<const char*>(g_wide_zero) + offX[p - 4];
+        __builtin_amdgcn_global_load_lds((w_gptr_t)src, (w_lptr_t)(base + wWBytes + (wid + 8 * (p - 4)) * 1024), 16, 0, 0);
+      }
+      return;
+    }
     const size_t koff = static_cast<size_t>(issue_kt) * wRowBytes;
     if (p < 4)
       __builtin_amdgcn_global_load_lds((w_gptr_t)(Wt + koff + offW[p]), (w_lptr_t)(base + (wid * 4 + p) * 1024), 16, 0, 0);
@@ -200,6 +251,28 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((w_lptr_t)lds));
   const uint32_t aW = lds_base + w_swz(wn * 64 + frow, fq);
   const uint32_t aX = lds_base + wWBytes + w_swz(wm * WR + frow, fq);
+  // TN: transposing reads.  In its 16-lane group (fq) lane 4q+p hands in the address of k-row q, columns 4p..4p+3 of a 4 x 16 block
+  // and receives the four k of column `frow`: block (tile t, half jb) = k-rows 8 fq + 4 jb .. +3 (+32 for the second half-step)
+  // x the tile's 16 columns.  [tile][jb] byte addresses inside a stage; the n-tiles of a wave are 32 bytes apart in a row.
+  uint32_t tW[4][2], tX[MF][2];
+  if constexpr (TN) {
+    const int q = frow >> 2, pp = frow & 3;
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+      const int kr = 8 * fq + 4 * jb + q;
+      const int f = (q << 2) | ((2 * fq + jb) & 3);      // = tn_f(kr)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int chunk = wn * 8 + a * 2 + (pp >> 1);
+        tW[a][jb] = lds_base + kr * 512 + (((chunk & 16) | ((chunk & 15) ^ f)) << 4) + 8 * (pp & 1);
+      }
+#pragma unroll
+      for (int b = 0; b < MF; ++b) {
+        const int chunk = wm * (WR / 8) + b * 2 + (pp >> 1);
+        tX[b][jb] = lds_base + wWBytes + kr * 256 + ((chunk ^ f) << 4) + 8 * (pp & 1);
+      }
+    }
+  }
 #ifdef W_STAMPS   // timing build only (tools/wide_stamps.py): per-wave cycle sums of the K loop's segments
 #define W_STAMP(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); st_sum[k] += static_cast<unsigned>(t_ - st_last); st_last = t_; } while (0)
 #else
@@ -388,7 +461,25 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
                      "+v"(f1w[3]), "+v"(f0x[0]), "+v"(f0x[1]), "+v"(f0x[2]), "+v"(f1x[0]), "+v"(f1x[1]), "+v"(f1x[2])     \
                    ::"memory");                                                                                           \
   } while (0)
-  if constexpr (FP8) {
+#define W_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+  // TN fragments as pairs of 8-byte halves (jb = 0: k 0..3, jb = 1: k 4..7 of the lane's eight)
+  w_u32x2_t h0w[TN ? 4 : 1][2], h0x[TN ? MF : 1][2], h1w[TN ? 4 : 1][2], h1x[TN ? MF : 1][2];
+#define W_WAIT_H(cnt, hw, hx)                                                                                            \
+  asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                                             \
+               : "+v"(hw[0][0]), "+v"(hw[0][1]), "+v"(hw[TN ? 1 : 0][0]), "+v"(hw[TN ? 1 : 0][1]), "+v"(hw[TN ? 2 : 0][0]), \
+                 "+v"(hw[TN ? 2 : 0][1]), "+v"(hw[TN ? 3 : 0][0]), "+v"(hw[TN ? 3 : 0][1]), "+v"(hx[0][0]), "+v"(hx[0][1]), \
+                 "+v"(hx[TN ? 1 : 0][0]), "+v"(hx[TN ? 1 : 0][1]), "+v"(hx[TN ? 2 : 0][0]), "+v"(hx[TN ? 2 : 0][1]),        \
+                 "+v"(hx[TN ? 3 : 0][0]), "+v"(hx[TN ? 3 : 0][1])::"memory")
+  auto mfma_h = [&](const w_u32x2_t (&w2)[2], const w_u32x2_t (&x2)[2], w_f32x4_t& c) {
+    const w_u32x4_t fw = {w2[0][0], w2[0][1], w2[1][0], w2[1][1]}, fx = {x2[0][0], x2[0][1], x2[1][0], x2[1][1]};
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(w_bf16x8_t, fw), __builtin_bit_cast(w_bf16x8_t, fx), c, 0, 0, 0);
+  };
+  if constexpr (TN) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { W_TR(h0w[a][0], tW[a][0], 0); W_TR(h0w[a][1], tW[a][1], 0); }
+#pragma unroll
+    for (int b = 0; b < MF; ++b) { W_TR(h0x[b][0], tX[b][0], 0); W_TR(h0x[b][1], tX[b][1], 0); }
+  } else if constexpr (FP8) {
     // fp8 K-step s starts with BOTH halves of W tiles 0,1 and of every X tile of stage s in (or on their way to) registers
     const uint32_t w0 = aW, w1 = aW ^ 64u, x0 = aX, x1 = aX ^ 64u;
     W_READ(f0w[0], w0, 0); W_READ(f1w[0], w1, 0); W_READ(f0w[1], w0, 2048); W_READ(f1w[1], w1, 2048);
@@ -408,7 +499,48 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
     }
 
     for (int kt = 0; kt < nk; ++kt) {
-      if constexpr (FP8) {
+      if constexpr (TN) {
+        // ---- TN K-step: the bf16 step below with every ds_read_b128 replaced by two transposing 8-byte reads ----------------
+        {
+          const uint32_t bo = static_cast<uint32_t>(cur) * STG;
+#pragma unroll
+          for (int a = 0; a < 4; ++a) { W_TR(h1w[a][0], tW[a][0] + bo, 16384); W_TR(h1w[a][1], tW[a][1] + bo, 16384); }
+#pragma unroll
+          for (int b = 0; b < MF; ++b) { W_TR(h1x[b][0], tX[b][0] + bo, 8192); W_TR(h1x[b][1], tX[b][1] + bo, 8192); }
+        }
+        W_WAIT_H(15, h0w, h0x);          // lgkmcnt has 4 bits: the 16 older reads (first half-step) and one of the new ones have landed
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(GB ? 0 : 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+          if constexpr (GB) { if (i % 3 == 0) issue_piece(i / 3); }
+          mfma_h(h0w[i / MF], h0x[i % MF], acc[i / MF][i % MF]);
+          if (i % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (GB) issue_done();
+        __builtin_amdgcn_sched_barrier(0);
+        W_WAIT_H(0, h1w, h1x);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int nxt = cur == 2 ? 0 : cur + 1;
+        {
+          const uint32_t bo = static_cast<uint32_t>(nxt) * STG;
+          __builtin_amdgcn_s_setprio(GB ? 1 : 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < NM; ++i) {
+            if constexpr (!GB) { if (i % 3 == 0) issue_piece(i / 3); }
+            if (i < 8) W_TR(h0w[i >> 1][i & 1], tW[i >> 1][i & 1] + bo, 0);
+            else W_TR(h0x[(i - 8) >> 1][i & 1], tX[(i - 8) >> 1][i & 1] + bo, 0);
+            mfma_h(h1w[i / MF], h1x[i % MF], acc[i / MF][i % MF]);
+            if (i % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+          }
+          if constexpr (!GB) issue_done();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+      } else if constexpr (FP8) {
         // ---- fp8 K-step: 4*MF scaled MFMAs of 128 k, 2*MF per half; same barrier / DMA / store protocol as below ---------
         constexpr int NM2 = 2 * MF;                    // MFMAs per half
         constexpr int NP = MF == 5 ? 7 : 6;            // LDS-DMA pieces per wave and stage
@@ -801,19 +933,56 @@ int launch_gemm_wide_splitk(int dt, const void* A, const void* W, float* out, fl
   const int grid = total < cus ? ((total + 7) & ~7) : cus;
   if (dt == CMH_F32)
     hipLaunchKernelGGL((gemm_wide_kernel<0, 0, 5>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),
-                       static_cast<const char*>(W), nullptr, nullptr, partials, M, N, K, 0, S, wide_order_group(N), WideScales{nullptr, 1.f, 1.f});
+                       static_cast<const char*>(W), nullptr, nullptr, partials, M, N, K, 0, S, wide_order_group(N), WideScales{nullptr, 1.f, 1.f, 0});
   else
     hipLaunchKernelGGL((gemm_wide_kernel<1, 0, 5>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),
-                       static_cast<const char*>(W), nullptr, nullptr, partials, M, N, K, 0, S, wide_order_group(N), WideScales{nullptr, 1.f, 1.f});
+                       static_cast<const char*>(W), nullptr, nullptr, partials, M, N, K, 0, S, wide_order_group(N), WideScales{nullptr, 1.f, 1.f, 0});
   const size_t n = static_cast<size_t>(M) * N;
   const size_t blocks = (n / 4 + 255) / 256;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, partials, S, n, out);
   return 0;
 }
 
+// out[Mm, Nn] f32 = sum_k Xk[k, m] * Wk[k, n]: bf16 operands as [Kd, Mm] / [Kd, Nn] row-major matrices (the reduction index is the
+// slow axis of both: wgrad's dY and X), split over S groups of workgroups whose f32 partial planes are summed afterwards.
+// The K range of a split need not divide Kd: rows past Kd read as zeros.  Returns CMH_ERR_INVALID when the shape does not fit
+// (Nn % 256, Mm % 128, 32-bit offsets) - the caller then takes the transposing path.
+bool gemm_wide_tn_supported(int Mm, int Nn, int Kd) {
+  static const bool off = []() { const char* e = getenv("CMH_WGRAD_TN"); return e && e[0] == '0'; }();
+  return !off && Nn % wBN == 0 && Mm % 128 == 0 && Kd > 0 &&
+         static_cast<size_t>(Kd) * (Mm > Nn ? Mm : Nn) * 2 < (1ull << 32);
+}
+
+int launch_gemm_wide_tn(const void* Xk, const void* Wk, float* out, float* partials, size_t part_bytes, int Mm, int Nn, int Kd,
+                        hipStream_t st) {
+  if (!gemm_wide_tn_supported(Mm, Nn, Kd)) return fail(CMH_ERR_INVALID, "gemm_tn: unsupported shape Mm=%d Nn=%d Kd=%d", Mm, Nn, Kd);
+  const int cus = wide_cus();
+  const int tiles = (Nn / wBN) * (Mm / 128);
+  const int nkt = (Kd + 63) / 64;
+  int S = cus / tiles;
+  if (S > nkt / 8) S = nkt / 8;
+  while (S > 1 && static_cast<size_t>(S) * Mm * Nn * 4 > part_bytes) --S;
+  if (S < 1) S = 1;
+  const int nk_per = (nkt + S - 1) / S;
+  const int Kpad = S * nk_per * 64;                      // the kernel's K: whole K-steps per split; rows >= Kd are zero-filled
+  const int total = tiles * S;
+  const int grid = total < cus ? ((total + 7) & ~7) : cus;
+  const WideScales sc{nullptr, 1.f, 1.f, Kd};
+  hipLaunchKernelGGL((gemm_wide_kernel<1, 0, 4, true>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(Xk),
+                     static_cast<const char*>(Wk), nullptr, nullptr, S > 1 ? static_cast<void*>(partials) : static_cast<void*>(out),
+                     Mm, Nn, Kpad, 0, S, 0, sc);
+  if (S > 1) {
+    const size_t n = static_cast<size_t>(Mm) * Nn;
+    const size_t blocks = (n / 4 + 255) / 256;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, partials, S,
+                       n, out);
+  }
+  return 0;
+}
+
 int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out,
                      int M, int N, int K, int epi, hipStream_t st, const float* colscale, float alpha, float oscale) {
-  const WideScales sc{colscale, alpha, oscale};
+  const WideScales sc{colscale, alpha, oscale, 0};
   const size_t esz = dt == CMH_F32 ? 4 : (dt == CMH_FP8 ? 1 : 2);
   if (static_cast<size_t>(M) * K * esz >= (1ull << 32) || static_cast<size_t>(wBN) * K * esz >= (1ull << 32))
     return fail(CMH_ERR_INVALID, "gemm: operand of %zu bytes exceeds the 32-bit offset range of the wide kernel",

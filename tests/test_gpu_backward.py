@@ -229,14 +229,25 @@ def test_hyp_loss_gradients_match_reference_goldens(golden, B, K, C, alpha, p):
         np.testing.assert_allclose(a.cpu().numpy(), g[f"{tag}_{name}"], rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("M,O,I", [(15, 128, 128), (1000, 256, 128), (4096, 768, 768), (12800, 3072, 768), (19712, 512, 2048)])
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("M,O,I", [(15, 128, 128), (1000, 256, 128), (4096, 768, 768), (12800, 3072, 768), (19712, 512, 2048),
+                                   (10499, 1536, 512), (777, 128, 256), (64, 128, 256)])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "bf16_tn"])
 def test_linear_wgrad(M, O, I, mode):
-    """dW = dY^T X, db = sum dY: padded K (M not a multiple of 64), plain and split-K launches."""
+    """dW = dY^T X, db = sum dY: padded K (M not a multiple of 64), plain and split-K launches.  "bf16_tn": both operands bf16
+    and row-major as the backward pass holds them -> the TN GEMM (transposing LDS reads, K tail zero-filled in the kernel) when
+    I % 256 == 0 and O % 128 == 0, the transposing path otherwise; products of bf16 values accumulate in f32 either way."""
     import backward_ops as B
     g = torch.Generator().manual_seed(M + O + I)
     dy = torch.randn(M, O, generator=g)
     x = torch.randn(M, I, generator=g)
+    if mode == "bf16_tn":
+        dyd, xd = dy.bfloat16().to(DEV), x.bfloat16().to(DEV)
+        ref_w = dy.bfloat16().double().t() @ x.bfloat16().double()
+        tol = dict(rtol=1e-3, atol=2e-3 * M ** 0.5)            # only the f32 summation order differs from the fp64 statement
+        dw, db = B.linear_wgrad(dyd, xd, "bf16")
+        torch.testing.assert_close(dw.cpu().double(), ref_w, **tol)
+        torch.testing.assert_close(db.cpu().double(), dy.bfloat16().double().sum(0), rtol=1e-5, atol=1e-4 * M ** 0.5)
+        return
     if mode == "bf16":
         dyd, xd = dy.to(DEV), x.bfloat16().to(DEV)             # f32 gradient stream x bf16 activation, as the towers call it
         ref_w = dy.bfloat16().double().t() @ x.bfloat16().double()
