@@ -97,47 +97,54 @@ __global__ __launch_bounds__(256) void colsum_partial4_kernel(const void* __rest
   }
 }
 
-// 32 columns x 8 row-slices per workgroup: slice s adds partial rows s, s+8, ... in f64 (a serial walk over several hundred
-// partial rows per column measured 79 us); fixed order -> deterministic.
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nb, int C,
-                                                           float* __restrict__ out, const float* __restrict__ partial2 = nullptr,
-                                                           float* __restrict__ out2 = nullptr) {
-  __shared__ double red[8][33];
+// 32 columns x kFinSlices row-slices per workgroup: slice s adds partial rows s, s + kFinSlices, ... in f64 (four independent
+// chains so that the loads overlap), the slices are combined in a fixed order -> deterministic.
+constexpr int kFinSlices = 32;
+__device__ __forceinline__ double colsum_slice(const float* __restrict__ partial, int nb, int C, int c, int sl) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int b = sl;
+  for (; b + 3 * kFinSlices < nb; b += 4 * kFinSlices) {
+    s0 += static_cast<double>(partial[static_cast<size_t>(b) * C + c]);
+    s1 += static_cast<double>(partial[static_cast<size_t>(b + kFinSlices) * C + c]);
+    s2 += static_cast<double>(partial[static_cast<size_t>(b + 2 * kFinSlices) * C + c]);
+    s3 += static_cast<double>(partial[static_cast<size_t>(b + 3 * kFinSlices) * C + c]);
+  }
+  for (; b < nb; b += kFinSlices) s0 += static_cast<double>(partial[static_cast<size_t>(b) * C + c]);
+  return (s0 + s1) + (s2 + s3);
+}
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ partial, int nb, int C,
+                                                            float* __restrict__ out, const float* __restrict__ partial2 = nullptr,
+                                                            float* __restrict__ out2 = nullptr) {
+  __shared__ double red[kFinSlices][33];
   if (blockIdx.y == 1) { partial = partial2; out = out2; }      // second (partial, out) pair in the same launch
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
-  double s = 0.0;
-  if (c < C)
-    for (int b = sl; b < nb; b += 8) s += static_cast<double>(partial[static_cast<size_t>(b) * C + c]);
-  red[sl][cl] = s;
+  red[sl][cl] = c < C ? colsum_slice(partial, nb, C, c, sl) : 0.0;
   __syncthreads();
   if (sl == 0 && c < C) {
     double t = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][cl];
+    for (int k = 0; k < kFinSlices; ++k) t += red[k][cl];
     out[c] = static_cast<float>(t);
   }
 }
 
 // Several (partial, out) pairs in one launch: blockIdx.y names the job (a block of the backward pass queues the final stage of
 // its bias / LayerNorm-parameter gradients — six tiny reductions — and launches them once).
-__global__ __launch_bounds__(256) void colsum_final_multi_kernel(FinalJobs jobs) {
-  __shared__ double red[8][33];
+__global__ __launch_bounds__(1024) void colsum_final_multi_kernel(FinalJobs jobs) {
+  __shared__ double red[kFinSlices][33];
   const int job = blockIdx.y;
   const float* __restrict__ partial = jobs.partial[job];
   const int nb = jobs.slices[job], C = jobs.cols[job];
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   if (blockIdx.x * 32 >= C) return;
-  double s = 0.0;
-  if (c < C)
-    for (int b = sl; b < nb; b += 8) s += static_cast<double>(partial[static_cast<size_t>(b) * C + c]);
-  red[sl][cl] = s;
+  red[sl][cl] = c < C ? colsum_slice(partial, nb, C, c, sl) : 0.0;
   __syncthreads();
   if (sl == 0 && c < C) {
     double t = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][cl];
+    for (int k = 0; k < kFinSlices; ++k) t += red[k][cl];
     jobs.out[job][c] = static_cast<float>(t);
   }
 }
@@ -148,7 +155,8 @@ __global__ __launch_bounds__(256) void colsum_final_multi_kernel(FinalJobs jobs)
 // One wave per row (lane owns elements lane*4 + 256*j, d <= 1024); a workgroup of 4 waves walks kLnRows rows, every lane keeps
 // its dg/db columns in registers, the 4 waves are combined through LDS and one partial row per workgroup goes to HBM
 // (column-summed by colsum_final_kernel).
-constexpr int kLnRows = 32;
+constexpr int kLnRows = 16;   // rows per workgroup: 800 workgroups for a 12 800-row layer (32 rows left the CUs at 1.5 waves per SIMD; 8 rows
+                              // double the partial rows the final reduction has to add: measured slower in total)
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ x, int xkind, const void* __restrict__ dy,
                                                             int dykind, const float* __restrict__ g, float* __restrict__ dx,
                                                             int accumulate, int M, int d, float* __restrict__ pg,
@@ -167,12 +175,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
       dg[j][k] = 0.f; db[j][k] = 0.f;
     }
   const int rbase = blockIdx.x * kLnRows;
-  for (int rr = wid; rr < kLnRows; rr += 4) {
-    const int row = rbase + rr;
-    if (row >= M) break;
+  // two rows per wave and iteration: both rows' loads are issued before either is reduced, so the second row's memory latency hides
+  // under the first row's three butterflies (one row at a time the kernel ran at 2.8 TB/s: 49 us for the 137 MB of a vision layer)
+  auto load_row = [&](int row, float (&xv)[4][4], float (&dv)[4][4]) -> size_t {
     const size_t xrow = row_index ? static_cast<size_t>(row_index[row]) : static_cast<size_t>(row);   // x / dx row (pooled rows)
-    float xv[4][4], dv[4][4];
-    float s = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int e0 = lane * 4 + 256 * j;
@@ -181,8 +187,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
       const float4 da = ok ? load4_as_f32(dy, static_cast<size_t>(row) * d + e0, dykind) : float4{0.f, 0.f, 0.f, 0.f};
       xv[j][0] = xa.x; xv[j][1] = xa.y; xv[j][2] = xa.z; xv[j][3] = xa.w;
       dv[j][0] = da.x; dv[j][1] = da.y; dv[j][2] = da.z; dv[j][3] = da.w;
-      s += (xa.x + xa.y) + (xa.z + xa.w);
     }
+    return xrow;
+  };
+  auto do_row = [&](size_t xrow, float (&xv)[4][4], float (&dv)[4][4]) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += (xv[j][0] + xv[j][1]) + (xv[j][2] + xv[j][3]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     const float mean = s / static_cast<float>(d);
@@ -229,6 +240,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
         if (dx_bf16) *reinterpret_cast<uint2*>(dx_bf16 + xrow * d + e0) = uint2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
       }
     }
+  };
+  for (int rr = wid * 2; rr < kLnRows; rr += 8) {
+    const int row = rbase + rr;
+    if (row >= M) break;
+    const bool two = row + 1 < M;
+    float xa[4][4], da[4][4], xb[4][4], dbv[4][4];
+    const size_t ra = load_row(row, xa, da);
+    const size_t rb = load_row(two ? row + 1 : row, xb, dbv);
+    do_row(ra, xa, da);
+    if (two) do_row(rb, xb, dbv);
   }
   // combine the 4 waves' dg / db columns, one partial row per workgroup
 #pragma unroll
@@ -309,7 +330,7 @@ int launch_colsum_partial(const void* x, int kind, int rows, int cols, float* pa
   return CMH_OK;
 }
 int launch_colsum_final(const float* partial, int slices, int cols, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, partial, slices, cols, out, nullptr, nullptr);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 31) / 32), dim3(1024), 0, st, partial, slices, cols, out, nullptr, nullptr);
   CMH_CHECK_LAUNCH("colsum_final");
   return CMH_OK;
 }
@@ -332,7 +353,7 @@ extern "C" int cmh_colsum(const void* x, int32_t kind, int32_t rows, int32_t col
   else
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 255) / 256, nb), dim3(256), 0, st, x, kind, rows, cols, partial);
   CMH_CHECK_LAUNCH("colsum_partial");
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, partial, nb, cols, out, nullptr, nullptr);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 31) / 32), dim3(1024), 0, st, partial, nb, cols, out, nullptr, nullptr);
   CMH_CHECK_LAUNCH("colsum_final");
   return CMH_OK;
 }
@@ -361,7 +382,7 @@ int launch_layernorm_backward(const void* x, int x_kind, const void* dy, int dy_
     defer->add(pb, nb, d, dbeta);
     return CMH_OK;
   }
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 31) / 32, 2), dim3(256), 0, st, pg, nb, d, dgamma, pb, dbeta);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 31) / 32, 2), dim3(1024), 0, st, pg, nb, d, dgamma, pb, dbeta);
   CMH_CHECK_LAUNCH("layernorm_backward dgamma/dbeta");
   return CMH_OK;
 }
@@ -370,7 +391,7 @@ int launch_final_jobs(FinalJobs& jobs, hipStream_t st) {
   if (jobs.n == 0) return CMH_OK;
   int maxc = 0;
   for (int i = 0; i < jobs.n; ++i) maxc = jobs.cols[i] > maxc ? jobs.cols[i] : maxc;
-  hipLaunchKernelGGL(colsum_final_multi_kernel, dim3((maxc + 31) / 32, jobs.n), dim3(256), 0, st, jobs);
+  hipLaunchKernelGGL(colsum_final_multi_kernel, dim3((maxc + 31) / 32, jobs.n), dim3(1024), 0, st, jobs);
   CMH_CHECK_LAUNCH("final reductions");
   jobs.n = 0;
   return CMH_OK;

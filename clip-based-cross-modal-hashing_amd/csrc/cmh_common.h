@@ -125,8 +125,9 @@ int launch_gemm_fp8(const void* A8, const void* W8, const float* colscale, float
 
 // gemm_wide.hip, TN form (wgrad): out[Mm, Nn] f32 = sum_k Xk[k, m] * Wk[k, n], bf16 operands [Kd, Mm] / [Kd, Nn] row-major
 bool gemm_wide_tn_supported(int Mm, int Nn, int Kd);
+// colsum_partial (optional): [*colsum_slices, Mm] partial column sums of Xk (wgrad's bias gradient, first stage), <= 64 slices
 int launch_gemm_wide_tn(const void* Xk, const void* Wk, float* out, float* partials, size_t part_bytes, int Mm, int Nn, int Kd,
-                        hipStream_t st);
+                        hipStream_t st, float* colsum_partial = nullptr, int* colsum_slices = nullptr);
 
 // LayerNorm over rows of x[M,d] (f32) -> out (f32 or bf16 per out_bf16). rows optionally gathered:
 // row r reads x[row_index[r]] when row_index != null.

@@ -173,14 +173,15 @@ int wgrad_core(int dt, const void* dY, int ky, int O, const void* X, int kx, int
   // bf16 mode: dW = dY^T X straight from the row-major operands (TN GEMM, transposing LDS reads): no transposed copies
   const void* dYb = ky == kBF16 ? dY : dYe;
   if (dt == CMH_BF16 && kx == kBF16 && dYb && gemm_wide_tn_supported(O, I, M)) {
-    if ((rc = launch_gemm_wide_tn(dYb, X, dW, w.part, w.part_bytes, O, I, M, st))) return rc;
-    if (db) {   // column sums of dY (from its most precise copy): first stage now, final stage with the block's other reductions
-      float* dbp = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(w.red) + 255) & ~static_cast<uintptr_t>(255));
-      if (w.red_bytes < static_cast<size_t>((M + 63) / 64) * O * 4 + 256) return fail(CMH_ERR_WORKSPACE, "wgrad: reduction scratch too small");
-      if ((rc = launch_colsum_partial(dY, ky, M, O, dbp, st))) return rc;
-      if (w.defer && w.defer->n < FinalJobs::kMax) w.defer->add(dbp, (M + 63) / 64, O, db);
-      else if ((rc = launch_colsum_final(dbp, (M + 63) / 64, O, db, st))) return rc;
-    }
+    // the bias gradient's first stage (column sums of dY per K split) is a by-product of the same launch
+    float* dbp = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(w.red) + 255) & ~static_cast<uintptr_t>(255));
+    const bool cs = db && w.red_bytes >= static_cast<size_t>(64) * O * 4 + 256;
+    int slices = 0;
+    if ((rc = launch_gemm_wide_tn(dYb, X, dW, w.part, w.part_bytes, O, I, M, st, cs ? dbp : nullptr, &slices))) return rc;
+    if (cs) {
+      if (w.defer && w.defer->n < FinalJobs::kMax) w.defer->add(dbp, slices, O, db);
+      else if ((rc = launch_colsum_final(dbp, slices, O, db, st))) return rc;
+    } else if (db && (rc = cmh_colsum(dY, ky, M, O, db, w.red, w.red_bytes, st))) return rc;
     return CMH_OK;
   }
   // db = column sums of dY: their first stage rides on the transpose of dY when that takes the tiled path
@@ -302,11 +303,16 @@ template <typename T>
 __global__ __launch_bounds__(256) void pool_wgrad_kernel(const T* __restrict__ pool, const float* __restrict__ dfeat,
                                                          float* __restrict__ dproj, int B, int d, int E) {
   const int i = blockIdx.x;
+  constexpr int kind = sizeof(T) == 4 ? kF32 : kBF16;
   for (int j = threadIdx.x; j < E; j += 256) {
-    float acc = 0.f;
-    for (int b = 0; b < B; ++b)
-      acc += load_as_f32(pool, static_cast<size_t>(b) * d + i, sizeof(T) == 4 ? kF32 : kBF16) * dfeat[static_cast<size_t>(b) * E + j];
-    dproj[static_cast<size_t>(i) * E + j] = acc;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // eight independent chains over the batch (one chain: 137 us)
+    int b = 0;
+    for (; b + 8 <= B; b += 8)
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        acc[u] = fmaf(load_as_f32(pool, static_cast<size_t>(b + u) * d + i, kind), dfeat[static_cast<size_t>(b + u) * E + j], acc[u]);
+    for (; b < B; ++b) acc[0] = fmaf(load_as_f32(pool, static_cast<size_t>(b) * d + i, kind), dfeat[static_cast<size_t>(b) * E + j], acc[0]);
+    dproj[static_cast<size_t>(i) * E + j] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   }
 }
 

@@ -71,6 +71,7 @@ struct WideScales {
   float alpha;             // EPI_SCALE: acc *= alpha * colscale[n]
   float oscale;            // EPI_OUT_FP8: out = e4m3(clamp(v * oscale))
   int kreal;               // TN: rows of the K-major operands that exist (K is padded to whole K-steps)
+  float* colsum;           // TN, optional: [ksplit, M] partial column sums of the Xk operand (wgrad: the bias gradient's first stage)
 };
 
 // TN operands (wgrad: dW[O,I] = dY^T X with dY [M,O] and X [M,I] as the backward pass has them, the reduction index m being the
@@ -474,6 +475,21 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
     const w_u32x4_t fw = {w2[0][0], w2[0][1], w2[1][0], w2[1][1]}, fx = {x2[0][0], x2[0][1], x2[1][0], x2[1][1]};
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(w_bf16x8_t, fw), __builtin_bit_cast(w_bf16x8_t, fx), c, 0, 0, 0);
   };
+  // TN: column sums of the Xk operand (= wgrad's bias gradient) ride along as one more MFMA per half-step against an all-ones
+  // operand: the four waves that share Xk fragments take one m-tile each (b = wn), in tiles of the first n-panel only
+  w_f32x4_t csacc = {0.f, 0.f, 0.f, 0.f};
+  const w_u32x2_t ones2[2] = {{0x3f803f80u, 0x3f803f80u}, {0x3f803f80u, 0x3f803f80u}};
+  bool do_cs = false;
+  auto cs_mfma = [&](const w_u32x2_t (&hx)[TN ? MF : 1][2]) __attribute__((always_inline)) {
+    if constexpr (TN) {
+      switch (wn) {     // wave-uniform; a runtime index would push the fragments to scratch
+        case 0: mfma_h(ones2, hx[0], csacc); break;
+        case 1: mfma_h(ones2, hx[1], csacc); break;
+        case 2: mfma_h(ones2, hx[2], csacc); break;
+        default: mfma_h(ones2, hx[3], csacc); break;
+      }
+    }
+  };
   if constexpr (TN) {
 #pragma unroll
     for (int a = 0; a < 4; ++a) { W_TR(h0w[a][0], tW[a][0], 0); W_TR(h0w[a][1], tW[a][1], 0); }
@@ -497,6 +513,15 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
 #pragma unroll
         for (int b = 0; b < MF; ++b) acc[a][b] = w_f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
+    if constexpr (TN) {
+      if (sc.colsum) {
+        const int virt_c = range_lo + slot + ti * per_xcd_blocks;
+        int tm_c, tn_c;
+        tile_coords(virt_c - (virt_c / base_total) * base_total, tm_c, tn_c);
+        do_cs = tn_c == 0;
+        csacc = w_f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+    }
 
     for (int kt = 0; kt < nk; ++kt) {
       if constexpr (TN) {
@@ -518,6 +543,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
           mfma_h(h0w[i / MF], h0x[i % MF], acc[i / MF][i % MF]);
           if (i % 3 == 2) __builtin_amdgcn_sched_barrier(0);
         }
+        if (do_cs) cs_mfma(h0x);
         if constexpr (GB) issue_done();
         __builtin_amdgcn_sched_barrier(0);
         W_WAIT_H(0, h1w, h1x);
@@ -536,6 +562,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
             mfma_h(h1w[i / MF], h1x[i % MF], acc[i / MF][i % MF]);
             if (i % 3 == 2) __builtin_amdgcn_sched_barrier(0);
           }
+          if (do_cs) cs_mfma(h1x);
           if constexpr (!GB) issue_done();
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -701,6 +728,13 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
     int tm, tn;
     tile_coords(logical, tm, tn);
     const int m0 = tm * BMt, n0 = tn * wBN;
+    if constexpr (TN) {
+      // every row of the ones-product holds the column sums: lane (fq = 0, frow) stores column m0 + wm*WR + wn*16 + frow of split `split`
+      if (do_cs && fq == 0) {
+        const int mc = m0 + wm * WR + wn * 16 + frow;
+        if (mc < M) sc.colsum[static_cast<size_t>(split) * M + mc] = csacc[0];
+      }
+    }
     // All loads first, then all stores: a load issued behind a store (or waited for with DMA in flight) would wait for
     // every older store to be acknowledged.
     if (FP8 && (epi & EPI_SCALE)) {   // dequantisation of fp8 operands, fused with the bias: acc * (alpha * colscale[n]) + bias[n]
@@ -933,10 +967,10 @@ int launch_gemm_wide_splitk(int dt, const void* A, const void* W, float* out, fl
   const int grid = total < cus ? ((total + 7) & ~7) : cus;
   if (dt == CMH_F32)
     hipLaunchKernelGGL((gemm_wide_kernel<0, 0, 5>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),
-                       static_cast<const char*>(W), nullptr, nullptr, partials, M, N, K, 0, S, wide_order_group(N), WideScales{nullptr, 1.f, 1.f, 0});
+                       static_cast<const char*>(W), nullptr, nullptr, partials, M, N, K, 0, S, wide_order_group(N), WideScales{nullptr, 1.f, 1.f, 0, nullptr});
   else
     hipLaunchKernelGGL((gemm_wide_kernel<1, 0, 5>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),
-                       static_cast<const char*>(W), nullptr, nullptr, partials, M, N, K, 0, S, wide_order_group(N), WideScales{nullptr, 1.f, 1.f, 0});
+                       static_cast<const char*>(W), nullptr, nullptr, partials, M, N, K, 0, S, wide_order_group(N), WideScales{nullptr, 1.f, 1.f, 0, nullptr});
   const size_t n = static_cast<size_t>(M) * N;
   const size_t blocks = (n / 4 + 255) / 256;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, partials, S, n, out);
@@ -954,20 +988,22 @@ bool gemm_wide_tn_supported(int Mm, int Nn, int Kd) {
 }
 
 int launch_gemm_wide_tn(const void* Xk, const void* Wk, float* out, float* partials, size_t part_bytes, int Mm, int Nn, int Kd,
-                        hipStream_t st) {
+                        hipStream_t st, float* colsum_partial, int* colsum_slices) {
   if (!gemm_wide_tn_supported(Mm, Nn, Kd)) return fail(CMH_ERR_INVALID, "gemm_tn: unsupported shape Mm=%d Nn=%d Kd=%d", Mm, Nn, Kd);
   const int cus = wide_cus();
   const int tiles = (Nn / wBN) * (Mm / 128);
   const int nkt = (Kd + 63) / 64;
   int S = cus / tiles;
   if (S > nkt / 8) S = nkt / 8;
+  if (S > 64) S = 64;                                    // (the column-sum partials are sized for 64 slices)
   while (S > 1 && static_cast<size_t>(S) * Mm * Nn * 4 > part_bytes) --S;
   if (S < 1) S = 1;
   const int nk_per = (nkt + S - 1) / S;
   const int Kpad = S * nk_per * 64;                      // the kernel's K: whole K-steps per split; rows >= Kd are zero-filled
   const int total = tiles * S;
   const int grid = total < cus ? ((total + 7) & ~7) : cus;
-  const WideScales sc{nullptr, 1.f, 1.f, Kd};
+  const WideScales sc{nullptr, 1.f, 1.f, Kd, colsum_partial};   // colsum_partial: [S, Mm] (>= 64 * Mm floats are always enough)
+  if (colsum_slices) *colsum_slices = S;
   hipLaunchKernelGGL((gemm_wide_kernel<1, 0, 4, true>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(Xk),
                      static_cast<const char*>(Wk), nullptr, nullptr, S > 1 ? static_cast<void*>(partials) : static_cast<void*>(out),
                      Mm, Nn, Kpad, 0, S, 0, sc);
@@ -982,7 +1018,7 @@ int launch_gemm_wide_tn(const void* Xk, const void* Wk, float* out, float* parti
 
 int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out,
                      int M, int N, int K, int epi, hipStream_t st, const float* colscale, float alpha, float oscale) {
-  const WideScales sc{colscale, alpha, oscale, 0};
+  const WideScales sc{colscale, alpha, oscale, 0, nullptr};
   const size_t esz = dt == CMH_F32 ? 4 : (dt == CMH_FP8 ? 1 : 2);
   if (static_cast<size_t>(M) * K * esz >= (1ull << 32) || static_cast<size_t>(wBN) * K * esz >= (1ull << 32))
     return fail(CMH_ERR_INVALID, "gemm: operand of %zu bytes exceeds the 32-bit offset range of the wide kernel",

@@ -39,16 +39,26 @@ __global__ __launch_bounds__(256) void la_dx_kernel(const float* __restrict__ dz
 // dW[n,k] = sum_m dz[m,n] x[m,k];  db[n] = sum_m dz[m,n]
 __global__ __launch_bounds__(256) void la_dw_kernel(const float* __restrict__ dz, const float* __restrict__ x, float* __restrict__ dw,
                                                     float* __restrict__ db, int M, int N, int K) {
+  // grid (N, ceil(K / 256)); eight independent chains over m (rows m = u mod 8), added in a fixed order: a single serial chain
+  // over the 256 batch rows on 64 workgroups took 160 us
   const int n = blockIdx.x;
-  for (int k = threadIdx.x; k < K; k += 256) {
-    float acc = 0.f;
-    for (int m = 0; m < M; ++m) acc = fmaf(dz[static_cast<size_t>(m) * N + n], x[static_cast<size_t>(m) * K + k], acc);
-    dw[static_cast<size_t>(n) * K + k] = acc;
+  const int k = blockIdx.y * 256 + threadIdx.x;
+  if (k < K) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int m = 0;
+    for (; m + 8 <= M; m += 8)
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        acc[u] = fmaf(dz[static_cast<size_t>(m + u) * N + n], x[static_cast<size_t>(m + u) * K + k], acc[u]);
+    for (; m < M; ++m) acc[0] = fmaf(dz[static_cast<size_t>(m) * N + n], x[static_cast<size_t>(m) * K + k], acc[0]);
+    dw[static_cast<size_t>(n) * K + k] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   }
-  if (threadIdx.x == 0) {
-    float acc = 0.f;
-    for (int m = 0; m < M; ++m) acc += dz[static_cast<size_t>(m) * N + n];
-    db[n] = acc;
+  if (blockIdx.y == 0 && threadIdx.x < 64) {     // db[n]: one wave, lanes stride over m, butterfly
+    float a = 0.f;
+    for (int m = threadIdx.x; m < M; m += 64) a += dz[static_cast<size_t>(m) * N + n];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (threadIdx.x == 0) db[n] = a;
   }
 }
 
@@ -541,7 +551,7 @@ extern "C" int cmh_linear_act_backward(const float* x, const float* w, const flo
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(la_dz_kernel, dim3((M * N + 255) / 256), dim3(256), 0, st, y, dy, drop_mask, keep_scale, act, dz, M * N);
   hipLaunchKernelGGL(la_dx_kernel, dim3(M), dim3(256), 0, st, dz, w, dx, M, N, K);
-  hipLaunchKernelGGL(la_dw_kernel, dim3(N), dim3(256), 0, st, dz, x, dw, db, M, N, K);
+  hipLaunchKernelGGL(la_dw_kernel, dim3(N, (K + 255) / 256), dim3(256), 0, st, dz, x, dw, db, M, N, K);
   CMH_CHECK_LAUNCH("linear_act_backward");
   return CMH_OK;
 }
