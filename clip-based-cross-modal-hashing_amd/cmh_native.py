@@ -67,7 +67,7 @@ class TextGrads(C.Structure):
 
 class AdamTensor(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64),
-                ("lr", C.c_float), ("weight_decay", C.c_float), ("max_grad_norm", C.c_float)]
+                ("lr", C.c_float), ("weight_decay", C.c_float), ("max_grad_norm", C.c_float), ("p_bf16", C.c_void_p)]
 
 
 class Taps(C.Structure):
@@ -635,7 +635,12 @@ def bert_adam_step(entries, b1, b2, eps):
         for t in (p, g, m, v):
             if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != p.numel():
                 raise NativeError("bert_adam_step: tensors must be contiguous f32 of one size")
-        arr[i] = AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(wd), float(mx))
+        # the encoder's bf16 GEMM copy of this parameter (model/base/model.py::_gemm_w), if one exists: the step rewrites it
+        copy = getattr(p, "_cmh_bf16", None)
+        if copy is not None and (copy.numel() != p.numel() or copy.device != p.device or copy.dtype != torch.bfloat16):
+            copy = None
+        arr[i] = AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), float(lr), float(wd), float(mx),
+                            None if copy is None else copy.data_ptr())
         total += p.numel()
     need = lib().cmh_bert_adam_workspace_bytes(len(entries), total)
     ws = workspace(need, dev, "adam")

@@ -30,6 +30,7 @@ struct AdamTensorDev {
   long long n;
   float lr, wd, max_norm;
   int first_chunk;                  // index of this tensor's first chunk
+  bf16_t* p_bf16;                   // optional: the encoder's bf16 GEMM copy of p, rewritten here (no cast pass per step)
 };
 
 struct AdamChunk { int tensor; int index; };   // chunk `index` of tensor `tensor`
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(256) void adam_update_kernel(const AdamTensorDev* _
       adam_elem(p.w, g.w, m.w, v.w, coef, clip, b1, omb1, b2, omb2, eps, t.wd, t.lr);
       p4[i] = p; m4[i] = m; w4[i] = v;
       if (clip) g4[i] = g;
+      if (t.p_bf16) *reinterpret_cast<uint2*>(t.p_bf16 + lo + i * 4) = uint2{pack_bf16x2(p.x, p.y), pack_bf16x2(p.z, p.w)};
     }
     tail = lo + v4 * 4;
   }
@@ -133,6 +135,7 @@ __global__ __launch_bounds__(256) void adam_update_kernel(const AdamTensorDev* _
     adam_elem(p, g, m, v, coef, clip, b1, omb1, b2, omb2, eps, t.wd, t.lr);
     t.p[i] = p; t.m[i] = m; t.v[i] = v;
     if (clip) t.g[i] = g;
+    if (t.p_bf16) t.p_bf16[i] = f32_to_bf16(p);
   }
 }
 
@@ -201,7 +204,8 @@ extern "C" int cmh_bert_adam_step(const cmh_adam_tensor* tensors, int32_t count,
   size_t ci = 0;
   for (int i = 0; i < count; ++i) {
     hT[i] = AdamTensorDev{tensors[i].p, tensors[i].g, tensors[i].m, tensors[i].v, tensors[i].n, tensors[i].lr,
-                          tensors[i].weight_decay, tensors[i].max_grad_norm, static_cast<int>(ci)};
+                          tensors[i].weight_decay, tensors[i].max_grad_norm, static_cast<int>(ci),
+                          static_cast<bf16_t*>(tensors[i].p_bf16)};
     const int nch = static_cast<int>((tensors[i].n + kAdamChunk - 1) / kAdamChunk);
     for (int c = 0; c < nch; ++c) hC[ci++] = AdamChunk{i, c};
   }

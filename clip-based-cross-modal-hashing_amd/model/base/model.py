@@ -117,6 +117,15 @@ def _prep(p: torch.Tensor, keep: list) -> torch.Tensor:
 
 
 def _gemm_w(p: torch.Tensor, dt: int, keep: list, transpose: bool = False) -> torch.Tensor:
+    if dt in (N.BF16, N.FP8) and not transpose and p.dtype == torch.float32 and p.is_contiguous():
+        # the bf16 copy lives on the parameter: the fused BertAdam step rewrites it together with the f32 values (cmh_adam_tensor.
+        # p_bf16) and stamps the version it is current for, so a training step pays no cast pass over the weights
+        t = getattr(p, "_cmh_bf16", None)
+        if t is None or t.device != p.device or t.numel() != p.numel() or getattr(p, "_cmh_bf16_version", None) != (p.data_ptr(), p._version):
+            t = N.cast_bf16(p.detach().reshape(p.shape[0], -1))
+            p._cmh_bf16, p._cmh_bf16_version = t, (p.data_ptr(), p._version)
+        keep.append(t)
+        return t
     t = p.detach().float()
     t = t.t().contiguous() if transpose else t.contiguous()
     t = t.reshape(t.shape[0], -1)

@@ -104,4 +104,7 @@ class BertAdam(Optimizer):
             N.bert_adam_step(entries, b1, b2, e)
             # the kernel wrote through raw pointers: tell autograd / the weight caches (model/base/model.py::_key)
             torch._C._increment_version([t for p, g, *_ in entries for t in (p, g)])
+            for p, *_ in entries:       # bf16 GEMM copies rewritten by the kernel are current for the new version
+                if getattr(p, "_cmh_bf16", None) is not None:
+                    p._cmh_bf16_version = (p.data_ptr(), p._version)
         return loss

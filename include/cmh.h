@@ -416,6 +416,8 @@ typedef struct cmh_adam_tensor {
   float* p; float* g; float* m; float* v;
   int64_t n;
   float lr, weight_decay, max_grad_norm;
+  void* p_bf16;             /* optional (NULL): bf16 [n] copy of p - the encoder's CMH_BF16 GEMM operand - rewritten with the updated
+                             * values (round-to-nearest-even, as cmh_cast_f32_to_bf16), so that no cast pass follows the step */
 } cmh_adam_tensor;
 size_t cmh_bert_adam_workspace_bytes(int32_t count, int64_t total_elems);
 /* b1 / b2 / eps are doubles because the reference forms 1 - b in python doubles before ATen rounds it to f32. */
