@@ -345,7 +345,7 @@ def main():
                      "gemm_ms_per_step_serialized": round(gemm_ms / a.steps, 4)},
     }
 
-    if rank == 0 and a.dtype != "f32" and not a.no_precision_legs:
+    if world == 1 and a.dtype != "f32" and not a.no_precision_legs:      # (step() holds a collective when world > 1: single-GPU runs only)
         try:
             # the precision story of the benchmarked mode: sign flips against the f32 parity mode on this very batch, and the same
             # step timed in f32 mode (towers serialized so that the per-launch events time the kernels)
