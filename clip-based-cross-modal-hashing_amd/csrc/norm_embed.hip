@@ -95,50 +95,61 @@ __global__ __launch_bounds__(256) void layernorm_h2b_kernel(const uint16_t* __re
                                                             const float* __restrict__ w, const float* __restrict__ b,
                                                             uint16_t* __restrict__ out, int M) {
   constexpr int d = NB * 256;
+  constexpr int RPH = NB <= 2 ? 2 : 1;     // rows per half-wave: narrow rows (512 elements = two loads per lane) have too few bytes in
+                                           // flight one at a time (10 499 x 512: 7.7 us = 2.8 TB/s); both rows' loads are issued first
   const int hl = threadIdx.x & 31;
-  const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
-  if (row >= M) return;
-  const size_t src = row_index ? static_cast<size_t>(row_index[row]) : static_cast<size_t>(row);
-  const uint16_t* xr = x + src * d;
   typedef __attribute__((ext_vector_type(4))) uint32_t u4;
-  float v[NB][8];
+  const int row0 = (blockIdx.x * 8 + (threadIdx.x >> 5)) * RPH;
+  if (row0 >= M) return;
+  float v[RPH][NB][8];
 #pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    const u4 u = *reinterpret_cast<const u4*>(xr + j * 256 + hl * 8);
+  for (int r = 0; r < RPH; ++r) {
+    const int row = row0 + r < M ? row0 + r : M - 1;
+    const size_t src = row_index ? static_cast<size_t>(row_index[row]) : static_cast<size_t>(row);
+    const uint16_t* xr = x + src * d;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { v[j][2 * k] = f16lo_to_f32(u[k]); v[j][2 * k + 1] = f16hi_to_f32(u[k]); }
+    for (int j = 0; j < NB; ++j) {
+      const u4 u = *reinterpret_cast<const u4*>(xr + j * 256 + hl * 8);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[r][j][2 * k] = f16lo_to_f32(u[k]); v[r][j][2 * k + 1] = f16hi_to_f32(u[k]); }
+    }
   }
   auto half_sum = [](float t) {
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
     return t;
   };
-  float s = 0.f;
 #pragma unroll
-  for (int j = 0; j < NB; ++j)
+  for (int r = 0; r < RPH; ++r) {
+    const int row = row0 + r;
+    float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s += v[j][k];
-  const float mean = half_sum(s) / static_cast<float>(d);
-  float ss = 0.f;
+    for (int j = 0; j < NB; ++j)
 #pragma unroll
-  for (int j = 0; j < NB; ++j)
+      for (int k = 0; k < 8; ++k) s += v[r][j][k];
+    const float mean = half_sum(s) / static_cast<float>(d);
+    float ss = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const float c = v[j][k] - mean; ss += c * c; }
-  const float rstd = 1.0f / sqrtf(half_sum(ss) / static_cast<float>(d) + 1e-5f);
-  uint16_t* orow = out + static_cast<size_t>(row) * d;
+    for (int j = 0; j < NB; ++j)
 #pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    const int e0 = j * 256 + hl * 8;
-    const float4 w0 = *reinterpret_cast<const float4*>(w + e0), w1 = *reinterpret_cast<const float4*>(w + e0 + 4);
-    const float4 b0 = *reinterpret_cast<const float4*>(b + e0), b1 = *reinterpret_cast<const float4*>(b + e0 + 4);
-    const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-    const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-    u4 pk;
+      for (int k = 0; k < 8; ++k) { const float c = v[r][j][k] - mean; ss += c * c; }
+    const float rstd = 1.0f / sqrtf(half_sum(ss) / static_cast<float>(d) + 1e-5f);
+    if (row >= M) continue;                 // (the butterflies above run for every lane of the wave)
+    uint16_t* orow = out + static_cast<size_t>(row) * d;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      pk[k] = pack_bf16x2((v[j][2 * k] - mean) * rstd * wv[2 * k] + bv[2 * k],
-                          (v[j][2 * k + 1] - mean) * rstd * wv[2 * k + 1] + bv[2 * k + 1]);
-    *reinterpret_cast<u4*>(orow + e0) = pk;
+    for (int j = 0; j < NB; ++j) {
+      const int e0 = j * 256 + hl * 8;
+      const float4 w0 = *reinterpret_cast<const float4*>(w + e0), w1 = *reinterpret_cast<const float4*>(w + e0 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(b + e0), b1 = *reinterpret_cast<const float4*>(b + e0 + 4);
+      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+      const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      u4 pk;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        pk[k] = pack_bf16x2((v[r][j][2 * k] - mean) * rstd * wv[2 * k] + bv[2 * k],
+                            (v[r][j][2 * k + 1] - mean) * rstd * wv[2 * k + 1] + bv[2 * k + 1]);
+      *reinterpret_cast<u4*>(orow + e0) = pk;
+    }
   }
 }
 
@@ -148,10 +159,10 @@ int launch_layernorm_x(const void* x, int x_f16, const int32_t* row_index, const
   if (x_f16 && out_bf16 && d % 256 == 0) {
     const uint16_t* xh = static_cast<const uint16_t*>(x);
     uint16_t* oh = static_cast<uint16_t*>(out);
-    const dim3 grid((M + 7) / 8), block(256);
+    const dim3 grid((M + 7) / 8), grid2((M + 15) / 16), block(256);     // two rows per half-wave for d <= 512
     switch (d / 256) {
-      case 1: hipLaunchKernelGGL(layernorm_h2b_kernel<1>, grid, block, 0, st, xh, row_index, w, b, oh, M); break;
-      case 2: hipLaunchKernelGGL(layernorm_h2b_kernel<2>, grid, block, 0, st, xh, row_index, w, b, oh, M); break;
+      case 1: hipLaunchKernelGGL(layernorm_h2b_kernel<1>, grid2, block, 0, st, xh, row_index, w, b, oh, M); break;
+      case 2: hipLaunchKernelGGL(layernorm_h2b_kernel<2>, grid2, block, 0, st, xh, row_index, w, b, oh, M); break;
       case 3: hipLaunchKernelGGL(layernorm_h2b_kernel<3>, grid, block, 0, st, xh, row_index, w, b, oh, M); break;
       default: hipLaunchKernelGGL(layernorm_h2b_kernel<4>, grid, block, 0, st, xh, row_index, w, b, oh, M); break;
     }
@@ -343,20 +354,31 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int64_t* __restri
 __global__ __launch_bounds__(1024) void text_pack_plan_kernel(const int64_t* __restrict__ tokens, int B, int L,
                                                               int32_t* __restrict__ seq_off) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int b = wave; b < B; b += 16) {
-    long long best = INT64_MIN;
-    int besti = 0;
-    for (int i = lane; i < L; i += 64) {
-      const long long v = tokens[static_cast<size_t>(b) * L + i];
-      if (v > best) { best = v; besti = i; }      // a lane's indices ascend: strict > keeps its first maximum
+  // four captions per wave and iteration, their row loads issued together (one caption at a time the 16 dependent
+  // load -> butterfly rounds of a 256-caption batch took 30 us)
+  for (int b0 = wave * 4; b0 < B; b0 += 64) {
+    long long best[4];
+    int besti[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      best[u] = INT64_MIN;
+      besti[u] = 0;
+      const int b = b0 + u < B ? b0 + u : B - 1;
+      for (int i = lane; i < L; i += 64) {
+        const long long v = tokens[static_cast<size_t>(b) * L + i];
+        if (v > best[u]) { best[u] = v; besti[u] = i; }      // a lane's indices ascend: strict > keeps its first maximum
+      }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const long long ov = __shfl_xor(best, o, 64);
-      const int oi = __shfl_xor(besti, o, 64);
-      if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const long long ov = __shfl_xor(best[u], o, 64);
+        const int oi = __shfl_xor(besti[u], o, 64);
+        if (ov > best[u] || (ov == best[u] && oi < besti[u])) { best[u] = ov; besti[u] = oi; }
+      }
+      if (lane == 0 && b0 + u < B) seq_off[b0 + u + 1] = besti[u] + 1;    // length, turned into an offset below
     }
-    if (lane == 0) seq_off[b + 1] = besti + 1;    // length, turned into an offset below
   }
   __syncthreads();
   if (wave == 0) {
