@@ -37,9 +37,9 @@ constexpr int NWAVE = NT / 64;
 constexpr int kIdxBits = 19;       // N < 2^19 = 524288
 constexpr uint32_t kIdxMask = (1u << kIdxBits) - 1;
 constexpr int kMaxWords = 64;      // K <= 2048 bits
-constexpr int kCoopMin = 2048;     // segments at least this long are partitioned by the whole workgroup
+constexpr int kChunk = 512;        // a longer segment is partitioned in chunks of this many positions, one wave per chunk
 constexpr int kLeaf = 16;          // libstdc++ _S_threshold
-constexpr int kSeqMax = 64;        // segments of 17..kSeqMax elements are finished sequentially, one lane each
+constexpr int kSeqMax = 32;        // segments of 17..kSeqMax elements are finished sequentially, one lane each
 
 __device__ __forceinline__ int ekey(uint32_t e) { return static_cast<int>(e >> kIdxBits); }
 __device__ __forceinline__ int eidx(uint32_t e) { return static_cast<int>(e & kIdxMask); }
@@ -58,6 +58,10 @@ struct QueryStore {
   uint32_t* leafbits; // [(N+31)/32] bit x = a segment starts at x
   uint32_t* relbits;  // [(N+31)/32] bit j = database item j is relevant to the query
   uint32_t* smallbits;// [(N+31)/32] bit x = a parked (17..kSeqMax element) segment starts at x
+  uint32_t* task;     // [tcap] one level's work list: segment index << 11 | chunk
+  uint32_t* cnt;      // [3*ccap] per chunk: L count, R count, swaps
+  uint32_t* seginfo;  // [N/(kSeqMax+1)+2] per queued segment: first chunk | number of chunks << 16
+  int tcap, ccap;
 };
 
 __host__ __device__ inline size_t store_words(int64_t N) {
@@ -65,7 +69,8 @@ __host__ __device__ inline size_t store_words(int64_t N) {
   const size_t tmpw = n + 2 * (n / 17) + 8;
   const size_t qw = 2 * (n / 17 + 2);
   const size_t bw = (n + 31) / 32;
-  return n + tmpw + 2 * qw + 3 * bw + 16;
+  const size_t tcap = n / (kSeqMax + 1) + n / kChunk + 8, ccap = 2 * (n / kChunk) + 8;
+  return n + tmpw + 2 * qw + 3 * bw + tcap + 3 * ccap + (n / (kSeqMax + 1) + 2) + 16;
 }
 
 __device__ inline QueryStore carve_store(uint32_t* base, int N) {
@@ -81,6 +86,11 @@ __device__ inline QueryStore carve_store(uint32_t* base, int N) {
   s.leafbits = s.qb + qw;
   s.relbits = s.leafbits + bw;
   s.smallbits = s.relbits + bw;
+  s.tcap = static_cast<int>(n / (kSeqMax + 1) + n / kChunk + 8);
+  s.ccap = static_cast<int>(2 * (n / kChunk) + 8);
+  s.task = s.smallbits + bw;
+  s.cnt = s.task + s.tcap;
+  s.seginfo = s.cnt + 3 * s.ccap;
   return s;
 }
 
@@ -88,12 +98,6 @@ __device__ inline QueryStore carve_store(uint32_t* base, int N) {
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   __builtin_amdgcn_wave_barrier();
-}
-
-template <bool BLOCK>
-__device__ __forceinline__ void group_sync() {
-  if constexpr (BLOCK) __syncthreads();
-  else wave_sync();
 }
 
 __device__ __forceinline__ int wave_sum_i(int v) {
@@ -164,116 +168,129 @@ __device__ inline void heap_sort_segment(uint32_t* e, int f, int l) {
 }
 
 // ---- one Hoare partition, closed form -------------------------------------------------------------------
-// Executed by a wave (BLOCK=false; lane in [0,64), wid=0, nw=1) or by the workgroup (BLOCK=true).
-// cnt: LDS scratch of 2*NWAVE+2 ints (BLOCK only).  Returns cut (same value in every participating lane).
-template <bool BLOCK>
-__device__ inline int partition_segment(const QueryStore& S, int f, int l, int lane, int wid, int nw, int* cnt) {
+// With L = ascending positions of [f+1, l) whose key >= pivot and R = descending positions whose key <= pivot (original values),
+// std::__unguarded_partition swaps exactly the pairs (L_i, R_i), i < s, s = #{i : L_i < R_i} (a prefix), and returns
+// min(L_s, R_{s-1}).  A pair beyond cap = n/2+1 can never swap, so the lists are cut there.
+// The partition by ONE wave, in one pass per list and without a count pass: L is filled walking up from f+1, R walking down
+// from l-1 (a lane's rank = the running count + v_mbcnt of the ballot), and each walk stops once its list holds cap entries (no pair
+// beyond cap can swap).  U = 64-element chunks per iteration (their reads are issued back to back); short segments take U = 1 and
+// never loop.  Everything here is issue-bound - four waves share a SIMD - so instructions, not LDS round trips, are what is counted.
+__device__ __forceinline__ int mbcnt64(uint64_t m) {
+  return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+}
+
+// A segment whose keys are all equal (most of a Hamming ranking ends in such runs: <= 2K+1 key values) needs no data to be sorted:
+// median-to-first swaps positions 0 and n/2, the partition loop swaps (1+i, n-1-i) until they meet, i.e. reverses [1, n-1], and
+// returns cut = 1 + (n-1)/2; both children are all-equal again, and the final insertion sort moves nothing.  So where an element
+// of the run ends up is a function of (n, its position) alone, and the whole introsort subtree is applied as ONE permutation
+// (through the segment's tmp slice) - its remaining levels, parked segments and leaves are never visited.  `budget` = depth budget
+// of the children: the shortcut is taken only when no heapsort fallback can occur below (levels needed <= budget).
+__device__ inline bool all_equal_shortcut(const QueryStore& S, int f, int l, int lane, int budget) {
   uint32_t* e = S.elem;
   const int n = l - f;
-  if (wid == 0 && lane == 0) median_to_first(e, f, l);
-  group_sync<BLOCK>();
+  const int key0 = ekey(e[f]);
+  for (int x0 = f + 1; x0 < l; x0 += 256) {
+    bool diff = false;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int x = x0 + 64 * u + lane;
+      if (x < l) diff |= ekey(e[x]) != key0;
+    }
+    if (__ballot(diff)) return false;
+  }
+  int levels = 0;
+  for (int m = 1 + (n - 1) / 2; m > kLeaf; m = 1 + (m - 1) / 2) ++levels;      // the left child is never the smaller one
+  if (levels > budget) return false;
+  uint32_t* slice = S.tmp + tmp_base(f);
+  for (int x = f + lane; x < l; x += 64) {
+    const uint32_t v = e[x];
+    int pos = x - f, nn = n, base = 0;
+    while (nn > kLeaf) {
+      const int mid = nn / 2;
+      pos = pos == 0 ? mid : (pos == mid ? 0 : pos);
+      pos = pos == 0 ? 0 : nn - pos;
+      const int c = 1 + (nn - 1) / 2;
+      if (pos < c) nn = c;
+      else { pos -= c; base += c; nn -= c; }
+    }
+    slice[base + pos] = v;
+  }
+  wave_sync();
+  for (int x = f + lane; x < l; x += 64) e[x] = slice[x - f];
+  wave_sync();
+  return true;
+}
+
+// returns the cut, or -1 when the segment was finished by the all-equal shortcut (no children)
+template <int U>
+__device__ inline int partition_wave(const QueryStore& S, int f, int l, int lane, int budget) {
+  uint32_t* e = S.elem;
+  const int n = l - f;
+  if (all_equal_shortcut(S, f, l, lane, budget)) return -1;
+  if (lane == 0) median_to_first(e, f, l);
+  wave_sync();
   const int p = ekey(e[f]);
   const int cap = n / 2 + 1;
   uint32_t* tL = S.tmp + tmp_base(f);
   uint32_t* tR = tL + cap;
-
-  // this wave's contiguous share of [f+1, l)
-  const int len = n - 1;
-  const int per = (((len + nw - 1) / nw) + 63) & ~63;
-  int a = f + 1 + wid * per;
-  a = a < l ? a : l;
-  int b = a + per;
-  b = b < l ? b : l;
-
-  // Both passes walk 4 chunks per iteration: the 4 LDS (or L2) reads are issued back to back, so their latency is paid
-  // once per 256 elements instead of once per 64 (these loops are pure latency chains otherwise).
-  int cL = 0, cR = 0;
-  for (int x0 = a; x0 < b; x0 += 256) {
-    int k[4];
-    bool v[4];
+  int Lc = 0, Rc = 0;
+  for (int x0 = f + 1; x0 < l && Lc < cap; x0 += 64 * U) {
+    int k[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int x = x0 + 64 * u + lane;
-      v[u] = x < b;
-      k[u] = v[u] ? ekey(e[x]) : 0;
+      k[u] = x < l ? ekey(e[x]) : -1;                       // -1 < every pivot
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      cL += __popcll(__ballot(v[u] && k[u] >= p));
-      cR += __popcll(__ballot(v[u] && k[u] <= p));
+    for (int u = 0; u < U; ++u) {
+      const bool isL = k[u] >= p;
+      const uint64_t m = __ballot(isL);
+      const int rk = Lc + mbcnt64(m);
+      if (isL && rk < cap) tL[rk] = static_cast<uint32_t>(x0 + 64 * u + lane);
+      Lc += __popcll(m);
     }
   }
-  int offL = 0, offR = 0, Lc = cL, Rc = cR;
-  if constexpr (BLOCK) {
-    if (lane == 0) { cnt[wid] = cL; cnt[NWAVE + wid] = cR; }
-    __syncthreads();
-    Lc = 0; Rc = 0;
-    for (int w = 0; w < nw; ++w) {
-      const int l_ = cnt[w], r_ = cnt[NWAVE + w];
-      if (w < wid) offL += l_;
-      if (w > wid) offR += r_;
-      Lc += l_; Rc += r_;
-    }
-  }
-  int runL = 0, runR = 0;
-  const uint64_t lt = lanemask_lt(lane);
-  for (int x0 = a; x0 < b; x0 += 256) {
-    int k[4];
-    bool v[4];
+  for (int x0 = l - 1; x0 > f && Rc < cap; x0 -= 64 * U) {
+    int k[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int x = x0 + 64 * u + lane;
-      v[u] = x < b;
-      k[u] = v[u] ? ekey(e[x]) : 0;
+    for (int u = 0; u < U; ++u) {
+      const int x = x0 - 64 * u - lane;
+      k[u] = x > f ? ekey(e[x]) : 0x7fffffff;               // above every pivot
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int x = x0 + 64 * u + lane;
-      const bool isL = v[u] && k[u] >= p, isR = v[u] && k[u] <= p;
-      const uint64_t mL = __ballot(isL), mR = __ballot(isR);
-      if (isL) {
-        const int rk = offL + runL + __popcll(mL & lt);
-        if (rk < cap) tL[rk] = static_cast<uint32_t>(x);
-      }
-      if (isR) {   // R is ordered by DEscending position
-        const int rk = offR + (cR - 1 - (runR + __popcll(mR & lt)));
-        if (rk < cap) tR[rk] = static_cast<uint32_t>(x);
-      }
-      runL += __popcll(mL);
-      runR += __popcll(mR);
+    for (int u = 0; u < U; ++u) {
+      const bool isR = k[u] <= p;
+      const uint64_t m = __ballot(isR);
+      const int rk = Rc + mbcnt64(m);                        // lane order == descending position
+      if (isR && rk < cap) tR[rk] = static_cast<uint32_t>(x0 - 64 * u - lane);
+      Rc += __popcll(m);
     }
   }
-  if constexpr (BLOCK) {
-    if (wid == 0 && lane == 0) cnt[2 * NWAVE] = 0;
-  }
-  group_sync<BLOCK>();
-
+  wave_sync();
   int npairs = Lc < Rc ? Lc : Rc;
   npairs = npairs < cap ? npairs : cap;
-  const int gtid = BLOCK ? wid * 64 + lane : lane;
-  const int gsize = BLOCK ? nw * 64 : 64;
-  int mine = 0;
-  for (int i = gtid; i < npairs; i += gsize) {
-    const uint32_t xl = tL[i], xr = tR[i];
-    if (xl < xr) {
-      const uint32_t t0 = e[xl];
-      e[xl] = e[xr];
-      e[xr] = t0;
-      ++mine;
+  int s = 0;
+  for (int i0 = 0; i0 < npairs; i0 += 64) {
+    const int i = i0 + lane;
+    bool sw = false;
+    if (i < npairs) {
+      const uint32_t xl = tL[i], xr = tR[i];
+      sw = xl < xr;
+      if (sw) {
+        const uint32_t t0 = e[xl];
+        e[xl] = e[xr];
+        e[xr] = t0;
+      }
     }
-  }
-  int s = wave_sum_i(mine);
-  if constexpr (BLOCK) {
-    if (lane == 0 && s) atomicAdd(&cnt[2 * NWAVE], s);
-    __syncthreads();
-    s = cnt[2 * NWAVE];
+    const int c = __popcll(__ballot(sw));
+    s += c;
+    if (c < 64) break;                                       // the swapping pairs are a prefix
   }
   const int lim = Lc < cap ? Lc : cap;
   const uint32_t c1 = s < lim ? tL[s] : 0x7fffffffu;
   const uint32_t c2 = s >= 1 ? tR[s - 1] : 0x7fffffffu;
-  const int cut = static_cast<int>(c1 < c2 ? c1 : c2);
-  group_sync<BLOCK>();
-  return cut;
+  wave_sync();
+  return static_cast<int>(c1 < c2 ? c1 : c2);
 }
 
 // Children of a partition: > kSeqMax elements -> next breadth-first level; 17..kSeqMax -> parked for the sequential
@@ -309,12 +326,12 @@ __device__ inline int seq_partition_pivot(uint32_t* e, int first, int last) {
   }
 }
 
-// std::__introsort_loop + the final insertion sort, restricted to one parked segment [f,l) (17..kSeqMax elements) and run by
-// ONE lane: small segments are latency chains, so a wave finishes 64 of them side by side instead of spending a whole
+// std::__introsort_loop restricted to one parked segment [f,l) (17..kSeqMax elements) and run by ONE lane (its cuts become leaf
+// boundaries, so the final insertion sort of its leaves happens in phase 2 with everybody else's): small segments are latency chains, so a wave finishes 64 of them side by side instead of spending a whole
 // ballot/scan round trip on each.  Explicit stack (packed first|last|depth, relative to f) in the segment's tmp slice:
 // it never holds more than min(depth, n-16) <= n entries.
-__device__ inline void seq_finish_segment(uint32_t* e, uint32_t* stack, int f, int l, int depth) {
-  // entries: bits 0..7 first, 8..15 last (last <= kSeqMax = 128 < 256), 16..31 depth budget
+__device__ inline void seq_finish_segment(uint32_t* e, uint32_t* stack, uint32_t* leafbits, int f, int l, int depth) {
+  // entries: bits 0..7 first, 8..15 last (last <= kSeqMax < 256), 16..31 depth budget
   int sp = 1;
   stack[0] = 0u | (static_cast<uint32_t>(l - f) << 8) | (static_cast<uint32_t>(depth) << 16);
   while (sp > 0) {
@@ -324,16 +341,10 @@ __device__ inline void seq_finish_segment(uint32_t* e, uint32_t* stack, int f, i
       if (d == 0) { heap_sort_segment(e, f + a, f + b); break; }
       --d;
       const int cut = seq_partition_pivot(e, f + a, f + b) - f;
+      atomicOr(&leafbits[(f + cut) >> 5], 1u << ((f + cut) & 31));   // its leaves are insertion-sorted with all the others (phase 2)
       stack[sp++] = static_cast<uint32_t>(cut) | (static_cast<uint32_t>(b) << 8) | (static_cast<uint32_t>(d) << 16);
       b = cut;
     }
-  }
-  for (int i = f + 1; i < l; ++i) {   // std::__final_insertion_sort == stable insertion sort of the nearly sorted range
-    const uint32_t v = e[i];
-    const int kv = ekey(v);
-    int j = i;
-    while (j > f && kv < ekey(e[j - 1])) { e[j] = e[j - 1]; --j; }
-    e[j] = v;
   }
 }
 
@@ -354,7 +365,7 @@ template <bool USE_LDS>
 __global__ __launch_bounds__(NT) void map_query_kernel(MapArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t dyn_smem[];
   __shared__ uint32_t sq[3][kMaxWords];     // query planes: sign, nz, label
-  __shared__ int scnt[2 * NWAVE + 4];
+  __shared__ int stask[2];                  // tasks of the level; chunks among them
   __shared__ int sqcount[2];
   __shared__ int swork[NWAVE + 2];
   __shared__ double sred[NWAVE];
@@ -493,7 +504,7 @@ __global__ __launch_bounds__(NT) void map_query_kernel(MapArgs A) {
     int depth = A.depth_limit >= 0 ? A.depth_limit : 2 * (31 - __clz(N));   // std::__lg(n) * 2
     uint32_t* qcur = S.qa;
     uint32_t* qnxt = S.qb;
-    int cur = 0;
+    int cur = 0, lvl = 0;
     if (tid == 0) {
       S.leafbits[0] = 1u;
     }
@@ -503,36 +514,183 @@ __global__ __launch_bounds__(NT) void map_query_kernel(MapArgs A) {
     while (true) {
       const int nseg = sqcount[cur];
       if (nseg == 0) break;
+      if (A.stamps && blockIdx.x == 0 && qi == 0 && tid == 0 && lvl < 28) {
+        A.stamps[8 + 2 * lvl] = __builtin_readcyclecounter();
+        A.stamps[9 + 2 * lvl] = static_cast<unsigned long long>(nseg);
+      }
+      ++lvl;
       if (depth == 0) {                                       // depth budget exhausted -> heapsort each segment
         for (int si = tid; si < nseg; si += NT) heap_sort_segment(e, static_cast<int>(qcur[2 * si]), static_cast<int>(qcur[2 * si + 1]));
         break;
       }
       --depth;
-      if (tid == 0) sqcount[cur ^ 1] = 0;
+      if (tid == 0) { sqcount[cur ^ 1] = 0; stask[0] = 0; stask[1] = 0; }      // tasks, chunks
       __syncthreads();
-      // big segments first, one at a time, by the whole workgroup (nseg is small whenever any exist)
-      for (int si = 0; si < nseg; ++si) {
+      // -- work list of the level: a segment of more than kChunk positions is cut into chunk tasks (its median moves to the front
+      //    here), a shorter one is one task.  Tasks go to the waves round-robin, so one long segment no longer holds a level up.
+      for (int si = tid; si < nseg; si += NT) {
         const int f = static_cast<int>(qcur[2 * si]), l = static_cast<int>(qcur[2 * si + 1]);
-        if (l - f < kCoopMin) continue;
-        const int cut = partition_segment<true>(S, f, l, lane, wid, NWAVE, scnt);
-        if (tid == 0) {
+        const int nc = (l - f - 1 > kChunk) ? (l - f - 2 + kChunk) / kChunk : 1;
+        const int base = atomicAdd(&stask[0], nc);
+        int cbase = 0;
+        if (nc > 1) { median_to_first(e, f, l); cbase = atomicAdd(&stask[1], nc); }
+        S.seginfo[si] = static_cast<uint32_t>(cbase) | (static_cast<uint32_t>(nc) << 16);
+        for (int j = 0; j < nc; ++j) S.task[base + j] = (static_cast<uint32_t>(si) << 11) | static_cast<uint32_t>(j);
+      }
+      __syncthreads();
+      if (A.stamps && blockIdx.x == 0 && qi == 0 && tid == 0 && lvl <= 16) A.stamps[64 + 8 * (lvl - 1) + 0] = __builtin_readcyclecounter();
+      const int ntask = stask[0];
+      const bool chunked = stask[1] != 0;
+      uint32_t* cntL = S.cnt;
+      uint32_t* cntR = S.cnt + S.ccap;
+      uint32_t* cntS = S.cnt + 2 * S.ccap;
+      // -- A: whole short segments; L / R counts of the chunks
+      for (int t = wid; t < ntask; t += NWAVE) {
+        const uint32_t tk = S.task[t];
+        const int si = static_cast<int>(tk >> 11), j = static_cast<int>(tk & 2047u);
+        const int f = static_cast<int>(qcur[2 * si]), l = static_cast<int>(qcur[2 * si + 1]);
+        const int n = l - f;
+        const uint32_t info = S.seginfo[si];
+        if ((info >> 16) == 1u) {
+          const int cut = n <= 65 ? partition_wave<1>(S, f, l, lane, depth) : n <= 129 ? partition_wave<2>(S, f, l, lane, depth) : partition_wave<4>(S, f, l, lane, depth);
+          if (lane == 0 && cut >= 0) {
+            atomicOr(&S.leafbits[cut >> 5], 1u << (cut & 31));
+            push_seg(S, qnxt, &sqcount[cur ^ 1], f, cut, depth);
+            push_seg(S, qnxt, &sqcount[cur ^ 1], cut, l, depth);
+          }
+        } else {
+          const int a = f + 1 + j * kChunk, b = a + kChunk < l ? a + kChunk : l;
+          const int p = ekey(e[f]);
+          int cL = 0, cR = 0;
+          for (int x0 = a; x0 < b; x0 += 256) {
+            int k[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int x = x0 + 64 * u + lane;
+              k[u] = x < b ? ekey(e[x]) : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              cL += __popcll(__ballot(k[u] >= p));
+              cR += __popcll(__ballot(k[u] >= 0 && k[u] <= p));
+            }
+          }
+          const int ci = static_cast<int>(info & 0xffffu) + j;
+          if (lane == 0) { cntL[ci] = static_cast<uint32_t>(cL); cntR[ci] = static_cast<uint32_t>(cR); }
+        }
+      }
+      if (chunked) {
+        __syncthreads();
+        if (A.stamps && blockIdx.x == 0 && qi == 0 && tid == 0 && lvl <= 16) A.stamps[64 + 8 * (lvl - 1) + 1] = __builtin_readcyclecounter();
+        // -- B: the chunks' positions go to the lists (L ascending from the chunks before, R descending from the chunks after)
+        for (int t = wid; t < ntask; t += NWAVE) {
+          const uint32_t tk = S.task[t];
+          const int si = static_cast<int>(tk >> 11), j = static_cast<int>(tk & 2047u);
+          const uint32_t info = S.seginfo[si];
+          const int nc = static_cast<int>(info >> 16), base = static_cast<int>(info & 0xffffu);
+          if (nc == 1) continue;
+          const int f = static_cast<int>(qcur[2 * si]), l = static_cast<int>(qcur[2 * si + 1]);
+          const int cap = (l - f) / 2 + 1;
+          int before = 0, after = 0;
+          for (int j0 = 0; j0 < nc; j0 += 64) {
+            const int jj = j0 + lane;
+            if (jj < j) before += static_cast<int>(cntL[base + jj]);
+            if (jj > j && jj < nc) after += static_cast<int>(cntR[base + jj]);
+          }
+          const int offL = wave_sum_i(before), offR = wave_sum_i(after);
+          const int ownR = static_cast<int>(cntR[base + j]);
+          uint32_t* tL = S.tmp + tmp_base(f);
+          uint32_t* tR = tL + cap;
+          const int a = f + 1 + j * kChunk, b = a + kChunk < l ? a + kChunk : l;
+          const int p = ekey(e[f]);
+          int runL = offL, runR = offR + ownR - 1;
+          for (int x0 = a; x0 < b; x0 += 256) {
+            int k[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int x = x0 + 64 * u + lane;
+              k[u] = x < b ? ekey(e[x]) : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int x = x0 + 64 * u + lane;
+              const bool isL = k[u] >= p, isR = k[u] >= 0 && k[u] <= p;
+              const uint64_t mL = __ballot(isL), mR = __ballot(isR);
+              const int rl = runL + mbcnt64(mL), rr = runR - mbcnt64(mR);
+              if (isL && rl < cap) tL[rl] = static_cast<uint32_t>(x);
+              if (isR && rr < cap) tR[rr] = static_cast<uint32_t>(x);
+              runL += __popcll(mL);
+              runR -= __popcll(mR);
+            }
+          }
+        }
+        __syncthreads();
+        if (A.stamps && blockIdx.x == 0 && qi == 0 && tid == 0 && lvl <= 16) A.stamps[64 + 8 * (lvl - 1) + 2] = __builtin_readcyclecounter();
+        // -- C: the pairs, cut into as many pieces as the segment has chunks
+        for (int t = wid; t < ntask; t += NWAVE) {
+          const uint32_t tk = S.task[t];
+          const int si = static_cast<int>(tk >> 11), j = static_cast<int>(tk & 2047u);
+          const uint32_t info = S.seginfo[si];
+          const int nc = static_cast<int>(info >> 16), base = static_cast<int>(info & 0xffffu);
+          if (nc == 1) continue;
+          const int f = static_cast<int>(qcur[2 * si]), l = static_cast<int>(qcur[2 * si + 1]);
+          const int cap = (l - f) / 2 + 1;
+          int sl = 0, sr = 0;
+          for (int j0 = 0; j0 < nc; j0 += 64) {
+            const int jj = j0 + lane;
+            if (jj < nc) { sl += static_cast<int>(cntL[base + jj]); sr += static_cast<int>(cntR[base + jj]); }
+          }
+          const int Lc = wave_sum_i(sl), Rc = wave_sum_i(sr);
+          int npairs = Lc < Rc ? Lc : Rc;
+          npairs = npairs < cap ? npairs : cap;
+          const int piece = (((cap + nc - 1) / nc) + 63) & ~63;
+          const int i0 = j * piece, i1 = i0 + piece < npairs ? i0 + piece : npairs;
+          const uint32_t* tL = S.tmp + tmp_base(f);
+          const uint32_t* tR = tL + cap;
+          int sw = 0;
+          for (int ib = i0; ib < i1; ib += 64) {
+            const int i = ib + lane;
+            bool did = false;
+            if (i < i1) {
+              const uint32_t xl = tL[i], xr = tR[i];
+              did = xl < xr;
+              if (did) {
+                const uint32_t t0 = e[xl];
+                e[xl] = e[xr];
+                e[xr] = t0;
+              }
+            }
+            const int c = __popcll(__ballot(did));
+            sw += c;
+            if (c < 64) break;                                 // the swapping pairs are a prefix
+          }
+          if (lane == 0) cntS[base + j] = static_cast<uint32_t>(sw);
+        }
+        __syncthreads();
+        if (A.stamps && blockIdx.x == 0 && qi == 0 && tid == 0 && lvl <= 16) A.stamps[64 + 8 * (lvl - 1) + 3] = __builtin_readcyclecounter();
+        // -- D: cut and children of the chunked segments
+        for (int si = tid; si < nseg; si += NT) {
+          const uint32_t info = S.seginfo[si];
+          const int nc = static_cast<int>(info >> 16), base = static_cast<int>(info & 0xffffu);
+          if (nc == 1) continue;
+          const int f = static_cast<int>(qcur[2 * si]), l = static_cast<int>(qcur[2 * si + 1]);
+          const int cap = (l - f) / 2 + 1;
+          int sw = 0, Lc = 0;
+          for (int j = 0; j < nc; ++j) { sw += static_cast<int>(cntS[base + j]); Lc += static_cast<int>(cntL[base + j]); }
+          const uint32_t* tL = S.tmp + tmp_base(f);
+          const uint32_t* tR = tL + cap;
+          const int lim = Lc < cap ? Lc : cap;
+          const uint32_t c1 = sw < lim ? tL[sw] : 0x7fffffffu;
+          const uint32_t c2 = sw >= 1 ? tR[sw - 1] : 0x7fffffffu;
+          const int cut = static_cast<int>(c1 < c2 ? c1 : c2);
           atomicOr(&S.leafbits[cut >> 5], 1u << (cut & 31));
           push_seg(S, qnxt, &sqcount[cur ^ 1], f, cut, depth);
           push_seg(S, qnxt, &sqcount[cur ^ 1], cut, l, depth);
         }
       }
-      // the rest: one wave per segment
-      for (int si = wid; si < nseg; si += NWAVE) {
-        const int f = static_cast<int>(qcur[2 * si]), l = static_cast<int>(qcur[2 * si + 1]);
-        if (l - f >= kCoopMin) continue;
-        const int cut = partition_segment<false>(S, f, l, lane, 0, 1, nullptr);
-        if (lane == 0) {
-          atomicOr(&S.leafbits[cut >> 5], 1u << (cut & 31));
-          push_seg(S, qnxt, &sqcount[cur ^ 1], f, cut, depth);
-          push_seg(S, qnxt, &sqcount[cur ^ 1], cut, l, depth);
-        }
-      }
       __syncthreads();
+      if (A.stamps && blockIdx.x == 0 && qi == 0 && tid == 0 && lvl <= 16) A.stamps[64 + 8 * (lvl - 1) + 4] = __builtin_readcyclecounter();
+      if (A.stamps && blockIdx.x == 0 && qi == 0 && tid == 0 && lvl <= 16) { A.stamps[64 + 8 * (lvl - 1) + 5] = ntask; A.stamps[64 + 8 * (lvl - 1) + 6] = stask[1]; }
       uint32_t* t = qcur; qcur = qnxt; qnxt = t;
       cur ^= 1;
     }
@@ -547,30 +705,53 @@ __global__ __launch_bounds__(NT) void map_query_kernel(MapArgs A) {
         bitsw &= bitsw - 1;
         uint32_t* slot = S.tmp + tmp_base(f);
         const int l = static_cast<int>(slot[0]), d = static_cast<int>(slot[1]);
-        seq_finish_segment(e, slot, f, l, d);
+        seq_finish_segment(e, slot, S.leafbits, f, l, d);
       }
     }
     __syncthreads();
 
     if (A.stamps && blockIdx.x == 0 && qi == 0 && tid == 0) A.stamps[3] = __builtin_readcyclecounter();
     // ---- phase 2: final insertion sort == stable sort of each <=16-element leaf ---------------------------
-    for (int wi = tid; wi < bw; wi += NT) {
-      uint32_t bitsw = S.leafbits[wi];
-      while (bitsw) {
-        const int bpos = __ffs(bitsw) - 1;
-        bitsw &= bitsw - 1;
-        const int s0 = wi * 32 + bpos;
-        int e1 = -1;                                          // next segment start within 16 positions
-        for (int x = s0 + 1; x <= s0 + kLeaf && x <= N; ++x) {
-          if (x == N || ((S.leafbits[x >> 5] >> (x & 31)) & 1u)) { e1 = x; break; }
+    // One thread per 16 positions; a leaf that starts there is loaded into registers (padded with keys above every real one) and
+    // sorted by the insertion sort's own compare-exchange sequence on adjacent elements (a strict '<' swaps, so equal keys keep
+    // their order): no dependent LDS round trips, and a wave whose leaves are all in order already skips the network.
+    for (int hw = tid; hw < 2 * bw; hw += NT) {
+      const uint32_t w0 = S.leafbits[hw >> 1];
+      const uint32_t w1 = (hw >> 1) + 1 < bw ? S.leafbits[(hw >> 1) + 1] : 0u;
+      const uint64_t both = static_cast<uint64_t>(w0) | (static_cast<uint64_t>(w1) << 32);
+      uint32_t starts = (w0 >> (16 * (hw & 1))) & 0xffffu;
+      while (__ballot(starts != 0)) {                            // wave-uniform trip count: the ballots below need every lane
+        int s0 = 0, n = 0;
+        if (starts) {
+          const int bpos = 16 * (hw & 1) + __ffs(starts) - 1;
+          starts &= starts - 1;
+          s0 = (hw >> 1) * 32 + bpos;
+          const uint64_t rest = bpos == 63 ? 0ull : both >> (bpos + 1);
+          int d = rest ? __ffsll(static_cast<long long>(rest)) : 1 << 20;      // distance to the next segment start
+          d = s0 + d > N ? N - s0 : d;
+          n = d <= kLeaf ? d : 0;                                  // longer: heap-sorted or an all-equal run, in its final order already
         }
-        if (e1 < 0) continue;                                 // longer than a leaf: heap-sorted, already in order
-        for (int i = s0 + 1; i < e1; ++i) {                   // std::__insertion_sort (stable)
-          const uint32_t v = e[i];
-          const int kv = ekey(v);
-          int j = i;
-          while (j > s0 && kv < ekey(e[j - 1])) { e[j] = e[j - 1]; --j; }
-          e[j] = v;
+        uint32_t v[kLeaf];
+#pragma unroll
+        for (int i = 0; i < kLeaf; ++i) v[i] = i < n ? e[s0 + i] : 0xffffffffu;
+        bool unsorted = false;
+#pragma unroll
+        for (int i = 1; i < kLeaf; ++i) unsorted |= (v[i] >> kIdxBits) < (v[i - 1] >> kIdxBits);
+        if (__ballot(unsorted) == 0) continue;
+#pragma unroll
+        for (int i = 1; i < kLeaf; ++i) {
+#pragma unroll
+          for (int j = i; j >= 1; --j) {
+            const uint32_t lo = v[j - 1], hi = v[j];
+            const bool sw = (hi | kIdxMask) < (lo & ~kIdxMask);       // key(hi) < key(lo)
+            v[j - 1] = sw ? hi : lo;
+            v[j] = sw ? lo : hi;
+          }
+        }
+        if (unsorted) {
+#pragma unroll
+          for (int i = 0; i < kLeaf; ++i)
+            if (i < n) e[s0 + i] = v[i];
         }
       }
     }
@@ -764,7 +945,7 @@ extern "C" int cmh_calc_neighbor(const uint32_t* la, const uint32_t* lb, int32_t
 extern "C" size_t cmh_map_workspace_bytes(int32_t Q, int64_t N, int32_t bits, int32_t tie_order) {
   (void)bits; (void)tie_order;
   if (Q <= 0 || N <= 0) return 0;
-  if (lds_bytes_needed(N) <= kLdsBudget) return 256;
+  if (lds_bytes_needed(N) <= kLdsBudget) return 4096;   // LDS mode: only the optional diagnostics stamps live here
   return static_cast<size_t>(map_slots(Q)) * store_words(N) * 4 + 256;
 }
 

@@ -88,6 +88,26 @@ def test_heapsort_fallback_matches_libstdcpp(depth):
         assert np.array_equal(perm[i], ref), (depth, i)
 
 
+@pytest.mark.parametrize("K,N,depth", [(8, 6000, -1), (16, 9000, -1), (8, 5000, 7), (8, 5000, 11), (4, 2500, -1), (32, 20000, -1)])
+def test_long_runs_of_equal_keys(K, N, depth):
+    """Few key values -> runs of hundreds of equal keys: the all-equal subtrees are applied as one closed-form permutation
+    (csrc/hamming_map.hip::all_equal_shortcut), with a depth budget that sometimes forbids it; N = 20000 takes the
+    workspace (non-LDS) path."""
+    rng = np.random.default_rng(K * 1000 + N + depth)
+    Q, C = 5, 6
+    qB = np.where(rng.random((Q, K)) < 0.5, -1.0, 1.0).astype(np.float32)
+    rB = np.where(rng.random((N, K)) < 0.5, -1.0, 1.0).astype(np.float32)
+    rB[: N // 3] = rB[0]                                   # one third of the database shares a code
+    qL = np.ones((Q, C), np.float32)
+    rL = (rng.random((N, C)) < 0.3).astype(np.float32)
+    _, _, perm = _gpu_map(qB, rB, qL, rL, want_perm=True, depth_limit=depth)
+    perm = perm.cpu().numpy()
+    for i in range(Q):
+        keys = oracle.hamming_row(qB[i], rB)
+        ref = oracle.sort_perm_depth(keys, depth) if depth >= 0 else oracle.sort_perm(keys)
+        assert np.array_equal(perm[i], ref), (K, N, depth, i)
+
+
 def test_size_independent_properties_at_full_size():
     """NUS-WIDE scale (N=190 834, 128-bit): ranking is a permutation, keys are sorted, AP in [0,1], identical
     queries give identical APs, and a query that equals a relevant DB code ranks a relevant item first."""

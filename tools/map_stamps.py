@@ -17,8 +17,20 @@ torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); N.hamming_map(qp, ql, rp, rl, K, C); e1.record(); torch.cuda.synchronize()
 ws = N.workspace(0, dev, "map")
-st = ws[:64].view(torch.int64).cpu().numpy()[:6]
+full = ws[:3072].view(torch.int64).cpu().numpy()
+st = full[:6]
 d = [int(st[i + 1] - st[i]) for i in range(5)]
 print("one direction: %.3f ms; query 0 of workgroup 0, cycles per phase (100 MHz ticks?):" % e0.elapsed_time(e1))
 for name, v in zip(["keys", "bfs", "parked-seq", "leaf", "ap"], d):
     print(f"  {name:10s} {v:10d}")
+lv = [(int(full[8 + 2 * i]), int(full[9 + 2 * i])) for i in range(28) if full[8 + 2 * i] and full[9 + 2 * i] < 100000]
+for i, (t, n) in enumerate(lv):
+    nxt = lv[i + 1][0] if i + 1 < len(lv) else int(st[2])
+    print(f"  level {i:2d}: {n:5d} segments {nxt - t:9d} cycles")
+for i in range(min(len(lv), 16)):
+    b = full[64 + 8 * i: 72 + 8 * i]
+    t0 = lv[i][0]
+    if b[1]:
+        print(f"  level {i:2d}: tasks {int(b[5]):4d} chunks {int(b[6]):3d}  build {int(b[0]-t0):6d}  A {int(b[1]-b[0]):6d}  B {int(b[2]-b[1]):6d}  C {int(b[3]-b[2]):6d}  D {int(b[4]-b[3]):6d}")
+    else:
+        print(f"  level {i:2d}: tasks {int(b[5]):4d} chunks {int(b[6]):3d}  build {int(b[0]-t0):6d}  A {int(b[4]-b[0]):6d}")
