@@ -37,7 +37,7 @@ constexpr int NWAVE = NT / 64;
 constexpr int kIdxBits = 19;       // N < 2^19 = 524288
 constexpr uint32_t kIdxMask = (1u << kIdxBits) - 1;
 constexpr int kMaxWords = 64;      // K <= 2048 bits
-constexpr int kChunk = 512;        // a longer segment is partitioned in chunks of this many positions, one wave per chunk
+constexpr int kChunk = 1024;       // a longer segment is partitioned in chunks of this many positions, one wave per chunk
 constexpr int kLeaf = 16;          // libstdc++ _S_threshold
 constexpr int kSeqMax = 32;        // segments of 17..kSeqMax elements are finished sequentially, one lane each
 
@@ -365,7 +365,7 @@ template <bool USE_LDS>
 __global__ __launch_bounds__(NT) void map_query_kernel(MapArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t dyn_smem[];
   __shared__ uint32_t sq[3][kMaxWords];     // query planes: sign, nz, label
-  __shared__ int stask[2];                  // tasks of the level; chunks among them
+  __shared__ int stask[3];                  // tasks of the level; chunks among them; the next task to hand out
   __shared__ int sqcount[2];
   __shared__ int swork[NWAVE + 2];
   __shared__ double sred[NWAVE];
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(NT) void map_query_kernel(MapArgs A) {
         break;
       }
       --depth;
-      if (tid == 0) { sqcount[cur ^ 1] = 0; stask[0] = 0; stask[1] = 0; }      // tasks, chunks
+      if (tid == 0) { sqcount[cur ^ 1] = 0; stask[0] = 0; stask[1] = 0; stask[2] = 0; }      // tasks, chunks, next task
       __syncthreads();
       // -- work list of the level: a segment of more than kChunk positions is cut into chunk tasks (its median moves to the front
       //    here), a shorter one is one task.  Tasks go to the waves round-robin, so one long segment no longer holds a level up.
@@ -545,7 +545,13 @@ __global__ __launch_bounds__(NT) void map_query_kernel(MapArgs A) {
       uint32_t* cntR = S.cnt + S.ccap;
       uint32_t* cntS = S.cnt + 2 * S.ccap;
       // -- A: whole short segments; L / R counts of the chunks
-      for (int t = wid; t < ntask; t += NWAVE) {
+      int guard = 0;
+      while (true) {                                            // tasks differ in length (33..kChunk+1 positions): first come, first served
+        int t = 0;
+        if (lane == 0) t = atomicAdd(&stask[2], 1);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t >= ntask) break;
+        if (++guard > ntask) break;                            // a wave can never be handed more tasks than exist: bounds the loop whatever happens
         const uint32_t tk = S.task[t];
         const int si = static_cast<int>(tk >> 11), j = static_cast<int>(tk & 2047u);
         const int f = static_cast<int>(qcur[2 * si]), l = static_cast<int>(qcur[2 * si + 1]);
