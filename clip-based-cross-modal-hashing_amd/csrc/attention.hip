@@ -184,7 +184,8 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const bf16_t* __rest
                                                             const int32_t* __restrict__ seq_off, float o8_inv_scale) {
   constexpr int NKS = NKT / 2;
   constexpr int TP = NKT * 16;
-  constexpr int VST = 66;   // LDS row stride in bf16 elements (132 B): the 4 lane groups land on different banks
+  constexpr int VST = 80;   // LDS row stride in bf16 elements (160 B = 40 dwords): 16-byte rows for the b128 stores, and the eight
+                            // key rows one 32-lane half touches in a transposed read start on banks 0,40,16,56,32,8,48,24
   __shared__ __attribute__((aligned(16))) bf16_t sV[TP * VST];
 
   const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
@@ -200,8 +201,7 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const bf16_t* __rest
     const int row = slot >> 3, ch = slot & 7;
     uint4 v = uint4{0u, 0u, 0u, 0u};
     if (row < Tn) v = *reinterpret_cast<const uint4*>(base + static_cast<size_t>(row) * ld + 2 * d + ch * 8);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(&sV[row * VST + ch * 8]);
-    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    *reinterpret_cast<uint4*>(&sV[row * VST + ch * 8]) = v;
   }
   // K fragments: A operand rows = keys
   abf16x8_t kf[NKT][2];
@@ -213,7 +213,9 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const bf16_t* __rest
     for (int s = 0; s < 2; ++s)
       kf[kt][s] = *reinterpret_cast<const abf16x8_t*>(base + static_cast<size_t>(row) * ld + d + s * 32 + g * 8);
   }
-  // which of this lane's keys (kt, r) -> key = 16kt + 4g + r are usable at all
+  // which of this lane's keys (kt, r) -> key = 16kt + 4g + r are usable at all (inside the sequence, not padded), and per key tile
+  // whether ALL / NONE of its 16 keys are (wave-uniform): only a mixed tile pays for per-score selects.  The causal mask only ever
+  // cuts the diagonal tile, where it is the same for every query tile: key <= query <=> 4g + r <= c.
   uint32_t keyok = 0;
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt)
@@ -224,21 +226,45 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const bf16_t* __rest
       if (ok && kpm) ok = kpm[srow + key] == 0;
       keyok |= (ok ? 1u : 0u) << (kt * 4 + r);
     }
+  uint32_t tile_all = 0, tile_none = 0;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    const uint32_t bits = (keyok >> (kt * 4)) & 15u;
+    if (__ballot(bits != 15u) == 0) tile_all |= 1u << kt;
+    if (__ballot(bits != 0u) == 0) tile_none |= 1u << kt;
+  }
+  uint32_t diagok = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) diagok |= (4 * g + r <= c ? 1u : 0u) << r;
   __syncthreads();
-  // V^T fragments: A operand rows = head-dim, k = keys in the permuted order
+  // V^T fragments: A operand rows = head-dim, k = keys in the permuted order.  ds_read_b64_tr_b16 hands lane c of a 16-lane group
+  // column c of a 4-key x 16-column block: lane 4q+p supplies the address of key row r0+q, columns 4p..4p+3; two reads (keys
+  // 32s+4g.. and 32s+16+4g..) make one fragment - 2 reads instead of 8 ds_read_u16 + packing.
   abf16x8_t vf[NKS][4];
+  {
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const uint32_t a0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lptr_t)sV)) +
+                        static_cast<uint32_t>(((4 * g + (c >> 2)) * VST + 4 * (c & 3)) * 2);
+    uint2 raw[NKS][4][2];
 #pragma unroll
-  for (int s = 0; s < NKS; ++s)
+    for (int s = 0; s < NKS; ++s)
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      abf16x8_t t;
+      for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int key = 32 * s + 16 * (j >> 2) + 4 * g + (j & 3);
-        t[j] = __builtin_bit_cast(__bf16, sV[key * VST + 16 * dt + c]);
-      }
-      vf[s][dt] = t;
+        for (int hh = 0; hh < 2; ++hh)
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2"
+                       : "=v"(raw[s][dt][hh])
+                       : "v"(a0), "i"((32 * s + 16 * hh) * VST * 2 + 32 * dt));
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(raw[s][0][0]), "+v"(raw[s][0][1]), "+v"(raw[s][1][0]), "+v"(raw[s][1][1]), "+v"(raw[s][2][0]),
+                     "+v"(raw[s][2][1]), "+v"(raw[s][3][0]), "+v"(raw[s][3][1]));
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        vf[s][dt] = __builtin_bit_cast(abf16x8_t, uint4{raw[s][dt][0].x, raw[s][dt][0].y, raw[s][dt][1].x, raw[s][dt][1].y});
     }
+  }
 
   const int nqt = (Tn + 15) >> 4;
   // the NEXT query tile's fragments are fetched while the current tile computes (8 more registers): loaded at the top of its
@@ -255,25 +281,28 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const bf16_t* __rest
     const int qrow = qt * 16 + c;
     abf16x8_t qf[2] = {qn[0], qn[1]};
     load_q(qt + 1, qn);        // rows are clamped to the sequence: the read past the last tile stays in bounds and is never used
+    // raw scores (the 1/sqrt(64) scale is folded into the exponent below): the softmax costs one add + one max, then sub, mul,
+    // v_exp, add per score - it is VALU issue, not the matrix pipe, that three waves per SIMD queue for in this kernel
     af32x4_t sc[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      sc[kt] = af32x4_t{0.f, 0.f, 0.f, 0.f};
-      if (!causal || kt <= qt) {
+      if ((causal && kt > qt) || ((tile_none >> kt) & 1u)) {
+        sc[kt] = af32x4_t{-1e30f, -1e30f, -1e30f, -1e30f};
+      } else {
+        sc[kt] = af32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 2; ++s) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][s], qf[s], sc[kt], 0, 0, 0);
+        uint32_t okb = (keyok >> (kt * 4)) & 15u;
+        if (causal && kt == qt) okb &= diagok;
+        if (!((tile_all >> kt) & 1u) || (causal && kt == qt)) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sc[kt][r] = ((okb >> r) & 1u) ? sc[kt][r] : -1e30f;
+        }
       }
     }
     float m = -1e30f;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + 4 * g + r;
-        const bool ok = ((keyok >> (kt * 4 + r)) & 1u) && (!causal || key <= qrow);
-        sc[kt][r] = ok ? sc[kt][r] * 0.125f : -1e30f;
-        m = fmaxf(m, sc[kt][r]);
-      }
+    for (int kt = 0; kt < NKT; ++kt) m = fmaxf(fmaxf(m, fmaxf(sc[kt][0], sc[kt][1])), fmaxf(sc[kt][2], sc[kt][3]));
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     float l = 0.f;
@@ -281,12 +310,13 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const bf16_t* __rest
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = sc[kt][r] > -1e29f ? __expf(sc[kt][r] - m) : 0.f;
+        const float p = __builtin_amdgcn_exp2f((sc[kt][r] - m) * 0.18033688011112042f);   // exp((s - m) / 8): masked scores give 0
         sc[kt][r] = p;
         l += p;
       }
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
+    l = m > -1e29f ? l : 0.f;                                   // every key masked: no row to normalise (as before: 0 / 0)
     af32x4_t oc[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) oc[dt] = af32x4_t{0.f, 0.f, 0.f, 0.f};

@@ -46,7 +46,7 @@ __device__ __forceinline__ int w_swz(int row, int chunk) { return row * wRowByte
 // x * sigmoid(1.702 x) with v_exp + v_rcp (1 ulp) instead of an IEEE division (~10 VALU ops): the epilogue applies it to
 // 80 accumulators per lane while the matrix pipe idles.
 __device__ __forceinline__ float w_quick_gelu(float v) {
-  return v * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v));
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * v));   // exp(-1.702 v) = 2^(-1.702 log2(e) v): one multiply
 }
 
 typedef const __attribute__((address_space(1))) void* w_gptr_t;
