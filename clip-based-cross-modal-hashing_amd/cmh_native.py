@@ -94,6 +94,7 @@ SIGNATURES = {
     "cmh_layernorm": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _p]),
     "cmh_attention": (C.c_int, [_i32, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "cmh_gemm_tuning": (C.c_int, [_i32, _i32]),
+    "cmh_set_pooled_tail": (C.c_int, [_i32]),
     "cmh_qmi_workspace_bytes": (_sz, [_i32]),
     "cmh_qmi_loss": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _f, _p, _p, _p, _sz, _p]),
     "cmh_qmi_loss_backward": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _f, _p, _p, _p, _p, _p, _sz, _p]),
@@ -319,6 +320,11 @@ def linear_gemm_fp8(x8, w8, colscale, alpha, bias=None, residual=None, quickgelu
     check(lib().cmh_linear_gemm_fp8(ptr(x8), ptr(w8), ptr(f32c(colscale)), float(alpha), ptr(None if bias is None else f32c(bias)),
                                     ptr(residual), ptr(o), float(out_scale), M, Nn, K, epi, stream_ptr(x8.device)), "cmh_linear_gemm_fp8")
     return o
+
+
+def set_pooled_tail(on: bool):
+    """Carry only the pooled rows through the last block of encode_image / encode_text (default on; include/cmh.h)."""
+    check(lib().cmh_set_pooled_tail(1 if on else 0), "cmh_set_pooled_tail")
 
 
 def gemm_tuning(tile_rows: int = -1, order_group: int = -1):

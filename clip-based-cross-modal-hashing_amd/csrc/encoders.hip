@@ -131,6 +131,54 @@ static int run_block(const cmh_block_weights& w, int dt, const TowerBufs& t, int
   return CMH_OK;
 }
 
+// The LAST block when only the pooled feature is wanted (encode_image / encode_text, model/base/model.py:247-250, 366-370): after its
+// attention nothing mixes rows any more - out_proj, ln_2, the MLP, ln_post / ln_final and the projection are all row-wise - so only the
+// B pooled rows (class token / EOT) are carried through them: three GEMMs of M = B instead of M = B*T.  Every kept row sees the
+// arithmetic of the full-size path (same kernels, same K order), so the features are bit-identical.  The compact rows live in the qkv
+// scratch, which is dead once the attention has run; *x_pooled [B, d] is the block's output (residual-stream type).
+static int g_pooled_tail = -1;   // -1: from the environment (default on)
+static bool pooled_tail_enabled() {
+  static const bool env_on = []() { const char* e = getenv("CMH_POOLED_TAIL"); return !(e && !strcmp(e, "0")); }();
+  return g_pooled_tail < 0 ? env_on : g_pooled_tail != 0;
+}
+
+static int run_block_pooled(const cmh_block_weights& w, int dtb, const TowerBufs& t, int B, int T, int d, int causal,
+                            const uint8_t* kpm, hipStream_t st, int M, const int32_t* seq_off, void** x_pooled) {
+  const int dt = dtb == CMH_FP8 ? CMH_BF16 : dtb;
+  const size_t e = dt == CMH_BF16 ? 2 : 4, xe = t.xh ? 2 : 4;
+  const int obf = dt == CMH_BF16 ? EPI_OUT_BF16 : 0;
+  const int rx = EPI_BIAS | EPI_RESIDUAL | (t.xh ? EPI_RES_F16 | EPI_OUT_F16 : 0);
+  const float* a = w.act_scale;
+  char* scratch = static_cast<char*>(t.qkv);
+  float* xp = reinterpret_cast<float*>(scratch);
+  void* hp = scratch + align_up(static_cast<size_t>(B) * d * 4, 256);
+  int rc;
+  if (dtb == CMH_FP8) {
+    CMH_CHECK_ARG(t.xh && w.in_proj_cs && w.out_proj_cs && w.fc_cs && w.proj_cs && a[0] > 0.f && a[1] > 0.f && a[2] > 0.f && a[3] > 0.f,
+                  "fp8 mode: scales missing (run the calibration pass)");
+    if ((rc = launch_layernorm_q(t.x, w.ln1_w, w.ln1_b, t.h, 1.0f / a[0], M, d, st))) return rc;
+    if ((rc = launch_gemm_fp8(t.h, w.in_proj_w, w.in_proj_cs, a[0], w.in_proj_b, nullptr, t.qkv, 1.f, M, 3 * d, d, EPI_BIAS | EPI_OUT_BF16, st))) return rc;
+    if ((rc = launch_attention_varlen(t.qkv, t.h, CMH_BF16, B, T, d, causal, kpm, seq_off, st, 1.0f / a[1]))) return rc;
+    if ((rc = launch_gather_rows2(t.x, xp, static_cast<int>(d * xe), t.h, hp, d, t.rows, B, st))) return rc;
+    if ((rc = launch_gemm_fp8(hp, w.out_proj_w, w.out_proj_cs, a[1], w.out_proj_b, xp, xp, 1.f, B, d, d, rx, st))) return rc;
+    if ((rc = launch_layernorm_q(xp, w.ln2_w, w.ln2_b, hp, 1.0f / a[2], B, d, st))) return rc;
+    if ((rc = launch_gemm_fp8(hp, w.fc_w, w.fc_cs, a[2], w.fc_b, nullptr, t.mlp, 1.0f / a[3], B, 4 * d, d,
+                              EPI_BIAS | EPI_QUICKGELU | EPI_OUT_FP8, st))) return rc;
+    if ((rc = launch_gemm_fp8(t.mlp, w.proj_w, w.proj_cs, a[3], w.proj_b, xp, xp, 1.f, B, d, 4 * d, rx, st))) return rc;
+  } else {
+    if ((rc = launch_layernorm_x(t.x, t.xh, nullptr, w.ln1_w, w.ln1_b, t.h, dt == CMH_BF16, M, d, st))) return rc;
+    if ((rc = launch_gemm(dt, t.h, w.in_proj_w, w.in_proj_b, nullptr, t.qkv, M, 3 * d, d, EPI_BIAS | obf, st))) return rc;
+    if ((rc = launch_attention_varlen(t.qkv, t.h, dt, B, T, d, causal, kpm, seq_off, st))) return rc;
+    if ((rc = launch_gather_rows2(t.x, xp, static_cast<int>(d * xe), t.h, hp, static_cast<int>(d * e), t.rows, B, st))) return rc;
+    if ((rc = launch_gemm(dt, hp, w.out_proj_w, w.out_proj_b, xp, xp, B, d, d, rx, st))) return rc;
+    if ((rc = launch_layernorm_x(xp, t.xh, nullptr, w.ln2_w, w.ln2_b, hp, dt == CMH_BF16, B, d, st))) return rc;
+    if ((rc = launch_gemm(dt, hp, w.fc_w, w.fc_b, nullptr, t.mlp, B, 4 * d, d, EPI_BIAS | EPI_QUICKGELU | obf, st))) return rc;
+    if ((rc = launch_gemm(dt, t.mlp, w.proj_w, w.proj_b, xp, xp, B, d, 4 * d, rx, st))) return rc;
+  }
+  *x_pooled = xp;
+  return CMH_OK;
+}
+
 static int final_projection(int dt, const void* pool, const void* w_t, float* feat, int B, int embed, int d,
                             hipStream_t st) {
   const int bk = dt == CMH_F32 ? 32 : 64;
@@ -159,6 +207,7 @@ static int check_tower(int dt, int width, int layers, int embed, const cmh_block
 using namespace cmh;
 
 extern "C" const char* cmh_last_error(void) { return err_buf(); }
+extern "C" int cmh_set_pooled_tail(int32_t on) { g_pooled_tail = on ? 1 : 0; return CMH_OK; }
 extern "C" int cmh_version(void) { return CMH_VERSION; }
 
 extern "C" size_t cmh_vit_workspace_bytes(const cmh_vit_weights* w, int32_t batch) {
@@ -201,7 +250,14 @@ static int vit_encode_impl(const cmh_vit_weights* w, const float* image, int32_t
   if ((rc = launch_vit_assemble_lnpre(patch_out, w->class_embedding, w->positional_embedding, w->ln_pre_w,
                                       w->ln_pre_b, t.x, t.xh, B, g2, d, st))) return rc;
   if ((rc = tap(taps, 0, t.x, static_cast<size_t>(M) * d * 4, st))) return rc;
+  const bool tail = feat && !tokens_out && !taps && !amax && w->layers > 0 && pooled_tail_enabled();
+  void* x_pooled = nullptr;
+  if (tail && (rc = launch_iota_rows(t.rows, B, T, st))) return rc;
   for (int i = 0; i < w->layers; ++i) {
+    if (tail && i == w->layers - 1) {
+      if ((rc = run_block_pooled(w->blocks[i], dtb, t, B, T, d, /*causal=*/0, nullptr, st, M, nullptr, &x_pooled))) return rc;
+      break;
+    }
     if ((rc = run_block(w->blocks[i], dtb, t, B, T, d, /*causal=*/0, nullptr, st, -1, nullptr, amax ? amax + 4 * i : nullptr))) return rc;
     if ((rc = tap(taps, 1 + i, t.x, static_cast<size_t>(M) * d * 4, st))) return rc;
   }
@@ -212,8 +268,12 @@ static int vit_encode_impl(const cmh_vit_weights* w, const float* image, int32_t
   }
   if (feat) {
     // ln_post on the class token, @ proj  (:247-250)
-    if ((rc = launch_iota_rows(t.rows, B, T, st))) return rc;
-    if ((rc = launch_layernorm_x(t.x, t.xh, t.rows, w->ln_post_w, w->ln_post_b, t.pool, dt == CMH_BF16, B, d, st))) return rc;
+    if (x_pooled) {
+      if ((rc = launch_layernorm_x(x_pooled, t.xh, nullptr, w->ln_post_w, w->ln_post_b, t.pool, dt == CMH_BF16, B, d, st))) return rc;
+    } else {
+      if ((rc = launch_iota_rows(t.rows, B, T, st))) return rc;
+      if ((rc = launch_layernorm_x(t.x, t.xh, t.rows, w->ln_post_w, w->ln_post_b, t.pool, dt == CMH_BF16, B, d, st))) return rc;
+    }
     if ((rc = final_projection(dt, t.pool, w->proj_t, feat, B, w->embed_dim, d, st))) return rc;
   }
   return CMH_OK;
@@ -288,7 +348,13 @@ static int text_encode_impl(const cmh_text_weights* w, const int64_t* tokens, in
   // token_embedding gather + positional_embedding[:L]; EOT row = argmax(tokens)  (model.py:360-362,370)
   if ((rc = launch_text_embed_packed(tokens, w->token_embedding, w->positional_embedding, t.x, t.xh, t.rows, B, L, d,
                                      w->vocab_size, seq_off, st))) return rc;
+  const bool tail = feat && !tokens_out && !taps && !amax && !eot_rows_out && w->layers > 0 && pooled_tail_enabled();
+  void* x_pooled = nullptr;
   for (int i = 0; i < w->layers; ++i) {
+    if (tail && i == w->layers - 1) {
+      if ((rc = run_block_pooled(w->blocks[i], dtb, t, B, L, d, /*causal=*/1, key_padding_mask, st, rows, seq_off, &x_pooled))) return rc;
+      break;
+    }
     if ((rc = run_block(w->blocks[i], dtb, t, B, L, d, /*causal=*/1, key_padding_mask, st, rows, seq_off, amax ? amax + 4 * i : nullptr))) return rc;
     if ((rc = tap(taps, 1 + i, t.x, static_cast<size_t>(M) * d * 4, st))) return rc;
   }
@@ -302,7 +368,8 @@ static int text_encode_impl(const cmh_text_weights* w, const int64_t* tokens, in
     return fail(CMH_ERR_LAUNCH, "text_encode: eot row copy failed");
   if (feat) {
     // ln_final (row-wise, so only the pooled rows are normalised), @ text_projection  (:366-370)
-    if ((rc = launch_layernorm_x(t.x, t.xh, t.rows, w->ln_final_w, w->ln_final_b, t.pool, dt == CMH_BF16, B, d, st))) return rc;
+    if ((rc = launch_layernorm_x(x_pooled ? x_pooled : t.x, t.xh, x_pooled ? nullptr : t.rows, w->ln_final_w, w->ln_final_b, t.pool,
+                                 dt == CMH_BF16, B, d, st))) return rc;
     if ((rc = final_projection(dt, t.pool, w->text_projection_t, feat, B, w->embed_dim, d, st))) return rc;
   }
   return CMH_OK;

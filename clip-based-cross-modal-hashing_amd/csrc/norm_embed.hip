@@ -430,6 +430,30 @@ int launch_iota_rows(int32_t* rows, int B, int T, hipStream_t st) {
   return CMH_OK;
 }
 
+// dstA[b] = srcA[rows[b]], dstB[b] = srcB[rows[b]] for rows of bytesA / bytesB (multiples of 16) bytes, one launch: the pooled rows
+// of the residual stream and of the attention output before the last block's row-wise tail (encoders.hip)
+__global__ __launch_bounds__(256) void gather_rows2_kernel(const uint4* __restrict__ srcA, uint4* __restrict__ dstA, int chunksA,
+                                                           const uint4* __restrict__ srcB, uint4* __restrict__ dstB, int chunksB,
+                                                           const int32_t* __restrict__ rows, int B) {
+  const int per = chunksA + chunksB;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * per) return;
+  const int b = i / per, ch = i - b * per;
+  const size_t r = static_cast<size_t>(rows[b]);
+  if (ch < chunksA) dstA[static_cast<size_t>(b) * chunksA + ch] = srcA[r * chunksA + ch];
+  else dstB[static_cast<size_t>(b) * chunksB + ch - chunksA] = srcB[r * chunksB + ch - chunksA];
+}
+
+int launch_gather_rows2(const void* srcA, void* dstA, int bytesA, const void* srcB, void* dstB, int bytesB, const int32_t* rows, int B,
+                        hipStream_t st) {
+  CMH_CHECK_ARG(bytesA > 0 && bytesA % 16 == 0 && bytesB > 0 && bytesB % 16 == 0, "gather_rows: rows of %d / %d bytes", bytesA, bytesB);
+  const int per = bytesA / 16 + bytesB / 16;
+  hipLaunchKernelGGL(gather_rows2_kernel, dim3((B * per + 255) / 256), dim3(256), 0, st, static_cast<const uint4*>(srcA),
+                     static_cast<uint4*>(dstA), bytesA / 16, static_cast<const uint4*>(srcB), static_cast<uint4*>(dstB), bytesB / 16, rows, B);
+  CMH_CHECK_LAUNCH("gather_rows");
+  return CMH_OK;
+}
+
 // ---- f32 -> bf16 ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
                                                         int64_t n) {

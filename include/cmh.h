@@ -184,6 +184,12 @@ int cmh_prof_gemm_end(double* total_ms, double* total_flops, int64_t* launches);
  * Process-wide, not thread-safe.  (No reference counterpart: upstream's GEMMs are ATen's, model/base/model.py:167-196.) */
 int cmh_gemm_tuning(int32_t tile_rows, int32_t order_group);
 
+/* encode_image / encode_text return one pooled row per sample (model/base/model.py:247-250, 366-370), and past the last block's
+ * attention every operation is row-wise, so cmh_vit_encode / cmh_text_encode[_packed] carry only those B rows through the last
+ * block's out_proj, ln_2 and MLP (bit-identical features, three GEMMs of M = B instead of M = B*T).  on = 0 switches that off
+ * (A/B measurements, the equality test); also CMH_POOLED_TAIL=0 in the environment.  Process-wide, not thread-safe. */
+int cmh_set_pooled_tail(int32_t on);
+
 /* ---------------------------------------------------------------------------------------------
  * fp8 encoder mode (CMH_FP8).  Mirrors the reference's precision hook convert_weights (model/base/model.py:391-412): the same
  * tensors it lowers to fp16 - Linear / MultiheadAttention weights - go to e4m3 here, with the activations that feed them.

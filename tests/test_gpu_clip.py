@@ -147,3 +147,35 @@ def test_packed_text_encode_is_bit_identical(mode):
     rows, total = m.last_text_rows
     assert rows == int((txt.argmax(1) + 1).sum()) and total == 12 * 77 and rows < total
     assert torch.equal(dense, packed)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16", "fp8"])
+def test_pooled_rows_through_the_last_block_are_bit_identical(mode):
+    """cmh_set_pooled_tail: only the class-token / EOT rows are carried through the last block's out_proj, ln_2 and MLP
+    (csrc/encoders.hip::run_block_pooled) - the features must equal the full-size path bit for bit, both towers, packed
+    and dense captions."""
+    import cmh_native as N
+    cfg = recipe.CLIP_VITB32
+    torch.manual_seed(11)
+    from model.base.model import CLIP
+    m = CLIP(**cfg).to(DEV).float().set_gemm_dtype("bf16" if mode == "fp8" else mode)
+    m.assume_frozen = True
+    img = torch.from_numpy(recipe.images(6, cfg["image_resolution"], 3)).to(DEV)
+    t = torch.from_numpy(recipe.captions(9, 77, cfg["vocab_size"], 4)).to(DEV)
+    if mode == "fp8":
+        m.calibrate_fp8(img, t)
+        m.set_gemm_dtype("fp8")
+    try:
+        with torch.no_grad():
+            outs = {}
+            for on in (False, True):
+                N.set_pooled_tail(on)
+                for pack in (False, True):
+                    m.pack_text = pack
+                    outs[on, pack] = (m.encode_image(img).clone(), m.encode_text(t).clone())
+    finally:
+        N.set_pooled_tail(True)
+    for pack in (False, True):
+        assert torch.equal(outs[False, pack][0], outs[True, pack][0])
+        assert torch.equal(outs[False, pack][1], outs[True, pack][1])
+    assert torch.isfinite(outs[True, True][0]).all() and outs[True, True][0].abs().sum() > 0
