@@ -61,6 +61,55 @@ __global__ __launch_bounds__(256) void transpose4_kernel(const void* __restrict_
   }
 }
 
+// Up to 4 same-dtype transposes in one launch (the four weight matrices a block's dgrad GEMMs take as W^T: each is 1-5 MB, and as four
+// launches the 96 transposes of a training step cost 0.48 ms of mostly launch latency).  R, C multiples of 4; dst_ld = R.
+struct TransposeJobs {
+  const void* src[4];
+  void* dst[4];
+  int R[4], C[4], first_tile[5];   // job j owns tiles [first_tile[j], first_tile[j+1]), 64 x 64 each, column-tile fastest
+  int n, kind;
+};
+__global__ __launch_bounds__(256) void transpose_multi_kernel(TransposeJobs J) {
+  __shared__ float tile[64][65];
+  int j = 0;
+  while (j + 1 < J.n && static_cast<int>(blockIdx.x) >= J.first_tile[j + 1]) ++j;
+  const int R = J.R[j], C = J.C[j], tcols = (C + 63) / 64, local = blockIdx.x - J.first_tile[j];
+  const int c0 = (local % tcols) * 64, r0 = (local / tcols) * 64;
+  const void* src = J.src[j];
+  void* dst = J.dst[j];
+  const int q = threadIdx.x & 15, p = threadIdx.x >> 4;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int i = pass * 16 + p, r = r0 + i, c = c0 + q * 4;
+    float4 v = float4{0.f, 0.f, 0.f, 0.f};
+    if (r < R && c < C) v = load4_as_f32(src, static_cast<size_t>(r) * C + c, J.kind);
+    tile[i][q * 4 + 0] = v.x; tile[i][q * 4 + 1] = v.y; tile[i][q * 4 + 2] = v.z; tile[i][q * 4 + 3] = v.w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int i = pass * 16 + p, c = c0 + i, r = r0 + q * 4;
+    if (c < C && r < R)
+      store4_from_f32(dst, static_cast<size_t>(c) * R + r, J.kind,
+                      float4{tile[q * 4 + 0][i], tile[q * 4 + 1][i], tile[q * 4 + 2][i], tile[q * 4 + 3][i]});
+  }
+}
+
+int launch_transpose_multi(const void* const* src, void* const* dst, const int* R, const int* C, int n, int kind, hipStream_t st) {
+  CMH_CHECK_ARG(n >= 1 && n <= 4 && (kind == kF32 || kind == kBF16 || kind == kF16), "transpose_multi: %d jobs", n);
+  TransposeJobs J;
+  J.n = n; J.kind = kind; J.first_tile[0] = 0;
+  for (int j = 0; j < n; ++j) {
+    CMH_CHECK_ARG(src[j] && dst[j] && R[j] > 0 && C[j] > 0 && R[j] % 4 == 0 && C[j] % 4 == 0, "transpose_multi: job %d is %d x %d", j, R[j], C[j]);
+    J.src[j] = src[j]; J.dst[j] = dst[j]; J.R[j] = R[j]; J.C[j] = C[j];
+    J.first_tile[j + 1] = J.first_tile[j] + ((R[j] + 63) / 64) * ((C[j] + 63) / 64);
+  }
+  for (int j = n; j < 4; ++j) { J.src[j] = nullptr; J.dst[j] = nullptr; J.R[j] = 0; J.C[j] = 0; J.first_tile[j + 1] = J.first_tile[n]; }
+  hipLaunchKernelGGL(transpose_multi_kernel, dim3(J.first_tile[n]), dim3(256), 0, st, J);
+  CMH_CHECK_LAUNCH("transpose_multi");
+  return CMH_OK;
+}
+
 // ---- column sums: partial[b, c] = sum over the block's rows; then a second pass over the partials ------------------------
 constexpr int kColRows = 64;    // rows per workgroup (= the transpose tile, whose fused column sums share the layout)
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const void* __restrict__ x, int kind, int R, int C,

@@ -169,6 +169,8 @@ int launch_attention_backward(int dtype, const void* qkv, const void* o, const v
 int launch_transpose(const void* src, int skind, void* dst, int dkind, int rows, int cols, int dst_ld, hipStream_t st,
                      float* colsum_partial = nullptr);   // + [ceil(rows/64), cols] partial column sums (vectorised path only)
 bool transpose_is_vectorised(const void* src, const void* dst, int rows, int cols, int dst_ld);
+// n <= 4 transposes of [R[j], C[j]] matrices of one element kind in one launch (R, C multiples of 4; dst [C, R])
+int launch_transpose_multi(const void* const* src, void* const* dst, const int* R, const int* C, int n, int kind, hipStream_t st);
 int launch_colsum_final(const float* partial, int slices, int cols, float* out, hipStream_t st);
 // deferred final stage of column reductions: up to kMax (partial [slices, cols] -> out [cols]) jobs for one launch
 struct FinalJobs {

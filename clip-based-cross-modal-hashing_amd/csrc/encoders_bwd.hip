@@ -61,7 +61,7 @@ struct TrainBufs {
   void* dqkv;          // [M,3d] e
   void* tA;            // [rmax, Mpad] e   dY^T
   void* tB;            // [rmax, Mpad] e   X^T
-  void* wT;            // [rmax * d] e     W^T
+  void* wT;            // [max(12 d, rmax) * d] e   W^T of the block's four weight matrices (one launch), or of one head matrix
   void* tokE;          // [M, embed] e
   float* projT;        // [embed, d] f32
   float* small;        // [2*B*max(d,E)] f32
@@ -109,7 +109,7 @@ TrainBufs carve_train(void* ws, size_t M, size_t B, size_t d, size_t e, size_t x
   t.tAB_bytes = rmax * mp * e;
   t.tA = a.take(t.tAB_bytes);
   t.tB = a.take(t.tAB_bytes);
-  t.wT = a.take(rmax * d * e);
+  t.wT = a.take((12 * d > rmax ? 12 * d : rmax) * d * e);   // the four W^T of a block side by side (12 d^2), or one head matrix
   t.tokE = a.take(M * embed * e);                           // all-token head: dtokens as a GEMM operand
   t.projT = a.take<float>(embed * d * 4);                   //                 d(proj^T) [embed, d] before its transpose
   const size_t wide = d > embed ? d : embed;
@@ -209,10 +209,13 @@ int wgrad(int dt, const void* dY, int ky, int O, const void* X, int kx, int I, i
 
 // dX[M, I] = dY[M, O] . W[O, I]  (W in the GEMM dtype, row-major [O, I]); out typed by `epi`
 int dgrad(int dt, const void* dYe, const void* W, int O, int I, int M, const void* aux, void* dX, int epi, TrainBufs& t,
-          hipStream_t st) {
+          hipStream_t st, const void* Wt = nullptr) {      // Wt: W^T [I, O] when the caller has it already
   int rc;
-  if ((rc = launch_transpose(W, ekind(dt), t.wT, ekind(dt), O, I, O, st))) return rc;      // W^T [I, O]
-  return launch_gemm(dt, dYe, t.wT, nullptr, static_cast<const float*>(aux), dX, M, I, O, epi, st);
+  if (!Wt) {
+    if ((rc = launch_transpose(W, ekind(dt), t.wT, ekind(dt), O, I, O, st))) return rc;      // W^T [I, O]
+    Wt = t.wT;
+  }
+  return launch_gemm(dt, dYe, Wt, nullptr, static_cast<const float*>(aux), dX, M, I, O, epi, st);
 }
 
 int block_backward(const cmh_block_weights& w, const BlockGradPtrs& g, int dt, int xh, const LayerTape& L, TrainBufs& t, int B,
@@ -236,14 +239,21 @@ int block_backward(const cmh_block_weights& w, const BlockGradPtrs& g, int dt, i
   const bool batched = off_ln1 + ln_ws <= t.red_bytes;
   FinalJobs* dj = batched ? &jobs : nullptr;
   char* red = static_cast<char*>(t.red);
+  // W^T of the four weight matrices, one launch: proj [d, 4d], fc [4d, d], out_proj [d, d], in_proj [3d, d]
+  const size_t esz = dt == CMH_BF16 ? 2 : 4, dd = static_cast<size_t>(d) * d;
+  char* wt = static_cast<char*>(t.wT);
+  const void* wsrc[4] = {w.proj_w, w.fc_w, w.out_proj_w, w.in_proj_w};
+  void* wdst[4] = {wt, wt + 4 * dd * esz, wt + 8 * dd * esz, wt + 9 * dd * esz};
+  const int wR[4] = {d, 4 * d, d, 3 * d}, wC[4] = {4 * d, d, d, d};
+  if ((rc = launch_transpose_multi(wsrc, wdst, wR, wC, 4, ek, st))) return rc;
   // 1. MLP projection (dxe_ready: the previous block's ln_1 backward already wrote t.dxe)
   if (dxe_ready && dx_copy) dxe = t.dxe;
   else if ((rc = as_gemm_operand(dt, t.dx, t.dxe, md, st, &dxe))) return rc;
-  if ((rc = dgrad(dt, dxe, w.proj_w, d, 4 * d, M, L.pre, t.dpre, EPI_MUL_DQGELU | obf, t, st))) return rc;
+  if ((rc = dgrad(dt, dxe, w.proj_w, d, 4 * d, M, L.pre, t.dpre, EPI_MUL_DQGELU | obf, t, st, wdst[0]))) return rc;
   if ((rc = wgrad(dt, t.dx, kF32, d, L.act, ek, 4 * d, M, g.proj_w, g.proj_b, t, st, dj, batched ? off_proj : 0,
                   dt == CMH_BF16 ? dxe : nullptr))) return rc;
   // 2. c_fc
-  if ((rc = dgrad(dt, t.dpre, w.fc_w, 4 * d, d, M, nullptr, t.dh, obf, t, st))) return rc;
+  if ((rc = dgrad(dt, t.dpre, w.fc_w, 4 * d, d, M, nullptr, t.dh, obf, t, st, wdst[1]))) return rc;
   if ((rc = wgrad(dt, t.dpre, ek, 4 * d, L.h2, ek, d, M, g.fc_w, g.fc_b, t, st, dj, batched ? off_fc : 0))) return rc;
   // 3. ln_2
   if ((rc = launch_layernorm_backward(L.x_mid, xk, t.dh, ek, w.ln2_w, nullptr, M, d, t.dx, 1, g.ln2_w, g.ln2_b,
@@ -251,13 +261,13 @@ int block_backward(const cmh_block_weights& w, const BlockGradPtrs& g, int dt, i
   // 4. out_proj
   if (dx_copy) dxe = t.dxe;
   else if ((rc = as_gemm_operand(dt, t.dx, t.dxe, md, st, &dxe))) return rc;
-  if ((rc = dgrad(dt, dxe, w.out_proj_w, d, d, M, nullptr, t.dh, obf, t, st))) return rc;
+  if ((rc = dgrad(dt, dxe, w.out_proj_w, d, d, M, nullptr, t.dh, obf, t, st, wdst[2]))) return rc;
   if ((rc = wgrad(dt, t.dx, kF32, d, L.attn, ek, d, M, g.out_w, g.out_b, t, st, dj, batched ? off_out : 0,
                   dt == CMH_BF16 ? dxe : nullptr))) return rc;
   // 5. attention
   if ((rc = launch_attention_backward(dt, L.qkv, L.attn, t.dh, t.dqkv, B, T, d, causal, kpm, seq_off, st))) return rc;
   // 6. in_proj
-  if ((rc = dgrad(dt, t.dqkv, w.in_proj_w, 3 * d, d, M, nullptr, t.dh, obf, t, st))) return rc;
+  if ((rc = dgrad(dt, t.dqkv, w.in_proj_w, 3 * d, d, M, nullptr, t.dh, obf, t, st, wdst[3]))) return rc;
   if ((rc = wgrad(dt, t.dqkv, ek, 3 * d, L.h1, ek, d, M, g.in_w, g.in_b, t, st, dj, batched ? off_in : 0))) return rc;
   // 7. ln_1
   if ((rc = launch_layernorm_backward(L.x_in, xk, t.dh, ek, w.ln1_w, nullptr, M, d, t.dx, 1, g.ln1_w, g.ln1_b,

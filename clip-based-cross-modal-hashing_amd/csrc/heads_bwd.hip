@@ -114,13 +114,13 @@ __global__ __launch_bounds__(64) void hyp_pairs_kernel(const float* __restrict__
 //   pair terms  : rows i, j both multi-label with label_i . label_j == 0, weight alpha / Z         (loss.py:42-64)
 //     x_sim[i,j] (counted at (i,j) and (j,i)) -> dxn_i += 2 w [x_sim > thr] xn_j;   t_sim likewise for yn;
 //     xt_sim[i,j] = xn_i . yn_j -> dxn_i += w [.] yn_j;   xt_sim[j,i] = xn_j . yn_i -> dyn_i += w [.] xn_j
+template <int KV>   // 64-column slices a lane owns: K <= 64 KV (sized to K: a 64-bit head pays for one slice, not for the 512-bit maximum)
 __global__ __launch_bounds__(64) void hyp_rows_kernel(const float* __restrict__ xn, const float* __restrict__ yn,
                                                       const float* __restrict__ pn, const float* __restrict__ nx,
                                                       const float* __restrict__ ny, const float* __restrict__ label,
                                                       const int* __restrict__ multi, const float* __restrict__ cnt, int B, int K,
                                                       int C, float thr, float alpha, const float* __restrict__ dloss,
                                                       float* __restrict__ dx, float* __restrict__ dy) {
-  constexpr int KV = 8;                                 // K <= 512
   const int b = blockIdx.x, lane = threadIdx.x;
   const float up = dloss ? dloss[0] : 1.f;
   const float invP = 1.f / cnt[0], invN = 1.f / cnt[1];
@@ -189,11 +189,11 @@ __global__ __launch_bounds__(64) void hyp_rows_kernel(const float* __restrict__ 
 }
 
 // One wave per proxy c: dpn[c] = sum_b G_x[b,c] xn[b] + G_t[b,c] yn[b], then through the normalisation
+template <int KV>
 __global__ __launch_bounds__(64) void hyp_proxy_kernel(const float* __restrict__ xn, const float* __restrict__ yn,
                                                        const float* __restrict__ pn, const float* __restrict__ np_,
                                                        const float* __restrict__ label, const float* __restrict__ cnt, int B, int K,
                                                        int C, float thr, const float* __restrict__ dloss, float* __restrict__ dp) {
-  constexpr int KV = 8;
   const int c = blockIdx.x, lane = threadIdx.x;
   const float up = dloss ? dloss[0] : 1.f;
   const float invP = 1.f / cnt[0], invN = 1.f / cnt[1];
@@ -579,9 +579,18 @@ extern "C" int cmh_dsph_hyp_loss_backward(const float* x, const float* y, const 
   hipLaunchKernelGGL(hyp_normalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, proxies, pn, np_, C, K);
   hipLaunchKernelGGL(hyp_counts_kernel, dim3(1), dim3(256), 0, st, label, B, C, multi, cnt);
   if (alpha > 0.f) hipLaunchKernelGGL(hyp_pairs_kernel, dim3(B), dim3(64), 0, st, label, multi, B, C, cnt);
-  hipLaunchKernelGGL(hyp_rows_kernel, dim3(B), dim3(64), 0, st, xn, yn, pn, nx, ny, label, multi, cnt, B, K, C, threshold, alpha, dloss,
-                     dx, dy);
-  hipLaunchKernelGGL(hyp_proxy_kernel, dim3(C), dim3(64), 0, st, xn, yn, pn, np_, label, cnt, B, K, C, threshold, dloss, dproxies);
+#define HYP_BWD(KV)                                                                                                               \
+  do {                                                                                                                          \
+    hipLaunchKernelGGL(hyp_rows_kernel<KV>, dim3(B), dim3(64), 0, st, xn, yn, pn, nx, ny, label, multi, cnt, B, K, C, threshold, alpha, \
+                       dloss, dx, dy);                                                                                          \
+    hipLaunchKernelGGL(hyp_proxy_kernel<KV>, dim3(C), dim3(64), 0, st, xn, yn, pn, np_, label, cnt, B, K, C, threshold, dloss,    \
+                       dproxies);                                                                                               \
+  } while (0)
+  if (K <= 64) HYP_BWD(1);
+  else if (K <= 128) HYP_BWD(2);
+  else if (K <= 256) HYP_BWD(4);
+  else HYP_BWD(8);
+#undef HYP_BWD
   CMH_CHECK_LAUNCH("dsph_hyp_loss_backward");
   return CMH_OK;
 }
