@@ -110,7 +110,9 @@ enum : int {
   EPI_MUL_DQGELU = 1024, // acc *= QuickGELU'(aux[m,n]); aux (in the residual slot) has the OUTPUT's type (bf16 with EPI_OUT_BF16,
                          // else f32): the dgrad through c_fc's activation.  N % 256 == 0 (wide kernel only); 256/512 are ablation bits
   EPI_SCALE = 2048,      // acc *= alpha * colscale[n] before the bias: dequantisation of fp8 operands (launch_gemm_fp8)
-  EPI_OUT_FP8 = 4096     // store OCP e4m3 of clamp(v * oscale, +-448) (the next fp8 GEMM's operand)
+  EPI_OUT_FP8 = 4096,    // store OCP e4m3 of clamp(v * oscale, +-448) (the next fp8 GEMM's operand)
+  EPI_SAVE_PRE = 8192    // (bf16 out, wide kernel) also store the value BEFORE the activation, as bf16 [M, N], through the residual
+                         // slot's pointer: the training forward of c_fc keeps the pre-activation for the backward
 };
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }

@@ -156,8 +156,15 @@ int block_forward_train(const cmh_block_weights& w, int dt, int xh, const LayerT
   if ((rc = launch_attention_varlen(L.qkv, L.attn, dt, B, T, d, causal, kpm, seq_off, st))) return rc;
   if ((rc = launch_gemm(dt, L.attn, w.out_proj_w, w.out_proj_b, static_cast<const float*>(L.x_in), L.x_mid, M, d, d, rx, st))) return rc;
   if ((rc = launch_layernorm_x(L.x_mid, xh, nullptr, w.ln2_w, w.ln2_b, L.h2, dt == CMH_BF16, M, d, st))) return rc;
-  if ((rc = launch_gemm(dt, L.h2, w.fc_w, w.fc_b, nullptr, L.pre, M, 4 * d, d, EPI_BIAS | obf, st))) return rc;
-  if ((rc = cmh_quick_gelu(L.pre, L.act, static_cast<int64_t>(M) * 4 * d, ekind(dt), st))) return rc;
+  static const bool fuse_act = []() { const char* e = getenv("CMH_FUSE_PRE"); return !(e && e[0] == '0'); }();
+  if (dt == CMH_BF16 && (4 * d) % 256 == 0 && fuse_act) {   // the N % 256 == 0 GEMM kernel has the epilogue
+    // one launch: the activation from the f32 accumulator into L.act, the bf16 pre-activation into L.pre (EPI_SAVE_PRE)
+    if ((rc = launch_gemm(dt, L.h2, w.fc_w, w.fc_b, static_cast<const float*>(L.pre), L.act, M, 4 * d, d,
+                          EPI_BIAS | EPI_QUICKGELU | EPI_SAVE_PRE | obf, st))) return rc;
+  } else {
+    if ((rc = launch_gemm(dt, L.h2, w.fc_w, w.fc_b, nullptr, L.pre, M, 4 * d, d, EPI_BIAS | obf, st))) return rc;
+    if ((rc = cmh_quick_gelu(L.pre, L.act, static_cast<int64_t>(M) * 4 * d, ekind(dt), st))) return rc;
+  }
   if ((rc = launch_gemm(dt, L.act, w.proj_w, w.proj_b, static_cast<const float*>(L.x_mid), x_next, M, d, 4 * d, rx, st))) return rc;
   return CMH_OK;
 }

@@ -239,7 +239,10 @@ int launch_gemm(int dt, const void* A, const void* W, const float* bias, const f
   static const bool wide = []() { const char* e = getenv("CMH_GEMM_WIDE"); return !(e && !strcmp(e, "0")); }();
   CMH_CHECK_ARG(!(epi & EPI_MUL_DQGELU) || (residual && gemm_wide_supported(N) && !(epi & (EPI_RESIDUAL | EPI_OUT_F16))),
                 "gemm: EPI_MUL_DQGELU needs aux in the residual slot, N %% 256 == 0 (N=%d), no residual / fp16 output", N);
-  const bool f16io = epi & (EPI_RES_F16 | EPI_OUT_F16 | EPI_MUL_DQGELU);   // only the wide kernel implements these epilogues
+  CMH_CHECK_ARG(!(epi & EPI_SAVE_PRE) || (residual && dt == CMH_BF16 && (epi & EPI_OUT_BF16) && gemm_wide_supported(N) &&
+                                          !(epi & (EPI_RESIDUAL | EPI_MUL_DQGELU | EPI_OUT_F16))),
+                "gemm: EPI_SAVE_PRE needs the second output in the residual slot, bf16 operands and output, N %% 256 == 0 (N=%d)", N);
+  const bool f16io = epi & (EPI_RES_F16 | EPI_OUT_F16 | EPI_MUL_DQGELU | EPI_SAVE_PRE);   // only the wide kernel implements these epilogues
   if ((impl == 1 && wide && gemm_wide_supported(N)) || f16io) {
     const int rc = launch_gemm_wide(dt, A, W, bias, residual, out, M, N, K, epi, st);
     if (rc) return rc;

@@ -756,6 +756,33 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
 #pragma unroll
         for (int b = 0; b < MF; ++b) acc[a][b] += bv[a];
     }
+#ifndef W_NO_SAVE_PRE
+    if constexpr (OUTBF && !FP8) {
+      if (epi & EPI_SAVE_PRE) {
+        // training forward of c_fc: the pre-activation (what QuickGELU' needs in the backward) leaves as bf16 through the residual
+        // slot's pointer, straight from the epilogue (same 16-byte layout as the main output), and the activation below is taken
+        // from the f32 accumulator: no separate QuickGELU pass over [M, 4d]
+        char* p2 = reinterpret_cast<char*>(const_cast<float*>(residual)) +
+                   (static_cast<size_t>(m0 + wm * WR + frow) * N + n0 + wn * 64 + (fq & 1) * 16 + (fq & 2) * 4) * 2;
+#pragma unroll
+        for (int b = 0; b < MF; ++b) {
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            uint32_t lo[2], hi[2];
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+              lo[w] = pack_bf16x2(acc[2 * pr][b][2 * w], acc[2 * pr][b][2 * w + 1]);
+              hi[w] = pack_bf16x2(acc[2 * pr + 1][b][2 * w], acc[2 * pr + 1][b][2 * w + 1]);
+            }
+            const w_u2_t s0 = __builtin_amdgcn_permlane16_swap(lo[0], hi[0], false, false);
+            const w_u2_t s1 = __builtin_amdgcn_permlane16_swap(lo[1], hi[1], false, false);
+            if (m0 + wm * WR + b * 16 + frow < M)
+              *reinterpret_cast<w_u32x4_t*>(p2 + b * row16 + pr * 64) = w_u32x4_t{s0[0], s1[0], s0[1], s1[1]};
+          }
+        }
+      }
+    }
+#endif
     if (epi & EPI_QUICKGELU) {
 #pragma unroll
       for (int a = 0; a < 4; ++a)
