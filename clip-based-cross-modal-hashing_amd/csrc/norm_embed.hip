@@ -351,55 +351,52 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int64_t* __restri
 // seq_off[b] = sum_{b' < b} (argmax(tokens[b']) + 1): the packed row offsets of encode_text without padding.  One workgroup of
 // 16 waves: a wave takes whole captions (coalesced row reads, first-maximum argmax by a butterfly on (value, index)), then wave 0
 // turns the lengths into offsets with 64-wide prefix scans.  (Round 1's one-thread-per-caption loop took 37 us at B = 256.)
-__global__ __launch_bounds__(1024) void text_pack_plan_kernel(const int64_t* __restrict__ tokens, int B, int L,
-                                                              int32_t* __restrict__ seq_off) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // four captions per wave and iteration, their row loads issued together (one caption at a time the 16 dependent
-  // load -> butterfly rounds of a 256-caption batch took 30 us)
-  for (int b0 = wave * 4; b0 < B; b0 += 64) {
-    long long best[4];
-    int besti[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      best[u] = INT64_MIN;
-      besti[u] = 0;
-      const int b = b0 + u < B ? b0 + u : B - 1;
-      for (int i = lane; i < L; i += 64) {
-        const long long v = tokens[static_cast<size_t>(b) * L + i];
-        if (v > best[u]) { best[u] = v; besti[u] = i; }      // a lane's indices ascend: strict > keeps its first maximum
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const long long ov = __shfl_xor(best[u], o, 64);
-        const int oi = __shfl_xor(besti[u], o, 64);
-        if (ov > best[u] || (ov == best[u] && oi < besti[u])) { best[u] = ov; besti[u] = oi; }
-      }
-      if (lane == 0 && b0 + u < B) seq_off[b0 + u + 1] = besti[u] + 1;    // length, turned into an offset below
-    }
-  }
+__global__ __launch_bounds__(256) void text_pack_plan_kernel(const int64_t* __restrict__ tokens, int B, int L,
+                                                             int32_t* __restrict__ seq_off) {
+  // One THREAD per caption: a running (max, first index) over its tokens - no cross-lane traffic at all.
+  // Then an inclusive scan of the lengths over the workgroup, 256 captions per pass.
+  __shared__ int wsum[4];
+  __shared__ int carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry = 0;
   __syncthreads();
-  if (wave == 0) {
-    int run = 0;
-    for (int base = 0; base < B; base += 64) {
-      const int idx = base + lane;
-      int v = idx < B ? seq_off[idx + 1] : 0;
+  for (int base = 0; base < B; base += 256) {
+    const int b = base + tid;
+    int len = 0;
+    if (b < B) {
+      const int64_t* row = tokens + static_cast<size_t>(b) * L;
+      long long best = INT64_MIN;
+      int besti = 0;
+      for (int i0 = 0; i0 < L; i0 += 16) {            // 16 loads in flight: one at a time the 77 dependent round trips took 35 us
+        long long v[16];
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(v, o, 64);
-        if (lane >= o) v += t;
+        for (int u = 0; u < 16; ++u) v[u] = i0 + u < L ? row[i0 + u] : INT64_MIN;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (v[u] > best) { best = v[u]; besti = i0 + u; }      // strict >: the first maximum, like torch.argmax
       }
-      if (idx < B) seq_off[idx + 1] = run + v;
-      run += __shfl(v, 63, 64);
+      len = besti + 1;
     }
-    if (lane == 0) seq_off[0] = 0;
+    int v = len;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(v, o, 64);
+      if (lane >= o) v += t;
+    }
+    if (lane == 63) wsum[wave] = v;
+    __syncthreads();
+    int before = carry;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    if (b < B) seq_off[b + 1] = before + v;
+    __syncthreads();
+    if (tid == 255) carry = before + v;
+    __syncthreads();
   }
+  if (tid == 0) seq_off[0] = 0;
 }
 
 int launch_text_pack_plan(const int64_t* tokens, int B, int L, int32_t* seq_off, hipStream_t st) {
-  hipLaunchKernelGGL(text_pack_plan_kernel, dim3(1), dim3(1024), 0, st, tokens, B, L, seq_off);
+  hipLaunchKernelGGL(text_pack_plan_kernel, dim3(1), dim3(256), 0, st, tokens, B, L, seq_off);
   CMH_CHECK_LAUNCH("text_pack_plan");
   return CMH_OK;
 }
