@@ -95,6 +95,9 @@ SIGNATURES = {
     "cmh_attention": (C.c_int, [_i32, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "cmh_gemm_tuning": (C.c_int, [_i32, _i32]),
     "cmh_set_pooled_tail": (C.c_int, [_i32]),
+    "cmh_msl_workspace_bytes": (_sz, [_i32]),
+    "cmh_msl_loss": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _sz, _p]),
+    "cmh_msl_loss_backward": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
     "cmh_qmi_workspace_bytes": (_sz, [_i32]),
     "cmh_qmi_loss": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _f, _p, _p, _p, _sz, _p]),
     "cmh_qmi_loss_backward": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _f, _p, _p, _p, _p, _p, _sz, _p]),
@@ -530,6 +533,33 @@ def dsph_hyp_loss(x, y, label, proxies, threshold, alpha):
     check(lib().cmh_dsph_hyp_loss(ptr(x), ptr(y), ptr(label), ptr(proxies), B, K, Cn, float(threshold), float(alpha),
                                   ptr(out), ptr(ws), ws.numel(), stream_ptr(x.device)), "cmh_dsph_hyp_loss")
     return out[0]
+
+
+def msl_loss(feats, labels, feat2=None):
+    """DMsH-LN multi-similarity loss (train/DMsH_LN/MSLOSS.py:13-55) -> loss 0-dim"""
+    feats, labels = f32c(feats), f32c(labels)
+    feat2 = None if feat2 is None else f32c(feat2)
+    require_gpu(feats, labels, feat2)
+    B, K = feats.shape
+    fit("msl_loss", (labels, (B, labels.shape[1])))
+    if feat2 is not None:
+        fit("msl_loss", (feat2, (B, K)))
+    out = torch.empty(1, dtype=torch.float32, device=feats.device)
+    ws = workspace(lib().cmh_msl_workspace_bytes(B), feats.device, "loss")
+    check(lib().cmh_msl_loss(ptr(feats), ptr(feat2), ptr(labels), B, K, labels.shape[1], ptr(out), ptr(ws), ws.numel(),
+                             stream_ptr(feats.device)), "cmh_msl_loss")
+    return out[0]
+
+
+def msl_loss_backward(feats, labels, feat2, dloss):
+    """-> (dfeats, dfeat2 | None); with feat2 = None the gradients of both roles of feats are summed into dfeats"""
+    B, K = feats.shape
+    dfeats = torch.empty_like(feats)
+    dfeat2 = None if feat2 is None else torch.empty_like(feat2)
+    ws = workspace(lib().cmh_msl_workspace_bytes(B), feats.device, "loss")
+    check(lib().cmh_msl_loss_backward(ptr(feats), ptr(feat2), ptr(labels), B, K, labels.shape[1], ptr(f32c(dloss).reshape(1)),
+                                      ptr(dfeats), ptr(dfeat2), ptr(ws), ws.numel(), stream_ptr(feats.device)), "cmh_msl_loss_backward")
+    return dfeats, dfeat2
 
 
 def qmi_loss(img, txt, label, eps=1e-8):

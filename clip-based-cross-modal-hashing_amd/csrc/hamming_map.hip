@@ -37,9 +37,15 @@ constexpr int NWAVE = NT / 64;
 constexpr int kIdxBits = 19;       // N < 2^19 = 524288
 constexpr uint32_t kIdxMask = (1u << kIdxBits) - 1;
 constexpr int kMaxWords = 64;      // K <= 2048 bits
-constexpr int kChunk = 1024;       // a longer segment is partitioned in chunks of this many positions, one wave per chunk
+#ifndef CMH_MAP_CHUNK
+#define CMH_MAP_CHUNK 1024
+#endif
+#ifndef CMH_MAP_SEQMAX
+#define CMH_MAP_SEQMAX 32
+#endif
+constexpr int kChunk = CMH_MAP_CHUNK;       // a longer segment is partitioned in chunks of this many positions, one wave per chunk
 constexpr int kLeaf = 16;          // libstdc++ _S_threshold
-constexpr int kSeqMax = 32;        // segments of 17..kSeqMax elements are finished sequentially, one lane each
+constexpr int kSeqMax = CMH_MAP_SEQMAX;        // segments of 17..kSeqMax elements are finished sequentially, one lane each
 
 __device__ __forceinline__ int ekey(uint32_t e) { return static_cast<int>(e >> kIdxBits); }
 __device__ __forceinline__ int eidx(uint32_t e) { return static_cast<int>(e & kIdxMask); }

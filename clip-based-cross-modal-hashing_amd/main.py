@@ -13,8 +13,9 @@ _REGISTRY = {
     'DNPH': ("train.DNPH_TOMM.hash_train", "DNPHTOMMTrainer"),
     'MITH': ("train.MITH.hash_train", "MITHTrainer"),
     'DNpH': ("train.DNpH_TMM.hash_train", "DNpHTMMTrainer"),
+    'DMsH_LN': ("train.DMsH_LN.hash_train", "DMsH_LNTrainer"),
 }
-_NOT_BUILT = ['DHaPH', 'DMsH_LN', 'DPBE', 'DDWSH', 'DDBH', 'DScPH', 'DPSIH', 'DGHDGH']
+_NOT_BUILT = ['DHaPH', 'DPBE', 'DDWSH', 'DDBH', 'DScPH', 'DPSIH', 'DGHDGH']
 
 
 class _LazyTrainers(dict):

@@ -223,6 +223,18 @@ int cmh_qmi_loss_backward(const float* img, const float* txt, const uint32_t* la
                           float eps, const float* sum_d, const float* dloss, float* dimg, float* dtxt, void* workspace,
                           size_t workspace_bytes, void* stream);
 
+/* DMsH-LN multi-similarity loss, reference train/DMsH_LN/MSLOSS.py:13-55 `MultiSimilarityLoss.forward(feats, labels, feat2)` in the
+ * branch its trainer takes (train/DMsH_LN/hash_train.py:58-60; not the "cifar10-1" branch): feats (and feat2, NULL = feats) f32
+ * [B,K] hash outputs, labels f32 [B,Kl] = the LabelNet codes (two samples are similar when their codes' dot product is > 0)
+ * -> loss f32 [1]; thresh 0.5, margin 0.1, scales 2 / 40 as the reference fixes them.  Backward: dfeats (and dfeat2 when feat2 is
+ * given; with feat2 = NULL both roles' gradients are summed into dfeats) = dloss[0] (NULL: 1) * d loss / d feats; it recomputes
+ * the forward's statistics, so the workspace need not be kept between the two calls.  B <= 16384, K, Kl <= 1024. */
+size_t cmh_msl_workspace_bytes(int32_t B);
+int cmh_msl_loss(const float* feats, const float* feat2, const float* labels, int32_t B, int32_t K, int32_t Kl, float* loss,
+                 void* workspace, size_t workspace_bytes, void* stream);
+int cmh_msl_loss_backward(const float* feats, const float* feat2, const float* labels, int32_t B, int32_t K, int32_t Kl,
+                          const float* dloss, float* dfeats, float* dfeat2, void* workspace, size_t workspace_bytes, void* stream);
+
 /* f32 -> bf16 (round-to-nearest-even) copy used to prepare CMH_BF16 GEMM weights. */
 int cmh_cast_f32_to_bf16(const float* src, void* dst_bf16, int64_t n, void* stream);
 

@@ -274,3 +274,41 @@ def test_every_method_learns(tmp_path, monkeypatch, method, K):
         tr.train_epoch(epoch)
     after = maps()
     assert after[0] > before[0] + 0.015 and sum(after) > sum(before) + 0.08, (method, before, after)
+
+
+def test_dmsh_ln_trainer_steps(tmp_path, monkeypatch):
+    """DMsH-LN end to end (train/DMsH_LN/hash_train.py): (1) as upstream ships it - a freshly initialised LabelNet whose codes make
+    every pair 'similar' - every row of the multi-similarity loss is skipped, the loss is the reference's constant zero
+    (MSLOSS.py:53-54) and an optimiser step moves nothing; (2) with label codes that do split the pairs (fc2's bias removes the
+    batch mean, as a trained LabelNet would) the loss is live and falls on a fixed batch through the native forward, loss,
+    backward and fused BertAdam."""
+    import argparse
+    import sys
+    import main
+    import dataset.synthetic as ds
+    ck = tmp_path / "clip.pt"
+    sd = recipe.clip_state_dict(dict(recipe.CLIP_TINY, embed_dim=512), 7)
+    torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, ck)
+    monkeypatch.setattr(ds, "SOT", 510); monkeypatch.setattr(ds, "EOT", 511)
+    monkeypatch.setattr(sys, "argv", ["main.py", "-clip-path", str(ck), "--save-dir", str(tmp_path / "run"), "--batch-size", "32",
+                                      "--num-workers", "0", "--resolution", "64", "--max-words", "16", "--query-num", "100",
+                                      "--train-num", "400", "--synthetic-size", "600", "--epochs", "0", "--gemm-dtype", "f32",
+                                      "--lr", "0.001", "--clip-lr", "0.0003"])
+    torch.manual_seed(0)
+    tr = main.trainers["DMsH_LN"](argparse.Namespace(method="DMsH_LN", dataset="synthetic", output_dim=32, is_train=True), 0)
+    for grp in tr.optimizer.param_groups:
+        grp["t_total"] = 100
+    tr.change_state(mode="train")
+    image, text, label, _ = next(iter(tr.train_loader))
+    watch = [tr.model.image_hash.fc.weight, tr.model.clip.visual.proj, tr.L_net.fc1.weight]
+    before = [w.detach().clone() for w in watch]
+    loss = tr._step(image, text, label)
+    assert float(loss) == 0.0
+    assert all(torch.equal(a, b.detach()) for a, b in zip(before, watch))
+    with torch.no_grad():
+        all_lab = tr.train_loader.dataset.get_all_label().to(DEV).float()
+        feat = torch.relu(all_lab @ tr.L_net.fc1.weight.t() + tr.L_net.fc1.bias)
+        tr.L_net.fc2.bias.copy_(-(feat.mean(0) @ tr.L_net.fc2.weight.t()))
+    losses = [float(tr._step(image, text, label)) for _ in range(12)]
+    assert losses[0] > 0.5 and losses[-1] < losses[0] - 0.15, losses          # measured 5.45 -> 5.17 (ten of the twelve steps are warm-up)
+    assert not torch.equal(before[0], watch[0].detach()) and torch.equal(before[2], watch[2].detach())     # LabelNet never moves

@@ -56,3 +56,22 @@ def test_dnph_tmm_qmi_loss(golden, B, K, C, p):
     loss = qmi_loss(c["x"], c["y"], c["lab"])
     want = float(g[f"{c['tag']}_loss"])
     assert abs(float(loss) - want) < 2e-5 * max(1.0, abs(want)), (float(loss), want)
+
+
+@pytest.mark.parametrize("B,K,C,p,epoch", [(8, 16, 24, 0.3, 0), (48, 32, 80, 0.05, 3), (256, 64, 24, 0.15, 7), (6, 16, 4, 1.0, 1)])
+def test_dmsh_ln_label_net_and_multi_similarity_loss(golden, B, K, C, p, epoch):
+    """numpy restatement of train/DMsH_LN/labelnet.py:13-21 and MSLOSS.py:13-55 against the reference's own values
+    (tests/golden/make_golden16.py): the label codes, then the three losses of a training step."""
+    from mslutil import msl_case
+    from oracle.msl_oracle import label_net, msl_loss
+    g = golden("msl.npz")
+    c = msl_case(B, K, C, p, epoch)
+    tag = c["tag"]
+    feat, hid, code = label_net(c["lab"], c["w1"], c["b1"], c["w2"], c["b2"], epoch)
+    np.testing.assert_allclose(hid, g[f"{tag}_ln_hid"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(code, g[f"{tag}_ln_code"], rtol=1e-4, atol=1e-5)
+    code = g[f"{tag}_ln_code"]
+    for name, (a, b) in (("ii", (c["x"], None)), ("tt", (c["y"], None)), ("it", (c["x"], c["y"]))):
+        want = float(g[f"{tag}_loss_{name}"])
+        got = float(msl_loss(a, code, b))
+        assert abs(got - want) < 2e-5 * max(1.0, abs(want)), (name, got, want)

@@ -32,6 +32,13 @@ batch = [torch.stack([torch.as_tensor(v) for v in c]) for c in cols]
 for name in ("optimizer", "optimizer_loss"):                 # keep the weights: this test compares gradients
     if hasattr(tr, name):
         getattr(tr, name).step = lambda *a, **k: None
+if method == "DMsH_LN":
+    # a freshly initialised LabelNet marks every pair as similar - the loss is the constant zero and there is nothing to compare;
+    # centre its codes on the 16 items (every rank computes the same bias from the same items)
+    with torch.no_grad():
+        lab16 = torch.stack([torch.as_tensor(it[2]) for it in items]).to(0).float()
+        feat = torch.relu(lab16 @ tr.L_net.fc1.weight.t() + tr.L_net.fc1.bias)
+        tr.L_net.fc2.bias.copy_(-(feat.mean(0) @ tr.L_net.fc2.weight.t()))
 if method == "MITH":
     image, text, kpm, label, index = batch
     tr.change_state(mode="valid")
@@ -42,7 +49,7 @@ if method == "MITH":
     tr.backward(loss)
 else:
     image, text, label, index = batch
-    loss = tr._step(image, text, label) if method in ("DSPH", "DNPH", "DCHMT", "DNpH") else tr._step(image, text, label, index)
+    loss = tr._step(image, text, label) if method in ("DSPH", "DNPH", "DCHMT", "DNpH", "DMsH_LN") else tr._step(image, text, label, index)
 grads = {}
 for name, p in tr.model.named_parameters():
     if p.grad is not None and any(k in name for k in ("proj", "hash", "resblocks.0.attn.in_proj_weight", "resblocks.1.mlp.c_fc.weight",
