@@ -98,6 +98,9 @@ SIGNATURES = {
     "cmh_msl_workspace_bytes": (_sz, [_i32]),
     "cmh_msl_loss": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _sz, _p]),
     "cmh_msl_loss_backward": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
+    "cmh_spl_workspace_bytes": (_sz, [_i32]),
+    "cmh_spl_loss": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _f, _f, _p, _p, _sz, _p]),
+    "cmh_spl_loss_backward": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _f, _f, _p, _p, _p, _p, _sz, _p]),
     "cmh_qmi_workspace_bytes": (_sz, [_i32]),
     "cmh_qmi_loss": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _f, _p, _p, _p, _sz, _p]),
     "cmh_qmi_loss_backward": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _f, _p, _p, _p, _p, _p, _sz, _p]),
@@ -560,6 +563,32 @@ def msl_loss_backward(feats, labels, feat2, dloss):
     check(lib().cmh_msl_loss_backward(ptr(feats), ptr(feat2), ptr(labels), B, K, labels.shape[1], ptr(f32c(dloss).reshape(1)),
                                       ptr(dfeats), ptr(dfeat2), ptr(ws), ws.numel(), stream_ptr(feats.device)), "cmh_msl_loss_backward")
     return dfeats, dfeat2
+
+
+def spl_loss(a, b, labels, temperature, delta):
+    """DHaPH self-paced contrastive loss (train/DHaPH/MSLoss.py:13-33); b = None: a against itself -> loss 0-dim"""
+    a, labels = f32c(a), f32c(labels)
+    b = None if b is None else f32c(b)
+    require_gpu(a, labels, b)
+    B, K = a.shape
+    fit("spl_loss", (labels, (B, labels.shape[1])), (b, (B, K)))
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
+    ws = workspace(lib().cmh_spl_workspace_bytes(B), a.device, "loss")
+    check(lib().cmh_spl_loss(ptr(a), ptr(b), ptr(labels), B, K, labels.shape[1], float(temperature), float(delta), ptr(out), ptr(ws),
+                             ws.numel(), stream_ptr(a.device)), "cmh_spl_loss")
+    return out[0]
+
+
+def spl_loss_backward(a, b, labels, temperature, delta, dloss):
+    """-> (da, db | None); with b = None the gradients of both roles of a are summed into da"""
+    B, K = a.shape
+    da = torch.empty_like(a)
+    db = None if b is None else torch.empty_like(b)
+    ws = workspace(lib().cmh_spl_workspace_bytes(B), a.device, "loss")
+    check(lib().cmh_spl_loss_backward(ptr(a), ptr(b), ptr(labels), B, K, labels.shape[1], float(temperature), float(delta),
+                                      ptr(f32c(dloss).reshape(1)), ptr(da), ptr(db), ptr(ws), ws.numel(), stream_ptr(a.device)),
+          "cmh_spl_loss_backward")
+    return da, db
 
 
 def qmi_loss(img, txt, label, eps=1e-8):

@@ -190,9 +190,204 @@ __global__ __launch_bounds__(256) void msl_bwd_cols_kernel(const float* __restri
   }
 }
 
+// ---- DHaPH self-paced contrastive loss: reference train/DHaPH/MSLoss.py:13-33 -------------------------------------------------------
+//   same = labels . labels^T > 0;  s = cos(a_i, b_j) (F.normalize, eps 1e-12);  e = exp(s / tau)
+//   self-paced weights (DETACHED, :28-29): w+ = exp(-1 - s)^(delta / 4) on the similar pairs, w- = exp(-1 + s)^delta on the others,
+//   delta = epoch / int(total / 3) up to a third of the run, then 1 (:23-27; delta = 0 <=> self_paced = False)
+//   loss = mean_i -log(P_i / (P_i + N_i)),  P_i = sum_same e w+,  N_i = sum_other e w-
+// Backward (weights are constants): d loss / d s_ij = (1 / (B tau)) [ e w (1 / (P_i + N_i)) - same_ij e w+ / P_i ], then through both
+// normalisations; a = b (the image-image / text-text calls): the two roles' gradients are added.
+// Workspace use: S = the cosines, same bits, row[i] = {P_i, N_i, loss_i}, G = d loss / d s, norms after row.
+__global__ __launch_bounds__(256) void spl_norms_kernel(const float* __restrict__ a, const float* __restrict__ b, int B, int K,
+                                                        float* __restrict__ norms) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= 2 * B) return;
+  const float* src = row < B ? a + static_cast<size_t>(row) * K : b + static_cast<size_t>(row - B) * K;
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s = fmaf(src[k], src[k], s);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) norms[row] = fmaxf(sqrtf(s), 1e-12f);
+}
+
+__global__ __launch_bounds__(256) void spl_rows_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                       const float* __restrict__ lab, const float* __restrict__ norms, int B, int K,
+                                                       int C, float inv_tau, float delta, MslWs w) {
+  __shared__ float sa[kMslMaxK], sl[kMslMaxK];
+  __shared__ float redf[4];
+  const int i = blockIdx.x, tid = threadIdx.x;
+  const float na = norms[i];
+  for (int k = tid; k < K; k += 256) sa[k] = a[static_cast<size_t>(i) * K + k] / na;
+  for (int k = tid; k < C; k += 256) sl[k] = lab[static_cast<size_t>(i) * C + k];
+  __syncthreads();
+  float* Si = w.S + static_cast<size_t>(i) * B;
+  uint8_t* Li = w.same + static_cast<size_t>(i) * B;
+  float P = 0.f, Nn = 0.f;
+  for (int j = tid; j < B; j += 256) {
+    const float* bj = b + static_cast<size_t>(j) * K;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s = fmaf(sa[k], bj[k], s);
+    s /= norms[B + j];
+    const float* lj = lab + static_cast<size_t>(j) * C;
+    float l = 0.f;
+    for (int k = 0; k < C; ++k) l = fmaf(sl[k], lj[k], l);
+    const bool same = l > 0.f;
+    Si[j] = s;
+    Li[j] = same ? 1 : 0;
+    const float e = expf(s * inv_tau);
+    if (same) P += e * expf((-1.f - s) * (delta * 0.25f));
+    else Nn += e * expf((-1.f + s) * delta);
+  }
+  auto addf = [](float x, float y) { return x + y; };
+  P = msl_block_reduce(P, redf, addf);
+  Nn = msl_block_reduce(Nn, redf, addf);
+  if (tid == 0) {
+    float* r = w.row + static_cast<size_t>(i) * 8;
+    r[0] = P; r[1] = Nn; r[6] = -logf(P / (Nn + P));
+  }
+}
+
+// G[i, :] = d loss / d s[i, :];  da[i, :] = through the normalisation of a_i of sum_j G[i, j] bn_j
+__global__ __launch_bounds__(256) void spl_bwd_rows_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           const float* __restrict__ norms, int B, int K, float inv_tau, float delta,
+                                                           MslWs w, const float* __restrict__ dloss, float* __restrict__ da) {
+  extern __shared__ float grow[];                    // [B] g_ij / |b_j|
+  __shared__ float redf[4];
+  const int i = blockIdx.x, tid = threadIdx.x;
+  const float* r = w.row + static_cast<size_t>(i) * 8;
+  const float P = r[0], Nn = r[1];
+  const float up = (dloss ? dloss[0] : 1.f) * inv_tau / static_cast<float>(B);
+  const float* Si = w.S + static_cast<size_t>(i) * B;
+  const uint8_t* Li = w.same + static_cast<size_t>(i) * B;
+  float* Gi = w.G + static_cast<size_t>(i) * B;
+  for (int j = tid; j < B; j += 256) {
+    const float s = Si[j];
+    const float e = expf(s * inv_tau);
+    float g;
+    if (Li[j]) { const float ew = e * expf((-1.f - s) * (delta * 0.25f)); g = up * ew * (1.f / (P + Nn) - 1.f / P); }
+    else g = up * e * expf((-1.f + s) * delta) / (P + Nn);
+    Gi[j] = g;
+    grow[j] = g / norms[B + j];
+  }
+  __syncthreads();
+  const float na = norms[i];
+  float dot = 0.f;
+  float dv[4];                                       // K <= 1024: four columns per thread
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int k = tid + 256 * q;
+    dv[q] = 0.f;
+    if (k < K) {
+      float a0 = 0.f, a1 = 0.f;
+      int j = 0;
+      for (; j + 2 <= B; j += 2) {
+        a0 = fmaf(grow[j], b[static_cast<size_t>(j) * K + k], a0);
+        a1 = fmaf(grow[j + 1], b[static_cast<size_t>(j + 1) * K + k], a1);
+      }
+      for (; j < B; ++j) a0 = fmaf(grow[j], b[static_cast<size_t>(j) * K + k], a0);
+      dv[q] = a0 + a1;                               // d loss / d an_i[k]
+      dot = fmaf(dv[q], a[static_cast<size_t>(i) * K + k] / na, dot);
+    }
+  }
+  dot = msl_block_reduce(dot, redf, [](float x, float y) { return x + y; });
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int k = tid + 256 * q;
+    if (k < K) da[static_cast<size_t>(i) * K + k] = (dv[q] - a[static_cast<size_t>(i) * K + k] / na * dot) / na;
+  }
+}
+
+// db[j, :] (accumulate ? += : =) through the normalisation of b_j of sum_i G[i, j] an_i
+__global__ __launch_bounds__(256) void spl_bwd_cols_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           const float* __restrict__ norms, int B, int K, MslWs w, int accumulate,
+                                                           float* __restrict__ db) {
+  extern __shared__ float gcol[];                    // [B] G[i, j] / |a_i|
+  __shared__ float redf[4];
+  const int j = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < B; i += 256) gcol[i] = w.G[static_cast<size_t>(i) * B + j] / norms[i];
+  __syncthreads();
+  const float nb = norms[B + j];
+  float dot = 0.f;
+  float dv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int k = tid + 256 * q;
+    dv[q] = 0.f;
+    if (k < K) {
+      float a0 = 0.f, a1 = 0.f;
+      int i = 0;
+      for (; i + 2 <= B; i += 2) {
+        a0 = fmaf(gcol[i], a[static_cast<size_t>(i) * K + k], a0);
+        a1 = fmaf(gcol[i + 1], a[static_cast<size_t>(i + 1) * K + k], a1);
+      }
+      for (; i < B; ++i) a0 = fmaf(gcol[i], a[static_cast<size_t>(i) * K + k], a0);
+      dv[q] = a0 + a1;
+      dot = fmaf(dv[q], b[static_cast<size_t>(j) * K + k] / nb, dot);
+    }
+  }
+  dot = msl_block_reduce(dot, redf, [](float x, float y) { return x + y; });
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int k = tid + 256 * q;
+    if (k < K) {
+      const float v = (dv[q] - b[static_cast<size_t>(j) * K + k] / nb * dot) / nb;
+      float* o = db + static_cast<size_t>(j) * K + k;
+      *o = accumulate ? *o + v : v;
+    }
+  }
+}
+
 }  // namespace cmh
 
 using namespace cmh;
+
+extern "C" size_t cmh_spl_workspace_bytes(int32_t B) {
+  if (B <= 0) return 0;
+  return msl_carve(nullptr, static_cast<size_t>(B)).total + align_up(static_cast<size_t>(B) * 8, 256);
+}
+
+static int spl_check(const float* a, const float* labels, int B, int K, int C, float tau, float delta, void* ws, size_t ws_bytes, const char* what) {
+  CMH_CHECK_ARG(a && labels && ws, "%s: null pointer", what);
+  CMH_CHECK_ARG(B > 0 && B <= 16384 && K > 0 && K <= kMslMaxK && C > 0 && C <= kMslMaxK, "%s: bad shape B=%d K=%d C=%d", what, B, K, C);
+  CMH_CHECK_ARG(tau > 0.f && delta >= 0.f && delta <= 1.f, "%s: temperature %g, delta %g", what, tau, delta);
+  if (ws_bytes < cmh_spl_workspace_bytes(B)) return fail(CMH_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, cmh_spl_workspace_bytes(B));
+  return CMH_OK;
+}
+
+extern "C" int cmh_spl_loss(const float* a, const float* b, const float* labels, int32_t B, int32_t K, int32_t C, float temperature,
+                            float delta, float* loss, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = spl_check(a, labels, B, K, C, temperature, delta, workspace, workspace_bytes, "spl_loss");
+  if (rc) return rc;
+  CMH_CHECK_ARG(loss, "spl_loss: null pointer");
+  const MslWs w = msl_carve(workspace, static_cast<size_t>(B));
+  float* norms = reinterpret_cast<float*>(reinterpret_cast<char*>(w.row) + align_up(static_cast<size_t>(B) * 32, 256));
+  hipStream_t st = as_stream(stream);
+  const float* bb = b ? b : a;
+  hipLaunchKernelGGL(spl_norms_kernel, dim3((2 * B + 3) / 4), dim3(256), 0, st, a, bb, B, K, norms);
+  hipLaunchKernelGGL(spl_rows_kernel, dim3(B), dim3(256), 0, st, a, bb, labels, norms, B, K, C, 1.0f / temperature, delta, w);
+  hipLaunchKernelGGL(msl_sum_kernel, dim3(1), dim3(64), 0, st, w.row, B, loss);
+  CMH_CHECK_LAUNCH("spl_loss");
+  return CMH_OK;
+}
+
+extern "C" int cmh_spl_loss_backward(const float* a, const float* b, const float* labels, int32_t B, int32_t K, int32_t C,
+                                     float temperature, float delta, const float* dloss, float* da, float* db, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  int rc = spl_check(a, labels, B, K, C, temperature, delta, workspace, workspace_bytes, "spl_loss_backward");
+  if (rc) return rc;
+  CMH_CHECK_ARG(da && (!b || db), "spl_loss_backward: null gradient pointer");
+  const MslWs w = msl_carve(workspace, static_cast<size_t>(B));
+  float* norms = reinterpret_cast<float*>(reinterpret_cast<char*>(w.row) + align_up(static_cast<size_t>(B) * 32, 256));
+  hipStream_t st = as_stream(stream);
+  const float* bb = b ? b : a;
+  const size_t lds = static_cast<size_t>(B) * 4;
+  hipLaunchKernelGGL(spl_norms_kernel, dim3((2 * B + 3) / 4), dim3(256), 0, st, a, bb, B, K, norms);
+  hipLaunchKernelGGL(spl_rows_kernel, dim3(B), dim3(256), 0, st, a, bb, labels, norms, B, K, C, 1.0f / temperature, delta, w);
+  hipLaunchKernelGGL(spl_bwd_rows_kernel, dim3(B), dim3(256), lds, st, a, bb, norms, B, K, 1.0f / temperature, delta, w, dloss, da);
+  hipLaunchKernelGGL(spl_bwd_cols_kernel, dim3(B), dim3(256), lds, st, a, bb, norms, B, K, w, b ? 0 : 1, b ? db : da);
+  CMH_CHECK_LAUNCH("spl_loss_backward");
+  return CMH_OK;
+}
 
 extern "C" size_t cmh_msl_workspace_bytes(int32_t B) {
   if (B <= 0) return 0;

@@ -14,8 +14,9 @@ _REGISTRY = {
     'MITH': ("train.MITH.hash_train", "MITHTrainer"),
     'DNpH': ("train.DNpH_TMM.hash_train", "DNpHTMMTrainer"),
     'DMsH_LN': ("train.DMsH_LN.hash_train", "DMsH_LNTrainer"),
+    'DHaPH': ("train.DHaPH.hash_train", "DHaPHTrainer"),
 }
-_NOT_BUILT = ['DHaPH', 'DPBE', 'DDWSH', 'DDBH', 'DScPH', 'DPSIH', 'DGHDGH']
+_NOT_BUILT = ['DPBE', 'DDWSH', 'DDBH', 'DScPH', 'DPSIH', 'DGHDGH']
 
 
 class _LazyTrainers(dict):

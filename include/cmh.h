@@ -235,6 +235,18 @@ int cmh_msl_loss(const float* feats, const float* feat2, const float* labels, in
 int cmh_msl_loss_backward(const float* feats, const float* feat2, const float* labels, int32_t B, int32_t K, int32_t Kl,
                           const float* dloss, float* dfeats, float* dfeat2, void* workspace, size_t workspace_bytes, void* stream);
 
+/* DHaPH self-paced contrastive loss, reference train/DHaPH/MSLoss.py:13-33 `MSLoss.forward(image_feature, text_feature, labels,
+ * epoch)`: a (and b, NULL = a: the image-image / text-text calls of train/DHaPH/hash_train.py:68-69) f32 [B,K] hash outputs, labels
+ * f32 [B,C] multi-hot -> loss f32 [1] = mean_i -log(P_i / (P_i + N_i)) over exp(cos / temperature) of the label-sharing / other
+ * pairs, with the detached self-paced weights exp(-1 - cos)^(delta/4) / exp(-1 + cos)^delta; delta in [0, 1] is what :23-27 derive
+ * from (epoch, totalepoch) (0 = self_paced off).  Backward: da (and db; with b = NULL both roles' gradients are summed into da) =
+ * dloss[0] (NULL: 1) * d loss / d a; it recomputes the forward's statistics.  B <= 16384, K, C <= 1024. */
+size_t cmh_spl_workspace_bytes(int32_t B);
+int cmh_spl_loss(const float* a, const float* b, const float* labels, int32_t B, int32_t K, int32_t C, float temperature, float delta,
+                 float* loss, void* workspace, size_t workspace_bytes, void* stream);
+int cmh_spl_loss_backward(const float* a, const float* b, const float* labels, int32_t B, int32_t K, int32_t C, float temperature,
+                          float delta, const float* dloss, float* da, float* db, void* workspace, size_t workspace_bytes, void* stream);
+
 /* f32 -> bf16 (round-to-nearest-even) copy used to prepare CMH_BF16 GEMM weights. */
 int cmh_cast_f32_to_bf16(const float* src, void* dst_bf16, int64_t n, void* stream);
 

@@ -31,3 +31,22 @@ def msl_loss(feats, labels, feat2=None, thresh=0.5, margin=0.1, scale_pos=2.0, s
             continue
         total += np.log1p(np.exp(-scale_pos * (pos - thresh)).sum()) / scale_pos + np.log1p(np.exp(scale_neg * (neg - thresh)).sum()) / scale_neg
     return np.float32(total / B)
+
+
+def spl_loss(image_feature, text_feature, labels, epoch, temperature=0.3, totalepoch=100, self_paced=True):
+    """DHaPH's self-paced contrastive loss, /root/reference/train/DHaPH/MSLoss.py:13-33 (pinned by tests/golden/spl.npz,
+    tests/golden/make_golden17.py)."""
+    f = np.float64
+    a, b, lab = image_feature.astype(f), text_feature.astype(f), labels.astype(f)
+    mask = (lab @ lab.T > 0).astype(f)                                                   # :15
+    an = a / np.maximum(np.sqrt((a * a).sum(1, keepdims=True)), 1e-12)
+    bn = b / np.maximum(np.sqrt((b * b).sum(1, keepdims=True)), 1e-12)
+    s = an @ bn.T                                                                        # :19
+    e = np.exp(s / temperature)
+    pos, neg = mask * e, (1 - mask) * e                                                  # :21-23
+    if self_paced:                                                                       # :25-31
+        third = int(totalepoch / 3)
+        delta = epoch / third if epoch <= third else 1
+        pos = pos * np.exp(-1 - s) ** (delta / 4)
+        neg = neg * np.exp(-1 + s) ** delta
+    return np.float32((-np.log(pos.sum(1) / (neg.sum(1) + pos.sum(1)))).mean())          # :32-33

@@ -18,3 +18,14 @@ def msl_case(B, K, C, p, epoch, seed=131):
     b2 = (-(np.maximum(lab @ w1.T + b1, 0).mean(0) @ w2.T)).astype(np.float32)
     return dict(tag=tag, epoch=epoch, lab=lab, w1=w1, b1=b1, w2=w2, b2=b2,
                 x=np.tanh(recipe.features(B, K, seed, f"msl_x_{tag}")), y=np.tanh(recipe.features(B, K, seed, f"msl_y_{tag}")))
+
+
+# DHaPH self-paced contrastive loss (train/DHaPH/MSLoss.py): (B, K, C, p, epoch, total_epochs)
+SPL_CASES = [(8, 16, 24, 0.3, 1, 100), (48, 32, 80, 0.08, 20, 100), (256, 64, 24, 0.15, 50, 100), (32, 128, 21, 0.2, 3, 2)]
+
+
+def spl_case(B, K, C, p, epoch, total, seed=151):
+    tag = f"B{B}_K{K}_C{C}_e{epoch}"
+    lab = recipe.labels(B, C, seed, p=p, tag=f"spl_lab_{tag}")
+    lab[lab.sum(1) == 0, 0] = 1.0            # an all-zero label row has no positive at all, not even itself: log(0) upstream
+    return dict(tag=tag, lab=lab, x=np.tanh(recipe.features(B, K, seed, f"spl_x_{tag}")), y=np.tanh(recipe.features(B, K, seed, f"spl_y_{tag}")))

@@ -242,7 +242,7 @@ def test_training_learns(tmp_path, monkeypatch):
     assert after[0] > before[0] + 0.06 and after[1] > before[1] + 0.04 and after[2] > before[2] + 0.12, (before, after)
 
 
-@pytest.mark.parametrize("method,K", [("DCHMT", 32), ("DNPH", 32), ("TwDH", 32), ("MITH", 16), ("DNpH", 32)])
+@pytest.mark.parametrize("method,K", [("DCHMT", 32), ("DNPH", 32), ("TwDH", 32), ("MITH", 16), ("DNpH", 32), ("DHaPH", 32)])
 def test_every_method_learns(tmp_path, monkeypatch, method, K):
     """The other four trainers on the same learnable synthetic set (eight short epochs each: their own heads, losses, backward
     kernels and the fused BertAdam): the image-to-text mAP and the sum of the four mAPs must rise (measured i->i: DCHMT 0.49 -> 0.59,

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from mslutil import CASES, msl_case
+from mslutil import CASES, SPL_CASES, msl_case, spl_case
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -59,3 +59,29 @@ def test_msl_refuses_what_is_not_built():
     x = torch.zeros(4, 8, device=DEV)
     with pytest.raises(NotImplementedError):
         MultiSimilarityLoss()(x, x, dataset="cifar10-1")
+
+
+@pytest.mark.parametrize("B,K,C,p,epoch,total", SPL_CASES)
+def test_dhaph_self_paced_losses_and_gradients_match_reference(golden, B, K, C, p, epoch, total):
+    """cmh_spl_loss / cmh_spl_loss_backward against the reference's MSLoss (train/DHaPH/MSLoss.py:6-33) and its autograd gradients,
+    the three calls of a training step summed as the trainer sums them (train/DHaPH/hash_train.py:68-70, 76)."""
+    from train.DHaPH.MSLoss import MSLoss
+    g = golden("spl.npz")
+    c = spl_case(B, K, C, p, epoch, total)
+    tag = c["tag"]
+    crit = MSLoss(temperature=0.3, totalepoch=total, self_paced=True)
+    x = torch.from_numpy(c["x"]).to(DEV).requires_grad_()
+    y = torch.from_numpy(c["y"]).to(DEV).requires_grad_()
+    lab = torch.from_numpy(c["lab"]).to(DEV)
+    losses = dict(ii=crit(x, x, lab, epoch), tt=crit(y, y, lab, epoch), it=crit(x, y, lab, epoch))
+    for name, l in losses.items():
+        want = float(g[f"{tag}_loss_{name}"])
+        assert abs(float(l.detach()) - want) < 1e-4 * max(1.0, abs(want)), (name, float(l.detach()), want)
+    with torch.no_grad():
+        plain = MSLoss(temperature=0.3, totalepoch=total, self_paced=False)(x, y, lab, epoch)
+    want = float(g[f"{tag}_loss_it_plain"])
+    assert abs(float(plain) - want) < 1e-4 * max(1.0, abs(want))
+    (2.0 * (losses["ii"] + losses["tt"] + losses["it"])).backward()
+    for got, name in ((x.grad, "gx"), (y.grad, "gy")):
+        ref = 2.0 * g[f"{tag}_{name}"]
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=2e-4, atol=2e-5 * np.abs(ref).max(), err_msg=name)

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("method", ["DSPH", "DCHMT", "TwDH", "DNPH", "MITH", "DNpH", "DMsH_LN"])
+@pytest.mark.parametrize("method", ["DSPH", "DCHMT", "TwDH", "DNPH", "MITH", "DNpH", "DMsH_LN", "DHaPH"])
 def test_two_ranks_stay_replicas(tmp_path, method):
     env = dict(os.environ, CMH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -40,7 +40,7 @@ def test_two_ranks_stay_replicas(tmp_path, method):
     assert len(list(run.glob("model-*.pth"))) == 2
 
 
-@pytest.mark.parametrize("method", ["DSPH", "DCHMT", "MITH", "DNpH", "DMsH_LN"])
+@pytest.mark.parametrize("method", ["DSPH", "DCHMT", "MITH", "DNpH", "DMsH_LN", "DHaPH"])
 def test_two_ranks_equal_one_rank(tmp_path, method):
     """north_star / SURVEY 8e: the pairwise loss sees the GLOBAL batch and evaluation shards the queries.  One step of two ranks
     (8 samples each) must reproduce one step of one process on the 16 samples: the same loss, the same gradients on every

@@ -60,8 +60,8 @@ def test_registry_is_lazy_and_cli_tolerant(monkeypatch):
     t = main.trainers.get("DSPH")
     assert t.__name__ == "DSPHTrainer"
     with pytest.raises(NotImplementedError):
-        main.trainers["DHaPH"]
-    for m in ("DCHMT", "TwDH", "DNPH", "MITH"):
+        main.trainers["DScPH"]
+    for m in ("DCHMT", "TwDH", "DNPH", "MITH", "DNpH", "DMsH_LN", "DHaPH"):
         assert main.trainers[m].__name__.endswith("Trainer")
     # both parsers tolerate each other's flags
     monkeypatch.setattr(sys, "argv", ["main.py", "--method", "DSPH", "--dataset", "synthetic", "--output-dim", "64",

@@ -75,3 +75,19 @@ def test_dmsh_ln_label_net_and_multi_similarity_loss(golden, B, K, C, p, epoch):
         want = float(g[f"{tag}_loss_{name}"])
         got = float(msl_loss(a, code, b))
         assert abs(got - want) < 2e-5 * max(1.0, abs(want)), (name, got, want)
+
+
+@pytest.mark.parametrize("B,K,C,p,epoch,total", [(8, 16, 24, 0.3, 1, 100), (48, 32, 80, 0.08, 20, 100), (256, 64, 24, 0.15, 50, 100), (32, 128, 21, 0.2, 3, 2)])
+def test_dhaph_self_paced_loss(golden, B, K, C, p, epoch, total):
+    """numpy restatement of train/DHaPH/MSLoss.py:13-33 against the reference's own values (tests/golden/make_golden17.py)."""
+    from mslutil import spl_case
+    from oracle.msl_oracle import spl_loss
+    g = golden("spl.npz")
+    c = spl_case(B, K, C, p, epoch, total)
+    tag = c["tag"]
+    for name, (a, b) in (("ii", (c["x"], c["x"])), ("tt", (c["y"], c["y"])), ("it", (c["x"], c["y"]))):
+        want = float(g[f"{tag}_loss_{name}"])
+        got = float(spl_loss(a, b, c["lab"], epoch, totalepoch=total))
+        assert abs(got - want) < 2e-5 * max(1.0, abs(want)), (name, got, want)
+    want = float(g[f"{tag}_loss_it_plain"])
+    assert abs(float(spl_loss(c["x"], c["y"], c["lab"], epoch, totalepoch=total, self_paced=False)) - want) < 2e-5 * max(1.0, abs(want))

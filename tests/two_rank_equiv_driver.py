@@ -49,7 +49,7 @@ if method == "MITH":
     tr.backward(loss)
 else:
     image, text, label, index = batch
-    loss = tr._step(image, text, label) if method in ("DSPH", "DNPH", "DCHMT", "DNpH", "DMsH_LN") else tr._step(image, text, label, index)
+    loss = tr._step(image, text, label) if method in ("DSPH", "DNPH", "DCHMT", "DNpH", "DMsH_LN", "DHaPH") else tr._step(image, text, label, index)
 grads = {}
 for name, p in tr.model.named_parameters():
     if p.grad is not None and any(k in name for k in ("proj", "hash", "resblocks.0.attn.in_proj_weight", "resblocks.1.mlp.c_fc.weight",
