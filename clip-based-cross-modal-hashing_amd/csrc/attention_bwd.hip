@@ -134,15 +134,17 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const T* __restrict_
 }  // namespace cmh
 
 // ============================================================================================================================
-// bf16 MFMA version (T <= 128): one 256-thread workgroup per (batch, head), every operand a plain row-major [rows][k] bf16 matrix
-// in LDS so that each of the five products is  out[i][j] = sum_k A[i][k] B[j][k]  on v_mfma_f32_16x16x32_bf16:
-//   S  [q][key] = Q . K^T          (A = Q,    B = K,    k = head dim)      dP [q][key] = dO . V^T     (A = dO,   B = V)
-//   dV^T[hd][key] = dO^T . P^T^T   (A = dO^T, B = P^T,  k = queries)       dK^T[hd][key] = Q^T . dS^T^T (A = Q^T, B = dS^T)
-//   dQ^T[hd][q]   = K^T . dS^T     (A = K^T,  B = dS,   k = keys)
-// Q, K, dO are staged twice (row-major and transposed), V once; a wave owns query tiles: it keeps the S and dP accumulators of
-// its 16 queries against all keys in registers, does the row softmax, D_q = sum_key P dP and dS = P (dP - D) / 8 there
-// (reductions across the 16 lanes of a row), and writes P^T, dS, dS^T (bf16) back to LDS for the second phase.
-// The three output products write 4 consecutive head-dim values per lane (8-byte stores), like the forward kernel.
+// bf16 MFMA version (T <= 96): one workgroup per (batch, head).  Q, K, V, dO are staged ONCE, row-major [rows][64] in LDS; the five
+// products  out[i][j] = sum_k A[i][k] B[j][k]  run on v_mfma_f32_16x16x32_bf16:
+//   S  [q][key] = Q . K^T      (A = Q,  B = K,  k = head dim)           dP [q][key] = dO . V^T   (A = dO, B = V)
+//   dV^T[hd][key] = sum_q   dO[q][hd]  P^T[key][q]                       dK^T[hd][key] = sum_q Q[q][hd] dS^T[key][q]
+//   dQ^T[hd][q]   = sum_key K[key][hd] dS^T[key][q]
+// The three output products contract over ROWS of the staged matrices: their A fragments (and dQ's B fragment) come out of the
+// row-major images through ds_read_b64_tr_b16 (lane c of a 16-lane group gets column c of a 4-row x 16-column block; two reads per
+// fragment, k order 4g..4g+3, 16+4g..16+4g+3) - no transposed copies (round 1 wrote Q^T, K^T, dO^T with 24 two-byte LDS stores per
+// 16-byte slot: a third of the kernel), and the operand read the plain way takes the same k order as two 8-byte reads.
+// A wave owns query tiles: it keeps the S and dP accumulators of its 16 queries against all keys in registers, does the row softmax,
+// D_q = sum_key P dP and dS = P (dP - D) / 8 there, and writes P^T and dS^T ([key][q], bf16, 8-byte stores) for the second phase.
 namespace cmh {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 ab_bf16x8_t;
@@ -159,6 +161,27 @@ __device__ __forceinline__ ab_f32x4_t ab_mma(const bf16_t* A, int lda, int arow0
   return acc;
 }
 
+// fragment of the TRANSPOSE of a row-major image M[k][col]: "row" col0 + c, k = k0 + {4g..4g+3, 16+4g..16+4g+3}
+// (every lane of the wave must be active: the read gathers across the 16 lanes of a group)
+// rows >= `rows` do not exist in the image (the contraction is padded to a multiple of 32): those lanes point at `zero_addr`, 8 zero bytes
+__device__ __forceinline__ ab_bf16x8_t ab_frag_tr(uint32_t lds_base, int ld, int k0, int col0, int g, int c, int rows, uint32_t zero_addr) {
+  const int r0 = k0 + 4 * g + (c >> 2);
+  const uint32_t off = static_cast<uint32_t>((r0 * ld + col0 + 4 * (c & 3)) * 2);
+  const uint32_t a0 = r0 < rows ? lds_base + off : zero_addr;
+  const uint32_t a1 = r0 + 16 < rows ? lds_base + off + static_cast<uint32_t>(16 * ld * 2) : zero_addr;
+  uint2 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi));
+  return __builtin_bit_cast(ab_bf16x8_t, uint4{lo.x, lo.y, hi.x, hi.y});
+}
+// fragment of a row-major image M[row][k] in the same k order: two 8-byte reads
+__device__ __forceinline__ ab_bf16x8_t ab_frag_perm(const bf16_t* M, int ld, int row, int k0, int g) {
+  const uint2 lo = *reinterpret_cast<const uint2*>(M + static_cast<size_t>(row) * ld + k0 + 4 * g);
+  const uint2 hi = *reinterpret_cast<const uint2*>(M + static_cast<size_t>(row) * ld + k0 + 16 + 4 * g);
+  return __builtin_bit_cast(ab_bf16x8_t, uint4{lo.x, lo.y, hi.x, hi.y});
+}
+
 __device__ __forceinline__ float ab_row_max(float v) {      // over the 16 lanes c of a lane group g
   v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64));
   v = fmaxf(v, __shfl_xor(v, 4, 64)); v = fmaxf(v, __shfl_xor(v, 8, 64));
@@ -169,32 +192,33 @@ __device__ __forceinline__ float ab_row_sum(float v) {
   return v;
 }
 
+template <int NT> struct AbwdShape {
+  static constexpr int TR = NT * 16, KP = ((NT + 1) / 2) * 32;
+  static constexpr int LR = NT <= 4 ? 80 : 72;   // leading dimension of the [rows][64] images: 160-byte rows keep the transposing reads of a
+                                                 // 32-lane half on distinct banks (T <= 64); 144-byte rows (partly 2-way) let two workgroups
+                                                 // of the longer captions share a CU
+  static constexpr int LT = KP + 8;              // leading dimension of P^T / dS^T [key][q]
+  static constexpr bool ALIAS = NT <= 4;         // every wave owns at most one query tile: P^T takes over V's slot after phase 1
+  static constexpr int kTotal = 4 * TR * LR + (ALIAS ? 1 : 2) * TR * LT;      // bf16 elements
+  static_assert(!ALIAS || LT <= LR, "P^T must fit V's slot");
+};
+
 template <int NT>    // row tiles: TR = 16 * NT rows, contraction over rows padded to KP = 32 * ceil(NT / 2)
 __global__ __launch_bounds__(NT <= 4 ? 256 : 512) void attention_bwd_mfma_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                                  bf16_t* __restrict__ dqkv, int B, int Tmax, int d, int causal,
                                                                  const uint8_t* __restrict__ kpm, const int32_t* __restrict__ seq_off) {
-  constexpr int TR = NT * 16, KP = ((NT + 1) / 2) * 32;
-  constexpr int LR = 72;            // leading dimension of the [rows][64] matrices (144 B rows)
-  constexpr int LT = KP + 8;        // leading dimension of the [..][KP] matrices
+  using SH = AbwdShape<NT>;
+  constexpr int TR = SH::TR, KP = SH::KP, LR = SH::LR, LT = SH::LT, kTotal = SH::kTotal;
+  constexpr bool ALIAS = SH::ALIAS;
   extern __shared__ __attribute__((aligned(16))) bf16_t sm[];
   bf16_t* sQ = sm;                   // [TR][LR]
   bf16_t* sK = sQ + TR * LR;
   bf16_t* sV = sK + TR * LR;
   bf16_t* sDO = sV + TR * LR;
-  bf16_t* sQT = sDO + TR * LR;       // [64][LT]   Q^T
-  bf16_t* sKT = sQT + 64 * LT;
-  bf16_t* sDOT = sKT + 64 * LT;
-  // Up to 4 row tiles (T <= 64, the image tower) every wave owns at most one query tile, so phase 1 can finish reading Q, K, V
-  // before anything is written back: P^T, dS, dS^T then take over the Q, K, V slots and the image shrinks from 92 to 65 KB —
-  // two workgroups per CU, which is what this latency-bound kernel needs (one workgroup's loads hide behind the other's MFMAs).
-  constexpr bool ALIAS = NT <= 4;
-  static_assert(!ALIAS || LT <= LR, "aliased operands must fit the row-major slots");
-  bf16_t* sPT = ALIAS ? sQ : sDOT + 64 * LT;       // [TR][LT]   P^T  [key][q]
-  bf16_t* sDS = ALIAS ? sK : sPT + TR * LT;        // [TR][LT]   dS   [q][key]
-  bf16_t* sDST = ALIAS ? sV : sDS + TR * LT;       // [TR][LT]   dS^T [key][q]
-  constexpr int kTotal = 4 * TR * LR + 3 * 64 * LT + (ALIAS ? 0 : 3 * TR * LT);
+  bf16_t* sDST = sDO + TR * LR;      // [TR][LT]   dS^T [key][q]
+  bf16_t* sPT = ALIAS ? sV : sDST + TR * LT;       // [TR][LT]   P^T  [key][q]
 
-  // NT > 4 (captions longer than 64 tokens): the 136 KB image allows one workgroup per CU, so it gets 8 waves instead of 4
+  // NT > 4 (captions longer than 64 tokens): 8 waves share the query tiles
   constexpr int NW = NT <= 4 ? 4 : 8, NTH = 64 * NW;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, c = lane & 15;
   const int heads = d / HDB;
@@ -207,30 +231,18 @@ __global__ __launch_bounds__(NT <= 4 ? 256 : 512) void attention_bwd_mfma_kernel
   bf16_t* dqb = dqkv + row0 * ld + h * HDB;
 
   // ---- stage: zero everything (padding rows / columns must be exact zeros), then the real rows ------------------------
-  for (int i = tid; i < kTotal / 2; i += NTH) reinterpret_cast<uint32_t*>(sm)[i] = 0u;
+  for (int i = tid; i < kTotal / 8; i += NTH) reinterpret_cast<uint4*>(sm)[i] = uint4{0u, 0u, 0u, 0u};
   __syncthreads();
   for (int slot = tid; slot < Tn * 8; slot += NTH) {
     const int r = slot >> 3, ch = slot & 7;
-    const uint4 q = *reinterpret_cast<const uint4*>(qb + static_cast<size_t>(r) * ld + ch * 8);
-    const uint4 k = *reinterpret_cast<const uint4*>(qb + d + static_cast<size_t>(r) * ld + ch * 8);
-    const uint4 v = *reinterpret_cast<const uint4*>(qb + 2 * d + static_cast<size_t>(r) * ld + ch * 8);
-    const uint4 o = *reinterpret_cast<const uint4*>(dob + static_cast<size_t>(r) * d + ch * 8);
-    *reinterpret_cast<uint4*>(sQ + r * LR + ch * 8) = q;
-    *reinterpret_cast<uint4*>(sK + r * LR + ch * 8) = k;
-    *reinterpret_cast<uint4*>(sV + r * LR + ch * 8) = v;
-    *reinterpret_cast<uint4*>(sDO + r * LR + ch * 8) = o;
-    const uint32_t qw[4] = {q.x, q.y, q.z, q.w}, kw[4] = {k.x, k.y, k.z, k.w}, ow[4] = {o.x, o.y, o.z, o.w};
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int hd = ch * 8 + e, sh = (e & 1) * 16;
-      sQT[hd * LT + r] = static_cast<bf16_t>(qw[e >> 1] >> sh);
-      sKT[hd * LT + r] = static_cast<bf16_t>(kw[e >> 1] >> sh);
-      sDOT[hd * LT + r] = static_cast<bf16_t>(ow[e >> 1] >> sh);
-    }
+    *reinterpret_cast<uint4*>(sQ + r * LR + ch * 8) = *reinterpret_cast<const uint4*>(qb + static_cast<size_t>(r) * ld + ch * 8);
+    *reinterpret_cast<uint4*>(sK + r * LR + ch * 8) = *reinterpret_cast<const uint4*>(qb + d + static_cast<size_t>(r) * ld + ch * 8);
+    *reinterpret_cast<uint4*>(sV + r * LR + ch * 8) = *reinterpret_cast<const uint4*>(qb + 2 * d + static_cast<size_t>(r) * ld + ch * 8);
+    *reinterpret_cast<uint4*>(sDO + r * LR + ch * 8) = *reinterpret_cast<const uint4*>(dob + static_cast<size_t>(r) * d + ch * 8);
   }
   __syncthreads();
 
-  // ---- phase 1: per query tile: S, dP, softmax, D, dS -> P^T, dS, dS^T ------------------------------------------------------
+  // ---- phase 1: per query tile: S, dP, softmax, D, dS -> P^T, dS^T ------------------------------------------------------------
   const int nrt = (Tn + 15) >> 4;        // row tiles that hold real rows
   auto phase1_compute = [&](int ti, ab_f32x4_t (&s)[NT], ab_f32x4_t (&dp)[NT], float (&dsum)[4]) __attribute__((always_inline)) {
 #pragma unroll
@@ -287,17 +299,15 @@ __global__ __launch_bounds__(NT <= 4 ? 256 : 512) void attention_bwd_mfma_kernel
       for (int r = 0; r < 4; ++r) dsv[r] = s[tj][r] * (dp[tj][r] - dsum[r]) * 0.125f;
       *reinterpret_cast<uint2*>(sPT + key * LT + q0) = uint2{pack_bf16x2(s[tj][0], s[tj][1]), pack_bf16x2(s[tj][2], s[tj][3])};
       *reinterpret_cast<uint2*>(sDST + key * LT + q0) = uint2{pack_bf16x2(dsv[0], dsv[1]), pack_bf16x2(dsv[2], dsv[3])};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sDS[(q0 + r) * LT + key] = f32_to_bf16(dsv[r]);
     }
   };
   if constexpr (ALIAS) {
     ab_f32x4_t s[NT], dp[NT];
     float dsum[4];
     if (wid < nrt) phase1_compute(wid, s, dp, dsum);
-    __syncthreads();                      // every wave is done with Q, K, V: their slots become P^T, dS, dS^T
-    // the padding of the new matrices must be exact zeros where phase 2 reads it: rows >= Tn and columns >= Tn
-    for (int i = tid; i < 3 * TR * LR / 2; i += NTH) reinterpret_cast<uint32_t*>(sQ)[i] = 0u;
+    __syncthreads();                      // every wave is done with V: its slot becomes P^T
+    // the padding of P^T must be exact zeros where phase 2 reads it: rows >= Tn and columns >= Tn
+    for (int i = tid; i < TR * LR / 8; i += NTH) reinterpret_cast<uint4*>(sV)[i] = uint4{0u, 0u, 0u, 0u};
     __syncthreads();
     if (wid < nrt) phase1_write(wid, s, dp, dsum);
   } else {
@@ -311,12 +321,23 @@ __global__ __launch_bounds__(NT <= 4 ? 256 : 512) void attention_bwd_mfma_kernel
   __syncthreads();
 
   // ---- phase 2: dV, dK (contraction over queries), dQ (over keys); out[hd = 16th + 4g + r][row = 16tr + c] --------------------
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const uint32_t aDO = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lptr_t)sDO)), aQ = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lptr_t)sQ)),
+                 aK = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lptr_t)sK)), aDST = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lptr_t)sDST));
+  const uint32_t aZero = aQ + 64 * 2;      // columns 64.. of Q's row 0: padding, zero since the first pass, never written
   constexpr int KS = KP / 32;
-  for (int job = wid; job < 3 * nrt * 4; job += NW) {
+  for (int job = wid; job < 3 * nrt * 4; job += NW) {          // wave-uniform trip count: the transposing reads need every lane
     const int prod = job / (nrt * 4), rem = job - prod * nrt * 4, tr = rem >> 2, th = rem & 3;
-    const bf16_t* A = prod == 0 ? sDOT : (prod == 1 ? sQT : sKT);
-    const bf16_t* Bm = prod == 0 ? sPT : (prod == 1 ? sDST : sDS);
-    const ab_f32x4_t acc = ab_mma(A, LT, th * 16, Bm, LT, tr * 16, KS, g, c);
+    const uint32_t aA = prod == 0 ? aDO : (prod == 1 ? aQ : aK);
+    const bf16_t* Bn = prod == 0 ? sPT : sDST;
+    ab_f32x4_t acc = ab_f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const ab_bf16x8_t fa = ab_frag_tr(aA, LR, ks * 32, th * 16, g, c, TR, aZero);          // dO^T / Q^T / K^T [hd][row k]
+      const ab_bf16x8_t fb = prod == 2 ? ab_frag_tr(aDST, LT, ks * 32, tr * 16, g, c, TR, aZero)   // dS [q][key k] = (dS^T)^T
+                                       : ab_frag_perm(Bn, LT, tr * 16 + c, ks * 32, g);     // P^T / dS^T [key][q k]
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc, 0, 0, 0);
+    }
     const int row = tr * 16 + c;
     if (row < Tn) {
       bf16_t* op = dqb + (prod == 0 ? 2 * d : (prod == 1 ? d : 0)) + static_cast<size_t>(row) * ld + th * 16 + 4 * g;
@@ -328,8 +349,7 @@ __global__ __launch_bounds__(NT <= 4 ? 256 : 512) void attention_bwd_mfma_kernel
 template <int NT>
 static int launch_attention_bwd_mfma(const void* qkv, const void* dout, void* dqkv, int B, int T, int d, int causal,
                                      const uint8_t* kpm, const int32_t* seq_off, hipStream_t st) {
-  constexpr int TR = NT * 16, KP = ((NT + 1) / 2) * 32;
-  const size_t lds = (static_cast<size_t>(4) * TR * 72 + 3 * 64 * (KP + 8) + (NT <= 4 ? 0 : 3 * TR * (KP + 8))) * 2;
+  const size_t lds = static_cast<size_t>(AbwdShape<NT>::kTotal) * 2;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_mfma_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           static_cast<int>(lds)) != hipSuccess) return fail(CMH_ERR_LAUNCH, "attention_backward: cannot reserve %zu bytes of LDS", lds);
   hipLaunchKernelGGL(attention_bwd_mfma_kernel<NT>, dim3(B * (d / HDB)), dim3(NT <= 4 ? 256 : 512), lds, st, static_cast<const bf16_t*>(qkv),
