@@ -206,6 +206,7 @@ __global__ __launch_bounds__(1024) void colsum_final_multi_kernel(FinalJobs jobs
 // (column-summed by colsum_final_kernel).
 constexpr int kLnRows = 16;   // rows per workgroup: 800 workgroups for a 12 800-row layer (32 rows left the CUs at 1.5 waves per SIMD; 8 rows
                               // double the partial rows the final reduction has to add: measured slower in total)
+template <int NV>   // 256-column slices a lane owns: d <= 256 NV (sized to d: a 768-wide row keeps 3 slices of dg / db / gamma, not 4)
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ x, int xkind, const void* __restrict__ dy,
                                                             int dykind, const float* __restrict__ g, float* __restrict__ dx,
                                                             int accumulate, int M, int d, float* __restrict__ pg,
@@ -213,25 +214,24 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
                                                             bf16_t* __restrict__ dx_bf16) {
   __shared__ float red[2][4][1024];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int nv = (d + 255) / 256;
-  float gam[4][4], dg[4][4], db[4][4];
+  float gam[NV][4], dg[NV][4], db[NV][4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < NV; ++j)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int e = lane * 4 + 256 * j + k;
-      gam[j][k] = (j < nv && e < d) ? g[e] : 0.f;
+      gam[j][k] = (e < d) ? g[e] : 0.f;
       dg[j][k] = 0.f; db[j][k] = 0.f;
     }
   const int rbase = blockIdx.x * kLnRows;
   // two rows per wave and iteration: both rows' loads are issued before either is reduced, so the second row's memory latency hides
   // under the first row's three butterflies (one row at a time the kernel ran at 2.8 TB/s: 49 us for the 137 MB of a vision layer)
-  auto load_row = [&](int row, float (&xv)[4][4], float (&dv)[4][4]) -> size_t {
+  auto load_row = [&](int row, float (&xv)[NV][4], float (&dv)[NV][4]) -> size_t {
     const size_t xrow = row_index ? static_cast<size_t>(row_index[row]) : static_cast<size_t>(row);   // x / dx row (pooled rows)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NV; ++j) {
       const int e0 = lane * 4 + 256 * j;
-      const bool ok = j < nv && e0 < d;
+      const bool ok = e0 < d;
       const float4 xa = ok ? load4_as_f32(x, xrow * d + e0, xkind) : float4{0.f, 0.f, 0.f, 0.f};
       const float4 da = ok ? load4_as_f32(dy, static_cast<size_t>(row) * d + e0, dykind) : float4{0.f, 0.f, 0.f, 0.f};
       xv[j][0] = xa.x; xv[j][1] = xa.y; xv[j][2] = xa.z; xv[j][3] = xa.w;
@@ -239,31 +239,31 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
     }
     return xrow;
   };
-  auto do_row = [&](size_t xrow, float (&xv)[4][4], float (&dv)[4][4]) {
+  auto do_row = [&](size_t xrow, float (&xv)[NV][4], float (&dv)[NV][4]) {
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s += (xv[j][0] + xv[j][1]) + (xv[j][2] + xv[j][3]);
+    for (int j = 0; j < NV; ++j) s += (xv[j][0] + xv[j][1]) + (xv[j][2] + xv[j][3]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     const float mean = s / static_cast<float>(d);
     float ss = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NV; ++j)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int e = lane * 4 + 256 * j + k;
-        if (j < nv && e < d) { const float c = xv[j][k] - mean; ss += c * c; }
+        if (e < d) { const float c = xv[j][k] - mean; ss += c * c; }
       }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
     const float rstd = 1.0f / sqrtf(ss / static_cast<float>(d) + 1e-5f);
     float sa = 0.f, sax = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NV; ++j)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int e = lane * 4 + 256 * j + k;
-        if (j < nv && e < d) {
+        if (e < d) {
           const float xh = (xv[j][k] - mean) * rstd;
           const float a = dv[j][k] * gam[j][k];
           sa += a; sax += a * xh;
@@ -277,9 +277,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
     for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); sax += __shfl_xor(sax, o, 64); }
     const float ma = sa / static_cast<float>(d), max_ = sax / static_cast<float>(d);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NV; ++j) {
       const int e0 = lane * 4 + 256 * j;
-      if (j < nv && e0 < d) {
+      if (e0 < d) {
         float4* o = reinterpret_cast<float4*>(dx + xrow * d + e0);
         float4 v = float4{rstd * (dv[j][0] - ma - xv[j][0] * max_), rstd * (dv[j][1] - ma - xv[j][1] * max_),
                           rstd * (dv[j][2] - ma - xv[j][2] * max_), rstd * (dv[j][3] - ma - xv[j][3] * max_)};
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
     const int row = rbase + rr;
     if (row >= M) break;
     const bool two = row + 1 < M;
-    float xa[4][4], da[4][4], xb[4][4], dbv[4][4];
+    float xa[NV][4], da[NV][4], xb[NV][4], dbv[NV][4];
     const size_t ra = load_row(row, xa, da);
     const size_t rb = load_row(two ? row + 1 : row, xb, dbv);
     do_row(ra, xa, da);
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
   }
   // combine the 4 waves' dg / db columns, one partial row per workgroup
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < NV; ++j)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int e = lane * 4 + 256 * j + k;
@@ -423,8 +423,14 @@ int launch_layernorm_backward(const void* x, int x_kind, const void* dy, int dy_
   const int nb = (M + kLnRows - 1) / kLnRows;
   float* pg = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
   float* pb = pg + static_cast<size_t>(nb) * d;
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, st, x, x_kind, dy, dy_kind, gamma, dx, accumulate, M, d, pg, pb,
-                     row_index, static_cast<bf16_t*>(dx_bf16));
+#define LN_BWD(NV)                                                                                                          \
+  hipLaunchKernelGGL(layernorm_bwd_kernel<NV>, dim3(nb), dim3(256), 0, st, x, x_kind, dy, dy_kind, gamma, dx, accumulate, M, d, pg, \
+                     pb, row_index, static_cast<bf16_t*>(dx_bf16))
+  if (d <= 256) LN_BWD(1);
+  else if (d <= 512) LN_BWD(2);
+  else if (d <= 768) LN_BWD(3);
+  else LN_BWD(4);
+#undef LN_BWD
   CMH_CHECK_LAUNCH("layernorm_backward");
   if (defer && defer->n + 2 <= FinalJobs::kMax) {      // the caller launches the final stage later (the partials stay in `workspace`)
     defer->add(pg, nb, d, dgamma);
