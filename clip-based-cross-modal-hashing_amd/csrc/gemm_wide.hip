@@ -38,9 +38,6 @@ constexpr int wBM = 160, wBN = 256;
 constexpr int wRowBytes = 128;
 constexpr int wWBytes = wBN * wRowBytes;            // 32 KB
 constexpr int wXBytes = wBM * wRowBytes;            // 20 KB
-constexpr int wStageBytes = wWBytes + wXBytes;      // 52 KB
-constexpr int wXPieces = wBM / 8;                   // 20 pieces of 1 KiB
-constexpr int wPend = 10;                           // deferred 16-byte stores per lane per tile (5 m-tiles x 2 column pairs)
 
 __device__ __forceinline__ int w_swz(int row, int chunk) { return row * wRowBytes + ((chunk ^ (row & 7)) << 4); }
 // x * sigmoid(1.702 x) with v_exp + v_rcp (1 ulp) instead of an IEEE division (~10 VALU ops): the epilogue applies it to
