@@ -37,7 +37,6 @@ typedef __attribute__((ext_vector_type(2))) unsigned w_u2_t;
 constexpr int wBM = 160, wBN = 256;
 constexpr int wRowBytes = 128;
 constexpr int wWBytes = wBN * wRowBytes;            // 32 KB
-constexpr int wXBytes = wBM * wRowBytes;            // 20 KB
 
 __device__ __forceinline__ int w_swz(int row, int chunk) { return row * wRowBytes + ((chunk ^ (row & 7)) << 4); }
 // x * sigmoid(1.702 x) with v_exp + v_rcp (1 ulp) instead of an IEEE division (~10 VALU ops): the epilogue applies it to
