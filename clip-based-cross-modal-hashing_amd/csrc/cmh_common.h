@@ -154,6 +154,8 @@ int launch_text_embed_packed(const int64_t* tokens, const float* tok_emb, const 
                              int B, int L, int d, int vocab, const int32_t* seq_off, hipStream_t st);
 // cls_row[b] = b*T
 int launch_iota_rows(int32_t* rows, int B, int T, hipStream_t st);
+int launch_scatter_rows(const void* src, const int32_t* rows, void* dst, int B, int row_bytes, hipStream_t st);
+bool pooled_tail_enabled();     // encoders.hip: cmh_set_pooled_tail / CMH_POOLED_TAIL (default on)
 int launch_gather_rows2(const void* srcA, void* dstA, int bytesA, const void* srcB, void* dstB, int bytesB, const int32_t* rows, int B,
                         hipStream_t st);
 // gemm_wide.hip: split-K for few-tile / long-K products (wgrad); plan returns S (1 = do not split), partials = S*M*N floats

@@ -137,7 +137,7 @@ static int run_block(const cmh_block_weights& w, int dt, const TowerBufs& t, int
 // arithmetic of the full-size path (same kernels, same K order), so the features are bit-identical.  The compact rows live in the qkv
 // scratch, which is dead once the attention has run; *x_pooled [B, d] is the block's output (residual-stream type).
 static int g_pooled_tail = -1;   // -1: from the environment (default on)
-static bool pooled_tail_enabled() {
+bool pooled_tail_enabled() {
   static const bool env_on = []() { const char* e = getenv("CMH_POOLED_TAIL"); return !(e && !strcmp(e, "0")); }();
   return g_pooled_tail < 0 ? env_on : g_pooled_tail != 0;
 }

@@ -127,6 +127,13 @@ TrainBufs carve_train(void* ws, size_t M, size_t B, size_t d, size_t e, size_t x
   return t;
 }
 
+// the last block's row-wise tail on the pooled rows only (block_forward_train / block_backward): the rule both calls of a step apply,
+// so cmh_set_pooled_tail must not change between a tape's forward and its backward; CMH_TRAIN_POOLED_TAIL=0 keeps the training
+// towers on the full-size path
+bool train_pooled_tail() {
+  static const bool off = []() { const char* e = getenv("CMH_TRAIN_POOLED_TAIL"); return e && e[0] == '0'; }();
+  return !off && pooled_tail_enabled();
+}
 int xkind(int xh) { return xh ? kF16 : kF32; }
 int ekind(int dt) { return dt == CMH_BF16 ? kBF16 : kF32; }
 
@@ -145,27 +152,41 @@ int as_gemm_operand(int dt, const float* x, void* scratch, size_t n, hipStream_t
 
 struct BlockGradPtrs { float *in_w, *in_b, *out_w, *out_b, *ln1_w, *ln1_b, *ln2_w, *ln2_b, *fc_w, *fc_b, *proj_w, *proj_b; };
 
+// pooled_rows (the LAST block of a tower whose only output is the pooled feature, like encoders.hip::run_block_pooled): after the
+// attention the block's row-wise tail - out_proj, ln_2, the MLP - runs on the B pooled rows only.  The tape slots then hold B-row
+// matrices: x_mid, h2, pre, act rows [0, B); the pooled attention rows (out_proj's wgrad operand) sit in h2 rows [B, 2B); x_next
+// receives B rows.  block_backward(..., pooled_rows) reads them back the same way.
 int block_forward_train(const cmh_block_weights& w, int dt, int xh, const LayerTape& L, void* x_next, int B, int T,
-                        int d, int causal, const uint8_t* kpm, hipStream_t st, int rows = -1, const int32_t* seq_off = nullptr) {
+                        int d, int causal, const uint8_t* kpm, hipStream_t st, int rows = -1, const int32_t* seq_off = nullptr,
+                        const int32_t* pooled_rows = nullptr) {
   const int M = rows >= 0 ? rows : B * T;
   const int obf = dt == CMH_BF16 ? EPI_OUT_BF16 : 0;
   const int rx = EPI_BIAS | EPI_RESIDUAL | (xh ? EPI_RES_F16 | EPI_OUT_F16 : 0);
+  const size_t esz = dt == CMH_BF16 ? 2 : 4, xsz = xh ? 2 : 4;
   int rc;
   if ((rc = launch_layernorm_x(L.x_in, xh, nullptr, w.ln1_w, w.ln1_b, L.h1, dt == CMH_BF16, M, d, st))) return rc;
   if ((rc = launch_gemm(dt, L.h1, w.in_proj_w, w.in_proj_b, nullptr, L.qkv, M, 3 * d, d, EPI_BIAS | obf, st))) return rc;
   if ((rc = launch_attention_varlen(L.qkv, L.attn, dt, B, T, d, causal, kpm, seq_off, st))) return rc;
-  if ((rc = launch_gemm(dt, L.attn, w.out_proj_w, w.out_proj_b, static_cast<const float*>(L.x_in), L.x_mid, M, d, d, rx, st))) return rc;
-  if ((rc = launch_layernorm_x(L.x_mid, xh, nullptr, w.ln2_w, w.ln2_b, L.h2, dt == CMH_BF16, M, d, st))) return rc;
+  const void* attn = L.attn;
+  if (pooled_rows) {
+    void* attn_p = static_cast<char*>(L.h2) + static_cast<size_t>(B) * d * esz;
+    if ((rc = launch_gather_rows2(L.x_in, L.x_mid, static_cast<int>(d * xsz), L.attn, attn_p, static_cast<int>(d * esz), pooled_rows, B, st))) return rc;
+    attn = attn_p;
+  }
+  const int Mt = pooled_rows ? B : M;
+  const void* resid = pooled_rows ? L.x_mid : L.x_in;          // pooled: the gathered residual rows are updated in place
+  if ((rc = launch_gemm(dt, attn, w.out_proj_w, w.out_proj_b, static_cast<const float*>(resid), L.x_mid, Mt, d, d, rx, st))) return rc;
+  if ((rc = launch_layernorm_x(L.x_mid, xh, nullptr, w.ln2_w, w.ln2_b, L.h2, dt == CMH_BF16, Mt, d, st))) return rc;
   static const bool fuse_act = []() { const char* e = getenv("CMH_FUSE_PRE"); return !(e && e[0] == '0'); }();
   if (dt == CMH_BF16 && (4 * d) % 256 == 0 && fuse_act) {   // the N % 256 == 0 GEMM kernel has the epilogue
     // one launch: the activation from the f32 accumulator into L.act, the bf16 pre-activation into L.pre (EPI_SAVE_PRE)
-    if ((rc = launch_gemm(dt, L.h2, w.fc_w, w.fc_b, static_cast<const float*>(L.pre), L.act, M, 4 * d, d,
+    if ((rc = launch_gemm(dt, L.h2, w.fc_w, w.fc_b, static_cast<const float*>(L.pre), L.act, Mt, 4 * d, d,
                           EPI_BIAS | EPI_QUICKGELU | EPI_SAVE_PRE | obf, st))) return rc;
   } else {
-    if ((rc = launch_gemm(dt, L.h2, w.fc_w, w.fc_b, nullptr, L.pre, M, 4 * d, d, EPI_BIAS | obf, st))) return rc;
-    if ((rc = cmh_quick_gelu(L.pre, L.act, static_cast<int64_t>(M) * 4 * d, ekind(dt), st))) return rc;
+    if ((rc = launch_gemm(dt, L.h2, w.fc_w, w.fc_b, nullptr, L.pre, Mt, 4 * d, d, EPI_BIAS | obf, st))) return rc;
+    if ((rc = cmh_quick_gelu(L.pre, L.act, static_cast<int64_t>(Mt) * 4 * d, ekind(dt), st))) return rc;
   }
-  if ((rc = launch_gemm(dt, L.act, w.proj_w, w.proj_b, static_cast<const float*>(L.x_mid), x_next, M, d, 4 * d, rx, st))) return rc;
+  if ((rc = launch_gemm(dt, L.act, w.proj_w, w.proj_b, static_cast<const float*>(L.x_mid), x_next, Mt, d, 4 * d, rx, st))) return rc;
   return CMH_OK;
 }
 
@@ -225,10 +246,17 @@ int dgrad(int dt, const void* dYe, const void* W, int O, int I, int M, const voi
   return launch_gemm(dt, dYe, Wt, nullptr, static_cast<const float*>(aux), dX, M, I, O, epi, st);
 }
 
+int zero_pad_buffers(TrainBufs& t, size_t M, hipStream_t st);
+
+// pooled_rows / dxp (the last block after block_forward_train(..., pooled_rows)): the incoming gradient is dxp [B, d] f32 on the
+// pooled rows; steps 1-4 run on those B rows, then the two gradients that go on - d(attention output) and the residual stream -
+// are scattered into zeroed full-size buffers for the attention backward and ln_1.
 int block_backward(const cmh_block_weights& w, const BlockGradPtrs& g, int dt, int xh, const LayerTape& L, TrainBufs& t, int B,
                    int T, int d, int causal, const uint8_t* kpm, hipStream_t st, bool dxe_ready, int rows = -1,
-                   const int32_t* seq_off = nullptr) {
+                   const int32_t* seq_off = nullptr, const int32_t* pooled_rows = nullptr, float* dxp = nullptr) {
   const int M = rows >= 0 ? rows : B * T;
+  const int Mt = pooled_rows ? B : M;                  // rows of the row-wise tail (steps 1-4)
+  float* dxt = pooled_rows ? dxp : t.dx;               // its gradient stream
   const int obf = dt == CMH_BF16 ? EPI_OUT_BF16 : 0;
   const int ek = ekind(dt), xk = xkind(xh);
   const size_t md = static_cast<size_t>(M) * d;
@@ -253,26 +281,39 @@ int block_backward(const cmh_block_weights& w, const BlockGradPtrs& g, int dt, i
   void* wdst[4] = {wt, wt + 4 * dd * esz, wt + 8 * dd * esz, wt + 9 * dd * esz};
   const int wR[4] = {d, 4 * d, d, 3 * d}, wC[4] = {4 * d, d, d, d};
   if ((rc = launch_transpose_multi(wsrc, wdst, wR, wC, 4, ek, st))) return rc;
+  if (pooled_rows && (rc = zero_pad_buffers(t, static_cast<size_t>(B), st))) return rc;      // the tail's transposes are B rows wide
   // 1. MLP projection (dxe_ready: the previous block's ln_1 backward already wrote t.dxe)
+  const size_t mtd = static_cast<size_t>(Mt) * d;
   if (dxe_ready && dx_copy) dxe = t.dxe;
-  else if ((rc = as_gemm_operand(dt, t.dx, t.dxe, md, st, &dxe))) return rc;
-  if ((rc = dgrad(dt, dxe, w.proj_w, d, 4 * d, M, L.pre, t.dpre, EPI_MUL_DQGELU | obf, t, st, wdst[0]))) return rc;
-  if ((rc = wgrad(dt, t.dx, kF32, d, L.act, ek, 4 * d, M, g.proj_w, g.proj_b, t, st, dj, batched ? off_proj : 0,
+  else if ((rc = as_gemm_operand(dt, dxt, t.dxe, mtd, st, &dxe))) return rc;
+  if ((rc = dgrad(dt, dxe, w.proj_w, d, 4 * d, Mt, L.pre, t.dpre, EPI_MUL_DQGELU | obf, t, st, wdst[0]))) return rc;
+  if ((rc = wgrad(dt, dxt, kF32, d, L.act, ek, 4 * d, Mt, g.proj_w, g.proj_b, t, st, dj, batched ? off_proj : 0,
                   dt == CMH_BF16 ? dxe : nullptr))) return rc;
   // 2. c_fc
-  if ((rc = dgrad(dt, t.dpre, w.fc_w, 4 * d, d, M, nullptr, t.dh, obf, t, st, wdst[1]))) return rc;
-  if ((rc = wgrad(dt, t.dpre, ek, 4 * d, L.h2, ek, d, M, g.fc_w, g.fc_b, t, st, dj, batched ? off_fc : 0))) return rc;
+  if ((rc = dgrad(dt, t.dpre, w.fc_w, 4 * d, d, Mt, nullptr, t.dh, obf, t, st, wdst[1]))) return rc;
+  if ((rc = wgrad(dt, t.dpre, ek, 4 * d, L.h2, ek, d, Mt, g.fc_w, g.fc_b, t, st, dj, batched ? off_fc : 0))) return rc;
   // 3. ln_2
-  if ((rc = launch_layernorm_backward(L.x_mid, xk, t.dh, ek, w.ln2_w, nullptr, M, d, t.dx, 1, g.ln2_w, g.ln2_b,
+  if ((rc = launch_layernorm_backward(L.x_mid, xk, t.dh, ek, w.ln2_w, nullptr, Mt, d, dxt, 1, g.ln2_w, g.ln2_b,
                                       batched ? red + off_ln2 : red, batched ? ln_ws : t.red_bytes, st, dx_copy, dj))) return rc;
   // 4. out_proj
   if (dx_copy) dxe = t.dxe;
-  else if ((rc = as_gemm_operand(dt, t.dx, t.dxe, md, st, &dxe))) return rc;
-  if ((rc = dgrad(dt, dxe, w.out_proj_w, d, d, M, nullptr, t.dh, obf, t, st, wdst[2]))) return rc;
-  if ((rc = wgrad(dt, t.dx, kF32, d, L.attn, ek, d, M, g.out_w, g.out_b, t, st, dj, batched ? off_out : 0,
+  else if ((rc = as_gemm_operand(dt, dxt, t.dxe, mtd, st, &dxe))) return rc;
+  const void* attn_rows = pooled_rows ? static_cast<const char*>(L.h2) + static_cast<size_t>(B) * d * esz : L.attn;
+  if ((rc = dgrad(dt, dxe, w.out_proj_w, d, d, Mt, nullptr, t.dh, obf, t, st, wdst[2]))) return rc;
+  if ((rc = wgrad(dt, dxt, kF32, d, attn_rows, ek, d, Mt, g.out_w, g.out_b, t, st, dj, batched ? off_out : 0,
                   dt == CMH_BF16 ? dxe : nullptr))) return rc;
+  const void* dattn = t.dh;
+  if (pooled_rows) {
+    // back to full size: d(attention output) is zero off the pooled rows (t.dxe is free now), the residual gradient likewise
+    if (hipMemsetAsync(t.dxe, 0, md * esz, st) != hipSuccess || hipMemsetAsync(t.dx, 0, md * 4, st) != hipSuccess)
+      return fail(CMH_ERR_LAUNCH, "backward: memset failed");
+    if ((rc = launch_scatter_rows(t.dh, pooled_rows, t.dxe, B, static_cast<int>(d * esz), st))) return rc;
+    if ((rc = launch_scatter_rows(dxp, pooled_rows, t.dx, B, d * 4, st))) return rc;
+    dattn = t.dxe;
+    if ((rc = zero_pad_buffers(t, static_cast<size_t>(M), st))) return rc;       // the B-row transposes left their rows in the padding
+  }
   // 5. attention
-  if ((rc = launch_attention_backward(dt, L.qkv, L.attn, t.dh, t.dqkv, B, T, d, causal, kpm, seq_off, st))) return rc;
+  if ((rc = launch_attention_backward(dt, L.qkv, L.attn, dattn, t.dqkv, B, T, d, causal, kpm, seq_off, st))) return rc;
   // 6. in_proj
   if ((rc = dgrad(dt, t.dqkv, w.in_proj_w, 3 * d, d, M, nullptr, t.dh, obf, t, st, wdst[3]))) return rc;
   if ((rc = wgrad(dt, t.dqkv, ek, 3 * d, L.h1, ek, d, M, g.in_w, g.in_b, t, st, dj, batched ? off_in : 0))) return rc;
@@ -333,9 +374,11 @@ __global__ __launch_bounds__(256) void pool_wgrad_kernel(const T* __restrict__ p
   }
 }
 
+// compact = the forward carried only the pooled rows through the last block (x_last holds B rows): the gradient stays compact too,
+// B rows of t.dx2, for block_backward(..., pooled_rows, dxp)
 int pooled_backward(int dt, int xh, const void* x_last, const int32_t* rows, const void* pool, const void* proj_t,
                     const float* ln_w, const float* dfeat, float* dproj, float* dln_w, float* dln_b, TrainBufs& t, int B, int M,
-                    int d, int E, hipStream_t st) {
+                    int d, int E, hipStream_t st, bool compact = false) {
   float* dpool = t.small;
   if (dt == CMH_F32) {
     hipLaunchKernelGGL(pool_dgrad_kernel<float>, dim3(B), dim3(256), 0, st, dfeat, static_cast<const float*>(proj_t), dpool, B, d, E);
@@ -345,6 +388,8 @@ int pooled_backward(int dt, int xh, const void* x_last, const int32_t* rows, con
     hipLaunchKernelGGL(pool_wgrad_kernel<bf16_t>, dim3(d), dim3(256), 0, st, static_cast<const bf16_t*>(pool), dfeat, dproj, B, d, E);
   }
   CMH_CHECK_LAUNCH("pooled projection backward");
+  if (compact)
+    return launch_layernorm_backward(x_last, xkind(xh), dpool, kF32, ln_w, nullptr, B, d, t.dx2, 0, dln_w, dln_b, t.red, t.red_bytes, st);
   if (hipMemsetAsync(t.dx, 0, static_cast<size_t>(M) * d * 4, st) != hipSuccess) return fail(CMH_ERR_LAUNCH, "backward: memset failed");
   return launch_layernorm_backward(x_last, xkind(xh), dpool, kF32, ln_w, rows, B, d, t.dx, 0, dln_w, dln_b, t.red, t.red_bytes, st);
 }
@@ -494,13 +539,15 @@ static int vit_forward_train_impl(const cmh_vit_weights* w, const float* image, 
   // x_pre = [cls ; patches] + positional (kept for ln_pre's backward), x_0 = ln_pre(x_pre)
   if ((rc = launch_vit_assemble(t.patch_out, w->class_embedding, w->positional_embedding, t.x_pre, B, g2, d, st))) return rc;
   if ((rc = launch_layernorm_any(t.x_pre, kF32, nullptr, w->ln_pre_w, w->ln_pre_b, t.L[0].x_in, xkind(xh), M, d, st))) return rc;
+  const bool tail = !tokens_out && train_pooled_tail();      // the same rule in vit_backward_impl
+  if ((rc = launch_iota_rows(t.rows, B, T, st))) return rc;
   for (int i = 0; i < w->layers; ++i) {
     void* nxt = i + 1 < w->layers ? t.L[i + 1].x_in : t.x_last;
-    if ((rc = block_forward_train(w->blocks[i], dt, xh, t.L[i], nxt, B, T, d, 0, nullptr, st))) return rc;
+    if ((rc = block_forward_train(w->blocks[i], dt, xh, t.L[i], nxt, B, T, d, 0, nullptr, st, -1, nullptr,
+                                  tail && i == w->layers - 1 ? t.rows : nullptr))) return rc;
   }
-  if ((rc = launch_iota_rows(t.rows, B, T, st))) return rc;
   if (tokens_out) return tokens_head_forward(dt, xh, t, w->ln_post_w, w->ln_post_b, w->proj_t, tokens_out, M, d, w->embed_dim, st);
-  if ((rc = launch_layernorm_x(t.x_last, xh, t.rows, w->ln_post_w, w->ln_post_b, t.pool, dt == CMH_BF16, B, d, st))) return rc;
+  if ((rc = launch_layernorm_x(t.x_last, xh, tail ? nullptr : t.rows, w->ln_post_w, w->ln_post_b, t.pool, dt == CMH_BF16, B, d, st))) return rc;
   const int bk = dt == CMH_F32 ? 32 : 64;
   if (w->embed_dim % 128 == 0 && d % bk == 0) return launch_gemm(dt, t.pool, w->proj_t, nullptr, nullptr, feat, B, w->embed_dim, d, 0, st);
   return launch_small_linear(dt, t.pool, w->proj_t, nullptr, nullptr, 1.f, CMH_ACT_NONE, feat, B, w->embed_dim, d, st);
@@ -534,14 +581,17 @@ static int vit_backward_impl(const cmh_vit_weights* w, int32_t batch, const floa
   hipStream_t st = as_stream(stream);
   TrainBufs t = carve_train(tape, static_cast<size_t>(M), B, d, e, xh ? 2 : 4, w->layers, static_cast<size_t>(B) * g2, pk, E);
   if ((rc = zero_pad_buffers(t, static_cast<size_t>(M), st))) return rc;
+  const bool tail = !dtokens && train_pooled_tail();
   if (dtokens) {
     if ((rc = tokens_head_backward(dt, xh, t, w->ln_post_w, w->ln_post_b, w->proj_t, dtokens, gr->proj, gr->ln_post_w, gr->ln_post_b, M, d,
                                    E, st))) return rc;
   } else if ((rc = pooled_backward(dt, xh, t.x_last, t.rows, t.pool, w->proj_t, w->ln_post_w, dfeat, gr->proj, gr->ln_post_w,
-                                   gr->ln_post_b, t, B, M, d, E, st))) return rc;
-  for (int i = w->layers - 1; i >= 0; --i)
+                                   gr->ln_post_b, t, B, M, d, E, st, tail))) return rc;
+  for (int i = w->layers - 1; i >= 0; --i) {
+    const bool last = i == w->layers - 1;
     if ((rc = block_backward(w->blocks[i], grads_of(gr->blocks[i]), dt, xh, t.L[i], t, B, T, d, 0, nullptr, st,
-                             i != w->layers - 1 || dtokens != nullptr))) return rc;
+                             !last || dtokens != nullptr, -1, nullptr, tail && last ? t.rows : nullptr, tail && last ? t.dx2 : nullptr))) return rc;
+  }
   // ln_pre, then the embeddings: x_pre[b,0] = cls + pos[0], x_pre[b,1+i] = patch_out[b*g2+i] + pos[1+i]
   if ((rc = launch_layernorm_backward(t.x_pre, kF32, t.dx, kF32, w->ln_pre_w, nullptr, M, d, t.dx2, 0, gr->ln_pre_w, gr->ln_pre_b,
                                       t.red, t.red_bytes, st))) return rc;
@@ -602,9 +652,11 @@ static int text_forward_train_impl(const cmh_text_weights* w, const int64_t* tok
   }
   if ((rc = launch_text_embed_packed(tokens, w->token_embedding, w->positional_embedding, t.L[0].x_in, xh, t.rows, B, L, d,
                                      w->vocab_size, seq_off, st))) return rc;
+  const bool tail = !tokens_out && train_pooled_tail();      // the same rule in text_backward_impl
   for (int i = 0; i < w->layers; ++i) {
     void* nxt = i + 1 < w->layers ? t.L[i + 1].x_in : t.x_last;
-    if ((rc = block_forward_train(w->blocks[i], dt, xh, t.L[i], nxt, B, L, d, 1, key_padding_mask, st, rows, seq_off))) return rc;
+    if ((rc = block_forward_train(w->blocks[i], dt, xh, t.L[i], nxt, B, L, d, 1, key_padding_mask, st, rows, seq_off,
+                                  tail && i == w->layers - 1 ? t.rows : nullptr))) return rc;
   }
   if (tokens_out) {
     if (eot_rows_out && hipMemcpyAsync(eot_rows_out, t.rows, static_cast<size_t>(B) * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
@@ -612,7 +664,7 @@ static int text_forward_train_impl(const cmh_text_weights* w, const int64_t* tok
     if (hipMemsetAsync(t.seq_off, 0, static_cast<size_t>(B + 1) * 4, st) != hipSuccess) return fail(CMH_ERR_LAUNCH, "text_forward_train_tokens: memset failed");
     return tokens_head_forward(dt, xh, t, w->ln_final_w, w->ln_final_b, w->text_projection_t, tokens_out, M, d, w->embed_dim, st);
   }
-  if ((rc = launch_layernorm_x(t.x_last, xh, t.rows, w->ln_final_w, w->ln_final_b, t.pool, dt == CMH_BF16, B, d, st))) return rc;
+  if ((rc = launch_layernorm_x(t.x_last, xh, tail ? nullptr : t.rows, w->ln_final_w, w->ln_final_b, t.pool, dt == CMH_BF16, B, d, st))) return rc;
   const int bk = dt == CMH_F32 ? 32 : 64;
   if (w->embed_dim % 128 == 0 && d % bk == 0)
     return launch_gemm(dt, t.pool, w->text_projection_t, nullptr, nullptr, feat, B, w->embed_dim, d, 0, st);
@@ -658,14 +710,17 @@ static int text_backward_impl(const cmh_text_weights* w, const int64_t* tokens, 
     rows = total;
   }
   if ((rc = zero_pad_buffers(t, static_cast<size_t>(rows), st))) return rc;
+  const bool tail = !dtokens && train_pooled_tail();
   if (dtokens) {
     if ((rc = tokens_head_backward(dt, xh, t, w->ln_final_w, w->ln_final_b, w->text_projection_t, dtokens, gr->text_projection,
                                    gr->ln_final_w, gr->ln_final_b, M, d, E, st))) return rc;
   } else if ((rc = pooled_backward(dt, xh, t.x_last, t.rows, t.pool, w->text_projection_t, w->ln_final_w, dfeat, gr->text_projection,
-                                   gr->ln_final_w, gr->ln_final_b, t, B, rows, d, E, st))) return rc;
-  for (int i = w->layers - 1; i >= 0; --i)
+                                   gr->ln_final_w, gr->ln_final_b, t, B, rows, d, E, st, tail))) return rc;
+  for (int i = w->layers - 1; i >= 0; --i) {
+    const bool last = i == w->layers - 1;
     if ((rc = block_backward(w->blocks[i], grads_of(gr->blocks[i]), dt, xh, t.L[i], t, B, L, d, 1, key_padding_mask, st,
-                             i != w->layers - 1 || dtokens != nullptr, rows, seq_off))) return rc;
+                             !last || dtokens != nullptr, rows, seq_off, tail && last ? t.rows : nullptr, tail && last ? t.dx2 : nullptr))) return rc;
+  }
   // x_0[b, t] = token_embedding[tokens[b, t]] + positional_embedding[t]
   if (hipMemsetAsync(gr->positional_embedding, 0, static_cast<size_t>(w->context_length) * d * 4, st) != hipSuccess ||
       hipMemsetAsync(gr->token_embedding, 0, static_cast<size_t>(w->vocab_size) * d * 4, st) != hipSuccess)

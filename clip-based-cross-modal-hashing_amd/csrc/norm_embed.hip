@@ -451,6 +451,25 @@ int launch_gather_rows2(const void* srcA, void* dstA, int bytesA, const void* sr
   return CMH_OK;
 }
 
+// dst[rows[b]] = src[b] for rows of row_bytes (a multiple of 16) bytes (dst zeroed by the caller): the pooled rows' gradients back
+// into the full-size streams before the last block's attention backward (encoders_bwd.hip)
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const uint4* __restrict__ src, const int32_t* __restrict__ rows,
+                                                           uint4* __restrict__ dst, int B, int chunks) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * chunks) return;
+  const int b = i / chunks, ch = i - b * chunks;
+  dst[static_cast<size_t>(rows[b]) * chunks + ch] = src[i];
+}
+
+int launch_scatter_rows(const void* src, const int32_t* rows, void* dst, int B, int row_bytes, hipStream_t st) {
+  CMH_CHECK_ARG(row_bytes > 0 && row_bytes % 16 == 0, "scatter_rows: row of %d bytes", row_bytes);
+  const int chunks = row_bytes / 16;
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3((B * chunks + 255) / 256), dim3(256), 0, st, static_cast<const uint4*>(src), rows,
+                     static_cast<uint4*>(dst), B, chunks);
+  CMH_CHECK_LAUNCH("scatter_rows");
+  return CMH_OK;
+}
+
 // ---- f32 -> bf16 ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
                                                         int64_t n) {

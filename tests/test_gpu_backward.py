@@ -147,6 +147,41 @@ def test_tower_gradients_match_reference_autograd(golden):
     print(f"tower gradients: worst relative-to-max error {worst:.2e} over {len(g['names'])} tensors")
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_pooled_tail_of_the_training_towers_matches_the_full_path(mode):
+    """The training forward / backward carry only the pooled rows through the last block's row-wise tail
+    (csrc/encoders_bwd.hip: block_forward_train / block_backward with pooled_rows).  Against the full-size path
+    (cmh_set_pooled_tail(0)): identical features, every parameter gradient equal up to the summation order of the weight
+    gradients (B rows instead of B*T rows of which all but B are zero).  Ragged captions: the text tower is packed."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import recipe
+    import cmh_native as Nn
+    from test_gpu_clip import _clip
+    cfg, seed, B, L = recipe.CLIP_TINY, 7, 5, 16
+    image = torch.from_numpy(recipe.images(B, cfg["image_resolution"], seed)).to(DEV)
+    text = torch.from_numpy(recipe.captions(B, L, cfg["vocab_size"], seed)).to(DEV)
+    g = torch.Generator().manual_seed(3)
+    gi, gt = torch.randn(B, cfg["embed_dim"], generator=g).to(DEV), torch.randn(B, cfg["embed_dim"], generator=g).to(DEV)
+    res = {}
+    try:
+        for on in (False, True):
+            Nn.set_pooled_tail(on)
+            clip = _clip(cfg, seed, mode)
+            fi, ft = clip.encode_image(image), clip.encode_text(text)
+            ((fi * gi).sum() + (ft * gt).sum()).backward()
+            res[on] = (fi.detach().clone(), ft.detach().clone(), {n: p.grad.detach().clone() for n, p in clip.named_parameters() if p.grad is not None})
+    finally:
+        Nn.set_pooled_tail(True)
+    assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
+    assert res[False][2].keys() == res[True][2].keys() and len(res[True][2]) > 50
+    tol = 2e-5 if mode == "f32" else 4e-3
+    for name, ref in res[False][2].items():
+        got = res[True][2][name]
+        err = float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-6)
+        assert err < tol, (name, err)
+
+
 @pytest.mark.parametrize("B,K,C,alpha", [(8, 16, 5, 0.8), (64, 64, 24, 0.8), (256, 64, 80, 0.8), (32, 128, 10, 0.0)])
 def test_hyp_loss_backward(B, K, C, alpha):
     """d HyP / d(x, y, proxies) against torch autograd (fp64) of the reference formula (train/DSPH/loss.py:22-72)."""
