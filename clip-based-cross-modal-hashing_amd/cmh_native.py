@@ -15,6 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CMH_LIB") or os.path.join(_HERE, "csrc", "build", "libcmh.so")   # CMH_LIB: A/B a kernel build
 
+ABI_VERSION = 3            # include/cmh.h CMH_VERSION: bumped whenever a struct layout or a signature changes
 F32, BF16, FP8 = 0, 1, 2
 ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
 TIE_REFERENCE, TIE_STABLE = 0, 1
@@ -95,6 +96,7 @@ SIGNATURES = {
     "cmh_attention": (C.c_int, [_i32, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "cmh_gemm_tuning": (C.c_int, [_i32, _i32]),
     "cmh_set_pooled_tail": (C.c_int, [_i32]),
+    "cmh_set_gemm_rows": (C.c_int, [_i32]),
     "cmh_msl_workspace_bytes": (_sz, [_i32]),
     "cmh_msl_loss": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _sz, _p]),
     "cmh_msl_loss_backward": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
@@ -111,6 +113,7 @@ SIGNATURES = {
     "cmh_linear_gemm_fp8": (C.c_int, [_p, _p, _p, _f, _p, _p, _p, _f, _i32, _i32, _i32, _i32, _p]),
     "cmh_prof_gemm_begin": (C.c_int, [_i32]),
     "cmh_prof_gemm_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "cmh_prof_gemm_by_kernel": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "cmh_cast_f32_to_bf16": (C.c_int, [_p, _p, _i64, _p]),
     "cmh_linear_act": (C.c_int, [_p, _p, _p, _p, _f, _i32, _p, _i32, _i32, _i32, _p]),
     "cmh_pair_softmax": (C.c_int, [_p, _p, _i32, _i32, _p]),
@@ -209,6 +212,8 @@ def lib():
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(l, name)          # AttributeError if the ABI lost a symbol
                 fn.restype, fn.argtypes = res, args
+            if l.cmh_version() != ABI_VERSION:  # a stale or diagnostic build with other struct layouts would read garbage pointers
+                raise NativeError(f"{LIB_PATH}: cmh_version() = {l.cmh_version()}, this binding was written for {ABI_VERSION}; rebuild it")
             _lib = l
     return _lib
 
@@ -333,6 +338,11 @@ def set_pooled_tail(on: bool):
     check(lib().cmh_set_pooled_tail(1 if on else 0), "cmh_set_pooled_tail")
 
 
+def set_gemm_rows(on: int = -1):
+    """Few-row GEMMs (M <= 512) on 64 x 64 tiles (csrc/gemm_rows.hip): 1 on (default), 0 = the wide kernel takes them, -1 = environment."""
+    check(lib().cmh_set_gemm_rows(int(on)), "cmh_set_gemm_rows")
+
+
 def gemm_tuning(tile_rows: int = -1, order_group: int = -1):
     """Pin the wide GEMM's tile height (96 / 128 / 160) and tile-order group (0 = n-fastest); -1 = automatic."""
     check(lib().cmh_gemm_tuning(int(tile_rows), int(order_group)), "cmh_gemm_tuning")
@@ -347,6 +357,13 @@ def prof_gemm_end():
     ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
     check(lib().cmh_prof_gemm_end(C.byref(ms), C.byref(fl), C.byref(n)), "cmh_prof_gemm_end")
     return ms.value, fl.value, n.value
+
+
+def prof_gemm_by_kernel():
+    """after prof_gemm_end(): {kernel: (ms, flops, launches)} of the timed launches, split by the kernel that ran them"""
+    ms, fl, n = (C.c_double * 3)(), (C.c_double * 3)(), (C.c_int64 * 3)()
+    check(lib().cmh_prof_gemm_by_kernel(ms, fl, n), "cmh_prof_gemm_by_kernel")
+    return {k: (ms[i], fl[i], n[i]) for i, k in enumerate(("gemm_wide_kernel", "gemm_rows_kernel", "fallback"))}
 
 
 # ------------------------------------------------------------------------------------------ tower blocks

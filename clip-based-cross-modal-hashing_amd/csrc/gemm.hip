@@ -204,6 +204,7 @@ struct GemmProf {
   std::vector<hipEvent_t> ev;     // pairs
   std::vector<double> flops;
   std::vector<std::array<int, 4>> dims;   // M, N, K, epi of each timed launch (CMH_GEMM_PROF_DUMP breakdown)
+  std::vector<int> kind;                  // kernel of each timed launch: 0 gemm_wide_kernel, 1 gemm_rows_kernel, 2 the 128 x 128 fallbacks
   size_t used = 0;
 };
 static GemmProf g_prof;
@@ -211,6 +212,10 @@ static GemmProf g_prof;
 void launch_gemm_glds(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out,
                       int M, int N, int K, int epi, hipStream_t st);   // gemm_glds.hip
 bool gemm_wide_supported(int N);                                         // gemm_wide.hip
+void gemm_wide_time_next(hipEvent_t start, hipEvent_t stop);             // gemm_wide.hip: the next wide launch stamps these events itself
+bool gemm_rows_takes(int M, int N, int K, int epi);                      // gemm_rows.hip: few rows (M <= 512), 64 x 64 tiles
+int launch_gemm_rows(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out, int M, int N, int K,
+                     int epi, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out,
                      int M, int N, int K, int epi, hipStream_t st, const float* colscale = nullptr, float alpha = 1.f,
                      float oscale = 1.f);
@@ -234,17 +239,28 @@ int launch_gemm(int dt, const void* A, const void* W, const float* bias, const f
                 "gemm: fp16 residual / output needs N %% 256 == 0 (N=%d) and excludes EPI_OUT_BF16", N);
   const int total = (N / kTile) * ((M + kTile - 1) / kTile);
   const bool timed = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
-  if (timed) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
   static const int impl = gemm_impl_from_env();
   static const bool wide = []() { const char* e = getenv("CMH_GEMM_WIDE"); return !(e && !strcmp(e, "0")); }();
+  // the wide kernel's launch stamps the event pair with its own begin / end (gemm_wide_time_next); the fallback kernels are
+  // bracketed by two recorded events; CMH_GEMM_PROF_BRACKET=1 brackets every launch (round 1-2's method, for comparison)
+  static const bool bracket = []() { const char* e = getenv("CMH_GEMM_PROF_BRACKET"); return e && e[0] == '1'; }();
+  const bool takes_rows = gemm_rows_takes(M, N, K, epi);
+  const bool takes_wide = !takes_rows && ((impl == 1 && wide && gemm_wide_supported(N)) || (epi & (EPI_RES_F16 | EPI_OUT_F16 | EPI_MUL_DQGELU | EPI_SAVE_PRE)));
+  const bool self_timed = timed && (takes_wide || takes_rows) && !bracket;
+  hipEvent_t ev0 = self_timed ? g_prof.ev[g_prof.used] : nullptr, ev1 = self_timed ? g_prof.ev[g_prof.used + 1] : nullptr;
+  if (timed && !self_timed) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
   CMH_CHECK_ARG(!(epi & EPI_MUL_DQGELU) || (residual && gemm_wide_supported(N) && !(epi & (EPI_RESIDUAL | EPI_OUT_F16))),
                 "gemm: EPI_MUL_DQGELU needs aux in the residual slot, N %% 256 == 0 (N=%d), no residual / fp16 output", N);
   CMH_CHECK_ARG(!(epi & EPI_SAVE_PRE) || (residual && dt == CMH_BF16 && (epi & EPI_OUT_BF16) && gemm_wide_supported(N) &&
                                           !(epi & (EPI_RESIDUAL | EPI_MUL_DQGELU | EPI_OUT_F16))),
                 "gemm: EPI_SAVE_PRE needs the second output in the residual slot, bf16 operands and output, N %% 256 == 0 (N=%d)", N);
-  const bool f16io = epi & (EPI_RES_F16 | EPI_OUT_F16 | EPI_MUL_DQGELU | EPI_SAVE_PRE);   // only the wide kernel implements these epilogues
-  if ((impl == 1 && wide && gemm_wide_supported(N)) || f16io) {
+  if (takes_rows) {
+    const int rc = launch_gemm_rows(dt, A, W, bias, residual, out, M, N, K, epi, st, ev0, ev1);
+    if (rc) return rc;
+  } else if (takes_wide) {
+    if (self_timed) gemm_wide_time_next(ev0, ev1);
     const int rc = launch_gemm_wide(dt, A, W, bias, residual, out, M, N, K, epi, st);
+    gemm_wide_time_next(nullptr, nullptr);
     if (rc) return rc;
   } else if (impl == 1)
     launch_gemm_glds(dt, A, W, bias, residual, out, M, N, K, epi, st);
@@ -255,9 +271,10 @@ int launch_gemm(int dt, const void* A, const void* W, const float* bias, const f
     hipLaunchKernelGGL(gemm_kernel<false>, dim3(total), dim3(256), 0, st, static_cast<const char*>(A),
                        static_cast<const char*>(W), bias, residual, out, M, N, K, epi);
   if (timed) {
-    (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
+    if (!self_timed) (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
     g_prof.flops.push_back(2.0 * M * static_cast<double>(N) * K);   // algorithmic FLOPs: real rows only
     g_prof.dims.push_back({M, N, K, epi});
+    g_prof.kind.push_back(takes_rows ? 1 : (takes_wide ? 0 : 2));
     g_prof.used += 2;
   }
   CMH_CHECK_LAUNCH("gemm");
@@ -275,13 +292,14 @@ int launch_gemm_fp8(const void* A8, const void* W8, const float* colscale, float
   const int okinds = ((epi & EPI_OUT_BF16) ? 1 : 0) + ((epi & EPI_OUT_F16) ? 1 : 0) + ((epi & EPI_OUT_FP8) ? 1 : 0);
   CMH_CHECK_ARG(okinds <= 1, "gemm_fp8: one output type at a time");
   const bool timed = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
-  if (timed) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
+  if (timed) gemm_wide_time_next(g_prof.ev[g_prof.used], g_prof.ev[g_prof.used + 1]);
   const int rc = launch_gemm_wide(CMH_FP8, A8, W8, bias, residual, out, M, N, K, epi | EPI_SCALE, st, colscale, alpha, oscale);
+  gemm_wide_time_next(nullptr, nullptr);
   if (rc) return rc;
   if (timed) {
-    (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
     g_prof.flops.push_back(2.0 * M * static_cast<double>(N) * K);
     g_prof.dims.push_back({M, N, K, epi | EPI_SCALE});
+    g_prof.kind.push_back(0);
     g_prof.used += 2;
   }
   CMH_CHECK_LAUNCH("gemm_fp8");
@@ -301,7 +319,23 @@ extern "C" int cmh_prof_gemm_begin(int32_t max_launches) {
   g_prof.used = 0;
   g_prof.flops.clear();
   g_prof.dims.clear();
+  g_prof.kind.clear();
   g_prof.on = true;
+  return CMH_OK;
+}
+
+extern "C" int cmh_prof_gemm_by_kernel(double* ms3, double* flops3, int64_t* launches3) {
+  using namespace cmh;
+  CMH_CHECK_ARG(ms3 && flops3 && launches3, "prof_gemm_by_kernel: null pointer");
+  CMH_CHECK_ARG(!g_prof.on, "prof_gemm_by_kernel: call cmh_prof_gemm_end first");
+  for (int k = 0; k < 3; ++k) { ms3[k] = 0.0; flops3[k] = 0.0; launches3[k] = 0; }
+  for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]) != hipSuccess)
+      return fail(CMH_ERR_LAUNCH, "prof_gemm_by_kernel: hipEventElapsedTime failed");
+    const int k = g_prof.kind[i / 2];
+    ms3[k] += t; flops3[k] += g_prof.flops[i / 2]; launches3[k] += 1;
+  }
   return CMH_OK;
 }
 

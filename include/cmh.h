@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define CMH_VERSION 1
+#define CMH_VERSION 3   /* = the round that last changed a struct layout or a signature; cmh_native.lib() refuses any other */
 
 typedef enum cmh_status {
   CMH_OK = 0,
@@ -171,18 +171,27 @@ int cmh_layernorm(const float* x, const float* w, const float* b, void* out, int
 int cmh_attention(int32_t dtype, const void* qkv, void* o, int32_t B, int32_t T, int32_t d, int32_t causal,
                   const uint8_t* key_padding_mask, void* stream);
 
-/* Measurement hook (bench.py `roofline`): while enabled, every GEMM launch of the library is bracketed by
- * HIP events recorded on the launch stream.  _end() synchronises on those events and returns the summed
- * launch durations, the summed algorithmic FLOPs (2*M*N*K, real rows only) and the launch count.
+/* Measurement hook (bench.py `roofline`): while enabled, every GEMM launch of the library is timed with a pair of HIP events
+ * on the launch stream.  The two hand-written GEMM kernels launch through hipExtLaunchKernelGGL, which stamps the pair with the
+ * dispatch's own begin / end - the duration rocprofv3's kernel trace reports; the 128 x 128 fallback kernels are bracketed by two
+ * recorded events (CMH_GEMM_PROF_BRACKET=1: every launch, round 1-2's method, which adds the marker packets' gaps to each launch).
+ * _end() synchronises on those events and returns the summed launch durations, the summed algorithmic FLOPs (2*M*N*K, real rows
+ * only) and the launch count over ALL GEMM launches; _by_kernel() (after _end) splits the same sums by kernel:
+ * [0] gemm_wide_kernel (N % 256 == 0: every large GEMM), [1] gemm_rows_kernel (M <= 512: the pooled-row tail), [2] the fallbacks.
  * Not thread-safe; single-stream benchmarking only. */
 int cmh_prof_gemm_begin(int32_t max_launches);
 int cmh_prof_gemm_end(double* total_ms, double* total_flops, int64_t* launches);
+int cmh_prof_gemm_by_kernel(double* ms3, double* flops3, int64_t* launches3);
 
 /* Tuning overrides of the N % 256 == 0 GEMM kernel, for A/B measurements and for tests that must reach every variant:
  * tile_rows in {96, 128, 160} pins the tile height (-1: chosen per launch from M, N, K and the CU count); order_group = n-panels
  * per group of the L2-aware tile order (0: plain n-fastest order, -1: chosen per launch).  Results do not depend on either.
  * Process-wide, not thread-safe.  (No reference counterpart: upstream's GEMMs are ATen's, model/base/model.py:167-196.) */
 int cmh_gemm_tuning(int32_t tile_rows, int32_t order_group);
+/* GEMMs of few rows (M <= 512: the pooled-row tail of the towers, small heads) run on 64 x 64 tiles (csrc/gemm_rows.hip) instead of
+ * the wide kernel's 96..160 x 256 ones: same bits per output element (same MFMA chain over K, same epilogue order), more workgroups.
+ * on = 0 sends them to the wide kernel again (A/B, tests), 1 forces the default, -1 = environment (CMH_GEMM_ROWS=0 is off). */
+int cmh_set_gemm_rows(int32_t on);
 
 /* encode_image / encode_text return one pooled row per sample (model/base/model.py:247-250, 366-370), and past the last block's
  * attention every operation is row-wise, so cmh_vit_encode / cmh_text_encode[_packed] carry only those B rows through the last

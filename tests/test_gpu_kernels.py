@@ -77,6 +77,44 @@ def test_gemm_wide_tile_variants(M, N, K):
         Nn.gemm_tuning(100, -1)
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 768, 768), (256, 3072, 768), (256, 768, 3072), (256, 512, 2048), (200, 512, 512), (37, 1536, 512), (512, 128, 64)])
+@pytest.mark.parametrize("mode", ["bf16", "f32"])
+def test_gemm_rows_kernel_gives_the_wide_kernels_bits(M, N, K, mode):
+    """csrc/gemm_rows.hip (few rows, 64 x 64 tiles) against the wide / 128 x 128 kernels on the same operands: identical bits
+    for every epilogue it takes over (the pooled-row tail relies on it), and both equal the fp64 statement within the mode's tolerance."""
+    import cmh_native as Nn
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    if mode == "bf16":
+        x, w = x.bfloat16(), w.bfloat16()
+    xd, wd, bd = x.to(_dev()), w.to(_dev()), b.to(_dev())
+    wide_ok = N % 256 == 0
+    cases = [dict(), dict(bias=bd, quickgelu=True, out_bf16=(mode == "bf16")), dict(bias=bd, residual=r.to(_dev()))]
+    if wide_ok:
+        cases.append(dict(bias=bd, residual=r.half().to(_dev()), out_f16=True))
+    outs = {}
+    try:
+        for on in (1, 0):
+            Nn.set_gemm_rows(on)
+            outs[on] = [Nn.linear_gemm(xd, wd, **kw) for kw in cases]
+    finally:
+        Nn.set_gemm_rows(-1)
+    for i, (a, c) in enumerate(zip(outs[1], outs[0])):
+        if i > 0 and not wide_ok:
+            # N % 256 != 0 goes to the 128 x 128 fallback kernels, which divide in QuickGELU and add the residual last: the rows
+            # kernel follows the WIDE kernel's operation order (v_rcp form; residual first when K is short), so only close here
+            torch.testing.assert_close(a.float(), c.float(), rtol=1e-2 if mode == "bf16" else 1e-5, atol=1e-2 if mode == "bf16" else 1e-5)
+            continue
+        assert torch.equal(a, c), (i, float((a.float() - c.float()).abs().max()))
+    ref = x.double() @ w.double().t()
+    tol = dict(rtol=2e-3, atol=2e-3) if mode == "bf16" else dict(rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(outs[1][0].cpu().double(), ref, **tol)
+    torch.testing.assert_close(outs[1][2].cpu().double(), ref + b.double() + r.double(), **tol)
+
+
 def test_gemm_asymmetric_identity():
     """A = I against an ASYMMETRIC W catches a transposed C write (cdna guide §3)."""
     import cmh_native as Nn
