@@ -33,6 +33,7 @@ namespace cmh {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 w_bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float w_f32x4_t;
+typedef __attribute__((ext_vector_type(2))) float w_f32x2_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t w_u32x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned w_u2_t;
 
@@ -805,12 +806,21 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
     }
 #endif
     if (epi & EPI_QUICKGELU) {
+      // two values at a time: the multiply by -1.702 log2(e), the +1 and the final product are packed-f32 instructions (v_pk_mul_f32 /
+      // v_pk_add_f32: two IEEE results per issue slot, same bits as w_quick_gelu); v_exp_f32 / v_rcp_f32 stay one value each
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < MF; ++b)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[a][b][j] = w_quick_gelu(acc[a][b][j]);
+          for (int j = 0; j < 4; j += 2) {
+            const w_f32x2_t v = {acc[a][b][j], acc[a][b][j + 1]};
+            const w_f32x2_t t = v * w_f32x2_t{-2.4554669595930157f, -2.4554669595930157f};
+            const w_f32x2_t d = w_f32x2_t{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + w_f32x2_t{1.0f, 1.0f};
+            const w_f32x2_t o = v * w_f32x2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+            acc[a][b][j] = o[0];
+            acc[a][b][j + 1] = o[1];
+          }
     }
     if (epi & (EPI_GELU | EPI_RELU)) {
 #pragma unroll
