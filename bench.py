@@ -120,7 +120,7 @@ def self_launch(n_gpus):
     on a new port, before giving up with a non-zero exit code."""
     import socket
     import subprocess
-    last = None
+    last, first_rc = None, None
     for attempt in range(2):
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
@@ -131,8 +131,16 @@ def self_launch(n_gpus):
         last = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
         lines = [ln for ln in last.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
         if last.returncode == 0 and lines:
-            print(lines[-1], flush=True)
+            line = lines[-1]
+            if attempt > 0:        # a failed first group must be visible in the line the driver parses, not only on stderr
+                rec = json.loads(line)
+                rec["relaunched"] = True
+                rec["first_rc"] = first_rc
+                line = json.dumps(rec)
+            print(line, flush=True)
             return 0
+        if first_rc is None:
+            first_rc = last.returncode
         print(f"bench.py: {n_gpus}-rank group exited with code {last.returncode} (attempt {attempt + 1})", file=sys.stderr, flush=True)
     return last.returncode or 1
 
@@ -497,7 +505,8 @@ def main():
                            max_grad_norm=1.0)
             sgd = torch.optim.SGD(hyp.parameters(), lr=0.02, momentum=0.9, weight_decay=0.0005)
 
-            # gradient means over the ranks, each tower's all-reduce queued from inside backward (dist_utils.GradSync)
+            # gradient means over the ranks (dist_utils.GradSync): the towers' gradients as in-place buckets of their flat buffer,
+            # queued from inside backward part by part; the heads' through the hook route
             vis_ids = {id(p) for p in clip.visual.parameters()}
             sync = du.GradSync([[p for p in params if id(p) not in vis_ids], list(clip.visual.parameters()),
                                 list(img_head.parameters()) + list(txt_head.parameters()) + list(hyp.parameters())])
@@ -505,10 +514,10 @@ def main():
             def train_step():
                 fi, ft = overlapped(lambda: clip.encode_image(image), lambda: clip.encode_text(text))
                 hi, ht = img_head(fi), txt_head(ft)
-                if world > 1:
-                    fused, widths = du.fuse_columns(hi.detach(), ht.detach(), label)
-                    du.all_gather_rows(fused)            # the exchange step; gradients flow through the local rows only
-                loss = hyp(hi, ht, label)
+                # the exchange step exactly as the trainers run it (train/DSPH/hash_train.py:_step -> TrainBase.loss_inputs): one
+                # fused, differentiable all-gather; the loss sees the global batch, gradients come back through the local rows
+                hi_g, ht_g, lab_g = du.gather_loss_inputs(hi, ht, label)
+                loss = hyp(hi_g, ht_g, lab_g)
                 opt.zero_grad(); sgd.zero_grad()
                 loss.backward()
                 sync.finish()                            # no-op on one GPU

@@ -120,6 +120,8 @@ SIGNATURES = {
     "cmh_sign_codes": (C.c_int, [_p, _p, _i64, _p]),
     "cmh_pair_argmax_codes": (C.c_int, [_p, _p, _i32, _i32, _p]),
     "cmh_pack_codes": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p]),
+    "cmh_unpack_codes": (C.c_int, [_p, _p, _i64, _i32, _p, _p]),
+    "cmh_map_mean": (C.c_int, [_p, _i32, _p, _p]),
     "cmh_pack_labels": (C.c_int, [_p, _i64, _i32, _p, _p, _p]),
     "cmh_hamming_dist": (C.c_int, [_p, _p, _p, _p, _i32, _i64, _i32, _p, _p]),
     "cmh_calc_neighbor": (C.c_int, [_p, _p, _i32, _i32, _i32, _p, _p]),
@@ -191,9 +193,11 @@ SIGNATURES = {
     "cmh_vit_train_bytes": (_sz, [C.POINTER(VitWeights), _i32]),
     "cmh_vit_forward_train": (C.c_int, [C.POINTER(VitWeights), _p, _i32, _p, _p, _sz, _p]),
     "cmh_vit_backward": (C.c_int, [C.POINTER(VitWeights), _i32, _p, C.POINTER(VitGrads), _p, _sz, _p]),
+    "cmh_vit_backward_part": (C.c_int, [C.POINTER(VitWeights), _i32, _p, C.POINTER(VitGrads), _p, _sz, _i32, _i32, _p]),
     "cmh_text_train_bytes": (_sz, [C.POINTER(TextWeights), _i32, _i32]),
     "cmh_text_forward_train": (C.c_int, [C.POINTER(TextWeights), _p, _i32, _i32, _p, _p, _p, _sz, _p]),
     "cmh_text_backward": (C.c_int, [C.POINTER(TextWeights), _p, _i32, _i32, _p, _p, C.POINTER(TextGrads), _p, _sz, _p]),
+    "cmh_text_backward_part": (C.c_int, [C.POINTER(TextWeights), _p, _i32, _i32, _p, _p, C.POINTER(TextGrads), _p, _sz, _i32, _i32, _p]),
     "cmh_bert_adam_workspace_bytes": (_sz, [_i32, _i64]),
     "cmh_bert_adam_step": (C.c_int, [C.POINTER(AdamTensor), _i32, C.c_double, C.c_double, C.c_double, _p, _sz, _p]),
 }
@@ -480,6 +484,28 @@ def pack_codes(codes, validate=True):
     if validate and int(bad.item()):
         raise NativeError("pack_codes: hash codes must be exactly -1, 0 or +1 (sign()/argmax codes)")
     return sp, nz
+
+
+def unpack_codes(sign_plane, nz_plane, bits: int):
+    """(sign_plane, nz_plane) int32 [n, ceil(bits/32)] -> f32 codes [n, bits] in {-1, 0, +1} (the inverse of pack_codes)."""
+    require_gpu(sign_plane, nz_plane)
+    sp, nz = sign_plane.contiguous(), nz_plane.contiguous()
+    n, W = sp.shape
+    if sp.dtype != torch.int32 or nz.dtype != torch.int32 or tuple(nz.shape) != (n, W) or W != (int(bits) + 31) // 32:
+        raise NativeError(f"unpack_codes: planes {tuple(sp.shape)} / {tuple(nz.shape)} do not hold {bits}-bit codes")
+    out = torch.empty(n, int(bits), dtype=torch.float32, device=sp.device)
+    if n:
+        check(lib().cmh_unpack_codes(ptr(sp), ptr(nz), n, int(bits), ptr(out), stream_ptr(sp.device)), "cmh_unpack_codes")
+    return out
+
+
+def map_mean(ap):
+    """f32 [Q] per-query APs -> their mean as the ranking kernel forms it: a sequential f32 sum in query order, / Q (0-dim tensor)."""
+    ap = f32c(ap)
+    require_gpu(ap)
+    out = torch.empty(1, dtype=torch.float32, device=ap.device)
+    check(lib().cmh_map_mean(ptr(ap), ap.numel(), ptr(out), stream_ptr(ap.device)), "cmh_map_mean")
+    return out[0]
 
 
 def pack_labels(labels):

@@ -20,6 +20,8 @@
 //   7. dx  += LayerNorm_bwd(x_in, dh1) (+ dln_1)
 // Gradients are WRITTEN (not accumulated) into caller-owned f32 buffers shaped like the reference's parameters.
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "cmh_common.h"
@@ -565,9 +567,15 @@ extern "C" int cmh_vit_forward_train_tokens(const cmh_vit_weights* w, const floa
   return vit_forward_train_impl(w, image, batch, nullptr, tokens_out, tape, tape_bytes, stream);
 }
 
+// layer_hi / layer_lo: the part of the backward pass this call runs - the head (ln_post, proj) iff layer_hi == layers, then blocks
+// layer_hi-1 .. layer_lo, then the embeddings (ln_pre, positional, class, conv1) iff layer_lo == 0.  The gradient stream between
+// parts lives in the tape, so consecutive parts (layers .. a, a .. b, b .. 0) equal the one-call form bit for bit; each part's
+// parameter gradients are final when it returns (a data-parallel trainer sends that bucket while the next part runs).
 static int vit_backward_impl(const cmh_vit_weights* w, int32_t batch, const float* dfeat, const float* dtokens, const cmh_vit_grads* gr,
-                             void* tape, size_t tape_bytes, void* stream) {
+                             void* tape, size_t tape_bytes, void* stream, int layer_hi = -1, int layer_lo = 0) {
   CMH_CHECK_ARG(w && (dfeat || dtokens) && gr && tape && batch > 0, "vit_backward: bad arguments");
+  if (layer_hi < 0) layer_hi = w->layers;
+  CMH_CHECK_ARG(0 <= layer_lo && layer_lo <= layer_hi && layer_hi <= w->layers, "vit_backward: layers [%d, %d) of %d", layer_lo, layer_hi, w->layers);
   int rc = check_train_tower(w->gemm_dtype, w->width, w->layers, w->embed_dim, w->blocks);
   if (rc) return rc;
   CMH_CHECK_ARG(gr->conv1_w && gr->class_embedding && gr->positional_embedding && gr->ln_pre_w && gr->ln_pre_b && gr->ln_post_w &&
@@ -580,18 +588,21 @@ static int vit_backward_impl(const cmh_vit_weights* w, int32_t batch, const floa
   const size_t e = dt == CMH_BF16 ? 2 : 4;
   hipStream_t st = as_stream(stream);
   TrainBufs t = carve_train(tape, static_cast<size_t>(M), B, d, e, xh ? 2 : 4, w->layers, static_cast<size_t>(B) * g2, pk, E);
-  if ((rc = zero_pad_buffers(t, static_cast<size_t>(M), st))) return rc;
   const bool tail = !dtokens && train_pooled_tail();
-  if (dtokens) {
-    if ((rc = tokens_head_backward(dt, xh, t, w->ln_post_w, w->ln_post_b, w->proj_t, dtokens, gr->proj, gr->ln_post_w, gr->ln_post_b, M, d,
-                                   E, st))) return rc;
-  } else if ((rc = pooled_backward(dt, xh, t.x_last, t.rows, t.pool, w->proj_t, w->ln_post_w, dfeat, gr->proj, gr->ln_post_w,
-                                   gr->ln_post_b, t, B, M, d, E, st, tail))) return rc;
-  for (int i = w->layers - 1; i >= 0; --i) {
+  if (layer_hi == w->layers) {
+    if ((rc = zero_pad_buffers(t, static_cast<size_t>(M), st))) return rc;
+    if (dtokens) {
+      if ((rc = tokens_head_backward(dt, xh, t, w->ln_post_w, w->ln_post_b, w->proj_t, dtokens, gr->proj, gr->ln_post_w, gr->ln_post_b, M, d,
+                                     E, st))) return rc;
+    } else if ((rc = pooled_backward(dt, xh, t.x_last, t.rows, t.pool, w->proj_t, w->ln_post_w, dfeat, gr->proj, gr->ln_post_w,
+                                     gr->ln_post_b, t, B, M, d, E, st, tail))) return rc;
+  }
+  for (int i = layer_hi - 1; i >= layer_lo; --i) {
     const bool last = i == w->layers - 1;
     if ((rc = block_backward(w->blocks[i], grads_of(gr->blocks[i]), dt, xh, t.L[i], t, B, T, d, 0, nullptr, st,
                              !last || dtokens != nullptr, -1, nullptr, tail && last ? t.rows : nullptr, tail && last ? t.dx2 : nullptr))) return rc;
   }
+  if (layer_lo > 0) return CMH_OK;
   // ln_pre, then the embeddings: x_pre[b,0] = cls + pos[0], x_pre[b,1+i] = patch_out[b*g2+i] + pos[1+i]
   if ((rc = launch_layernorm_backward(t.x_pre, kF32, t.dx, kF32, w->ln_pre_w, nullptr, M, d, t.dx2, 0, gr->ln_pre_w, gr->ln_pre_b,
                                       t.red, t.red_bytes, st))) return rc;
@@ -611,6 +622,12 @@ extern "C" int cmh_vit_backward(const cmh_vit_weights* w, int32_t batch, const f
   return vit_backward_impl(w, batch, dfeat, nullptr, gr, tape, tape_bytes, stream);
 }
 
+extern "C" int cmh_vit_backward_part(const cmh_vit_weights* w, int32_t batch, const float* dfeat, const cmh_vit_grads* gr, void* tape,
+                                     size_t tape_bytes, int32_t layer_hi, int32_t layer_lo, void* stream) {
+  CMH_CHECK_ARG(dfeat && layer_hi >= 0, "vit_backward_part: bad arguments");
+  return vit_backward_impl(w, batch, dfeat, nullptr, gr, tape, tape_bytes, stream, layer_hi, layer_lo);
+}
+
 extern "C" int cmh_vit_backward_tokens(const cmh_vit_weights* w, int32_t batch, const float* dtokens, const cmh_vit_grads* gr,
                                        void* tape, size_t tape_bytes, void* stream) {
   CMH_CHECK_ARG(dtokens, "vit_backward_tokens: null gradient");
@@ -618,6 +635,23 @@ extern "C" int cmh_vit_backward_tokens(const cmh_vit_weights* w, int32_t batch, 
 }
 
 // ================================================================================================================ text
+// The packed row count of a text tape (the GEMM grids need it on the host): text_forward_train reads it back once and remembers
+// it here, keyed by the tape's address, so that the backward call(s) on the same tape need no stream synchronisation of their own.
+namespace {
+std::mutex g_tape_rows_mu;
+std::unordered_map<const void*, int> g_tape_rows;
+void remember_tape_rows(const void* tape, int rows) {
+  std::lock_guard<std::mutex> lk(g_tape_rows_mu);
+  if (g_tape_rows.size() > 64) g_tape_rows.clear();      // tapes of long-gone steps
+  g_tape_rows[tape] = rows;
+}
+int recall_tape_rows(const void* tape) {
+  std::lock_guard<std::mutex> lk(g_tape_rows_mu);
+  const auto it = g_tape_rows.find(tape);
+  return it == g_tape_rows.end() ? -1 : it->second;
+}
+}  // namespace
+
 extern "C" size_t cmh_text_train_bytes(const cmh_text_weights* w, int32_t batch, int32_t seq_len) {
   if (!w || batch <= 0 || seq_len <= 0) return 0;
   const size_t e = w->gemm_dtype == CMH_BF16 ? 2 : 4, xs = train_xh(w->gemm_dtype, w->width) ? 2 : 4;
@@ -649,6 +683,7 @@ static int text_forward_train_impl(const cmh_text_weights* w, const int64_t* tok
     CMH_CHECK_ARG(total > 0 && total <= M, "text_forward_train: bad packed row count %d", total);
     seq_off = t.seq_off;
     rows = total;
+    remember_tape_rows(tape, rows);
   }
   if ((rc = launch_text_embed_packed(tokens, w->token_embedding, w->positional_embedding, t.L[0].x_in, xh, t.rows, B, L, d,
                                      w->vocab_size, seq_off, st))) return rc;
@@ -686,8 +721,10 @@ extern "C" int cmh_text_forward_train_tokens(const cmh_text_weights* w, const in
 
 static int text_backward_impl(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
                               const uint8_t* key_padding_mask, const float* dfeat, const float* dtokens, const cmh_text_grads* gr,
-                              void* tape, size_t tape_bytes, void* stream) {
+                              void* tape, size_t tape_bytes, void* stream, int layer_hi = -1, int layer_lo = 0) {   // parts: see vit_backward_impl
   CMH_CHECK_ARG(w && tokens && (dfeat || dtokens) && gr && tape && batch > 0 && seq_len > 0, "text_backward: bad arguments");
+  if (layer_hi < 0) layer_hi = w->layers;
+  CMH_CHECK_ARG(0 <= layer_lo && layer_lo <= layer_hi && layer_hi <= w->layers, "text_backward: layers [%d, %d) of %d", layer_lo, layer_hi, w->layers);
   int rc = check_train_tower(w->gemm_dtype, w->width, w->layers, w->embed_dim, w->blocks);
   if (rc) return rc;
   CMH_CHECK_ARG(gr->token_embedding && gr->positional_embedding && gr->ln_final_w && gr->ln_final_b && gr->text_projection &&
@@ -702,25 +739,30 @@ static int text_backward_impl(const cmh_text_weights* w, const int64_t* tokens, 
   const int32_t* seq_off = nullptr;
   int rows = M;
   if (!dtokens && text_packing(key_padding_mask)) {       // same rule as the forward call that filled this tape
-    int32_t total = 0;
-    if (hipMemcpyAsync(&total, t.seq_off + B, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-      return fail(CMH_ERR_LAUNCH, "text_backward: reading the packed row count failed");
+    int32_t total = recall_tape_rows(tape);                // remembered by the forward call (no synchronisation here)
+    if (total < 0) {                                       // a tape this process did not fill: read the count back
+      if (hipMemcpyAsync(&total, t.seq_off + B, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return fail(CMH_ERR_LAUNCH, "text_backward: reading the packed row count failed");
+    }
     CMH_CHECK_ARG(total > 0 && total <= M, "text_backward: the tape holds no packed plan (row count %d)", total);
     seq_off = t.seq_off;
     rows = total;
   }
-  if ((rc = zero_pad_buffers(t, static_cast<size_t>(rows), st))) return rc;
   const bool tail = !dtokens && train_pooled_tail();
-  if (dtokens) {
-    if ((rc = tokens_head_backward(dt, xh, t, w->ln_final_w, w->ln_final_b, w->text_projection_t, dtokens, gr->text_projection,
-                                   gr->ln_final_w, gr->ln_final_b, M, d, E, st))) return rc;
-  } else if ((rc = pooled_backward(dt, xh, t.x_last, t.rows, t.pool, w->text_projection_t, w->ln_final_w, dfeat, gr->text_projection,
-                                   gr->ln_final_w, gr->ln_final_b, t, B, rows, d, E, st, tail))) return rc;
-  for (int i = w->layers - 1; i >= 0; --i) {
+  if (layer_hi == w->layers) {
+    if ((rc = zero_pad_buffers(t, static_cast<size_t>(rows), st))) return rc;
+    if (dtokens) {
+      if ((rc = tokens_head_backward(dt, xh, t, w->ln_final_w, w->ln_final_b, w->text_projection_t, dtokens, gr->text_projection,
+                                     gr->ln_final_w, gr->ln_final_b, M, d, E, st))) return rc;
+    } else if ((rc = pooled_backward(dt, xh, t.x_last, t.rows, t.pool, w->text_projection_t, w->ln_final_w, dfeat, gr->text_projection,
+                                     gr->ln_final_w, gr->ln_final_b, t, B, rows, d, E, st, tail))) return rc;
+  }
+  for (int i = layer_hi - 1; i >= layer_lo; --i) {
     const bool last = i == w->layers - 1;
     if ((rc = block_backward(w->blocks[i], grads_of(gr->blocks[i]), dt, xh, t.L[i], t, B, L, d, 1, key_padding_mask, st,
                              !last || dtokens != nullptr, rows, seq_off, tail && last ? t.rows : nullptr, tail && last ? t.dx2 : nullptr))) return rc;
   }
+  if (layer_lo > 0) return CMH_OK;
   // x_0[b, t] = token_embedding[tokens[b, t]] + positional_embedding[t]
   if (hipMemsetAsync(gr->positional_embedding, 0, static_cast<size_t>(w->context_length) * d * 4, st) != hipSuccess ||
       hipMemsetAsync(gr->token_embedding, 0, static_cast<size_t>(w->vocab_size) * d * 4, st) != hipSuccess)
@@ -742,6 +784,13 @@ extern "C" int cmh_text_backward(const cmh_text_weights* w, const int64_t* token
                                  size_t tape_bytes, void* stream) {
   CMH_CHECK_ARG(dfeat, "text_backward: null gradient");
   return text_backward_impl(w, tokens, batch, seq_len, key_padding_mask, dfeat, nullptr, gr, tape, tape_bytes, stream);
+}
+
+extern "C" int cmh_text_backward_part(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
+                                      const uint8_t* key_padding_mask, const float* dfeat, const cmh_text_grads* gr, void* tape,
+                                      size_t tape_bytes, int32_t layer_hi, int32_t layer_lo, void* stream) {
+  CMH_CHECK_ARG(dfeat && layer_hi >= 0, "text_backward_part: bad arguments");
+  return text_backward_impl(w, tokens, batch, seq_len, key_padding_mask, dfeat, nullptr, gr, tape, tape_bytes, stream, layer_hi, layer_lo);
 }
 
 extern "C" int cmh_text_backward_tokens(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,

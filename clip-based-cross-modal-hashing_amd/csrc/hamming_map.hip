@@ -854,6 +854,17 @@ __global__ __launch_bounds__(256) void pack_codes_kernel(const float* __restrict
   if (isbad) *bad = 1;
 }
 
+// the inverse of pack_codes_kernel: bit planes -> f32 codes in {-1, 0, +1}
+__global__ __launch_bounds__(256) void unpack_codes_kernel(const uint32_t* __restrict__ sp, const uint32_t* __restrict__ np, int64_t n,
+                                                           int bits, int W, float* __restrict__ codes) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n * bits) return;
+  const int64_t row = i / bits;
+  const int t = static_cast<int>(i - row * bits);
+  const uint32_t s = sp[row * W + (t >> 5)] >> (t & 31) & 1u, z = np[row * W + (t >> 5)] >> (t & 31) & 1u;
+  codes[i] = z ? (s ? 1.f : -1.f) : 0.f;
+}
+
 __global__ __launch_bounds__(256) void pack_labels_kernel(const float* __restrict__ lab, int64_t n, int classes, int LW,
                                                           uint32_t* __restrict__ out, int32_t* __restrict__ bad) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -916,6 +927,23 @@ extern "C" int cmh_pack_codes(const float* codes, int64_t n, int32_t bits, uint3
   hipLaunchKernelGGL(pack_codes_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, as_stream(stream),
                      codes, n, bits, W, sign_plane, nz_plane, bad_flag);
   CMH_CHECK_LAUNCH("pack_codes");
+  return CMH_OK;
+}
+
+extern "C" int cmh_unpack_codes(const uint32_t* sign_plane, const uint32_t* nz_plane, int64_t n, int32_t bits, float* codes, void* stream) {
+  CMH_CHECK_ARG(sign_plane && nz_plane && codes, "unpack_codes: null pointer");
+  CMH_CHECK_ARG(n > 0 && bits > 0 && bits <= 32 * kMaxWords, "unpack_codes: n=%lld bits=%d", static_cast<long long>(n), bits);
+  const int64_t total = n * bits;
+  hipLaunchKernelGGL(unpack_codes_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                     sign_plane, nz_plane, n, bits, (bits + 31) / 32, codes);
+  CMH_CHECK_LAUNCH("unpack_codes");
+  return CMH_OK;
+}
+
+extern "C" int cmh_map_mean(const float* ap, int32_t Q, float* map, void* stream) {
+  CMH_CHECK_ARG(ap && map && Q > 0, "map_mean: bad arguments");
+  hipLaunchKernelGGL(map_mean_kernel, dim3(1), dim3(64), 0, as_stream(stream), ap, Q, map);
+  CMH_CHECK_LAUNCH("map_mean");
   return CMH_OK;
 }
 

@@ -146,9 +146,14 @@ def gather_query_sharded_ap(ap_local: torch.Tensor, n_query: int) -> torch.Tenso
 
 
 def mean_in_query_order(ap: torch.Tensor) -> torch.Tensor:
-    """f32 running sum in query order / Q (utils/calc_utils.py:37-38 `map += AP; map / num_query`)."""
+    """f32 running sum in query order / Q (utils/calc_utils.py:37-38 `map += AP; map / num_query`).  On the GPU this is the very
+    kernel that cmh_hamming_map appends to a ranking (cmh_map_mean: one thread adds the APs in order), so the mean of gathered
+    per-query APs is the single-GPU value bit for bit; CPU tensors (the gloo tests) take the same sum as a host loop."""
+    if ap.is_cuda:
+        import cmh_native as N
+        return N.map_mean(ap.detach())
     acc = torch.zeros((), dtype=torch.float32)
-    for v in ap.detach().float().cpu():
+    for v in ap.detach().float():
         acc = acc + v
     return acc / ap.numel()
 
@@ -211,19 +216,22 @@ def allreduce_mean_(tensors: list[torch.Tensor], bucket_bytes: int = 256 << 20) 
 
 
 class GradSync:
-    """allreduce_mean_ started from inside the backward pass ("overlapped with backward").
+    """Gradient means over the ranks, queued from inside the backward pass ("bucketed ... overlapped with backward").
 
-    The parameters are cut into groups in the order their gradients complete — the text tower, the image tower, the rest
-    (hash heads, loss parameters) — and a post-accumulate hook on every parameter counts its group down; the moment a group
-    is complete its gradients are packed into one flat buffer and an asynchronous ring all-reduce is queued, so the text
-    tower's 254 MB travel over xGMI while the image tower's backward kernels are still running.  `finish()` (after
-    `loss.backward()`, before the optimiser) sends whatever did not go out early, waits, and writes the means back.
+    Two routes, one `finish()`:
+      * BUCKETS of the native towers.  cmh_vit_backward / cmh_text_backward run in parts (model/base/train_ops.py: the head + the
+        last blocks first, the embeddings last); all gradients of a tower call live in ONE flat buffer in completion order, and the
+        moment a part returns its slice of that buffer is all-reduced IN PLACE (asynchronously: the first message of a step leaves
+        after a third of the first tower's backward).  The parameters' .grad are views of the same buffer, so nothing is packed and
+        nothing is copied back; `finish()` only waits and divides.
+      * HOOKS for everything else (hash heads, loss parameters, any module that does not go through the native bridges): the
+        parameters are cut into groups, a post-accumulate hook on every parameter counts its group down, and a complete group is
+        packed into one flat message (these groups are a few hundred KB).  Which parameters receive a gradient is learnt from the
+        previous step (the first step sends everything from `finish()`); a gradient that shows up after its group was sent goes out
+        in `finish()`.
 
-    Which parameters receive a gradient is learnt from the previous step (the first step sends everything from `finish()`);
-    a gradient that shows up after its group was sent goes out in `finish()`; one that stays away only delays its group
-    until `finish()`.  The result is the same as allreduce_mean_ over the same gradients: same sums, same division.
-    Contract (as for allreduce_mean_): in a given step every rank produces gradients for the same parameters, one backward
-    pass per `finish()`; the messages then have the same composition and order on all ranks."""
+    Same sums and the same division as allreduce_mean_ over the same gradients.  Contract: in a given step every rank produces
+    gradients for the same parameters, one backward pass per `finish()`, gradients cleared (set to None) between steps."""
 
     def __init__(self, groups):
         self.world = world_size()
@@ -234,10 +242,22 @@ class GradSync:
         self._arrived = [[] for _ in self.groups]
         self._sent = [False] * len(self.groups)
         self._late, self._pending, self._handles = [], [], []
+        self._buckets, self._via_bucket = [], set()           # in-place messages of this step; ids of the parameters they cover
+        self.bucket_log = []                                  # (elements, parameters) of every in-place message of the last step
         if self.world > 1:
             for g in self.groups:
                 for p in g:
                     self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
+            self._install_sink()
+
+    def _install_sink(self):
+        try:
+            from model.base import train_ops
+        except ImportError:                                    # host-only use (tests of the hook route)
+            self._train_ops = None
+            return
+        self._train_ops = train_ops
+        train_ops.BUCKET_SINK = self._on_bucket
 
     @staticmethod
     def for_model(model, *extra_modules):
@@ -254,12 +274,26 @@ class GradSync:
         for h in self._handles:
             h.remove()
         self._handles = []
+        if getattr(self, "_train_ops", None) is not None and self._train_ops.BUCKET_SINK == self._on_bucket:
+            self._train_ops.BUCKET_SINK = None
+
+    def _on_bucket(self, flat, params, views):
+        """a part of a tower's backward has written its last gradient: all-reduce its slice of the flat buffer where it lies"""
+        if self.world == 1:
+            return
+        # remember WHERE each gradient lies, not the view objects: autograd adopts a returned gradient as p.grad only while nobody
+        # else holds a reference to it (otherwise it clones it)
+        spans = [(v.storage_offset() - flat.storage_offset(), v.numel()) for v in views]
+        self._buckets.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, params, spans))
+        self._via_bucket.update(id(p) for p in params)
 
     def _send(self, params):
         flat = torch.cat([p.grad.reshape(-1) for p in params])
         self._pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, params))
 
     def _on_grad(self, p):
+        if id(p) in self._via_bucket:          # already travelling inside its tower's bucket
+            return
         gi = self._group_of[id(p)]
         if self._sent[gi]:
             self._late.append(p)
@@ -279,6 +313,16 @@ class GradSync:
         if self._late:
             self._send(self._late)
         on_gpu = torch.cuda.is_available()
+        self.bucket_log = []
+        for work, flat, params, spans in self._buckets:
+            work.wait()
+            flat.div_(self.world)
+            self.bucket_log.append((flat.numel(), len(params)))
+            for p, (off, n) in zip(params, spans):
+                # autograd adopts the view itself as p.grad; if it made its own tensor instead (a gradient accumulated into an
+                # existing one, a layout it did not like), that tensor holds this rank's values and takes the mean from the buffer
+                if p.grad is not None and p.grad.data_ptr() != flat.data_ptr() + 4 * off:
+                    p.grad.copy_(flat[off:off + n].view_as(p.grad))
         for work, flat, params in self._pending:
             work.wait()
             if on_gpu and flat.is_cuda:
@@ -296,3 +340,4 @@ class GradSync:
         self._arrived = [[] for _ in self.groups]
         self._sent = [False] * len(self.groups)
         self._late, self._pending = [], []
+        self._buckets, self._via_bucket = [], set()

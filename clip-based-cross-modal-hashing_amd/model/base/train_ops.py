@@ -31,11 +31,58 @@ def text_params(clip):
     return head + [p for blk in clip.transformer.resblocks for p in block_params(blk)]
 
 
-def _grad_buffers(params):
+# Data-parallel hook (dist_utils.GradSync): called as BUCKET_SINK(flat_slice, params, views) from inside a tower's backward the
+# moment a part of the pass has written its last gradient, with the 1-D f32 slice of the flat buffer that holds exactly that part's
+# gradients (views[i] = the gradient of params[i] inside it); the sink may queue an in-place all-reduce on the slice: the values
+# reach the parameters' .grad (those very views, once autograd has adopted them) without any packing or copy-back.
+BUCKET_SINK = None
+PARTS = 3          # tower backward calls per step: blocks in PARTS near-equal ranges, last layers first
+
+
+def _grad_buffers(params, order=None):
+    """One flat f32 buffer for all gradients of a tower call; returns (grads as views in `params` order, flat).  `order` lists
+    the parameter indices in the order the backward pass completes them, so that every part is one contiguous slice."""
     for p in params:
         if p.dtype != torch.float32 or not p.is_contiguous():
             raise N.NativeError("training needs contiguous float32 parameters (model.float())")
-    return [torch.empty_like(p) for p in params]
+    order = list(range(len(params))) if order is None else order
+    sizes = [(params[i].numel() + 3) // 4 * 4 for i in order]                 # 16-byte aligned views
+    flat = torch.empty(sum(sizes), dtype=torch.float32, device=params[0].device)
+    grads, off = [None] * len(params), 0
+    for i, n in zip(order, sizes):
+        grads[i] = flat[off:off + params[i].numel()].view_as(params[i])
+        off += n
+    return grads, flat
+
+
+def _layer_parts(layers, parts=None):
+    """[(hi, lo), ...] block ranges of the backward calls, last layers first"""
+    parts = max(1, min(parts or PARTS, layers)) if layers > 0 else 1
+    cuts = [layers - (layers * k) // parts for k in range(parts + 1)]
+    return [(cuts[k], cuts[k + 1]) for k in range(parts)]
+
+
+def _part_order(nhead, head_first, layers, ranges):
+    """Flat-buffer order and slice boundaries: [head parameters that the first part completes][blocks of part 0, last first] ...
+    [blocks of the last part][head parameters that the last part completes].  -> (order, element boundaries per part)"""
+    order, bounds = list(head_first), []
+    for k, (hi, lo) in enumerate(ranges):
+        for layer in range(hi - 1, lo - 1, -1):
+            order += list(range(nhead + 12 * layer, nhead + 12 * (layer + 1)))
+        if k == len(ranges) - 1:
+            order += [i for i in range(nhead) if i not in head_first]
+        bounds.append(len(order))
+    return order, bounds
+
+
+def _sink(flat, params, grads, order, bounds, k):
+    if BUCKET_SINK is None:
+        return
+    size = lambda i: (params[i].numel() + 3) // 4 * 4
+    lo = sum(size(i) for i in order[:bounds[k - 1]]) if k else 0
+    hi = sum(size(i) for i in order[:bounds[k]])
+    idx = order[(bounds[k - 1] if k else 0):bounds[k]]
+    BUCKET_SINK(flat[lo:hi], [params[i] for i in idx], [grads[i] for i in idx])
 
 
 def _block_grads(grads, nhead):
@@ -63,12 +110,16 @@ class VitTrain(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dfeat):
         s, params = ctx.struct, ctx.params
-        grads = _grad_buffers(params)
+        ranges = _layer_parts(s.layers)
+        order, bounds = _part_order(8, (5, 6, 7), s.layers, ranges)       # ln_post.weight / bias, proj come with the first part
+        grads, flat = _grad_buffers(params, order)
         blocks = _block_grads(grads, 8)
         g = N.VitGrads(*[t.data_ptr() for t in grads[:8]], C.cast(blocks, C.POINTER(N.BlockGrads)))
         dfeat = N.f32c(dfeat)
-        N.check(N.lib().cmh_vit_backward(C.byref(s), ctx.B, N.ptr(dfeat), C.byref(g), N.ptr(ctx.tape), ctx.tape.numel(),
-                                         N.stream_ptr(dfeat.device)), "cmh_vit_backward")
+        for k, (hi, lo) in enumerate(ranges):
+            N.check(N.lib().cmh_vit_backward_part(C.byref(s), ctx.B, N.ptr(dfeat), C.byref(g), N.ptr(ctx.tape), ctx.tape.numel(), hi, lo,
+                                                  N.stream_ptr(dfeat.device)), "cmh_vit_backward_part")
+            _sink(flat, params, grads, order, bounds, k)
         ctx.tape = None
         return (None, None) + tuple(grads)
 
@@ -88,13 +139,17 @@ class TextTrain(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dfeat):
         s, params, text = ctx.struct, ctx.params, ctx.text
-        grads = _grad_buffers(params)
+        ranges = _layer_parts(s.layers)
+        order, bounds = _part_order(5, (2, 3, 4), s.layers, ranges)       # ln_final.weight / bias, text_projection: first part
+        grads, flat = _grad_buffers(params, order)
         blocks = _block_grads(grads, 5)
         g = N.TextGrads(*[t.data_ptr() for t in grads[:5]], C.cast(blocks, C.POINTER(N.BlockGrads)))
         dfeat = N.f32c(dfeat)
         B, L = text.shape
-        N.check(N.lib().cmh_text_backward(C.byref(s), N.ptr(text), B, L, N.ptr(ctx.kpm), N.ptr(dfeat), C.byref(g), N.ptr(ctx.tape),
-                                          ctx.tape.numel(), N.stream_ptr(dfeat.device)), "cmh_text_backward")
+        for k, (hi, lo) in enumerate(ranges):
+            N.check(N.lib().cmh_text_backward_part(C.byref(s), N.ptr(text), B, L, N.ptr(ctx.kpm), N.ptr(dfeat), C.byref(g), N.ptr(ctx.tape),
+                                                   ctx.tape.numel(), hi, lo, N.stream_ptr(dfeat.device)), "cmh_text_backward_part")
+            _sink(flat, params, grads, order, bounds, k)
         ctx.tape = None
         return (None, None, None) + tuple(grads)
 
@@ -117,12 +172,14 @@ class VitTrainTokens(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dtok):
         s, params = ctx.struct, ctx.params
-        grads = _grad_buffers(params)
+        grads, flat = _grad_buffers(params)
         blocks = _block_grads(grads, 8)
         g = N.VitGrads(*[t.data_ptr() for t in grads[:8]], C.cast(blocks, C.POINTER(N.BlockGrads)))
         dtok = N.f32c(dtok)
         N.check(N.lib().cmh_vit_backward_tokens(C.byref(s), ctx.B, N.ptr(dtok), C.byref(g), N.ptr(ctx.tape), ctx.tape.numel(),
                                                 N.stream_ptr(dtok.device)), "cmh_vit_backward_tokens")
+        if BUCKET_SINK is not None:
+            BUCKET_SINK(flat, list(params), list(grads))
         ctx.tape = None
         return (None, None) + tuple(grads)
 
@@ -146,7 +203,7 @@ class TextTrainTokens(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dtok, _drows):
         s, params, text = ctx.struct, ctx.params, ctx.text
-        grads = _grad_buffers(params)
+        grads, flat = _grad_buffers(params)
         blocks = _block_grads(grads, 5)
         g = N.TextGrads(*[t.data_ptr() for t in grads[:5]], C.cast(blocks, C.POINTER(N.BlockGrads)))
         dtok = N.f32c(dtok)
@@ -154,6 +211,8 @@ class TextTrainTokens(torch.autograd.Function):
         N.check(N.lib().cmh_text_backward_tokens(C.byref(s), N.ptr(text), B, L, N.ptr(ctx.kpm), N.ptr(dtok), C.byref(g),
                                                  N.ptr(ctx.tape), ctx.tape.numel(), N.stream_ptr(dtok.device)),
                 "cmh_text_backward_tokens")
+        if BUCKET_SINK is not None:
+            BUCKET_SINK(flat, list(params), list(grads))
         ctx.tape = None
         return (None, None, None) + tuple(grads)
 

@@ -146,14 +146,24 @@ class TrainBase(object):
 
     def _gather_code_shards(self, seen, *buffers):
         """With one process per GPU every rank has encoded its share of the set (rows `seen` of each buffer): ONE fused all-gather
-        of (position, codes...) rows fills the rest, so all ranks hold the whole code matrices before ranking."""
+        fills the rest, so all ranks hold the whole code matrices before ranking.  What travels is PACKED (SURVEY 8e "all-gather
+        packed DB codes"): per item an int32 position and, per code matrix, the two bit planes of cmh_pack_codes (sign, non-zero) -
+        4 + 2 * 2 * ceil(K/32) * 4 bytes for an (image, text) pair instead of 4 + 2 * K * 4 bytes of floats (NUS-WIDE, 128 bit:
+        6.9 MB instead of 196 MB); every rank then restores the reference's float buffers (train/base.py:130-148: save_mat and
+        calc_map_k take them) with cmh_unpack_codes.  Codes are exactly -1 / 0 / +1 (sign, argmax), so nothing is lost."""
         if du.world_size() == 1 or not seen:
             return
         mine = torch.cat(seen)
-        fused, widths = du.fuse_columns(mine.unsqueeze(1), *[b[mine] for b in buffers])      # f32: positions < 2^24 stay exact
-        parts = du.split_columns(du.all_gather_rows(fused, du.row_counts(mine.numel(), fused.device)), widths)
-        for buf, rows in zip(buffers, parts[1:]):
-            du.scatter_by_index(buf, parts[0].view(-1), rows)
+        cols, widths = [mine.to(torch.int32).unsqueeze(1)], [1]
+        for b in buffers:
+            sp, nz = N.pack_codes(b[mine])                          # validates the -1 / 0 / +1 domain (one flag read per matrix)
+            cols += [sp, nz]
+            widths += [sp.shape[1], nz.shape[1]]
+        fused = torch.cat(cols, dim=1).contiguous()
+        parts = torch.split(du.all_gather_rows(fused, du.row_counts(mine.numel(), fused.device)), widths, dim=1)
+        pos = parts[0].reshape(-1).long()
+        for i, buf in enumerate(buffers):
+            buf[pos] = N.unpack_codes(parts[1 + 2 * i], parts[2 + 2 * i], buf.shape[1])
 
     def get_code(self, data_loader, length: int):
         return self._code_loop(data_loader, length, lambda i, t, b: (

@@ -293,6 +293,10 @@ int cmh_pair_argmax_codes(const float* p, float* codes, int32_t M, int32_t K, vo
 /* bad_flag (device i32, caller zeroes it) is set to 1 if any code is not exactly -1, 0 or +1. */
 int cmh_pack_codes(const float* codes, int64_t n, int32_t bits, uint32_t* sign_plane,
                    uint32_t* nz_plane, int32_t* bad_flag, void* stream);
+/* The inverse of cmh_pack_codes: codes f32 [n, bits] in {-1, 0, +1} from the two bit planes.  Data-parallel evaluation exchanges the
+ * PLANES (16 bytes per 64-bit code pair instead of 512 bytes of floats: SURVEY 8e "all-gather packed DB codes") and restores the
+ * reference's float code matrices (train/base.py:130-148 img_buffer / text_buffer) on every rank with this call. */
+int cmh_unpack_codes(const uint32_t* sign_plane, const uint32_t* nz_plane, int64_t n, int32_t bits, float* codes, void* stream);
 /* bad_flag set if any label is negative or NaN (the reference's `L.L^T > 0` test then stops
  * being an intersection test). */
 int cmh_pack_labels(const float* labels, int64_t n, int32_t classes, uint32_t* packed,
@@ -326,6 +330,9 @@ int cmh_hamming_map(const uint32_t* q_sign, const uint32_t* q_nz, const uint32_t
                     int32_t Q, int64_t N, int32_t bits, int32_t classes, int64_t topk,
                     int32_t tie_order, int32_t depth_limit_override, float* ap, float* map,
                     int32_t* perm, void* workspace, size_t workspace_bytes, void* stream);
+/* map[1] = (((ap[0] + ap[1]) + ...) / Q), f32, in query order: the mean cmh_hamming_map itself appends, exposed for per-query APs
+ * that were computed on query shards by several ranks and gathered (utils/calc_utils.py:37-38 `map += AP`; `map / num_query`). */
+int cmh_map_mean(const float* ap, int32_t Q, float* map, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Pairwise similarity / quantisation losses (forward).  All f32; `loss` is a device scalar.
@@ -582,6 +589,13 @@ int cmh_vit_forward_train(const cmh_vit_weights* w, const float* image, int32_t 
                           void* stream);
 int cmh_vit_backward(const cmh_vit_weights* w, int32_t batch, const float* dfeat, const cmh_vit_grads* grads, void* tape,
                      size_t tape_bytes, void* stream);
+/* cmh_vit_backward in parts, for a data-parallel trainer that sends each bucket of gradients while the next part runs: one call
+ * runs the head (ln_post, proj) iff layer_hi == layers, then blocks layer_hi-1 .. layer_lo, then the embeddings (ln_pre, positional,
+ * class, conv1) iff layer_lo == 0; the gradient stream between parts stays in the tape.  Consecutive parts (layers..a, a..b, b..0)
+ * on one tape write exactly the gradients of the one-call form; the parameters of a part are final when its call returns.
+ * (Upstream: one loss.backward(), train/DSPH/hash_train.py:66.) */
+int cmh_vit_backward_part(const cmh_vit_weights* w, int32_t batch, const float* dfeat, const cmh_vit_grads* grads, void* tape,
+                          size_t tape_bytes, int32_t layer_hi, int32_t layer_lo, void* stream);
 /* The same two calls for the MITH trunk (model/MITH.py:56-82): ln_post + proj on EVERY token.  tokens_out / dtokens f32
  * [batch * (g*g + 1), embed_dim] (row b*(g*g+1) is the class token); tape as for cmh_vit_forward_train. */
 int cmh_vit_forward_train_tokens(const cmh_vit_weights* w, const float* image, int32_t batch, float* tokens_out, void* tape,
@@ -594,6 +608,10 @@ int cmh_text_forward_train(const cmh_text_weights* w, const int64_t* tokens, int
 int cmh_text_backward(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
                       const uint8_t* key_padding_mask, const float* dfeat, const cmh_text_grads* grads, void* tape,
                       size_t tape_bytes, void* stream);
+/* cmh_text_backward in parts (see cmh_vit_backward_part): head = ln_final + text_projection, embeddings = token + positional. */
+int cmh_text_backward_part(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
+                           const uint8_t* key_padding_mask, const float* dfeat, const cmh_text_grads* grads, void* tape,
+                           size_t tape_bytes, int32_t layer_hi, int32_t layer_lo, void* stream);
 
 /* CLIP1.encode_text of the MITH trunk under training (model/MITH.py:120-144): causal mask + key_padding_mask, every position is
  * run (no packing), ln_final + text_projection on every token.  tokens_out / dtokens f32 [batch * seq_len, embed_dim];

@@ -171,6 +171,69 @@ def _global_loss_worker(rank, world, port, out_dir):
     open(os.path.join(out_dir, f"gl{rank}"), "w").write("ok")
 
 
+def _bucket_worker(rank, world, port, out_dir):
+    """GradSync's in-place bucket route on gloo: a stand-in for a native tower (an autograd Function whose backward writes all
+    gradients into ONE flat buffer from model/base/train_ops.py and reports every finished part to BUCKET_SINK) must end with the
+    means of allreduce_mean_, with the parameters' .grad being views of the flat buffer (no packing, no copy-back)."""
+    from conftest import PKG  # noqa: F401
+    import dist_utils as du
+    from model.base import train_ops as T
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    du.init_from_env("gloo")
+    layers, nhead = 5, 3
+    torch.manual_seed(2)
+    params = [torch.nn.Parameter(torch.randn(4 * (i % 3 + 1), 4)) for i in range(nhead + 12 * layers)]
+    seen = {}
+
+    class FakeTower(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, *ps):
+            ctx.ps = ps
+            return x.sum() * sum(p.sum() for p in ps)
+
+        @staticmethod
+        def backward(ctx, g):
+            ranges = T._layer_parts(layers)
+            order, bounds = T._part_order(nhead, (1, 2), layers, ranges)
+            grads, flat = T._grad_buffers(list(ctx.ps), order)
+            seen["flat"], seen["ranges"] = flat, ranges
+            done = set()
+            for k, (hi, lo) in enumerate(ranges):          # what cmh_*_backward_part(hi, lo) writes
+                idx = ([1, 2] if k == 0 else []) + [nhead + 12 * l + j for l in range(lo, hi) for j in range(12)] + \
+                      ([0] if k == len(ranges) - 1 else [])
+                for i in idx:
+                    grads[i].fill_(float((rank + 1) * (i + 1)))
+                done |= set(idx)
+                T._sink(flat, list(ctx.ps), grads, order, bounds, k)
+            assert done == set(range(len(ctx.ps)))
+            return (None,) + tuple(grads)
+
+    head = torch.nn.Linear(3, 2)
+    sync = du.GradSync([params, list(head.parameters())])
+    for step in range(2):
+        for p in params + list(head.parameters()):
+            p.grad = None
+        (FakeTower.apply(torch.ones(2), *params) + head(torch.ones(3) * (rank + 1)).sum()).backward()
+        sync.finish()
+        assert seen["ranges"] == [(5, 4), (4, 2), (2, 0)] and [n for _, n in sync.bucket_log] == [2 + 12, 24, 24 + 1], sync.bucket_log
+        flat = seen["flat"]
+        for i, p in enumerate(params):
+            assert torch.equal(p.grad, torch.full_like(p, 1.5 * (i + 1))), i                            # mean of (i+1) and 2 (i+1)
+            assert flat.data_ptr() <= p.grad.data_ptr() < flat.data_ptr() + flat.numel() * 4, "gradient was copied out of the flat buffer"
+        assert torch.equal(head.weight.grad, torch.full_like(head.weight, 1.5))                         # the hook route, same step
+    sync.remove()
+    assert T.BUCKET_SINK is None
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+    open(os.path.join(out_dir, f"bk{rank}"), "w").write("ok")
+
+
+def test_world2_in_place_gradient_buckets(tmp_path):
+    port = _free_port()
+    mp.spawn(_bucket_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "bk0").exists() and (tmp_path / "bk1").exists()
+
+
 def test_world2_global_batch_loss_equals_single_process(tmp_path):
     """gather_loss_inputs + GradSync: loss and every gradient of a 2-rank step equal a 1-process step on the concatenated batch."""
     port = _free_port()

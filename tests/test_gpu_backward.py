@@ -182,6 +182,54 @@ def test_pooled_tail_of_the_training_towers_matches_the_full_path(mode):
         assert err < tol, (name, err)
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_tower_backward_in_parts_equals_one_call(mode):
+    """cmh_vit_backward_part / cmh_text_backward_part (model/base/train_ops.py runs each tower's backward as PARTS calls so that a
+    data-parallel trainer can send every bucket of gradients while the next part runs): the same gradients as ONE call, bit for
+    bit, all of them views of one flat buffer, and the bucket sink sees every parameter exactly once, last layers first."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import recipe
+    from model.base import train_ops as T
+    from test_gpu_clip import _clip
+    cfg, seed, B, L = recipe.CLIP_TINY, 7, 5, 16
+    image = torch.from_numpy(recipe.images(B, cfg["image_resolution"], seed)).to(DEV)
+    text = torch.from_numpy(recipe.captions(B, L, cfg["vocab_size"], seed)).to(DEV)
+    g = torch.Generator().manual_seed(3)
+    gi, gt = torch.randn(B, cfg["embed_dim"], generator=g).to(DEV), torch.randn(B, cfg["embed_dim"], generator=g).to(DEV)
+    res, sunk = {}, []
+    old_parts, old_sink = T.PARTS, T.BUCKET_SINK
+    try:
+        for parts in (1, 2):
+            T.PARTS = parts
+            T.BUCKET_SINK = (lambda flat, params, views: sunk.append((flat.numel(), [id(p) for p in params],
+                                                                       sum(v.numel() for v in views)))) if parts == 2 else None
+            clip = _clip(cfg, seed, mode)
+            ((clip.encode_image(image) * gi).sum() + (clip.encode_text(text) * gt).sum()).backward()
+            res[parts] = {n: p.grad for n, p in clip.named_parameters() if p.grad is not None}
+            if parts == 2:
+                names = {id(p): n for n, p in clip.named_parameters()}
+    finally:
+        T.PARTS, T.BUCKET_SINK = old_parts, old_sink
+    assert res[1].keys() == res[2].keys() and len(res[1]) > 50
+    for n in res[1]:
+        if n == "token_embedding.weight":      # the one atomic scatter of the backward pass: sums in arrival order
+            torch.testing.assert_close(res[1][n], res[2][n], rtol=1e-4, atol=1e-5 * float(res[1][n].abs().max()))
+        else:
+            assert torch.equal(res[1][n], res[2][n]), n
+        assert res[2][n].untyped_storage().nbytes() > 4 * res[2][n].numel(), n      # lives inside its tower's flat buffer
+    assert len(sunk) == 4                                         # 2 towers x 2 parts (the tiny towers have 2 blocks)
+    covered = [i for _, ids, _ in sunk for i in ids]
+    assert len(covered) == len(set(covered)) == len(res[2])       # every parameter in exactly one bucket
+    for numel, ids, vsum in sunk:
+        assert numel == vsum                                      # the slice holds exactly its parameters' gradients
+    first = [names[i] for i in sunk[0][1]] + [names[i] for i in sunk[2][1]]
+    assert any("resblocks.1." in n for n in first) and not any("resblocks.0." in n for n in first)     # last block first
+    assert any("ln_post" in n or "ln_final" in n for n in first)                                       # with the head
+    last = [names[i] for i in sunk[1][1]] + [names[i] for i in sunk[3][1]]
+    assert any("positional_embedding" in n for n in last)
+
+
 @pytest.mark.parametrize("B,K,C,alpha", [(8, 16, 5, 0.8), (64, 64, 24, 0.8), (256, 64, 80, 0.8), (32, 128, 10, 0.0)])
 def test_hyp_loss_backward(B, K, C, alpha):
     """d HyP / d(x, y, proxies) against torch autograd (fp64) of the reference formula (train/DSPH/loss.py:22-72)."""

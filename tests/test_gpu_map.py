@@ -45,6 +45,34 @@ def test_map_matches_reference_goldens(golden, name):
             assert np.array_equal(perm[i], g[f"{name}_ind{i}"])
 
 
+@pytest.mark.parametrize("n,K", [(1, 16), (77, 64), (1000, 128), (513, 48)])
+def test_unpack_codes_is_the_inverse_of_pack_codes(n, K):
+    """cmh_unpack_codes: what data-parallel evaluation does with the gathered bit planes (train/base.py::_gather_code_shards)."""
+    import cmh_native as N
+    g = torch.Generator().manual_seed(n + K)
+    codes = torch.randint(-1, 2, (n, K), generator=g).float().to(DEV)          # -1, 0, +1: sign() yields exact zeros too
+    sp, nz = N.pack_codes(codes)
+    assert torch.equal(N.unpack_codes(sp, nz, K), codes)
+    with pytest.raises(N.NativeError):
+        N.unpack_codes(sp, nz, K + 64)
+
+
+def test_map_mean_is_the_ranking_kernels_own_mean(golden):
+    """cmh_map_mean on a per-query AP vector = the mAP cmh_hamming_map returns with it, bit for bit (dist_utils.mean_in_query_order
+    uses it on APs gathered from query shards)."""
+    import cmh_native as N
+    g = golden("map.npz")
+    qB, rB, qL, rL, k = case_inputs(g, "corr_1k_64_k50")
+    mp, ap, _ = _gpu_map(qB, rB, qL, rL, k)
+    assert float(N.map_mean(ap)) == float(mp)
+    acc = np.float32(0)
+    for v in ap.cpu().numpy():
+        acc = np.float32(acc + v)
+    assert float(N.map_mean(ap)) == float(acc / np.float32(ap.numel()))
+    import dist_utils as du
+    assert float(du.mean_in_query_order(ap)) == float(mp)
+
+
 def test_entry_point_calc_map_k_matrix(golden):
     """The reference-shaped API (utils/calc_utils.py) with CPU labels, like train/base.py:259 passes them."""
     from utils.calc_utils import calc_hammingDist, calc_map_k_matrix, calc_neighbor

@@ -63,6 +63,10 @@ def test_two_ranks_equal_one_rank(tmp_path, method):
         if method != "MITH":     # MITH logs a rank-local mean for its per-sample terms; its gradients are the global ones
             assert abs(got["loss"] - ref["loss"]) <= 2e-6 * abs(ref["loss"]), (got["loss"], ref["loss"])
         assert got["maps"] == ref["maps"], (got["maps"], ref["maps"])
+        # the towers' gradients travelled as in-place buckets of the flat buffer (2 towers x >= 2 parts; MITH's all-token trunk: one
+        # bucket per tower) and the parameters' .grad are views of that buffer: nothing packed, nothing copied back
+        assert got["buckets"] is not None and len(got["buckets"]) >= (2 if method == "MITH" else 4), got["buckets"]
+        assert got["tower_grad_is_view"]
         g = np.load(tmp_path / f"grads_w2r{r}.npz")
         assert set(g.files) == set(g_ref.files)
         for name in g_ref.files:
