@@ -193,6 +193,7 @@ def main():
                          "metric's gradient all-reduce can never stall the headline scaling line)")
     ap.add_argument("--no-overlap-towers", action="store_true", help="run the text tower after the image tower on one stream")
     ap.add_argument("--no-precision-legs", action="store_true", help="skip flip_rate_vs_f32 and the timed f32-mode / fp8-mode legs")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the one-number-per-BASELINE-config legs (bench_configs.py)")
     ap.add_argument("--map-queries", type=int, default=5000)
     ap.add_argument("--map-db", type=int, default=15015)
     a = ap.parse_args()
@@ -595,6 +596,24 @@ def main():
                 out["input_pipeline"]["captions_per_s"] = None
         except Exception as exc:
             out["input_pipeline"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+
+    if rank == 0 and world == 1 and not a.no_config_legs:
+        # one timed number for each of the other BASELINE.json configs (the headline above is configs[1]); each leg builds its own
+        # model, so the headline's is released first
+        import gc
+        import bench_configs
+        del clip, img_head, txt_head, hyp
+        gc.collect()
+        torch.cuda.empty_cache()
+        for name, leg in bench_configs.LEGS:
+            try:
+                t_leg = time.perf_counter()
+                out[name] = leg(dev) if name != "dchmt_epoch" else leg(dev, cpu_sample=not a.no_cpu_baseline)
+                out[name]["leg_wallclock_s"] = round(time.perf_counter() - t_leg, 1)
+            except Exception as exc:
+                out[name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            gc.collect()
+            torch.cuda.empty_cache()
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cb = cpu_baseline(L, K)

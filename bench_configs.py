@@ -1,0 +1,268 @@
+"""One timed number per BASELINE.json config besides the headline (configs[1]), for bench.py (rank 0, one GPU, a few seconds each):
+
+  configs[0]  dchmt_epoch       DCHMT, 16 bit, batch 32: one training epoch over 1 000 synthetic pairs + the four calc_map_k
+                                directions on 1 000 x 1 000 (reference train/DCHMT/hash_train.py:44-68, train/base.py:255-262),
+                                through this repository's own trainer; beside it the same step's arithmetic on the host cores
+  configs[2]  mith_step         MITH, 64 bit, batch 256: all-token ViT-B/32 trunk + HashingModel forward at 32 / 77 caption tokens
+                                (model/MITH.py:427-453) and the full training step at 32 tokens (train/MITH/hash_train.py:80-201)
+  configs[3]  map_eval_nuswide  5 000 queries x 190 834 database codes x 128 bit, 21 classes, the four directions, reference tie
+                                order (utils/calc_utils.py:16-39 at NUS-WIDE scale)
+  configs[4]  twdh_fp8          TwDH long (128 bit) + short (16 bit) codes through the fp8 towers (model/TwDH.py:146-167), scales
+                                calibrated on ANOTHER batch than the one measured
+
+Every leg builds its own model from seeded random weights (no checkpoint or dataset travels), returns a dict and never raises past
+bench.py's try/except.  Nothing here is part of `value`."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+
+def _sync_time(fn, n):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n, out
+
+
+def map_eval_nuswide(dev, Q=5000, Nn=190834, K=128, C=21):
+    import cmh_native as N
+    g = torch.Generator().manual_seed(4321)
+    rL, qL = (torch.rand(Nn, C, generator=g) < 0.1).float(), (torch.rand(Q, C, generator=g) < 0.1).float()
+    W = torch.randn(C, K, generator=g)
+    mk = lambda lab: torch.sign(lab @ W + 0.5 * torch.randn(lab.shape[0], K, generator=g) + 1e-3).to(dev)
+    planes = {k: N.pack_codes(v) for k, v in dict(r_img=mk(rL), r_txt=mk(rL), q_img=mk(qL), q_txt=mk(qL)).items()}
+    rLp, qLp = N.pack_labels(rL.to(dev)), N.pack_labels(qL.to(dev))
+
+    def four(tie):
+        return [N.hamming_map(planes[a], qLp, planes[b], rLp, K, C, tie_order=tie)[0]
+                for a, b in (("q_img", "r_txt"), ("q_txt", "r_img"), ("q_img", "r_img"), ("q_txt", "r_txt"))]
+    out = {}
+    for tie, name in ((N.TIE_REFERENCE, "reference"), (N.TIE_STABLE, "stable")):
+        four(tie)
+        dt, maps = _sync_time(lambda: four(tie), 1)
+        out[name] = (dt * 1e3, float(maps[0]))
+    alg = 4 * ((Q + Nn) * K // 8 + (Q + Nn) * ((C + 7) // 8) + 4 * Q)
+    return {"ms": round(out["reference"][0], 2), "directions": 4, "Q": Q, "N": Nn, "bits": K, "classes": C,
+            "code_pairs_per_s": round(4.0 * Q * Nn / (out["reference"][0] * 1e-3), 1),
+            "algorithmic_GBps": round(alg / (out["reference"][0] * 1e-3) / 1e9, 3),
+            "tie_order": "reference (libstdc++ introsort)", "mAP_i2t": round(out["reference"][1], 6),
+            "stable_tie_order": {"ms": round(out["stable"][0], 2), "mAP_i2t": round(out["stable"][1], 6)},
+            "what": "configs[3] DNPH nuswide 128 bit: full-database Hamming mAP, 4 directions, codes resident (one GPU: all queries)"}
+
+
+def _vitb32_state(seed):
+    import recipe
+    return {k: torch.from_numpy(v) for k, v in recipe.clip_state_dict(recipe.CLIP_VITB32, seed).items()}
+
+
+def mith_step(dev, B=256, K=64, C=80, bank=10000):
+    """forward: all-token trunk + HashingModel -> sign codes; training step: + the five loss groups against the memory bank,
+    backward through HashingModel and both towers, fused BertAdam (the reference's loop body, train/MITH/hash_train.py:80-201)."""
+    from types import SimpleNamespace
+    import recipe
+    import cmh_native as N
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+    import mithutil as mu
+    from model.MITH import HashingModel, build_model
+    from model.base.optimization import BertAdam
+    from train.MITH.hash_train import MITHTrainer
+    torch.manual_seed(0)
+    clip = build_model(_vitb32_state(1)).to(dev).float().set_gemm_dtype("bf16")
+    hm = HashingModel(clip_embed_dim=512, args=SimpleNamespace(output_dim=K, **mu.ARGS)).to(dev).eval().set_gemm_dtype("bf16")
+    img = torch.randn(B, 3, 224, 224, device=dev)
+    out = {"batch": B, "bits": K, "what": "configs[2] MITH coco 64 bit: ViT-B/32 trunk returning every token + HashingModel (bf16 GEMMs)"}
+
+    def fwd(txt, kpm):
+        with torch.no_grad():
+            seq_i, _, cls_i = clip.encode_image(img)
+            seq_t, _, nk, eos = clip.encode_text(txt, kpm)
+            od = hm(seq_i, seq_t, cls_i, eos, nk)            # codes as the trainer's evaluation forms them (train/MITH/hash_train.py:127-131)
+            return N.sign_codes(od['img_tokens_hash'] + od['img_cls_hash']), N.sign_codes(od['txt_tokens_hash'] + od['txt_cls_hash'])
+    for L in (32, 77):
+        txt = torch.from_numpy(recipe.captions(B, L, 49408, 1)).to(dev)
+        kpm = txt == 0
+        for _ in range(2):
+            fwd(txt, kpm)
+        dt, _ = _sync_time(lambda: fwd(txt, kpm), 5)
+        out[f"forward_{L}_tokens"] = {"ms": round(dt * 1e3, 3), "pairs_per_s": round(B / dt, 1)}
+    # training step at the reference's default caption length (argsbase.py:20 --max-words 32)
+    hm.train()
+    txt = torch.from_numpy(recipe.captions(B, 32, 49408, 1)).to(dev)
+    kpm = txt == 0
+    label = (torch.rand(B, C, device=dev) < 0.1).float()
+    opt = BertAdam([{"params": [p for n, p in clip.named_parameters() if n != "logit_scale"], "lr": 1e-5}, {"params": hm.parameters(), "lr": 1e-3}],
+                   lr=1e-3, warmup=0.1, schedule="warmup_cosine", b1=0.9, b2=0.98, e=1e-6, t_total=1000, weight_decay=0.2, max_grad_norm=1.0)
+    me = SimpleNamespace(args=SimpleNamespace(**mu.HP), rank=0, k_bits=K, train_labels=(torch.rand(bank, C, device=dev) < 0.1).float())
+    for n in ("img_buffer_tokens", "img_buffer_cls", "txt_buffer_tokens", "txt_buffer_cls"):
+        setattr(me, n, torch.randn(bank, K, device=dev))
+    for name in ("bayesian_loss", "info_nce_loss", "info_nce_loss_bmm", "quantization_loss_2", "make_B", "sq_diff"):
+        setattr(me, name, (lambda n: (lambda *x, **k: getattr(MITHTrainer, n)(me, *x, **k)))(name))
+    me._grad = MITHTrainer._grad
+
+    def step():
+        seq_i, _, cls_i = clip.encode_image(img)
+        seq_t, _, nk, eos = clip.encode_text(txt, kpm)
+        loss = sum(MITHTrainer.compute_loss(me, hm(seq_i, seq_t, cls_i, eos, nk), label).values())
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(2):
+        step()
+    dt, loss = _sync_time(step, 3)
+    out["train_step_32_tokens"] = {"ms": round(dt * 1e3, 3), "pairs_per_s": round(B / dt, 1), "loss": round(float(loss.detach()), 4),
+                                   "memory_bank_rows": bank, "classes": C}
+    return out
+
+
+def twdh_fp8(dev, B=256, K=128, S=16, C=21):
+    import recipe
+    import cmh_native as N
+    from model.TwDH import MTwDH
+    from train.TwDH.hash_train import synthetic_assets
+    seed = 3
+    lc, sc, tr = synthetic_assets(C, K, short_dims=(S,), seed=seed)
+    torch.manual_seed(seed)
+    model = MTwDH(outputDim=K, clipPath=_vitb32_state(seed), saveDir="/tmp/cmh_bench_twdh", long_center=lc, short_center=sc, trans=tr).to(dev)
+    model.float().eval()
+    g = torch.Generator().manual_seed(77)
+    img, cal_img = torch.randn(B, 3, 224, 224, generator=g).to(dev), torch.randn(B, 3, 224, 224, generator=g).to(dev)
+    txt = torch.from_numpy(recipe.captions(B, 32, 49408, 5)).to(dev)
+    cal_txt = torch.from_numpy(recipe.captions(B, 32, 49408, 6)).to(dev)
+
+    def codes():
+        with torch.no_grad():
+            li, si, lt, st, _, _ = model(img, txt)
+            return [N.pair_argmax_codes(v.reshape(B, -1)) for v in (li, si[str(S)], lt, st[str(S)])]
+    res = {}
+    for mode in ("fp8", "bf16", "f32"):
+        model.clip.set_gemm_dtype(mode)
+        if mode == "fp8":
+            with torch.no_grad():
+                model.clip.calibrate_fp8(image=cal_img, text=cal_txt)       # NOT the measured batch
+        for _ in range(2):
+            codes()
+        dt, c = _sync_time(codes, 3 if mode == "f32" else 10)
+        res[mode] = (dt, c)
+    diff = lambda a, b: round(float(sum((x != y).float().sum() for x, y in zip(a, b)) / sum(x.numel() for x in a)), 5)
+    dt8 = res["fp8"][0]
+    return {"ms": round(dt8 * 1e3, 3), "pairs_per_s": round(B / dt8, 1), "codes_per_s": round(2 * B / dt8, 1),
+            "code_bits_per_s": round(2 * B * (K + S) / dt8, 1), "batch": B, "long_bits": K, "short_bits": S,
+            "bf16_ms": round(res["bf16"][0] * 1e3, 3), "speedup_vs_bf16": round(res["bf16"][0] / dt8, 3),
+            "bits_differing_from_f32_mode": diff(res["fp8"][1], res["f32"][1]),
+            "bf16_bits_differing_from_f32_mode": diff(res["bf16"][1], res["f32"][1]),
+            "what": "configs[4] TwDH nuswide 16+128: image + 32-token caption -> fp8 towers -> ModalityHash -> long + short argmax codes; "
+                    "activation scales calibrated on a different seeded batch"}
+
+
+def dchmt_epoch(dev, cpu_sample=True, pairs=1000, batch=32, bits=16):
+    import recipe
+    import main
+    from train.DCHMT.hash_train import DCHMTTrainer
+    tmp = "/tmp/cmh_bench_dchmt"
+    os.makedirs(tmp, exist_ok=True)
+    ck = os.path.join(tmp, "vitb32_random.pt")
+    torch.save(_vitb32_state(11), ck)
+    argv, run = sys.argv, DCHMTTrainer.run
+    sys.argv = ["main.py", "-clip-path", ck, "--save-dir", os.path.join(tmp, "run"), "--batch-size", str(batch), "--num-workers", "0",
+                "--query-num", str(pairs), "--train-num", str(pairs), "--synthetic-size", str(2 * pairs), "--gemm-dtype", "bf16",
+                "--epochs", "1", "--save-mat", "false"]
+    DCHMTTrainer.run = lambda self: None                   # construct only; the epoch and the evaluation are timed below
+    try:
+        torch.manual_seed(1)
+        tr = main.trainers["DCHMT"](argparse.Namespace(method="DCHMT", dataset="synthetic", output_dim=bits, is_train=True), dev.index or 0)
+    finally:
+        sys.argv, DCHMTTrainer.run = argv, run
+    # the synthetic set draws every item on the host (numpy normal deviates, ~1 ms per image): keep that out of the numbers the
+    # way a resident dataset would be - materialise the three sets once, then iterate over tensors
+    def resident(loader):
+        items = [loader.dataset[i] for i in range(len(loader.dataset))]
+        cols = [torch.stack([torch.as_tensor(v) for v in c]) for c in zip(*items)]
+        ds = torch.utils.data.TensorDataset(*cols)
+        return torch.utils.data.DataLoader(ds, batch_size=batch, shuffle=False)
+    tr.train_loader, tr.query_loader, tr.retrieval_loader = (resident(l) for l in (tr.train_loader, tr.query_loader, tr.retrieval_loader))
+    tr.save_model = lambda epoch: None
+    step0 = tr._step(*[t for t in next(iter(tr.train_loader))][:3])          # warm-up step: weight copies, workspaces
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tr.train_epoch(0)
+    torch.cuda.synchronize()
+    t_train = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    maps = tr.valid(0)
+    torch.cuda.synchronize()
+    t_eval = time.perf_counter() - t0
+    steps = len(tr.train_loader)
+    out = {"train_epoch_s": round(t_train, 3), "steps": steps, "ms_per_step": round(t_train / steps * 1e3, 2),
+           "pairs_per_s_training": round(pairs / t_train, 1), "valid_s": round(t_eval, 3),
+           "valid_what": f"encode {pairs} queries + {pairs} database pairs, 4 x calc_map_k {pairs} x {pairs}",
+           "mAP_i2t": round(float(maps[0]), 6), "batch": batch, "bits": bits, "first_loss": round(float(step0.detach()), 4),
+           "what": "configs[0] DCHMT flickr25k 16 bit, batch 32, random-init ViT-B/32 (bf16 mode): the trainer's own train_epoch + valid "
+                   "on a resident synthetic set of 1 000 train / 1 000 query / 1 000 database pairs"}
+    del tr
+    torch.cuda.empty_cache()
+    if cpu_sample:
+        out["cpu"] = _dchmt_cpu_sample(pairs, batch, bits)
+        out["cpu"]["epoch_speedup"] = round(out["cpu"]["train_epoch_s_extrapolated"] / t_train, 1)
+    return out
+
+
+def _dchmt_cpu_sample(pairs, batch, bits):
+    """The same step's dominant arithmetic on the host cores, BASELINE.md 4 (2): both towers forward + backward through ATen's CPU
+    ops (oracle/torch_cpu.py, fp32), the select head, a pairwise loss of the reference's shape and an Adam update of all 151 M
+    parameters; two steps timed, extrapolated to the epoch.  Plus calc_map_k 1k x 1k with the reference's algorithm (oracle)."""
+    import recipe
+    import oracle
+    from oracle.torch_cpu import TorchClip
+    try:
+        threads = max(1, min(len(os.sched_getaffinity(0)), 16))
+    except AttributeError:
+        threads = max(1, min(os.cpu_count() or 1, 16))
+    torch.set_num_threads(threads)
+    tc = TorchClip(recipe.clip_state_dict(recipe.CLIP_VITB32, 11))
+    params = [v.requires_grad_(True) for v in tc.sd.values() if v.dtype == torch.float32]
+    head_i, head_t = torch.nn.Linear(512, 2 * bits), torch.nn.Linear(512, 2 * bits)
+    opt = torch.optim.Adam(params + list(head_i.parameters()) + list(head_t.parameters()), lr=1e-5)
+    img = torch.from_numpy(recipe.images(batch, 224, 4))
+    txt = torch.from_numpy(recipe.captions(batch, 32, 49408, 4))
+    lab = (torch.rand(batch, 24) < 0.15).float()
+    enc_i, enc_t = TorchClip.encode_image.__wrapped__, TorchClip.encode_text.__wrapped__     # the bodies, without no_grad
+
+    def step():
+        hi = torch.softmax(head_i(enc_i(tc, img)).view(batch, bits, 2), -1).reshape(batch, -1)
+        ht = torch.softmax(head_t(enc_t(tc, txt)).view(batch, bits, 2), -1).reshape(batch, -1)
+        sim = (lab @ lab.t() > 0).float()
+        loss = ((torch.cdist(hi, ht) - (1 - sim)) ** 2).mean() + ((torch.cdist(hi, hi) - (1 - sim)) ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    t0 = time.perf_counter()
+    step()
+    first = time.perf_counter() - t0
+    n = 1
+    t0 = time.perf_counter()
+    if first < 8.0:
+        step()
+        per = time.perf_counter() - t0
+    else:
+        per = first
+    steps = (pairs + batch - 1) // batch
+    rng = np.random.default_rng(0)
+    qL, rL = (rng.random((pairs, 24)) < 0.15).astype(np.float32), (rng.random((pairs, 24)) < 0.15).astype(np.float32)
+    qB, rB = np.sign(rng.standard_normal((pairs, bits))).astype(np.float32), np.sign(rng.standard_normal((pairs, bits))).astype(np.float32)
+    t0 = time.perf_counter()
+    oracle.map_k(qB, rB, qL, rL)
+    t_map = time.perf_counter() - t0
+    return {"step_s": round(per, 3), "steps_timed": n + (1 if first < 8.0 else 0), "threads": threads,
+            "train_epoch_s_extrapolated": round(per * steps, 1), "calc_map_k_1k_x_1k_s": round(t_map, 3), "kind": "port",
+            "what": "ATen CPU ops, fp32: both towers fwd + bwd, select head, pairwise loss, Adam on all parameters; extrapolated to "
+                    f"{steps} steps; calc_map_k by the C++ restatement of the reference's algorithm (one direction)"}
+
+
+LEGS = (("map_eval_nuswide", map_eval_nuswide), ("twdh_fp8", twdh_fp8), ("mith_step", mith_step), ("dchmt_epoch", dchmt_epoch))
