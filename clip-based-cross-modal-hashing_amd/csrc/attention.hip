@@ -266,6 +266,19 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const bf16_t* __rest
     }
   }
 
+#if defined(ATT_ABL) && ATT_ABL == 3
+  {
+    float keep = 0.f;
+#pragma unroll
+    for (int s = 0; s < NKS; ++s)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) keep += static_cast<float>(vf[s][dt][0]);
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) keep += static_cast<float>(kf[kt][0][0]) + static_cast<float>(kf[kt][1][0]);
+    if (keep == 123.456f) o[0] = 1;
+    return;
+  }
+#endif
   const int nqt = (Tn + 15) >> 4;
   // the NEXT query tile's fragments are fetched while the current tile computes (8 more registers): loaded at the top of its
   // own iteration, each tile's first MFMA waited a full L2 / Infinity-Cache round trip for them
@@ -305,15 +318,23 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const bf16_t* __rest
     for (int kt = 0; kt < NKT; ++kt) m = fmaxf(fmaxf(m, fmaxf(sc[kt][0], sc[kt][1])), fmaxf(sc[kt][2], sc[kt][3]));
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float l = 0.f;
+    // exp((s - m) / 8) = 2^(s c - m c), c = log2(e) / 8: ONE packed FMA per two scores (v_pk_fma_f32) ahead of the v_exp_f32, and the
+    // row sums as packed adds - this kernel is VALU-issue bound (three waves per SIMD queue for it), not matrix-pipe bound
+    typedef __attribute__((ext_vector_type(2))) float af32x2_t;
+    const float kC = 0.18033688011112042f;
+    const af32x2_t mc = {-m * kC, -m * kC}, cc = {kC, kC};
+    af32x2_t l2 = {0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = __builtin_amdgcn_exp2f((sc[kt][r] - m) * 0.18033688011112042f);   // exp((s - m) / 8): masked scores give 0
-        sc[kt][r] = p;
-        l += p;
+      for (int r = 0; r < 4; r += 2) {
+        const af32x2_t e = __builtin_elementwise_fma(af32x2_t{sc[kt][r], sc[kt][r + 1]}, cc, mc);   // masked scores (-1e30) give 2^-huge = 0
+        const af32x2_t p = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+        sc[kt][r] = p[0];
+        sc[kt][r + 1] = p[1];
+        l2 += p;
       }
+    float l = l2[0] + l2[1];
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     l = m > -1e29f ? l : 0.f;                                   // every key masked: no row to normalise (as before: 0 / 0)
@@ -328,6 +349,15 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const bf16_t* __rest
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) oc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[s][dt], pb, oc[dt], 0, 0, 0);
     }
+#if defined(ATT_ABL) && (ATT_ABL == 1 || ATT_ABL == 2)
+    {
+      float keep = l;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) keep += oc[dt][0] + oc[dt][1] + oc[dt][2] + oc[dt][3];
+      if (keep == 123.456f) o[0] = 1;
+      continue;
+    }
+#endif
     if (qrow < Tn && o8_inv_scale > 0.f) {
       // fp8 mode: the out_proj GEMM's operand leaves as e4m3(o / act_scale), 4 bytes per lane and head-dim tile
       const float inv = o8_inv_scale / l;
@@ -339,15 +369,26 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const bf16_t* __rest
         w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(oc[dt][2] * inv), cl(oc[dt][3] * inv), w, true);
         *reinterpret_cast<uint32_t*>(op8 + 16 * dt) = static_cast<uint32_t>(w);
       }
-    } else if (qrow < Tn) {
+    } else {
+      // bf16 output, 16 bytes per lane and store: v_permlane16_swap exchanges, between the lane rows (g, g+1), the packed words of
+      // two neighbouring head-dim tiles, so that an even lane row owns 8 consecutive dims of tile 2p and an odd one 8 consecutive
+      // dims of tile 2p+1 - two 16-byte stores per lane and query tile (64-byte runs per row) instead of four 8-byte ones: the
+      // kernel's store tail was issue-bound (profiles/r03_attention_ablation.txt: 6 of 20 us; staging the tile through LDS to write
+      // whole 128-byte rows measured no better: 18.1 against 17.8 us)
       const float inv = 1.0f / l;
-      bf16_t* op = o + (srow + qrow) * d + h * HD + 4 * g;
+      bf16_t* op = o + (srow + (qrow < Tn ? qrow : Tn - 1)) * d + h * HD + (g & 1) * 16 + (g & 2) * 4;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        uint2 pk;
-        pk.x = static_cast<uint32_t>(f32_to_bf16(oc[dt][0] * inv)) | (static_cast<uint32_t>(f32_to_bf16(oc[dt][1] * inv)) << 16);
-        pk.y = static_cast<uint32_t>(f32_to_bf16(oc[dt][2] * inv)) | (static_cast<uint32_t>(f32_to_bf16(oc[dt][3] * inv)) << 16);
-        *reinterpret_cast<uint2*>(op + 16 * dt) = pk;
+      for (int pr = 0; pr < 2; ++pr) {
+        uint32_t lo[2], hi[2];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          lo[w] = pack_bf16x2(oc[2 * pr][2 * w] * inv, oc[2 * pr][2 * w + 1] * inv);
+          hi[w] = pack_bf16x2(oc[2 * pr + 1][2 * w] * inv, oc[2 * pr + 1][2 * w + 1] * inv);
+        }
+        typedef __attribute__((ext_vector_type(2))) unsigned au2_t;
+        const au2_t s0 = __builtin_amdgcn_permlane16_swap(lo[0], hi[0], false, false);
+        const au2_t s1 = __builtin_amdgcn_permlane16_swap(lo[1], hi[1], false, false);
+        if (qrow < Tn) *reinterpret_cast<uint4*>(op + 32 * pr) = uint4{s0[0], s1[0], s0[1], s1[1]};
       }
     }
   }
