@@ -687,7 +687,8 @@ static int text_forward_train_impl(const cmh_text_weights* w, const int64_t* tok
   }
   if ((rc = launch_text_embed_packed(tokens, w->token_embedding, w->positional_embedding, t.L[0].x_in, xh, t.rows, B, L, d,
                                      w->vocab_size, seq_off, st))) return rc;
-  const bool tail = !tokens_out && train_pooled_tail();      // the same rule in text_backward_impl
+  // (the gathered attention rows are parked behind the first B rows of the h2 slot: the pooled tail needs 2 B rows of tape there)
+  const bool tail = !tokens_out && train_pooled_tail() && rows >= 2 * B;      // the same rule in text_backward_impl
   for (int i = 0; i < w->layers; ++i) {
     void* nxt = i + 1 < w->layers ? t.L[i + 1].x_in : t.x_last;
     if ((rc = block_forward_train(w->blocks[i], dt, xh, t.L[i], nxt, B, L, d, 1, key_padding_mask, st, rows, seq_off,
@@ -748,7 +749,7 @@ static int text_backward_impl(const cmh_text_weights* w, const int64_t* tokens, 
     seq_off = t.seq_off;
     rows = total;
   }
-  const bool tail = !dtokens && train_pooled_tail();
+  const bool tail = !dtokens && train_pooled_tail() && rows >= 2 * B;
   if (layer_hi == w->layers) {
     if ((rc = zero_pad_buffers(t, static_cast<size_t>(rows), st))) return rc;
     if (dtokens) {

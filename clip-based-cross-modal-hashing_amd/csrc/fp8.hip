@@ -28,13 +28,16 @@ __global__ __launch_bounds__(256) void fp8_quantize_rows_kernel(const float* __r
   if (row >= N) return;
   const float* src = w + static_cast<size_t>(row) * K;
   float m = 0.f;
+  bool nan = false;      // fmaxf drops NaN operands: a NaN weight makes the row's scale NaN (and with it every output of that channel)
   for (int k = lane * 4; k < K; k += 256) {
     const float4 v = *reinterpret_cast<const float4*>(src + k);
+    nan |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
     m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  const float scale = m > 0.f ? m / 448.f : 1.f;
+  nan = __any(nan);
+  const float scale = nan ? __uint_as_float(0x7fc00000u) : (m > 0.f ? m / 448.f : 1.f);
   const float inv = 1.f / scale;
   if (lane == 0) colscale[row] = scale;
   uint32_t* dst = reinterpret_cast<uint32_t*>(q + static_cast<size_t>(row) * K);
@@ -66,10 +69,13 @@ __global__ __launch_bounds__(256) void fp8_dequantize_kernel(const uint32_t* __r
 // out[0] = max(out[0], max |x|): non-negative floats order like their bit patterns, so one atomicMax per workgroup
 __global__ __launch_bounds__(256) void amax_kernel(const void* __restrict__ x, int kind, size_t n4, float* __restrict__ out) {
   float m = 0.f;
+  bool nan = false;      // fmaxf drops NaN operands, so a NaN is tracked on its own and reported as +inf (scales then fail loudly)
   for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < n4; i += static_cast<size_t>(gridDim.x) * 256) {
     const float4 v = load4_as_f32(x, i * 4, kind);
+    nan |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
     m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
   }
+  if (nan) m = __uint_as_float(0x7f800000u);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   __shared__ float part[4];
@@ -77,7 +83,6 @@ __global__ __launch_bounds__(256) void amax_kernel(const void* __restrict__ x, i
   __syncthreads();
   if (threadIdx.x == 0) {
     m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
-    if (!(m == m)) m = __uint_as_float(0x7f800000u);   // a NaN anywhere must not hide: report +inf
     atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
   }
 }

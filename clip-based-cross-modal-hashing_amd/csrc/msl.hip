@@ -341,6 +341,11 @@ __global__ __launch_bounds__(256) void spl_bwd_cols_kernel(const float* __restri
 
 using namespace cmh;
 
+// Largest (global) batch of the multi-similarity / self-paced losses: the backward kernels keep one f32 per batch row in dynamic
+// LDS (B * 4 bytes next to ~1 KB of static LDS, inside the 64 KB a launch gets without raising its limit) and the workspace holds
+// two [B, B] f32 matrices (512 MB at the limit).  Under data parallelism B is the GLOBAL batch (dist_utils.gather_loss_inputs).
+static constexpr int kMslMaxB = 8192;
+
 extern "C" size_t cmh_spl_workspace_bytes(int32_t B) {
   if (B <= 0) return 0;
   return msl_carve(nullptr, static_cast<size_t>(B)).total + align_up(static_cast<size_t>(B) * 8, 256);
@@ -348,7 +353,7 @@ extern "C" size_t cmh_spl_workspace_bytes(int32_t B) {
 
 static int spl_check(const float* a, const float* labels, int B, int K, int C, float tau, float delta, void* ws, size_t ws_bytes, const char* what) {
   CMH_CHECK_ARG(a && labels && ws, "%s: null pointer", what);
-  CMH_CHECK_ARG(B > 0 && B <= 16384 && K > 0 && K <= kMslMaxK && C > 0 && C <= kMslMaxK, "%s: bad shape B=%d K=%d C=%d", what, B, K, C);
+  CMH_CHECK_ARG(B > 0 && B <= kMslMaxB && K > 0 && K <= kMslMaxK && C > 0 && C <= kMslMaxK, "%s: bad shape B=%d K=%d C=%d", what, B, K, C);
   CMH_CHECK_ARG(tau > 0.f && delta >= 0.f && delta <= 1.f, "%s: temperature %g, delta %g", what, tau, delta);
   if (ws_bytes < cmh_spl_workspace_bytes(B)) return fail(CMH_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, cmh_spl_workspace_bytes(B));
   return CMH_OK;
@@ -396,7 +401,7 @@ extern "C" size_t cmh_msl_workspace_bytes(int32_t B) {
 
 static int msl_check(const float* x, const float* labels, int B, int K, int Kl, void* workspace, size_t workspace_bytes, const char* what) {
   CMH_CHECK_ARG(x && labels && workspace, "%s: null pointer", what);
-  CMH_CHECK_ARG(B > 0 && B <= 16384 && K > 0 && K <= kMslMaxK && Kl > 0 && Kl <= kMslMaxK, "%s: bad shape B=%d K=%d Kl=%d", what, B, K, Kl);
+  CMH_CHECK_ARG(B > 0 && B <= kMslMaxB && K > 0 && K <= kMslMaxK && Kl > 0 && Kl <= kMslMaxK, "%s: bad shape B=%d K=%d Kl=%d", what, B, K, Kl);
   if (workspace_bytes < cmh_msl_workspace_bytes(B)) return fail(CMH_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", what, workspace_bytes, cmh_msl_workspace_bytes(B));
   return CMH_OK;
 }

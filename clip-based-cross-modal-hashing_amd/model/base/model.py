@@ -207,6 +207,7 @@ class CLIP(nn.Module):
         self._txt_cache = _TowerCache()
         self.assume_frozen = False     # True: skip the per-call parameter-version scan (pure inference)
         self._fp8_amax = {"vit": None, "text": None}     # [layers, 4] calibration maxima of the four GEMM inputs per block
+        self._fp8_amax_key = {"vit": None, "text": None}  # the parameter versions those maxima were measured with
 
     # -- reference API ---------------------------------------------------------------------------
     def initialize_parameters(self):
@@ -280,6 +281,7 @@ class CLIP(nn.Module):
                     if not bool(torch.isfinite(vals).all()):
                         raise N.NativeError("calibrate_fp8: non-finite activations in the calibration batch")
                     self._fp8_amax[tower] = vals.tolist()
+                    self._fp8_amax_key[tower] = self._fp8_param_key(tower)
                     (self._vit_cache if tower == "vit" else self._txt_cache).key = None       # scales changed: rebuild the fp8 structs
                     out.append(feat)
         finally:
@@ -294,6 +296,20 @@ class CLIP(nn.Module):
     @property
     def gemm_dtype(self) -> str:
         return {N.BF16: "bf16", N.FP8: "fp8"}.get(self._gemm_dtype, "f32")
+
+    def _fp8_param_key(self, tower):
+        blocks = self.visual.transformer if tower == "vit" else self.transformer
+        return tuple((p.data_ptr(), p._version) for p in blocks.parameters())
+
+    def _fp8_scales_current(self, tower):
+        """Activation scales belong to the weights they were calibrated with: after load_state_dict or a training step the blocks
+        produce other magnitudes, and stale per-tensor scales saturate at +-448 or waste range.  A change of any block parameter
+        since the calibration drops the maxima, so that the next fp8 batch calibrates itself (assume_frozen skips the check)."""
+        if self._fp8_amax[tower] is not None and not self.assume_frozen and self._fp8_amax_key[tower] != self._fp8_param_key(tower):
+            import warnings
+            warnings.warn(f"fp8 mode: the {tower} tower's weights changed since calibrate_fp8; re-calibrating on this batch")
+            self._fp8_amax[tower] = None
+        return self._fp8_amax[tower] is not None
 
     # -- native weight structs -------------------------------------------------------------------
     def _key(self, params):
@@ -363,8 +379,8 @@ class CLIP(nn.Module):
         """image f32 [B,3,R,R] -> [B, embed_dim] f32  (reference model/base/model.py:356-357,228-252)."""
         image = N.f32c(image)
         N.require_gpu(image, self.visual.proj)
-        if self._gemm_dtype == N.FP8 and self._fp8_amax["vit"] is None:
-            self.calibrate_fp8(image=image)              # first batch calibrates the activation scales
+        if self._gemm_dtype == N.FP8 and not self._fp8_scales_current("vit"):
+            self.calibrate_fp8(image=image)              # first batch (or first after a weight change) calibrates the activation scales
         s = self._vit_struct()
         B = image.shape[0]
         if tuple(image.shape[1:]) != (3, s.resolution, s.resolution):
@@ -389,7 +405,7 @@ class CLIP(nn.Module):
         """text i64 [B,L] -> [B, embed_dim] f32  (reference model/base/model.py:359-372)."""
         N.require_gpu(text, self.text_projection)
         text = text.to(torch.int64).contiguous()
-        if self._gemm_dtype == N.FP8 and self._fp8_amax["text"] is None:
+        if self._gemm_dtype == N.FP8 and not self._fp8_scales_current("text"):
             self.calibrate_fp8(text=text)
         s = self._text_struct()
         B, L = text.shape

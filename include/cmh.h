@@ -237,7 +237,8 @@ int cmh_qmi_loss_backward(const float* img, const float* txt, const uint32_t* la
  * [B,K] hash outputs, labels f32 [B,Kl] = the LabelNet codes (two samples are similar when their codes' dot product is > 0)
  * -> loss f32 [1]; thresh 0.5, margin 0.1, scales 2 / 40 as the reference fixes them.  Backward: dfeats (and dfeat2 when feat2 is
  * given; with feat2 = NULL both roles' gradients are summed into dfeats) = dloss[0] (NULL: 1) * d loss / d feats; it recomputes
- * the forward's statistics, so the workspace need not be kept between the two calls.  B <= 16384, K, Kl <= 1024. */
+ * the forward's statistics, so the workspace need not be kept between the two calls.  B <= 8192 (the global batch under data parallelism: B * 4 bytes of
+ * dynamic LDS per backward launch, two [B, B] f32 matrices of workspace), K, Kl <= 1024. */
 size_t cmh_msl_workspace_bytes(int32_t B);
 int cmh_msl_loss(const float* feats, const float* feat2, const float* labels, int32_t B, int32_t K, int32_t Kl, float* loss,
                  void* workspace, size_t workspace_bytes, void* stream);
@@ -249,7 +250,7 @@ int cmh_msl_loss_backward(const float* feats, const float* feat2, const float* l
  * f32 [B,C] multi-hot -> loss f32 [1] = mean_i -log(P_i / (P_i + N_i)) over exp(cos / temperature) of the label-sharing / other
  * pairs, with the detached self-paced weights exp(-1 - cos)^(delta/4) / exp(-1 + cos)^delta; delta in [0, 1] is what :23-27 derive
  * from (epoch, totalepoch) (0 = self_paced off).  Backward: da (and db; with b = NULL both roles' gradients are summed into da) =
- * dloss[0] (NULL: 1) * d loss / d a; it recomputes the forward's statistics.  B <= 16384, K, C <= 1024. */
+ * dloss[0] (NULL: 1) * d loss / d a; it recomputes the forward's statistics.  B <= 8192 (as above), K, C <= 1024. */
 size_t cmh_spl_workspace_bytes(int32_t B);
 int cmh_spl_loss(const float* a, const float* b, const float* labels, int32_t B, int32_t K, int32_t C, float temperature, float delta,
                  float* loss, void* workspace, size_t workspace_bytes, void* stream);

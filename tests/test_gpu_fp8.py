@@ -202,3 +202,35 @@ def test_twdh_codes_through_fp8_encoders():
         rate = float((a != r).float().mean())
         print(f"TwDH {name} codes, fp8 vs f32 encoders: {rate:.4f} of the bits differ")
         assert rate < 0.10, (name, rate)
+
+
+def test_amax_reports_nan_as_inf_and_stale_scales_recalibrate():
+    """cmh_amax must not let a NaN hide (fmaxf drops NaN operands): it reports +inf, which calibrate_fp8 refuses.  And activation
+    scales are tied to the weights they were measured with: a changed block parameter re-calibrates on the next fp8 batch."""
+    import ctypes as C
+    import warnings
+    import cmh_native as Nn
+    x = torch.randn(4096, device=DEV)
+    x[1234] = float("nan")
+    out = torch.zeros(1, device=DEV)
+    Nn.check(Nn.lib().cmh_amax(Nn.ptr(x), 0, x.numel(), Nn.ptr(out), Nn.stream_ptr(x.device)), "cmh_amax")
+    assert float(out) == float("inf")
+    w = torch.randn(8, 256, device=DEV)
+    w[3, 77] = float("nan")
+    _, cs = Nn.fp8_quantize_weight(w)
+    assert bool(torch.isnan(cs[3])) and bool(torch.isfinite(cs[[0, 1, 2, 4, 5, 6, 7]]).all())
+    import recipe
+    from test_gpu_clip import _clip
+    cfg = dict(recipe.CLIP_TINY, vision_width=256, transformer_width=256, transformer_heads=4)
+    clip = _clip(cfg, 5, "fp8")
+    img = torch.from_numpy(recipe.images(4, cfg["image_resolution"], 5)).to(DEV)
+    with torch.no_grad():
+        clip.encode_image(img)
+        first = clip._fp8_amax["vit"]
+        assert first is not None
+        clip.visual.transformer.resblocks[0].mlp.c_fc.weight.mul_(3.0)          # a "training step"
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            clip.encode_image(img)
+        assert any("re-calibrating" in str(r.message) for r in rec)
+        assert clip._fp8_amax["vit"] != first
