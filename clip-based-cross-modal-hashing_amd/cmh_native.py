@@ -88,7 +88,7 @@ SIGNATURES = {
     "cmh_text_workspace_bytes": (_sz, [C.POINTER(TextWeights), _i32, _i32]),
     "cmh_vit_encode": (C.c_int, [C.POINTER(VitWeights), _p, _i32, _p, _p, _sz, C.POINTER(Taps), _p]),
     "cmh_text_encode": (C.c_int, [C.POINTER(TextWeights), _p, _i32, _i32, _p, _p, _p, _sz, C.POINTER(Taps), _p]),
-    "cmh_text_encode_packed": (C.c_int, [C.POINTER(TextWeights), _p, _i32, _i32, _p, C.POINTER(C.c_int32), _p, _sz, _p]),
+    "cmh_text_encode_packed": (C.c_int, [C.POINTER(TextWeights), _p, _i32, _i32, _p, _p, _p, _sz, _p]),
     "cmh_vit_calibrate_fp8": (C.c_int, [C.POINTER(VitWeights), _p, _i32, _p, _p, _p, _sz, _p]),
     "cmh_text_calibrate_fp8": (C.c_int, [C.POINTER(TextWeights), _p, _i32, _i32, _p, _p, _p, _sz, _p]),
     "cmh_linear_gemm": (C.c_int, [_i32, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),

@@ -118,12 +118,14 @@ enum : int {
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
 
 // C[M,N] = epilogue(A[M,K] . W[N,K]^T).  A/W dtype = dt (f32 or bf16); residual f32; out f32|bf16.
+// m_dev (optional, device int32): the real row count when M is only an upper bound (packed text rows); m_hint: a likely value of
+// it for the tile-height choice (never for correctness)
 int launch_gemm(int dt, const void* A, const void* W, const float* bias, const float* residual,
-                void* out, int M, int N, int K, int epi, hipStream_t st);
+                void* out, int M, int N, int K, int epi, hipStream_t st, const int32_t* m_dev = nullptr, int m_hint = -1);
 // C = epilogue(alpha * colscale[n] * (A8 . W8^T)): OCP e4m3 operands [M,K] / [N,K] (K % 128 == 0, N % 256 == 0), f32 accumulate;
 // out f32 | bf16 | fp16 | (EPI_OUT_FP8) e4m3 of v * oscale.  EPI_SCALE is implied.
 int launch_gemm_fp8(const void* A8, const void* W8, const float* colscale, float alpha, const float* bias, const float* residual,
-                    void* out, float oscale, int M, int N, int K, int epi, hipStream_t st);
+                    void* out, float oscale, int M, int N, int K, int epi, hipStream_t st, const int32_t* m_dev = nullptr, int m_hint = -1);
 
 // gemm_wide.hip, TN form (wgrad): out[Mm, Nn] f32 = sum_k Xk[k, m] * Wk[k, n], bf16 operands [Kd, Mm] / [Kd, Nn] row-major
 bool gemm_wide_tn_supported(int Mm, int Nn, int Kd);
@@ -136,8 +138,9 @@ int launch_gemm_wide_tn(const void* Xk, const void* Wk, float* out, float* parti
 int launch_layernorm(const float* x, const int32_t* row_index, const float* w, const float* b,
                      void* out, int out_bf16, int M, int d, hipStream_t st);
 // same, x either f32 or (x_f16) the fp16 residual stream of the bf16 mode
+// m_dev (optional, device int32): the real row count when M is only an upper bound (packed text rows: no host round trip)
 int launch_layernorm_x(const void* x, int x_f16, const int32_t* row_index, const float* w, const float* b,
-                       void* out, int out_bf16, int M, int d, hipStream_t st);
+                       void* out, int out_bf16, int M, int d, hipStream_t st, const int32_t* m_dev = nullptr);
 
 // image [B,3,R,R] f32 -> patches [B*g*g, 3*p*p] (dt)
 int launch_patchify(const float* image, void* patches, int dt, int B, int R, int p, hipStream_t st);
@@ -200,7 +203,8 @@ int launch_attention_varlen(const void* qkv, void* o, int dt, int B, int T, int 
                             const uint8_t* key_padding_mask, const int32_t* seq_off, hipStream_t st,
                             float o8_inv_scale = 0.f);   // > 0 (bf16 qkv, T <= 128): o is e4m3 of o * o8_inv_scale (fp8 mode)
 // fp8.hip: LayerNorm of the fp16 residual stream straight to e4m3 (y * inv_scale); max |x| into a device scalar (running maximum)
-int launch_layernorm_q(const void* x_f16, const float* w, const float* b, void* out_fp8, float inv_scale, int M, int d, hipStream_t st);
+int launch_layernorm_q(const void* x_f16, const float* w, const float* b, void* out_fp8, float inv_scale, int M, int d, hipStream_t st,
+                       const int32_t* m_dev = nullptr);
 int launch_amax(const void* x, int kind, size_t n, float* out, hipStream_t st);
 
 // y[M,N] f32 = act((x[M,K] . w[N,K]^T + bias) * mask*keep_scale); x,w dtype dt; any N, K%4==0, K<=4096

@@ -16,6 +16,7 @@
 //   pool e   [B, d]    ln_post / ln_final of the pooled rows
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "cmh_common.h"
 
@@ -50,6 +51,7 @@ struct TowerBufs {
   void* mlp;
   int32_t* rows;
   void* pool;
+  int32_t* seq;     // [B + 2] packed text: row offsets of the captions, seq[B] = the packed row count (read by the kernels themselves)
   size_t total;
 };
 
@@ -63,6 +65,7 @@ static TowerBufs carve(void* ws, size_t M, size_t B, size_t d, size_t e, size_t 
   t.mlp = a.take(mlp_b > extra_mlp ? mlp_b : extra_mlp);
   t.rows = static_cast<int32_t*>(a.take(B * 4));
   t.pool = a.take(B * d * e);
+  t.seq = static_cast<int32_t*>(a.take((B + 2) * 4));
   t.total = a.off;
   return t;
 }
@@ -80,29 +83,30 @@ static int tap(const cmh_taps* taps, int idx, const float* x, size_t bytes, hipS
 // scales of cmh_block_weights.act_scale (LayerNorm -> launch_layernorm_q, attention -> its fp8 store, QuickGELU -> the c_fc
 // epilogue); the GEMM epilogues undo act_scale * colscale[n].  Residual stream fp16, qkv bf16 (attention is the bf16 kernel).
 static int run_block_fp8(const cmh_block_weights& w, const TowerBufs& t, int B, int T, int d, int causal, const uint8_t* kpm,
-                         hipStream_t st, int M, const int32_t* seq_off) {
+                         hipStream_t st, int M, const int32_t* seq_off, const int32_t* md = nullptr, int mh = -1) {
   const float* a = w.act_scale;
   CMH_CHECK_ARG(t.xh, "fp8 mode runs on the fp16 residual stream (width %% 256 == 0, no taps)");
   CMH_CHECK_ARG(w.in_proj_cs && w.out_proj_cs && w.fc_cs && w.proj_cs, "fp8 mode: weight scales missing");
   CMH_CHECK_ARG(a[0] > 0.f && a[1] > 0.f && a[2] > 0.f && a[3] > 0.f, "fp8 mode: activation scales missing (run the calibration pass)");
   const int rx = EPI_BIAS | EPI_RESIDUAL | EPI_RES_F16 | EPI_OUT_F16;
   int rc;
-  if ((rc = launch_layernorm_q(t.x, w.ln1_w, w.ln1_b, t.h, 1.0f / a[0], M, d, st))) return rc;
-  if ((rc = launch_gemm_fp8(t.h, w.in_proj_w, w.in_proj_cs, a[0], w.in_proj_b, nullptr, t.qkv, 1.f, M, 3 * d, d, EPI_BIAS | EPI_OUT_BF16, st))) return rc;
+  if ((rc = launch_layernorm_q(t.x, w.ln1_w, w.ln1_b, t.h, 1.0f / a[0], M, d, st, md))) return rc;
+  if ((rc = launch_gemm_fp8(t.h, w.in_proj_w, w.in_proj_cs, a[0], w.in_proj_b, nullptr, t.qkv, 1.f, M, 3 * d, d, EPI_BIAS | EPI_OUT_BF16, st, md, mh))) return rc;
   if ((rc = launch_attention_varlen(t.qkv, t.h, CMH_BF16, B, T, d, causal, kpm, seq_off, st, 1.0f / a[1]))) return rc;
-  if ((rc = launch_gemm_fp8(t.h, w.out_proj_w, w.out_proj_cs, a[1], w.out_proj_b, t.x, t.x, 1.f, M, d, d, rx, st))) return rc;
-  if ((rc = launch_layernorm_q(t.x, w.ln2_w, w.ln2_b, t.h, 1.0f / a[2], M, d, st))) return rc;
+  if ((rc = launch_gemm_fp8(t.h, w.out_proj_w, w.out_proj_cs, a[1], w.out_proj_b, t.x, t.x, 1.f, M, d, d, rx, st, md, mh))) return rc;
+  if ((rc = launch_layernorm_q(t.x, w.ln2_w, w.ln2_b, t.h, 1.0f / a[2], M, d, st, md))) return rc;
   if ((rc = launch_gemm_fp8(t.h, w.fc_w, w.fc_cs, a[2], w.fc_b, nullptr, t.mlp, 1.0f / a[3], M, 4 * d, d,
-                            EPI_BIAS | EPI_QUICKGELU | EPI_OUT_FP8, st))) return rc;
-  if ((rc = launch_gemm_fp8(t.mlp, w.proj_w, w.proj_cs, a[3], w.proj_b, t.x, t.x, 1.f, M, d, 4 * d, rx, st))) return rc;
+                            EPI_BIAS | EPI_QUICKGELU | EPI_OUT_FP8, st, md, mh))) return rc;
+  if ((rc = launch_gemm_fp8(t.mlp, w.proj_w, w.proj_cs, a[3], w.proj_b, t.x, t.x, 1.f, M, d, 4 * d, rx, st, md, mh))) return rc;
   return CMH_OK;
 }
 
 static int run_block(const cmh_block_weights& w, int dt, const TowerBufs& t, int B, int T, int d, int causal,
                      const uint8_t* kpm, hipStream_t st, int rows = -1, const int32_t* seq_off = nullptr,
-                     float* amax = nullptr) {   // amax [4] (bf16 mode): running maxima of the four GEMM inputs (fp8 calibration)
+                     float* amax = nullptr,     // amax [4] (bf16 mode): running maxima of the four GEMM inputs (fp8 calibration)
+                     const int32_t* md = nullptr, int mh = -1) {   // md: the packed row count on the device (rows = upper bound)
   const int M = rows >= 0 ? rows : B * T;      // packed variable-length text: `rows` real rows, T = the longest sequence
-  if (dt == CMH_FP8) return run_block_fp8(w, t, B, T, d, causal, kpm, st, M, seq_off);
+  if (dt == CMH_FP8) return run_block_fp8(w, t, B, T, d, causal, kpm, st, M, seq_off, md, mh);
   const int obf = dt == CMH_BF16 ? EPI_OUT_BF16 : 0;
   const int rx = EPI_BIAS | EPI_RESIDUAL | (t.xh ? EPI_RES_F16 | EPI_OUT_F16 : 0);
   int rc;
@@ -121,13 +125,13 @@ static int run_block(const cmh_block_weights& w, int dt, const TowerBufs& t, int
     if ((rc = launch_amax(t.mlp, kBF16, n * 4, amax + 3, st))) return rc;
     return launch_gemm(dt, t.mlp, w.proj_w, w.proj_b, t.x, t.x, M, d, 4 * d, rx, st);
   }
-  if ((rc = launch_layernorm_x(t.x, t.xh, nullptr, w.ln1_w, w.ln1_b, t.h, dt == CMH_BF16, M, d, st))) return rc;
-  if ((rc = launch_gemm(dt, t.h, w.in_proj_w, w.in_proj_b, nullptr, t.qkv, M, 3 * d, d, EPI_BIAS | obf, st))) return rc;
+  if ((rc = launch_layernorm_x(t.x, t.xh, nullptr, w.ln1_w, w.ln1_b, t.h, dt == CMH_BF16, M, d, st, md))) return rc;
+  if ((rc = launch_gemm(dt, t.h, w.in_proj_w, w.in_proj_b, nullptr, t.qkv, M, 3 * d, d, EPI_BIAS | obf, st, md, mh))) return rc;
   if ((rc = launch_attention_varlen(t.qkv, t.h, dt, B, T, d, causal, kpm, seq_off, st))) return rc;
-  if ((rc = launch_gemm(dt, t.h, w.out_proj_w, w.out_proj_b, t.x, t.x, M, d, d, rx, st))) return rc;
-  if ((rc = launch_layernorm_x(t.x, t.xh, nullptr, w.ln2_w, w.ln2_b, t.h, dt == CMH_BF16, M, d, st))) return rc;
-  if ((rc = launch_gemm(dt, t.h, w.fc_w, w.fc_b, nullptr, t.mlp, M, 4 * d, d, EPI_BIAS | EPI_QUICKGELU | obf, st))) return rc;
-  if ((rc = launch_gemm(dt, t.mlp, w.proj_w, w.proj_b, t.x, t.x, M, d, 4 * d, rx, st))) return rc;
+  if ((rc = launch_gemm(dt, t.h, w.out_proj_w, w.out_proj_b, t.x, t.x, M, d, d, rx, st, md, mh))) return rc;
+  if ((rc = launch_layernorm_x(t.x, t.xh, nullptr, w.ln2_w, w.ln2_b, t.h, dt == CMH_BF16, M, d, st, md))) return rc;
+  if ((rc = launch_gemm(dt, t.h, w.fc_w, w.fc_b, nullptr, t.mlp, M, 4 * d, d, EPI_BIAS | EPI_QUICKGELU | obf, st, md, mh))) return rc;
+  if ((rc = launch_gemm(dt, t.mlp, w.proj_w, w.proj_b, t.x, t.x, M, d, 4 * d, rx, st, md, mh))) return rc;
   return CMH_OK;
 }
 
@@ -143,7 +147,8 @@ bool pooled_tail_enabled() {
 }
 
 static int run_block_pooled(const cmh_block_weights& w, int dtb, const TowerBufs& t, int B, int T, int d, int causal,
-                            const uint8_t* kpm, hipStream_t st, int M, const int32_t* seq_off, void** x_pooled) {
+                            const uint8_t* kpm, hipStream_t st, int M, const int32_t* seq_off, void** x_pooled,
+                            const int32_t* md = nullptr, int mh = -1) {
   const int dt = dtb == CMH_FP8 ? CMH_BF16 : dtb;
   const size_t e = dt == CMH_BF16 ? 2 : 4, xe = t.xh ? 2 : 4;
   const int obf = dt == CMH_BF16 ? EPI_OUT_BF16 : 0;
@@ -156,8 +161,8 @@ static int run_block_pooled(const cmh_block_weights& w, int dtb, const TowerBufs
   if (dtb == CMH_FP8) {
     CMH_CHECK_ARG(t.xh && w.in_proj_cs && w.out_proj_cs && w.fc_cs && w.proj_cs && a[0] > 0.f && a[1] > 0.f && a[2] > 0.f && a[3] > 0.f,
                   "fp8 mode: scales missing (run the calibration pass)");
-    if ((rc = launch_layernorm_q(t.x, w.ln1_w, w.ln1_b, t.h, 1.0f / a[0], M, d, st))) return rc;
-    if ((rc = launch_gemm_fp8(t.h, w.in_proj_w, w.in_proj_cs, a[0], w.in_proj_b, nullptr, t.qkv, 1.f, M, 3 * d, d, EPI_BIAS | EPI_OUT_BF16, st))) return rc;
+    if ((rc = launch_layernorm_q(t.x, w.ln1_w, w.ln1_b, t.h, 1.0f / a[0], M, d, st, md))) return rc;
+    if ((rc = launch_gemm_fp8(t.h, w.in_proj_w, w.in_proj_cs, a[0], w.in_proj_b, nullptr, t.qkv, 1.f, M, 3 * d, d, EPI_BIAS | EPI_OUT_BF16, st, md, mh))) return rc;
     if ((rc = launch_attention_varlen(t.qkv, t.h, CMH_BF16, B, T, d, causal, kpm, seq_off, st, 1.0f / a[1]))) return rc;
     if ((rc = launch_gather_rows2(t.x, xp, static_cast<int>(d * xe), t.h, hp, d, t.rows, B, st))) return rc;
     if ((rc = launch_gemm_fp8(hp, w.out_proj_w, w.out_proj_cs, a[1], w.out_proj_b, xp, xp, 1.f, B, d, d, rx, st))) return rc;
@@ -166,8 +171,8 @@ static int run_block_pooled(const cmh_block_weights& w, int dtb, const TowerBufs
                               EPI_BIAS | EPI_QUICKGELU | EPI_OUT_FP8, st))) return rc;
     if ((rc = launch_gemm_fp8(t.mlp, w.proj_w, w.proj_cs, a[3], w.proj_b, xp, xp, 1.f, B, d, 4 * d, rx, st))) return rc;
   } else {
-    if ((rc = launch_layernorm_x(t.x, t.xh, nullptr, w.ln1_w, w.ln1_b, t.h, dt == CMH_BF16, M, d, st))) return rc;
-    if ((rc = launch_gemm(dt, t.h, w.in_proj_w, w.in_proj_b, nullptr, t.qkv, M, 3 * d, d, EPI_BIAS | obf, st))) return rc;
+    if ((rc = launch_layernorm_x(t.x, t.xh, nullptr, w.ln1_w, w.ln1_b, t.h, dt == CMH_BF16, M, d, st, md))) return rc;
+    if ((rc = launch_gemm(dt, t.h, w.in_proj_w, w.in_proj_b, nullptr, t.qkv, M, 3 * d, d, EPI_BIAS | obf, st, md, mh))) return rc;
     if ((rc = launch_attention_varlen(t.qkv, t.h, dt, B, T, d, causal, kpm, seq_off, st))) return rc;
     if ((rc = launch_gather_rows2(t.x, xp, static_cast<int>(d * xe), t.h, hp, static_cast<int>(d * e), t.rows, B, st))) return rc;
     if ((rc = launch_gemm(dt, hp, w.out_proj_w, w.out_proj_b, xp, xp, B, d, d, rx, st))) return rc;
@@ -177,6 +182,34 @@ static int run_block_pooled(const cmh_block_weights& w, int dtb, const TowerBufs
   }
   *x_pooled = xp;
   return CMH_OK;
+}
+
+// The packed row count of the LAST finished call for a (batch, seq_len), as a hint for the next call's tile heights: every call
+// queues an asynchronous copy of its count into a pinned host word and records an event; the next call takes the value if that
+// event has completed (hipEventQuery never blocks) and keeps its previous hint otherwise.  Results never depend on the hint.
+namespace {
+struct RowsHint { int B = 0, L = 0, hint = -1; int32_t* pinned = nullptr; hipEvent_t ev = nullptr; bool pending = false; };
+std::mutex g_hint_mu;
+RowsHint g_hint;
+}  // namespace
+static int rows_hint_exchange(const int32_t* count_dev, int B, int L, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_hint_mu);
+  RowsHint& h = g_hint;
+  if (!h.pinned) {
+    if (hipHostMalloc(reinterpret_cast<void**>(&h.pinned), 64, hipHostMallocDefault) != hipSuccess) { h.pinned = nullptr; return -1; }
+    if (hipEventCreateWithFlags(&h.ev, hipEventDisableTiming) != hipSuccess) { h.ev = nullptr; return -1; }
+  }
+  if (!h.ev) return -1;
+  if (h.pending && hipEventQuery(h.ev) == hipSuccess) {
+    h.pending = false;
+    if (h.B == B && h.L == L && *h.pinned > 0 && *h.pinned <= B * L) h.hint = *h.pinned;
+  }
+  const int out = (h.B == B && h.L == L) ? h.hint : -1;
+  if (!h.pending) {          // one copy in flight at a time: the pinned word is not rewritten under a reader
+    if (h.B != B || h.L != L) { h.B = B; h.L = L; h.hint = -1; }
+    if (hipMemcpyAsync(h.pinned, count_dev, 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipEventRecord(h.ev, st) == hipSuccess) h.pending = true;
+  }
+  return out;
 }
 
 static int final_projection(int dt, const void* pool, const void* w_t, float* feat, int B, int embed, int d,
@@ -323,26 +356,30 @@ static int text_encode_impl(const cmh_text_weights* w, const int64_t* tokens, in
   // the dense path (row-wise kernels, per-row dot products, attention over the same key tiles), so the features are
   // bit-identical.  The row count is read back once (the GEMM grids need it on the host).
   const int32_t* seq_off = nullptr;
-  int rows = M;
+  const int32_t* md = nullptr;      // device-side row count of the packed matrix (the kernels read it themselves)
+  int rows = M, mh = -1;
   if (packed_rows_out) {
     CMH_CHECK_ARG(!key_padding_mask && !tokens_out && !taps, "text_encode_packed: pooled features only, no mask / taps");
-    int32_t* so = static_cast<int32_t*>(t.pool) ;   // pool [B,d] e is free until the final LayerNorm: B+1 ints fit (d >= 128)
-    if ((rc = launch_text_pack_plan(tokens, B, L, so, st))) return rc;
-    int32_t total = 0;
-    if (hipMemcpyAsync(&total, so + B, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-      return fail(CMH_ERR_LAUNCH, "text_encode_packed: reading the packed row count failed");
-    // the offsets must outlive the pool buffer's reuse: keep them at the tail of the mlp scratch (M*4d*e bytes, rows*4d*e used)
-    int32_t* keep = reinterpret_cast<int32_t*>(static_cast<char*>(t.mlp) + static_cast<size_t>(M) * 4 * d * e - align_up(static_cast<size_t>(B + 1) * 4, 256));
-    CMH_CHECK_ARG(total > 0 && total <= M, "text_encode_packed: bad packed row count %d", total);
-    if (static_cast<size_t>(total) * 4 * d * e + align_up(static_cast<size_t>(B + 1) * 4, 256) > static_cast<size_t>(M) * 4 * d * e) {
-      seq_off = nullptr;                    // (almost) nothing to skip: run dense
-    } else {
-      if (hipMemcpyAsync(keep, so, static_cast<size_t>(B + 1) * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
-        return fail(CMH_ERR_LAUNCH, "text_encode_packed: copy failed");
-      seq_off = keep;
+    if ((rc = launch_text_pack_plan(tokens, B, L, t.seq, st))) return rc;
+    seq_off = t.seq;
+    if (amax || d % 256 != 0) {
+      // the calibration pass reduces over whole buffers on the host's row count, and widths that are not a multiple of 256 (the
+      // test-sized towers) run on the 128 x 128 fallback GEMMs, which take their row count from the host: these two alone read
+      // the count back (one synchronisation)
+      int32_t total = 0;
+      if (hipMemcpyAsync(&total, t.seq + B, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return fail(CMH_ERR_LAUNCH, "text_encode_packed: reading the packed row count failed");
+      CMH_CHECK_ARG(total > 0 && total <= M, "text_encode_packed: bad packed row count %d", total);
       rows = total;
+    } else {
+      // LayerNorm and the GEMMs take M = B*L as an upper bound and read the real count from seq[B]; the tile height is chosen for
+      // the count of an earlier call (rows_hint: captions of one dataset are alike), never waited for
+      md = t.seq + B;
+      mh = rows_hint_exchange(t.seq + B, B, L, st);
     }
-    *packed_rows_out = rows;
+    if (packed_rows_out != reinterpret_cast<int32_t*>(1) &&
+        hipMemcpyAsync(packed_rows_out, t.seq + B, 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return fail(CMH_ERR_LAUNCH, "text_encode_packed: copying the row count failed");
   }
 
   // token_embedding gather + positional_embedding[:L]; EOT row = argmax(tokens)  (model.py:360-362,370)
@@ -352,10 +389,10 @@ static int text_encode_impl(const cmh_text_weights* w, const int64_t* tokens, in
   void* x_pooled = nullptr;
   for (int i = 0; i < w->layers; ++i) {
     if (tail && i == w->layers - 1) {
-      if ((rc = run_block_pooled(w->blocks[i], dtb, t, B, L, d, /*causal=*/1, key_padding_mask, st, rows, seq_off, &x_pooled))) return rc;
+      if ((rc = run_block_pooled(w->blocks[i], dtb, t, B, L, d, /*causal=*/1, key_padding_mask, st, rows, seq_off, &x_pooled, md, mh))) return rc;
       break;
     }
-    if ((rc = run_block(w->blocks[i], dtb, t, B, L, d, /*causal=*/1, key_padding_mask, st, rows, seq_off, amax ? amax + 4 * i : nullptr))) return rc;
+    if ((rc = run_block(w->blocks[i], dtb, t, B, L, d, /*causal=*/1, key_padding_mask, st, rows, seq_off, amax ? amax + 4 * i : nullptr, md, mh))) return rc;
     if ((rc = tap(taps, 1 + i, t.x, static_cast<size_t>(M) * d * 4, st))) return rc;
   }
   if (tokens_out) {
@@ -384,10 +421,10 @@ extern "C" int cmh_text_encode(const cmh_text_weights* w, const int64_t* tokens,
 }
 
 extern "C" int cmh_text_encode_packed(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len, float* feat,
-                                      int32_t* rows_computed, void* workspace, size_t workspace_bytes, void* stream) {
-  CMH_CHECK_ARG(feat && rows_computed, "text_encode_packed: null pointer");
+                                      int32_t* rows_computed_dev, void* workspace, size_t workspace_bytes, void* stream) {
+  CMH_CHECK_ARG(feat, "text_encode_packed: null pointer");
   return text_encode_impl(w, tokens, batch, seq_len, nullptr, feat, nullptr, nullptr, workspace, workspace_bytes, nullptr, stream,
-                          rows_computed);
+                          rows_computed_dev ? rows_computed_dev : reinterpret_cast<int32_t*>(1));   // 1: packed, count not wanted
 }
 
 extern "C" int cmh_vit_calibrate_fp8(const cmh_vit_weights* w, const float* image, int32_t batch, float* feat, float* amax,
@@ -399,9 +436,9 @@ extern "C" int cmh_vit_calibrate_fp8(const cmh_vit_weights* w, const float* imag
 extern "C" int cmh_text_calibrate_fp8(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len, float* feat,
                                       float* amax, void* workspace, size_t workspace_bytes, void* stream) {
   CMH_CHECK_ARG(feat && amax, "text_calibrate_fp8: null pointer");
-  int32_t rows = 0;   // the packed path: calibrate on the rows the fp8 mode will compute
-  return text_encode_impl(w, tokens, batch, seq_len, nullptr, feat, nullptr, nullptr, workspace, workspace_bytes, nullptr, stream, &rows,
-                          amax);
+  // the packed path: calibrate on the rows the fp8 mode will compute
+  return text_encode_impl(w, tokens, batch, seq_len, nullptr, feat, nullptr, nullptr, workspace, workspace_bytes, nullptr, stream,
+                          reinterpret_cast<int32_t*>(1), amax);
 }
 
 extern "C" int cmh_text_encode_tokens(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,

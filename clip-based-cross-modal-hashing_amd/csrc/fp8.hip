@@ -100,8 +100,9 @@ int launch_amax(const void* x, int kind, size_t n, float* out, hipStream_t st) {
 template <int NB>
 __global__ __launch_bounds__(256) void layernorm_h2q_kernel(const uint16_t* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ b, uint8_t* __restrict__ out, int M,
-                                                            float inv_scale) {
+                                                            float inv_scale, const int32_t* __restrict__ m_dev) {
   constexpr int d = NB * 256;
+  if (m_dev) { const int md = *m_dev; M = md < M ? md : M; }
   const int hl = threadIdx.x & 31;
   const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
   if (row >= M) return;
@@ -146,16 +147,17 @@ __global__ __launch_bounds__(256) void layernorm_h2q_kernel(const uint16_t* __re
   }
 }
 
-int launch_layernorm_q(const void* x_f16, const float* w, const float* b, void* out_fp8, float inv_scale, int M, int d, hipStream_t st) {
+int launch_layernorm_q(const void* x_f16, const float* w, const float* b, void* out_fp8, float inv_scale, int M, int d, hipStream_t st,
+                       const int32_t* m_dev) {
   CMH_CHECK_ARG(d % 256 == 0 && d <= 1024, "layernorm (fp8): d=%d must be a multiple of 256, <= 1024", d);
   const uint16_t* xh = static_cast<const uint16_t*>(x_f16);
   uint8_t* o = static_cast<uint8_t*>(out_fp8);
   const dim3 grid((M + 7) / 8), block(256);
   switch (d / 256) {
-    case 1: hipLaunchKernelGGL(layernorm_h2q_kernel<1>, grid, block, 0, st, xh, w, b, o, M, inv_scale); break;
-    case 2: hipLaunchKernelGGL(layernorm_h2q_kernel<2>, grid, block, 0, st, xh, w, b, o, M, inv_scale); break;
-    case 3: hipLaunchKernelGGL(layernorm_h2q_kernel<3>, grid, block, 0, st, xh, w, b, o, M, inv_scale); break;
-    default: hipLaunchKernelGGL(layernorm_h2q_kernel<4>, grid, block, 0, st, xh, w, b, o, M, inv_scale); break;
+    case 1: hipLaunchKernelGGL(layernorm_h2q_kernel<1>, grid, block, 0, st, xh, w, b, o, M, inv_scale, m_dev); break;
+    case 2: hipLaunchKernelGGL(layernorm_h2q_kernel<2>, grid, block, 0, st, xh, w, b, o, M, inv_scale, m_dev); break;
+    case 3: hipLaunchKernelGGL(layernorm_h2q_kernel<3>, grid, block, 0, st, xh, w, b, o, M, inv_scale, m_dev); break;
+    default: hipLaunchKernelGGL(layernorm_h2q_kernel<4>, grid, block, 0, st, xh, w, b, o, M, inv_scale, m_dev); break;
   }
   CMH_CHECK_LAUNCH("layernorm_fp8");
   return CMH_OK;

@@ -218,7 +218,16 @@ int launch_gemm_rows(int dt, const void* A, const void* W, const float* bias, co
                      int epi, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out,
                      int M, int N, int K, int epi, hipStream_t st, const float* colscale = nullptr, float alpha = 1.f,
-                     float oscale = 1.f);
+                     float oscale = 1.f, const int32_t* m_dev = nullptr, int m_hint = -1);
+
+// the measurement hook counts algorithmic FLOPs on REAL rows: with a device-side row count it reads that count back (a stream
+// synchronisation, inside a profiled run only)
+static int prof_real_rows(int M, const int32_t* m_dev, hipStream_t st) {
+  if (!m_dev) return M;
+  int32_t v = M;
+  if (hipMemcpyAsync(&v, m_dev, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return M;
+  return v > 0 && v < M ? v : M;
+}
 
 // CMH_GEMM_IMPL=regstage selects the v1 register-staged kernel (A/B testing); default = LDS-DMA kernel.
 static int gemm_impl_from_env() {
@@ -227,7 +236,7 @@ static int gemm_impl_from_env() {
 }
 
 int launch_gemm(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out,
-                int M, int N, int K, int epi, hipStream_t st) {
+                int M, int N, int K, int epi, hipStream_t st, const int32_t* m_dev, int m_hint) {
   const int bk = dt == CMH_F32 ? 32 : 64;
   CMH_CHECK_ARG(dt == CMH_F32 || dt == CMH_BF16, "gemm: bad dtype %d", dt);
   CMH_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
@@ -244,7 +253,7 @@ int launch_gemm(int dt, const void* A, const void* W, const float* bias, const f
   // the wide kernel's launch stamps the event pair with its own begin / end (gemm_wide_time_next); the fallback kernels are
   // bracketed by two recorded events; CMH_GEMM_PROF_BRACKET=1 brackets every launch (round 1-2's method, for comparison)
   static const bool bracket = []() { const char* e = getenv("CMH_GEMM_PROF_BRACKET"); return e && e[0] == '1'; }();
-  const bool takes_rows = gemm_rows_takes(M, N, K, epi);
+  const bool takes_rows = !m_dev && gemm_rows_takes(M, N, K, epi);
   const bool takes_wide = !takes_rows && ((impl == 1 && wide && gemm_wide_supported(N)) || (epi & (EPI_RES_F16 | EPI_OUT_F16 | EPI_MUL_DQGELU | EPI_SAVE_PRE)));
   const bool self_timed = timed && (takes_wide || takes_rows) && !bracket;
   hipEvent_t ev0 = self_timed ? g_prof.ev[g_prof.used] : nullptr, ev1 = self_timed ? g_prof.ev[g_prof.used + 1] : nullptr;
@@ -259,9 +268,11 @@ int launch_gemm(int dt, const void* A, const void* W, const float* bias, const f
     if (rc) return rc;
   } else if (takes_wide) {
     if (self_timed) gemm_wide_time_next(ev0, ev1);
-    const int rc = launch_gemm_wide(dt, A, W, bias, residual, out, M, N, K, epi, st);
+    const int rc = launch_gemm_wide(dt, A, W, bias, residual, out, M, N, K, epi, st, nullptr, 1.f, 1.f, m_dev, m_hint);
     gemm_wide_time_next(nullptr, nullptr);
     if (rc) return rc;
+  } else if (m_dev) {
+    return fail(CMH_ERR_INVALID, "gemm: a device-side row count needs the wide kernel (N %% 256 == 0, N=%d)", N);
   } else if (impl == 1)
     launch_gemm_glds(dt, A, W, bias, residual, out, M, N, K, epi, st);
   else if (dt == CMH_F32)
@@ -272,8 +283,9 @@ int launch_gemm(int dt, const void* A, const void* W, const float* bias, const f
                        static_cast<const char*>(W), bias, residual, out, M, N, K, epi);
   if (timed) {
     if (!self_timed) (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
-    g_prof.flops.push_back(2.0 * M * static_cast<double>(N) * K);   // algorithmic FLOPs: real rows only
-    g_prof.dims.push_back({M, N, K, epi});
+    const int Mr = prof_real_rows(M, m_dev, st);
+    g_prof.flops.push_back(2.0 * Mr * static_cast<double>(N) * K);   // algorithmic FLOPs: real rows only
+    g_prof.dims.push_back({Mr, N, K, epi});
     g_prof.kind.push_back(takes_rows ? 1 : (takes_wide ? 0 : 2));
     g_prof.used += 2;
   }
@@ -282,7 +294,7 @@ int launch_gemm(int dt, const void* A, const void* W, const float* bias, const f
 }
 
 int launch_gemm_fp8(const void* A8, const void* W8, const float* colscale, float alpha, const float* bias, const float* residual,
-                    void* out, float oscale, int M, int N, int K, int epi, hipStream_t st) {
+                    void* out, float oscale, int M, int N, int K, int epi, hipStream_t st, const int32_t* m_dev, int m_hint) {
   CMH_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm_fp8: empty problem M=%d N=%d K=%d", M, N, K);
   CMH_CHECK_ARG(gemm_wide_supported(N) && K % 128 == 0, "gemm_fp8: N=%d must be a multiple of 256 and K=%d of 128", N, K);
   CMH_CHECK_ARG(A8 && W8 && out && colscale, "gemm_fp8: null pointer");
@@ -293,12 +305,13 @@ int launch_gemm_fp8(const void* A8, const void* W8, const float* colscale, float
   CMH_CHECK_ARG(okinds <= 1, "gemm_fp8: one output type at a time");
   const bool timed = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
   if (timed) gemm_wide_time_next(g_prof.ev[g_prof.used], g_prof.ev[g_prof.used + 1]);
-  const int rc = launch_gemm_wide(CMH_FP8, A8, W8, bias, residual, out, M, N, K, epi | EPI_SCALE, st, colscale, alpha, oscale);
+  const int rc = launch_gemm_wide(CMH_FP8, A8, W8, bias, residual, out, M, N, K, epi | EPI_SCALE, st, colscale, alpha, oscale, m_dev, m_hint);
   gemm_wide_time_next(nullptr, nullptr);
   if (rc) return rc;
   if (timed) {
-    g_prof.flops.push_back(2.0 * M * static_cast<double>(N) * K);
-    g_prof.dims.push_back({M, N, K, epi | EPI_SCALE});
+    const int Mr = prof_real_rows(M, m_dev, st);
+    g_prof.flops.push_back(2.0 * Mr * static_cast<double>(N) * K);
+    g_prof.dims.push_back({Mr, N, K, epi | EPI_SCALE});
     g_prof.kind.push_back(0);
     g_prof.used += 2;
   }

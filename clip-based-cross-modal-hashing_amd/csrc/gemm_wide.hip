@@ -94,6 +94,7 @@ struct WideScales {
   float oscale;            // EPI_OUT_FP8: out = e4m3(clamp(v * oscale))
   int kreal;               // TN: rows of the K-major operands that exist (K is padded to whole K-steps)
   float* colsum;           // TN, optional: [ksplit, M] partial column sums of the Xk operand (wgrad: the bias gradient's first stage)
+  const int* m_dev;        // optional: the real row count on the device (M is then an upper bound)
 };
 
 // TN operands (wgrad: dW[O,I] = dY^T X with dY [M,O] and X [M,I] as the backward pass has them, the reduction index m being the
@@ -109,8 +110,11 @@ template <int DT, int OK, int MF, bool TN = false>   // DT: 0 f32, 1 bf16, 2 fp8
                                     // outputs; MF = 16-row m-fragments per wave: tile rows = 32*MF (160, 128 or 96); TN: above
 __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__ X, const char* __restrict__ W,
                                                         const float* __restrict__ bias, const float* residual,
-                                                        void* out, int M, int N, int K, int epi, int ksplit, int ordG,
+                                                        void* out, int Mub, int N, int K, int epi, int ksplit, int ordG,
                                                         WideScales sc) {
+  // M: the row count; sc.m_dev (packed text rows) holds the real one on the device, Mub is then only an upper bound
+  int M = Mub;
+  if (sc.m_dev) { const int md = *sc.m_dev; M = md < Mub ? md : Mub; }
   constexpr bool F32 = DT == 0, FP8 = DT == 2, OUTBF = OK == 1, OUT8 = OK == 2;
   constexpr int BMt = 32 * MF;                       // tile rows
   constexpr int WR = 16 * MF;                        // rows per wave
@@ -1040,10 +1044,10 @@ int launch_gemm_wide_splitk(int dt, const void* A, const void* W, float* out, fl
   const int grid = total < cus ? ((total + 7) & ~7) : cus;
   if (dt == CMH_F32)
     hipLaunchKernelGGL((gemm_wide_kernel<0, 0, 5>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),
-                       static_cast<const char*>(W), nullptr, nullptr, partials, M, N, K, 0, S, wide_order_group(N), WideScales{nullptr, 1.f, 1.f, 0, nullptr});
+                       static_cast<const char*>(W), nullptr, nullptr, partials, M, N, K, 0, S, wide_order_group(N), WideScales{nullptr, 1.f, 1.f, 0, nullptr, nullptr});
   else
     hipLaunchKernelGGL((gemm_wide_kernel<1, 0, 5>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),
-                       static_cast<const char*>(W), nullptr, nullptr, partials, M, N, K, 0, S, wide_order_group(N), WideScales{nullptr, 1.f, 1.f, 0, nullptr});
+                       static_cast<const char*>(W), nullptr, nullptr, partials, M, N, K, 0, S, wide_order_group(N), WideScales{nullptr, 1.f, 1.f, 0, nullptr, nullptr});
   const size_t n = static_cast<size_t>(M) * N;
   const size_t blocks = (n / 4 + 255) / 256;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, partials, S, n, out);
@@ -1075,7 +1079,7 @@ int launch_gemm_wide_tn(const void* Xk, const void* Wk, float* out, float* parti
   const int Kpad = S * nk_per * 64;                      // the kernel's K: whole K-steps per split; rows >= Kd are zero-filled
   const int total = tiles * S;
   const int grid = total < cus ? ((total + 7) & ~7) : cus;
-  const WideScales sc{nullptr, 1.f, 1.f, Kd, colsum_partial};   // colsum_partial: [S, Mm] (>= 64 * Mm floats are always enough)
+  const WideScales sc{nullptr, 1.f, 1.f, Kd, colsum_partial, nullptr};   // colsum_partial: [S, Mm] (>= 64 * Mm floats are always enough)
   if (colsum_slices) *colsum_slices = S;
   hipLaunchKernelGGL((gemm_wide_kernel<1, 0, 4, true>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(Xk),
                      static_cast<const char*>(Wk), nullptr, nullptr, S > 1 ? static_cast<void*>(partials) : static_cast<void*>(out),
@@ -1090,8 +1094,9 @@ int launch_gemm_wide_tn(const void* Xk, const void* Wk, float* out, float* parti
 }
 
 int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out,
-                     int M, int N, int K, int epi, hipStream_t st, const float* colscale, float alpha, float oscale) {
-  const WideScales sc{colscale, alpha, oscale, 0, nullptr};
+                     int M, int N, int K, int epi, hipStream_t st, const float* colscale, float alpha, float oscale,
+                     const int32_t* m_dev, int m_hint) {
+  const WideScales sc{colscale, alpha, oscale, 0, nullptr, m_dev};
   const size_t esz = dt == CMH_F32 ? 4 : (dt == CMH_FP8 ? 1 : 2);
   if (static_cast<size_t>(M) * K * esz >= (1ull << 32) || static_cast<size_t>(wBN) * K * esz >= (1ull << 32))
     return fail(CMH_ERR_INVALID, "gemm: operand of %zu bytes exceeds the 32-bit offset range of the wide kernel",
@@ -1102,8 +1107,9 @@ int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, co
   // round of 220 tiles keeps 86 % of the CUs busy instead of 65 % (166 tiles of 128 rows).  CMH_GEMM_BM=96|128|160 forces one.
   const int cus = wide_cus();
   const int nk = K / (dt == CMH_F32 ? 32 : (dt == CMH_FP8 ? 128 : 64));
+  const int Mc = m_dev && m_hint > 0 && m_hint <= M ? m_hint : M;   // the tile height is chosen for the likely row count
   auto cost = [&](int mf) {   // rounds x (rows + the per-K-step cost that does not shrink with the tile: W fragment reads, barrier) x K-steps
-    const int tiles = (N / wBN) * ((M + 32 * mf - 1) / (32 * mf));
+    const int tiles = (N / wBN) * ((Mc + 32 * mf - 1) / (32 * mf));
     return static_cast<long long>((tiles + cus - 1) / cus) * (10 * mf + 6) * (nk + 4);
   };
   const int forced = g_force_rows;

@@ -70,9 +70,11 @@ __device__ __forceinline__ float4 load_x4(const void* row, int e0) {
 template <bool XH>
 __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ x, const int32_t* __restrict__ row_index,
                                                         const float* __restrict__ w, const float* __restrict__ b,
-                                                        void* __restrict__ out, int out_kind, int M, int d) {
+                                                        void* __restrict__ out, int out_kind, int M, int d,
+                                                        const int32_t* __restrict__ m_dev) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m_dev) { const int md = *m_dev; M = md < M ? md : M; }      // packed text: the real row count lives on the device
   if (row >= M) return;
   const size_t src = row_index ? static_cast<size_t>(row_index[row]) : static_cast<size_t>(row);
   const char* xr = static_cast<const char*>(x) + src * d * (XH ? 2 : 4);
@@ -93,8 +95,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
 template <int NB>   // d / 256
 __global__ __launch_bounds__(256) void layernorm_h2b_kernel(const uint16_t* __restrict__ x, const int32_t* __restrict__ row_index,
                                                             const float* __restrict__ w, const float* __restrict__ b,
-                                                            uint16_t* __restrict__ out, int M) {
+                                                            uint16_t* __restrict__ out, int M, const int32_t* __restrict__ m_dev) {
   constexpr int d = NB * 256;
+  if (m_dev) { const int md = *m_dev; M = md < M ? md : M; }      // packed text: the real row count lives on the device
   constexpr int RPH = NB <= 2 ? 2 : 1;     // rows per half-wave: narrow rows (512 elements = two loads per lane) have too few bytes in
                                            // flight one at a time (10 499 x 512: 7.7 us = 2.8 TB/s); both rows' loads are issued first
   const int hl = threadIdx.x & 31;
@@ -154,32 +157,32 @@ __global__ __launch_bounds__(256) void layernorm_h2b_kernel(const uint16_t* __re
 }
 
 int launch_layernorm_x(const void* x, int x_f16, const int32_t* row_index, const float* w, const float* b, void* out,
-                       int out_bf16, int M, int d, hipStream_t st) {
+                       int out_bf16, int M, int d, hipStream_t st, const int32_t* m_dev) {
   CMH_CHECK_ARG(d % 4 == 0 && d <= 256 * kMaxVec, "layernorm: d=%d must be a multiple of 4 and <= 1024", d);
   if (x_f16 && out_bf16 && d % 256 == 0) {
     const uint16_t* xh = static_cast<const uint16_t*>(x);
     uint16_t* oh = static_cast<uint16_t*>(out);
     const dim3 grid((M + 7) / 8), grid2((M + 15) / 16), block(256);     // two rows per half-wave for d <= 512
     switch (d / 256) {
-      case 1: hipLaunchKernelGGL(layernorm_h2b_kernel<1>, grid2, block, 0, st, xh, row_index, w, b, oh, M); break;
-      case 2: hipLaunchKernelGGL(layernorm_h2b_kernel<2>, grid2, block, 0, st, xh, row_index, w, b, oh, M); break;
-      case 3: hipLaunchKernelGGL(layernorm_h2b_kernel<3>, grid, block, 0, st, xh, row_index, w, b, oh, M); break;
-      default: hipLaunchKernelGGL(layernorm_h2b_kernel<4>, grid, block, 0, st, xh, row_index, w, b, oh, M); break;
+      case 1: hipLaunchKernelGGL(layernorm_h2b_kernel<1>, grid2, block, 0, st, xh, row_index, w, b, oh, M, m_dev); break;
+      case 2: hipLaunchKernelGGL(layernorm_h2b_kernel<2>, grid2, block, 0, st, xh, row_index, w, b, oh, M, m_dev); break;
+      case 3: hipLaunchKernelGGL(layernorm_h2b_kernel<3>, grid, block, 0, st, xh, row_index, w, b, oh, M, m_dev); break;
+      default: hipLaunchKernelGGL(layernorm_h2b_kernel<4>, grid, block, 0, st, xh, row_index, w, b, oh, M, m_dev); break;
     }
     CMH_CHECK_LAUNCH("layernorm");
     return CMH_OK;
   }
   if (x_f16)
-    hipLaunchKernelGGL(layernorm_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, x, row_index, w, b, out, out_bf16, M, d);
+    hipLaunchKernelGGL(layernorm_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, x, row_index, w, b, out, out_bf16, M, d, m_dev);
   else
-    hipLaunchKernelGGL(layernorm_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, x, row_index, w, b, out, out_bf16, M, d);
+    hipLaunchKernelGGL(layernorm_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, x, row_index, w, b, out, out_bf16, M, d, m_dev);
   CMH_CHECK_LAUNCH("layernorm");
   return CMH_OK;
 }
 
 int launch_layernorm(const float* x, const int32_t* row_index, const float* w, const float* b, void* out,
                      int out_bf16, int M, int d, hipStream_t st) {
-  return launch_layernorm_x(x, 0, row_index, w, b, out, out_bf16, M, d, st);
+  return launch_layernorm_x(x, 0, row_index, w, b, out, out_bf16, M, d, st, nullptr);
 }
 
 // any input kind (f32 / fp16) to any output kind (f32 / bf16 / fp16): the training forward's ln_pre writes the stream's type
@@ -188,9 +191,9 @@ int launch_layernorm_any(const void* x, int x_kind, const int32_t* row_index, co
   CMH_CHECK_ARG(d % 4 == 0 && d <= 256 * kMaxVec, "layernorm: d=%d must be a multiple of 4 and <= 1024", d);
   CMH_CHECK_ARG((x_kind == 0 || x_kind == 2) && out_kind >= 0 && out_kind <= 2, "layernorm: bad kinds %d -> %d", x_kind, out_kind);
   if (x_kind == 2)
-    hipLaunchKernelGGL(layernorm_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, x, row_index, w, b, out, out_kind, M, d);
+    hipLaunchKernelGGL(layernorm_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, x, row_index, w, b, out, out_kind, M, d, nullptr);
   else
-    hipLaunchKernelGGL(layernorm_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, x, row_index, w, b, out, out_kind, M, d);
+    hipLaunchKernelGGL(layernorm_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, x, row_index, w, b, out, out_kind, M, d, nullptr);
   CMH_CHECK_LAUNCH("layernorm");
   return CMH_OK;
 }

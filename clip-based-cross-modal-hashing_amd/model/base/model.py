@@ -291,7 +291,16 @@ class CLIP(nn.Module):
     # encode_text skips the padding after each caption's EOT (bit-identical pooled features, cmh_text_encode_packed);
     # CMH_TEXT_PACK=0 or `clip.pack_text = False` computes all context_length positions like the reference
     pack_text = os.environ.get("CMH_TEXT_PACK", "1") != "0"
-    last_text_rows = None
+    _last_text_rows = None
+
+    @property
+    def last_text_rows(self):
+        """(rows computed, batch * seq_len) of the last packed encode_text, or None; reading it fetches the count from the device
+        (the only synchronisation: the encode itself never waits for it)."""
+        if self._last_text_rows is None:
+            return None
+        rows, dense = self._last_text_rows
+        return int(rows.item()), dense
 
     @property
     def gemm_dtype(self) -> str:
@@ -422,10 +431,10 @@ class CLIP(nn.Module):
         ws = N.workspace(need, text.device, f"text@{N.stream_ptr(text.device)}")
         if kpm is None and taps is None and self.pack_text:
             # only the tokens up to each caption's EOT can reach the pooled row under the causal mask: skip the padding
-            rows = C.c_int32(0)
-            N.check(N.lib().cmh_text_encode_packed(C.byref(s), N.ptr(text), B, L, N.ptr(feat), C.byref(rows), N.ptr(ws), ws.numel(),
+            rows = torch.empty(1, dtype=torch.int32, device=text.device)       # the count stays on the device: nothing waits for it
+            N.check(N.lib().cmh_text_encode_packed(C.byref(s), N.ptr(text), B, L, N.ptr(feat), N.ptr(rows), N.ptr(ws), ws.numel(),
                                                    N.stream_ptr(text.device)), "cmh_text_encode_packed")
-            self.last_text_rows = (rows.value, B * L)
+            self._last_text_rows = (rows, B * L)
             return no_backward(feat, self.text_projection)
         tp, _arr = self._taps(taps)
         N.check(N.lib().cmh_text_encode(C.byref(s), N.ptr(text), B, L, N.ptr(kpm), N.ptr(feat), N.ptr(ws), ws.numel(),

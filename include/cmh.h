@@ -148,10 +148,14 @@ int cmh_text_calibrate_fp8(const cmh_text_weights* w, const int64_t* tokens, int
 
 /* encode_text without the padding: under the causal mask (model/base/model.py:340-346) no token after a caption's EOT can
  * influence the EOT row that encode_text returns (:366-370), so only the tokens 0..EOT of every caption are computed, packed
- * into one matrix of rows_computed <= batch*seq_len rows.  `feat` is bit-identical to cmh_text_encode's.  Synchronises the
- * stream once (the packed row count sizes the GEMM grids).  Same workspace as cmh_text_encode. */
+ * into one matrix of <= batch*seq_len rows.  `feat` is bit-identical to cmh_text_encode's.  Nothing is synchronised: the packed row
+ * count stays on the device - LayerNorm and the GEMM kernels read it themselves (their grids are sized for batch*seq_len rows) - and
+ * rows_computed_dev (DEVICE int32 [1], may be NULL) receives a copy for the caller to read whenever it likes.  The GEMMs' tile
+ * height is chosen for the count of an earlier call with the same (batch, seq_len), fetched without ever waiting; the first call
+ * assumes batch*seq_len.  (Widths that are not a multiple of 256 - test-sized towers on the 128 x 128 fallback GEMMs - read the count
+ * back once instead.)  Same workspace as cmh_text_encode. */
 int cmh_text_encode_packed(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len, float* feat,
-                           int32_t* rows_computed, void* workspace, size_t workspace_bytes, void* stream);
+                           int32_t* rows_computed_dev, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Building blocks of the towers, exported for unit-level parity tests and for heads that want them.

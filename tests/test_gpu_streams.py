@@ -47,3 +47,28 @@ def test_vitb32_overlap_and_fp16_stream_consistent(monkeypatch):
         torch.cuda.synchronize()
     assert torch.isfinite(ri).all() and torch.isfinite(rt).all()
     assert torch.equal(oi, ri) and torch.equal(ot, rt)
+
+
+def test_packed_encode_text_never_waits_for_the_device():
+    """cmh_text_encode_packed keeps the packed row count on the device (LayerNorm and the GEMM kernels read it themselves): the
+    call must return while earlier work of its stream is still running, and the count is fetched only when asked for."""
+    from model.base.model import CLIP
+    torch.manual_seed(6)
+    clip = CLIP(**recipe.CLIP_VITB32).to(DEV).float().set_gemm_dtype("bf16")
+    clip.assume_frozen = True
+    txt = torch.from_numpy(recipe.captions(64, 77, recipe.CLIP_VITB32["vocab_size"], 6)).to(DEV)
+    with torch.no_grad():
+        ref = clip.encode_text(txt)                       # builds the weight copies and the workspace
+        torch.cuda.synchronize()
+        a = torch.randn(8192, 8192, device=DEV)
+        for _ in range(12):                               # a few hundred milliseconds of queued work ahead of the encode
+            a = (a @ a).clamp_(-1, 1)
+        out = clip.encode_text(txt)
+        assert not torch.cuda.current_stream().query(), "encode_text waited for the stream (host synchronisation in the forward path)"
+        torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    rows, dense = clip.last_text_rows
+    assert dense == 64 * 77 and 64 * 3 <= rows < dense
+    clip.pack_text = False
+    with torch.no_grad():
+        assert torch.equal(clip.encode_text(txt), ref)    # dense == packed, bit for bit
