@@ -48,15 +48,18 @@ def test_vitb32_f32_matches_reference_goldens(golden):
     rows = g["v_rows"]
     taps = [torch.empty(2 * 50, 768, device=DEV) for _ in range(13)]
     img = m.encode_image(torch.from_numpy(recipe.images(2, 224, seed)).to(DEV), taps=taps)
-    np.testing.assert_allclose(taps[0].cpu().numpy().reshape(2, 50, 768)[:, rows], g["v_ln_pre_rows"], rtol=1e-4, atol=1e-4)
+    # north_star's tolerance (1e-4) at full size, with the measured error behind it: on MI355X the largest |difference| to the
+    # reference's own outputs is 1.0e-5 at any tap (values up to 4.9; 8.8e-6 after block 11, 3.8e-6 / 7.5e-6 on the image / text
+    # features), so |d| <= 2e-5 + 1e-4 |ref| holds with a margin of four (round 2 allowed 2e-4 + 1e-3 |ref| here)
+    tol = dict(rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(taps[0].cpu().numpy().reshape(2, 50, 768)[:, rows], g["v_ln_pre_rows"], **tol)
     for i in (0, 5, 11):
-        np.testing.assert_allclose(taps[1 + i].cpu().numpy().reshape(2, 50, 768)[:, rows], g[f"v_block{i}_rows"],
-                                   rtol=1e-3, atol=2e-4)
-    np.testing.assert_allclose(img.detach().cpu().numpy(), g["img_feat"], rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(taps[1 + i].cpu().numpy().reshape(2, 50, 768)[:, rows], g[f"v_block{i}_rows"], **tol)
+    np.testing.assert_allclose(img.detach().cpu().numpy(), g["img_feat"], **tol)
     txt = m.encode_text(torch.from_numpy(recipe.captions(2, 77, cfg["vocab_size"], seed)).to(DEV))
-    np.testing.assert_allclose(txt.detach().cpu().numpy(), g["txt_feat_L77"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(txt.detach().cpu().numpy(), g["txt_feat_L77"], **tol)
     txt = m.encode_text(torch.from_numpy(recipe.captions(2, 32, cfg["vocab_size"], seed + 1)).to(DEV))
-    np.testing.assert_allclose(txt.detach().cpu().numpy(), g["txt_feat_L32"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(txt.detach().cpu().numpy(), g["txt_feat_L32"], **tol)
 
 
 def test_vitb32_bf16_close_to_f32_and_flip_rate(golden):

@@ -14,16 +14,19 @@ rp, qp, rl, ql = N.pack_codes(r), N.pack_codes(q), N.pack_labels(rL.to(dev)), N.
 for _ in range(2):
     N.hamming_map(qp, ql, rp, rl, K, C)
 torch.cuda.synchronize()
+ws = N.workspace(0, dev, "map")
+ws[:3072].zero_()              # the stamp area: levels the run never reaches must read as zero, not as whatever the buffer held
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); N.hamming_map(qp, ql, rp, rl, K, C); e1.record(); torch.cuda.synchronize()
-ws = N.workspace(0, dev, "map")
 full = ws[:3072].view(torch.int64).cpu().numpy()
 st = full[:6]
 d = [int(st[i + 1] - st[i]) for i in range(5)]
 print("one direction: %.3f ms; query 0 of workgroup 0, cycles per phase (100 MHz ticks?):" % e0.elapsed_time(e1))
 for name, v in zip(["keys", "bfs", "parked-seq", "leaf", "ap"], d):
     print(f"  {name:10s} {v:10d}")
-lv = [(int(full[8 + 2 * i]), int(full[9 + 2 * i])) for i in range(28) if full[8 + 2 * i] and full[9 + 2 * i] < 100000]
+# a level was reached iff its stamp lies inside the breadth-first phase of this query
+lv = [(int(full[8 + 2 * i]), int(full[9 + 2 * i])) for i in range(28)
+      if st[1] <= full[8 + 2 * i] <= st[2] and 0 < full[9 + 2 * i] < 100000]
 for i, (t, n) in enumerate(lv):
     nxt = lv[i + 1][0] if i + 1 < len(lv) else int(st[2])
     print(f"  level {i:2d}: {n:5d} segments {nxt - t:9d} cycles")

@@ -36,7 +36,7 @@ for name, (M, Nn, K, epi) in shapes.items():
         buf = np.zeros(256 * 8, dtype=np.uint64)
         assert lib.cmh_debug_wide_timeline(buf.ctypes.data_as(ctypes.c_void_p)) == 0
         t = buf.reshape(256, 8)[:, :6].astype(np.float64)
-        t = t[t[:, 0] > 0]
+        t = t[(t > 0).all(axis=1)]           # workgroups that ran (a workgroup without a tile returns before its first stamp)
         t = (t - t[:, 0].min()) / 100.0
         rows.append(t)
     t = rows[-1]
