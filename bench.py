@@ -457,8 +457,9 @@ def main():
         def four(tie=N.TIE_REFERENCE):
             res = []
             for qk, rk in (("q_img", "r_txt"), ("q_txt", "r_img"), ("q_img", "r_img"), ("q_txt", "r_txt")):
-                _, ap_l, _ = N.hamming_map(planes[qk], qLp, planes[rk], rLp, K, C, tie_order=tie)
-                res.append(du.mean_in_query_order(du.gather_query_sharded_ap(ap_l, Q)) if world > 1 else ap_l.mean())
+                mp, ap_l, _ = N.hamming_map(planes[qk], qLp, planes[rk], rLp, K, C, tie_order=tie)
+                # one rank: the kernel's own mean; several: the same sequential f32 sum over the gathered per-query APs (cmh_map_mean)
+                res.append(du.mean_in_query_order(du.gather_query_sharded_ap(ap_l, Q)) if world > 1 else mp)
             return res
 
         def timed(tie):
