@@ -3,7 +3,7 @@
 import re, sys
 s = open(sys.argv[1]).read()
 want = tuple(sys.argv[2:5])
-for f in re.split(r'\n(?=_ZN3cmh16gemm_wide_kernel\w+:\n)', s):
+for f in re.split(r'\n(?=_ZN3cmh16gemm_wide_kernel\w+:)', s):
     m = re.match(r'(_ZN3cmh16gemm_wide_kernelILi(\d)ELi(\d)ELi(\d)E\w+):', f)
     if not m:
         continue
