@@ -161,8 +161,8 @@ def twdh_fp8(dev, B=256, K=128, S=16, C=21):
                     "activation scales calibrated on a different seeded batch"}
 
 
-def dchmt_epoch(dev, cpu_sample=True, pairs=1000, batch=32, bits=16):
-    import recipe
+def dchmt_trainer(dev, pairs=1000, batch=32, bits=16):
+    """The DCHMT trainer of configs[0] on a resident synthetic set (constructed, not run)."""
     import main
     from train.DCHMT.hash_train import DCHMTTrainer
     tmp = "/tmp/cmh_bench_dchmt"
@@ -179,15 +179,31 @@ def dchmt_epoch(dev, cpu_sample=True, pairs=1000, batch=32, bits=16):
         tr = main.trainers["DCHMT"](argparse.Namespace(method="DCHMT", dataset="synthetic", output_dim=bits, is_train=True), dev.index or 0)
     finally:
         sys.argv, DCHMTTrainer.run = argv, run
-    # the synthetic set draws every item on the host (numpy normal deviates, ~1 ms per image): keep that out of the numbers the
-    # way a resident dataset would be - materialise the three sets once, then iterate over tensors
-    def resident(loader):
-        items = [loader.dataset[i] for i in range(len(loader.dataset))]
-        cols = [torch.stack([torch.as_tensor(v) for v in c]) for c in zip(*items)]
-        ds = torch.utils.data.TensorDataset(*cols)
-        return torch.utils.data.DataLoader(ds, batch_size=batch, shuffle=False)
+    # the synthetic set draws every item on the host (numpy normal deviates, ~1 ms per image) and a worker-less DataLoader collates
+    # and copies each 19 MB batch inside the step (27 of the 38 ms per step measured that way, tools/step_host_profile.py): keep
+    # both out of the numbers the way the contract asks (inputs resident in HBM) - materialise the three sets once on the device,
+    # then hand out slices
+    class Resident:
+        def __init__(self, loader):
+            items = [loader.dataset[i] for i in range(len(loader.dataset))]
+            self.cols = [torch.stack([torch.as_tensor(v) for v in c]).to(dev) for c in zip(*items)]
+            self.dataset = torch.utils.data.TensorDataset(*self.cols)
+
+        def __len__(self):
+            return (len(self.dataset) + batch - 1) // batch
+
+        def __iter__(self):
+            for i in range(0, len(self.dataset), batch):
+                yield tuple(c[i:i + batch] for c in self.cols)
+
+    resident = Resident
     tr.train_loader, tr.query_loader, tr.retrieval_loader = (resident(l) for l in (tr.train_loader, tr.query_loader, tr.retrieval_loader))
     tr.save_model = lambda epoch: None
+    return tr
+
+
+def dchmt_epoch(dev, cpu_sample=True, pairs=1000, batch=32, bits=16):
+    tr = dchmt_trainer(dev, pairs, batch, bits)
     step0 = tr._step(*[t for t in next(iter(tr.train_loader))][:3])          # warm-up step: weight copies, workspaces
     torch.cuda.synchronize()
     t0 = time.perf_counter()
