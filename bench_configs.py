@@ -91,6 +91,8 @@ def mith_step(dev, B=256, K=64, C=80, bank=10000):
             fwd(txt, kpm)
         dt, _ = _sync_time(lambda: fwd(txt, kpm), 5)
         out[f"forward_{L}_tokens"] = {"ms": round(dt * 1e3, 3), "pairs_per_s": round(B / dt, 1)}
+    if os.environ.get("CMH_LEG_FWD_ONLY") == "1":      # (tools/leg_trace.sh: a kernel trace of the forward alone)
+        return out
     # training step at the reference's default caption length (argsbase.py:20 --max-words 32)
     hm.train()
     txt = torch.from_numpy(recipe.captions(B, 32, 49408, 1)).to(dev)

@@ -64,17 +64,88 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const T* __restrict__
         }
       }
     }
+    // the butterfly leaves every sum in every lane: lane u keeps output u, then ONE pass of bias / mask / activation / store for the
+    // four (a lane-0-only epilogue per output made the wave walk through tanhf once per output)
+    float t = 0.f;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      float t = wsum(s[u]);
-      const int n = n0 + u;
-      if (lane == 0 && n < N) {
-        if (bias) t += bias[n];
-        if (mask) t *= mask[static_cast<size_t>(m) * N + n] * keep_scale;
-        if (act == CMH_ACT_TANH) t = tanhf(t);
-        else if (act == CMH_ACT_RELU) t = fmaxf(t, 0.f);
-        y[static_cast<size_t>(m) * N + n] = t;
+      const float v = wsum(s[u]);
+      if (lane == u) t = v;
+    }
+    const int n = n0 + lane;
+    if (lane < 4 && n < N) {
+      if (bias) t += bias[n];
+      if (mask) t *= mask[static_cast<size_t>(m) * N + n] * keep_scale;
+      if (act == CMH_ACT_TANH) t = tanhf(t);
+      else if (act == CMH_ACT_RELU) t = fmaxf(t, 0.f);
+      y[static_cast<size_t>(m) * N + n] = t;
+    }
+  }
+}
+
+// The same arithmetic for MANY rows (MITH's token-level concept similarities: 12 544 x 512 -> 64): one block per row re-reads the
+// whole weight matrix from L2 for every row (1.6 GB for that shape, 267 us).  Here a block owns R consecutive rows, keeps their
+// K <= 1024 inputs in registers and applies every weight vector it loads to all of them.  Each output is still formed by the same
+// lane partition of k, the same FMA chain per lane and the same butterfly: bit-identical to small_linear_kernel.
+template <typename T, int R, int KV>   // KV float4 per lane and row: K <= 256 KV
+__global__ __launch_bounds__(256, 2) void small_linear_rows_kernel(const T* __restrict__ x, const T* __restrict__ w,
+                                                                const float* __restrict__ bias, const float* __restrict__ mask,
+                                                                float keep_scale, int act, float* __restrict__ y, int M, int N, int K) {
+  const int m0 = blockIdx.x * R;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float4 xv[R][KV];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int m = m0 + r < M ? m0 + r : M - 1;
+    const T* xr = x + static_cast<size_t>(m) * K;
+#pragma unroll
+    for (int j = 0; j < KV; ++j) {
+      const int k0 = lane * 4 + 256 * j;
+      xv[r][j] = k0 < K ? ld4(xr + k0) : float4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  for (int n0 = wid * 4; n0 < N; n0 += 16) {
+    float s[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s[r][u] = 0.f;
+#pragma unroll
+    for (int j = 0; j < KV; ++j) {
+      const int k0 = lane * 4 + 256 * j;
+      if (k0 < K) {
+        float4 wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int n = n0 + u < N ? n0 + u : N - 1;
+          wv[u] = ld4(w + static_cast<size_t>(n) * K + k0);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            s[r][u] = fmaf(xv[r][j].x, wv[u].x, s[r][u]);
+            s[r][u] = fmaf(xv[r][j].y, wv[u].y, s[r][u]);
+            s[r][u] = fmaf(xv[r][j].z, wv[u].z, s[r][u]);
+            s[r][u] = fmaf(xv[r][j].w, wv[u].w, s[r][u]);
+          }
       }
+    }
+    float t = 0.f;          // lane 4 r + u keeps output (row r, column u): one epilogue pass for the 4 R outputs
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float v = wsum(s[r][u]);
+        if (lane == r * 4 + u) t = v;
+      }
+    const int n = n0 + (lane & 3), m = m0 + (lane >> 2);
+    if (lane < 4 * R && n < N && m < M) {
+      if (bias) t += bias[n];
+      if (mask) t *= mask[static_cast<size_t>(m) * N + n] * keep_scale;
+      if (act == CMH_ACT_TANH) t = tanhf(t);
+      else if (act == CMH_ACT_RELU) t = fmaxf(t, 0.f);
+      y[static_cast<size_t>(m) * N + n] = t;
     }
   }
 }
@@ -83,6 +154,18 @@ int launch_small_linear(int dt, const void* x, const void* w, const float* bias,
                         float keep_scale, int act, float* y, int M, int N, int K, hipStream_t st) {
   CMH_CHECK_ARG(M > 0 && N > 0 && K > 0, "linear: empty problem M=%d N=%d K=%d", M, N, K);
   CMH_CHECK_ARG(K % 4 == 0 && K <= 256 * kSLMaxVec, "linear: K=%d must be a multiple of 4 and <= 4096", K);
+  static const bool rows_off = []() { const char* e = getenv("CMH_SMALL_LINEAR_ROWS"); return e && e[0] == '0'; }();
+  if (dt == CMH_F32 && K <= 1024 && M >= 2048 && !rows_off) {   // >= 256 blocks of 8 rows: the chip stays full
+    constexpr int R = 8;
+    if (K <= 512)
+      hipLaunchKernelGGL((small_linear_rows_kernel<float, R, 2>), dim3((M + R - 1) / R), dim3(256), 0, st, static_cast<const float*>(x),
+                         static_cast<const float*>(w), bias, mask, keep_scale, act, y, M, N, K);
+    else   // (four rows: eight rows of 1024 inputs do not fit two waves per SIMD)
+      hipLaunchKernelGGL((small_linear_rows_kernel<float, 4, 4>), dim3((M + 3) / 4), dim3(256), 0, st, static_cast<const float*>(x),
+                         static_cast<const float*>(w), bias, mask, keep_scale, act, y, M, N, K);
+    CMH_CHECK_LAUNCH("small_linear_rows");
+    return CMH_OK;
+  }
   if (dt == CMH_F32)
     hipLaunchKernelGGL(small_linear_kernel<float>, dim3(M), dim3(256), 0, st, static_cast<const float*>(x),
                        static_cast<const float*>(w), bias, mask, keep_scale, act, y, M, N, K);

@@ -164,3 +164,22 @@ def test_twdh_step_gradients_match_reference_goldens(golden, B, K, S, C):
     np.testing.assert_allclose(hi.norm.running_mean.cpu().numpy(), g[f"{tag}_img_running_mean"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(hi.norm.running_var.cpu().numpy(), g[f"{tag}_img_running_var"], rtol=1e-5, atol=1e-6)
     assert int(hi.norm.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("M,N,K,act", [(12544, 64, 512, "tanh"), (2051, 30, 512, "none"), (4096, 128, 1024, "relu"), (3000, 16, 260, "tanh")])
+def test_linear_act_many_rows_has_the_one_row_kernels_bits(M, N, K, act):
+    """cmh_linear_act on >= 2048 rows takes the kernel that keeps eight rows' inputs in registers per block (MITH's token-level
+    concept similarities, model/MITH.py:441-442 upstream); every output is formed by the same lane partition, FMA chain and
+    butterfly as in the one-row-per-block kernel, so slices of fewer rows (which take that kernel) give the same bits."""
+    import cmh_native as N_
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(DEV)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    a = {"tanh": N_.ACT_TANH, "none": N_.ACT_NONE, "relu": N_.ACT_RELU}[act]
+    full = N_.linear_act(x, w, b, a)
+    parts = torch.cat([N_.linear_act(x[i:i + 1000].contiguous(), w, b, a) for i in range(0, M, 1000)])
+    assert torch.equal(full, parts)
+    ref = x.double() @ w.double().t() + b.double()
+    ref = torch.tanh(ref) if act == "tanh" else (ref.clamp_min(0) if act == "relu" else ref)
+    torch.testing.assert_close(full.double(), ref, rtol=1e-4, atol=1e-5)
