@@ -367,8 +367,11 @@ struct MapArgs {
   unsigned long long* stamps; // optional: 6 cycle stamps of (workgroup 0, first query) at the phase boundaries (diagnostics)
 };
 
+#ifndef CMH_MAP_GLOBAL_WAVES
+#define CMH_MAP_GLOBAL_WAVES 8   // waves per SIMD asked of the workspace-mode variant: 8 = two 1024-thread workgroups per CU (64 VGPRs)
+#endif
 template <bool USE_LDS>
-__global__ __launch_bounds__(NT) void map_query_kernel(MapArgs A) {
+__global__ __launch_bounds__(NT, USE_LDS ? 4 : CMH_MAP_GLOBAL_WAVES) void map_query_kernel(MapArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t dyn_smem[];
   __shared__ uint32_t sq[3][kMaxWords];     // query planes: sign, nz, label
   __shared__ int stask[3];                  // tasks of the level; chunks among them; the next task to hand out
@@ -910,7 +913,8 @@ __global__ __launch_bounds__(256) void neighbor_kernel(const uint32_t* __restric
 }
 
 static size_t lds_bytes_needed(int64_t N) { return store_words(N) * 4; }
-constexpr size_t kLdsBudget = 150 * 1024;   // of 160 KiB; static __shared__ of the kernel takes ~2 KiB
+// of 160 KiB; static __shared__ of the kernel takes ~5 KiB.  CMH_MAP_LDS=0 (diagnostic): every size takes the workspace mode
+static const size_t kLdsBudget = []() { const char* e = getenv("CMH_MAP_LDS"); return e && e[0] == '0' ? size_t{0} : size_t{150 * 1024}; }();
 
 static int map_slots(int Q) { return Q < 1024 ? Q : 1024; }
 
