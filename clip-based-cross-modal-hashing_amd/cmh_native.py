@@ -179,6 +179,7 @@ SIGNATURES = {
     "cmh_l2_normalize_backward": (C.c_int, [_p, _p, _p, _i32, _i32, _p]),
     "cmh_bitwise_hash_backward": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p]),
     "cmh_mith_bayesian_backward_workspace_bytes": (_sz, [_i32, _i32]),
+    "cmh_info_nce_workspace_bytes": (_sz, [_i32, _i32]),
     "cmh_mith_bayesian_loss_backward": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _sz, _p]),
     "cmh_info_nce_backward": (C.c_int, [_p, _p, _i32, _i32, _i32, _f, _p, _p, _p, _p, _sz, _p]),
     "cmh_sq_diff_sum_backward": (C.c_int, [_p, _p, C.c_int64, _p, _p, _p, _p]),

@@ -234,6 +234,68 @@ __global__ __launch_bounds__(256) void bayes_kernel(const float* __restrict__ ba
   if (threadIdx.x == 0 && t != 0.0) atomicAdd(acc, t);
 }
 
+// ---- the same loss on the f32 matrix pipe (K and C <= 128) ----------------------------------------------------------------------------
+// The loop above spends its time in butterflies: every (bank row, batch row) pair costs a 6-step wave reduction for 64 + 80
+// products (384 us for 256 x 10 000 x 64 bit x 80 classes).  v_mfma_f32_16x16x4_f32 forms 16 x 16 such dot products as k-ordered f32
+// FMA chains with one operand element per lane and no cross-lane step: a wave keeps 16 batch rows as B operands (bq / lq: element
+// j = k 4j + lane/16 of row lane%16) and walks over 16-row tiles of the bank; lane (row%16 = lane&15, quad = lane>>4) then holds the
+// pairs (bank row 4 quad + r, batch row lane&15), r = 0..3.  Values differ from the loop above by f32 summation order only.
+typedef float m_f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int kBayesQ = 32;   // operand quads per lane: K, C <= 128
+
+struct BayesOperands { float bq[kBayesQ], lq[kBayesQ]; };
+
+__device__ __forceinline__ void bayes_load_batch(BayesOperands& o, const float* __restrict__ batch, const float* __restrict__ label, int b,
+                                                 int K, int C, int quad) {
+#pragma unroll
+  for (int j = 0; j < kBayesQ; ++j) {
+    const int k = 4 * j + quad;
+    o.bq[j] = k < K ? batch[static_cast<size_t>(b) * K + k] : 0.f;
+    o.lq[j] = k < C ? label[static_cast<size_t>(b) * C + k] : 0.f;
+  }
+}
+
+// d[r], l[r]: bank row (tile row 4 quad + r) . batch row, bank label row . batch label row; `m` = this lane's (clamped) bank row
+__device__ __forceinline__ void bayes_tile(const BayesOperands& o, const float* __restrict__ bank, const float* __restrict__ bank_label,
+                                           int m, int K, int C, int quad, m_f32x4_t& d, m_f32x4_t& l) {
+  const float* br = bank + static_cast<size_t>(m) * K;
+  const float* lr = bank_label + static_cast<size_t>(m) * C;
+  d = m_f32x4_t{0.f, 0.f, 0.f, 0.f};
+  l = m_f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < kBayesQ; ++j) {
+    const int k = 4 * j + quad;
+    if (4 * j < K) d = __builtin_amdgcn_mfma_f32_16x16x4f32(k < K ? br[k] : 0.f, o.bq[j], d, 0, 0, 0);
+    if (4 * j < C) l = __builtin_amdgcn_mfma_f32_16x16x4f32(k < C ? lr[k] : 0.f, o.lq[j], l, 0, 0, 0);
+  }
+}
+
+// grid (ceil(B / 16), slices); a wave takes every fourth 16-row tile of its bank slice
+__global__ __launch_bounds__(256) void bayes_mfma_kernel(const float* __restrict__ bank, const float* __restrict__ batch,
+                                                         const float* __restrict__ bank_label, const float* __restrict__ label,
+                                                         int Mb, int B, int K, int C, double* __restrict__ acc) {
+  __shared__ double sh[4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r16 = lane & 15, quad = lane >> 4;
+  const int b0 = blockIdx.x * 16, sl = blockIdx.y;
+  const int per_slice = (Mb + gridDim.y - 1) / gridDim.y;
+  const int s0 = sl * per_slice, s1 = s0 + per_slice < Mb ? s0 + per_slice : Mb;
+  BayesOperands o;
+  bayes_load_batch(o, batch, label, b0 + r16 < B ? b0 + r16 : B - 1, K, C, quad);
+  double v = 0.0;
+  for (int mt = s0 + wid * 16; mt < s1; mt += 64) {
+    m_f32x4_t d, l;
+    bayes_tile(o, bank, bank_label, mt + r16 < s1 ? mt + r16 : s1 - 1, K, C, quad, d, l);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (mt + quad * 4 + r < s1 && b0 + r16 < B) {
+        const float sv = 0.5f * fminf(fmaxf(d[r], -64.f), 64.f);
+        v += static_cast<double>((l[r] > 0.f ? sv : 0.f) - logf(1.f + expf(sv)));
+      }
+  }
+  const double t = m_block_sum(v, sh);
+  if (threadIdx.x == 0 && t != 0.0) atomicAdd(acc, t);
+}
+
 // Grouped row cross-entropy with diagonal targets: row i (group g = i / G, index t = i % G) scores a_i . b_j / temp against
 // the G rows j of its group; acc += logsumexp_j - score_{i,t}.  G = N: info_nce_loss; G = L: info_nce_loss_bmm.
 __global__ __launch_bounds__(256) void row_ce_kernel(const float* __restrict__ a, const float* __restrict__ b, int R, int G,
@@ -337,6 +399,72 @@ __global__ __launch_bounds__(256) void bayes_bwd_kernel(const float* __restrict_
   for (int k = threadIdx.x; k < K; k += 256)
     partial[(static_cast<size_t>(sl) * B + b) * K + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
 }
+// The backward on the matrix pipe (K % 16 == 0, K, C <= 128): grid (ceil(B / 16), kBayesSlices).  Phase A = the forward's tiles, the
+// coefficient of every (bank row, batch row) pair goes to LDS as cf[bank row][batch row]; phase B = dbatch tile [16 batch rows, K]
+// += cf^T . bank, again 16x16x4 MFMAs: A operand = cf (lane: batch row lane&15, bank row 4 i + lane>>4), B operand = 4 bank rows x 16
+// bits (a 64-byte segment per row).  A wave takes every fourth quad of bank rows; the four partial tiles meet in LDS.
+constexpr int kBayesChunk = 640;      // bank rows per LDS pass (a 10 000-row bank in 16 slices: one pass)
+constexpr int kBayesCfLd = 20;        // floats per cf row: 16 + 4 (lanes of one store hit 64 different banks)
+
+__global__ __launch_bounds__(256) void bayes_bwd_mfma_kernel(const float* __restrict__ bank, const float* __restrict__ batch,
+                                                             const float* __restrict__ bank_label, const float* __restrict__ label,
+                                                             int Mb, int B, int K, int C, const float* __restrict__ dloss,
+                                                             float* __restrict__ partial) {
+  __shared__ float cf[kBayesChunk * kBayesCfLd];
+  __shared__ float red[4][16][128 + 4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r16 = lane & 15, quad = lane >> 4;
+  const int b0 = blockIdx.x * 16, sl = blockIdx.y;
+  const int per_slice = (Mb + kBayesSlices - 1) / kBayesSlices;
+  const int s0 = sl * per_slice, s1 = s0 + per_slice < Mb ? s0 + per_slice : Mb;
+  const float g = -(dloss ? dloss[0] : 1.f) * 0.5f / (static_cast<float>(Mb) * static_cast<float>(B));
+  BayesOperands o;
+  bayes_load_batch(o, batch, label, b0 + r16 < B ? b0 + r16 : B - 1, K, C, quad);
+  const int KT = K / 16;
+  m_f32x4_t dacc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) dacc[t] = m_f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int c0 = s0; c0 < s1; c0 += kBayesChunk) {
+    const int c1 = c0 + kBayesChunk < s1 ? c0 + kBayesChunk : s1;
+    const int rows16 = (c1 - c0 + 15) & ~15;                 // phase B reads whole quads: rows past c1 hold zeros
+    __syncthreads();                                         // (the previous chunk's phase B is done with cf)
+    for (int mt = c0 + wid * 16; mt < c0 + rows16; mt += 64) {
+      m_f32x4_t d, l;
+      bayes_tile(o, bank, bank_label, mt + r16 < c1 ? mt + r16 : c1 - 1, K, C, quad, d, l);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mm = mt + quad * 4 + r;
+        float c = 0.f;
+        if (mm < c1 && b0 + r16 < B && d[r] >= -64.f && d[r] <= 64.f) {
+          const float sig = 1.0f / (1.0f + expf(-0.5f * d[r]));
+          c = g * ((l[r] > 0.f ? 1.f : 0.f) - sig);
+        }
+        cf[(mm - c0) * kBayesCfLd + r16] = c;
+      }
+    }
+    __syncthreads();
+    for (int mq = wid * 4; mq < rows16; mq += 16) {
+      const int ml = mq + quad;                              // this lane's bank row of the quad
+      const float a = cf[ml * kBayesCfLd + r16];
+      const int m = c0 + ml < c1 ? c0 + ml : c1 - 1;         // (its coefficient is zero past c1)
+      const float* br = bank + static_cast<size_t>(m) * K + r16;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        if (t < KT) dacc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, br[t * 16], dacc[t], 0, 0, 0);
+    }
+  }
+  // dacc[t][r] = (batch row 4 quad + r, bit 16 t + lane&15) of this wave's share
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+    if (t < KT)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wid][quad * 4 + r][t * 16 + r16] = dacc[t][r];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 16 * K; i += 256) {
+    const int bb = i / K, k = i - bb * K;
+    if (b0 + bb < B)
+      partial[(static_cast<size_t>(sl) * B + b0 + bb) * K + k] = (red[0][bb][k] + red[1][bb][k]) + (red[2][bb][k] + red[3][bb][k]);
+  }
+}
 // dbatch[b,k] = sum over the slices, in slice order
 __global__ __launch_bounds__(256) void bayes_bwd_reduce_kernel(const float* __restrict__ partial, int n, float* __restrict__ dbatch) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -408,6 +536,138 @@ __global__ __launch_bounds__(256) void info_nce_bwd_kernel(const float* __restri
     float acc = 0.f;
     for (int j = 0; j < G; ++j) acc = fmaf(wj[j], y[static_cast<size_t>(g0 + j) * D + d], acc);
     dx[static_cast<size_t>(i) * D + d] = acc * scale;
+  }
+}
+
+// ---- InfoNCE on the f32 matrix pipe (D % 64 == 0 and a workspace for the score matrix) ---------------------------------------------------
+// The kernels above give every candidate row to ONE lane that walks its D products alone, recompute the scores in a second pass and once
+// more per direction (token-level term of configs[2]: 16 384 rows in groups of 64, D = 512: ~0.5 ms per launch, six launches per step).
+// Here the scores S = a_i . b_j / T of a group are formed once, as 16 x 16 tiles of k-ordered f32 FMA chains (v_mfma_f32_16x16x4_f32; a
+// lane loads 4 consecutive k of its row and feeds them to four MFMAs, so the k order inside a block of 16 is permuted - both operands
+// alike), both directions' log-sum-exps are row / column reductions of S, and the gradients are S-shaped weights times the other operand,
+// tiled the same way.
+__device__ __forceinline__ m_f32x4_t m_ld4(const float* p) { return *reinterpret_cast<const m_f32x4_t*>(p); }
+
+// one wave per 16 x 16 tile of a group's G x G scores
+__global__ __launch_bounds__(256) void nce_scores_kernel(const float* __restrict__ a, const float* __restrict__ b, int R, int G, int D,
+                                                         float inv_temp, float* __restrict__ S) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r16 = lane & 15, quad = lane >> 4;
+  const int tg = (G + 15) / 16;
+  const long tile = static_cast<long>(blockIdx.x) * 4 + wid, total = static_cast<long>(R / G) * tg * tg;
+  if (tile >= total) return;
+  const int grp = static_cast<int>(tile / (tg * tg)), rem = static_cast<int>(tile - static_cast<long>(grp) * tg * tg);
+  const int it = rem / tg, jt = rem - it * tg, g0 = grp * G;
+  const int ia = it * 16 + r16 < G ? it * 16 + r16 : G - 1, jb = jt * 16 + r16 < G ? jt * 16 + r16 : G - 1;
+  const float* ar = a + static_cast<size_t>(g0 + ia) * D + 4 * quad;
+  const float* br = b + static_cast<size_t>(g0 + jb) * D + 4 * quad;
+  m_f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int k0 = 0; k0 < D; k0 += 16) {
+    const m_f32x4_t av = m_ld4(ar + k0), bv = m_ld4(br + k0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], acc, 0, 0, 0);
+  }
+  const int j = jt * 16 + r16;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = it * 16 + quad * 4 + r;
+    if (i < G && j < G) S[static_cast<size_t>(g0 + i) * G + j] = acc[r] * inv_temp;
+  }
+}
+
+// grid (groups, ceil(G / 64)): block (grp, sb) takes rows and columns [64 sb, 64 sb + 64) of the group: lse_row[i] = logsumexp_j S_ij,
+// lse_col[j] = logsumexp_i S_ij (either may be NULL), acc += (lse_row[i] - S_ii) + (lse_col[i] - S_ii)
+__global__ __launch_bounds__(256) void nce_lse_kernel(const float* __restrict__ S, int G, float* __restrict__ lse_row,
+                                                      float* __restrict__ lse_col, double* __restrict__ acc) {
+  __shared__ double sh[4];
+  __shared__ float cmx[4][64], cse[4][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, grp = blockIdx.x, sb = blockIdx.y;
+  const float* Sg = S + static_cast<size_t>(grp) * G * G;
+  double v = 0.0;
+  for (int i = sb * 64 + wid; i < sb * 64 + 64 && i < G; i += 4) {
+    const float* row = Sg + static_cast<size_t>(i) * G;
+    float mx = -1e30f;
+    for (int j = lane; j < G; j += 64) mx = fmaxf(mx, row[j]);
+    mx = m_wave_max(mx);
+    float se = 0.f;
+    for (int j = lane; j < G; j += 64) se += expf(row[j] - mx);
+    se = m_wave_sum(se);
+    const float l = mx + logf(se);
+    if (lane == 0) {
+      if (lse_row) lse_row[static_cast<size_t>(grp) * G + i] = l;
+      v += static_cast<double>(l - row[i]);
+    }
+  }
+  // columns: lane = column, the four waves take a quarter of the rows each, the partial (max, sum) pairs meet in LDS
+  const int j = sb * 64 + lane;
+  const int per = (G + 3) / 4, i0 = wid * per, i1 = i0 + per < G ? i0 + per : G;
+  float mx = -1e30f, se = 0.f;
+  if (j < G) {
+    for (int i = i0; i < i1; ++i) mx = fmaxf(mx, Sg[static_cast<size_t>(i) * G + j]);
+    for (int i = i0; i < i1; ++i) se += expf(Sg[static_cast<size_t>(i) * G + j] - mx);
+  }
+  cmx[wid][lane] = mx;
+  cse[wid][lane] = se;
+  __syncthreads();
+  if (wid == 0 && j < G) {
+    const float m4 = fmaxf(fmaxf(cmx[0][lane], cmx[1][lane]), fmaxf(cmx[2][lane], cmx[3][lane]));
+    float s4 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s4 += cse[w][lane] * expf(cmx[w][lane] - m4);   // (an empty quarter: 0 * exp(-1e30 - m4) = 0)
+    const float l = m4 + logf(s4);
+    if (lse_col) lse_col[static_cast<size_t>(grp) * G + j] = l;
+    v += static_cast<double>(l - Sg[static_cast<size_t>(j) * G + j]);
+  }
+  const double t = m_block_sum(v, sh);
+  if (acc && threadIdx.x == 0 && t != 0.0) atomicAdd(acc, t);
+}
+
+// S -> W in place: W_ij = exp(S_ij - lse_row[i]) + exp(S_ij - lse_col[j]) - 2 [i == j]
+__global__ __launch_bounds__(256) void nce_weights_kernel(float* __restrict__ S, const float* __restrict__ lse_row,
+                                                          const float* __restrict__ lse_col, int G, size_t n) {
+  const size_t idx = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (idx >= n) return;
+  const size_t i = idx / G;                 // global row
+  const int j = static_cast<int>(idx - i * G);
+  const size_t g0 = (i / G) * G;
+  const float sv = S[idx];
+  S[idx] = expf(sv - lse_row[i]) + expf(sv - lse_col[g0 + j]) - (i - g0 == static_cast<size_t>(j) ? 2.f : 0.f);
+}
+
+// out[g0 + i, :] = scale * sum_j w(i, j) y[g0 + j, :], w(i, j) = W[g0 + i][j] (TR = false) or W[g0 + j][i] (TR = true);
+// one wave per 16 rows x 64 columns
+template <bool TR>
+__global__ __launch_bounds__(256) void nce_grad_kernel(const float* __restrict__ W, const float* __restrict__ y, int R, int G, int D,
+                                                       const float* __restrict__ dloss, float scale0, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r16 = lane & 15, quad = lane >> 4;
+  const int tg = (G + 15) / 16, dq = D / 64;
+  const long wv = static_cast<long>(blockIdx.x) * 4 + wid, total = static_cast<long>(R / G) * tg * dq;
+  if (wv >= total) return;
+  const int grp = static_cast<int>(wv / (tg * dq)), rem = static_cast<int>(wv - static_cast<long>(grp) * tg * dq);
+  const int it = rem / dq, d0 = (rem - it * dq) * 64, g0 = grp * G;
+  const int ii = it * 16 + r16 < G ? it * 16 + r16 : G - 1;
+  m_f32x4_t acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = m_f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int j0 = 0; j0 < G; j0 += 16) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int jj = j0 + 4 * quad + e;
+      const int jc = jj < G ? jj : G - 1;
+      float wv_ = TR ? W[static_cast<size_t>(g0 + jc) * G + ii] : W[static_cast<size_t>(g0 + ii) * G + jc];
+      if (jj >= G) wv_ = 0.f;
+      const float* yr = y + static_cast<size_t>(g0 + jc) * D + d0 + r16;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv_, yr[16 * t], acc[t], 0, 0, 0);
+    }
+  }
+  const float scale = (dloss ? dloss[0] : 1.f) * scale0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = it * 16 + quad * 4 + r;
+    if (i < G)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) out[static_cast<size_t>(g0 + i) * D + d0 + 16 * t + r16] = acc[t][r] * scale;
   }
 }
 
@@ -557,6 +817,11 @@ extern "C" int cmh_mith_mix(const float* img_cls, const float* img_tok, const fl
   return CMH_OK;
 }
 
+static bool bayes_mfma_off() {   // CMH_BAYES_MFMA=0: the butterfly kernels (A/B, and the shapes the tiles do not cover)
+  static const bool off = []() { const char* e = getenv("CMH_BAYES_MFMA"); return e && e[0] == '0'; }();
+  return off;
+}
+
 extern "C" int cmh_sq_diff_sum(const float* a, const float* b, int64_t n, float* out, void* workspace, size_t workspace_bytes,
                                void* stream) {
   CMH_CHECK_ARG(a && b && out && workspace && n > 0 && workspace_bytes >= 256, "sq_diff_sum: bad arguments");
@@ -579,10 +844,18 @@ extern "C" int cmh_mith_bayesian_loss(const float* bank, const float* batch, con
   double* acc = static_cast<double*>(workspace);
   if (hipMemsetAsync(acc, 0, 8, st) != hipSuccess) return fail(CMH_ERR_LAUNCH, "mith_bayesian_loss: memset failed");
   const int64_t n = static_cast<int64_t>(Mb) * B;
-  hipLaunchKernelGGL(bayes_kernel, dim3(B, Mb >= 1024 ? 16 : 1), dim3(256), 0, st, bank, batch, bank_label, label, Mb, B, K, C, acc);
+  if (K <= 128 && C <= 128 && !bayes_mfma_off())
+    hipLaunchKernelGGL(bayes_mfma_kernel, dim3((B + 15) / 16, Mb >= 1024 ? 16 : 1), dim3(256), 0, st, bank, batch, bank_label, label, Mb, B, K, C, acc);
+  else
+    hipLaunchKernelGGL(bayes_kernel, dim3(B, Mb >= 1024 ? 16 : 1), dim3(256), 0, st, bank, batch, bank_label, label, Mb, B, K, C, acc);
   hipLaunchKernelGGL(read_acc_kernel, dim3(1), dim3(1), 0, st, acc, -1.0 / static_cast<double>(n), out);
   CMH_CHECK_LAUNCH("mith_bayesian_loss");
   return CMH_OK;
+}
+
+// workspace of the matrix-pipe path of cmh_info_nce / cmh_info_nce_backward: 256 bytes of accumulators, the R x G scores, two R-vectors
+extern "C" size_t cmh_info_nce_workspace_bytes(int32_t R, int32_t G) {
+  return R > 0 && G > 0 ? 256 + (static_cast<size_t>(R) * G + 2 * static_cast<size_t>(R)) * 4 + 256 : 0;
 }
 
 extern "C" int cmh_info_nce(const float* a, const float* b, int32_t R, int32_t G, int32_t D, float temperature, float* out,
@@ -592,9 +865,17 @@ extern "C" int cmh_info_nce(const float* a, const float* b, int32_t R, int32_t G
   hipStream_t st = as_stream(stream);
   double* acc = static_cast<double*>(workspace);
   if (hipMemsetAsync(acc, 0, 8, st) != hipSuccess) return fail(CMH_ERR_LAUNCH, "info_nce: memset failed");
-  const size_t smem = static_cast<size_t>(4) * D * sizeof(float);
-  hipLaunchKernelGGL(row_ce_kernel, dim3((R + 3) / 4), dim3(256), smem, st, a, b, R, G, D, 1.0f / temperature, acc);
-  hipLaunchKernelGGL(row_ce_kernel, dim3((R + 3) / 4), dim3(256), smem, st, b, a, R, G, D, 1.0f / temperature, acc);
+  if (D % 64 == 0 && workspace_bytes >= cmh_info_nce_workspace_bytes(R, G) && !bayes_mfma_off()) {
+    float* S = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256);
+    const long tiles = static_cast<long>(R / G) * ((G + 15) / 16) * ((G + 15) / 16);
+    hipLaunchKernelGGL(nce_scores_kernel, dim3(static_cast<unsigned>((tiles + 3) / 4)), dim3(256), 0, st, a, b, R, G, D, 1.0f / temperature, S);
+    hipLaunchKernelGGL(nce_lse_kernel, dim3(R / G, (G + 63) / 64), dim3(256), 0, st, S, G, static_cast<float*>(nullptr),
+                       static_cast<float*>(nullptr), acc);
+  } else {
+    const size_t smem = static_cast<size_t>(4) * D * sizeof(float);
+    hipLaunchKernelGGL(row_ce_kernel, dim3((R + 3) / 4), dim3(256), smem, st, a, b, R, G, D, 1.0f / temperature, acc);
+    hipLaunchKernelGGL(row_ce_kernel, dim3((R + 3) / 4), dim3(256), smem, st, b, a, R, G, D, 1.0f / temperature, acc);
+  }
   hipLaunchKernelGGL(read_acc_kernel, dim3(1), dim3(1), 0, st, acc, 0.5 / static_cast<double>(R), out);
   CMH_CHECK_LAUNCH("info_nce");
   return CMH_OK;
@@ -659,7 +940,10 @@ extern "C" int cmh_mith_bayesian_loss_backward(const float* bank, const float* b
   if (workspace_bytes < cmh_mith_bayesian_backward_workspace_bytes(B, K)) return fail(CMH_ERR_WORKSPACE, "mith_bayesian_loss_backward: workspace too small");
   float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(bayes_bwd_kernel, dim3(B, kBayesSlices), dim3(256), 0, st, bank, batch, bank_label, label, Mb, B, K, C, dloss, partial);
+  if (K % 16 == 0 && C <= 128 && !bayes_mfma_off())
+    hipLaunchKernelGGL(bayes_bwd_mfma_kernel, dim3((B + 15) / 16, kBayesSlices), dim3(256), 0, st, bank, batch, bank_label, label, Mb, B, K, C, dloss, partial);
+  else
+    hipLaunchKernelGGL(bayes_bwd_kernel, dim3(B, kBayesSlices), dim3(256), 0, st, bank, batch, bank_label, label, Mb, B, K, C, dloss, partial);
   hipLaunchKernelGGL(bayes_bwd_reduce_kernel, dim3((B * K + 255) / 256), dim3(256), 0, st, partial, B * K, dbatch);
   CMH_CHECK_LAUNCH("mith_bayesian_loss_backward");
   return CMH_OK;
@@ -675,6 +959,22 @@ extern "C" int cmh_info_nce_backward(const float* a, const float* b, int32_t R, 
   float* lse_b = lse_a + R;
   hipStream_t st = as_stream(stream);
   const float it = 1.0f / temperature;
+  if (D % 64 == 0 && workspace_bytes >= cmh_info_nce_workspace_bytes(R, G) && !bayes_mfma_off()) {
+    float* S = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256);
+    float* lr = S + static_cast<size_t>(R) * G;
+    float* lc = lr + R;
+    const int tg = (G + 15) / 16;
+    const long tiles = static_cast<long>(R / G) * tg * tg, gw = static_cast<long>(R / G) * tg * (D / 64);
+    const size_t n = static_cast<size_t>(R) * G;
+    hipLaunchKernelGGL(nce_scores_kernel, dim3(static_cast<unsigned>((tiles + 3) / 4)), dim3(256), 0, st, a, b, R, G, D, it, S);
+    hipLaunchKernelGGL(nce_lse_kernel, dim3(R / G, (G + 63) / 64), dim3(256), 0, st, S, G, lr, lc, static_cast<double*>(nullptr));
+    hipLaunchKernelGGL(nce_weights_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, S, lr, lc, G, n);
+    const float scale0 = 0.5f * it / static_cast<float>(R);
+    hipLaunchKernelGGL(nce_grad_kernel<false>, dim3(static_cast<unsigned>((gw + 3) / 4)), dim3(256), 0, st, S, b, R, G, D, dloss, scale0, da);
+    hipLaunchKernelGGL(nce_grad_kernel<true>, dim3(static_cast<unsigned>((gw + 3) / 4)), dim3(256), 0, st, S, a, R, G, D, dloss, scale0, db);
+    CMH_CHECK_LAUNCH("info_nce_backward");
+    return CMH_OK;
+  }
   const dim3 grid((R + 3) / 4);
   hipLaunchKernelGGL(row_lse_kernel, grid, dim3(256), static_cast<size_t>(4) * D * 4, st, a, b, R, G, D, it, lse_a);
   hipLaunchKernelGGL(row_lse_kernel, grid, dim3(256), static_cast<size_t>(4) * D * 4, st, b, a, R, G, D, it, lse_b);

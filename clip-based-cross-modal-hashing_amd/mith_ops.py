@@ -159,7 +159,7 @@ def info_nce(a, b, group=None, temperature=0.07):
     D = a.shape[-1]
     R = a.numel() // D
     G = R if group is None else group
-    out, ws = _scalar(a.device), N.workspace(256, a.device, "loss")
+    out, ws = _scalar(a.device), N.workspace(N.lib().cmh_info_nce_workspace_bytes(R, G), a.device, "nce")
     N.check(N.lib().cmh_info_nce(N.ptr(a), N.ptr(b), R, G, D, float(temperature), N.ptr(out), N.ptr(ws), ws.numel(),
                                  N.stream_ptr(a.device)), "cmh_info_nce")
     return out[0]

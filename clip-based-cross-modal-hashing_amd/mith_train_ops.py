@@ -205,7 +205,7 @@ class InfoNceFn(torch.autograd.Function):
         G = R if ctx.group is None else ctx.group
         da, db = torch.empty_like(a), torch.empty_like(b)
         g = N.f32c(g).reshape(1)
-        ws = N.workspace(2 * R * 4 + 512, a.device, "nce")
+        ws = N.workspace(N.lib().cmh_info_nce_workspace_bytes(R, G), a.device, "nce")
         N.check(N.lib().cmh_info_nce_backward(N.ptr(a), N.ptr(b), R, G, D, ctx.temperature, N.ptr(g), N.ptr(da), N.ptr(db), N.ptr(ws),
                                               ws.numel(), N.stream_ptr(a.device)), "cmh_info_nce_backward")
         return da, db, None, None

@@ -454,6 +454,10 @@ int cmh_mith_bayesian_loss(const float* bank, const float* batch, const float* b
  * (:103-114), a/b = [N*L, D] with G = L reproduces info_nce_loss_bmm (:116-136). */
 int cmh_info_nce(const float* a, const float* b, int32_t R, int32_t G, int32_t D, float temperature, float* out,
                  void* workspace, size_t workspace_bytes, void* stream);
+/* Workspace that lets cmh_info_nce / cmh_info_nce_backward form the R x G score matrix once, as 16 x 16 tiles on the f32 matrix
+ * pipe (round 3; needs D % 64 == 0).  With a smaller workspace (>= 256 bytes forward, >= 8 R + 256 backward) both calls keep the
+ * per-row kernels of round 1: same values up to f32 summation order. */
+size_t cmh_info_nce_workspace_bytes(int32_t R, int32_t G);
 
 /* ---------------------------------------------------------------------------------------------
  * BertAdam, one fused multi-tensor step (model/base/optimization.py:103-168; SURVEY 8f "next" #1).

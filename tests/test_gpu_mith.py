@@ -264,3 +264,57 @@ def test_mismatched_feature_width_fails_loudly():
         M.gemm(z(4, 512), z(128, 512), None, residual=z(4, 64))
     with pytest.raises(N.NativeError):
         N.layernorm(z(4, 64), z(512), z(512))
+
+
+@pytest.mark.parametrize("R,G,D", [(256, 256, 512), (1024, 64, 512), (120, 40, 64), (200, 200, 128), (96, 8, 64)])
+def test_info_nce_on_the_matrix_pipe_equals_the_per_row_kernels(R, G, D):
+    """cmh_info_nce / cmh_info_nce_backward with the workspace of cmh_info_nce_workspace_bytes form the scores once as 16 x 16 MFMA
+    tiles (train/MITH/hash_train.py:103-136 upstream: info_nce_loss / info_nce_loss_bmm); with a small workspace they keep the
+    per-row kernels.  Both against torch autograd in float64, and against each other (f32 summation order apart); group sizes that are
+    not multiples of the tile included."""
+    import cmh_native as N
+    g = torch.Generator().manual_seed(R + G + D)
+    a = torch.nn.functional.normalize(torch.randn(R, D, generator=g), dim=-1).to(DEV)
+    b = torch.nn.functional.normalize(torch.randn(R, D, generator=g), dim=-1).to(DEV)
+    dl = torch.tensor([0.7], device=DEV)
+    res = {}
+    for name, nbytes in (("tiles", N.lib().cmh_info_nce_workspace_bytes(R, G)), ("rows", 2 * R * 4 + 512)):
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+        out = torch.zeros(1, device=DEV)
+        da, db = torch.full_like(a, float("nan")), torch.full_like(b, float("nan"))
+        N.check(N.lib().cmh_info_nce(N.ptr(a), N.ptr(b), R, G, D, 0.07, N.ptr(out), N.ptr(ws), ws.numel(), N.stream_ptr(a.device)), "nce")
+        N.check(N.lib().cmh_info_nce_backward(N.ptr(a), N.ptr(b), R, G, D, 0.07, N.ptr(dl), N.ptr(da), N.ptr(db), N.ptr(ws), ws.numel(),
+                                              N.stream_ptr(a.device)), "nce_bwd")
+        res[name] = (out.cpu().double(), da.cpu().double(), db.cpu().double())
+    a64, b64 = a.cpu().double().requires_grad_(True), b.cpu().double().requires_grad_(True)
+    sc = torch.einsum("gid,gjd->gij", a64.view(-1, G, D), b64.view(-1, G, D)) / 0.07
+    tgt = torch.arange(G).repeat(R // G)
+    loss = 0.5 * (torch.nn.functional.cross_entropy(sc.reshape(R, G), tgt) + torch.nn.functional.cross_entropy(sc.transpose(1, 2).reshape(R, G), tgt))
+    (0.7 * loss).backward()
+    for name, (lo, da, db) in res.items():
+        torch.testing.assert_close(lo[0], loss.detach(), rtol=2e-6, atol=2e-6, msg=lambda m: f"{name}: {m}")
+        for got, ref in ((da, a64.grad), (db, b64.grad)):
+            assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), name
+    torch.testing.assert_close(res["tiles"][1], res["rows"][1], rtol=1e-4, atol=1e-6 * float(res["rows"][1].abs().max()))
+
+
+@pytest.mark.parametrize("Mb,B,K,C", [(10000, 256, 64, 80), (1500, 37, 32, 21), (700, 130, 128, 24), (300, 16, 16, 5)])
+def test_bayesian_loss_on_the_matrix_pipe(Mb, B, K, C):
+    """cmh_mith_bayesian_loss(+_backward) as 16 x 16 MFMA tiles (K, C <= 128) against torch autograd in float64 (train/MITH/hash_train.py:
+    138-144 upstream), ragged bank slices and batch tiles included, and one pair beyond the +-64 clamp (no gradient there)."""
+    import mith_train_ops as T
+    g = torch.Generator().manual_seed(Mb + B + K + C)
+    bank = torch.randn(Mb, K, generator=g).tanh()
+    bank[3] = 4.0                                              # bank_3 . batch_5 = 4 * 4 * K > 64: clamped
+    batch = torch.randn(B, K, generator=g).tanh()
+    batch[5] = 4.0
+    bl, lab = (torch.rand(Mb, C, generator=g) < 0.15).float(), (torch.rand(B, C, generator=g) < 0.15).float()
+    x = batch.to(DEV).requires_grad_(True)
+    loss = T.BayesianLossFn.apply(bank.to(DEV), x, bl.to(DEV), lab.to(DEV))
+    (0.3 * loss).backward()
+    x64 = batch.double().requires_grad_(True)
+    s = 0.5 * (bank.double() @ x64.t()).clamp(-64, 64)
+    ref = -(((bl.double() @ lab.double().t()) > 0).double() * s - torch.log(1 + torch.exp(s))).mean()
+    (0.3 * ref).backward()
+    torch.testing.assert_close(loss.detach().cpu().double(), ref.detach(), rtol=2e-6, atol=2e-6)
+    assert float((x.grad.cpu().double() - x64.grad).abs().max()) <= 2e-5 * float(x64.grad.abs().max())
