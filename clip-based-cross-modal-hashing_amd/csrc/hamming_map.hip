@@ -27,6 +27,7 @@
 // caller's workspace otherwise (COCO / NUS-WIDE scale).  Integer/byte work, HBM/LDS-latency bound — no
 // MFMA on purpose.
 #include <cstdlib>
+#include <cstring>
 
 #include "cmh_common.h"
 
@@ -97,6 +98,39 @@ __device__ inline QueryStore carve_store(uint32_t* base, int N) {
   s.task = s.smallbits + bw;
   s.cnt = s.task + s.tcap;
   s.seginfo = s.cnt + 3 * s.ccap;
+  return s;
+}
+
+// Hybrid placement (mid-size N): the elements, the bitmaps and the task lists stay in LDS, the L / R position lists and the two segment
+// queues go to the workgroup's workspace slice: ~4.4 bytes of LDS per item instead of ~9.9, so that TWO queries share a CU.
+__host__ __device__ inline size_t hybrid_lds_words(int64_t N) {
+  const size_t n = static_cast<size_t>(N);
+  const size_t bw = (n + 31) / 32;
+  const size_t tcap = n / (kSeqMax + 1) + n / kChunk + 8, ccap = 2 * (n / kChunk) + 8;
+  return n + 3 * bw + tcap + 3 * ccap + (n / (kSeqMax + 1) + 2) + 16;
+}
+__host__ __device__ inline size_t hybrid_glob_words(int64_t N) {
+  const size_t n = static_cast<size_t>(N);
+  return (n + 2 * (n / 17) + 8) + 2 * (2 * (n / 17 + 2)) + 16;
+}
+__device__ inline QueryStore carve_hybrid(uint32_t* lds, uint32_t* glob, int N) {
+  QueryStore s;
+  const size_t n = static_cast<size_t>(N);
+  const size_t tmpw = n + 2 * (n / 17) + 8;
+  const size_t qw = 2 * (n / 17 + 2);
+  const size_t bw = (n + 31) / 32;
+  s.elem = lds;
+  s.leafbits = s.elem + n;
+  s.relbits = s.leafbits + bw;
+  s.smallbits = s.relbits + bw;
+  s.tcap = static_cast<int>(n / (kSeqMax + 1) + n / kChunk + 8);
+  s.ccap = static_cast<int>(2 * (n / kChunk) + 8);
+  s.task = s.smallbits + bw;
+  s.cnt = s.task + s.tcap;
+  s.seginfo = s.cnt + 3 * s.ccap;
+  s.tmp = glob;
+  s.qa = s.tmp + tmpw;
+  s.qb = s.qa + qw;
   return s;
 }
 
@@ -363,15 +397,14 @@ struct MapArgs {
   int stable;                 // CMH_TIE_STABLE: full sort of (key, index) instead of the introsort emulation
   float* ap;
   int32_t* perm;              // may be null
-  uint32_t* gstore;           // global slices (USE_LDS=false): gridDim.x * store_words(N)
+  uint32_t* gstore;           // workspace slices (MODE 0: gridDim.x * store_words(N); MODE 2: gridDim.x * hybrid_glob_words(N))
   unsigned long long* stamps; // optional: 6 cycle stamps of (workgroup 0, first query) at the phase boundaries (diagnostics)
 };
 
-#ifndef CMH_MAP_GLOBAL_WAVES
-#define CMH_MAP_GLOBAL_WAVES 8   // waves per SIMD asked of the workspace-mode variant: 8 = two 1024-thread workgroups per CU (64 VGPRs)
-#endif
-template <bool USE_LDS>
-__global__ __launch_bounds__(NT, USE_LDS ? 4 : CMH_MAP_GLOBAL_WAVES) void map_query_kernel(MapArgs A) {
+// MODE 0: everything in the workspace slice, 1: everything in LDS, 2: hybrid (above).  WAVES: waves per SIMD the variant is compiled
+// for - 4 = one 1024-thread workgroup per CU (<= 128 VGPRs), 8 = two (64 VGPRs, a few spills)
+template <int MODE, int WAVES>
+__global__ __launch_bounds__(NT, WAVES) void map_query_kernel(MapArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t dyn_smem[];
   __shared__ uint32_t sq[3][kMaxWords];     // query planes: sign, nz, label
   __shared__ int stask[3];                  // tasks of the level; chunks among them; the next task to hand out
@@ -383,7 +416,8 @@ __global__ __launch_bounds__(NT, USE_LDS ? 4 : CMH_MAP_GLOBAL_WAVES) void map_qu
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int N = A.N, W = A.W, LW = A.LW;
   QueryStore S;
-  if constexpr (USE_LDS) S = carve_store(dyn_smem, N);
+  if constexpr (MODE == 1) S = carve_store(dyn_smem, N);
+  else if constexpr (MODE == 2) S = carve_hybrid(dyn_smem, A.gstore + static_cast<size_t>(blockIdx.x) * hybrid_glob_words(N), N);
   else S = carve_store(A.gstore + static_cast<size_t>(blockIdx.x) * store_words(N), N);
   uint32_t* e = S.elem;
   const int bw = (N + 31) / 32;
@@ -913,8 +947,26 @@ __global__ __launch_bounds__(256) void neighbor_kernel(const uint32_t* __restric
 }
 
 static size_t lds_bytes_needed(int64_t N) { return store_words(N) * 4; }
-// of 160 KiB; static __shared__ of the kernel takes ~5 KiB.  CMH_MAP_LDS=0 (diagnostic): every size takes the workspace mode
-static const size_t kLdsBudget = []() { const char* e = getenv("CMH_MAP_LDS"); return e && e[0] == '0' ? size_t{0} : size_t{150 * 1024}; }();
+constexpr size_t kLdsOne = 150 * 1024;   // one workgroup per CU: of 160 KiB; static __shared__ of the kernel takes ~5 KiB
+constexpr size_t kLdsTwo = 74 * 1024;    // two workgroups per CU
+
+// Where a query's working set lives: MAP_LDS2 everything in LDS, two queries per CU (N <= ~7.6 k); MAP_HYBRID elements in LDS, position
+// lists in the workspace, two per CU (N <= ~17 k: MIRFlickr); MAP_LDS1 everything in LDS, one per CU; MAP_GLOBAL workspace, two per CU
+// (COCO / NUS-WIDE).  CMH_MAP_MODE=lds1|hybrid|global (diagnostic) overrides where the size allows it.
+enum MapMode { MAP_GLOBAL = 0, MAP_LDS1 = 1, MAP_HYBRID = 2, MAP_LDS2 = 3 };
+static MapMode map_mode(int64_t N) {
+  static const char* forced = getenv("CMH_MAP_MODE");
+  const size_t full = lds_bytes_needed(N), hyb = hybrid_lds_words(N) * 4;
+  if (forced) {
+    if (!strcmp(forced, "global")) return MAP_GLOBAL;
+    if (!strcmp(forced, "lds1") && full <= kLdsOne) return MAP_LDS1;
+    if (!strcmp(forced, "hybrid") && hyb <= kLdsTwo) return MAP_HYBRID;
+  }
+  if (full <= kLdsTwo) return MAP_LDS2;
+  if (hyb <= kLdsTwo) return MAP_HYBRID;
+  if (full <= kLdsOne) return MAP_LDS1;
+  return MAP_GLOBAL;
+}
 
 static int map_slots(int Q) { return Q < 1024 ? Q : 1024; }
 
@@ -989,8 +1041,11 @@ extern "C" int cmh_calc_neighbor(const uint32_t* la, const uint32_t* lb, int32_t
 extern "C" size_t cmh_map_workspace_bytes(int32_t Q, int64_t N, int32_t bits, int32_t tie_order) {
   (void)bits; (void)tie_order;
   if (Q <= 0 || N <= 0) return 0;
-  if (lds_bytes_needed(N) <= kLdsBudget) return 4096;   // LDS mode: only the optional diagnostics stamps live here
-  return static_cast<size_t>(map_slots(Q)) * store_words(N) * 4 + 256;
+  const size_t slots = static_cast<size_t>(map_slots(Q));
+  const MapMode mode = map_mode(N);       // (the same decision cmh_hamming_map takes, CMH_MAP_MODE included)
+  if (mode == MAP_GLOBAL) return slots * store_words(N) * 4 + 256;
+  if (mode == MAP_HYBRID) return slots * hybrid_glob_words(N) * 4 + 256;
+  return 4096;                            // all-LDS placements: only the optional diagnostics stamps live here
 }
 
 extern "C" int cmh_hamming_map(const uint32_t* q_sign, const uint32_t* q_nz, const uint32_t* q_label,
@@ -1012,16 +1067,22 @@ extern "C" int cmh_hamming_map(const uint32_t* q_sign, const uint32_t* q_nz, con
   a.Q = Q; a.N = static_cast<int>(N); a.bits = bits; a.W = (bits + 31) / 32; a.LW = (classes + 31) / 32;
   a.topk = topk; a.depth_limit = depth_limit_override; a.stable = tie_order == CMH_TIE_STABLE; a.ap = ap; a.perm = perm;
   a.gstore = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
-  a.stamps = getenv("CMH_MAP_STAMPS") ? reinterpret_cast<unsigned long long*>(a.gstore) : nullptr;   // LDS mode only: slice 0 unused
-  const size_t lds = lds_bytes_needed(N);
-  if (lds <= kLdsBudget) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(map_query_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)
-      return fail(CMH_ERR_LAUNCH, "hamming_map: cannot reserve %zu bytes of LDS", lds);
-    hipLaunchKernelGGL(map_query_kernel<true>, dim3(map_slots(Q)), dim3(NT), lds, st, a);
-  } else {
-    hipLaunchKernelGGL(map_query_kernel<false>, dim3(map_slots(Q)), dim3(NT), 0, st, a);
-  }
+  const MapMode mode = map_mode(N);
+  // diagnostics stamps (tools/map_stamps.py, CMH_MAP_MODE=lds1): only where the workspace holds nothing else
+  a.stamps = getenv("CMH_MAP_STAMPS") && (mode == MAP_LDS1 || mode == MAP_LDS2) ? reinterpret_cast<unsigned long long*>(a.gstore) : nullptr;
+  const size_t lds = mode == MAP_GLOBAL ? 0 : (mode == MAP_HYBRID ? hybrid_lds_words(N) * 4 : lds_bytes_needed(N));
+#define MAP_GO(MODE, WAVES)                                                                                                      \
+  do {                                                                                                                           \
+    if (lds && hipFuncSetAttribute(reinterpret_cast<const void*>(map_query_kernel<MODE, WAVES>),                                 \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)             \
+      return fail(CMH_ERR_LAUNCH, "hamming_map: cannot reserve %zu bytes of LDS", lds);                                          \
+    hipLaunchKernelGGL((map_query_kernel<MODE, WAVES>), dim3(map_slots(Q)), dim3(NT), lds, st, a);                               \
+  } while (0)
+  if (mode == MAP_LDS2) MAP_GO(1, 8);
+  else if (mode == MAP_HYBRID) MAP_GO(2, 8);
+  else if (mode == MAP_LDS1) MAP_GO(1, 4);
+  else MAP_GO(0, 8);
+#undef MAP_GO
   CMH_CHECK_LAUNCH("hamming_map");
   hipLaunchKernelGGL(map_mean_kernel, dim3(1), dim3(64), 0, st, ap, Q, map);
   CMH_CHECK_LAUNCH("map_mean");

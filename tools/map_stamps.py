@@ -1,5 +1,6 @@
 import os, sys
 os.environ["CMH_MAP_STAMPS"] = "1"
+os.environ.setdefault("CMH_MAP_MODE", "lds1")      # the stamps live in the workspace, which only the all-LDS placements leave free
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "clip-based-cross-modal-hashing_amd"))
 import torch, cmh_native as N
