@@ -951,9 +951,10 @@ constexpr size_t kLdsOne = 150 * 1024;   // one workgroup per CU: of 160 KiB; st
 constexpr size_t kLdsTwo = 74 * 1024;    // two workgroups per CU
 
 // Where a query's working set lives: MAP_LDS2 everything in LDS, two queries per CU (N <= ~7.6 k); MAP_HYBRID elements in LDS, position
-// lists in the workspace, two per CU (N <= ~17 k: MIRFlickr); MAP_LDS1 everything in LDS, one per CU; MAP_GLOBAL workspace, two per CU
-// (COCO / NUS-WIDE).  CMH_MAP_MODE=lds1|hybrid|global (diagnostic) overrides where the size allows it.
-enum MapMode { MAP_GLOBAL = 0, MAP_LDS1 = 1, MAP_HYBRID = 2, MAP_LDS2 = 3 };
+// lists in the workspace, two per CU (N <= ~17 k: MIRFlickr); MAP_HYBRID1 the same with one query per CU (N <= ~35 k); MAP_GLOBAL
+// workspace, two per CU (COCO / NUS-WIDE); MAP_LDS1 (everything in LDS, one per CU: round 2's placement) only on request.
+// CMH_MAP_MODE=lds1|hybrid|hybrid1|global (diagnostic) overrides where the size allows it.
+enum MapMode { MAP_GLOBAL = 0, MAP_LDS1 = 1, MAP_HYBRID = 2, MAP_LDS2 = 3, MAP_HYBRID1 = 4 };
 static MapMode map_mode(int64_t N) {
   static const char* forced = getenv("CMH_MAP_MODE");
   const size_t full = lds_bytes_needed(N), hyb = hybrid_lds_words(N) * 4;
@@ -961,10 +962,11 @@ static MapMode map_mode(int64_t N) {
     if (!strcmp(forced, "global")) return MAP_GLOBAL;
     if (!strcmp(forced, "lds1") && full <= kLdsOne) return MAP_LDS1;
     if (!strcmp(forced, "hybrid") && hyb <= kLdsTwo) return MAP_HYBRID;
+    if (!strcmp(forced, "hybrid1") && hyb <= kLdsOne) return MAP_HYBRID1;
   }
   if (full <= kLdsTwo) return MAP_LDS2;
   if (hyb <= kLdsTwo) return MAP_HYBRID;
-  if (full <= kLdsOne) return MAP_LDS1;
+  if (hyb <= kLdsOne) return MAP_HYBRID1;     // 17 k < N <= 35 k: one query per CU, elements in LDS (5000 x 20 015: 4.6 ms against 5.9 from the workspace)
   return MAP_GLOBAL;
 }
 
@@ -1044,7 +1046,7 @@ extern "C" size_t cmh_map_workspace_bytes(int32_t Q, int64_t N, int32_t bits, in
   const size_t slots = static_cast<size_t>(map_slots(Q));
   const MapMode mode = map_mode(N);       // (the same decision cmh_hamming_map takes, CMH_MAP_MODE included)
   if (mode == MAP_GLOBAL) return slots * store_words(N) * 4 + 256;
-  if (mode == MAP_HYBRID) return slots * hybrid_glob_words(N) * 4 + 256;
+  if (mode == MAP_HYBRID || mode == MAP_HYBRID1) return slots * hybrid_glob_words(N) * 4 + 256;
   return 4096;                            // all-LDS placements: only the optional diagnostics stamps live here
 }
 
@@ -1070,7 +1072,7 @@ extern "C" int cmh_hamming_map(const uint32_t* q_sign, const uint32_t* q_nz, con
   const MapMode mode = map_mode(N);
   // diagnostics stamps (tools/map_stamps.py, CMH_MAP_MODE=lds1): only where the workspace holds nothing else
   a.stamps = getenv("CMH_MAP_STAMPS") && (mode == MAP_LDS1 || mode == MAP_LDS2) ? reinterpret_cast<unsigned long long*>(a.gstore) : nullptr;
-  const size_t lds = mode == MAP_GLOBAL ? 0 : (mode == MAP_HYBRID ? hybrid_lds_words(N) * 4 : lds_bytes_needed(N));
+  const size_t lds = mode == MAP_GLOBAL ? 0 : (mode == MAP_HYBRID || mode == MAP_HYBRID1 ? hybrid_lds_words(N) * 4 : lds_bytes_needed(N));
 #define MAP_GO(MODE, WAVES)                                                                                                      \
   do {                                                                                                                           \
     if (lds && hipFuncSetAttribute(reinterpret_cast<const void*>(map_query_kernel<MODE, WAVES>),                                 \
@@ -1080,6 +1082,7 @@ extern "C" int cmh_hamming_map(const uint32_t* q_sign, const uint32_t* q_nz, con
   } while (0)
   if (mode == MAP_LDS2) MAP_GO(1, 8);
   else if (mode == MAP_HYBRID) MAP_GO(2, 8);
+  else if (mode == MAP_HYBRID1) MAP_GO(2, 4);
   else if (mode == MAP_LDS1) MAP_GO(1, 4);
   else MAP_GO(0, 8);
 #undef MAP_GO

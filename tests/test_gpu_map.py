@@ -173,7 +173,7 @@ def test_bad_codes_are_refused():
 
 @pytest.mark.parametrize("Q,N,K,C,k,zeros", [(5, 7, 16, 4, None, False), (9, 200, 64, 8, 50, False), (6, 1000, 128, 12, None, True),
                                               (4, 4097, 512, 24, 1000, False), (3, 5000, 2048, 24, None, True),
-                                              (3, 30000, 64, 24, 5000, False)])
+                                              (3, 30000, 64, 24, 5000, False), (3, 12000, 64, 24, None, False)])   # 12 000: elements in LDS, lists in the workspace
 def test_stable_tie_order_matches_stable_sort(Q, N, K, C, k, zeros):
     """CMH_TIE_STABLE: ties by ascending database index == the oracle's std::stable_sort ranking, bit-exact (1, 2 and 3
     radix passes; LDS- and workspace-resident queries; codes with zeros; a query without relevant items)."""
