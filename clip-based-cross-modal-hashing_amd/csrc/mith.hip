@@ -749,23 +749,41 @@ __global__ __launch_bounds__(256) void bithash_dx_kernel(const float* __restrict
   const float dz = dy[i] * (1.0f - y[i] * y[i]);
   for (int d = lane; d < D; d += 64) dx[static_cast<size_t>(i) * D + d] = dz * w[static_cast<size_t>(k) * D + d];
 }
+// grid (K, ceil(D / 64)): 64 feature columns per workgroup, the four waves take a quarter of the samples each (four chains per thread),
+// the quarter sums meet in LDS in wave order (round 1: K workgroups of one 256-long chain per thread, 204 us at 256 x 64 x 512)
 __global__ __launch_bounds__(256) void bithash_dw_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                          const float* __restrict__ dy, float* __restrict__ dw, float* __restrict__ db,
                                                          int Nb, int K, int D) {
-  const int k = blockIdx.x;
-  float sb = 0.f;
-  for (int d = threadIdx.x; d < D; d += 256) {
-    float acc = 0.f;
-    for (int n = 0; n < Nb; ++n) {
-      const size_t i = static_cast<size_t>(n) * K + k;
-      acc = fmaf(dy[i] * (1.0f - y[i] * y[i]), x[i * D + d], acc);
+  __shared__ float red[4][64];
+  __shared__ float redb[4];
+  const int k = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int d = blockIdx.y * 64 + lane;
+  const int per = (Nb + 3) / 4, n0 = wid * per, n1 = n0 + per < Nb ? n0 + per : Nb;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (d < D) {
+    int n = n0;
+    for (; n + 4 <= n1; n += 4) {
+      const size_t i0 = static_cast<size_t>(n) * K + k, i1 = i0 + K, i2 = i1 + K, i3 = i2 + K;
+      a0 = fmaf(dy[i0] * (1.0f - y[i0] * y[i0]), x[i0 * D + d], a0);
+      a1 = fmaf(dy[i1] * (1.0f - y[i1] * y[i1]), x[i1 * D + d], a1);
+      a2 = fmaf(dy[i2] * (1.0f - y[i2] * y[i2]), x[i2 * D + d], a2);
+      a3 = fmaf(dy[i3] * (1.0f - y[i3] * y[i3]), x[i3 * D + d], a3);
     }
-    dw[static_cast<size_t>(k) * D + d] = acc;
+    for (; n < n1; ++n) {
+      const size_t i = static_cast<size_t>(n) * K + k;
+      a0 = fmaf(dy[i] * (1.0f - y[i] * y[i]), x[i * D + d], a0);
+    }
   }
-  if (threadIdx.x == 0) {
-    for (int n = 0; n < Nb; ++n) { const size_t i = static_cast<size_t>(n) * K + k; sb += dy[i] * (1.0f - y[i] * y[i]); }
-    db[k] = sb;
+  red[wid][lane] = (a0 + a1) + (a2 + a3);
+  if (blockIdx.y == 0) {                       // db[k]: lanes across the wave's samples, wave sums in wave order
+    float sb = 0.f;
+    for (int n = n0 + lane; n < n1; n += 64) { const size_t i = static_cast<size_t>(n) * K + k; sb += dy[i] * (1.0f - y[i] * y[i]); }
+    sb = m_wave_sum(sb);
+    if (lane == 0) redb[wid] = sb;
   }
+  __syncthreads();
+  if (wid == 0 && d < D) dw[static_cast<size_t>(k) * D + d] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (blockIdx.y == 0 && threadIdx.x == 0) db[k] = (redb[0] + redb[1]) + (redb[2] + redb[3]);
 }
 
 }  // namespace cmh
@@ -922,7 +940,7 @@ extern "C" int cmh_bitwise_hash_backward(const float* x, const float* w, const f
   CMH_CHECK_ARG(x && w && y && dy && dx && dw && db && B > 0 && K > 0 && D > 0, "bitwise_hash_backward: bad arguments");
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(bithash_dx_kernel, dim3((B * K + 3) / 4), dim3(256), 0, st, w, y, dy, dx, B * K, K, D);
-  hipLaunchKernelGGL(bithash_dw_kernel, dim3(K), dim3(256), 0, st, x, y, dy, dw, db, B, K, D);
+  hipLaunchKernelGGL(bithash_dw_kernel, dim3(K, (D + 63) / 64), dim3(256), 0, st, x, y, dy, dw, db, B, K, D);
   CMH_CHECK_LAUNCH("bitwise_hash_backward");
   return CMH_OK;
 }
