@@ -56,6 +56,7 @@ def test_packed_encode_text_never_waits_for_the_device():
     torch.manual_seed(6)
     clip = CLIP(**recipe.CLIP_VITB32).to(DEV).float().set_gemm_dtype("bf16")
     clip.assume_frozen = True
+    clip.pack_text = True                                 # (the default; CMH_TEXT_PACK=0 in the environment would switch it off)
     txt = torch.from_numpy(recipe.captions(64, 77, recipe.CLIP_VITB32["vocab_size"], 6)).to(DEV)
     with torch.no_grad():
         ref = clip.encode_text(txt)                       # builds the weight copies and the workspace
