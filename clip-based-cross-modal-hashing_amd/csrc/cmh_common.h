@@ -120,6 +120,7 @@ __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + e
 // C[M,N] = epilogue(A[M,K] . W[N,K]^T).  A/W dtype = dt (f32 or bf16); residual f32; out f32|bf16.
 // m_dev (optional, device int32): the real row count when M is only an upper bound (packed text rows); m_hint: a likely value of
 // it for the tile-height choice (never for correctness)
+bool gemm_wide_enabled();          // false under the CMH_GEMM_WIDE=0 diagnostic (gemm.hip)
 int launch_gemm(int dt, const void* A, const void* W, const float* bias, const float* residual,
                 void* out, int M, int N, int K, int epi, hipStream_t st, const int32_t* m_dev = nullptr, int m_hint = -1);
 // C = epilogue(alpha * colscale[n] * (A8 . W8^T)): OCP e4m3 operands [M,K] / [N,K] (K % 128 == 0, N % 256 == 0), f32 accumulate;

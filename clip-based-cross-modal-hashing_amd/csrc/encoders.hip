@@ -362,10 +362,10 @@ static int text_encode_impl(const cmh_text_weights* w, const int64_t* tokens, in
     CMH_CHECK_ARG(!key_padding_mask && !tokens_out && !taps, "text_encode_packed: pooled features only, no mask / taps");
     if ((rc = launch_text_pack_plan(tokens, B, L, t.seq, st))) return rc;
     seq_off = t.seq;
-    if (amax || d % 256 != 0) {
+    if (amax || d % 256 != 0 || !gemm_wide_enabled()) {
       // the calibration pass reduces over whole buffers on the host's row count, and widths that are not a multiple of 256 (the
-      // test-sized towers) run on the 128 x 128 fallback GEMMs, which take their row count from the host: these two alone read
-      // the count back (one synchronisation)
+      // test-sized towers) - or any width under the CMH_GEMM_WIDE=0 diagnostic - run on the 128 x 128 fallback GEMMs, which take
+      // their row count from the host: these alone read the count back (one synchronisation)
       int32_t total = 0;
       if (hipMemcpyAsync(&total, t.seq + B, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
         return fail(CMH_ERR_LAUNCH, "text_encode_packed: reading the packed row count failed");

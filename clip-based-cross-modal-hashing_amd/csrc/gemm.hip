@@ -235,6 +235,12 @@ static int gemm_impl_from_env() {
   return (e && !strcmp(e, "regstage")) ? 0 : 1;
 }
 
+// CMH_GEMM_WIDE=0 (A/B against round 1's 128 x 128 kernels): launches that do not need the wide kernel's epilogues avoid it
+bool gemm_wide_enabled() {
+  static const bool wide = []() { const char* e = getenv("CMH_GEMM_WIDE"); return !(e && !strcmp(e, "0")); }();
+  return wide;
+}
+
 int launch_gemm(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out,
                 int M, int N, int K, int epi, hipStream_t st, const int32_t* m_dev, int m_hint) {
   const int bk = dt == CMH_F32 ? 32 : 64;
@@ -249,11 +255,11 @@ int launch_gemm(int dt, const void* A, const void* W, const float* bias, const f
   const int total = (N / kTile) * ((M + kTile - 1) / kTile);
   const bool timed = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
   static const int impl = gemm_impl_from_env();
-  static const bool wide = []() { const char* e = getenv("CMH_GEMM_WIDE"); return !(e && !strcmp(e, "0")); }();
+  static const bool wide = gemm_wide_enabled();
   // the wide kernel's launch stamps the event pair with its own begin / end (gemm_wide_time_next); the fallback kernels are
   // bracketed by two recorded events; CMH_GEMM_PROF_BRACKET=1 brackets every launch (round 1-2's method, for comparison)
   static const bool bracket = []() { const char* e = getenv("CMH_GEMM_PROF_BRACKET"); return e && e[0] == '1'; }();
-  const bool takes_rows = !m_dev && gemm_rows_takes(M, N, K, epi);
+  const bool takes_rows = wide && !m_dev && gemm_rows_takes(M, N, K, epi);   // (it reproduces the wide kernel's bits: off with it)
   const bool takes_wide = !takes_rows && ((impl == 1 && wide && gemm_wide_supported(N)) || (epi & (EPI_RES_F16 | EPI_OUT_F16 | EPI_MUL_DQGELU | EPI_SAVE_PRE)));
   const bool self_timed = timed && (takes_wide || takes_rows) && !bracket;
   hipEvent_t ev0 = self_timed ? g_prof.ev[g_prof.used] : nullptr, ev1 = self_timed ? g_prof.ev[g_prof.used + 1] : nullptr;
