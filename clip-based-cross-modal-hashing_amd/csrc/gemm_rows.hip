@@ -1,4 +1,4 @@
-// GEMM for FEW ROWS (M <= 512): out[M,N] = epi(X[M,K].W[N,K]^T) on 64(m) x 64(n) tiles, one 256-thread workgroup per tile.
+// GEMM for FEW ROWS (M <= 2048; round 3 started with 512): out[M,N] = epi(X[M,K].W[N,K]^T) on 64(m) x 64(n) tiles, one 256-thread workgroup per tile.
 //
 // Why it exists.  The pooled-row tail of the towers (encoders.hip: run_block_pooled) multiplies B = 256 rows by the block's
 // weights: three GEMMs of M = 256 per tower and step.  On the wide kernel (gemm_wide.hip: 96..160 x 256 tiles, one persistent
@@ -199,7 +199,10 @@ static int g_rows_on = -1;   // cmh_set_gemm_rows: -1 = from the environment (CM
 bool gemm_rows_takes(int M, int N, int K, int epi) {
   static const bool env_off = []() { const char* e = getenv("CMH_GEMM_ROWS"); return e && e[0] == '0'; }();
   const bool off = g_rows_on < 0 ? env_off : g_rows_on == 0;
-  if (off || M > 512 || N % rT != 0) return false;
+  // up to 2048 rows: a 1 600-row operand (batch 32 of the image tower, configs[0]) has 51..204 wide tiles for 256 CUs; on 64 x 64
+  // tiles the same launch fills the chip (configs[0]: validation -10 %, training step -1..3 %; CMH_GEMM_ROWS_MAX_M to compare)
+  static const int max_m = []() { const char* e = getenv("CMH_GEMM_ROWS_MAX_M"); return e ? atoi(e) : 2048; }();
+  if (off || M > max_m || N % rT != 0) return false;
   if (epi & (EPI_MUL_DQGELU | EPI_SCALE | EPI_OUT_FP8 | EPI_SAVE_PRE | 256 | 512)) return false;
   if ((epi & EPI_OUT_F16) && (epi & EPI_OUT_BF16)) return false;
   (void)K;

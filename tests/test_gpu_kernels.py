@@ -77,7 +77,7 @@ def test_gemm_wide_tile_variants(M, N, K):
         Nn.gemm_tuning(100, -1)
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 768, 768), (256, 3072, 768), (256, 768, 3072), (256, 512, 2048), (200, 512, 512), (37, 1536, 512), (512, 128, 64)])
+@pytest.mark.parametrize("M,N,K", [(256, 768, 768), (256, 3072, 768), (256, 768, 3072), (256, 512, 2048), (200, 512, 512), (37, 1536, 512), (512, 128, 64), (1600, 768, 768), (2048, 2304, 768)])
 @pytest.mark.parametrize("mode", ["bf16", "f32"])
 def test_gemm_rows_kernel_gives_the_wide_kernels_bits(M, N, K, mode):
     """csrc/gemm_rows.hip (few rows, 64 x 64 tiles) against the wide / 128 x 128 kernels on the same operands: identical bits
