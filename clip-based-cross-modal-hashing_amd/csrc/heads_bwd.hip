@@ -150,11 +150,19 @@ __global__ __launch_bounds__(64) void hyp_rows_kernel(const float* __restrict__ 
   }
   if (alpha > 0.f && cnt[2] > 0.f && multi[b]) {
     const float w = alpha / cnt[2];
-    for (int j = 0; j < B; ++j) {
-      if (!multi[j]) continue;
-      float ll = 0.f;
-      for (int c = lane; c < C; c += 64) ll = fmaf(label[static_cast<size_t>(b) * C + c], label[static_cast<size_t>(j) * C + c], ll);
-      if (wsum(ll) != 0.f) continue;
+    // which j pair with b: 64 candidates at a time, one per lane (a butterfly per candidate made this the longest part of the kernel:
+    // 161 us at batch 256); the qualifying ones are then visited in ascending j, as before - same sums, same order
+    for (int j0 = 0; j0 < B; j0 += 64) {
+      bool pairs = false;
+      if (j0 + lane < B && multi[j0 + lane]) {
+        float ll = 0.f;
+        for (int c = 0; c < C; ++c) ll = fmaf(label[static_cast<size_t>(b) * C + c], label[static_cast<size_t>(j0 + lane) * C + c], ll);
+        pairs = ll == 0.f;
+      }
+      unsigned long long todo = __ballot(pairs);
+    while (todo) {
+      const int j = j0 + __builtin_ctzll(todo);
+      todo &= todo - 1;
       float xj[KV], yj[KV], sx = 0.f, st = 0.f, sxt = 0.f, stx = 0.f;
 #pragma unroll
       for (int v = 0; v < KV; ++v) {
@@ -170,6 +178,7 @@ __global__ __launch_bounds__(64) void hyp_rows_kernel(const float* __restrict__ 
         gx[v] = fmaf(a, xj[v], fmaf(cq, yj[v], gx[v]));
         gy[v] = fmaf(bq, yj[v], fmaf(dq, xj[v], gy[v]));
       }
+    }
     }
   }
   // through F.normalize: d a = (g - an (an . g)) / max(||a||, eps)
@@ -189,18 +198,22 @@ __global__ __launch_bounds__(64) void hyp_rows_kernel(const float* __restrict__ 
 }
 
 // One wave per proxy c: dpn[c] = sum_b G_x[b,c] xn[b] + G_t[b,c] yn[b], then through the normalisation
+// (four waves per proxy, a quarter of the batch each, partial rows added in wave order: one wave per proxy left the chip with C = 24
+// waves for a 256-long chain of butterflies, 103 us)
 template <int KV>
-__global__ __launch_bounds__(64) void hyp_proxy_kernel(const float* __restrict__ xn, const float* __restrict__ yn,
+__global__ __launch_bounds__(256) void hyp_proxy_kernel(const float* __restrict__ xn, const float* __restrict__ yn,
                                                        const float* __restrict__ pn, const float* __restrict__ np_,
                                                        const float* __restrict__ label, const float* __restrict__ cnt, int B, int K,
                                                        int C, float thr, const float* __restrict__ dloss, float* __restrict__ dp) {
-  const int c = blockIdx.x, lane = threadIdx.x;
+  __shared__ float part[4][64 * KV];
+  const int c = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const float up = dloss ? dloss[0] : 1.f;
   const float invP = 1.f / cnt[0], invN = 1.f / cnt[1];
   float pc[KV], g[KV];
 #pragma unroll
   for (int v = 0; v < KV; ++v) { const int k = lane + 64 * v; pc[v] = k < K ? pn[static_cast<size_t>(c) * K + k] : 0.f; g[v] = 0.f; }
-  for (int b = 0; b < B; ++b) {
+  const int per = (B + 3) / 4, b0 = wid * per, b1 = b0 + per < B ? b0 + per : B;
+  for (int b = b0; b < b1; ++b) {
     float xb[KV], yb[KV], cx = 0.f, ct = 0.f;
 #pragma unroll
     for (int v = 0; v < KV; ++v) {
@@ -217,6 +230,12 @@ __global__ __launch_bounds__(64) void hyp_proxy_kernel(const float* __restrict__
 #pragma unroll
     for (int v = 0; v < KV; ++v) g[v] = fmaf(wx, xb[v], fmaf(wt, yb[v], g[v]));
   }
+#pragma unroll
+  for (int v = 0; v < KV; ++v) part[wid][lane + 64 * v] = g[v];
+  __syncthreads();
+  if (wid != 0) return;
+#pragma unroll
+  for (int v = 0; v < KV; ++v) g[v] = (part[0][lane + 64 * v] + part[1][lane + 64 * v]) + (part[2][lane + 64 * v] + part[3][lane + 64 * v]);
   float pg = 0.f;
 #pragma unroll
   for (int v = 0; v < KV; ++v) pg = fmaf(pc[v], g[v], pg);
@@ -583,7 +602,7 @@ extern "C" int cmh_dsph_hyp_loss_backward(const float* x, const float* y, const 
   do {                                                                                                                          \
     hipLaunchKernelGGL(hyp_rows_kernel<KV>, dim3(B), dim3(64), 0, st, xn, yn, pn, nx, ny, label, multi, cnt, B, K, C, threshold, alpha, \
                        dloss, dx, dy);                                                                                          \
-    hipLaunchKernelGGL(hyp_proxy_kernel<KV>, dim3(C), dim3(64), 0, st, xn, yn, pn, np_, label, cnt, B, K, C, threshold, dloss,    \
+    hipLaunchKernelGGL(hyp_proxy_kernel<KV>, dim3(C), dim3(256), 0, st, xn, yn, pn, np_, label, cnt, B, K, C, threshold, dloss,    \
                        dproxies);                                                                                               \
   } while (0)
   if (K <= 64) HYP_BWD(1);
