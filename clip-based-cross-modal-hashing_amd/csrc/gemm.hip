@@ -216,6 +216,8 @@ void gemm_wide_time_next(hipEvent_t start, hipEvent_t stop);             // gemm
 bool gemm_rows_takes(int M, int N, int K, int epi);                      // gemm_rows.hip: few rows (M <= 512), 64 x 64 tiles
 int launch_gemm_rows(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out, int M, int N, int K,
                      int epi, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+int launch_gemm_rows_fp8(const void* A, const void* W, const float* colscale, float alpha, const float* bias, const float* residual,
+                         void* out, float oscale, int M, int N, int K, int epi, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out,
                      int M, int N, int K, int epi, hipStream_t st, const float* colscale = nullptr, float alpha = 1.f,
                      float oscale = 1.f, const int32_t* m_dev = nullptr, int m_hint = -1);
@@ -310,15 +312,22 @@ int launch_gemm_fp8(const void* A8, const void* W8, const float* colscale, float
   const int okinds = ((epi & EPI_OUT_BF16) ? 1 : 0) + ((epi & EPI_OUT_F16) ? 1 : 0) + ((epi & EPI_OUT_FP8) ? 1 : 0);
   CMH_CHECK_ARG(okinds <= 1, "gemm_fp8: one output type at a time");
   const bool timed = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
-  if (timed) gemm_wide_time_next(g_prof.ev[g_prof.used], g_prof.ev[g_prof.used + 1]);
-  const int rc = launch_gemm_wide(CMH_FP8, A8, W8, bias, residual, out, M, N, K, epi | EPI_SCALE, st, colscale, alpha, oscale, m_dev, m_hint);
-  gemm_wide_time_next(nullptr, nullptr);
-  if (rc) return rc;
+  const bool takes_rows = gemm_wide_enabled() && !m_dev && gemm_rows_takes(M, N, K, epi | EPI_SCALE);   // few rows: 64 x 64 tiles, the same bits
+  if (takes_rows) {
+    const int rc = launch_gemm_rows_fp8(A8, W8, colscale, alpha, bias, residual, out, oscale, M, N, K, epi | EPI_SCALE, st,
+                                        timed ? g_prof.ev[g_prof.used] : nullptr, timed ? g_prof.ev[g_prof.used + 1] : nullptr);
+    if (rc) return rc;
+  } else {
+    if (timed) gemm_wide_time_next(g_prof.ev[g_prof.used], g_prof.ev[g_prof.used + 1]);
+    const int rc = launch_gemm_wide(CMH_FP8, A8, W8, bias, residual, out, M, N, K, epi | EPI_SCALE, st, colscale, alpha, oscale, m_dev, m_hint);
+    gemm_wide_time_next(nullptr, nullptr);
+    if (rc) return rc;
+  }
   if (timed) {
     const int Mr = prof_real_rows(M, m_dev, st);
     g_prof.flops.push_back(2.0 * Mr * static_cast<double>(N) * K);
     g_prof.dims.push_back({Mr, N, K, epi | EPI_SCALE});
-    g_prof.kind.push_back(0);
+    g_prof.kind.push_back(takes_rows ? 1 : 0);
     g_prof.used += 2;
   }
   CMH_CHECK_LAUNCH("gemm_fp8");

@@ -12,7 +12,8 @@
 // operations in the same order (residual pre-loaded into the accumulator when the wide kernel would: no activation, <= 16 K-steps),
 // so the pooled-row tail stays bit-identical to the full-size path (tests/test_gpu_clip.py::
 // test_pooled_rows_through_the_last_block_are_bit_identical).  Epilogues: bias, QuickGELU / GELU / ReLU, f32 or fp16 residual,
-// f32 / bf16 / fp16 output; everything else (fp8, EPI_MUL_DQGELU, EPI_SAVE_PRE) stays on the wide kernel.
+// f32 / bf16 / fp16 output, and the fp8 mode's e4m3 operands with scale + bias, fp16 / bf16 / e4m3 output; EPI_MUL_DQGELU and
+// EPI_SAVE_PRE stay on the wide kernel.
 #include <hip/hip_ext.h>
 
 #include <cstdlib>
@@ -39,13 +40,16 @@ __device__ __forceinline__ float r_quick_gelu(float v) {
 typedef const __attribute__((address_space(1))) void* r_gptr_t;
 typedef __attribute__((address_space(3))) void* r_lptr_t;
 
-template <bool F32>
+struct RowsScales { const float* colscale; float alpha, oscale; };   // fp8: acc * (alpha * colscale[n]) + bias; e4m3 output of v * oscale
+
+template <int DT>   // operands: 0 f32, 1 bf16, 2 OCP e4m3 (the wide kernel's fp8 K-step: one scaled MFMA of 128 k per fragment pair)
 __global__ __launch_bounds__(256) void gemm_rows_kernel(const char* __restrict__ X, const char* __restrict__ W,
                                                         const float* __restrict__ bias, const float* residual, void* out, int M, int N,
-                                                        int K, int epi) {
+                                                        int K, int epi, RowsScales sc) {
+  constexpr bool F32 = DT == 0, FP8 = DT == 2;
   __shared__ __attribute__((aligned(1024))) char lds[rStages * 2 * rHalf];   // [stage][0 = W, 1 = X][64 rows x 128 B]
 
-  constexpr int ELT = F32 ? 4 : 2;
+  constexpr int ELT = F32 ? 4 : (FP8 ? 1 : 2);
   constexpr int BK = rRowBytes / ELT;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const char* __restrict__
     }
   };
   // the wide kernel's rule (gemm_wide.hip: res_first): short K without an activation starts from the residual tile
-  const bool res_first = (epi & EPI_RESIDUAL) && !(epi & (EPI_QUICKGELU | EPI_GELU | EPI_RELU)) && nk <= 16;
+  const bool res_first = (epi & EPI_RESIDUAL) && !(epi & (EPI_QUICKGELU | EPI_GELU | EPI_RELU | EPI_SCALE)) && nk <= 16;
   if (res_first) add_residual();
 
   // LDS-DMA: a stage = 8 W pieces + 8 X pieces of 1 KiB (8 rows each); wave w moves pieces 2w, 2w+1 of both operands.
@@ -124,6 +128,28 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const char* __restrict__
     if (kt + 3 < nk) stage(kt + 3);
     const char* tW = lds + (kt & (rStages - 1)) * 2 * rHalf;
     const char* tX = tW + rHalf;
+    if constexpr (FP8) {
+      // both 16-byte halves of a lane's 32 k (chunks fq and fq + 4, as in the wide kernel) form one 8-register operand
+      typedef __attribute__((ext_vector_type(8))) int r_i32x8_t;
+      r_i32x8_t fw8[2], fx8[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const r_u32x4_t w0 = *reinterpret_cast<const r_u32x4_t*>(tW + r_swz(wn * 32 + t * 16 + frow, fq));
+        const r_u32x4_t w1 = *reinterpret_cast<const r_u32x4_t*>(tW + r_swz(wn * 32 + t * 16 + frow, fq + 4));
+        const r_u32x4_t x0 = *reinterpret_cast<const r_u32x4_t*>(tX + r_swz(wm * 32 + t * 16 + frow, fq));
+        const r_u32x4_t x1 = *reinterpret_cast<const r_u32x4_t*>(tX + r_swz(wm * 32 + t * 16 + frow, fq + 4));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          fw8[t][j] = static_cast<int>(w0[j]); fw8[t][4 + j] = static_cast<int>(w1[j]);
+          fx8[t][j] = static_cast<int>(x0[j]); fx8[t][4 + j] = static_cast<int>(x1[j]);
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw8[a], fx8[b], acc[a][b], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    } else
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int chunk = ks * 4 + fq;
@@ -150,7 +176,16 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const char* __restrict__
   }
 
   // ---- epilogue: the wide kernel's operations in the wide kernel's order ----
-  if (epi & EPI_BIAS) {
+  if (FP8 && (epi & EPI_SCALE)) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const r_f32x4_t cs = *reinterpret_cast<const r_f32x4_t*>(sc.colscale + n0 + wn * 32 + a * 16 + fq * 4) * sc.alpha;
+      const r_f32x4_t bv = (epi & EPI_BIAS) ? *reinterpret_cast<const r_f32x4_t*>(bias + n0 + wn * 32 + a * 16 + fq * 4)
+                                            : r_f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = acc[a][b] * cs + bv;
+    }
+  } else if (epi & EPI_BIAS) {
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       const r_f32x4_t bv = *reinterpret_cast<const r_f32x4_t*>(bias + n0 + wn * 32 + a * 16 + fq * 4);
@@ -183,6 +218,14 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const char* __restrict__
     for (int a = 0; a < 2; ++a) {
       const size_t o = static_cast<size_t>(m) * N + n0 + wn * 32 + a * 16 + fq * 4;
       const r_f32x4_t v = acc[a][b];
+      if (FP8 && (epi & EPI_OUT_FP8)) {           // the wide kernel's conversion; a lane's 4 consecutive n are one dword
+        float q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[j] = fminf(fmaxf(v[j] * sc.oscale, -448.f), 448.f);
+        int w8 = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], 0, false);
+        w8 = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w8, true);
+        *reinterpret_cast<int*>(static_cast<char*>(out) + o) = w8;
+      } else
       if (epi & EPI_OUT_F16)
         *reinterpret_cast<uint2*>(static_cast<uint16_t*>(out) + o) = uint2{pack_f16x2(v[0], v[1]), pack_f16x2(v[2], v[3])};
       else if (epi & EPI_OUT_BF16)
@@ -203,7 +246,7 @@ bool gemm_rows_takes(int M, int N, int K, int epi) {
   // tiles the same launch fills the chip (configs[0]: validation -10 %, training step -1..3 %; CMH_GEMM_ROWS_MAX_M to compare)
   static const int max_m = []() { const char* e = getenv("CMH_GEMM_ROWS_MAX_M"); return e ? atoi(e) : 2048; }();
   if (off || M > max_m || N % rT != 0) return false;
-  if (epi & (EPI_MUL_DQGELU | EPI_SCALE | EPI_OUT_FP8 | EPI_SAVE_PRE | 256 | 512)) return false;
+  if (epi & (EPI_MUL_DQGELU | EPI_SAVE_PRE | 256 | 512)) return false;   // (EPI_SCALE / EPI_OUT_FP8: the e4m3 instantiation, launch_gemm_rows_fp8)
   if ((epi & EPI_OUT_F16) && (epi & EPI_OUT_BF16)) return false;
   (void)K;
   return true;
@@ -216,12 +259,21 @@ int launch_gemm_rows(int dt, const void* A, const void* W, const float* bias, co
   do {                                                                                                                        \
     if (ev0)                                                                                                                  \
       hipExtLaunchKernelGGL(KERNEL, dim3(grid), dim3(256), 0, st, ev0, ev1, 0, static_cast<const char*>(A),                    \
-                            static_cast<const char*>(W), bias, residual, out, M, N, K, epi);                                  \
+                            static_cast<const char*>(W), bias, residual, out, M, N, K, epi, sc);                              \
     else                                                                                                                      \
       hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(256), 0, st, static_cast<const char*>(A), static_cast<const char*>(W), bias, \
-                         residual, out, M, N, K, epi);                                                                        \
+                         residual, out, M, N, K, epi, sc);                                                                    \
   } while (0)
-  if (dt == CMH_F32) R_GO(gemm_rows_kernel<true>); else R_GO(gemm_rows_kernel<false>);
+  const RowsScales sc{nullptr, 1.f, 1.f};
+  if (dt == CMH_F32) R_GO(gemm_rows_kernel<0>); else R_GO(gemm_rows_kernel<1>);
+  return 0;
+}
+
+int launch_gemm_rows_fp8(const void* A, const void* W, const float* colscale, float alpha, const float* bias, const float* residual,
+                         void* out, float oscale, int M, int N, int K, int epi, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+  const int grid = (N / rT) * ((M + rT - 1) / rT);
+  const RowsScales sc{colscale, alpha, oscale};
+  R_GO(gemm_rows_kernel<2>);
 #undef R_GO
   return 0;
 }

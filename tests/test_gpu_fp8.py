@@ -239,3 +239,32 @@ def test_amax_reports_nan_as_inf_and_stale_scales_recalibrate():
             clip.encode_image(img)
         assert any("re-calibrating" in str(r.message) for r in rec)
         assert clip._fp8_amax["vit"] != first
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 768, 768), (256, 3072, 768), (256, 768, 3072), (200, 512, 2048), (1600, 1536, 512)])
+def test_fp8_gemm_rows_kernel_gives_the_wide_kernels_bits(M, N, K):
+    """The few-row kernel's e4m3 instantiation (csrc/gemm_rows.hip, the fp8 mode's pooled-row tail) against the wide kernel on the same
+    operands: identical bits for plain, bias + QuickGELU -> bf16, bias + fp16 residual -> fp16 and bias + QuickGELU -> e4m3 outputs."""
+    import cmh_native as Nn
+    g = torch.Generator().manual_seed(M + 2 * N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * (torch.rand(N, 1, generator=g) + 0.1) * K ** -0.5
+    b = torch.randn(N, generator=g).to(DEV)
+    r = torch.randn(M, N, generator=g).half().to(DEV)
+    ax = float(x.abs().max()) / 448
+    x8 = Nn.fp8_quantize(x.to(DEV), ax)
+    w8, cs = Nn.fp8_quantize_weight(w.to(DEV))
+    outs = {}
+    try:
+        for on in (1, 0):
+            Nn.set_gemm_rows(on)
+            outs[on] = (Nn.linear_gemm_fp8(x8, w8, cs, ax), Nn.linear_gemm_fp8(x8, w8, cs, ax, bias=b, quickgelu=True, out="bf16"),
+                        Nn.linear_gemm_fp8(x8, w8, cs, ax, bias=b, residual=r, out="f16"),
+                        Nn.linear_gemm_fp8(x8, w8, cs, ax, bias=b, quickgelu=True, out="fp8", out_scale=0.05))
+    finally:
+        Nn.set_gemm_rows(-1)
+    for i, (a_, c_) in enumerate(zip(outs[1], outs[0])):
+        assert torch.equal(a_.view(torch.uint8) if a_.dtype not in (torch.float32, torch.float16, torch.bfloat16) else a_,
+                           c_.view(torch.uint8) if c_.dtype not in (torch.float32, torch.float16, torch.bfloat16) else c_), i
+    base = Nn.fp8_dequantize(x8, ax).cpu().double() @ (Nn.fp8_dequantize(w8).cpu() * cs.cpu()[:, None]).double().t()
+    torch.testing.assert_close(outs[1][0].cpu().double(), base, rtol=1e-4, atol=1e-4 * float(base.abs().max()))
