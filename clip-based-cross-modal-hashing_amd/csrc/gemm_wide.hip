@@ -403,27 +403,56 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   // acc += residual tile at (m0, n0): f32 rows, or (EPI_RES_F16) fp16 rows read in the 16-byte layout of the packed output
   // (lane = one row x 8 consecutive n) and brought back to the accumulator layout by the same v_permlane16_swap.
   auto add_residual = [&](int m0, int n0) __attribute__((always_inline)) {
+    if constexpr (FP8 && MF == 5) {
+      // fp8, 160 rows (fp16 residual stream only): two groups of row fragments, 24 + 16 registers in flight instead of 40 - still
+      // every load before any store.  With all 40 (and the f32 path's 80) the allocator spills long-lived values whose reloads land
+      // inside the K loop (tools/asm_loop_scratch.py)
+      const uint16_t* res16 = reinterpret_cast<const uint16_t*>(residual);
+      const int col = n0 + wn * 64 + (fq & 1) * 16 + (fq & 2) * 4;    // + 32*pair
+      constexpr int BG = 3;
+#pragma unroll
+      for (int bg = 0; bg < MF; bg += BG) {
+        w_u32x4_t r[2 * BG];
+#pragma unroll
+        for (int b = bg; b < bg + BG && b < MF; ++b) {
+          int m = m0 + wm * WR + b * 16 + frow;
+          m = m < M ? m : M - 1;
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr)
+            r[(b - bg) * 2 + pr] = *reinterpret_cast<const w_u32x4_t*>(res16 + static_cast<size_t>(m) * N + col + 32 * pr);
+        }
+#pragma unroll
+        for (int b = bg; b < bg + BG && b < MF; ++b) {
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            const w_u32x4_t q = r[(b - bg) * 2 + pr];
+            const w_u2_t s0 = __builtin_amdgcn_permlane16_swap(q[0], q[2], false, false);
+            const w_u2_t s1 = __builtin_amdgcn_permlane16_swap(q[1], q[3], false, false);
+            acc[2 * pr][b][0] += f16lo_to_f32(s0[0]); acc[2 * pr][b][1] += f16hi_to_f32(s0[0]);
+            acc[2 * pr][b][2] += f16lo_to_f32(s1[0]); acc[2 * pr][b][3] += f16hi_to_f32(s1[0]);
+            acc[2 * pr + 1][b][0] += f16lo_to_f32(s0[1]); acc[2 * pr + 1][b][1] += f16hi_to_f32(s0[1]);
+            acc[2 * pr + 1][b][2] += f16lo_to_f32(s1[1]); acc[2 * pr + 1][b][3] += f16hi_to_f32(s1[1]);
+          }
+        }
+      }
+    } else
     if (epi & EPI_RES_F16) {
       const uint16_t* res16 = reinterpret_cast<const uint16_t*>(residual);
       const int col = n0 + wn * 64 + (fq & 1) * 16 + (fq & 2) * 4;    // + 32*pair
-      // (fp8, 160 rows: two groups of row fragments, 24 + 16 registers in flight instead of 40 - still every load before any store)
-      constexpr int BG = (FP8 && MF == 5) ? 3 : MF;
+      w_u32x4_t r[NPEND];
 #pragma unroll
-      for (int bg = 0; bg < MF; bg += BG) {
-      w_u32x4_t r[2 * BG];
-#pragma unroll
-      for (int b = bg; b < bg + BG && b < MF; ++b) {
+      for (int b = 0; b < MF; ++b) {
         int m = m0 + wm * WR + b * 16 + frow;
         m = m < M ? m : M - 1;
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr)
-          r[(b - bg) * 2 + pr] = *reinterpret_cast<const w_u32x4_t*>(res16 + static_cast<size_t>(m) * N + col + 32 * pr);
+          r[b * 2 + pr] = *reinterpret_cast<const w_u32x4_t*>(res16 + static_cast<size_t>(m) * N + col + 32 * pr);
       }
 #pragma unroll
-      for (int b = bg; b < bg + BG && b < MF; ++b) {
+      for (int b = 0; b < MF; ++b) {
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
-          const w_u32x4_t q = r[(b - bg) * 2 + pr];
+          const w_u32x4_t q = r[b * 2 + pr];
           const w_u2_t s0 = __builtin_amdgcn_permlane16_swap(q[0], q[2], false, false);   // -> words 0 of tiles 2pr, 2pr+1
           const w_u2_t s1 = __builtin_amdgcn_permlane16_swap(q[1], q[3], false, false);   // -> words 1
           acc[2 * pr][b][0] += f16lo_to_f32(s0[0]); acc[2 * pr][b][1] += f16hi_to_f32(s0[0]);
@@ -432,8 +461,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
           acc[2 * pr + 1][b][2] += f16lo_to_f32(s1[1]); acc[2 * pr + 1][b][3] += f16hi_to_f32(s1[1]);
         }
       }
-      }
-    } else if constexpr (!FP8) {   // (the fp8 mode's residual stream is fp16; 80 more registers here push its 160-row variant into scratch)
+    } else if constexpr (!FP8) {   // (the fp8 mode's residual stream is fp16)
       w_f32x4_t rv[4][MF];
 #pragma unroll
       for (int b = 0; b < MF; ++b) {
@@ -521,19 +549,6 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
       }
     }
   };
-  // fp8, 160 rows: the 56 fragment registers of the NEXT tile's first K-step are not carried through the epilogue (with them, 80
-  // accumulators and the epilogue's own loads hipcc spills LDS-DMA offsets inside the K loop, behind vmcnt(0)): the last K-step of a
-  // tile reads nothing ahead and every tile starts with its own reads - one exposed LDS latency per tile.
-  constexpr bool kTileReads = false;   // (measured: scratch inside the K loop either way - kept as an experiment switch)
-  auto fp8_first_reads = [&](int buf) __attribute__((always_inline)) {
-    const uint32_t bo = static_cast<uint32_t>(buf) * STG;
-    const uint32_t w0 = aW + bo, w1 = (aW + bo) ^ 64u, x0 = aX + bo, x1 = (aX + bo) ^ 64u;
-    W_READ(f0w[0], w0, 0); W_READ(f1w[0], w1, 0); W_READ(f0w[1], w0, 2048); W_READ(f1w[1], w1, 2048);
-    W_READ(f0x[0], x0, 0); W_READ(f1x[0], x1, 0); W_READ(f0x[1], x0, 2048); W_READ(f1x[1], x1, 2048);
-    W_READ(f0x[2], x0, 4096); W_READ(f1x[2], x1, 4096);
-    if constexpr (MF >= 4) { W_READ(f0x[MF >= 4 ? 3 : 0], x0, 6144); W_READ(f1x[MF >= 4 ? 3 : 0], x1, 6144); }
-    if constexpr (MF == 5) { W_READ(f0x[MF - 1], x0, 8192); W_READ(f1x[MF - 1], x1, 8192); }
-  };
   if constexpr (TN) {
 #pragma unroll
     for (int a = 0; a < 4; ++a) { W_TR(h0w[a][0], tW[a][0], 0); W_TR(h0w[a][1], tW[a][1], 0); }
@@ -541,13 +556,77 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
     for (int b = 0; b < MF; ++b) { W_TR(h0x[b][0], tX[b][0], 0); W_TR(h0x[b][1], tX[b][1], 0); }
   } else if constexpr (FP8) {
     // fp8 K-step s starts with BOTH halves of W tiles 0,1 and of every X tile of stage s in (or on their way to) registers
-    // (160 rows: read at the top of every tile instead, see kTileReads)
-    if constexpr (!kTileReads) fp8_first_reads(0);
+    const uint32_t w0 = aW, w1 = aW ^ 64u, x0 = aX, x1 = aX ^ 64u;
+    W_READ(f0w[0], w0, 0); W_READ(f1w[0], w1, 0); W_READ(f0w[1], w0, 2048); W_READ(f1w[1], w1, 2048);
+    W_READ(f0x[0], x0, 0); W_READ(f1x[0], x1, 0); W_READ(f0x[1], x0, 2048); W_READ(f1x[1], x1, 2048);
+    W_READ(f0x[2], x0, 4096); W_READ(f1x[2], x1, 4096);
+    if constexpr (MF >= 4) { W_READ(f0x[MF >= 4 ? 3 : 0], x0, 6144); W_READ(f1x[MF >= 4 ? 3 : 0], x1, 6144); }
+    if constexpr (MF == 5) { W_READ(f0x[MF - 1], x0, 8192); W_READ(f1x[MF - 1], x1, 8192); }
   } else {
     load_frags(f0w, f0x, 0, 0);   // from here on F0 of K-step s+1 (also across tiles) is fetched in the second half of s
   }
-  auto fp8_step = [&](int kt, auto pf) __attribute__((always_inline)) {
-    constexpr bool PF = decltype(pf)::value;   // false: the last K-step of a tile when kTileReads (no reads ahead)
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    if (ti > 0) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < MF; ++b) acc[a][b] = w_f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (TN) {
+      if (sc.colsum) {
+        const int virt_c = range_lo + slot + ti * per_xcd_blocks;
+        int tm_c, tn_c;
+        tile_coords(virt_c - (virt_c / base_total) * base_total, tm_c, tn_c);
+        do_cs = tn_c == 0;
+        csacc = w_f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+
+    for (int kt = 0; kt < nk; ++kt) {
+      if constexpr (TN) {
+        // ---- TN K-step: the bf16 step below with every ds_read_b128 replaced by two transposing 8-byte reads ----------------
+        {
+          const uint32_t bo = static_cast<uint32_t>(cur) * STG;
+#pragma unroll
+          for (int a = 0; a < 4; ++a) { W_TR(h1w[a][0], tW[a][0] + bo, 16384); W_TR(h1w[a][1], tW[a][1] + bo, 16384); }
+#pragma unroll
+          for (int b = 0; b < MF; ++b) { W_TR(h1x[b][0], tX[b][0] + bo, 8192); W_TR(h1x[b][1], tX[b][1] + bo, 8192); }
+        }
+        W_WAIT_H(15, h0w, h0x);          // lgkmcnt has 4 bits: the 16 older reads (first half-step) and one of the new ones have landed
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(GB ? 0 : 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+          if constexpr (GB) { if (i % 3 == 0) issue_piece(i / 3); }
+          mfma_h(h0w[i / MF], h0x[i % MF], acc[i / MF][i % MF]);
+          if (i % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (do_cs) cs_mfma(h0x);
+        if constexpr (GB) issue_done();
+        __builtin_amdgcn_sched_barrier(0);
+        W_WAIT_H(0, h1w, h1x);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int nxt = cur == 2 ? 0 : cur + 1;
+        {
+          const uint32_t bo = static_cast<uint32_t>(nxt) * STG;
+          __builtin_amdgcn_s_setprio(GB ? 1 : 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < NM; ++i) {
+            if constexpr (!GB) { if (i % 3 == 0) issue_piece(i / 3); }
+            if (i < 8) W_TR(h0w[i >> 1][i & 1], tW[i >> 1][i & 1] + bo, 0);
+            else W_TR(h0x[(i - 8) >> 1][i & 1], tX[(i - 8) >> 1][i & 1] + bo, 0);
+            mfma_h(h1w[i / MF], h1x[i % MF], acc[i / MF][i % MF]);
+            if (i % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+          }
+          if (do_cs) cs_mfma(h1x);
+          if constexpr (!GB) issue_done();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+      } else if constexpr (FP8) {
         // ---- fp8 K-step: 4*MF scaled MFMAs of 128 k, 2*MF per half; same barrier / DMA / store protocol as below ---------
         constexpr int NM2 = 2 * MF;                    // MFMAs per half
         constexpr int NP = MF == 5 ? 7 : 6;            // LDS-DMA pieces per wave and stage
@@ -602,7 +681,6 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
 #pragma unroll
               for (int pc = 0; pc < NP; ++pc) if (i == pc * NM2 / NP) issue_piece(pc);
             }
-            if constexpr (PF) {
             if (i == 0) W_READ(f0w[0], nW0, 0);
             if (i == 1) W_READ(f1w[0], nW1, 0);
             if (i == 2) { W_READ(f0w[1], nW0, 2048); W_READ(f0x[0], nX0, 0); }
@@ -611,86 +689,17 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
             if (i == 5) W_READ(f1x[1], nX1, 2048);
             if constexpr (MF >= 4) { if (i == 6) W_READ(f0x[2], nX0, 4096); if (i == 7) W_READ(f1x[2], nX1, 4096); }
             if constexpr (MF == 5) { if (i == 8) W_READ(f0x[MF > 3 ? 3 : 0], nX0, 6144); if (i == 9) W_READ(f1x[MF > 3 ? 3 : 0], nX1, 6144); }
-            }
             mfma8(f0w[2 + (i & 1)], f1w[2 + (i & 1)], f0x[i >> 1], f1x[i >> 1], acc[2 + (i & 1)][i >> 1]);
             __builtin_amdgcn_sched_barrier(0);
           }
           // the last X tile's registers are free only now
-          if constexpr (PF) {
           if constexpr (MF == 3) { W_READ(f0x[2], nX0, 4096); W_READ(f1x[2], nX1, 4096); }
           if constexpr (MF == 4) { W_READ(f0x[MF > 3 ? 3 : 0], nX0, 6144); W_READ(f1x[MF > 3 ? 3 : 0], nX1, 6144); }
           if constexpr (MF == 5) { W_READ(f0x[MF - 1], nX0, 8192); W_READ(f1x[MF - 1], nX1, 8192); }
-          } else { (void)nW0; (void)nW1; (void)nX0; (void)nX1; }
           if constexpr (!GB) issue_done();
         }
         __builtin_amdgcn_sched_barrier(0);
         cur = nxt;
-  };
-  for (int ti = 0; ti < my_tiles; ++ti) {
-    if (ti > 0) {
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < MF; ++b) acc[a][b] = w_f32x4_t{0.f, 0.f, 0.f, 0.f};
-    }
-    if constexpr (TN) {
-      if (sc.colsum) {
-        const int virt_c = range_lo + slot + ti * per_xcd_blocks;
-        int tm_c, tn_c;
-        tile_coords(virt_c - (virt_c / base_total) * base_total, tm_c, tn_c);
-        do_cs = tn_c == 0;
-        csacc = w_f32x4_t{0.f, 0.f, 0.f, 0.f};
-      }
-    }
-
-    if constexpr (kTileReads) fp8_first_reads(cur);
-    const int nk_loop = kTileReads ? nk - 1 : nk;   // (kTileReads: the tile's last K-step follows the loop, without reads ahead)
-    for (int kt = 0; kt < nk_loop; ++kt) {
-      if constexpr (TN) {
-        // ---- TN K-step: the bf16 step below with every ds_read_b128 replaced by two transposing 8-byte reads ----------------
-        {
-          const uint32_t bo = static_cast<uint32_t>(cur) * STG;
-#pragma unroll
-          for (int a = 0; a < 4; ++a) { W_TR(h1w[a][0], tW[a][0] + bo, 16384); W_TR(h1w[a][1], tW[a][1] + bo, 16384); }
-#pragma unroll
-          for (int b = 0; b < MF; ++b) { W_TR(h1x[b][0], tX[b][0] + bo, 8192); W_TR(h1x[b][1], tX[b][1] + bo, 8192); }
-        }
-        W_WAIT_H(15, h0w, h0x);          // lgkmcnt has 4 bits: the 16 older reads (first half-step) and one of the new ones have landed
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(GB ? 0 : 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < NM; ++i) {
-          if constexpr (GB) { if (i % 3 == 0) issue_piece(i / 3); }
-          mfma_h(h0w[i / MF], h0x[i % MF], acc[i / MF][i % MF]);
-          if (i % 3 == 2) __builtin_amdgcn_sched_barrier(0);
-        }
-        if (do_cs) cs_mfma(h0x);
-        if constexpr (GB) issue_done();
-        __builtin_amdgcn_sched_barrier(0);
-        W_WAIT_H(0, h1w, h1x);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const int nxt = cur == 2 ? 0 : cur + 1;
-        {
-          const uint32_t bo = static_cast<uint32_t>(nxt) * STG;
-          __builtin_amdgcn_s_setprio(GB ? 1 : 0);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int i = 0; i < NM; ++i) {
-            if constexpr (!GB) { if (i % 3 == 0) issue_piece(i / 3); }
-            if (i < 8) W_TR(h0w[i >> 1][i & 1], tW[i >> 1][i & 1] + bo, 0);
-            else W_TR(h0x[(i - 8) >> 1][i & 1], tX[(i - 8) >> 1][i & 1] + bo, 0);
-            mfma_h(h1w[i / MF], h1x[i % MF], acc[i / MF][i % MF]);
-            if (i % 3 == 2) __builtin_amdgcn_sched_barrier(0);
-          }
-          if (do_cs) cs_mfma(h1x);
-          if constexpr (!GB) issue_done();
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        cur = nxt;
-      } else if constexpr (FP8) {
-        fp8_step(kt, std::true_type{});
       } else {
       W_STAMP(0);   // second half of the previous K-step (+ epilogue at kt = 0)
 #ifndef W_ABL_NOREAD
@@ -768,7 +777,6 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
       cur = nxt;
       }
     }
-    if constexpr (kTileReads) fp8_step(nk - 1, std::false_type{});
     pend_valid = false;   // sps * nk >= 10: every deferred store of the previous tile has been issued
     if (ti == 0) W_TL(2);              // first tile's K loop done
     if (ti == my_tiles - 1) W_TL(3);   // last tile's K loop done
@@ -928,7 +936,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
         pend[b][0] = q01[0]; pend[b][1] = q01[1]; pend[b][2] = q23[0]; pend[b][3] = q23[1];
       }
       pend_ptr = static_cast<char*>(out) + static_cast<size_t>(m0 + wm * WR + frow) * N + n0 + wn * 64 + fq * 16;
-      if (DEFER && full && ti + 1 < my_tiles && !(epi & (256 | 512))) {
+      if (full && ti + 1 < my_tiles && !(epi & (256 | 512))) {
         pend_valid = true;
       } else if (!(epi & 256)) {
 #pragma unroll
@@ -960,16 +968,9 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
           const w_u2_t s0 = __builtin_amdgcn_permlane16_swap(lo[0], hi[0], false, false);
           const w_u2_t s1 = __builtin_amdgcn_permlane16_swap(lo[1], hi[1], false, false);
           pend[b * 2 + pr][0] = s0[0]; pend[b * 2 + pr][1] = s1[0]; pend[b * 2 + pr][2] = s0[1]; pend[b * 2 + pr][3] = s1[1];
-          if constexpr (!DEFER) {
-            if (!(epi & 256) && m0 + wm * WR + b * 16 + frow < M)
-              w_store16(static_cast<char*>(out) + (static_cast<size_t>(m0 + wm * WR + frow) * N + col) * 2 + b * row16 + pr * 64, pend[b * 2 + pr]);
-          }
         }
       }
       pend_ptr = static_cast<char*>(out) + (static_cast<size_t>(m0 + wm * WR + frow) * N + col) * 2;
-      if constexpr (!DEFER) {
-        // (stored above)
-      } else
       if (DEFER && full && ti + 1 < my_tiles && !(epi & (256 | 512))) {   // 512 = ablation: store from the epilogue
         pend_valid = true;                       // leave under the next tile's MFMAs
       } else if (!(epi & 256)) {                 // 256 = timing-only ablation: skip stores
@@ -1149,10 +1150,10 @@ int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, co
   const int forced = g_force_rows;
   // fp8: 128 rows at most - except with e4m3 OUTPUT (the c_fc launches).  The 160-row variant needs 56 fragment registers live
   // across the epilogue (both 16-byte halves of the next K-step's operands, as aligned 8-register MFMA operands) next to 80
-  // accumulators and the pending stores: with 16-bit or f32 outputs (10 pending stores, the residual path) hipcc spills inside the
-  // K loop (scratch reloads with vmcnt(0) drain the LDS-DMA pipeline: measured 64 us against bf16's 46 on QKV); with e4m3 outputs
-  // (5 pending stores) and the epilogue paths fp8 never takes compiled out, the K loop is free of scratch
-  // (tools/asm_loop_scratch.py: every variant a launch can select must show no scratch at loop depth 2).
+  // accumulators and the pending stores: with 16-bit or f32 outputs (10 pending stores) hipcc spills inside the K loop (scratch
+  // reloads with vmcnt(0) drain the LDS-DMA pipeline: measured 64 us against bf16's 46 on QKV); with e4m3 outputs (5 pending
+  // stores) and the epilogue paths fp8 never takes compiled out, the K loop is free of scratch (tools/asm_loop_scratch.py: every
+  // variant a launch can select must show no scratch at loop depth 2).
   int mf = dt == CMH_FP8 && !(epi & EPI_OUT_FP8) ? 4 : 5;
   if (mf == 5 && cost(4) < cost(mf)) mf = 4;
   if (cost(3) < cost(mf)) mf = 3;
