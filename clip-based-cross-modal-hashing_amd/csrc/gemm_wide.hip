@@ -120,7 +120,10 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   constexpr int WR = 16 * MF;                        // rows per wave
   constexpr int STG = wWBytes + BMt * wRowBytes;     // bytes per stage: 52 KB (MF = 5) or 48 KB (MF = 4)
   constexpr int XP = BMt / 8;                        // X pieces of 1 KiB per stage: 20 or 16
-  constexpr int NPEND = OUT8 ? MF : 2 * MF;          // deferred 16-byte stores per lane per tile
+  constexpr int NPEND = OUT8 ? MF : 2 * MF;          // 16-byte stores per lane per tile
+  // how many of them wait under the next tile's MFMAs (fp8, 160 rows, 16-bit output: only 4 - with all 10 pending next to 72 fragment
+  // registers and 80 accumulators the allocator spills inside the K loop; the other 6 leave from the epilogue)
+  constexpr int NDEFER = (FP8 && MF == 5 && OK == 1) ? 4 : NPEND;
   constexpr int NM = 4 * MF;                         // MFMAs per 32-deep half-step
   static_assert(MF >= 3 && MF <= 5, "wave layout: 2(m) x 4(n) waves of MF x 4 fragments");
   static_assert(!TN || (DT == 1 && OK == 0 && MF == 4), "TN: bf16 operands, f32 (split-K) output, 128-row tile");
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   char* pend_ptr = nullptr;            // &out[(m0 + wm*WR + frow) * N + col] of the pending tile
   constexpr int OEL = OUT8 ? 1 : 2;    // bytes per output element of the packed store paths
   const size_t row16 = static_cast<size_t>(16) * N * OEL;   // bytes between the 16-row fragments of a wave
-  const int sps = (NPEND + nk - 1) / nk;   // stores per K-step so that all 10 leave within one tile's K loop
+  const int sps = (NDEFER + nk - 1) / nk;   // stores per K-step so that all of them leave within one tile's K loop
   auto store_pending = [&](int idx) {
     switch (idx) {   // compile-time register choice per case: no dynamically indexed vector arrays (they would go to scratch)
 #define W_ST(j) case j: if constexpr (j < NPEND) w_store16(pend_ptr + (OUT8 ? j : j / 2) * row16 + (OUT8 ? 0 : (j % 2) * 64), pend[j < NPEND ? j : 0]); break;
@@ -367,7 +370,8 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   // the prologue instead of sitting exposed in the epilogue (residual GEMMs have <= 1 tile per workgroup: N = 512 / 768).
   // Measured inside the encoder: K = 512 / 768: -2.9 / -1.6 us per launch; K = 2048 / 3072: +0.3 / +2.3 us (the 40 MB burst
   // delays the first stage and a long K loop has no trouble hiding the epilogue's loads behind other workgroups) -> nk <= 16.
-  const bool res_first = (epi & EPI_RESIDUAL) && !(epi & (EPI_QUICKGELU | EPI_GELU | EPI_RELU | EPI_SCALE)) && nk <= 16;
+  // (fp8 launches always carry EPI_SCALE: never there - said at compile time, so that the prologue holds no residual code)
+  const bool res_first = !FP8 && (epi & EPI_RESIDUAL) && !(epi & (EPI_QUICKGELU | EPI_GELU | EPI_RELU | EPI_SCALE)) && nk <= 16;
   auto mfma = [&](const w_u32x4_t& fw, const w_u32x4_t& fx, w_f32x4_t& c) {
     if constexpr (FP8) {
       (void)fw; (void)fx; (void)c;   // the fp8 K-step multiplies whole 128-k rows: mfma8 below
@@ -635,7 +639,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
             if (pend_valid) {
               for (int j = 0; j < sps; ++j) {
                 const int idx = kt * sps + j;
-                if (idx < NPEND) { store_pending(idx); ++ns; }
+                if (idx < NDEFER) { store_pending(idx); ++ns; }
               }
             }
           }
@@ -714,7 +718,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
           if (pend_valid) {
             for (int j = 0; j < sps; ++j) {
               const int idx = kt * sps + j;
-              if (idx < NPEND) { store_pending(idx); ++ns; }
+              if (idx < NDEFER) { store_pending(idx); ++ns; }
             }
           }
         }
@@ -973,6 +977,9 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
       pend_ptr = static_cast<char*>(out) + (static_cast<size_t>(m0 + wm * WR + frow) * N + col) * 2;
       if (DEFER && full && ti + 1 < my_tiles && !(epi & (256 | 512))) {   // 512 = ablation: store from the epilogue
         pend_valid = true;                       // leave under the next tile's MFMAs
+#pragma unroll
+        for (int j = NDEFER; j < NPEND; ++j)     // (the part that does not wait; a full tile: every row exists)
+          w_store16(pend_ptr + (j / 2) * row16 + (j % 2) * 64, pend[j]);
       } else if (!(epi & 256)) {                 // 256 = timing-only ablation: skip stores
 #pragma unroll
         for (int j = 0; j < NPEND; ++j)
@@ -1148,16 +1155,20 @@ int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, co
     return static_cast<long long>((tiles + cus - 1) / cus) * (10 * mf + 6) * (nk + 4);
   };
   const int forced = g_force_rows;
-  // fp8: 128 rows at most - except with e4m3 OUTPUT (the c_fc launches).  The 160-row variant needs 56 fragment registers live
-  // across the epilogue (both 16-byte halves of the next K-step's operands, as aligned 8-register MFMA operands) next to 80
-  // accumulators and the pending stores: with 16-bit or f32 outputs (10 pending stores) hipcc spills inside the K loop (scratch
-  // reloads with vmcnt(0) drain the LDS-DMA pipeline: measured 64 us against bf16's 46 on QKV); with e4m3 outputs (5 pending
-  // stores) and the epilogue paths fp8 never takes compiled out, the K loop is free of scratch (tools/asm_loop_scratch.py: every
-  // variant a launch can select must show no scratch at loop depth 2).
+  // fp8: 160 rows by default only with e4m3 OUTPUT (the c_fc launches).  The 160-row variant needs 56 fragment registers live across the epilogue
+  // (both 16-byte halves of the next K-step's operands, as aligned 8-register MFMA operands) next to 80 accumulators and the pending
+  // stores; left alone hipcc spills inside the K loop (scratch reloads with vmcnt(0) drain the LDS-DMA pipeline: measured 64 us
+  // against bf16's 46 on QKV).  With the epilogue paths fp8 never takes compiled out, the residual loads in two groups and - for the
+  // 16-bit outputs - only 4 of the 10 stores deferred, the K loops of the e4m3- and 16-bit-output variants are free of scratch
+  // (tools/asm_loop_scratch.py: every variant a launch can select must show no scratch at loop depth 2).
+  // (the f32-output fp8 variant still spills in its K loop; the 16-bit-output one is loop-clean but pays 28 scratch instructions per
+  // tile in its epilogue: serialized GEMM time of an fp8 step -1.3 %, the overlapped step -1.5 % in pairs/s, A/B/A/B on one box - so
+  // it is taken only on request, CMH_GEMM_BM=160 / cmh_gemm_tuning)
+  const bool fp8_160 = epi & (EPI_OUT_FP8 | EPI_OUT_BF16 | EPI_OUT_F16);
   int mf = dt == CMH_FP8 && !(epi & EPI_OUT_FP8) ? 4 : 5;
   if (mf == 5 && cost(4) < cost(mf)) mf = 4;
   if (cost(3) < cost(mf)) mf = 3;
-  if (forced == 96 || forced == 128 || (forced == 160 && (dt != CMH_FP8 || (epi & EPI_OUT_FP8)))) mf = forced / 32;
+  if (forced == 96 || forced == 128 || (forced == 160 && (dt != CMH_FP8 || fp8_160))) mf = forced / 32;
   const int total = (N / wBN) * ((M + 32 * mf - 1) / (32 * mf));
   int grid = total < cus ? ((total + 7) & ~7) : cus;
   const int ordg = wide_order_group(N);
@@ -1195,7 +1206,11 @@ int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, co
       else
         W_LAUNCH(2, 2);
     } else if (obf) {
-      W_LAUNCH(2, 1);
+      if (mf == 5)
+        W_GO((gemm_wide_kernel<2, 1, 5>), grid, st, static_cast<const char*>(A), static_cast<const char*>(W), bias, residual, out, M, N,
+             K, epi, 1, ordg, sc);
+      else
+        W_LAUNCH(2, 1);
     } else {
       W_LAUNCH(2, 0);
     }
