@@ -199,3 +199,29 @@ def test_stable_tie_order_matches_stable_sort(Q, N, K, C, k, zeros):
         _, _, perm_ref = Nn.hamming_map(Nn.pack_codes(t(qB)), Nn.pack_labels(t(qL)), Nn.pack_codes(t(rB)), Nn.pack_labels(t(rL)),
                                         K, C, topk=k, want_perm=True)
         assert not np.array_equal(perm_ref.cpu().numpy()[1:], perm[1:])
+
+
+@pytest.mark.parametrize("N", [7512, 7513, 16276, 16277, 33027, 33028])
+def test_ranking_at_the_placement_boundaries(N):
+    """csrc/hamming_map.hip keeps a query's working set in LDS (twice per CU up to 7 512 items), elements in LDS + lists in the workspace
+    (twice per CU up to 16 276, once up to 33 027) or all of it in the workspace: the last size of each placement and the first of
+    the next, complete permutations against the oracle's introsort and the stable order against std::stable_sort."""
+    import cmh_native as Nn
+    rng = np.random.default_rng(N)
+    Q, K, C = 3, 32, 8
+    qB = np.where(rng.random((Q, K)) < 0.5, -1.0, 1.0).astype(np.float32)
+    rB = np.where(rng.random((N, K)) < 0.5, -1.0, 1.0).astype(np.float32)
+    qL = (rng.random((Q, C)) < 0.3).astype(np.float32)
+    rL = (rng.random((N, C)) < 0.3).astype(np.float32)
+    qL[:, 0] = 1.0                      # (a query without any relevant item is skipped like upstream's `continue`: no ranking to compare)
+    rL[:7, 0] = 1.0
+    _, ap, perm = _gpu_map(qB, rB, qL, rL, want_perm=True)
+    perm = perm.cpu().numpy()
+    for i in range(Q):
+        assert np.array_equal(perm[i], oracle.sort_perm(oracle.hamming_row(qB[i], rB))), (N, i)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    _, _, sperm = Nn.hamming_map(Nn.pack_codes(t(qB)), Nn.pack_labels(t(qL)), Nn.pack_codes(t(rB)), Nn.pack_labels(t(rL)), K, C,
+                                 tie_order=Nn.TIE_STABLE, want_perm=True)
+    for i in range(Q):
+        keys = oracle.hamming_row(qB[i], rB)
+        assert np.array_equal(sperm[i].cpu().numpy(), np.argsort(keys, kind="stable")), (N, i)
