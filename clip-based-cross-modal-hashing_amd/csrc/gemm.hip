@@ -213,14 +213,13 @@ void launch_gemm_glds(int dt, const void* A, const void* W, const float* bias, c
                       int M, int N, int K, int epi, hipStream_t st);   // gemm_glds.hip
 bool gemm_wide_supported(int N);                                         // gemm_wide.hip
 void gemm_wide_time_next(hipEvent_t start, hipEvent_t stop);             // gemm_wide.hip: the next wide launch stamps these events itself
-bool gemm_rows_takes(int M, int N, int K, int epi);                      // gemm_rows.hip: few rows (M <= 512), 64 x 64 tiles
 int launch_gemm_rows(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out, int M, int N, int K,
                      int epi, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 int launch_gemm_rows_fp8(const void* A, const void* W, const float* colscale, float alpha, const float* bias, const float* residual,
                          void* out, float oscale, int M, int N, int K, int epi, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out,
                      int M, int N, int K, int epi, hipStream_t st, const float* colscale = nullptr, float alpha = 1.f,
-                     float oscale = 1.f, const int32_t* m_dev = nullptr, int m_hint = -1);
+                     float oscale = 1.f, const int32_t* m_dev = nullptr, int m_hint = -1, const LnFold* ln = nullptr);
 
 // the measurement hook counts algorithmic FLOPs on REAL rows: with a device-side row count it reads that count back (a stream
 // synchronisation, inside a profiled run only)
@@ -244,8 +243,10 @@ bool gemm_wide_enabled() {
 }
 
 int launch_gemm(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out,
-                int M, int N, int K, int epi, hipStream_t st, const int32_t* m_dev, int m_hint) {
+                int M, int N, int K, int epi, hipStream_t st, const int32_t* m_dev, int m_hint, const LnFold* ln) {
   const int bk = dt == CMH_F32 ? 32 : 64;
+  if (ln && !ln->mode) ln = nullptr;
+  CMH_CHECK_ARG(!ln || (gemm_wide_supported(N) && gemm_wide_enabled()), "gemm: the LayerNorm fold needs the wide kernel (N %% 256 == 0, N=%d)", N);
   CMH_CHECK_ARG(dt == CMH_F32 || dt == CMH_BF16, "gemm: bad dtype %d", dt);
   CMH_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
   CMH_CHECK_ARG(N % kTile == 0, "gemm: N=%d must be a multiple of %d", N, kTile);
@@ -261,8 +262,8 @@ int launch_gemm(int dt, const void* A, const void* W, const float* bias, const f
   // the wide kernel's launch stamps the event pair with its own begin / end (gemm_wide_time_next); the fallback kernels are
   // bracketed by two recorded events; CMH_GEMM_PROF_BRACKET=1 brackets every launch (round 1-2's method, for comparison)
   static const bool bracket = []() { const char* e = getenv("CMH_GEMM_PROF_BRACKET"); return e && e[0] == '1'; }();
-  const bool takes_rows = wide && !m_dev && gemm_rows_takes(M, N, K, epi);   // (it reproduces the wide kernel's bits: off with it)
-  const bool takes_wide = !takes_rows && ((impl == 1 && wide && gemm_wide_supported(N)) || (epi & (EPI_RES_F16 | EPI_OUT_F16 | EPI_MUL_DQGELU | EPI_SAVE_PRE)));
+  const bool takes_rows = wide && !m_dev && !ln && gemm_rows_takes(M, N, K, epi);   // (it reproduces the wide kernel's bits: off with it)
+  const bool takes_wide = !takes_rows && (ln || (impl == 1 && wide && gemm_wide_supported(N)) || (epi & (EPI_RES_F16 | EPI_OUT_F16 | EPI_MUL_DQGELU | EPI_SAVE_PRE)));
   const bool self_timed = timed && (takes_wide || takes_rows) && !bracket;
   hipEvent_t ev0 = self_timed ? g_prof.ev[g_prof.used] : nullptr, ev1 = self_timed ? g_prof.ev[g_prof.used + 1] : nullptr;
   if (timed && !self_timed) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
@@ -276,7 +277,7 @@ int launch_gemm(int dt, const void* A, const void* W, const float* bias, const f
     if (rc) return rc;
   } else if (takes_wide) {
     if (self_timed) gemm_wide_time_next(ev0, ev1);
-    const int rc = launch_gemm_wide(dt, A, W, bias, residual, out, M, N, K, epi, st, nullptr, 1.f, 1.f, m_dev, m_hint);
+    const int rc = launch_gemm_wide(dt, A, W, bias, residual, out, M, N, K, epi, st, nullptr, 1.f, 1.f, m_dev, m_hint, ln);
     gemm_wide_time_next(nullptr, nullptr);
     if (rc) return rc;
   } else if (m_dev) {
