@@ -358,15 +358,17 @@ def linear_gemm_fp8(x8, w8, colscale, alpha, bias=None, residual=None, quickgelu
     return o
 
 
-def linear_gemm_ln_producer(x, w, bias, residual):
+def linear_gemm_ln_producer(x, w, bias, residual, out=None, part=None):
     """A residual GEMM of the bf16 mode that also leaves the row statistics of its fp16 output for the LayerNorm folded into the next
     GEMM: returns (out fp16 [M, N], part f32 [N/256, M, 2]).  x, w bf16; residual fp16 (include/cmh.h: cmh_linear_gemm_lnfold, mode 1)."""
     require_gpu(x, w, bias, residual)
     x, w, residual = x.contiguous(), w.contiguous(), residual.contiguous()
     M, K = x.shape
     Nn = w.shape[0]
-    out = torch.empty(M, Nn, dtype=torch.float16, device=x.device)
-    part = torch.zeros(Nn // 256, M, 2, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(M, Nn, dtype=torch.float16, device=x.device)
+    if part is None:
+        part = torch.zeros(Nn // 256, M, 2, dtype=torch.float32, device=x.device)
     epi = EPI_BIAS | EPI_RESIDUAL | EPI_RES_F16 | EPI_OUT_F16
     check(lib().cmh_linear_gemm_lnfold(ptr(x), ptr(w), ptr(f32c(bias)), ptr(residual), ptr(out), M, Nn, K, epi, 1, ptr(part), None,
                                        stream_ptr(x.device)), "cmh_linear_gemm_lnfold")
@@ -391,9 +393,20 @@ def set_pooled_tail(on: bool):
     check(lib().cmh_set_pooled_tail(1 if on else 0), "cmh_set_pooled_tail")
 
 
+_ln_fold = -1
+
+
 def set_ln_fold(on: int = -1):
-    """LayerNorms folded into the GEMMs around them (bf16 mode, > 2048 rows; include/cmh.h): 1 on, 0 off, -1 = environment."""
+    """LayerNorms folded into the GEMMs around them (bf16 mode, > 2048 rows; include/cmh.h): 1 on, 0 off, -1 = environment
+    (CMH_LN_FOLD=1; the default is off)."""
+    global _ln_fold
     check(lib().cmh_set_ln_fold(int(on)), "cmh_set_ln_fold")
+    _ln_fold = int(on)
+
+
+def ln_fold_requested() -> bool:
+    """Should the towers' weight caches hold the folded copies of in_proj / c_fc?"""
+    return _ln_fold == 1 if _ln_fold >= 0 else os.environ.get("CMH_LN_FOLD", "0") == "1"
 
 
 def set_gemm_rows(on: int = -1):

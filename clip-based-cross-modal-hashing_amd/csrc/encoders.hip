@@ -110,9 +110,12 @@ enum : int {
   FOLD_LN2 = 2,        // ln_2: c_fc reads the raw stream; out_proj leaves the statistics
   FOLD_EMIT_NEXT = 4   // c_proj leaves the statistics for the next block's ln_1
 };
-static int g_ln_fold = -1;   // cmh_set_ln_fold: -1 = from the environment (CMH_LN_FOLD=0 switches it off)
+// Default OFF (measured, profiles/r03_g_lnfold_ab.txt): the fold removes 46 LayerNorm launches per step, but the GEMMs that take them
+// over lose as much as the launches cost - the f16 MFMA on the raw stream clocks lower than the bf16 one on normalised rows, and the
+// statistics cost the epilogues (where the matrix pipe idles on every CU) more than a bandwidth-bound LayerNorm kernel costs.
+static int g_ln_fold = -1;   // cmh_set_ln_fold: -1 = from the environment (CMH_LN_FOLD=1 switches it on)
 static bool ln_fold_env() {
-  static const bool on = []() { const char* e = getenv("CMH_LN_FOLD"); return !(e && !strcmp(e, "0")); }();
+  static const bool on = []() { const char* e = getenv("CMH_LN_FOLD"); return e && !strcmp(e, "1"); }();
   return g_ln_fold < 0 ? on : g_ln_fold != 0;
 }
 // Can this tower call fold at all?  bf16 mode on the fp16 stream, the folded weights present, every GEMM on the wide kernel (the

@@ -386,6 +386,8 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   // the prologue instead of sitting exposed in the epilogue (residual GEMMs have <= 1 tile per workgroup: N = 512 / 768).
   // Measured inside the encoder: K = 512 / 768: -2.9 / -1.6 us per launch; K = 2048 / 3072: +0.3 / +2.3 us (the 40 MB burst
   // delays the first stage and a long K loop has no trouble hiding the epilogue's loads behind other workgroups) -> nk <= 16.
+  // (Round 3 tried the other order - stage 0's DMA first, the residual rows behind it as inline-asm loads under the same counted
+  // wait, added after the other prologue stages were issued: 0.5 % slower on the bench line, A/B/A/B on one box; not kept.)
   // (fp8 launches always carry EPI_SCALE: never there - said at compile time, so that the prologue holds no residual code)
   const bool res_first = !FP8 && (epi & EPI_RESIDUAL) && !(epi & (EPI_QUICKGELU | EPI_GELU | EPI_RELU | EPI_SCALE)) && nk <= 16;
   auto mfma = [&](const w_u32x4_t& fw, const w_u32x4_t& fx, w_f32x4_t& c) {
@@ -424,6 +426,37 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   w_f32x4_t acc[4][MF];   // [n-tile][m-tile]
   // acc += residual tile at (m0, n0): f32 rows, or (EPI_RES_F16) fp16 rows read in the 16-byte layout of the packed output
   // (lane = one row x 8 consecutive n) and brought back to the accumulator layout by the same v_permlane16_swap.
+  // fp16 residual rows in the 16-byte layout of the packed output (lane = one row x 8 consecutive n), brought back to the accumulator
+  // layout by the same v_permlane16_swap
+  auto load_res16 = [&](int m0, int n0, w_u32x4_t (&r)[NPEND]) __attribute__((always_inline)) {
+    const uint16_t* res16 = reinterpret_cast<const uint16_t*>(residual);
+    const int col = n0 + wn * 64 + (fq & 1) * 16 + (fq & 2) * 4;    // + 32*pair
+#pragma unroll
+    for (int b = 0; b < MF; ++b) {
+      int m = m0 + wm * WR + b * 16 + frow;
+      m = m < M ? m : M - 1;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr)
+        if constexpr (!OUT8) r[b * 2 + pr] = *reinterpret_cast<const w_u32x4_t*>(res16 + static_cast<size_t>(m) * N + col + 32 * pr);
+    }
+  };
+  auto apply_res16 = [&](const w_u32x4_t (&r)[NPEND]) __attribute__((always_inline)) {
+    if constexpr (!OUT8) {
+#pragma unroll
+      for (int b = 0; b < MF; ++b) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const w_u32x4_t q = r[b * 2 + pr];
+          const w_u2_t s0 = __builtin_amdgcn_permlane16_swap(q[0], q[2], false, false);   // -> words 0 of tiles 2pr, 2pr+1
+          const w_u2_t s1 = __builtin_amdgcn_permlane16_swap(q[1], q[3], false, false);   // -> words 1
+          acc[2 * pr][b][0] += f16lo_to_f32(s0[0]); acc[2 * pr][b][1] += f16hi_to_f32(s0[0]);
+          acc[2 * pr][b][2] += f16lo_to_f32(s1[0]); acc[2 * pr][b][3] += f16hi_to_f32(s1[0]);
+          acc[2 * pr + 1][b][0] += f16lo_to_f32(s0[1]); acc[2 * pr + 1][b][1] += f16hi_to_f32(s0[1]);
+          acc[2 * pr + 1][b][2] += f16lo_to_f32(s1[1]); acc[2 * pr + 1][b][3] += f16hi_to_f32(s1[1]);
+        }
+      }
+    }
+  };
   auto add_residual = [&](int m0, int n0) __attribute__((always_inline)) {
     if constexpr (FP8 && MF == 5) {
       // fp8, 160 rows (fp16 residual stream only): two groups of row fragments, 24 + 16 registers in flight instead of 40 - still
@@ -459,30 +492,9 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
       }
     } else
     if (epi & EPI_RES_F16) {
-      const uint16_t* res16 = reinterpret_cast<const uint16_t*>(residual);
-      const int col = n0 + wn * 64 + (fq & 1) * 16 + (fq & 2) * 4;    // + 32*pair
       w_u32x4_t r[NPEND];
-#pragma unroll
-      for (int b = 0; b < MF; ++b) {
-        int m = m0 + wm * WR + b * 16 + frow;
-        m = m < M ? m : M - 1;
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr)
-          r[b * 2 + pr] = *reinterpret_cast<const w_u32x4_t*>(res16 + static_cast<size_t>(m) * N + col + 32 * pr);
-      }
-#pragma unroll
-      for (int b = 0; b < MF; ++b) {
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-          const w_u32x4_t q = r[b * 2 + pr];
-          const w_u2_t s0 = __builtin_amdgcn_permlane16_swap(q[0], q[2], false, false);   // -> words 0 of tiles 2pr, 2pr+1
-          const w_u2_t s1 = __builtin_amdgcn_permlane16_swap(q[1], q[3], false, false);   // -> words 1
-          acc[2 * pr][b][0] += f16lo_to_f32(s0[0]); acc[2 * pr][b][1] += f16hi_to_f32(s0[0]);
-          acc[2 * pr][b][2] += f16lo_to_f32(s1[0]); acc[2 * pr][b][3] += f16hi_to_f32(s1[0]);
-          acc[2 * pr + 1][b][0] += f16lo_to_f32(s0[1]); acc[2 * pr + 1][b][1] += f16hi_to_f32(s0[1]);
-          acc[2 * pr + 1][b][2] += f16lo_to_f32(s1[1]); acc[2 * pr + 1][b][3] += f16hi_to_f32(s1[1]);
-        }
-      }
+      load_res16(m0, n0, r);
+      apply_res16(r);
     } else if constexpr (!FP8) {   // (the fp8 mode's residual stream is fp16)
       w_f32x4_t rv[4][MF];
 #pragma unroll
@@ -826,11 +838,19 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
       for (int b = 0; b < MF; ++b) {
         int m = m0 + wm * WR + b * 16 + frow;
         m = m < M ? m : M - 1;
-        float s1 = 0.f, s2 = 0.f;
-        for (int p = 0; p < sc.ln_nparts; ++p) {
-          const w_f32x2_t v = *reinterpret_cast<const w_f32x2_t*>(sc.ln_part + (static_cast<size_t>(p) * Mub + m) * 2);
-          s1 += v[0];
-          s2 += v[1];
+        // all loads first (a runtime-bounded loop would wait for each panel's pair in turn: 15 L2 round trips per tile): up to four
+        // panels (width <= 1024) from clamped addresses, the ones past ln_nparts dropped by a select
+        w_f32x2_t pv[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int pc = p < sc.ln_nparts ? p : sc.ln_nparts - 1;
+          pv[p] = *reinterpret_cast<const w_f32x2_t*>(sc.ln_part + (static_cast<size_t>(pc) * Mub + m) * 2);
+        }
+        float s1 = pv[0][0], s2 = pv[0][1];
+#pragma unroll
+        for (int p = 1; p < 4; ++p) {
+          s1 += p < sc.ln_nparts ? pv[p][0] : 0.f;
+          s2 += p < sc.ln_nparts ? pv[p][1] : 0.f;
         }
         const float mean = s1 * inv_d;
         const float var = fmaxf(s2 * inv_d - mean * mean, 0.f);

@@ -147,18 +147,18 @@ FP8_HEADROOM = 2.0     # act_scale = FP8_HEADROOM * amax(calibration batch) / 44
 
 
 def ln_fold_enabled() -> bool:
-    """CMH_LN_FOLD=0 keeps every LayerNorm a launch of its own (A/B runs)."""
-    return os.environ.get("CMH_LN_FOLD", "1") != "0"
+    """The LayerNorm fold is opt-in (cmh_native.set_ln_fold(1) or CMH_LN_FOLD=1): measured, it does not pay."""
+    return N.ln_fold_requested()
 
 
 def _fold_blocks(resblocks, arr, dt: int, keep: list):
     """Inference in bf16 mode: ln_1 / ln_2 folded into in_proj / c_fc (csrc/gemm_wide.hip, template parameter LN).  Filled in on the
     first inference call of a weight state (a training step never pays for it)."""
     if dt != N.BF16 or not ln_fold_enabled():
-        return
+        return False
     for i, blk in enumerate(resblocks):
         if blk.ln_1.weight.shape[0] % 256 != 0:
-            return
+            return True
         b = arr[i]
         wf, bf, cf = N.ln_fold_weight(blk.attn.in_proj_weight, blk.ln_1.weight, blk.ln_1.bias, blk.attn.in_proj_bias)
         b.in_proj_wf, b.in_proj_bf, b.in_proj_cf = wf.data_ptr(), bf.data_ptr(), cf.data_ptr()
@@ -166,6 +166,7 @@ def _fold_blocks(resblocks, arr, dt: int, keep: list):
         wf, bf, cf = N.ln_fold_weight(blk.mlp.c_fc.weight, blk.ln_2.weight, blk.ln_2.bias, blk.mlp.c_fc.bias)
         b.fc_wf, b.fc_bf, b.fc_cf = wf.data_ptr(), bf.data_ptr(), cf.data_ptr()
         keep.extend((wf, bf, cf))
+    return True
 
 
 def _fill_blocks(resblocks, dt: int, keep: list, act_amax=None):
@@ -373,8 +374,7 @@ class CLIP(nn.Module):
             s.blocks = C.cast(c.blocks, C.POINTER(N.BlockWeights))
             c.struct, c.keep, c.key, c.folded = s, keep, key, False
         if fold and not c.folded:
-            _fold_blocks(v.transformer.resblocks, c.blocks, self._gemm_dtype, c.keep)
-            c.folded = True
+            c.folded = _fold_blocks(v.transformer.resblocks, c.blocks, self._gemm_dtype, c.keep)
         return c.struct
 
     def _text_struct(self, fold=False):
@@ -400,8 +400,7 @@ class CLIP(nn.Module):
             s.blocks = C.cast(c.blocks, C.POINTER(N.BlockWeights))
             c.struct, c.keep, c.key, c.folded = s, keep, key, False
         if fold and not c.folded:
-            _fold_blocks(self.transformer.resblocks, c.blocks, self._gemm_dtype, c.keep)
-            c.folded = True
+            c.folded = _fold_blocks(self.transformer.resblocks, c.blocks, self._gemm_dtype, c.keep)
         return c.struct
 
     @staticmethod

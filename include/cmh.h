@@ -230,8 +230,9 @@ int cmh_set_pooled_tail(int32_t on);
 /* bf16 mode on the fp16 residual stream: ln_1 (from the second block on) and ln_2 (up to the last block but one) are not launches of
  * their own - the residual GEMM before them leaves per-row sums, the Linear after them reads the raw stream against the folded
  * weights of cmh_block_weights.in_proj_wf / fc_wf and normalises in its epilogue (csrc/gemm_wide.hip).  Applies when the towers'
- * GEMMs run on the wide kernel (more than 2048 rows per call) and the folded weights are present.  on = 0 switches it off (A/B
- * measurements, tests), 1 on, -1 = environment (CMH_LN_FOLD=0 is off).  Process-wide, not thread-safe. */
+ * GEMMs run on the wide kernel (more than 2048 rows per call) and the folded weights are present.  OFF by default: measured on
+ * configs[1] it removes 46 launches per step and costs the GEMMs as much.  on = 1 switches it on, 0 off,
+ * -1 = environment (CMH_LN_FOLD=1 is on).  Process-wide, not thread-safe. */
 int cmh_set_ln_fold(int32_t on);
 
 /* ---------------------------------------------------------------------------------------------
