@@ -1266,8 +1266,8 @@ int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, co
   const WideScales sc{colscale, alpha, oscale, 0, nullptr, m_dev, ln ? ln->part : nullptr, ln ? ln->colsum : nullptr, ln ? ln->nparts : 0};
   const int lnm = ln ? ln->mode : 0;
   if (lnm) {
-    if (dt != CMH_BF16 || !ln->part || (lnm == 1 && !(epi & EPI_OUT_F16)) || (lnm == 2 && (!(epi & EPI_OUT_BF16) || !(epi & EPI_BIAS) || !ln->colsum || ln->nparts * wBN != K)))
-      return fail(CMH_ERR_INVALID, "gemm: LayerNorm fold mode %d needs the bf16 mode, fp16 output (producer) / bias, bf16 output, K = 256 * parts (consumer)", lnm);
+    if (dt != CMH_BF16 || !ln->part || (lnm == 1 && !(epi & EPI_OUT_F16)) || (lnm == 2 && (!(epi & EPI_OUT_BF16) || !(epi & EPI_BIAS) || !ln->colsum || ln->nparts * wBN != K || ln->nparts > 4)))
+      return fail(CMH_ERR_INVALID, "gemm: LayerNorm fold mode %d needs the bf16 mode, fp16 output (producer) / bias, bf16 output, K = 256 * parts <= 1024 (consumer)", lnm);
   }
   const size_t esz = dt == CMH_F32 ? 4 : (dt == CMH_FP8 ? 1 : 2);
   if (static_cast<size_t>(M) * K * esz >= (1ull << 32) || static_cast<size_t>(wBN) * K * esz >= (1ull << 32))
