@@ -76,6 +76,13 @@ __device__ __forceinline__ void w_store16(void* p, const w_u32x4_t& v) {
 typedef const __attribute__((address_space(1))) void* w_gptr_t;
 typedef __attribute__((address_space(3))) void* w_lptr_t;
 
+// cache policy of the LDS-DMA loads (the builtin's aux operand: 1 sc0, 2 nt, 16 sc1), per operand; diagnostic builds: -DW_X_CPOL=2 ...
+#ifndef W_X_CPOL
+#define W_X_CPOL 0
+#endif
+#ifndef W_W_CPOL
+#define W_W_CPOL 0
+#endif
 #ifdef W_STAMPS
 __device__ unsigned g_wide_stamps[256 * 8 * 4];
 #endif
@@ -270,12 +277,12 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
     }
     const size_t koff = static_cast<size_t>(issue_kt) * wRowBytes;
     if (p < 4)
-      __builtin_amdgcn_global_load_lds((w_gptr_t)(Wt + koff + offW[p]), (w_lptr_t)(base + (wid * 4 + p) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((w_gptr_t)(Wt + koff + offW[p]), (w_lptr_t)(base + (wid * 4 + p) * 1024), 16, 0, W_W_CPOL);
     else if (p < 6)
       __builtin_amdgcn_global_load_lds((w_gptr_t)(Xt + koff + offX[p - 4]),
-                                       (w_lptr_t)(base + wWBytes + (p == 4 ? wid : xpiece1) * 1024), 16, 0, 0);
+                                       (w_lptr_t)(base + wWBytes + (p == 4 ? wid : xpiece1) * 1024), 16, 0, W_X_CPOL);
     else if (three)
-      __builtin_amdgcn_global_load_lds((w_gptr_t)(Xt + koff + offX[2]), (w_lptr_t)(base + wWBytes + (wid + 16) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((w_gptr_t)(Xt + koff + offX[2]), (w_lptr_t)(base + wWBytes + (wid + 16) * 1024), 16, 0, W_X_CPOL);
   };
   // The K loop below is ONE straight-line steady state: it issues a stage in every K-step.  The three stages issued past
   // the workgroup's last one re-stage its last tile into buffers nobody reads any more (drained before the kernel ends).
