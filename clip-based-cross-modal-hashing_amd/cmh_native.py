@@ -98,6 +98,7 @@ SIGNATURES = {
     "cmh_gemm_tuning": (C.c_int, [_i32, _i32]),
     "cmh_set_pooled_tail": (C.c_int, [_i32]),
     "cmh_set_ln_fold": (C.c_int, [_i32]),
+    "cmh_set_gemm_big": (C.c_int, [_i32]),
     "cmh_set_gemm_rows": (C.c_int, [_i32]),
     "cmh_msl_workspace_bytes": (_sz, [_i32]),
     "cmh_msl_loss": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _sz, _p]),
@@ -407,6 +408,11 @@ def set_ln_fold(on: int = -1):
 def ln_fold_requested() -> bool:
     """Should the towers' weight caches hold the folded copies of in_proj / c_fc?"""
     return _ln_fold == 1 if _ln_fold >= 0 else os.environ.get("CMH_LN_FOLD", "0") == "1"
+
+
+def set_gemm_big(on: int = -1):
+    """Many-tile bf16 GEMMs on 256 x 256 tiles (csrc/gemm_big.hip; off by default): 1 on, 0 off, -1 = environment (CMH_GEMM_BIG=1)."""
+    check(lib().cmh_set_gemm_big(int(on)), "cmh_set_gemm_big")
 
 
 def set_gemm_rows(on: int = -1):

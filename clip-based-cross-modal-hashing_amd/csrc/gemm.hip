@@ -217,6 +217,9 @@ int launch_gemm_rows(int dt, const void* A, const void* W, const float* bias, co
                      int epi, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 int launch_gemm_rows_fp8(const void* A, const void* W, const float* colscale, float alpha, const float* bias, const float* residual,
                          void* out, float oscale, int M, int N, int K, int epi, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+bool gemm_big_takes(int dt, int M, int N, int K, int epi, const void* residual);   // gemm_big.hip: 256 x 256 tiles (in_proj / c_fc)
+int launch_gemm_big(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int epi, hipStream_t st,
+                    const int32_t* m_dev, hipEvent_t ev0, hipEvent_t ev1);
 int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out,
                      int M, int N, int K, int epi, hipStream_t st, const float* colscale = nullptr, float alpha = 1.f,
                      float oscale = 1.f, const int32_t* m_dev = nullptr, int m_hint = -1, const LnFold* ln = nullptr);
@@ -263,8 +266,11 @@ int launch_gemm(int dt, const void* A, const void* W, const float* bias, const f
   // bracketed by two recorded events; CMH_GEMM_PROF_BRACKET=1 brackets every launch (round 1-2's method, for comparison)
   static const bool bracket = []() { const char* e = getenv("CMH_GEMM_PROF_BRACKET"); return e && e[0] == '1'; }();
   const bool takes_rows = wide && !m_dev && !ln && gemm_rows_takes(M, N, K, epi);   // (it reproduces the wide kernel's bits: off with it)
-  const bool takes_wide = !takes_rows && (ln || (impl == 1 && wide && gemm_wide_supported(N)) || (epi & (EPI_RES_F16 | EPI_OUT_F16 | EPI_MUL_DQGELU | EPI_SAVE_PRE)));
-  const bool self_timed = timed && (takes_wide || takes_rows) && !bracket;
+  // (the tile count is judged on the likely row count when the real one lives on the device)
+  const bool takes_big = !takes_rows && wide && impl == 1 && !ln && (!(epi & EPI_BIAS) || bias) &&
+                         gemm_big_takes(dt, m_dev && m_hint > 0 && m_hint <= M ? m_hint : M, N, K, epi, residual);
+  const bool takes_wide = !takes_rows && !takes_big && (ln || (impl == 1 && wide && gemm_wide_supported(N)) || (epi & (EPI_RES_F16 | EPI_OUT_F16 | EPI_MUL_DQGELU | EPI_SAVE_PRE)));
+  const bool self_timed = timed && (takes_wide || takes_rows || takes_big) && !bracket;
   hipEvent_t ev0 = self_timed ? g_prof.ev[g_prof.used] : nullptr, ev1 = self_timed ? g_prof.ev[g_prof.used + 1] : nullptr;
   if (timed && !self_timed) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
   CMH_CHECK_ARG(!(epi & EPI_MUL_DQGELU) || (residual && gemm_wide_supported(N) && !(epi & (EPI_RESIDUAL | EPI_OUT_F16))),
@@ -274,6 +280,9 @@ int launch_gemm(int dt, const void* A, const void* W, const float* bias, const f
                 "gemm: EPI_SAVE_PRE needs the second output in the residual slot, bf16 operands and output, N %% 256 == 0 (N=%d)", N);
   if (takes_rows) {
     const int rc = launch_gemm_rows(dt, A, W, bias, residual, out, M, N, K, epi, st, ev0, ev1);
+    if (rc) return rc;
+  } else if (takes_big) {
+    const int rc = launch_gemm_big(A, W, bias, out, M, N, K, epi, st, m_dev, ev0, ev1);
     if (rc) return rc;
   } else if (takes_wide) {
     if (self_timed) gemm_wide_time_next(ev0, ev1);
@@ -295,7 +304,7 @@ int launch_gemm(int dt, const void* A, const void* W, const float* bias, const f
     const int Mr = prof_real_rows(M, m_dev, st);
     g_prof.flops.push_back(2.0 * Mr * static_cast<double>(N) * K);   // algorithmic FLOPs: real rows only
     g_prof.dims.push_back({Mr, N, K, epi});
-    g_prof.kind.push_back(takes_rows ? 1 : (takes_wide ? 0 : 2));
+    g_prof.kind.push_back(takes_rows ? 1 : (takes_wide || takes_big ? 0 : 2));
     g_prof.used += 2;
   }
   CMH_CHECK_LAUNCH("gemm");

@@ -221,6 +221,13 @@ int cmh_gemm_tuning(int32_t tile_rows, int32_t order_group);
  * on = 0 sends them to the wide kernel again (A/B, tests), 1 forces the default, -1 = environment (CMH_GEMM_ROWS=0 is off). */
 int cmh_set_gemm_rows(int32_t on);
 
+/* Optional second tile shape for cmh_linear_gemm and the towers' in_proj / c_fc launches (bf16, bias [+ QuickGELU], bf16 output, at
+ * least 240 tiles of 256 x 256): gemm_big_kernel, 256 x 256 tiles on four waves of 128 x 128 (csrc/gemm_big.hip) - 128 FLOP per byte
+ * fetched into LDS where the 160 x 256 tile has 98, same bits per output element.  OFF by default: faster at K >= ~2048 (+17 % at
+ * 12 800 x 2304 x 3072), slower at the encoder's K = 512 / 768.  on = 1 switches it on, 0 off, -1 = environment
+ * (CMH_GEMM_BIG=1 is on). */
+int cmh_set_gemm_big(int32_t on);
+
 /* encode_image / encode_text return one pooled row per sample (model/base/model.py:247-250, 366-370), and past the last block's
  * attention every operation is row-wise, so cmh_vit_encode / cmh_text_encode[_packed] carry only those B rows through the last
  * block's out_proj, ln_2 and MLP (bit-identical features, three GEMMs of M = B instead of M = B*T).  on = 0 switches that off
