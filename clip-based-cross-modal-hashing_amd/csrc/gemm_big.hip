@@ -53,7 +53,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const char* __restrict__ 
                                                        int K, int epi, const int* __restrict__ m_dev) {
   int M = Mub;
   if (m_dev) { const int md = *m_dev; M = md < Mub ? md : Mub; }
-  __shared__ __attribute__((aligned(1024))) char lds[2 * gStage];
+  __shared__ __attribute__((aligned(1024))) char lds[5 * gHalf];   // W stage s in buffer s % 2 at [0, 64 KB), X stage s in buffer s % 3 behind them: all 160 KB
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -104,13 +104,13 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const char* __restrict__ 
   };
   int issue_kt = 0, issue_tile = 0, issue_buf = 0;
   auto issue_piece = [&](int i) {   // i is a compile-time constant at every call site
-    __builtin_amdgcn_global_load_lds((g_gptr_t)(src_tile + static_cast<size_t>(issue_kt) * gRowB + off[i]),
-                                     (g_lptr_t)(lds + issue_buf * gStage + (wid * 8 + i) * 1024), 16, 0, 0);
+    char* dst = group_b ? lds + 2 * gHalf + issue_buf * gHalf + ((wid - 4) * 8 + i) * 1024 : lds + issue_buf * gHalf + (wid * 8 + i) * 1024;
+    __builtin_amdgcn_global_load_lds((g_gptr_t)(src_tile + static_cast<size_t>(issue_kt) * gRowB + off[i]), (g_lptr_t)dst, 16, 0, 0);
   };
   // The K loop is one straight-line steady state: it issues a stage in every K-step.  The two stages issued past the workgroup's
   // last one re-stage its last tile into buffers nobody reads any more (drained before the kernel ends).
   auto issue_done = [&]() {
-    issue_buf ^= 1;
+    issue_buf = group_b ? (issue_buf == 2 ? 0 : issue_buf + 1) : (issue_buf ^ 1);
     if (++issue_kt == nk) {
       issue_kt = 0;
       if (++issue_tile < my_tiles) set_issue_tile(issue_tile);
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const char* __restrict__ 
   // rows of the next half-step (the other k half of this stage in the first half, the next stage's first half after the barrier).
   const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((g_lptr_t)lds));
   const uint32_t aW = lds_base + g_swz(wn * 64 + frow, fq);
-  const uint32_t aX = lds_base + gHalf + g_swz(wm * 128 + frow, fq);
+  const uint32_t aX = lds_base + 2 * gHalf + g_swz(wm * 128 + frow, fq);
 #define G_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
 #define G_WAIT_ALL(cnt)                                                                                                     \
   asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                                                \
@@ -161,18 +161,24 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const char* __restrict__ 
 #pragma unroll
   for (int i = 0; i < 8; ++i) issue_piece(i);
   issue_done();
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // stage 0 landed (stage 1 may fly)
+  if (group_b) {     // the X operand runs one stage further ahead (three buffers)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) issue_piece(i);
+    issue_done();
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // X stage 0 landed (two younger stages may fly)
+  } else {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // W stage 0 landed (stage 1 may fly)
+  }
   __builtin_amdgcn_s_barrier();
   G_READ(f0w[0], aW, 0); G_READ(f0w[1], aW, 2048); G_READ(f0w[2], aW, 4096); G_READ(f0w[3], aW, 6144);
 #pragma unroll
   for (int b = 0; b < 8; ++b) G_XREAD(b, aX);
 
-  int cur = 0;
-  bool stores_pending = false;   // the previous tile's 16 stores per lane are younger than the stage the next counted wait needs
+  int cw = 0, cx = 0;            // W buffer (s % 2) and X buffer (s % 3) of the K-step being multiplied
+  int sp = 0;                    // K-steps for which the previous tile's 16 stores per lane are younger than the stage a counted wait needs
   for (int ti = 0; ti < my_tiles; ++ti) {
     for (int kt = 0; kt < nk; ++kt) {
-      const uint32_t bo = static_cast<uint32_t>(cur) * gStage;
-      const uint32_t w1 = (aW + bo) ^ 64u, x1 = (aX + bo) ^ 64u;
+      const uint32_t w1 = (aW + static_cast<uint32_t>(cw) * gHalf) ^ 64u, x1 = (aX + static_cast<uint32_t>(cx) * gHalf) ^ 64u;
       // ---- first half: the W fragments of the second half go out, then everything older (this half's fragments) has landed
       G_READ(f1w[0], w1, 0); G_READ(f1w[1], w1, 2048); G_READ(f1w[2], w1, 4096); G_READ(f1w[3], w1, 6144);
       G_WAIT_ALL(4);
@@ -181,40 +187,58 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const char* __restrict__ 
       for (int b = 0; b < 8; ++b) {
 #pragma unroll
         for (int a = 0; a < 4; ++a) mfma(f0w[a], xf[b], acc[a][b]);
+#ifndef G_ABL_NOXREAD
         G_XREAD(b, x1);                       // this tile's rows, k 32..63 of the same stage
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
       // ---- middle: own reads done; stage s+1 landed (older than the previous tile's stores, when those are in flight); barrier
       G_WAIT_ALL(0);
-      if (stores_pending) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      stores_pending = false;
+      // vmcnt is one in-order queue.  Waves 0..3 (W pieces): stage s+1 is the youngest stage issued - unless the previous tile's 16
+      // stores followed it (first K-step of a tile).  Waves 4..7 (X pieces): one more stage of 8 pieces is younger, and the stores sit
+      // between stages for the first two K-steps of a tile.
+      if (group_b) {
+        if (sp > 0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        if (sp == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      sp = sp > 0 ? sp - 1 : 0;
+#ifndef G_ABL_NOBARRIER
       __builtin_amdgcn_s_barrier();
+#endif
       // ---- second half: MFMAs on the second k half; stage s+2 into the buffer just released (group A's pieces among the first
       // MFMAs, group B's among the last: the two waves of a SIMD do not sit in the DMA issue together), fragments of stage s+1
-      const int nxt = cur ^ 1;
-      const uint32_t bn = static_cast<uint32_t>(nxt) * gStage;
-      const uint32_t w0 = aW + bn, x0 = aX + bn;
+      const int nw = cw ^ 1, nx = cx == 2 ? 0 : cx + 1;
+      const uint32_t w0 = aW + static_cast<uint32_t>(nw) * gHalf, x0 = aX + static_cast<uint32_t>(nx) * gHalf;
       G_READ(f0w[0], w0, 0); G_READ(f0w[1], w0, 2048); G_READ(f0w[2], w0, 4096); G_READ(f0w[3], w0, 6144);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int b = 0; b < 8; ++b) {
+#ifndef G_ABL_NODMA
         if (!group_b) { if (b < 4) issue_piece(2 * b); }
         else { if (b >= 4) issue_piece(2 * (b - 4)); }
+#endif
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
+#ifndef G_ABL_NODMA
           if (a == 2) {
             if (!group_b) { if (b < 4) issue_piece(2 * b + 1); }
             else { if (b >= 4) issue_piece(2 * (b - 4) + 1); }
           }
+#endif
           mfma(f1w[a], xf[b], acc[a][b]);
         }
+#ifndef G_ABL_NOXREAD
         G_XREAD(b, x0);                       // the next stage's first k half
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
       issue_done();
       __builtin_amdgcn_sched_barrier(0);
-      cur = nxt;
+      cw = nw;
+      cx = nx;
     }
 
     // ---- epilogue of tile ti (the next tile's first two stages are already in flight) ----
@@ -249,10 +273,10 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const char* __restrict__ 
       }
     }
     if (full) {
-      stores_pending = true;
+      sp = 2;
     } else {   // a partial tile may have skipped store instructions: no counting on them
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      stores_pending = false;
+      sp = 0;
     }
     zero_acc();
   }
