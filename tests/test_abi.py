@@ -98,3 +98,28 @@ def test_argument_validation_of_the_later_entry_points():
         assert len(lib.cmh_last_error()) > 0
     assert lib.cmh_image_preprocess_workspace_bytes(0, 10, 10, 16) == 0 and lib.cmh_blocks_train_bytes(0, 0, 8, 128, 2) == 0
     assert lib.cmh_bpe_vocab_size(None) == 0
+
+
+def test_struct_layouts_of_the_header_match_the_ctypes_mirrors(tmp_path):
+    """The host binding re-declares the ABI's structs in ctypes; a field added on one side only would shift every pointer behind it
+    (the version check catches a stale LIBRARY, not a stale mirror).  gcc compiles include/cmh.h and reports sizeof / the offset of
+    each struct's last member; the ctypes classes must agree."""
+    import ctypes as C
+    import cmh_native as N
+    pairs = {"cmh_block_weights": (N.BlockWeights, "fc_cf"), "cmh_vit_weights": (N.VitWeights, "blocks"),
+             "cmh_text_weights": (N.TextWeights, "blocks"), "cmh_taps": (N.Taps, "count"),
+             "cmh_block_grads": (N.BlockGrads, "proj_b"), "cmh_vit_grads": (N.VitGrads, None), "cmh_text_grads": (N.TextGrads, None),
+             "cmh_adam_tensor": (N.AdamTensor, None)}
+    pairs = {k: v for k, v in pairs.items() if v[0] is not None}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "cmh.h"', 'int main(void) {']
+    for name, (_, last) in pairs.items():
+        src.append(f'  printf("{name} %zu %zu\\n", sizeof({name}), {f"offsetof({name}, {last})" if last else "(size_t)0"});')
+    src += ['  return 0;', '}']
+    c_file, exe = tmp_path / "layout.c", tmp_path / "layout"
+    c_file.write_text("\n".join(src))
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(c_file), "-o", str(exe)])
+    got = {ln.split()[0]: (int(ln.split()[1]), int(ln.split()[2])) for ln in subprocess.check_output([str(exe)], text=True).splitlines()}
+    for name, (cls, last) in pairs.items():
+        assert C.sizeof(cls) == got[name][0], (name, C.sizeof(cls), got[name][0])
+        if last:
+            assert getattr(cls, last).offset == got[name][1], (name, last)
