@@ -210,6 +210,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     rank, world, _ = du.init_from_env()
+    dist_on = du.active()     # collectives run: more than one rank - or CMH_FORCE_DIST=1, which executes the N > 1 branch on RCCL in a group of one
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local)
     B, L, K, C = a.batch, a.seq_len, a.bits, a.classes
@@ -234,7 +235,7 @@ def main():
             else:
                 hi = tower(clip.encode_image, img_head, image)
                 ht = tower(clip.encode_text, txt_head, text)
-            if world > 1:   # the path's one exchange step: fused all-gather of the per-rank code blocks
+            if dist_on:   # the path's one exchange step: fused all-gather of the per-rank code blocks
                 fused, widths = du.fuse_columns(hi, ht, label)
                 hi_g, ht_g, lab_g = du.split_columns(du.all_gather_rows(fused), widths)
             else:
@@ -243,11 +244,11 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    if world > 1:   # the first use of a collective builds its rings: keep that out of the timed region whatever --warmup says
+    if dist_on:   # the first use of a collective builds its rings: keep that out of the timed region whatever --warmup says
         du.all_gather_rows(torch.zeros(B, 2 * K + C, device=dev))
         barrier()
     step()          # set-up, not a step of the measurement: the first pass builds the bf16 weight copies and sizes the workspaces
@@ -276,7 +277,7 @@ def main():
     # final projections run on gemm_rows_kernel and are reported beside it, not averaged into it
     gemm_ms, gemm_flops, gemm_launches = by_kernel["gemm_wide_kernel"]
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist_on:
         torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(elapsed.item())
     assert torch.isfinite(loss).item(), "non-finite loss"
@@ -298,7 +299,7 @@ def main():
             step()
         barrier()
         dense_el = torch.tensor([time.perf_counter() - td0], dtype=torch.float64, device=dev)
-        if world > 1:
+        if dist_on:
             torch.distributed.all_reduce(dense_el, op=torch.distributed.ReduceOp.MAX)
         value_dense = pairs / float(dense_el.item())
         clip.pack_text = True
@@ -402,40 +403,6 @@ def main():
             out["f32_mode"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
             clip.set_gemm_dtype(a.dtype)
         try:
-            # the LayerNorm fold (opt-in): the same step with ln_1 / ln_2 applied by the GEMMs around them, timed like the
-            # headline (towers overlapped), its GEMM launches in a serialized pass - so that the driver's own box says whether it pays
-            N.set_ln_fold(1)
-            nl = max(2, min(a.steps, 10))
-            for _ in range(3):
-                step()
-            torch.cuda.synchronize()
-            tl0 = time.perf_counter()
-            for _ in range(nl):
-                step()
-            torch.cuda.synchronize()
-            ln_ms = (time.perf_counter() - tl0) / nl * 1e3
-            N.prof_gemm_begin(nl * 128)
-            for _ in range(nl):
-                step(overlap=False)
-            torch.cuda.synchronize()
-            N.prof_gemm_end()
-            g_ms, g_fl, g_n = N.prof_gemm_by_kernel()["gemm_wide_kernel"]
-            ln_tf = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
-            out["ln_fold_mode"] = {"pairs_per_s": round(B / ln_ms * 1e3, 2), "ms_per_step": round(ln_ms, 4), "steps": nl,
-                                   "speedup_vs_headline": round(out["ms_per_step"] / ln_ms, 3),
-                                   "roofline": {"bound": "mfma", "achieved": round(ln_tf, 2), "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
-                                                "frac": round(ln_tf / PEAK_TFLOPS["bf16"], 4), "launches": int(g_n),
-                                                "gemm_ms_per_step_serialized": round(g_ms / nl, 4)},
-                                   "flip_rate_vs_f32": flip_rates(clip, (img_head, txt_head), image, text),
-                                   "what": "cmh_set_ln_fold(1): 46 of the step's 50 LayerNorm launches folded into the GEMMs around them "
-                                           "(residual GEMMs leave row sums, in_proj / c_fc read the raw fp16 stream against fp16 W * gamma: "
-                                           "v_mfma_f32_16x16x32_f16); NOT the default - the GEMMs lose more than the launches cost"}
-        except Exception as exc:
-            out["ln_fold_mode"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
-        finally:
-            N.set_ln_fold(-1)
-            step()
-        try:
             # BASELINE configs[4]'s encoder arithmetic on the same workload: the blocks' four GEMMs on e4m3 operands (fp8 MFMA),
             # scales calibrated on ANOTHER seeded batch; timed like the headline (towers overlapped), roofline leg serialized
             clip.set_gemm_dtype("fp8")
@@ -498,7 +465,7 @@ def main():
             for qk, rk in (("q_img", "r_txt"), ("q_txt", "r_img"), ("q_img", "r_img"), ("q_txt", "r_txt")):
                 mp, ap_l, _ = N.hamming_map(planes[qk], qLp, planes[rk], rLp, K, C, tie_order=tie)
                 # one rank: the kernel's own mean; several: the same sequential f32 sum over the gathered per-query APs (cmh_map_mean)
-                res.append(du.mean_in_query_order(du.gather_query_sharded_ap(ap_l, Q)) if world > 1 else mp)
+                res.append(du.mean_in_query_order(du.gather_query_sharded_ap(ap_l, Q)) if dist_on else mp)
             return res
 
         def timed(tie):
@@ -662,7 +629,7 @@ def main():
         out["cpu_baseline"] = cb
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

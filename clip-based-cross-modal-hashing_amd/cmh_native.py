@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CMH_LIB") or os.path.join(_HERE, "csrc", "build", "libcmh.so")   # CMH_LIB: A/B a kernel build
 
-ABI_VERSION = 4            # include/cmh.h CMH_VERSION: bumped whenever a struct layout or a signature changes
+ABI_VERSION = 5            # include/cmh.h CMH_VERSION: bumped whenever a struct layout or a signature changes
 F32, BF16, FP8 = 0, 1, 2
 ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
 TIE_REFERENCE, TIE_STABLE = 0, 1
@@ -29,8 +29,7 @@ class BlockWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "ln1_w", "ln1_b", "ln2_w", "ln2_b",
         "fc_w", "fc_b", "proj_w", "proj_b",
-        "in_proj_cs", "out_proj_cs", "fc_cs", "proj_cs")] + [("act_scale", C.c_float * 4)] + [     # fp8 mode only
-        (n, C.c_void_p) for n in ("in_proj_wf", "in_proj_bf", "in_proj_cf", "fc_wf", "fc_bf", "fc_cf")]   # bf16 mode: LayerNorm fold (optional)
+        "in_proj_cs", "out_proj_cs", "fc_cs", "proj_cs")] + [("act_scale", C.c_float * 4)]     # fp8 mode only
 
 
 class VitWeights(C.Structure):
@@ -97,8 +96,6 @@ SIGNATURES = {
     "cmh_attention": (C.c_int, [_i32, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "cmh_gemm_tuning": (C.c_int, [_i32, _i32]),
     "cmh_set_pooled_tail": (C.c_int, [_i32]),
-    "cmh_set_ln_fold": (C.c_int, [_i32]),
-    "cmh_set_gemm_big": (C.c_int, [_i32]),
     "cmh_set_gemm_rows": (C.c_int, [_i32]),
     "cmh_msl_workspace_bytes": (_sz, [_i32]),
     "cmh_msl_loss": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _sz, _p]),
@@ -118,8 +115,6 @@ SIGNATURES = {
     "cmh_prof_gemm_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "cmh_prof_gemm_by_kernel": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "cmh_cast_f32_to_bf16": (C.c_int, [_p, _p, _i64, _p]),
-    "cmh_ln_fold_weight": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p]),
-    "cmh_linear_gemm_lnfold": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p]),
     "cmh_linear_act": (C.c_int, [_p, _p, _p, _p, _f, _i32, _p, _i32, _i32, _i32, _p]),
     "cmh_pair_softmax": (C.c_int, [_p, _p, _i32, _i32, _p]),
     "cmh_sign_codes": (C.c_int, [_p, _p, _i64, _p]),
@@ -276,22 +271,6 @@ def cast_bf16(src: torch.Tensor) -> torch.Tensor:
     return dst
 
 
-def ln_fold_weight(w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, bias):
-    """Linear weight [N, K] with the LayerNorm before it folded in -> (fp16 w * gamma, f32 bias + w . beta, f32 row sums of the fp16
-    weight): the operands of the GEMM that normalises in its epilogue (include/cmh.h: cmh_ln_fold_weight)."""
-    w = f32c(w.detach())
-    require_gpu(w)
-    N_, K_ = w.shape
-    gamma, beta = f32c(gamma.detach()), f32c(beta.detach())
-    bias = None if bias is None else f32c(bias.detach())
-    wf = torch.empty(N_, K_, dtype=torch.float16, device=w.device)
-    bf = torch.empty(N_, dtype=torch.float32, device=w.device)
-    cf = torch.empty(N_, dtype=torch.float32, device=w.device)
-    check(lib().cmh_ln_fold_weight(ptr(w), ptr(gamma), ptr(beta), ptr(bias), ptr(wf), ptr(bf), ptr(cf), N_, K_, stream_ptr(w.device)),
-          "cmh_ln_fold_weight")
-    return wf, bf, cf
-
-
 def _kind(t: torch.Tensor) -> int:
     return {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[t.dtype]
 
@@ -359,60 +338,9 @@ def linear_gemm_fp8(x8, w8, colscale, alpha, bias=None, residual=None, quickgelu
     return o
 
 
-def linear_gemm_ln_producer(x, w, bias, residual, out=None, part=None):
-    """A residual GEMM of the bf16 mode that also leaves the row statistics of its fp16 output for the LayerNorm folded into the next
-    GEMM: returns (out fp16 [M, N], part f32 [N/256, M, 2]).  x, w bf16; residual fp16 (include/cmh.h: cmh_linear_gemm_lnfold, mode 1)."""
-    require_gpu(x, w, bias, residual)
-    x, w, residual = x.contiguous(), w.contiguous(), residual.contiguous()
-    M, K = x.shape
-    Nn = w.shape[0]
-    if out is None:
-        out = torch.empty(M, Nn, dtype=torch.float16, device=x.device)
-    if part is None:
-        part = torch.zeros(Nn // 256, M, 2, dtype=torch.float32, device=x.device)
-    epi = EPI_BIAS | EPI_RESIDUAL | EPI_RES_F16 | EPI_OUT_F16
-    check(lib().cmh_linear_gemm_lnfold(ptr(x), ptr(w), ptr(f32c(bias)), ptr(residual), ptr(out), M, Nn, K, epi, 1, ptr(part), None,
-                                       stream_ptr(x.device)), "cmh_linear_gemm_lnfold")
-    return out, part
-
-
-def linear_gemm_ln_consumer(x16, part, wf, bf, cf, quickgelu=False):
-    """epi(LayerNorm(x16) @ w0.T + b0) as bf16, from the raw fp16 rows, the producer's statistics and ln_fold_weight's operands (mode 2)."""
-    require_gpu(x16, part, wf, bf, cf)
-    x16, wf = x16.contiguous(), wf.contiguous()
-    M, K = x16.shape
-    Nn = wf.shape[0]
-    out = torch.empty(M, Nn, dtype=torch.bfloat16, device=x16.device)
-    epi = EPI_BIAS | EPI_OUT_BF16 | (EPI_QUICKGELU if quickgelu else 0)
-    check(lib().cmh_linear_gemm_lnfold(ptr(x16), ptr(wf), ptr(bf), None, ptr(out), M, Nn, K, epi, 2, ptr(part), ptr(cf),
-                                       stream_ptr(x16.device)), "cmh_linear_gemm_lnfold")
-    return out
-
-
 def set_pooled_tail(on: bool):
     """Carry only the pooled rows through the last block of encode_image / encode_text (default on; include/cmh.h)."""
     check(lib().cmh_set_pooled_tail(1 if on else 0), "cmh_set_pooled_tail")
-
-
-_ln_fold = -1
-
-
-def set_ln_fold(on: int = -1):
-    """LayerNorms folded into the GEMMs around them (bf16 mode, > 2048 rows; include/cmh.h): 1 on, 0 off, -1 = environment
-    (CMH_LN_FOLD=1; the default is off)."""
-    global _ln_fold
-    check(lib().cmh_set_ln_fold(int(on)), "cmh_set_ln_fold")
-    _ln_fold = int(on)
-
-
-def ln_fold_requested() -> bool:
-    """Should the towers' weight caches hold the folded copies of in_proj / c_fc?"""
-    return _ln_fold == 1 if _ln_fold >= 0 else os.environ.get("CMH_LN_FOLD", "0") == "1"
-
-
-def set_gemm_big(on: int = -1):
-    """Many-tile bf16 GEMMs on 256 x 256 tiles (csrc/gemm_big.hip; off by default): 1 on, 0 off, -1 = environment (CMH_GEMM_BIG=1)."""
-    check(lib().cmh_set_gemm_big(int(on)), "cmh_set_gemm_big")
 
 
 def set_gemm_rows(on: int = -1):

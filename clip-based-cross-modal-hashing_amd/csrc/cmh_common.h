@@ -121,19 +121,9 @@ __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + e
 // m_dev (optional, device int32): the real row count when M is only an upper bound (packed text rows); m_hint: a likely value of
 // it for the tile-height choice (never for correctness)
 bool gemm_wide_enabled();          // false under the CMH_GEMM_WIDE=0 diagnostic (gemm.hip)
-// LayerNorm folded into the GEMM after it (gemm_wide.hip, template parameter LN; wide kernel only, bf16 mode on the fp16 stream):
-//   mode 1 (producer: a residual GEMM with fp16 output) also writes part[N/256][M][2] = per-row (sum, sum of squares) of every
-//          256-column panel of its output;
-//   mode 2 (consumer: QKV / c_fc with bf16 output) takes A = the RAW fp16 stream, W = the fp16 weight with gamma folded in, bias =
-//          b + W beta, colsum = row sums of that weight, and normalises in its epilogue from part[nparts][M][2].
-struct LnFold { int mode; float* part; const float* colsum; int nparts; };
 bool gemm_rows_takes(int M, int N, int K, int epi);   // gemm_rows.hip: this launch would run on the few-row kernel
 int launch_gemm(int dt, const void* A, const void* W, const float* bias, const float* residual,
-                void* out, int M, int N, int K, int epi, hipStream_t st, const int32_t* m_dev = nullptr, int m_hint = -1,
-                const LnFold* ln = nullptr);
-// W' = fp16(W * gamma[k]), bias' = bias + W beta, colsum[n] = sum_k W'[n,k] (of the rounded values): the operands of a mode-2 launch
-int launch_ln_fold_weight(const float* w, const float* gamma, const float* beta, const float* bias, void* w_f16, float* bias_out,
-                          float* colsum_out, int N, int K, hipStream_t st);
+                void* out, int M, int N, int K, int epi, hipStream_t st, const int32_t* m_dev = nullptr, int m_hint = -1);
 // C = epilogue(alpha * colscale[n] * (A8 . W8^T)): OCP e4m3 operands [M,K] / [N,K] (K % 128 == 0, N % 256 == 0), f32 accumulate;
 // out f32 | bf16 | fp16 | (EPI_OUT_FP8) e4m3 of v * oscale.  EPI_SCALE is implied.
 int launch_gemm_fp8(const void* A8, const void* W8, const float* colscale, float alpha, const float* bias, const float* residual,

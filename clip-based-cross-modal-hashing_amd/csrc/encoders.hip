@@ -52,7 +52,6 @@ struct TowerBufs {
   int32_t* rows;
   void* pool;
   int32_t* seq;     // [B + 2] packed text: row offsets of the captions, seq[B] = the packed row count (read by the kernels themselves)
-  float* lnstat;    // [d / 256][M][2] per-row (sum, sum of squares) of the stream as the last residual GEMM wrote it (LayerNorm fold)
   size_t total;
 };
 
@@ -67,7 +66,6 @@ static TowerBufs carve(void* ws, size_t M, size_t B, size_t d, size_t e, size_t 
   t.rows = static_cast<int32_t*>(a.take(B * 4));
   t.pool = a.take(B * d * e);
   t.seq = static_cast<int32_t*>(a.take((B + 2) * 4));
-  t.lnstat = static_cast<float*>(a.take(((d + 255) / 256) * M * 2 * 4));
   t.total = a.off;
   return t;
 }
@@ -103,45 +101,10 @@ static int run_block_fp8(const cmh_block_weights& w, const TowerBufs& t, int B, 
   return CMH_OK;
 }
 
-// LayerNorm fold (bf16 mode, fp16 stream; gemm_wide.hip, template parameter LN): which of a block's LayerNorms are applied by the
-// GEMM after them instead of a launch of their own, and which residual GEMMs leave the row statistics for the next one.
-enum : int {
-  FOLD_LN1 = 1,        // ln_1: in_proj reads the raw stream; the statistics were left by the previous block's c_proj
-  FOLD_LN2 = 2,        // ln_2: c_fc reads the raw stream; out_proj leaves the statistics
-  FOLD_EMIT_NEXT = 4   // c_proj leaves the statistics for the next block's ln_1
-};
-// Default OFF (measured, profiles/r03_g_lnfold_ab.txt): the fold removes 46 LayerNorm launches per step, but the GEMMs that take them
-// over lose as much as the launches cost - the f16 MFMA on the raw stream clocks lower than the bf16 one on normalised rows, and the
-// statistics cost the epilogues (where the matrix pipe idles on every CU) more than a bandwidth-bound LayerNorm kernel costs.
-static int g_ln_fold = -1;   // cmh_set_ln_fold: -1 = from the environment (CMH_LN_FOLD=1 switches it on)
-static bool ln_fold_env() {
-  static const bool on = []() { const char* e = getenv("CMH_LN_FOLD"); return e && !strcmp(e, "1"); }();
-  return g_ln_fold < 0 ? on : g_ln_fold != 0;
-}
-// Can this tower call fold at all?  bf16 mode on the fp16 stream, the folded weights present, every GEMM on the wide kernel (the
-// few-row kernel has no fold: batches of <= 2048 rows keep their LayerNorm launches), not the calibration pass.
-static bool ln_fold_usable(const cmh_block_weights* blocks, int layers, int dtb, const TowerBufs& t, int M, int d, const int32_t* md,
-                           const float* amax) {
-  if (dtb != CMH_BF16 || !t.xh || amax || layers < 2 || !ln_fold_env() || !gemm_wide_enabled() || d % 256 != 0) return false;
-  // (M: the dense row count also for packed text, so that packed and dense captions of one batch take the same arithmetic)
-  if (gemm_rows_takes(M, d, d, EPI_BIAS | EPI_RESIDUAL | EPI_RES_F16 | EPI_OUT_F16)) return false;
-  for (int i = 0; i < layers; ++i)
-    if (!blocks[i].in_proj_wf || !blocks[i].in_proj_bf || !blocks[i].in_proj_cf || !blocks[i].fc_wf || !blocks[i].fc_bf || !blocks[i].fc_cf)
-      return false;
-  return true;
-}
-// block i of `layers`: ln_1 folds from block 1 on, ln_2 up to the last block but one (the last block's MLP may run on the pooled rows
-// only, on the few-row kernel: it keeps its LayerNorm whether the tail is pooled or not, so both give the same bits)
-static int fold_flags(bool usable, int i, int layers) {
-  if (!usable) return 0;
-  return (i >= 1 ? FOLD_LN1 : 0) | (i + 1 < layers ? FOLD_LN2 | FOLD_EMIT_NEXT : 0);
-}
-
 static int run_block(const cmh_block_weights& w, int dt, const TowerBufs& t, int B, int T, int d, int causal,
                      const uint8_t* kpm, hipStream_t st, int rows = -1, const int32_t* seq_off = nullptr,
                      float* amax = nullptr,     // amax [4] (bf16 mode): running maxima of the four GEMM inputs (fp8 calibration)
-                     const int32_t* md = nullptr, int mh = -1,     // md: the packed row count on the device (rows = upper bound)
-                     int fold = 0) {                               // FOLD_* (bf16 mode only)
+                     const int32_t* md = nullptr, int mh = -1) {   // md: the packed row count on the device (rows = upper bound)
   const int M = rows >= 0 ? rows : B * T;      // packed variable-length text: `rows` real rows, T = the longest sequence
   if (dt == CMH_FP8) return run_block_fp8(w, t, B, T, d, causal, kpm, st, M, seq_off, md, mh);
   const int obf = dt == CMH_BF16 ? EPI_OUT_BF16 : 0;
@@ -162,24 +125,13 @@ static int run_block(const cmh_block_weights& w, int dt, const TowerBufs& t, int
     if ((rc = launch_amax(t.mlp, kBF16, n * 4, amax + 3, st))) return rc;
     return launch_gemm(dt, t.mlp, w.proj_w, w.proj_b, t.x, t.x, M, d, 4 * d, rx, st);
   }
-  const LnFold emit{1, t.lnstat, nullptr, 0};
-  const LnFold use1{2, t.lnstat, w.in_proj_cf, d / 256}, use2{2, t.lnstat, w.fc_cf, d / 256};
-  if (fold & FOLD_LN1) {
-    if ((rc = launch_gemm(dt, t.x, w.in_proj_wf, w.in_proj_bf, nullptr, t.qkv, M, 3 * d, d, EPI_BIAS | obf, st, md, mh, &use1))) return rc;
-  } else {
-    if ((rc = launch_layernorm_x(t.x, t.xh, nullptr, w.ln1_w, w.ln1_b, t.h, dt == CMH_BF16, M, d, st, md))) return rc;
-    if ((rc = launch_gemm(dt, t.h, w.in_proj_w, w.in_proj_b, nullptr, t.qkv, M, 3 * d, d, EPI_BIAS | obf, st, md, mh))) return rc;
-  }
+  if ((rc = launch_layernorm_x(t.x, t.xh, nullptr, w.ln1_w, w.ln1_b, t.h, dt == CMH_BF16, M, d, st, md))) return rc;
+  if ((rc = launch_gemm(dt, t.h, w.in_proj_w, w.in_proj_b, nullptr, t.qkv, M, 3 * d, d, EPI_BIAS | obf, st, md, mh))) return rc;
   if ((rc = launch_attention_varlen(t.qkv, t.h, dt, B, T, d, causal, kpm, seq_off, st))) return rc;
-  if ((rc = launch_gemm(dt, t.h, w.out_proj_w, w.out_proj_b, t.x, t.x, M, d, d, rx, st, md, mh, (fold & FOLD_LN2) ? &emit : nullptr))) return rc;
-  if (fold & FOLD_LN2) {
-    if ((rc = launch_gemm(dt, t.x, w.fc_wf, w.fc_bf, nullptr, t.mlp, M, 4 * d, d, EPI_BIAS | EPI_QUICKGELU | obf, st, md, mh, &use2))) return rc;
-  } else {
-    if ((rc = launch_layernorm_x(t.x, t.xh, nullptr, w.ln2_w, w.ln2_b, t.h, dt == CMH_BF16, M, d, st, md))) return rc;
-    if ((rc = launch_gemm(dt, t.h, w.fc_w, w.fc_b, nullptr, t.mlp, M, 4 * d, d, EPI_BIAS | EPI_QUICKGELU | obf, st, md, mh))) return rc;
-  }
-  if ((rc = launch_gemm(dt, t.mlp, w.proj_w, w.proj_b, t.x, t.x, M, d, 4 * d, rx, st, md, mh, (fold & FOLD_EMIT_NEXT) ? &emit : nullptr))) return rc;
-  return CMH_OK;
+  if ((rc = launch_gemm(dt, t.h, w.out_proj_w, w.out_proj_b, t.x, t.x, M, d, d, rx, st, md, mh))) return rc;
+  if ((rc = launch_layernorm_x(t.x, t.xh, nullptr, w.ln2_w, w.ln2_b, t.h, dt == CMH_BF16, M, d, st, md))) return rc;
+  if ((rc = launch_gemm(dt, t.h, w.fc_w, w.fc_b, nullptr, t.mlp, M, 4 * d, d, EPI_BIAS | EPI_QUICKGELU | obf, st, md, mh))) return rc;
+  return launch_gemm(dt, t.mlp, w.proj_w, w.proj_b, t.x, t.x, M, d, 4 * d, rx, st, md, mh);
 }
 
 // The LAST block when only the pooled feature is wanted (encode_image / encode_text, model/base/model.py:247-250, 366-370): after its
@@ -195,7 +147,7 @@ bool pooled_tail_enabled() {
 
 static int run_block_pooled(const cmh_block_weights& w, int dtb, const TowerBufs& t, int B, int T, int d, int causal,
                             const uint8_t* kpm, hipStream_t st, int M, const int32_t* seq_off, void** x_pooled,
-                            const int32_t* md = nullptr, int mh = -1, int fold = 0) {
+                            const int32_t* md = nullptr, int mh = -1) {
   const int dt = dtb == CMH_FP8 ? CMH_BF16 : dtb;
   const size_t e = dt == CMH_BF16 ? 2 : 4, xe = t.xh ? 2 : 4;
   const int obf = dt == CMH_BF16 ? EPI_OUT_BF16 : 0;
@@ -218,13 +170,8 @@ static int run_block_pooled(const cmh_block_weights& w, int dtb, const TowerBufs
                               EPI_BIAS | EPI_QUICKGELU | EPI_OUT_FP8, st))) return rc;
     if ((rc = launch_gemm_fp8(t.mlp, w.proj_w, w.proj_cs, a[3], w.proj_b, xp, xp, 1.f, B, d, 4 * d, rx, st))) return rc;
   } else {
-    if (fold & FOLD_LN1) {
-      const LnFold use1{2, t.lnstat, w.in_proj_cf, d / 256};
-      if ((rc = launch_gemm(dt, t.x, w.in_proj_wf, w.in_proj_bf, nullptr, t.qkv, M, 3 * d, d, EPI_BIAS | obf, st, md, mh, &use1))) return rc;
-    } else {
-      if ((rc = launch_layernorm_x(t.x, t.xh, nullptr, w.ln1_w, w.ln1_b, t.h, dt == CMH_BF16, M, d, st, md))) return rc;
-      if ((rc = launch_gemm(dt, t.h, w.in_proj_w, w.in_proj_b, nullptr, t.qkv, M, 3 * d, d, EPI_BIAS | obf, st, md, mh))) return rc;
-    }
+    if ((rc = launch_layernorm_x(t.x, t.xh, nullptr, w.ln1_w, w.ln1_b, t.h, dt == CMH_BF16, M, d, st, md))) return rc;
+    if ((rc = launch_gemm(dt, t.h, w.in_proj_w, w.in_proj_b, nullptr, t.qkv, M, 3 * d, d, EPI_BIAS | obf, st, md, mh))) return rc;
     if ((rc = launch_attention_varlen(t.qkv, t.h, dt, B, T, d, causal, kpm, seq_off, st))) return rc;
     if ((rc = launch_gather_rows2(t.x, xp, static_cast<int>(d * xe), t.h, hp, static_cast<int>(d * e), t.rows, B, st))) return rc;
     if ((rc = launch_gemm(dt, hp, w.out_proj_w, w.out_proj_b, xp, xp, B, d, d, rx, st))) return rc;
@@ -293,7 +240,6 @@ using namespace cmh;
 
 extern "C" const char* cmh_last_error(void) { return err_buf(); }
 extern "C" int cmh_set_pooled_tail(int32_t on) { g_pooled_tail = on ? 1 : 0; return CMH_OK; }
-extern "C" int cmh_set_ln_fold(int32_t on) { g_ln_fold = on < 0 ? -1 : (on ? 1 : 0); return CMH_OK; }
 extern "C" int cmh_version(void) { return CMH_VERSION; }
 
 extern "C" size_t cmh_vit_workspace_bytes(const cmh_vit_weights* w, int32_t batch) {
@@ -339,14 +285,12 @@ static int vit_encode_impl(const cmh_vit_weights* w, const float* image, int32_t
   const bool tail = feat && !tokens_out && !taps && !amax && w->layers > 0 && pooled_tail_enabled();
   void* x_pooled = nullptr;
   if (tail && (rc = launch_iota_rows(t.rows, B, T, st))) return rc;
-  const bool foldable = ln_fold_usable(w->blocks, w->layers, dtb, t, M, d, nullptr, amax);
   for (int i = 0; i < w->layers; ++i) {
-    const int fold = fold_flags(foldable, i, w->layers);
     if (tail && i == w->layers - 1) {
-      if ((rc = run_block_pooled(w->blocks[i], dtb, t, B, T, d, /*causal=*/0, nullptr, st, M, nullptr, &x_pooled, nullptr, -1, fold))) return rc;
+      if ((rc = run_block_pooled(w->blocks[i], dtb, t, B, T, d, /*causal=*/0, nullptr, st, M, nullptr, &x_pooled))) return rc;
       break;
     }
-    if ((rc = run_block(w->blocks[i], dtb, t, B, T, d, /*causal=*/0, nullptr, st, -1, nullptr, amax ? amax + 4 * i : nullptr, nullptr, -1, fold))) return rc;
+    if ((rc = run_block(w->blocks[i], dtb, t, B, T, d, /*causal=*/0, nullptr, st, -1, nullptr, amax ? amax + 4 * i : nullptr))) return rc;
     if ((rc = tap(taps, 1 + i, t.x, static_cast<size_t>(M) * d * 4, st))) return rc;
   }
   if (tokens_out) {
@@ -442,14 +386,12 @@ static int text_encode_impl(const cmh_text_weights* w, const int64_t* tokens, in
                                      w->vocab_size, seq_off, st))) return rc;
   const bool tail = feat && !tokens_out && !taps && !amax && !eot_rows_out && w->layers > 0 && pooled_tail_enabled();
   void* x_pooled = nullptr;
-  const bool foldable = ln_fold_usable(w->blocks, w->layers, dtb, t, M, d, md, amax);
   for (int i = 0; i < w->layers; ++i) {
-    const int fold = fold_flags(foldable, i, w->layers);
     if (tail && i == w->layers - 1) {
-      if ((rc = run_block_pooled(w->blocks[i], dtb, t, B, L, d, /*causal=*/1, key_padding_mask, st, rows, seq_off, &x_pooled, md, mh, fold))) return rc;
+      if ((rc = run_block_pooled(w->blocks[i], dtb, t, B, L, d, /*causal=*/1, key_padding_mask, st, rows, seq_off, &x_pooled, md, mh))) return rc;
       break;
     }
-    if ((rc = run_block(w->blocks[i], dtb, t, B, L, d, /*causal=*/1, key_padding_mask, st, rows, seq_off, amax ? amax + 4 * i : nullptr, md, mh, fold))) return rc;
+    if ((rc = run_block(w->blocks[i], dtb, t, B, L, d, /*causal=*/1, key_padding_mask, st, rows, seq_off, amax ? amax + 4 * i : nullptr, md, mh))) return rc;
     if ((rc = tap(taps, 1 + i, t.x, static_cast<size_t>(M) * d * 4, st))) return rc;
   }
   if (tokens_out) {
@@ -535,15 +477,6 @@ extern "C" int cmh_linear_gemm(int32_t dtype, const void* x, const void* w, cons
                                void* out, int32_t M, int32_t N, int32_t K, int32_t epilogue, void* stream) {
   CMH_CHECK_ARG(x && w && out, "linear_gemm: null pointer");
   return launch_gemm(dtype, x, w, bias, residual, out, M, N, K, epilogue, as_stream(stream));
-}
-
-extern "C" int cmh_linear_gemm_lnfold(const void* x, const void* w, const float* bias, const void* residual, void* out, int32_t M,
-                                      int32_t N, int32_t K, int32_t epilogue, int32_t ln_mode, float* ln_part, const float* ln_colsum,
-                                      void* stream) {
-  CMH_CHECK_ARG(x && w && out && ln_part, "linear_gemm_lnfold: null pointer");
-  CMH_CHECK_ARG(ln_mode == 1 || ln_mode == 2, "linear_gemm_lnfold: mode %d (1 producer, 2 consumer)", ln_mode);
-  const LnFold ln{ln_mode, ln_part, ln_colsum, ln_mode == 2 ? K / 256 : 0};
-  return launch_gemm(CMH_BF16, x, w, bias, static_cast<const float*>(residual), out, M, N, K, epilogue, as_stream(stream), nullptr, -1, &ln);
 }
 
 extern "C" int cmh_layernorm(const float* x, const float* w, const float* b, void* out, int32_t out_dtype, int32_t M,

@@ -1,25 +1,15 @@
-// GEMM with fused epilogue for the CLIP towers:  out[M,N] = epi( X[M,K] . W[N,K]^T )
+// GEMM dispatch for the CLIP towers:  out[M,N] = epi( X[M,K] . W[N,K]^T )
 //
 // Replaces every nn.Linear / in_proj / conv1-as-GEMM of the reference's transformer blocks
 // (model/base/model.py:171-196 ResidualAttentionBlock, :215 conv1, :250 proj, :370 text_projection).
 //
-// gfx950 design
-//  * one 128(n) x 128(m) output tile per 256-thread workgroup, 4 waves as 2(n) x 2(m), each wave a
-//    64x64 sub-tile = 4x4 MFMA 16x16 accumulators (64 acc VGPRs).
-//  * operands are both K-contiguous ([rows, K] row-major), so W rows feed the MFMA "A" operand and X
-//    rows the "B" operand: D = W_tile . X_tile^T, i.e. each lane ends up with 4 CONSECUTIVE n for one
-//    m -> 16-byte (f32) / 8-byte (bf16) epilogue loads+stores, bias as one float4.
-//  * a tile row is always 128 bytes: 64 bf16 (BK=64, v_mfma_f32_16x16x32_bf16, 2 k-steps) or 32 f32
-//    (BK=32, v_mfma_f32_16x16x4_f32, exact fp32 FMA chain; k is visited in a permuted order so one
-//    ds_read_b128 feeds 4 MFMAs).  Same staging code for both dtypes.
-//  * LDS image [128 rows][8 chunks of 16 B], chunk index XOR (row & 7): conflict-free for both the
-//    ds_write_b128 of the staging pass (8 lanes cover one 128-B row) and the ds_read_b128 fragment
-//    reads (16 lanes of a read group hit 16 distinct (row parity, chunk) pairs).
-//  * global -> register -> LDS double buffering, one barrier per K-step; loads for step k+1 are issued
-//    before the MFMAs of step k.
-//  * XCD-aware tile order: blocks that share an XCD (blockIdx % 8) walk n fastest over a contiguous
-//    range of tiles, so an X panel is re-used from that XCD's L2 across the N/128 column tiles and
-//    the whole W (<= 4.7 MB bf16) stays L2-resident.
+// This file only CHOOSES the kernel and carries the measurement hook (cmh_prof_gemm_*):
+//   N % 256 == 0 (every ViT-B/32 encoder GEMM)          -> gemm_wide_kernel   (gemm_wide.hip: 160/128/96 x 256 persistent tiles)
+//   ... and M <= 2048 rows (pooled tail, projections)    -> gemm_rows_kernel   (gemm_rows.hip: 64 x 64 tiles, the same bits)
+//   N % 128 == 0 only (test-sized towers, width 128/384) -> gemm_glds_kernel   (gemm_glds.hip: 128 x 128 LDS-DMA tiles)
+// Round 1's register-staged 128 x 128 kernel (CMH_GEMM_IMPL=regstage) and round 3's two measured-slower experiments (the 256 x 256
+// "big" tile, the LayerNorm fold inside the wide kernel) left the tree in round 4; DESIGN.md 4.3 keeps their numbers, git history
+// (commit 20b80d8 and before) their code.
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -31,172 +21,7 @@
 
 namespace cmh {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
-
-constexpr int kTile = 128;             // rows per operand tile
-constexpr int kRowBytes = 128;         // bytes per tile row
-constexpr int kTileBytes = kTile * kRowBytes;
-
-__device__ __forceinline__ int swz(int row, int chunk) { return row * kRowBytes + ((chunk ^ (row & 7)) << 4); }
-
-__device__ __forceinline__ float quick_gelu(float v) { return v / (1.0f + __expf(-1.702f * v)); }
-
-template <bool F32>
-__global__ __launch_bounds__(256) void gemm_kernel(const char* __restrict__ X, const char* __restrict__ W,
-                                                   const float* __restrict__ bias,
-                                                   const float* residual, void* out,
-                                                   int M, int N, int K, int epi) {
-  __shared__ __attribute__((aligned(16))) char lds[2][2][kTileBytes];   // [buf][0=W,1=X]
-
-  constexpr int ELT = F32 ? 4 : 2;
-  constexpr int BK = kRowBytes / ELT;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = tid >> 6;
-  const int wn = wid >> 1, wm = wid & 1;
-
-  // ---- XCD-aware, bijective block -> tile map ------------------------------------------------
-  const int tiles_n = N / kTile;
-  const int tiles_m = (M + kTile - 1) / kTile;
-  const int total = tiles_n * tiles_m;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, local = bid >> 3;
-  const int q = total >> 3, r = total & 7;
-  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-  const int tile_m = logical / tiles_n;
-  const int tile_n = logical - tile_m * tiles_n;
-  const int m0 = tile_m * kTile, n0 = tile_n * kTile;
-
-  // ---- staging: each thread moves 4 x 16 B of the W tile and 4 x 16 B of the X tile ---------
-  const size_t row_stride = static_cast<size_t>(K) * ELT;
-  const char* gW[4];
-  const char* gX[4];
-  int lds_off[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int id = tid + 256 * i;
-    const int row = id >> 3, c = id & 7;
-    lds_off[i] = swz(row, c);
-    gW[i] = W + static_cast<size_t>(n0 + row) * row_stride + c * 16;
-    int xr = m0 + row;
-    xr = xr < M ? xr : M - 1;   // clamp: rows past M are computed on duplicated data, never stored
-    gX[i] = X + static_cast<size_t>(xr) * row_stride + c * 16;
-  }
-
-  f32x4_t acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  u32x4_t rW[4], rX[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    rW[i] = *reinterpret_cast<const u32x4_t*>(gW[i]);
-    rX[i] = *reinterpret_cast<const u32x4_t*>(gX[i]);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    *reinterpret_cast<u32x4_t*>(&lds[0][0][lds_off[i]]) = rW[i];
-    *reinterpret_cast<u32x4_t*>(&lds[0][1][lds_off[i]]) = rX[i];
-  }
-  __syncthreads();
-
-  const int nk = K / BK;
-  const int frow = lane & 15;     // row inside a 16-row fragment
-  const int fq = lane >> 4;       // k-group of the lane
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      const size_t koff = static_cast<size_t>(kt + 1) * kRowBytes;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        rW[i] = *reinterpret_cast<const u32x4_t*>(gW[i] + koff);
-        rX[i] = *reinterpret_cast<const u32x4_t*>(gX[i] + koff);
-      }
-    }
-    const char* tW = &lds[cur][0][0];
-    const char* tX = &lds[cur][1][0];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int chunk = ks * 4 + fq;
-      u32x4_t fw[4], fx[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        fw[t] = *reinterpret_cast<const u32x4_t*>(tW + swz(wn * 64 + t * 16 + frow, chunk));
-        fx[t] = *reinterpret_cast<const u32x4_t*>(tX + swz(wm * 64 + t * 16 + frow, chunk));
-      }
-      if constexpr (F32) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fw[a][s]),
-                                                               __uint_as_float(fx[b][s]), acc[a][b], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[a]),
-                                                                __builtin_bit_cast(bf16x8_t, fx[b]),
-                                                                acc[a][b], 0, 0, 0);
-      }
-    }
-    if (kt + 1 < nk) {
-      const int nxt = cur ^ 1;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<u32x4_t*>(&lds[nxt][0][lds_off[i]]) = rW[i];
-        *reinterpret_cast<u32x4_t*>(&lds[nxt][1][lds_off[i]]) = rX[i];
-      }
-    }
-    __syncthreads();
-  }
-
-  // ---- epilogue: lane holds n = nbase + 4*fq + {0..3} for m = mbase + frow -------------------
-#pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    const int m = m0 + wm * 64 + b * 16 + frow;
-    if (m >= M) continue;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int n = n0 + wn * 64 + a * 16 + fq * 4;
-      f32x4_t v = acc[a][b];
-      if (epi & EPI_BIAS) {
-        const f32x4_t bv = *reinterpret_cast<const f32x4_t*>(bias + n);
-        v += bv;
-      }
-      if (epi & EPI_QUICKGELU) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = quick_gelu(v[j]);
-      }
-      if (epi & (EPI_GELU | EPI_RELU)) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (epi & EPI_GELU) ? gelu_erf(v[j]) : fmaxf(v[j], 0.f);
-      }
-      const size_t o = static_cast<size_t>(m) * N + n;
-      if (epi & EPI_RESIDUAL) {
-        const f32x4_t rv = *reinterpret_cast<const f32x4_t*>(residual + o);
-        v += rv;
-      }
-      if (epi & EPI_OUT_BF16) {
-        uint2 pk;
-        pk.x = static_cast<uint32_t>(f32_to_bf16(v[0])) | (static_cast<uint32_t>(f32_to_bf16(v[1])) << 16);
-        pk.y = static_cast<uint32_t>(f32_to_bf16(v[2])) | (static_cast<uint32_t>(f32_to_bf16(v[3])) << 16);
-        *reinterpret_cast<uint2*>(static_cast<bf16_t*>(out) + o) = pk;
-      } else {
-        *reinterpret_cast<f32x4_t*>(static_cast<float*>(out) + o) = v;
-      }
-    }
-  }
-}
+constexpr int kTile = 128;             // N granule of the smallest tile any GEMM kernel of the library has
 
 // ---- optional launch timing (bench.py roofline): HIP events around every GEMM launch on its own stream ----
 struct GemmProf {
@@ -217,12 +42,9 @@ int launch_gemm_rows(int dt, const void* A, const void* W, const float* bias, co
                      int epi, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 int launch_gemm_rows_fp8(const void* A, const void* W, const float* colscale, float alpha, const float* bias, const float* residual,
                          void* out, float oscale, int M, int N, int K, int epi, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
-bool gemm_big_takes(int dt, int M, int N, int K, int epi, const void* residual);   // gemm_big.hip: 256 x 256 tiles (in_proj / c_fc)
-int launch_gemm_big(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int epi, hipStream_t st,
-                    const int32_t* m_dev, hipEvent_t ev0, hipEvent_t ev1);
 int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out,
                      int M, int N, int K, int epi, hipStream_t st, const float* colscale = nullptr, float alpha = 1.f,
-                     float oscale = 1.f, const int32_t* m_dev = nullptr, int m_hint = -1, const LnFold* ln = nullptr);
+                     float oscale = 1.f, const int32_t* m_dev = nullptr, int m_hint = -1);
 
 // the measurement hook counts algorithmic FLOPs on REAL rows: with a device-side row count it reads that count back (a stream
 // synchronisation, inside a profiled run only)
@@ -233,12 +55,6 @@ static int prof_real_rows(int M, const int32_t* m_dev, hipStream_t st) {
   return v > 0 && v < M ? v : M;
 }
 
-// CMH_GEMM_IMPL=regstage selects the v1 register-staged kernel (A/B testing); default = LDS-DMA kernel.
-static int gemm_impl_from_env() {
-  const char* e = getenv("CMH_GEMM_IMPL");
-  return (e && !strcmp(e, "regstage")) ? 0 : 1;
-}
-
 // CMH_GEMM_WIDE=0 (A/B against round 1's 128 x 128 kernels): launches that do not need the wide kernel's epilogues avoid it
 bool gemm_wide_enabled() {
   static const bool wide = []() { const char* e = getenv("CMH_GEMM_WIDE"); return !(e && !strcmp(e, "0")); }();
@@ -246,10 +62,8 @@ bool gemm_wide_enabled() {
 }
 
 int launch_gemm(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out,
-                int M, int N, int K, int epi, hipStream_t st, const int32_t* m_dev, int m_hint, const LnFold* ln) {
+                int M, int N, int K, int epi, hipStream_t st, const int32_t* m_dev, int m_hint) {
   const int bk = dt == CMH_F32 ? 32 : 64;
-  if (ln && !ln->mode) ln = nullptr;
-  CMH_CHECK_ARG(!ln || (gemm_wide_supported(N) && gemm_wide_enabled()), "gemm: the LayerNorm fold needs the wide kernel (N %% 256 == 0, N=%d)", N);
   CMH_CHECK_ARG(dt == CMH_F32 || dt == CMH_BF16, "gemm: bad dtype %d", dt);
   CMH_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
   CMH_CHECK_ARG(N % kTile == 0, "gemm: N=%d must be a multiple of %d", N, kTile);
@@ -258,19 +72,14 @@ int launch_gemm(int dt, const void* A, const void* W, const float* bias, const f
   CMH_CHECK_ARG(!(epi & EPI_RESIDUAL) || residual, "gemm: EPI_RESIDUAL without residual");
   CMH_CHECK_ARG(!(epi & (EPI_RES_F16 | EPI_OUT_F16)) || (gemm_wide_supported(N) && !(epi & EPI_OUT_BF16)),
                 "gemm: fp16 residual / output needs N %% 256 == 0 (N=%d) and excludes EPI_OUT_BF16", N);
-  const int total = (N / kTile) * ((M + kTile - 1) / kTile);
   const bool timed = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
-  static const int impl = gemm_impl_from_env();
   static const bool wide = gemm_wide_enabled();
   // the wide kernel's launch stamps the event pair with its own begin / end (gemm_wide_time_next); the fallback kernels are
   // bracketed by two recorded events; CMH_GEMM_PROF_BRACKET=1 brackets every launch (round 1-2's method, for comparison)
   static const bool bracket = []() { const char* e = getenv("CMH_GEMM_PROF_BRACKET"); return e && e[0] == '1'; }();
-  const bool takes_rows = wide && !m_dev && !ln && gemm_rows_takes(M, N, K, epi);   // (it reproduces the wide kernel's bits: off with it)
-  // (the tile count is judged on the likely row count when the real one lives on the device)
-  const bool takes_big = !takes_rows && wide && impl == 1 && !ln && (!(epi & EPI_BIAS) || bias) &&
-                         gemm_big_takes(dt, m_dev && m_hint > 0 && m_hint <= M ? m_hint : M, N, K, epi, residual);
-  const bool takes_wide = !takes_rows && !takes_big && (ln || (impl == 1 && wide && gemm_wide_supported(N)) || (epi & (EPI_RES_F16 | EPI_OUT_F16 | EPI_MUL_DQGELU | EPI_SAVE_PRE)));
-  const bool self_timed = timed && (takes_wide || takes_rows || takes_big) && !bracket;
+  const bool takes_rows = wide && !m_dev && gemm_rows_takes(M, N, K, epi);   // (it reproduces the wide kernel's bits: off with it)
+  const bool takes_wide = !takes_rows && ((wide && gemm_wide_supported(N)) || (epi & (EPI_RES_F16 | EPI_OUT_F16 | EPI_MUL_DQGELU | EPI_SAVE_PRE)));
+  const bool self_timed = timed && (takes_wide || takes_rows) && !bracket;
   hipEvent_t ev0 = self_timed ? g_prof.ev[g_prof.used] : nullptr, ev1 = self_timed ? g_prof.ev[g_prof.used + 1] : nullptr;
   if (timed && !self_timed) (void)hipEventRecord(g_prof.ev[g_prof.used], st);
   CMH_CHECK_ARG(!(epi & EPI_MUL_DQGELU) || (residual && gemm_wide_supported(N) && !(epi & (EPI_RESIDUAL | EPI_OUT_F16))),
@@ -281,30 +90,22 @@ int launch_gemm(int dt, const void* A, const void* W, const float* bias, const f
   if (takes_rows) {
     const int rc = launch_gemm_rows(dt, A, W, bias, residual, out, M, N, K, epi, st, ev0, ev1);
     if (rc) return rc;
-  } else if (takes_big) {
-    const int rc = launch_gemm_big(A, W, bias, out, M, N, K, epi, st, m_dev, ev0, ev1);
-    if (rc) return rc;
   } else if (takes_wide) {
     if (self_timed) gemm_wide_time_next(ev0, ev1);
-    const int rc = launch_gemm_wide(dt, A, W, bias, residual, out, M, N, K, epi, st, nullptr, 1.f, 1.f, m_dev, m_hint, ln);
+    const int rc = launch_gemm_wide(dt, A, W, bias, residual, out, M, N, K, epi, st, nullptr, 1.f, 1.f, m_dev, m_hint);
     gemm_wide_time_next(nullptr, nullptr);
     if (rc) return rc;
   } else if (m_dev) {
     return fail(CMH_ERR_INVALID, "gemm: a device-side row count needs the wide kernel (N %% 256 == 0, N=%d)", N);
-  } else if (impl == 1)
+  } else {
     launch_gemm_glds(dt, A, W, bias, residual, out, M, N, K, epi, st);
-  else if (dt == CMH_F32)
-    hipLaunchKernelGGL(gemm_kernel<true>, dim3(total), dim3(256), 0, st, static_cast<const char*>(A),
-                       static_cast<const char*>(W), bias, residual, out, M, N, K, epi);
-  else
-    hipLaunchKernelGGL(gemm_kernel<false>, dim3(total), dim3(256), 0, st, static_cast<const char*>(A),
-                       static_cast<const char*>(W), bias, residual, out, M, N, K, epi);
+  }
   if (timed) {
     if (!self_timed) (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
     const int Mr = prof_real_rows(M, m_dev, st);
     g_prof.flops.push_back(2.0 * Mr * static_cast<double>(N) * K);   // algorithmic FLOPs: real rows only
     g_prof.dims.push_back({Mr, N, K, epi});
-    g_prof.kind.push_back(takes_rows ? 1 : (takes_wide || takes_big ? 0 : 2));
+    g_prof.kind.push_back(takes_rows ? 1 : (takes_wide ? 0 : 2));
     g_prof.used += 2;
   }
   CMH_CHECK_LAUNCH("gemm");

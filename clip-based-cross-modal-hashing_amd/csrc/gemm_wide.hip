@@ -104,10 +104,6 @@ struct WideScales {
   int kreal;               // TN: rows of the K-major operands that exist (K is padded to whole K-steps)
   float* colsum;           // TN, optional: [ksplit, M] partial column sums of the Xk operand (wgrad: the bias gradient's first stage)
   const int* m_dev;        // optional: the real row count on the device (M is then an upper bound)
-  // LayerNorm folded into the GEMM that follows it (LN = 1 / 2 instantiations, see the template):
-  float* ln_part;          // [parts][Mub][2] f32: per-row (sum, sum of squares) of each 256-column panel of a residual GEMM's fp16 output
-  const float* ln_cs;      // LN = 2: [N] row sums of the folded fp16 weight W' = W * gamma
-  int ln_nparts;           // LN = 2: panels to add up (= width / 256)
 };
 
 // TN operands (wgrad: dW[O,I] = dY^T X with dY [M,O] and X [M,I] as the backward pass has them, the reduction index m being the
@@ -119,15 +115,7 @@ struct WideScales {
 __device__ const uint4 g_wide_zero[16] = {};   // 256 zero bytes: the source of k-rows past the end of the Xk operand
 typedef __attribute__((ext_vector_type(2))) uint32_t w_u32x2_t;
 
-// LayerNorm fold (bf16 mode on the fp16 residual stream, encoders.hip: run_block).  LN(x) W^T + b = rstd_m (x W'^T - mean_m colsum(W')) + b'
-// with W' = W * gamma and b' = b + W beta, so the GEMM after a LayerNorm can read the RAW fp16 stream as its X operand (LDS-DMA cannot
-// normalise on the way) and apply the row statistics in its epilogue: no LayerNorm launch, no normalised copy of the stream.
-//   LN = 1: the producer (out_proj / c_proj with fp16 output): next to its tile it leaves, per row, the sum and the sum of squares of the
-//           tile's 256 values AS ROUNDED to fp16 (v_dot2_f32_f16 on the packed output words, lanes -> waves in a fixed order, so a
-//           row's statistics do not depend on the tile height or on which rows share its tile) in ln_part[tile_n][row].
-//   LN = 2: the consumer (QKV / c_fc): fp16 operands (v_mfma_f32_16x16x32_f16, the bf16 instruction's rate; W' is an fp16 copy), epilogue
-//           acc * rstd_m + ((-mean_m rstd_m) * colsum[n] + b'[n]) with mean / variance from the panels' partial sums.
-template <int DT, int OK, int MF, bool TN = false, int LN = 0>   // DT: 0 f32, 1 bf16, 2 fp8 operands; OK: 0 f32, 1 16-bit (bf16 / fp16), 2 fp8
+template <int DT, int OK, int MF, bool TN = false>   // DT: 0 f32, 1 bf16, 2 fp8 operands; OK: 0 f32, 1 16-bit (bf16 / fp16), 2 fp8
                                     // outputs; MF = 16-row m-fragments per wave: tile rows = 32*MF (160, 128 or 96); TN: above
 __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__ X, const char* __restrict__ W,
                                                         const float* __restrict__ bias, const float* residual,
@@ -148,10 +136,8 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   constexpr int NM = 4 * MF;                         // MFMAs per 32-deep half-step
   static_assert(MF >= 3 && MF <= 5, "wave layout: 2(m) x 4(n) waves of MF x 4 fragments");
   static_assert(!TN || (DT == 1 && OK == 0 && MF == 4), "TN: bf16 operands, f32 (split-K) output, 128-row tile");
-  static_assert(LN == 0 || (DT == 1 && OK == 1 && !TN), "LayerNorm fold: 2-byte operands, 16-bit output");
   constexpr int PSTEP = MF == 3 ? 2 : 3;             // one LDS-DMA piece per PSTEP MFMAs: 6 (MF = 3, 4) or 7 pieces in 4*MF MFMAs
   __shared__ __attribute__((aligned(1024))) char lds[3 * STG];
-  __shared__ float ln_lds[LN == 1 ? 3 * BMt * 2 : 1];   // LN = 1: the row sums of waves wn = 0..2 on their way to wave wn = 3 (3840 B at 160 rows)
 
   constexpr int ELT = F32 ? 4 : (FP8 ? 1 : 2);
   constexpr int BK = wRowBytes / ELT;
@@ -404,8 +390,6 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
 #pragma unroll
       for (int s = 0; s < 4; ++s)
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fw[s]), __uint_as_float(fx[s]), c, 0, 0, 0);
-    } else if constexpr (LN == 2) {
-      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(w_f16x8_t, fw), __builtin_bit_cast(w_f16x8_t, fx), c, 0, 0, 0);
     } else {
       c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(w_bf16x8_t, fw), __builtin_bit_cast(w_bf16x8_t, fx), c,
                                                   0, 0, 0);
@@ -837,41 +821,6 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
     }
     // All loads first, then all stores: a load issued behind a store (or waited for with DMA in flight) would wait for
     // every older store to be acknowledged.
-    if constexpr (LN == 2) {
-      // the LayerNorm that preceded this GEMM: per row mean and 1/std from the producer's panel sums (fixed order), then one FMA pair per element
-      const float inv_d = 1.0f / static_cast<float>(K);
-      float rs[MF], nm[MF];
-#pragma unroll
-      for (int b = 0; b < MF; ++b) {
-        int m = m0 + wm * WR + b * 16 + frow;
-        m = m < M ? m : M - 1;
-        // all loads first (a runtime-bounded loop would wait for each panel's pair in turn: 15 L2 round trips per tile): up to four
-        // panels (width <= 1024) from clamped addresses, the ones past ln_nparts dropped by a select
-        w_f32x2_t pv[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const int pc = p < sc.ln_nparts ? p : sc.ln_nparts - 1;
-          pv[p] = *reinterpret_cast<const w_f32x2_t*>(sc.ln_part + (static_cast<size_t>(pc) * Mub + m) * 2);
-        }
-        float s1 = pv[0][0], s2 = pv[0][1];
-#pragma unroll
-        for (int p = 1; p < 4; ++p) {
-          s1 += p < sc.ln_nparts ? pv[p][0] : 0.f;
-          s2 += p < sc.ln_nparts ? pv[p][1] : 0.f;
-        }
-        const float mean = s1 * inv_d;
-        const float var = fmaxf(s2 * inv_d - mean * mean, 0.f);
-        rs[b] = __builtin_amdgcn_rsqf(var + 1e-5f);
-        nm[b] = -mean * rs[b];
-      }
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const w_f32x4_t cs = *reinterpret_cast<const w_f32x4_t*>(sc.ln_cs + n0 + wn * 64 + a * 16 + fq * 4);
-        const w_f32x4_t bv = *reinterpret_cast<const w_f32x4_t*>(bias + n0 + wn * 64 + a * 16 + fq * 4);
-#pragma unroll
-        for (int b = 0; b < MF; ++b) acc[a][b] = acc[a][b] * rs[b] + (cs * nm[b] + bv);
-      }
-    } else
     if (FP8 && (epi & EPI_SCALE)) {   // dequantisation of fp8 operands, fused with the bias: acc * (alpha * colscale[n]) + bias[n]
       // (fp8 instantiations only, one n-tile at a time: the 160-row variants have no registers to spare)
 #pragma unroll
@@ -1046,66 +995,6 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
           pend[b * 2 + pr][0] = s0[0]; pend[b * 2 + pr][1] = s1[0]; pend[b * 2 + pr][2] = s0[1]; pend[b * 2 + pr][3] = s1[1];
         }
       }
-      if constexpr (LN == 1) {
-        // row statistics of this tile's fp16 output for the LayerNorm folded into the next GEMM.  A lane holds 16 values of each of
-        // its MF rows (two packed stores of 8): sum and sum of squares by v_dot2_f32_f16 in store order, then over the four lane
-        // quarters (xor 16, xor 32), then over the four waves of a row through LDS: ((wn0 + wn1) + wn2) + wn3.
-        __builtin_amdgcn_sched_barrier(0);   // nothing of this moves up into the packing above (80 accumulators + the growing stores)
-        // (addresses from a laundered lane row: hoisted out of the tile loop they would stay live across the K loop, which has no
-        // register to spare at 160 rows - tools/asm_loop_scratch.py)
-        int frow_l = frow;
-        asm volatile("" : "+v"(frow_l));
-        const uint32_t ln_a = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((w_lptr_t)ln_lds)) + ((wm * WR + frow_l) << 3);
-        const w_f16x2_t one2 = {static_cast<_Float16>(1.0f), static_cast<_Float16>(1.0f)};
-        float s1[MF], s2[MF];
-#pragma unroll
-        for (int b = 0; b < MF; ++b) {
-          float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-          for (int pr = 0; pr < 2; ++pr)
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-              const uint32_t word = pend[b * 2 + pr][w];   // (a scalar first: __builtin_bit_cast applied to a vector ELEMENT reads element 0)
-              const w_f16x2_t h = __builtin_bit_cast(w_f16x2_t, word);
-              t1 = __builtin_amdgcn_fdot2(h, one2, t1, false);
-              t2 = __builtin_amdgcn_fdot2(h, h, t2, false);
-            }
-          // the four lane quarters of a row: v_permlane16_swap / v_permlane32_swap of a value with itself leave (even, odd) halves
-          // side by side, so two adds give every lane the total ((q0 + q1) + (q2 + q3))
-          const w_u2_t a1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(t1), __float_as_uint(t1), false, false);
-          const w_u2_t a2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(t2), __float_as_uint(t2), false, false);
-          t1 = __uint_as_float(a1[0]) + __uint_as_float(a1[1]);
-          t2 = __uint_as_float(a2[0]) + __uint_as_float(a2[1]);
-          const w_u2_t b1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t1), __float_as_uint(t1), false, false);
-          const w_u2_t b2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t2), __float_as_uint(t2), false, false);
-          s1[b] = __uint_as_float(b1[0]) + __uint_as_float(b1[1]);
-          s2[b] = __uint_as_float(b2[0]) + __uint_as_float(b2[1]);
-        }
-        if (wn < 3 && fq == 0) {
-#define W_LNW(bb) if constexpr (bb < MF) { const w_f32x2_t v = {s1[bb < MF ? bb : 0], s2[bb < MF ? bb : 0]}; \
-            asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(ln_a + wn * (BMt * 8)), "v"(v), "n"(bb * 128) : "memory"); }
-          W_LNW(0) W_LNW(1) W_LNW(2) W_LNW(3) W_LNW(4)
-#undef W_LNW
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (wn == 3 && fq == 0) {
-#pragma unroll
-          for (int b = 0; b < MF; ++b) {
-            w_f32x2_t p0, p1, p2;
-            const uint32_t a0 = ln_a + b * 128;
-            asm volatile("ds_read_b64 %0, %1" : "=v"(p0) : "v"(a0) : "memory");
-            asm volatile("ds_read_b64 %0, %1" : "=v"(p1) : "v"(a0 + BMt * 8) : "memory");
-            asm volatile("ds_read_b64 %0, %1" : "=v"(p2) : "v"(a0 + 2 * BMt * 8) : "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p0), "+v"(p1), "+v"(p2)::"memory");
-            const int m = m0 + wm * WR + b * 16 + frow;
-            if (m < M) {
-              const w_f32x2_t v = {((p0[0] + p1[0]) + p2[0]) + s1[b], ((p0[1] + p1[1]) + p2[1]) + s2[b]};
-              *reinterpret_cast<w_f32x2_t*>(sc.ln_part + (static_cast<size_t>(tn) * Mub + m) * 2) = v;
-            }
-          }
-        }
-      }
       pend_ptr = static_cast<char*>(out) + (static_cast<size_t>(m0 + wm * WR + frow) * N + col) * 2;
       if (DEFER && full && ti + 1 < my_tiles && !(epi & (256 | 512))) {   // 512 = ablation: store from the epilogue
         pend_valid = true;                       // leave under the next tile's MFMAs
@@ -1269,13 +1158,8 @@ int launch_gemm_wide_tn(const void* Xk, const void* Wk, float* out, float* parti
 
 int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out,
                      int M, int N, int K, int epi, hipStream_t st, const float* colscale, float alpha, float oscale,
-                     const int32_t* m_dev, int m_hint, const LnFold* ln) {
-  const WideScales sc{colscale, alpha, oscale, 0, nullptr, m_dev, ln ? ln->part : nullptr, ln ? ln->colsum : nullptr, ln ? ln->nparts : 0};
-  const int lnm = ln ? ln->mode : 0;
-  if (lnm) {
-    if (dt != CMH_BF16 || !ln->part || (lnm == 1 && !(epi & EPI_OUT_F16)) || (lnm == 2 && (!(epi & EPI_OUT_BF16) || !(epi & EPI_BIAS) || !ln->colsum || ln->nparts * wBN != K || ln->nparts > 4)))
-      return fail(CMH_ERR_INVALID, "gemm: LayerNorm fold mode %d needs the bf16 mode, fp16 output (producer) / bias, bf16 output, K = 256 * parts <= 1024 (consumer)", lnm);
-  }
+                     const int32_t* m_dev, int m_hint) {
+  const WideScales sc{colscale, alpha, oscale, 0, nullptr, m_dev};
   const size_t esz = dt == CMH_F32 ? 4 : (dt == CMH_FP8 ? 1 : 2);
   if (static_cast<size_t>(M) * K * esz >= (1ull << 32) || static_cast<size_t>(wBN) * K * esz >= (1ull << 32))
     return fail(CMH_ERR_INVALID, "gemm: operand of %zu bytes exceeds the 32-bit offset range of the wide kernel",
@@ -1323,22 +1207,6 @@ int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, co
   } while (0)
   const bool obf = epi & (EPI_OUT_BF16 | EPI_OUT_F16);   // 16-bit outputs share the packed store path
   const bool o8 = epi & EPI_OUT_FP8;
-  if (lnm) {
-#define W_LAUNCH_LN(LNM)                                                                                                  \
-  do {                                                                                                                    \
-    if (mf == 3)                                                                                                          \
-      W_GO((gemm_wide_kernel<1, 1, 3, false, LNM>), grid, st, static_cast<const char*>(A), static_cast<const char*>(W), bias, \
-           residual, out, M, N, K, epi, 1, ordg, sc);                                                                     \
-    else if (mf == 4)                                                                                                     \
-      W_GO((gemm_wide_kernel<1, 1, 4, false, LNM>), grid, st, static_cast<const char*>(A), static_cast<const char*>(W), bias, \
-           residual, out, M, N, K, epi, 1, ordg, sc);                                                                     \
-    else                                                                                                                  \
-      W_GO((gemm_wide_kernel<1, 1, 5, false, LNM>), grid, st, static_cast<const char*>(A), static_cast<const char*>(W), bias, \
-           residual, out, M, N, K, epi, 1, ordg, sc);                                                                     \
-  } while (0)
-    if (lnm == 1) W_LAUNCH_LN(1); else W_LAUNCH_LN(2);
-#undef W_LAUNCH_LN
-  } else
   if (dt == CMH_F32) { if (obf) W_LAUNCH(0, 1); else W_LAUNCH(0, 0); }
   else if (dt == CMH_BF16) { if (obf) W_LAUNCH(1, 1); else W_LAUNCH(1, 0); }
   else {

@@ -489,54 +489,7 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
     dst[i] = f32_to_bf16(src[i]);
 }
 
-// LayerNorm folded into the Linear after it (gemm_wide.hip, LN = 2): one wave per output row n of W [N, K].
-//   W'[n,k] = fp16(W[n,k] * gamma[k]);  bias'[n] = bias[n] + sum_k W[n,k] beta[k];  colsum[n] = sum_k float(W'[n,k])
-// (the column sum is taken over the ROUNDED weights: it has to cancel mean * sum_k W' exactly as the MFMA sees it).  Lane l owns
-// k = 2l, 2l+1 (+128 per step); sums in f32, lanes combined by a butterfly: the same value for every launch.
-__global__ __launch_bounds__(256) void ln_fold_weight_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, const float* __restrict__ bias,
-                                                             uint32_t* __restrict__ w16, float* __restrict__ bias_out,
-                                                             float* __restrict__ colsum, int N, int K) {
-  const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= N) return;
-  float cs = 0.f, bb = 0.f;
-  for (int k = 2 * lane; k < K; k += 128) {
-    const float2 wv = *reinterpret_cast<const float2*>(w + static_cast<size_t>(n) * K + k);
-    const float2 g = *reinterpret_cast<const float2*>(gamma + k);
-    const float2 be = *reinterpret_cast<const float2*>(beta + k);
-    const uint32_t pk = pack_f16x2(wv.x * g.x, wv.y * g.y);
-    w16[(static_cast<size_t>(n) * K + k) >> 1] = pk;
-    cs += f16lo_to_f32(pk) + f16hi_to_f32(pk);
-    bb += wv.x * be.x + wv.y * be.y;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    cs += __shfl_xor(cs, o);
-    bb += __shfl_xor(bb, o);
-  }
-  if (lane == 0) {
-    colsum[n] = cs;
-    bias_out[n] = (bias ? bias[n] : 0.f) + bb;
-  }
-}
-
-int launch_ln_fold_weight(const float* w, const float* gamma, const float* beta, const float* bias, void* w_f16, float* bias_out,
-                          float* colsum_out, int N, int K, hipStream_t st) {
-  CMH_CHECK_ARG(w && gamma && beta && w_f16 && bias_out && colsum_out, "ln_fold_weight: null pointer");
-  CMH_CHECK_ARG(N > 0 && K > 0 && K % 2 == 0, "ln_fold_weight: N=%d K=%d (K even)", N, K);
-  hipLaunchKernelGGL(ln_fold_weight_kernel, dim3((N + 3) / 4), dim3(256), 0, st, w, gamma, beta, bias, static_cast<uint32_t*>(w_f16),
-                     bias_out, colsum_out, N, K);
-  CMH_CHECK_LAUNCH("ln_fold_weight");
-  return CMH_OK;
-}
-
 }  // namespace cmh
-
-extern "C" int cmh_ln_fold_weight(const float* w, const float* gamma, const float* beta, const float* bias, void* w_f16,
-                                  float* bias_out, float* colsum_out, int32_t N, int32_t K, void* stream) {
-  return cmh::launch_ln_fold_weight(w, gamma, beta, bias, w_f16, bias_out, colsum_out, N, K, cmh::as_stream(stream));
-}
 
 extern "C" int cmh_cast_f32_to_bf16(const float* src, void* dst_bf16, int64_t n, void* stream) {
   using namespace cmh;

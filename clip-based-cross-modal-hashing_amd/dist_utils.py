@@ -15,12 +15,25 @@ import torch
 import torch.distributed as dist
 
 
+def forced() -> bool:
+    """CMH_FORCE_DIST=1: join a process group and run EVERY collective of the path even when the group has one rank.  A group of
+    one is what a one-GPU box can give RCCL: communicator creation bound to the device, all_gather_into_tensor / all_reduce /
+    broadcast on device tensors, the asynchronous in-place buckets of GradSync and their stream hand-over all execute for real
+    (tests/test_gpu_rccl_one_rank.py); what it cannot show is a ring over xGMI or a rank-dependent bug."""
+    return os.environ.get("CMH_FORCE_DIST", "0") == "1"
+
+
+def active() -> bool:
+    """Do the collectives of the path run in this process?  (a group of more than one rank, or a forced group of one)"""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or forced())
+
+
 def init_from_env(backend: str | None = None):
     """Initialise the default process group from RANK/WORLD_SIZE/MASTER_* (torchrun).  -> (rank, world, local)"""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or forced()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -63,7 +76,7 @@ def split_columns(fused: torch.Tensor, widths: list[int]) -> list[torch.Tensor]:
 def all_gather_rows(block: torch.Tensor, counts: list[int] | None = None) -> torch.Tensor:
     """Concatenate the [B_r, w] blocks of all ranks in rank order.  Equal B_r -> one all_gather_into_tensor
     (RCCL ring over xGMI); ragged -> pad to the max, gather, and strip (counts = rows per rank)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not active():
         return block
     world = dist.get_world_size()
     block = block.contiguous()
@@ -102,7 +115,7 @@ def gather_loss_inputs(*blocks: torch.Tensor) -> list[torch.Tensor]:
     come back as the global-batch tensors [world * B_local, w_i], rank-major, on every rank.  Differentiable (see
     _GatherRowsFn); blocks that need no gradient (labels) ride along in the same message.  Every rank must contribute the same
     number of rows (the trainers' DistributedSampler pads the epoch so that they do).  One rank: returned unchanged."""
-    if world_size() == 1:
+    if not active():
         return list(blocks)
     widths = [b.shape[1] for b in blocks]
     fused = torch.cat([b.float() for b in blocks], dim=1).contiguous()
@@ -115,7 +128,7 @@ def gather_loss_inputs(*blocks: torch.Tensor) -> list[torch.Tensor]:
 
 def broadcast_tensor_(t: torch.Tensor, src: int = 0) -> torch.Tensor:
     """t on every rank := rank `src`'s (a random draw that a single-GPU run would make once for the whole batch)."""
-    if world_size() > 1:
+    if active():
         dist.broadcast(t, src=src)
     return t
 
@@ -127,7 +140,7 @@ def query_shard(n_query: int) -> tuple[int, int]:
 
 def row_counts(n_local: int, device) -> list[int] | None:
     """Rows every rank contributes to a ragged all_gather_rows (the last batch of an epoch may differ between ranks)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not active():
         return None
     mine = torch.tensor([n_local], dtype=torch.int64, device=device)
     every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
@@ -139,7 +152,7 @@ def gather_query_sharded_ap(ap_local: torch.Tensor, n_query: int) -> torch.Tenso
     """Per-query APs computed on query shards -> the full [Q] vector in QUERY ORDER on every rank, so the final
     mean is accumulated in the same order as a single-GPU run (the reference sums in query order)."""
     world = world_size()
-    if world == 1:
+    if not active():
         return ap_local
     counts = [shard_range(n_query, r, world)[1] - shard_range(n_query, r, world)[0] for r in range(world)]
     return all_gather_rows(ap_local.reshape(-1, 1), counts).reshape(-1)
@@ -166,7 +179,7 @@ def scatter_by_index(buffer: torch.Tensor, index: torch.Tensor, rows: torch.Tens
 
 def broadcast_modules_(modules, src: int = 0) -> None:
     """Parameters and buffers of `modules` on every rank := rank `src`'s, in flat per-dtype messages."""
-    if world_size() == 1:
+    if not active():
         return
     seen, by_dtype = set(), {}
     for m in modules:
@@ -189,7 +202,7 @@ def allreduce_mean_(tensors: list[torch.Tensor], bucket_bytes: int = 256 << 20) 
     packed into flat buckets of ~bucket_bytes so that a step is a handful of large ring all-reduces (xGMI rings are per-link
     bound: few big messages, not 302 small ones), one bucket in flight while the next is being packed."""
     world = world_size()
-    if world == 1 or not tensors:
+    if not active() or not tensors:
         return
     buckets, cur, cur_bytes = [], [], 0
     for t in tensors:
@@ -235,6 +248,7 @@ class GradSync:
 
     def __init__(self, groups):
         self.world = world_size()
+        self.on = active()                                    # collectives run (more than one rank, or CMH_FORCE_DIST=1)
         self.groups = [[p for p in g if p.requires_grad] for g in groups]
         self.groups = [g for g in self.groups if g]
         self._group_of = {id(p): gi for gi, g in enumerate(self.groups) for p in g}
@@ -244,7 +258,7 @@ class GradSync:
         self._late, self._pending, self._handles = [], [], []
         self._buckets, self._via_bucket = [], set()           # in-place messages of this step; ids of the parameters they cover
         self.bucket_log = []                                  # (elements, parameters) of every in-place message of the last step
-        if self.world > 1:
+        if self.on:
             for g in self.groups:
                 for p in g:
                     self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
@@ -279,7 +293,7 @@ class GradSync:
 
     def _on_bucket(self, flat, params, views):
         """a part of a tower's backward has written its last gradient: all-reduce its slice of the flat buffer where it lies"""
-        if self.world == 1:
+        if not self.on:
             return
         # remember WHERE each gradient lies, not the view objects: autograd adopts a returned gradient as p.grad only while nobody
         # else holds a reference to it (otherwise it clones it)
@@ -305,7 +319,7 @@ class GradSync:
             self._sent[gi] = True
 
     def finish(self):
-        if self.world == 1:
+        if not self.on:
             return
         for gi in range(len(self.groups)):
             if not self._sent[gi] and self._arrived[gi]:

@@ -56,5 +56,5 @@ if __name__ == "__main__":
         torch.cuda.set_device(gpu)
     trainer = trainers.get(args.method)
     trainer(args, gpu)
-    if world > 1:
+    if du.active():
         torch.distributed.destroy_process_group()

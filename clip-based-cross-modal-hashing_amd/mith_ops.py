@@ -47,7 +47,7 @@ def gemm(x, w, bias=None, residual=None, act=None, dtype=N.F32):
 def vit_encode_tokens(clip, image):
     image = N.f32c(image)
     N.require_gpu(image)
-    s = clip._vit_struct(fold=True)
+    s = clip._vit_struct()
     B = image.shape[0]
     T = (s.resolution // s.patch) ** 2 + 1
     out = torch.empty(B * T, s.embed_dim, dtype=torch.float32, device=image.device)
@@ -60,7 +60,7 @@ def vit_encode_tokens(clip, image):
 def text_encode_tokens(clip, text, key_padding_mask):
     N.require_gpu(text)
     text = text.to(torch.int64).contiguous()
-    s = clip._text_struct(fold=True)
+    s = clip._text_struct()
     B, L = text.shape
     out = torch.empty(B * L, s.embed_dim, dtype=torch.float32, device=text.device)
     rows = torch.empty(B, dtype=torch.int32, device=text.device)

@@ -106,7 +106,6 @@ class _TowerCache:
         self.keep = []          # tensors that must outlive the structs
         self.struct = None
         self.blocks = None
-        self.folded = False     # the LayerNorm-folded copies of in_proj / c_fc exist (bf16 mode, made on the first inference call)
 
 
 def _prep(p: torch.Tensor, keep: list) -> torch.Tensor:
@@ -144,29 +143,6 @@ def _fp8_w(p: torch.Tensor, keep: list):
 
 
 FP8_HEADROOM = 2.0     # act_scale = FP8_HEADROOM * amax(calibration batch) / 448: later batches may exceed the calibration maximum
-
-
-def ln_fold_enabled() -> bool:
-    """The LayerNorm fold is opt-in (cmh_native.set_ln_fold(1) or CMH_LN_FOLD=1): measured, it does not pay."""
-    return N.ln_fold_requested()
-
-
-def _fold_blocks(resblocks, arr, dt: int, keep: list):
-    """Inference in bf16 mode: ln_1 / ln_2 folded into in_proj / c_fc (csrc/gemm_wide.hip, template parameter LN).  Filled in on the
-    first inference call of a weight state (a training step never pays for it)."""
-    if dt != N.BF16 or not ln_fold_enabled():
-        return False
-    for i, blk in enumerate(resblocks):
-        if blk.ln_1.weight.shape[0] % 256 != 0:
-            return True
-        b = arr[i]
-        wf, bf, cf = N.ln_fold_weight(blk.attn.in_proj_weight, blk.ln_1.weight, blk.ln_1.bias, blk.attn.in_proj_bias)
-        b.in_proj_wf, b.in_proj_bf, b.in_proj_cf = wf.data_ptr(), bf.data_ptr(), cf.data_ptr()
-        keep.extend((wf, bf, cf))
-        wf, bf, cf = N.ln_fold_weight(blk.mlp.c_fc.weight, blk.ln_2.weight, blk.ln_2.bias, blk.mlp.c_fc.bias)
-        b.fc_wf, b.fc_bf, b.fc_cf = wf.data_ptr(), bf.data_ptr(), cf.data_ptr()
-        keep.extend((wf, bf, cf))
-    return True
 
 
 def _fill_blocks(resblocks, dt: int, keep: list, act_amax=None):
@@ -350,7 +326,7 @@ class CLIP(nn.Module):
             return (self._gemm_dtype, str(self.device), "frozen")
         return (self._gemm_dtype, str(self.device)) + tuple((p.data_ptr(), p._version) for p in params)
 
-    def _vit_struct(self, fold=False):
+    def _vit_struct(self):
         v, c = self.visual, self._vit_cache
         key = self._key(list(v.parameters()))
         if c.key != key:
@@ -372,12 +348,10 @@ class CLIP(nn.Module):
             s.proj_t = _gemm_w(v.proj, dt, keep, transpose=True).data_ptr()
             c.blocks = _fill_blocks(v.transformer.resblocks, dt, keep, self._fp8_amax["vit"])
             s.blocks = C.cast(c.blocks, C.POINTER(N.BlockWeights))
-            c.struct, c.keep, c.key, c.folded = s, keep, key, False
-        if fold and not c.folded:
-            c.folded = _fold_blocks(v.transformer.resblocks, c.blocks, self._gemm_dtype, c.keep)
+            c.struct, c.keep, c.key = s, keep, key
         return c.struct
 
-    def _text_struct(self, fold=False):
+    def _text_struct(self):
         c = self._txt_cache
         params = [self.token_embedding.weight, self.positional_embedding, self.ln_final.weight, self.ln_final.bias,
                   self.text_projection] + list(self.transformer.parameters())
@@ -398,9 +372,7 @@ class CLIP(nn.Module):
             s.text_projection_t = _gemm_w(self.text_projection, dt, keep, transpose=True).data_ptr()
             c.blocks = _fill_blocks(self.transformer.resblocks, dt, keep, self._fp8_amax["text"])
             s.blocks = C.cast(c.blocks, C.POINTER(N.BlockWeights))
-            c.struct, c.keep, c.key, c.folded = s, keep, key, False
-        if fold and not c.folded:
-            c.folded = _fold_blocks(self.transformer.resblocks, c.blocks, self._gemm_dtype, c.keep)
+            c.struct, c.keep, c.key = s, keep, key
         return c.struct
 
     @staticmethod
@@ -429,7 +401,7 @@ class CLIP(nn.Module):
                 if self._gemm_dtype == N.FP8:
                     raise N.NativeError("the fp8 mode is inference-only: use torch.no_grad() or set_gemm_dtype('bf16' | 'f32') to train")
                 return T.VitTrain.apply(self, image, *params)
-        s = self._vit_struct(fold=True)
+        s = self._vit_struct()
         feat = torch.empty(B, s.embed_dim, dtype=torch.float32, device=image.device)
         need = N.lib().cmh_vit_workspace_bytes(C.byref(s), B)
         ws = N.workspace(need, image.device, f"vit@{N.stream_ptr(image.device)}")   # one scratch per stream: sub-batches may overlap
@@ -455,7 +427,7 @@ class CLIP(nn.Module):
                 if self._gemm_dtype == N.FP8:
                     raise N.NativeError("the fp8 mode is inference-only: use torch.no_grad() or set_gemm_dtype('bf16' | 'f32') to train")
                 return T.TextTrain.apply(self, text, kpm, *params)
-        s = self._text_struct(fold=True)
+        s = self._text_struct()
         feat = torch.empty(B, s.embed_dim, dtype=torch.float32, device=text.device)
         need = N.lib().cmh_text_workspace_bytes(C.byref(s), B, L)
         ws = N.workspace(need, text.device, f"text@{N.stream_ptr(text.device)}")

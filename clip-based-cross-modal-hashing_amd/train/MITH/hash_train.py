@@ -127,7 +127,7 @@ class MITHTrainer(TrainBase):
             output_dict = self.model(image, text, key_padding_mask)
             index = index.to(self.rank)
             codes = [output_dict[k].detach() for k in ('img_cls_hash', 'txt_cls_hash', 'img_tokens_hash', 'txt_tokens_hash')]
-            if du.world_size() > 1:
+            if du.active():
                 # every rank's memory bank takes every rank's (index, codes): one fused all-gather per step
                 fused, widths = du.fuse_columns(index.view(-1, 1).float(), *codes)
                 parts = du.split_columns(du.all_gather_rows(fused, du.row_counts(fused.shape[0], fused.device)), widths)

@@ -64,7 +64,7 @@ class TwDHTrainer(TrainBase):
         dev = torch.device("cuda", self.rank) if isinstance(self.rank, int) else torch.device(self.rank)
         if random_center is None:
             random_center = torch.randint(0, 2, (Hash_center.shape[1],)).float() * 2 - 1
-            if du.world_size() > 1:   # one draw per step for the whole (global) batch, as in a single-GPU run: rank 0's
+            if du.active():   # one draw per step for the whole (global) batch, as in a single-GPU run: rank 0's
                 random_center = du.broadcast_tensor_(random_center.to(dev), 0)
         return N.twdh_targets(labels.to(dev).float(), Hash_center.to(dev).float(), random_center.to(dev).float())
 
@@ -98,7 +98,7 @@ class TwDHTrainer(TrainBase):
         image = image.to(self.rank, non_blocking=True)
         text = text.to(self.rank, non_blocking=True)
         il, ish, tl, tsh, lc, sc = self.model(image, text)
-        if du.world_size() > 1:
+        if du.active():
             # ONE fused all-gather of the long and short pair probabilities + labels: the BCE / quantisation means run over
             # the global batch (BatchNorm1d of the image head keeps the rank's batch statistics)
             keys = list(ish.keys())

@@ -34,7 +34,7 @@ class TrainBase(object):
         self.rank = getattr(args, "rank", rank)   # GPU ID
         self._init_dataset()
         self._init_model()
-        if du.world_size() > 1:          # replicas start from rank 0's weights (heads and loss parameters are drawn at random)
+        if du.active():          # replicas start from rank 0's weights (heads and loss parameters are drawn at random)
             du.broadcast_modules_([m for m in vars(self).values() if isinstance(m, torch.nn.Module)])
         self.global_step = 0
         self.max_mapi2t = 0
@@ -91,7 +91,7 @@ class TrainBase(object):
         With one process per GPU each rank draws its share of every epoch from a DistributedSampler (the short tail is
         padded by repeats, so all ranks run the same number of steps); evaluation sets are cut the same way, unshuffled."""
         sampler = None
-        if du.world_size() > 1:
+        if du.active():
             from torch.utils.data.distributed import DistributedSampler
             sampler = DistributedSampler(data, shuffle=train, seed=int(getattr(self.args, "seed", 0) or 0))
         kw = dict(batch_size=self.args.batch_size, num_workers=self.args.num_workers, sampler=sampler, shuffle=sampler is None)
@@ -151,7 +151,7 @@ class TrainBase(object):
         4 + 2 * 2 * ceil(K/32) * 4 bytes for an (image, text) pair instead of 4 + 2 * K * 4 bytes of floats (NUS-WIDE, 128 bit:
         6.9 MB instead of 196 MB); every rank then restores the reference's float buffers (train/base.py:130-148: save_mat and
         calc_map_k take them) with cmh_unpack_codes.  Codes are exactly -1 / 0 / +1 (sign, argmax), so nothing is lost."""
-        if du.world_size() == 1 or not seen:
+        if not du.active() or not seen:
             return
         mine = torch.cat(seen)
         cols, widths = [mine.to(torch.int32).unsqueeze(1)], [1]
@@ -185,7 +185,7 @@ class TrainBase(object):
     def backward(self, loss, *loss_modules):
         """loss.backward(); with one process per GPU also the gradient means over the ranks, each tower's all-reduce queued from
         inside the backward pass as soon as its last gradient is written (dist_utils.GradSync)."""
-        if du.world_size() > 1 and getattr(self, "_grad_sync", None) is None:
+        if du.active() and getattr(self, "_grad_sync", None) is None:
             self._grad_sync = du.GradSync.for_model(self.model, *loss_modules)
         loss.backward()
         if getattr(self, "_grad_sync", None) is not None:
@@ -206,7 +206,7 @@ class TrainBase(object):
             if getattr(self, "train_sampler", None) is not None:
                 self.train_sampler.set_epoch(epoch)
             self.train_epoch(epoch)
-            if du.world_size() > 1:     # replicas must hold identical weights after every epoch: log a checksum per rank
+            if du.active():     # replicas must hold identical weights after every epoch: log a checksum per rank
                 with torch.no_grad():
                     total = sum(p.double().sum() for p in self.model.parameters())
                 self.logger.info(f">>>>>> [{epoch}/{self.args.epochs}] replica checksum: {float(total)!r}")
@@ -231,7 +231,7 @@ class TrainBase(object):
         ranks its own contiguous share of the QUERIES against the whole database, and the per-query APs are gathered in query
         order and summed in f32 exactly like the kernel's own mean (reference utils/calc_utils.py:37-38), so the value is the
         single-GPU one bit for bit (reference call sites train/base.py:259-262, :299-302)."""
-        if du.world_size() == 1:
+        if not du.active():
             return calc_map_k(query_codes, retrieval_codes, self.query_labels, self.retrieval_labels, k, self.rank)
         n_query = query_codes.shape[0]
         lo, hi = du.query_shard(n_query)

@@ -11,9 +11,18 @@
  * Conventions
  *  - plain pointers and sizes only; no torch types.  All data pointers are DEVICE pointers unless
  *    a parameter says "host".  `stream` is a hipStream_t passed as void* (NULL = default stream).
- *  - the library never allocates or frees device memory and never synchronises the device:
- *    every call only enqueues kernels on `stream` (graph-capturable).  Scratch comes from the
- *    caller (`workspace`, size from the matching *_workspace_bytes()).
+ *  - the library never allocates or frees DEVICE memory: scratch comes from the caller
+ *    (`workspace`, size from the matching *_workspace_bytes()).  It owns two small page-locked HOST
+ *    buffers, created on first use and kept for the life of the process: the staging ring of
+ *    cmh_bert_adam_step's tensor tables and one 64-byte word through which the packed text
+ *    encoders learn, without waiting, how many rows earlier calls packed.
+ *  - the inference entry points (cmh_vit_encode*, cmh_text_encode*, heads, losses, codes, ranking)
+ *    only enqueue kernels on `stream` and never wait for the device (graph-capturable).  The
+ *    calls that DO wait for `stream` say so at their declaration: the fp8 calibration pass
+ *    (cmh_*_calibrate_fp8), cmh_prof_gemm_end, the packed TRAINING forward of the text tower
+ *    (cmh_text_forward_train reads the packed row count once: it sizes the tape's grids and the
+ *    backward's split-K plans), and towers whose width is not a multiple of 256 when they take
+ *    packed captions (test-sized configurations).
  *  - return value: 0 on success, negative cmh_status on error; cmh_last_error() gives the text
  *    (thread-local).  No exceptions cross the ABI.
  *  - matrices are dense row-major.  Linear weights are [out_features, in_features] exactly as
@@ -31,7 +40,7 @@
 extern "C" {
 #endif
 
-#define CMH_VERSION 4   /* = the round that last changed a struct layout or a signature; cmh_native.lib() refuses any other */
+#define CMH_VERSION 5   /* = the round that last changed a struct layout or a signature; cmh_native.lib() refuses any other */
 
 typedef enum cmh_status {
   CMH_OK = 0,
@@ -80,16 +89,6 @@ typedef struct cmh_block_weights {
   const float* proj_cs;     /* [d] */
   float act_scale[4];       /* per-tensor scales of the four GEMM inputs: ln_1 output, attention output, ln_2 output,
                              * QuickGELU(c_fc) output; x_fp8 = e4m3(x / act_scale).  From cmh_*_calibrate_fp8: headroom * amax / 448 */
-  /* CMH_BF16 only, optional (all six or none; NULL = every LayerNorm is its own launch): ln_1 / ln_2 folded into the Linear after
-   * them - model/base/model.py:191-196 `self.attn(self.ln_1(x))`, `self.mlp(self.ln_2(x))` - from cmh_ln_fold_weight.  Used on the
-   * fp16 residual stream (width % 256 == 0, no taps) when the GEMMs take the wide kernel (more than 2048 rows, or packed text):
-   * LN(x) W^T + b = rstd (x W'^T - mean colsum(W')) + b' with the row statistics left by the GEMM that wrote x. */
-  const void* in_proj_wf;   /* fp16 [3d, d] = in_proj_w * ln1_w[k] */
-  const float* in_proj_bf;  /* [3d] = in_proj_b + in_proj_w . ln1_b */
-  const float* in_proj_cf;  /* [3d] = row sums of in_proj_wf */
-  const void* fc_wf;        /* fp16 [4d, d] = fc_w * ln2_w[k] */
-  const float* fc_bf;       /* [4d] */
-  const float* fc_cf;       /* [4d] */
 } cmh_block_weights;
 
 /* Image tower = reference model/base/model.py:210-252 VisionTransformer. */
@@ -181,20 +180,6 @@ int cmh_linear_gemm(int32_t dtype, const void* x, const void* w, const float* bi
 /* LayerNorm over the last dim of x f32 [M,d] (eps 1e-5, fp32 statistics; model/base/model.py:153-159). */
 int cmh_layernorm(const float* x, const float* w, const float* b, void* out, int32_t out_dtype, int32_t M,
                   int32_t d, void* stream);
-/* The operands of a Linear with the LayerNorm before it folded in (cmh_block_weights.in_proj_wf / fc_wf and their companions; replaces
- * the reference's separate `ln_1` / `ln_2` modules, model/base/model.py:153-159,191-196): w f32 [N, K] (Linear weight), gamma / beta
- * f32 [K] (the LayerNorm's), bias f32 [N] or NULL -> w_f16 [N, K] = fp16(w * gamma), bias_out [N] = bias + w . beta,
- * colsum_out [N] = row sums of w_f16 as rounded.  K even. */
-/* The two GEMMs of a folded LayerNorm, exported for unit-level parity tests (the towers launch them from run_block).  16-bit
- * operands, N % 256 == 0, K % 64 == 0, the wide kernel at any M.
- *   ln_mode 1 (producer): out = fp16 (epilogue must carry CMH_EPI_OUT_F16 = 128; residual, if any, fp16 with CMH_EPI_RES_F16 = 64) of
- *     epi(x . w^T) with bf16 x / w; ln_part [N/256][M][2] f32 receives per row the (sum, sum of squares) of each 256-column panel.
- *   ln_mode 2 (consumer): x = the raw fp16 rows [M, K], w / bias / ln_colsum from cmh_ln_fold_weight, ln_part [K/256][M][2] from the
- *     producer of x; out (bf16, CMH_EPI_OUT_BF16 | CMH_EPI_BIAS [| CMH_EPI_QUICKGELU]) = epi(LayerNorm(x) . w0^T + b0). */
-int cmh_linear_gemm_lnfold(const void* x, const void* w, const float* bias, const void* residual, void* out, int32_t M, int32_t N,
-                           int32_t K, int32_t epilogue, int32_t ln_mode, float* ln_part, const float* ln_colsum, void* stream);
-int cmh_ln_fold_weight(const float* w, const float* gamma, const float* beta, const float* bias, void* w_f16, float* bias_out,
-                       float* colsum_out, int32_t N, int32_t K, void* stream);
 /* softmax(q k^T / 8 [+causal] [+key padding]) v per head (head dim 64) on packed qkv [B*T, 3d] -> o [B*T, d]. */
 int cmh_attention(int32_t dtype, const void* qkv, void* o, int32_t B, int32_t T, int32_t d, int32_t causal,
                   const uint8_t* key_padding_mask, void* stream);
@@ -221,26 +206,11 @@ int cmh_gemm_tuning(int32_t tile_rows, int32_t order_group);
  * on = 0 sends them to the wide kernel again (A/B, tests), 1 forces the default, -1 = environment (CMH_GEMM_ROWS=0 is off). */
 int cmh_set_gemm_rows(int32_t on);
 
-/* Optional second tile shape for cmh_linear_gemm and the towers' in_proj / c_fc launches (bf16, bias [+ QuickGELU], bf16 output, at
- * least 240 tiles of 256 x 256): gemm_big_kernel, 256 x 256 tiles on four waves of 128 x 128 (csrc/gemm_big.hip) - 128 FLOP per byte
- * fetched into LDS where the 160 x 256 tile has 98, same bits per output element.  OFF by default: faster at K >= ~2048 (+17 % at
- * 12 800 x 2304 x 3072), slower at the encoder's K = 512 / 768.  on = 1 switches it on, 0 off, -1 = environment
- * (CMH_GEMM_BIG=1 is on). */
-int cmh_set_gemm_big(int32_t on);
-
 /* encode_image / encode_text return one pooled row per sample (model/base/model.py:247-250, 366-370), and past the last block's
  * attention every operation is row-wise, so cmh_vit_encode / cmh_text_encode[_packed] carry only those B rows through the last
  * block's out_proj, ln_2 and MLP (bit-identical features, three GEMMs of M = B instead of M = B*T).  on = 0 switches that off
  * (A/B measurements, the equality test); also CMH_POOLED_TAIL=0 in the environment.  Process-wide, not thread-safe. */
 int cmh_set_pooled_tail(int32_t on);
-
-/* bf16 mode on the fp16 residual stream: ln_1 (from the second block on) and ln_2 (up to the last block but one) are not launches of
- * their own - the residual GEMM before them leaves per-row sums, the Linear after them reads the raw stream against the folded
- * weights of cmh_block_weights.in_proj_wf / fc_wf and normalises in its epilogue (csrc/gemm_wide.hip).  Applies when the towers'
- * GEMMs run on the wide kernel (more than 2048 rows per call) and the folded weights are present.  OFF by default: measured on
- * configs[1] it removes 46 launches per step and costs the GEMMs as much.  on = 1 switches it on, 0 off,
- * -1 = environment (CMH_LN_FOLD=1 is on).  Process-wide, not thread-safe. */
-int cmh_set_ln_fold(int32_t on);
 
 /* ---------------------------------------------------------------------------------------------
  * fp8 encoder mode (CMH_FP8).  Mirrors the reference's precision hook convert_weights (model/base/model.py:391-412): the same

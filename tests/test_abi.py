@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     exported = set(re.findall(r" T (cmh_[a-z0-9_]+)", out))
     assert set(declared) <= exported, sorted(set(declared) - exported)
     assert set(N.SIGNATURES) == set(declared)
-    assert lib.cmh_version() == N.ABI_VERSION == 4
+    assert lib.cmh_version() == N.ABI_VERSION == 5
     assert lib.cmh_last_error() is not None
 
 
@@ -106,7 +106,7 @@ def test_struct_layouts_of_the_header_match_the_ctypes_mirrors(tmp_path):
     each struct's last member; the ctypes classes must agree."""
     import ctypes as C
     import cmh_native as N
-    pairs = {"cmh_block_weights": (N.BlockWeights, "fc_cf"), "cmh_vit_weights": (N.VitWeights, "blocks"),
+    pairs = {"cmh_block_weights": (N.BlockWeights, "act_scale"), "cmh_vit_weights": (N.VitWeights, "blocks"),
              "cmh_text_weights": (N.TextWeights, "blocks"), "cmh_taps": (N.Taps, "count"),
              "cmh_block_grads": (N.BlockGrads, "proj_b"), "cmh_vit_grads": (N.VitGrads, None), "cmh_text_grads": (N.TextGrads, None),
              "cmh_adam_tensor": (N.AdamTensor, None)}

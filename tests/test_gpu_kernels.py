@@ -192,27 +192,3 @@ def test_gemm_fp16_residual_stream(M, N, K):
         Nn.linear_gemm(x.to(_dev()), w[:128].to(_dev()), residual=r[:, :128].contiguous().to(_dev()), out_f16=True)
 
 
-@pytest.mark.parametrize("M,N,K,act", [(12800, 2304, 768, False), (10499, 1536, 512, True), (7000, 2304, 768, True), (4100, 4096, 192, False)])
-def test_gemm_big_kernel_gives_the_wide_kernels_bits(M, N, K, act):
-    """csrc/gemm_big.hip (256 x 256 tiles, four waves of 128 x 128; opt-in): the same MFMA chain per output element as the wide
-    kernel, then bias, QuickGELU, one rounding - identical bits, partial last tiles included (cmh_set_gemm_big)."""
-    import cmh_native as Nn
-    g = torch.Generator().manual_seed(M + N + K)
-    x = torch.randn(M, K, generator=g).bfloat16().to(_dev())
-    w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().to(_dev())
-    b = torch.randn(N, generator=g).to(_dev())
-    try:
-        Nn.set_gemm_big(0)
-        ref = Nn.linear_gemm(x, w, bias=b, quickgelu=act, out_bf16=True)
-        Nn.set_gemm_big(1)
-        out = Nn.linear_gemm(x, w, bias=b, quickgelu=act, out_bf16=True)
-        nob = Nn.linear_gemm(x, w, quickgelu=act, out_bf16=True)
-        Nn.set_gemm_big(0)
-        nob_ref = Nn.linear_gemm(x, w, quickgelu=act, out_bf16=True)
-    finally:
-        Nn.set_gemm_big(-1)
-    assert torch.equal(out, ref) and torch.equal(nob, nob_ref)
-    r64 = x.cpu().double() @ w.cpu().double().t() + b.cpu().double()
-    if act:
-        r64 = r64 * torch.sigmoid(1.702 * r64)
-    torch.testing.assert_close(out.cpu().double(), r64, rtol=1e-2, atol=1e-2)

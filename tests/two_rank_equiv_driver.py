@@ -14,11 +14,11 @@ import main
 out, method = sys.argv[1], sys.argv[2]
 rank, world, _ = du.init_from_env()
 torch.cuda.set_device(0)
-tag = f"w{world}r{rank}"
+tag = f"w{world}r{rank}" + ("f" if du.forced() else "")     # f: a FORCED group of one rank (CMH_FORCE_DIST=1: every collective runs)
 ck = os.path.join(out, f"clip_{tag}.pt")
 torch.save({k: torch.from_numpy(v) for k, v in recipe.clip_state_dict(dict(recipe.CLIP_TINY, embed_dim=512), 7).items()}, ck)
 ds.SOT, ds.EOT = 510, 511
-sys.argv = ["main.py", "-clip-path", ck, "--save-dir", os.path.join(out, f"run_w{world}"), "--batch-size", "16", "--num-workers", "0",
+sys.argv = ["main.py", "-clip-path", ck, "--save-dir", os.path.join(out, f"run_{tag}"), "--batch-size", "16", "--num-workers", "0",
             "--resolution", "64", "--max-words", "16", "--query-num", "25", "--train-num", "50", "--synthetic-size", "120",
             "--gemm-dtype", "f32", "--epochs", "0"]
 torch.manual_seed(100)                                       # the same heads / loss parameters in every process
@@ -69,6 +69,6 @@ json.dump({"loss": float(loss.detach()), "maps": maps, "n_grads": len(grads),
            "buckets": [list(b) for b in sync.bucket_log] if sync is not None else None,          # in-place messages of the step
            "tower_grad_is_view": tower_p.grad is not None and tower_p.grad.untyped_storage().nbytes() > 4 * tower_p.grad.numel()},
           open(os.path.join(out, f"res_{tag}.json"), "w"))
-if world > 1:
+if du.active():
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
