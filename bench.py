@@ -178,6 +178,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region of exactly --steps steps is run this many times; value = the MEDIAN region (value_runs lists min / median / max)")
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (configs[1]: 256)")
     ap.add_argument("--seq-len", type=int, default=77)
     ap.add_argument("--bits", type=int, default=64)
@@ -256,13 +258,27 @@ def main():
         step()
     barrier()
     overlap = not a.no_overlap_towers
+    reps = max(1, a.repeats)
     if not overlap:
-        N.prof_gemm_begin(a.steps * 128)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step()
-    barrier()
-    t1 = time.perf_counter()
+        N.prof_gemm_begin(a.steps * reps * 128)
+
+    def max_over_ranks(seconds):
+        el = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        if dist_on:
+            torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+        return float(el.item())
+
+    # The timed region: EXACTLY --steps steps between two barrier + synchronize pairs, MAX over the ranks - run `reps` times back to
+    # back (boxes of this pool differ by 10 % and the clock moves with the load: one 0.08 s sample cannot show a 1-3 % change).
+    # `value` / `ms_per_step` are the MEDIAN region's; `value_runs` carries min / median / max of the same regions.
+    region_s = []
+    for _ in range(reps):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            loss = step()
+        barrier()
+        region_s.append(max_over_ranks(time.perf_counter() - t0))
     if overlap:
         # With the towers on two streams a GEMM's start-to-end time includes the time its workgroups wait for CUs held by
         # the other tower's kernel, so per-launch HIP events (and rocprofv3's kernel trace) no longer time the kernel.  The
@@ -271,15 +287,14 @@ def main():
         for _ in range(a.steps):
             step(overlap=False)
         barrier()
+    prof_steps = a.steps if overlap else a.steps * reps
     all_ms, all_flops, all_launches = N.prof_gemm_end()
     by_kernel = N.prof_gemm_by_kernel()
     # the dominant kernel is gemm_wide_kernel (every GEMM of M >= 10 k rows); the M = 256 launches of the pooled-row tail and of the
     # final projections run on gemm_rows_kernel and are reported beside it, not averaged into it
     gemm_ms, gemm_flops, gemm_launches = by_kernel["gemm_wide_kernel"]
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if dist_on:
-        torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
+    srt = sorted(region_s)
+    elapsed = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
     assert torch.isfinite(loss).item(), "non-finite loss"
 
     pairs = a.steps * B * world
@@ -298,10 +313,7 @@ def main():
         for _ in range(a.steps):
             step()
         barrier()
-        dense_el = torch.tensor([time.perf_counter() - td0], dtype=torch.float64, device=dev)
-        if dist_on:
-            torch.distributed.all_reduce(dense_el, op=torch.distributed.ReduceOp.MAX)
-        value_dense = pairs / float(dense_el.item())
+        value_dense = pairs / max_over_ranks(time.perf_counter() - td0)
         clip.pack_text = True
     peak = PEAK_TFLOPS[a.dtype]
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
@@ -337,6 +349,10 @@ def main():
         "metric": "image+text pairs/s encoded+hashed per GPU; mAP@K eval wallclock (64-bit)",
         "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "value_runs": {"pairs_per_s": [round(pairs / x, 2) for x in (srt[-1], elapsed, srt[0])], "ms_per_step": [round(x / a.steps * 1e3, 4) for x in (srt[0], elapsed, srt[-1])],
+                       "regions": reps, "steps_per_region": a.steps,
+                       "what": "[min, median, max] over back-to-back timed regions of exactly --steps steps each; value / ms_per_step = the median region"},
+        "collectives": (None if not dist_on else torch.distributed.get_backend() + (" (forced group of one)" if world == 1 else "")),
         "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "residual_stream": ("fp16" if a.dtype == "bf16" and os.environ.get("CMH_RESID_F16", "1") != "0" else "f32"),
         "arithmetic": ("bf16 MFMA operands, f32 accumulate, f32 LayerNorm statistics / softmax, fp16 residual stream" if a.dtype == "bf16"
@@ -360,15 +376,15 @@ def main():
                      "avg_launch_us": round(gemm_ms * 1e3 / max(gemm_launches, 1), 2),
                      "timing": "HIP events stamped by the dispatch itself (hipExtLaunchKernelGGL start/stop events on the launch "
                                "stream): the kernel's own begin-to-end time, as rocprofv3's kernel trace reports it",
-                     "other_gemm_kernels": {k: {"launches": int(v[2]), "ms_per_step": round(v[0] / a.steps, 4),
+                     "other_gemm_kernels": {k: {"launches": int(v[2]), "ms_per_step": round(v[0] / prof_steps, 4),
                                                 "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[0] > 0 else 0.0}
                                             for k, v in by_kernel.items() if k != "gemm_wide_kernel" and v[2] > 0},
-                     "all_gemm_launches": {"launches": int(all_launches), "ms_per_step": round(all_ms / a.steps, 4),
+                     "all_gemm_launches": {"launches": int(all_launches), "ms_per_step": round(all_ms / prof_steps, 4),
                                            "tflops": round(all_flops / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else 0.0},
                      "measured_in": ("the timed region" if not overlap else
                                      "a second pass of the same K steps with the two towers serialized (per-launch events "
                                      "overlap when the towers share the GPU); value/ms_per_step are from the overlapped region"),
-                     "gemm_ms_per_step_serialized": round(gemm_ms / a.steps, 4)},
+                     "gemm_ms_per_step_serialized": round(gemm_ms / prof_steps, 4)},
     }
 
     if world == 1 and a.dtype != "f32" and not a.no_precision_legs:      # (step() holds a collective when world > 1: single-GPU runs only)
@@ -377,7 +393,7 @@ def main():
             # step timed in f32 mode (towers serialized so that the per-launch events time the kernels)
             out["flip_rate_vs_f32"] = flip_rates(clip, (img_head, txt_head), image, text)
             clip.set_gemm_dtype("f32")
-            nf = max(2, min(a.steps, 5))
+            nf = max(2, min(a.steps, 10))
             for _ in range(2):
                 step()
             torch.cuda.synchronize()
@@ -537,11 +553,11 @@ def main():
                 train_step()
             barrier()
             t0 = time.perf_counter()
-            nts = 5
+            nts = max(20, a.steps)
             for _ in range(nts):
                 tl = train_step()
             barrier()
-            tms = (time.perf_counter() - t0) / nts * 1e3
+            tms = max_over_ranks(time.perf_counter() - t0) / nts * 1e3
             out["train_step"] = {"ms": round(tms, 3), "pairs_per_s": round(B * world / tms * 1e3, 1), "steps": nts,
                                  "what": "DSPH step: forward with tape + HyP loss + backward (heads, both towers) + fused BertAdam",
                                  "loss": round(float(tl.detach()), 5)}
@@ -592,17 +608,23 @@ def main():
             ms_c = (time.perf_counter() - t0) / 10 * 1e3
             out["input_pipeline"]["cached_epoch_batch_ms"] = round(ms_c, 3)
             out["input_pipeline"]["cached_images_per_s"] = round(B / ms_c * 1e3, 1)
-            try:
-                from model.base.simple_tokenizer import SimpleTokenizer
-                tok = SimpleTokenizer()
-                words = "a man riding a wave on top of a surfboard while two dogs play in the snow near the old red barn".split()
-                caps = [" ".join(rng.choice(words, size=int(rng.integers(8, 25)))) for _ in range(20000)]
-                tok.encode_captions(caps[:2000], 32)
-                t0 = time.perf_counter()
-                tok.encode_captions(caps, 32)
-                out["input_pipeline"]["captions_per_s"] = round(len(caps) / (time.perf_counter() - t0), 1)
-            except FileNotFoundError:
-                out["input_pipeline"]["captions_per_s"] = None
+            # the native batch tokenizer (cmh_bpe_encode_captions).  Its merges table is DATA the user supplies (the CLIP vocabulary is
+            # not shipped); when it is absent the same code path is timed on the repository's own miniature merges file - fewer merges
+            # per word, so it reads somewhat faster than the real vocabulary would; the field says which one was used
+            from model.base.simple_tokenizer import SimpleTokenizer, default_bpe
+            vocab = default_bpe()
+            which = "the CLIP merges file (bpe_simple_vocab_16e6)"
+            if not os.path.exists(vocab):
+                vocab = os.path.join(ROOT, "tests", "golden", "mini_bpe_merges.txt")
+                which = "tests/golden/mini_bpe_merges.txt (270 merges; the CLIP merges file is not shipped)"
+            tok = SimpleTokenizer(vocab)
+            words = "a man riding a wave on top of a surfboard while two dogs play in the snow near the old red barn".split()
+            caps = [" ".join(rng.choice(words, size=int(rng.integers(8, 25)))) for _ in range(20000)]
+            tok.encode_captions(caps[:2000], 32)
+            t0 = time.perf_counter()
+            tok.encode_captions(caps, 32)
+            out["input_pipeline"]["captions_per_s"] = round(len(caps) / (time.perf_counter() - t0), 1)
+            out["input_pipeline"]["captions_vocabulary"] = which
         except Exception as exc:
             out["input_pipeline"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 

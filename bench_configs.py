@@ -176,9 +176,18 @@ def dchmt_trainer(dev, pairs=1000, batch=32, bits=16):
                 "--query-num", str(pairs), "--train-num", str(pairs), "--synthetic-size", str(2 * pairs), "--gemm-dtype", "bf16",
                 "--epochs", "1", "--save-mat", "false"]
     DCHMTTrainer.run = lambda self: None                   # construct only; the epoch and the evaluation are timed below
+    # class-structured items (dataset/synthetic.py `signal`): every class owns an image pattern and a few caption tokens.  Pure N(0,1)
+    # noise images collapse to ONE 16-bit code under a random-init ViT (round 3's leg: MAP(t->i) == MAP(i->i) to 16 digits, an
+    # all-ties ranking); with structure the database holds many distinct codes and the mAPs of the four directions differ
+    import dataset.synthetic as ds
+    signal0, ds.SyntheticPairs.signal = ds.SyntheticPairs.signal, 2.0
+    tile0, ds.SyntheticPairs.tile = ds.SyntheticPairs.tile, 32      # patch-periodic patterns: see dataset/synthetic.py
     try:
         torch.manual_seed(1)
         tr = main.trainers["DCHMT"](argparse.Namespace(method="DCHMT", dataset="synthetic", output_dim=bits, is_train=True), dev.index or 0)
+    except BaseException:
+        ds.SyntheticPairs.signal, ds.SyntheticPairs.tile = signal0, tile0
+        raise
     finally:
         sys.argv, DCHMTTrainer.run = argv, run
     # the synthetic set draws every item on the host (numpy normal deviates, ~1 ms per image) and a worker-less DataLoader collates
@@ -199,7 +208,10 @@ def dchmt_trainer(dev, pairs=1000, batch=32, bits=16):
                 yield tuple(c[i:i + batch] for c in self.cols)
 
     resident = Resident
-    tr.train_loader, tr.query_loader, tr.retrieval_loader = (resident(l) for l in (tr.train_loader, tr.query_loader, tr.retrieval_loader))
+    try:
+        tr.train_loader, tr.query_loader, tr.retrieval_loader = (resident(l) for l in (tr.train_loader, tr.query_loader, tr.retrieval_loader))
+    finally:
+        ds.SyntheticPairs.signal, ds.SyntheticPairs.tile = signal0, tile0     # the items are materialised: the class attributes go back
     tr.save_model = lambda epoch: None
     return tr
 
@@ -217,12 +229,16 @@ def dchmt_epoch(dev, cpu_sample=True, pairs=1000, batch=32, bits=16):
     torch.cuda.synchronize()
     t_eval = time.perf_counter() - t0
     steps = len(tr.train_loader)
+    with torch.no_grad():                                   # (untimed) how degenerate is the ranked database?
+        _, _, r_img, r_txt, _, _ = tr._codes_for_eval()
+        distinct = [int(torch.unique(c, dim=0).shape[0]) for c in (r_img, r_txt)]
     out = {"train_epoch_s": round(t_train, 3), "steps": steps, "ms_per_step": round(t_train / steps * 1e3, 2),
            "pairs_per_s_training": round(pairs / t_train, 1), "valid_s": round(t_eval, 3),
            "valid_what": f"encode {pairs} queries + {pairs} database pairs, 4 x calc_map_k {pairs} x {pairs}",
-           "mAP_i2t": round(float(maps[0]), 6), "batch": batch, "bits": bits, "first_loss": round(float(step0.detach()), 4),
+           "mAP_i2t": round(float(maps[0]), 6), "mAP_4": [round(float(m), 6) for m in maps[:4]],
+           "distinct_database_codes": {"image": distinct[0], "text": distinct[1], "of": pairs}, "batch": batch, "bits": bits, "first_loss": round(float(step0.detach()), 4),
            "what": "configs[0] DCHMT flickr25k 16 bit, batch 32, random-init ViT-B/32 (bf16 mode): the trainer's own train_epoch + valid "
-                   "on a resident synthetic set of 1 000 train / 1 000 query / 1 000 database pairs"}
+                   "on a resident, class-structured synthetic set of 1 000 train / 1 000 query / 1 000 database pairs"}
     del tr
     torch.cuda.empty_cache()
     if cpu_sample:

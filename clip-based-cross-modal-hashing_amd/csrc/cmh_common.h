@@ -121,6 +121,16 @@ __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + e
 // m_dev (optional, device int32): the real row count when M is only an upper bound (packed text rows); m_hint: a likely value of
 // it for the tile-height choice (never for correctness)
 bool gemm_wide_enabled();          // false under the CMH_GEMM_WIDE=0 diagnostic (gemm.hip)
+// One GEMM of a grouped launch (gemm_wide.hip, template parameter GRP): two problems with the same arithmetic (dt, output kind,
+// epilogue flags) in ONE persistent grid - the same layer of the image and the text tower.  launch_gemm_grouped runs them as two plain
+// launches when the wide kernel cannot take both (N % 256, few rows, CMH_GEMM_WIDE=0): results never depend on the grouping.
+struct GemmProblem {
+  const void* A; const void* W; const float* bias; const float* residual; void* out;
+  int M, N, K;
+  const int32_t* m_dev; int m_hint;                           // device-side row count (M = upper bound) and its likely value
+  const float* colscale; float alpha, oscale;                 // fp8 operands (launch_gemm_fp8's arguments); unused otherwise
+};
+int launch_gemm_grouped(int dt, const GemmProblem& a, const GemmProblem& b, int epi, hipStream_t st);
 bool gemm_rows_takes(int M, int N, int K, int epi);   // gemm_rows.hip: this launch would run on the few-row kernel
 int launch_gemm(int dt, const void* A, const void* W, const float* bias, const float* residual,
                 void* out, int M, int N, int K, int epi, hipStream_t st, const int32_t* m_dev = nullptr, int m_hint = -1);

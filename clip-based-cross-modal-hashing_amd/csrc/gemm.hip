@@ -145,6 +145,59 @@ int launch_gemm_fp8(const void* A8, const void* W8, const float* colscale, float
   return CMH_OK;
 }
 
+int launch_gemm_wide_grouped(int dt, const GemmProblem& a, const GemmProblem& b, int epi, hipStream_t st);   // gemm_wide.hip
+
+static int g_grouped = -1;   // cmh_set_gemm_grouped: -1 = environment (CMH_GEMM_GROUPED=0 switches grouping off)
+bool gemm_grouping_enabled() {
+  static const bool env_on = []() { const char* e = getenv("CMH_GEMM_GROUPED"); return !(e && !strcmp(e, "0")); }();
+  return g_grouped < 0 ? env_on : g_grouped != 0;
+}
+
+// The same layer of both towers as ONE launch of the wide kernel when it can take both problems; two plain launches otherwise
+// (identical results either way).  fp8: EPI_SCALE is implied, as in launch_gemm_fp8.
+int launch_gemm_grouped(int dt, const GemmProblem& a, const GemmProblem& b, int epi, hipStream_t st) {
+  const int bk = dt == CMH_F32 ? 32 : (dt == CMH_FP8 ? 128 : 64);
+  auto fits = [&](const GemmProblem& g) {
+    return g.M > 0 && g.K > 0 && gemm_wide_supported(g.N) && g.K % bk == 0 && (g.m_dev || !gemm_rows_takes(g.M, g.N, g.K, epi));
+  };
+  const bool fp8 = dt == CMH_FP8;
+  const bool groupable = gemm_grouping_enabled() && gemm_wide_enabled() && fits(a) && fits(b) &&
+                         !(epi & (EPI_MUL_DQGELU | EPI_SAVE_PRE)) &&
+                         (fp8 ? (epi & (EPI_OUT_BF16 | EPI_OUT_F16 | EPI_OUT_FP8)) != 0
+                              : (dt == CMH_BF16) == ((epi & (EPI_OUT_BF16 | EPI_OUT_F16)) != 0));
+  if (!groupable) {
+    for (const GemmProblem* g : {&a, &b}) {
+      const int rc = fp8 ? launch_gemm_fp8(g->A, g->W, g->colscale, g->alpha, g->bias, g->residual, g->out, g->oscale, g->M, g->N, g->K,
+                                           epi, st, g->m_dev, g->m_hint)
+                         : launch_gemm(dt, g->A, g->W, g->bias, g->residual, g->out, g->M, g->N, g->K, epi, st, g->m_dev, g->m_hint);
+      if (rc) return rc;
+    }
+    return CMH_OK;
+  }
+  for (const GemmProblem* g : {&a, &b}) {
+    CMH_CHECK_ARG(g->A && g->W && g->out, "gemm (grouped): null pointer");
+    CMH_CHECK_ARG(!(epi & EPI_BIAS) || g->bias, "gemm (grouped): EPI_BIAS without bias");
+    CMH_CHECK_ARG(!(epi & EPI_RESIDUAL) || g->residual, "gemm (grouped): EPI_RESIDUAL without residual");
+    CMH_CHECK_ARG(!fp8 || g->colscale, "gemm (grouped): fp8 operands without weight scales");
+  }
+  const bool timed = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
+  if (timed) gemm_wide_time_next(g_prof.ev[g_prof.used], g_prof.ev[g_prof.used + 1]);
+  // the longer K first: its tiles are the long jobs of the static schedule
+  const bool a_first = a.K >= b.K;
+  const int rc = launch_gemm_wide_grouped(dt, a_first ? a : b, a_first ? b : a, fp8 ? epi | EPI_SCALE : epi, st);
+  gemm_wide_time_next(nullptr, nullptr);
+  if (rc) return rc;
+  if (timed) {
+    const int Ma = prof_real_rows(a.M, a.m_dev, st), Mb = prof_real_rows(b.M, b.m_dev, st);
+    g_prof.flops.push_back(2.0 * Ma * static_cast<double>(a.N) * a.K + 2.0 * Mb * static_cast<double>(b.N) * b.K);
+    g_prof.dims.push_back({Ma + Mb, a.N + b.N, a.K, epi | (1 << 20)});   // (1 << 20: a grouped launch; rows / columns summed)
+    g_prof.kind.push_back(0);
+    g_prof.used += 2;
+  }
+  CMH_CHECK_LAUNCH("gemm (grouped)");
+  return CMH_OK;
+}
+
 }  // namespace cmh
 
 extern "C" int cmh_prof_gemm_begin(int32_t max_launches) {

@@ -106,6 +106,23 @@ struct WideScales {
   const int* m_dev;        // optional: the real row count on the device (M is then an upper bound)
 };
 
+// GROUPED launches (template parameter GRP; round 4).  The two CLIP towers are 12 blocks of the same four GEMMs, and one tower's
+// launch leaves the chip idle where the other has work: the text GEMMs (K = 512, 8 K-steps per tile) cannot amortise a launch's
+// fixed third - first stage landing on 256 CUs at once, last tile's epilogue and store drain - and the image GEMMs end with
+// 0.2-0.4 of a round of CUs idle.  A grouped launch gives ONE persistent grid two problems: the kernel's own arguments describe the
+// first (the longer K: the image tower's), WideProblem the second; a workgroup walks its share of the first problem's tiles and then
+// continues - same XCD, same stride - into the second problem's, so the workgroups that got one image tile fewer take the first
+// text tiles, the flat K-step pipeline runs across the problem switch like across any tile boundary (no second prologue, no
+// drain in between), and per block of the towers there is one launch instead of two.  Both problems share the epilogue flags, the
+// operand / output types and the tile height; per-problem are the pointers, M (or its device-side count), N, K and the fp8 scales.
+// Every output element sees the arithmetic of an ungrouped launch (same K order, same epilogue): bit-identical results.
+struct WideProblem {
+  const char* X; const char* W; const float* bias; const float* residual; void* out;
+  const float* colscale; const int* m_dev;
+  int Mub, N, K;
+  float alpha, oscale;
+};
+
 // TN operands (wgrad: dW[O,I] = dY^T X with dY [M,O] and X [M,I] as the backward pass has them, the reduction index m being the
 // SLOW axis of both): out[Mm,Nn] = sum_k Xk[k,m] Wk[k,n].  A stage holds 64 k-rows of both operands as they lie in memory (rows
 // of 512 B = this tile's 256 n, rows of 256 B = its 128 m; LDS-DMA pieces are whole rows, 16-byte chunks XOR-swizzled on the
@@ -115,15 +132,28 @@ struct WideScales {
 __device__ const uint4 g_wide_zero[16] = {};   // 256 zero bytes: the source of k-rows past the end of the Xk operand
 typedef __attribute__((ext_vector_type(2))) uint32_t w_u32x2_t;
 
-template <int DT, int OK, int MF, bool TN = false>   // DT: 0 f32, 1 bf16, 2 fp8 operands; OK: 0 f32, 1 16-bit (bf16 / fp16), 2 fp8
-                                    // outputs; MF = 16-row m-fragments per wave: tile rows = 32*MF (160, 128 or 96); TN: above
+template <int DT, int OK, int MF, bool TN = false, bool GRP = false>   // DT: 0 f32, 1 bf16, 2 fp8 operands; OK: 0 f32, 1 16-bit (bf16 /
+                                    // fp16), 2 fp8 outputs; MF = 16-row m-fragments per wave: tile rows = 32*MF (160, 128 or 96); TN, GRP: above
 __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__ X, const char* __restrict__ W,
-                                                        const float* __restrict__ bias, const float* residual,
-                                                        void* out, int Mub, int N, int K, int epi, int ksplit, int ordG,
-                                                        WideScales sc) {
+                                                        const float* __restrict__ bias_a, const float* residual_a,
+                                                        void* out_a, int Mub, int N_a, int K, int epi, int ksplit, int ordG,
+                                                        WideScales sc_a, WideProblem p1) {
+  // The names the compute side (K loop, epilogue) reads.  Plain launches never reassign them - they ARE the arguments; a grouped
+  // launch moves them to the second problem once per workgroup (to_problem1 below).  The issue side, which runs up to three stages
+  // ahead of the compute side, keeps its own view (i_* in set_issue_tile).
+  const float* bias = bias_a;
+  const float* residual = residual_a;
+  void* out = out_a;
+  int N = N_a;
+  WideScales sc = sc_a;
   // M: the row count; sc.m_dev (packed text rows) holds the real one on the device, Mub is then only an upper bound
   int M = Mub;
   if (sc.m_dev) { const int md = *sc.m_dev; M = md < Mub ? md : Mub; }
+  int M1 = 0;          // GRP: the second problem's row count
+  if constexpr (GRP) {
+    M1 = p1.Mub;
+    if (p1.m_dev) { const int md = *p1.m_dev; M1 = md < M1 ? md : M1; }
+  }
   constexpr bool F32 = DT == 0, FP8 = DT == 2, OUTBF = OK == 1, OUT8 = OK == 2;
   constexpr int BMt = 32 * MF;                       // tile rows
   constexpr int WR = 16 * MF;                        // rows per wave
@@ -136,6 +166,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   constexpr int NM = 4 * MF;                         // MFMAs per 32-deep half-step
   static_assert(MF >= 3 && MF <= 5, "wave layout: 2(m) x 4(n) waves of MF x 4 fragments");
   static_assert(!TN || (DT == 1 && OK == 0 && MF == 4), "TN: bf16 operands, f32 (split-K) output, 128-row tile");
+  static_assert(!GRP || !TN, "grouped launches: the NT forward GEMMs only (no split-K, plain n-fastest tile order)");
   constexpr int PSTEP = MF == 3 ? 2 : 3;             // one LDS-DMA piece per PSTEP MFMAs: 6 (MF = 3, 4) or 7 pieces in 4*MF MFMAs
   __shared__ __attribute__((aligned(1024))) char lds[3 * STG];
 
@@ -156,7 +187,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   const int xpiece1 = wid + 8 < XP ? wid + 8 : wid;
 
   // ---- this workgroup's tiles: XCD x = blockIdx%8 owns a contiguous range of the n-fastest tile order ----
-  const int tiles_n = N / wBN;
+  int tiles_n = N / wBN;
   const int tiles_m = (M + BMt - 1) / BMt;
   // split-K (wgrad: few output tiles, very long K): virtual tile v = split * base_total + tile computes K-steps
   // [split * nk, (split + 1) * nk) into the f32 partial plane out + split * M * N (summed by splitk_reduce_kernel)
@@ -166,10 +197,23 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   const int q = total >> 3, r = total & 7;
   const int range_lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   const int range_len = xcd < r ? q + 1 : q;
-  const int my_tiles = slot < range_len ? (range_len - slot + per_xcd_blocks - 1) / per_xcd_blocks : 0;
+  // GRP: this XCD's contiguous range of the SECOND problem's tiles follows its range of the first in the workgroups' stride:
+  // position j = slot + ti * per_xcd_blocks of the concatenation, so a workgroup's first n_first tiles are the first problem's
+  int tiles_n1 = 0, range_lo1 = 0, range_len1 = 0, n_first = 0;
+  if constexpr (GRP) {
+    tiles_n1 = p1.N / wBN;
+    const int total1 = tiles_n1 * ((M1 + BMt - 1) / BMt);
+    const int q1 = total1 >> 3, r1 = total1 & 7;
+    range_lo1 = xcd < r1 ? xcd * (q1 + 1) : r1 * (q1 + 1) + (xcd - r1) * q1;
+    range_len1 = xcd < r1 ? q1 + 1 : q1;
+    n_first = slot < range_len ? (range_len - slot + per_xcd_blocks - 1) / per_xcd_blocks : 0;
+  }
+  const int span = GRP ? range_len + range_len1 : range_len;
+  const int my_tiles = slot < span ? (span - slot + per_xcd_blocks - 1) / per_xcd_blocks : 0;
   if (my_tiles == 0) return;
 
-  const int nk = K / BK / ksplit;   // K-steps per (virtual) tile
+  int nk = K / BK / ksplit;   // K-steps per (virtual) tile
+  const int nk1 = GRP ? p1.K / BK : 0;
   // Tile order inside the n-fastest ranges above would sweep ALL of W (3.5 MB at N = 2304, K = 768) with every round of an XCD's
   // 32 workgroups: more than its 4 MiB L2 holds next to the X tiles and the outputs passing through, so W came back from the
   // Infinity Cache once per round (round 1: 4.4x read amplification on the QKV / c_fc shapes).  Order: bands of `band` m-tiles
@@ -190,6 +234,18 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
     tn = g * ordG + (rem2 - mi * glen);
   };
   const uint32_t row_stride = static_cast<uint32_t>(K) * ELT;
+  // (virtual) tile ti of this workgroup -> its split and its logical index in the n-fastest order of its problem
+  auto tile_logical = [&](int ti, int& split) {
+    if constexpr (GRP) {
+      split = 0;
+      const int j = slot + ti * per_xcd_blocks;
+      return ti < n_first ? range_lo + j : range_lo1 + (j - range_len);
+    } else {
+      const int virt = range_lo + slot + ti * per_xcd_blocks;
+      split = virt / base_total;
+      return virt - split * base_total;
+    }
+  };
 
   // ---- issue side.  DMA source = uniform tile base (SGPRs) + 32-bit per-lane offset (one VGPR per piece):
   // lane i of a 1-KiB piece fills LDS (row 8*piece + i/8, physical chunk i%8) and fetches logical chunk (i%8)^(row&7).
@@ -220,7 +276,39 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   int issue_krow0 = 0;   // TN: first k-row of the (virtual) tile being staged
   const char* Wt = W;   // W + n0*row_stride (+ the split's K offset) of the tile being staged
   const char* Xt = X;   // X (+ the split's K offset)
+  // GRP: the issue side's view of the problem it is staging (the kernel arguments until its first tile of the second problem)
+  bool i_second = false;
+  int i_nk = nk, i_M = M;
+  uint32_t i_row_stride = row_stride;
   auto set_issue_tile = [&](int ti) {
+    if constexpr (GRP) {
+      int split;
+      const int logical = tile_logical(ti, split);
+      if (ti >= n_first && !i_second) {      // once per workgroup: the W-piece offsets follow the second problem's row stride
+        i_second = true;
+        i_nk = nk1;
+        i_M = M1;
+        i_row_stride = static_cast<uint32_t>(p1.K) * ELT;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = (wid * 4 + i) * 8 + sub;
+          offW[i] = static_cast<uint32_t>(row) * i_row_stride + (((lane & 7) ^ (row & 7)) << 4);
+        }
+      }
+      const int tn_i = i_second ? tiles_n1 : N_a / wBN;
+      const int tm = logical / tn_i, tn = logical - tm * tn_i;
+      const int m0 = tm * BMt, n0 = tn * wBN;
+      Wt = (i_second ? p1.W : W) + static_cast<size_t>(n0) * i_row_stride;
+      Xt = i_second ? p1.X : X;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int row = (i == 1 ? xpiece1 : wid + 8 * i) * 8 + sub;
+        int xr = m0 + row;
+        xr = xr < i_M ? xr : i_M - 1;
+        offX[i] = static_cast<uint32_t>(xr) * i_row_stride + (((lane & 7) ^ (row & 7)) << 4);
+      }
+      return;
+    }
     const int virt = range_lo + slot + ti * per_xcd_blocks;
     const int split = virt / base_total, logical = virt - split * base_total;
     int tm, tn;
@@ -274,7 +362,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   // the workgroup's last one re-stage its last tile into buffers nobody reads any more (drained before the kernel ends).
   auto issue_done = [&]() {
     issue_buf = issue_buf == 2 ? 0 : issue_buf + 1;
-    if (++issue_kt == nk) {
+    if (++issue_kt == (GRP ? i_nk : nk)) {
       issue_kt = 0;
       if (++issue_tile < my_tiles) set_issue_tile(issue_tile);
     }
@@ -348,11 +436,12 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   bool pend_valid = false;
   char* pend_ptr = nullptr;            // &out[(m0 + wm*WR + frow) * N + col] of the pending tile
   constexpr int OEL = OUT8 ? 1 : 2;    // bytes per output element of the packed store paths
-  const size_t row16 = static_cast<size_t>(16) * N * OEL;   // bytes between the 16-row fragments of a wave
-  const int sps = (NDEFER + nk - 1) / nk;   // stores per K-step so that all of them leave within one tile's K loop
+  size_t row16 = static_cast<size_t>(16) * N * OEL;   // bytes between the 16-row fragments of a wave
+  size_t pend_row16 = row16;                          // GRP: the same of the PENDING tile (it may belong to the first problem still)
+  int sps = (NDEFER + nk - 1) / nk;   // stores per K-step so that all of them leave within one tile's K loop
   auto store_pending = [&](int idx) {
     switch (idx) {   // compile-time register choice per case: no dynamically indexed vector arrays (they would go to scratch)
-#define W_ST(j) case j: if constexpr (j < NPEND) w_store16(pend_ptr + (OUT8 ? j : j / 2) * row16 + (OUT8 ? 0 : (j % 2) * 64), pend[j < NPEND ? j : 0]); break;
+#define W_ST(j) case j: if constexpr (j < NPEND) w_store16(pend_ptr + (OUT8 ? j : j / 2) * (GRP ? pend_row16 : row16) + (OUT8 ? 0 : (j % 2) * 64), pend[j < NPEND ? j : 0]); break;
       W_ST(0) W_ST(1) W_ST(2) W_ST(3) W_ST(4) W_ST(5) W_ST(6) W_ST(7) W_ST(8) W_ST(9)
 #undef W_ST
       default: break;
@@ -382,6 +471,16 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   // (Round 3 tried the other order - stage 0's DMA first, the residual rows behind it as inline-asm loads under the same counted
   // wait, added after the other prologue stages were issued: 0.5 % slower on the bench line, A/B/A/B on one box; not kept.)
   // (fp8 launches always carry EPI_SCALE: never there - said at compile time, so that the prologue holds no residual code)
+  // GRP: the compute side moves on to the second problem (once per workgroup: before its first tile if it has none of the first
+  // problem's, else at the top of tile n_first)
+  [[maybe_unused]] auto to_problem1 = [&]() {
+    M = M1; N = p1.N; bias = p1.bias; residual = p1.residual; out = p1.out;
+    sc.colscale = p1.colscale; sc.alpha = p1.alpha; sc.oscale = p1.oscale;
+    nk = nk1; tiles_n = tiles_n1;
+    row16 = static_cast<size_t>(16) * N * OEL;
+    sps = (NDEFER + nk - 1) / nk;
+  };
+  if constexpr (GRP) { if (n_first == 0) to_problem1(); }
   const bool res_first = !FP8 && (epi & EPI_RESIDUAL) && !(epi & (EPI_QUICKGELU | EPI_GELU | EPI_RELU | EPI_SCALE)) && nk <= 16;
   auto mfma = [&](const w_u32x4_t& fw, const w_u32x4_t& fx, w_f32x4_t& c) {
     if constexpr (FP8) {
@@ -508,7 +607,8 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
     for (int b = 0; b < MF; ++b) acc[a][b] = w_f32x4_t{0.f, 0.f, 0.f, 0.f};
   if (res_first) {
     int tm, tn;
-    tile_coords(range_lo + slot, tm, tn);
+    if constexpr (GRP) { int sp_; tile_coords(tile_logical(0, sp_), tm, tn); }
+    else tile_coords(range_lo + slot, tm, tn);
     add_residual(tm * BMt, tn * wBN);
   }
   set_issue_tile(0);
@@ -596,6 +696,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < MF; ++b) acc[a][b] = w_f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if constexpr (GRP) { if (ti == n_first) to_problem1(); }
     }
     if constexpr (TN) {
       if (sc.colsum) {
@@ -807,8 +908,8 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
     if (ti == my_tiles - 1) W_TL(3);   // last tile's K loop done
 
     // ---- epilogue of tile ti (the next tile's first stages are already in flight) ----------------------------
-    const int virt = range_lo + slot + ti * per_xcd_blocks;
-    const int split = virt / base_total, logical = virt - split * base_total;
+    int split;
+    const int logical = tile_logical(ti, split);
     int tm, tn;
     tile_coords(logical, tm, tn);
     const int m0 = tm * BMt, n0 = tn * wBN;
@@ -961,6 +1062,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
         pend[b][0] = q01[0]; pend[b][1] = q01[1]; pend[b][2] = q23[0]; pend[b][3] = q23[1];
       }
       pend_ptr = static_cast<char*>(out) + static_cast<size_t>(m0 + wm * WR + frow) * N + n0 + wn * 64 + fq * 16;
+      if constexpr (GRP) pend_row16 = row16;
       if (full && ti + 1 < my_tiles && !(epi & (256 | 512))) {
         pend_valid = true;
       } else if (!(epi & 256)) {
@@ -996,6 +1098,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
         }
       }
       pend_ptr = static_cast<char*>(out) + (static_cast<size_t>(m0 + wm * WR + frow) * N + col) * 2;
+      if constexpr (GRP) pend_row16 = row16;
       if (DEFER && full && ti + 1 < my_tiles && !(epi & (256 | 512))) {   // 512 = ablation: store from the epilogue
         pend_valid = true;                       // leave under the next tile's MFMAs
 #pragma unroll
@@ -1107,10 +1210,10 @@ int launch_gemm_wide_splitk(int dt, const void* A, const void* W, float* out, fl
   const int grid = total < cus ? ((total + 7) & ~7) : cus;
   if (dt == CMH_F32)
     hipLaunchKernelGGL((gemm_wide_kernel<0, 0, 5>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),
-                       static_cast<const char*>(W), nullptr, nullptr, partials, M, N, K, 0, S, wide_order_group(N), WideScales{nullptr, 1.f, 1.f, 0, nullptr, nullptr});
+                       static_cast<const char*>(W), nullptr, nullptr, partials, M, N, K, 0, S, wide_order_group(N), WideScales{nullptr, 1.f, 1.f, 0, nullptr, nullptr}, WideProblem{});
   else
     hipLaunchKernelGGL((gemm_wide_kernel<1, 0, 5>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(A),
-                       static_cast<const char*>(W), nullptr, nullptr, partials, M, N, K, 0, S, wide_order_group(N), WideScales{nullptr, 1.f, 1.f, 0, nullptr, nullptr});
+                       static_cast<const char*>(W), nullptr, nullptr, partials, M, N, K, 0, S, wide_order_group(N), WideScales{nullptr, 1.f, 1.f, 0, nullptr, nullptr}, WideProblem{});
   const size_t n = static_cast<size_t>(M) * N;
   const size_t blocks = (n / 4 + 255) / 256;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, partials, S, n, out);
@@ -1146,7 +1249,7 @@ int launch_gemm_wide_tn(const void* Xk, const void* Wk, float* out, float* parti
   if (colsum_slices) *colsum_slices = S;
   hipLaunchKernelGGL((gemm_wide_kernel<1, 0, 4, true>), dim3(grid), dim3(512), 0, st, static_cast<const char*>(Xk),
                      static_cast<const char*>(Wk), nullptr, nullptr, S > 1 ? static_cast<void*>(partials) : static_cast<void*>(out),
-                     Mm, Nn, Kpad, 0, S, 0, sc);
+                     Mm, Nn, Kpad, 0, S, 0, sc, WideProblem{});
   if (S > 1) {
     const size_t n = static_cast<size_t>(Mm) * Nn;
     const size_t blocks = (n / 4 + 255) / 256;
@@ -1197,13 +1300,13 @@ int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, co
   do {                                                                                                                    \
     if (mf == 3)                                                                                                          \
       W_GO((gemm_wide_kernel<DT, OK, 3>), grid, st, static_cast<const char*>(A), static_cast<const char*>(W), bias,       \
-           residual, out, M, N, K, epi, 1, ordg, sc);                                                                     \
+           residual, out, M, N, K, epi, 1, ordg, sc, WideProblem{});                                                                     \
     else if (mf == 4)                                                                                                     \
       W_GO((gemm_wide_kernel<DT, OK, 4>), grid, st, static_cast<const char*>(A), static_cast<const char*>(W), bias,       \
-           residual, out, M, N, K, epi, 1, ordg, sc);                                                                     \
+           residual, out, M, N, K, epi, 1, ordg, sc, WideProblem{});                                                                     \
     else                                                                                                                  \
       W_GO((gemm_wide_kernel<DT, OK, 5>), grid, st, static_cast<const char*>(A), static_cast<const char*>(W), bias,       \
-           residual, out, M, N, K, epi, 1, ordg, sc);                                                                     \
+           residual, out, M, N, K, epi, 1, ordg, sc, WideProblem{});                                                                     \
   } while (0)
   const bool obf = epi & (EPI_OUT_BF16 | EPI_OUT_F16);   // 16-bit outputs share the packed store path
   const bool o8 = epi & EPI_OUT_FP8;
@@ -1215,21 +1318,21 @@ int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, co
   do {                                                                                                                    \
     if (mf == 3)                                                                                                          \
       W_GO((gemm_wide_kernel<DT, OK, 3>), grid, st, static_cast<const char*>(A), static_cast<const char*>(W), bias,       \
-           residual, out, M, N, K, epi, 1, ordg, sc);                                                                     \
+           residual, out, M, N, K, epi, 1, ordg, sc, WideProblem{});                                                                     \
     else                                                                                                                  \
       W_GO((gemm_wide_kernel<DT, OK, 4>), grid, st, static_cast<const char*>(A), static_cast<const char*>(W), bias,       \
-           residual, out, M, N, K, epi, 1, ordg, sc);                                                                     \
+           residual, out, M, N, K, epi, 1, ordg, sc, WideProblem{});                                                                     \
   } while (0)
     if (o8) {
       if (mf == 5)
         W_GO((gemm_wide_kernel<2, 2, 5>), grid, st, static_cast<const char*>(A), static_cast<const char*>(W), bias, residual, out, M, N,
-             K, epi, 1, ordg, sc);
+             K, epi, 1, ordg, sc, WideProblem{});
       else
         W_LAUNCH(2, 2);
     } else if (obf) {
       if (mf == 5)
         W_GO((gemm_wide_kernel<2, 1, 5>), grid, st, static_cast<const char*>(A), static_cast<const char*>(W), bias, residual, out, M, N,
-             K, epi, 1, ordg, sc);
+             K, epi, 1, ordg, sc, WideProblem{});
       else
         W_LAUNCH(2, 1);
     } else {
@@ -1237,6 +1340,72 @@ int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, co
     }
   }
 #undef W_LAUNCH
+  return 0;
+}
+
+// Two problems in one persistent grid (template parameter GRP; see WideProblem).  `a` should be the problem with the longer K (its
+// tiles go first); both share dt, the output kind and the epilogue flags.  The tile height is the one whose WORST workgroup - the
+// kernel's own static assignment, replayed here - finishes first.
+int launch_gemm_wide_grouped(int dt, const GemmProblem& a, const GemmProblem& b, int epi, hipStream_t st) {
+  const size_t esz = dt == CMH_F32 ? 4 : (dt == CMH_FP8 ? 1 : 2);
+  for (const GemmProblem* g : {&a, &b})
+    if (static_cast<size_t>(g->M) * g->K * esz >= (1ull << 32) || static_cast<size_t>(wBN) * g->K * esz >= (1ull << 32))
+      return fail(CMH_ERR_INVALID, "gemm (grouped): operand of %zu bytes exceeds the 32-bit offset range of the wide kernel",
+                  static_cast<size_t>(g->M) * g->K * esz);
+  const int cus = wide_cus();
+  const int bk = dt == CMH_F32 ? 32 : (dt == CMH_FP8 ? 128 : 64);
+  const int nk0 = a.K / bk, nk1 = b.K / bk;
+  auto likely = [](const GemmProblem& g) { return g.m_dev && g.m_hint > 0 && g.m_hint <= g.M ? g.m_hint : g.M; };
+  const int Ma = likely(a), Mb = likely(b);
+  auto tiles_of = [](int M, int N, int mf) { return (N / wBN) * ((M + 32 * mf - 1) / (32 * mf)); };
+  auto grid_of = [&](int mf) {   // sized for the upper bounds: workgroups beyond the real tile count exit at once
+    const int total = tiles_of(a.M, a.N, mf) + tiles_of(b.M, b.N, mf);
+    return total < cus ? ((total + 7) & ~7) : cus;
+  };
+  auto cost = [&](int mf) {
+    const int t0 = tiles_of(Ma, a.N, mf), t1 = tiles_of(Mb, b.N, mf), per = grid_of(mf) >> 3;
+    long long worst = 0;
+    for (int x = 0; x < 8; ++x) {
+      const int len0 = (t0 >> 3) + (x < (t0 & 7)), len1 = (t1 >> 3) + (x < (t1 & 7));
+      for (int sl = 0; sl < per; ++sl) {
+        const int n0 = sl < len0 ? (len0 - sl + per - 1) / per : 0;
+        const int nall = sl < len0 + len1 ? (len0 + len1 - sl + per - 1) / per : 0;
+        const long long c = static_cast<long long>(n0) * (nk0 + 4) + static_cast<long long>(nall - n0) * (nk1 + 4);
+        worst = c > worst ? c : worst;
+      }
+    }
+    return worst * (10 * mf + 6);
+  };
+  const int forced = g_force_rows;
+  const bool fp8_160 = epi & EPI_OUT_FP8;       // (the 16-bit-output 160-row fp8 variant is an opt-in of the plain launches only)
+  int mf = dt == CMH_FP8 && !fp8_160 ? 4 : 5;
+  if (mf == 5 && cost(4) < cost(mf)) mf = 4;
+  if (cost(3) < cost(mf)) mf = 3;
+  if (forced == 96 || forced == 128 || (forced == 160 && (dt != CMH_FP8 || fp8_160))) mf = forced / 32;
+  const int grid = grid_of(mf);
+  const WideScales sc{a.colscale, a.alpha, a.oscale, 0, nullptr, a.m_dev};
+  const WideProblem p1{static_cast<const char*>(b.A), static_cast<const char*>(b.W), b.bias, b.residual, b.out, b.colscale, b.m_dev,
+                       b.M, b.N, b.K, b.alpha, b.oscale};
+#define W_LAUNCH_G(DT, OK, MFV)                                                                                            \
+  W_GO((gemm_wide_kernel<DT, OK, MFV, false, true>), grid, st, static_cast<const char*>(a.A), static_cast<const char*>(a.W), a.bias, \
+       a.residual, a.out, a.M, a.N, a.K, epi, 1, 0, sc, p1)
+#define W_LAUNCH_G3(DT, OK)                                                                                                \
+  do { if (mf == 3) W_LAUNCH_G(DT, OK, 3); else if (mf == 4) W_LAUNCH_G(DT, OK, 4); else W_LAUNCH_G(DT, OK, 5); } while (0)
+  const bool obf = epi & (EPI_OUT_BF16 | EPI_OUT_F16);
+  if (dt == CMH_F32) {
+    if (obf) return fail(CMH_ERR_INVALID, "gemm (grouped): f32 operands come with f32 outputs");
+    W_LAUNCH_G3(0, 0);
+  } else if (dt == CMH_BF16) {
+    if (!obf) return fail(CMH_ERR_INVALID, "gemm (grouped): bf16 operands come with 16-bit outputs");
+    W_LAUNCH_G3(1, 1);
+  } else if (epi & EPI_OUT_FP8) {
+    W_LAUNCH_G3(2, 2);
+  } else {
+    if (!obf) return fail(CMH_ERR_INVALID, "gemm (grouped): fp8 operands come with 16-bit or e4m3 outputs");
+    if (mf == 3) W_LAUNCH_G(2, 1, 3); else W_LAUNCH_G(2, 1, 4);
+  }
+#undef W_LAUNCH_G3
+#undef W_LAUNCH_G
   return 0;
 }
 

@@ -16,6 +16,10 @@ class SyntheticPairs(Dataset):
     image pattern and a few caption tokens, an item shows the patterns / tokens of its labels plus noise — something a model can
     learn, so a few epochs must raise the mAP (tests/test_gpu_heads_losses.py::test_training_learns)."""
     signal = 0.0
+    # tile > 0: a class's image pattern is ONE tile x tile block repeated over the image (tile = the ViT's patch size: every patch
+    # embedding then moves the same way, which survives the near-uniform attention of a random-init tower - a full-size noise
+    # pattern averages out over the 49 patches and every image collapses onto one hash code); 0: a full-size pattern
+    tile = 0
 
     def __init__(self, ids, labels, max_words, resolution, seed):
         self.ids, self.labels = ids, labels
@@ -39,7 +43,12 @@ class SyntheticPairs(Dataset):
             classes = np.nonzero(self.labels[index])[0]
             for c in classes:
                 proto = np.random.default_rng([self.seed, 7919, int(c)])
-                image += self.signal * proto.standard_normal(image.shape).astype(np.float32)
+                if self.tile > 0:
+                    reps = -(-self.resolution // self.tile)
+                    block = proto.standard_normal((3, self.tile, self.tile)).astype(np.float32)
+                    image += self.signal * np.tile(block, (1, reps, reps))[:, :self.resolution, :self.resolution]
+                else:
+                    image += self.signal * proto.standard_normal(image.shape).astype(np.float32)
                 words = proto.integers(1, SOT, size=3)                       # the class's caption tokens
                 for w in words:
                     cap[int(rng.integers(1, max(n, 2)))] = w

@@ -66,6 +66,7 @@ np.savez(os.path.join(out, f"grads_{tag}.npz"), **grads)
 sync = getattr(tr, "_grad_sync", None)
 tower_p = tr.model.clip.visual.transformer.resblocks[0].attn.in_proj_weight
 json.dump({"loss": float(loss.detach()), "maps": maps, "n_grads": len(grads),
+           "backend": torch.distributed.get_backend() if du.active() else None,
            "buckets": [list(b) for b in sync.bucket_log] if sync is not None else None,          # in-place messages of the step
            "tower_grad_is_view": tower_p.grad is not None and tower_p.grad.untyped_storage().nbytes() > 4 * tower_p.grad.numel()},
           open(os.path.join(out, f"res_{tag}.json"), "w"))
