@@ -193,7 +193,10 @@ def main():
     ap.add_argument("--train-step", action="store_true",
                     help="also time the training step when --gpus > 1 (default: single-GPU runs only, so that the secondary "
                          "metric's gradient all-reduce can never stall the headline scaling line)")
-    ap.add_argument("--no-overlap-towers", action="store_true", help="run the text tower after the image tower on one stream")
+    ap.add_argument("--towers", default="streams", choices=["pair", "streams", "serial"],
+                    help="how a step runs the two towers: pair = in lock-step, layer i of both sharing its GEMM launches (cmh_clip_encode_pair); "
+                         "streams = one HIP stream per tower; serial = the text tower after the image tower on one stream")
+    ap.add_argument("--no-overlap-towers", action="store_true", help="= --towers serial")
     ap.add_argument("--no-precision-legs", action="store_true", help="skip flip_rate_vs_f32 and the timed f32-mode / fp8-mode legs")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the one-number-per-BASELINE-config legs (bench_configs.py)")
     ap.add_argument("--map-queries", type=int, default=5000)
@@ -229,9 +232,20 @@ def main():
         N.pack_codes(N.sign_codes(h), validate=False)
         return h
 
-    def step(overlap=not a.no_overlap_towers):
+    towers = "serial" if a.no_overlap_towers else a.towers
+
+    def finish(head, feat):
+        h = head(feat)
+        N.pack_codes(N.sign_codes(h), validate=False)
+        return h
+
+    def step(overlap=None, how=None):
+        how = how or ("serial" if overlap is False else towers)
         with torch.no_grad():
-            if overlap:   # the two towers are independent until the loss: one HIP stream each (streams.py)
+            if how == "pair":       # both towers in lock-step: layer i of both is one grouped GEMM launch (csrc/encoders.hip)
+                fi, ft = clip.encode_pair(image, text)
+                hi, ht = finish(img_head, fi), finish(txt_head, ft)
+            elif how == "streams":   # the two towers are independent until the loss: one HIP stream each (streams.py)
                 hi, ht = overlapped(lambda: tower(clip.encode_image, img_head, image),
                                     lambda: tower(clip.encode_text, txt_head, text))
             else:
@@ -257,7 +271,7 @@ def main():
     for _ in range(a.warmup):
         step()
     barrier()
-    overlap = not a.no_overlap_towers
+    overlap = towers == "streams"      # per-launch events overlap only when the towers run on two streams
     reps = max(1, a.repeats)
     if not overlap:
         N.prof_gemm_begin(a.steps * reps * 128)
@@ -335,6 +349,8 @@ def main():
                     total += M * K * e + Nn * K * e + M * Nn * osz + res * M * Nn * xs
                     n += 1
         total += B * 49 * 3072 * e + 768 * 3072 * e + B * 49 * 768 * 4                         # conv1 as a GEMM
+        if towers == "pair":      # layer i of both towers is ONE launch: 45 grouped launches + conv1
+            n //= 2
         return total, n + 1
     # HBM-side bytes per GEMM launch cannot be counted from inside this process: they come from the two rocprofv3 --pmc
     # passes of this same command (tools/pmc_bench_traffic.sh), committed under profiles/; null if absent / other dtype.
@@ -361,7 +377,9 @@ def main():
                                f"{L}-token captions: encode_image+encode_text -> LinearHash -> sign -> pack -> "
                                "[all-gather] -> HyP loss fwd", "per_gpu_batch": B, "global_batch": B * world,
                    "seq_len": L, "bits": K, "weights": "random-init ViT-B/32", "parallelism": f"batch-shard x{world}",
-                   "streams": "image and text tower on one HIP stream each" if not a.no_overlap_towers else "single stream"},
+                   "towers": towers,
+                   "streams": {"pair": "one stream, the towers in lock-step: layer i of both shares its GEMM launches (grouped)",
+                               "streams": "image and text tower on one HIP stream each", "serial": "single stream, tower after tower"}[towers]},
         "per_gpu_value": round(value / world, 2),
         "text_rows": {"computed": rows_c, "dense": rows_d,
                       "note": "caption tokens after the EOT cannot reach the pooled feature under the causal mask; they are not "
@@ -404,7 +422,7 @@ def main():
             f32_ms = (time.perf_counter() - tf0) / nf * 1e3
             N.prof_gemm_begin(nf * 128)
             for _ in range(nf):
-                step(overlap=False)
+                step(how="pair" if towers == "pair" else "serial")
             torch.cuda.synchronize()
             N.prof_gemm_end()
             g_ms, g_fl, g_n = N.prof_gemm_by_kernel()["gemm_wide_kernel"]
@@ -436,7 +454,7 @@ def main():
             fp8_ms = (time.perf_counter() - t8) / a.steps * 1e3
             N.prof_gemm_begin(a.steps * 128)
             for _ in range(a.steps):
-                step(overlap=False)
+                step(how="pair" if towers == "pair" else "serial")
             torch.cuda.synchronize()
             N.prof_gemm_end()
             by8 = N.prof_gemm_by_kernel()

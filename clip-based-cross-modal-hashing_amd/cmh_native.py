@@ -32,6 +32,13 @@ class BlockWeights(C.Structure):
         "in_proj_cs", "out_proj_cs", "fc_cs", "proj_cs")] + [("act_scale", C.c_float * 4)]     # fp8 mode only
 
 
+class GemmProblem(C.Structure):
+    """include/cmh.h cmh_gemm_problem: one of the two GEMMs of a grouped launch."""
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("out", C.c_void_p),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("m_dev", C.c_void_p), ("colscale", C.c_void_p),
+                ("alpha", C.c_float), ("out_scale", C.c_float)]
+
+
 class VitWeights(C.Structure):
     _fields_ = [("gemm_dtype", C.c_int32), ("resolution", C.c_int32), ("patch", C.c_int32),
                 ("width", C.c_int32), ("layers", C.c_int32), ("embed_dim", C.c_int32),
@@ -97,6 +104,9 @@ SIGNATURES = {
     "cmh_gemm_tuning": (C.c_int, [_i32, _i32]),
     "cmh_set_pooled_tail": (C.c_int, [_i32]),
     "cmh_set_gemm_rows": (C.c_int, [_i32]),
+    "cmh_set_gemm_grouped": (C.c_int, [_i32]),
+    "cmh_linear_gemm_grouped": (C.c_int, [_i32, C.POINTER(GemmProblem), C.POINTER(GemmProblem), _i32, _p]),
+    "cmh_clip_encode_pair": (C.c_int, [C.POINTER(VitWeights), _p, C.POINTER(TextWeights), _p, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p, _sz, _p]),
     "cmh_msl_workspace_bytes": (_sz, [_i32]),
     "cmh_msl_loss": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _sz, _p]),
     "cmh_msl_loss_backward": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
@@ -336,6 +346,54 @@ def linear_gemm_fp8(x8, w8, colscale, alpha, bias=None, residual=None, quickgelu
     check(lib().cmh_linear_gemm_fp8(ptr(x8), ptr(w8), ptr(f32c(colscale)), float(alpha), ptr(None if bias is None else f32c(bias)),
                                     ptr(residual), ptr(o), float(out_scale), M, Nn, K, epi, stream_ptr(x8.device)), "cmh_linear_gemm_fp8")
     return o
+
+
+def set_gemm_grouped(on: int = -1):
+    """Layer i of both towers as ONE grouped GEMM launch (csrc/gemm_wide.hip, GRP): 1 on (default), 0 = two plain launches, -1 = environment
+    (CMH_GEMM_GROUPED=0 is off).  Results never depend on it."""
+    check(lib().cmh_set_gemm_grouped(int(on)), "cmh_set_gemm_grouped")
+
+
+def linear_gemm_grouped(problems, quickgelu=False, out="f32", m_dev=(None, None)):
+    """Two GEMMs of one kind as one launch (include/cmh.h: cmh_linear_gemm_grouped).  problems = two dicts with x, w and optionally
+    bias, residual, and - e4m3 operands (uint8 tensors) - colscale, alpha, out_scale; out in {"f32", "bf16", "f16", "fp8"};
+    m_dev: per problem an int32 device tensor holding the real row count (or None).  Returns the two outputs."""
+    assert len(problems) == 2
+    kinds = {("u8" if p["x"].dtype == torch.uint8 else ("bf16" if p["x"].dtype == torch.bfloat16 else "f32")) for p in problems}
+    if len(kinds) != 1:
+        raise NativeError("linear_gemm_grouped: both problems must share the operand type")
+    kind = kinds.pop()
+    dt = {"f32": F32, "bf16": BF16, "u8": FP8}[kind]
+    odt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16, "fp8": torch.uint8}[out]
+    has_bias = problems[0].get("bias") is not None
+    has_res = problems[0].get("residual") is not None
+    res_f16 = has_res and problems[0]["residual"].dtype == torch.float16
+    epi = (EPI_BIAS if has_bias else 0) | (EPI_QUICKGELU if quickgelu else 0) | (EPI_RESIDUAL if has_res else 0) | \
+          (EPI_RES_F16 if res_f16 else 0) | {"f32": 0, "bf16": EPI_OUT_BF16, "f16": EPI_OUT_F16, "fp8": EPI_OUT_FP8}[out]
+    structs, outs, keep = [], [], []
+    for p, md in zip(problems, m_dev):
+        x, w = p["x"].contiguous(), p["w"].contiguous()
+        require_gpu(x, w, p.get("bias"), p.get("residual"), p.get("colscale"), md)
+        M, K = x.shape
+        Nn = w.shape[0]
+        if w.shape[1] != K or (p.get("bias") is not None) != has_bias or (p.get("residual") is not None) != has_res or \
+                (has_bias and p["bias"].numel() != Nn) or (has_res and tuple(p["residual"].shape) != (M, Nn)) or \
+                (kind == "u8" and (p.get("colscale") is None or p["colscale"].numel() != Nn)):
+            raise NativeError(f"linear_gemm_grouped: x {tuple(x.shape)}, w {tuple(w.shape)}: operand shapes / kinds do not fit together")
+        o = torch.empty(M, Nn, dtype=odt, device=x.device)
+        bias = f32c(p["bias"]) if has_bias else None
+        res = None
+        if has_res:
+            res = p["residual"].contiguous() if res_f16 else f32c(p["residual"])
+        cs = f32c(p["colscale"]) if kind == "u8" else None
+        g = GemmProblem(ptr(x), ptr(w), ptr(bias), ptr(res), ptr(o), M, Nn, K, ptr(md), ptr(cs), float(p.get("alpha", 1.0)),
+                        float(p.get("out_scale", 1.0)))
+        structs.append(g)
+        outs.append(o)
+        keep += [x, w, bias, res, cs]
+    check(lib().cmh_linear_gemm_grouped(dt, C.byref(structs[0]), C.byref(structs[1]), epi, stream_ptr(outs[0].device)),
+          "cmh_linear_gemm_grouped")
+    return outs
 
 
 def set_pooled_tail(on: bool):

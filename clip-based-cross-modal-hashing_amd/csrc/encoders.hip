@@ -147,7 +147,8 @@ bool pooled_tail_enabled() {
 
 static int run_block_pooled(const cmh_block_weights& w, int dtb, const TowerBufs& t, int B, int T, int d, int causal,
                             const uint8_t* kpm, hipStream_t st, int M, const int32_t* seq_off, void** x_pooled,
-                            const int32_t* md = nullptr, int mh = -1) {
+                            const int32_t* md = nullptr, int mh = -1,
+                            bool head_done = false) {   // ln_1, QKV and the attention have run already (run_block_pair)
   const int dt = dtb == CMH_FP8 ? CMH_BF16 : dtb;
   const size_t e = dt == CMH_BF16 ? 2 : 4, xe = t.xh ? 2 : 4;
   const int obf = dt == CMH_BF16 ? EPI_OUT_BF16 : 0;
@@ -160,9 +161,11 @@ static int run_block_pooled(const cmh_block_weights& w, int dtb, const TowerBufs
   if (dtb == CMH_FP8) {
     CMH_CHECK_ARG(t.xh && w.in_proj_cs && w.out_proj_cs && w.fc_cs && w.proj_cs && a[0] > 0.f && a[1] > 0.f && a[2] > 0.f && a[3] > 0.f,
                   "fp8 mode: scales missing (run the calibration pass)");
-    if ((rc = launch_layernorm_q(t.x, w.ln1_w, w.ln1_b, t.h, 1.0f / a[0], M, d, st, md))) return rc;
-    if ((rc = launch_gemm_fp8(t.h, w.in_proj_w, w.in_proj_cs, a[0], w.in_proj_b, nullptr, t.qkv, 1.f, M, 3 * d, d, EPI_BIAS | EPI_OUT_BF16, st, md, mh))) return rc;
-    if ((rc = launch_attention_varlen(t.qkv, t.h, CMH_BF16, B, T, d, causal, kpm, seq_off, st, 1.0f / a[1]))) return rc;
+    if (!head_done) {
+      if ((rc = launch_layernorm_q(t.x, w.ln1_w, w.ln1_b, t.h, 1.0f / a[0], M, d, st, md))) return rc;
+      if ((rc = launch_gemm_fp8(t.h, w.in_proj_w, w.in_proj_cs, a[0], w.in_proj_b, nullptr, t.qkv, 1.f, M, 3 * d, d, EPI_BIAS | EPI_OUT_BF16, st, md, mh))) return rc;
+      if ((rc = launch_attention_varlen(t.qkv, t.h, CMH_BF16, B, T, d, causal, kpm, seq_off, st, 1.0f / a[1]))) return rc;
+    }
     if ((rc = launch_gather_rows2(t.x, xp, static_cast<int>(d * xe), t.h, hp, d, t.rows, B, st))) return rc;
     if ((rc = launch_gemm_fp8(hp, w.out_proj_w, w.out_proj_cs, a[1], w.out_proj_b, xp, xp, 1.f, B, d, d, rx, st))) return rc;
     if ((rc = launch_layernorm_q(xp, w.ln2_w, w.ln2_b, hp, 1.0f / a[2], B, d, st))) return rc;
@@ -170,9 +173,11 @@ static int run_block_pooled(const cmh_block_weights& w, int dtb, const TowerBufs
                               EPI_BIAS | EPI_QUICKGELU | EPI_OUT_FP8, st))) return rc;
     if ((rc = launch_gemm_fp8(t.mlp, w.proj_w, w.proj_cs, a[3], w.proj_b, xp, xp, 1.f, B, d, 4 * d, rx, st))) return rc;
   } else {
-    if ((rc = launch_layernorm_x(t.x, t.xh, nullptr, w.ln1_w, w.ln1_b, t.h, dt == CMH_BF16, M, d, st, md))) return rc;
-    if ((rc = launch_gemm(dt, t.h, w.in_proj_w, w.in_proj_b, nullptr, t.qkv, M, 3 * d, d, EPI_BIAS | obf, st, md, mh))) return rc;
-    if ((rc = launch_attention_varlen(t.qkv, t.h, dt, B, T, d, causal, kpm, seq_off, st))) return rc;
+    if (!head_done) {
+      if ((rc = launch_layernorm_x(t.x, t.xh, nullptr, w.ln1_w, w.ln1_b, t.h, dt == CMH_BF16, M, d, st, md))) return rc;
+      if ((rc = launch_gemm(dt, t.h, w.in_proj_w, w.in_proj_b, nullptr, t.qkv, M, 3 * d, d, EPI_BIAS | obf, st, md, mh))) return rc;
+      if ((rc = launch_attention_varlen(t.qkv, t.h, dt, B, T, d, causal, kpm, seq_off, st))) return rc;
+    }
     if ((rc = launch_gather_rows2(t.x, xp, static_cast<int>(d * xe), t.h, hp, static_cast<int>(d * e), t.rows, B, st))) return rc;
     if ((rc = launch_gemm(dt, hp, w.out_proj_w, w.out_proj_b, xp, xp, B, d, d, rx, st))) return rc;
     if ((rc = launch_layernorm_x(xp, t.xh, nullptr, w.ln2_w, w.ln2_b, hp, dt == CMH_BF16, B, d, st))) return rc;
@@ -181,6 +186,79 @@ static int run_block_pooled(const cmh_block_weights& w, int dtb, const TowerBufs
   }
   *x_pooled = xp;
   return CMH_OK;
+}
+
+// ---- both towers in lock-step (round 4: grouped launches) ---------------------------------------------------------------------------
+// The image and the text tower are 12 blocks of the same four GEMMs (model/base/model.py:167-207, built twice by CLIP.__init__:
+// :254-306); run one after the other - or on two streams - every GEMM is a launch of its own whose fixed third (first stage landing
+// on 256 CUs at once, last tile's epilogue and store drain) the short-K text launches cannot amortise, and whose last round leaves
+// CUs idle.  Here layer i of BOTH towers is one grouped launch of the wide kernel (gemm_wide.hip, GRP): ~50 GEMM launches per encoded
+// batch instead of ~100, text tiles filling the image launches' last round.  Every output element sees the arithmetic of the
+// single-tower path: the features are bit-identical (tests/test_gpu_grouped.py).
+struct TowerRun {
+  TowerBufs t;
+  int dtb = 0, d = 0, B = 0, T = 0, M = 0, causal = 0;   // M: rows (an upper bound when md is set)
+  const int32_t* seq_off = nullptr;                      // packed text: per-caption row offsets
+  const int32_t* md = nullptr;                           // packed text: the row count on the device
+  int mh = -1;                                           // ... and its likely value (tile heights only)
+};
+
+static GemmProblem problem_of(const TowerRun& r, const void* A, const void* W, const float* bias, const void* residual, void* out, int N,
+                              int K, const float* colscale = nullptr, float alpha = 1.f, float oscale = 1.f) {
+  return GemmProblem{A, W, bias, static_cast<const float*>(residual), out, r.M, N, K, r.md, r.mh, colscale, alpha, oscale};
+}
+
+// the full-size part of a block for both towers: ln_1, QKV, attention (then, unless `upto_attention`, out_proj, ln_2, c_fc, c_proj)
+static int run_block_pair(const cmh_block_weights& wa, const cmh_block_weights& wb, const TowerRun& a, const TowerRun& b, hipStream_t st,
+                          bool upto_attention) {
+  const int dtb = a.dtb;
+  int rc;
+  if (dtb == CMH_FP8) {
+    for (const auto* pr : {&a, &b}) {
+      const cmh_block_weights& w = pr == &a ? wa : wb;
+      const float* s = w.act_scale;
+      CMH_CHECK_ARG(pr->t.xh, "fp8 mode runs on the fp16 residual stream (width %% 256 == 0, no taps)");
+      CMH_CHECK_ARG(w.in_proj_cs && w.out_proj_cs && w.fc_cs && w.proj_cs, "fp8 mode: weight scales missing");
+      CMH_CHECK_ARG(s[0] > 0.f && s[1] > 0.f && s[2] > 0.f && s[3] > 0.f, "fp8 mode: activation scales missing (run the calibration pass)");
+    }
+    const float *sa = wa.act_scale, *sb = wb.act_scale;
+    const int rx = EPI_BIAS | EPI_RESIDUAL | EPI_RES_F16 | EPI_OUT_F16;
+    if ((rc = launch_layernorm_q(a.t.x, wa.ln1_w, wa.ln1_b, a.t.h, 1.0f / sa[0], a.M, a.d, st, a.md))) return rc;
+    if ((rc = launch_layernorm_q(b.t.x, wb.ln1_w, wb.ln1_b, b.t.h, 1.0f / sb[0], b.M, b.d, st, b.md))) return rc;
+    if ((rc = launch_gemm_grouped(CMH_FP8, problem_of(a, a.t.h, wa.in_proj_w, wa.in_proj_b, nullptr, a.t.qkv, 3 * a.d, a.d, wa.in_proj_cs, sa[0]),
+                                  problem_of(b, b.t.h, wb.in_proj_w, wb.in_proj_b, nullptr, b.t.qkv, 3 * b.d, b.d, wb.in_proj_cs, sb[0]),
+                                  EPI_BIAS | EPI_OUT_BF16, st))) return rc;
+    if ((rc = launch_attention_varlen(a.t.qkv, a.t.h, CMH_BF16, a.B, a.T, a.d, a.causal, nullptr, a.seq_off, st, 1.0f / sa[1]))) return rc;
+    if ((rc = launch_attention_varlen(b.t.qkv, b.t.h, CMH_BF16, b.B, b.T, b.d, b.causal, nullptr, b.seq_off, st, 1.0f / sb[1]))) return rc;
+    if (upto_attention) return CMH_OK;
+    if ((rc = launch_gemm_grouped(CMH_FP8, problem_of(a, a.t.h, wa.out_proj_w, wa.out_proj_b, a.t.x, a.t.x, a.d, a.d, wa.out_proj_cs, sa[1]),
+                                  problem_of(b, b.t.h, wb.out_proj_w, wb.out_proj_b, b.t.x, b.t.x, b.d, b.d, wb.out_proj_cs, sb[1]), rx, st))) return rc;
+    if ((rc = launch_layernorm_q(a.t.x, wa.ln2_w, wa.ln2_b, a.t.h, 1.0f / sa[2], a.M, a.d, st, a.md))) return rc;
+    if ((rc = launch_layernorm_q(b.t.x, wb.ln2_w, wb.ln2_b, b.t.h, 1.0f / sb[2], b.M, b.d, st, b.md))) return rc;
+    if ((rc = launch_gemm_grouped(CMH_FP8, problem_of(a, a.t.h, wa.fc_w, wa.fc_b, nullptr, a.t.mlp, 4 * a.d, a.d, wa.fc_cs, sa[2], 1.0f / sa[3]),
+                                  problem_of(b, b.t.h, wb.fc_w, wb.fc_b, nullptr, b.t.mlp, 4 * b.d, b.d, wb.fc_cs, sb[2], 1.0f / sb[3]),
+                                  EPI_BIAS | EPI_QUICKGELU | EPI_OUT_FP8, st))) return rc;
+    return launch_gemm_grouped(CMH_FP8, problem_of(a, a.t.mlp, wa.proj_w, wa.proj_b, a.t.x, a.t.x, a.d, 4 * a.d, wa.proj_cs, sa[3]),
+                               problem_of(b, b.t.mlp, wb.proj_w, wb.proj_b, b.t.x, b.t.x, b.d, 4 * b.d, wb.proj_cs, sb[3]), rx, st);
+  }
+  const int dt = dtb;
+  const int obf = dt == CMH_BF16 ? EPI_OUT_BF16 : 0;
+  const int rx = EPI_BIAS | EPI_RESIDUAL | (a.t.xh ? EPI_RES_F16 | EPI_OUT_F16 : 0);
+  if ((rc = launch_layernorm_x(a.t.x, a.t.xh, nullptr, wa.ln1_w, wa.ln1_b, a.t.h, dt == CMH_BF16, a.M, a.d, st, a.md))) return rc;
+  if ((rc = launch_layernorm_x(b.t.x, b.t.xh, nullptr, wb.ln1_w, wb.ln1_b, b.t.h, dt == CMH_BF16, b.M, b.d, st, b.md))) return rc;
+  if ((rc = launch_gemm_grouped(dt, problem_of(a, a.t.h, wa.in_proj_w, wa.in_proj_b, nullptr, a.t.qkv, 3 * a.d, a.d),
+                                problem_of(b, b.t.h, wb.in_proj_w, wb.in_proj_b, nullptr, b.t.qkv, 3 * b.d, b.d), EPI_BIAS | obf, st))) return rc;
+  if ((rc = launch_attention_varlen(a.t.qkv, a.t.h, dt, a.B, a.T, a.d, a.causal, nullptr, a.seq_off, st))) return rc;
+  if ((rc = launch_attention_varlen(b.t.qkv, b.t.h, dt, b.B, b.T, b.d, b.causal, nullptr, b.seq_off, st))) return rc;
+  if (upto_attention) return CMH_OK;
+  if ((rc = launch_gemm_grouped(dt, problem_of(a, a.t.h, wa.out_proj_w, wa.out_proj_b, a.t.x, a.t.x, a.d, a.d),
+                                problem_of(b, b.t.h, wb.out_proj_w, wb.out_proj_b, b.t.x, b.t.x, b.d, b.d), rx, st))) return rc;
+  if ((rc = launch_layernorm_x(a.t.x, a.t.xh, nullptr, wa.ln2_w, wa.ln2_b, a.t.h, dt == CMH_BF16, a.M, a.d, st, a.md))) return rc;
+  if ((rc = launch_layernorm_x(b.t.x, b.t.xh, nullptr, wb.ln2_w, wb.ln2_b, b.t.h, dt == CMH_BF16, b.M, b.d, st, b.md))) return rc;
+  if ((rc = launch_gemm_grouped(dt, problem_of(a, a.t.h, wa.fc_w, wa.fc_b, nullptr, a.t.mlp, 4 * a.d, a.d),
+                                problem_of(b, b.t.h, wb.fc_w, wb.fc_b, nullptr, b.t.mlp, 4 * b.d, b.d), EPI_BIAS | EPI_QUICKGELU | obf, st))) return rc;
+  return launch_gemm_grouped(dt, problem_of(a, a.t.mlp, wa.proj_w, wa.proj_b, a.t.x, a.t.x, a.d, 4 * a.d),
+                             problem_of(b, b.t.mlp, wb.proj_w, wb.proj_b, b.t.x, b.t.x, b.d, 4 * b.d), rx, st);
 }
 
 // The packed row count of the LAST finished call for a (batch, seq_len), as a hint for the next call's tile heights: every call
@@ -250,9 +328,10 @@ extern "C" size_t cmh_vit_workspace_bytes(const cmh_vit_weights* w, int32_t batc
   return carve(nullptr, B * T, B, d, e, B * g2 * d * 4, B * g2 * pk * e).total;
 }
 
-static int vit_encode_impl(const cmh_vit_weights* w, const float* image, int32_t batch, float* feat, float* tokens_out,
-                           void* workspace, size_t workspace_bytes, const cmh_taps* taps, void* stream, float* amax = nullptr) {
-  CMH_CHECK_ARG(w && image && (feat || tokens_out) && workspace, "vit_encode: null pointer");
+// validation + everything before the first block: conv1 as a patch-matrix GEMM, [class ; patches] + positional, ln_pre
+static int vit_begin(const cmh_vit_weights* w, const float* image, int32_t batch, bool want_out, void* workspace, size_t workspace_bytes,
+                     const cmh_taps* taps, hipStream_t st, float* amax, TowerRun& r) {
+  CMH_CHECK_ARG(w && image && want_out && workspace, "vit_encode: null pointer");
   CMH_CHECK_ARG(batch > 0, "vit_encode: batch %d", batch);
   int rc = check_tower(w->gemm_dtype, w->width, w->layers, w->embed_dim, w->blocks);
   if (rc) return rc;
@@ -268,10 +347,10 @@ static int vit_encode_impl(const cmh_vit_weights* w, const float* image, int32_t
   const size_t need = cmh_vit_workspace_bytes(w, batch);
   if (workspace_bytes < need) return fail(CMH_ERR_WORKSPACE, "vit_encode: workspace %zu < %zu bytes", workspace_bytes, need);
   CMH_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "vit_encode: workspace must be 256-byte aligned");
-  hipStream_t st = as_stream(stream);
-  TowerBufs t = carve(workspace, static_cast<size_t>(M), B, d, e, static_cast<size_t>(B) * g2 * d * 4,
-                      static_cast<size_t>(B) * g2 * pk * e);
+  TowerBufs& t = r.t;
+  t = carve(workspace, static_cast<size_t>(M), B, d, e, static_cast<size_t>(B) * g2 * d * 4, static_cast<size_t>(B) * g2 * pk * e);
   t.xh = resid_f16(dtb, d, taps);
+  r.dtb = dtb; r.d = d; r.B = B; r.T = T; r.M = M; r.causal = 0;
   void* patches = t.mlp;
   float* patch_out = static_cast<float*>(t.qkv);
 
@@ -281,18 +360,14 @@ static int vit_encode_impl(const cmh_vit_weights* w, const float* image, int32_t
   // [class ; patches] + positional, ln_pre  (:237-239)
   if ((rc = launch_vit_assemble_lnpre(patch_out, w->class_embedding, w->positional_embedding, w->ln_pre_w,
                                       w->ln_pre_b, t.x, t.xh, B, g2, d, st))) return rc;
-  if ((rc = tap(taps, 0, t.x, static_cast<size_t>(M) * d * 4, st))) return rc;
-  const bool tail = feat && !tokens_out && !taps && !amax && w->layers > 0 && pooled_tail_enabled();
-  void* x_pooled = nullptr;
-  if (tail && (rc = launch_iota_rows(t.rows, B, T, st))) return rc;
-  for (int i = 0; i < w->layers; ++i) {
-    if (tail && i == w->layers - 1) {
-      if ((rc = run_block_pooled(w->blocks[i], dtb, t, B, T, d, /*causal=*/0, nullptr, st, M, nullptr, &x_pooled))) return rc;
-      break;
-    }
-    if ((rc = run_block(w->blocks[i], dtb, t, B, T, d, /*causal=*/0, nullptr, st, -1, nullptr, amax ? amax + 4 * i : nullptr))) return rc;
-    if ((rc = tap(taps, 1 + i, t.x, static_cast<size_t>(M) * d * 4, st))) return rc;
-  }
+  return tap(taps, 0, t.x, static_cast<size_t>(M) * d * 4, st);
+}
+
+// ln_post (+ proj) after the last block: on every token (MITH trunk) and / or on the class token
+static int vit_finish(const cmh_vit_weights* w, const TowerRun& r, void* x_pooled, float* feat, float* tokens_out, hipStream_t st) {
+  const TowerBufs& t = r.t;
+  const int dt = r.dtb == CMH_FP8 ? CMH_BF16 : r.dtb, d = r.d, B = r.B, T = r.T, M = r.M;
+  int rc;
   if (tokens_out) {
     // MITH trunk (model/MITH.py:70-80): ln_post and proj on EVERY token
     if ((rc = launch_layernorm_x(t.x, t.xh, nullptr, w->ln_post_w, w->ln_post_b, t.h, dt == CMH_BF16, M, d, st))) return rc;
@@ -309,6 +384,28 @@ static int vit_encode_impl(const cmh_vit_weights* w, const float* image, int32_t
     if ((rc = final_projection(dt, t.pool, w->proj_t, feat, B, w->embed_dim, d, st))) return rc;
   }
   return CMH_OK;
+}
+
+static int vit_encode_impl(const cmh_vit_weights* w, const float* image, int32_t batch, float* feat, float* tokens_out,
+                           void* workspace, size_t workspace_bytes, const cmh_taps* taps, void* stream, float* amax = nullptr) {
+  hipStream_t st = as_stream(stream);
+  TowerRun r;
+  int rc = vit_begin(w, image, batch, feat || tokens_out, workspace, workspace_bytes, taps, st, amax, r);
+  if (rc) return rc;
+  const TowerBufs& t = r.t;
+  const int dtb = r.dtb, d = r.d, B = r.B, T = r.T, M = r.M;
+  const bool tail = feat && !tokens_out && !taps && !amax && w->layers > 0 && pooled_tail_enabled();
+  void* x_pooled = nullptr;
+  if (tail && (rc = launch_iota_rows(t.rows, B, T, st))) return rc;
+  for (int i = 0; i < w->layers; ++i) {
+    if (tail && i == w->layers - 1) {
+      if ((rc = run_block_pooled(w->blocks[i], dtb, t, B, T, d, /*causal=*/0, nullptr, st, M, nullptr, &x_pooled))) return rc;
+      break;
+    }
+    if ((rc = run_block(w->blocks[i], dtb, t, B, T, d, /*causal=*/0, nullptr, st, -1, nullptr, amax ? amax + 4 * i : nullptr))) return rc;
+    if ((rc = tap(taps, 1 + i, t.x, static_cast<size_t>(M) * d * 4, st))) return rc;
+  }
+  return vit_finish(w, r, x_pooled, feat, tokens_out, st);
 }
 
 extern "C" int cmh_vit_encode(const cmh_vit_weights* w, const float* image, int32_t batch, float* feat,
@@ -329,11 +426,11 @@ extern "C" size_t cmh_text_workspace_bytes(const cmh_text_weights* w, int32_t ba
   return carve(nullptr, static_cast<size_t>(batch) * seq_len, batch, w->width, e, 0, 0).total;
 }
 
-static int text_encode_impl(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
-                            const uint8_t* key_padding_mask, float* feat, float* tokens_out, int32_t* eot_rows_out,
-                            void* workspace, size_t workspace_bytes, const cmh_taps* taps, void* stream,
-                            int32_t* packed_rows_out = nullptr, float* amax = nullptr) {
-  CMH_CHECK_ARG(w && tokens && (feat || tokens_out) && workspace, "text_encode: null pointer");
+// validation + everything before the first block: the pack plan (packed mode), token + positional embedding, the EOT rows
+static int text_begin(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len, const uint8_t* key_padding_mask,
+                      bool want_out, bool tokens_wanted, void* workspace, size_t workspace_bytes, const cmh_taps* taps, hipStream_t st,
+                      int32_t* packed_rows_out, float* amax, TowerRun& r) {
+  CMH_CHECK_ARG(w && tokens && want_out && workspace, "text_encode: null pointer");
   CMH_CHECK_ARG(batch > 0 && seq_len > 0, "text_encode: batch %d seq_len %d", batch, seq_len);
   int rc = check_tower(w->gemm_dtype, w->width, w->layers, w->embed_dim, w->blocks);
   if (rc) return rc;
@@ -345,8 +442,8 @@ static int text_encode_impl(const cmh_text_weights* w, const int64_t* tokens, in
   const size_t need = cmh_text_workspace_bytes(w, batch, seq_len);
   if (workspace_bytes < need) return fail(CMH_ERR_WORKSPACE, "text_encode: workspace %zu < %zu bytes", workspace_bytes, need);
   CMH_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "text_encode: workspace must be 256-byte aligned");
-  hipStream_t st = as_stream(stream);
-  TowerBufs t = carve(workspace, static_cast<size_t>(M), B, d, e, 0, 0);
+  TowerBufs& t = r.t;
+  t = carve(workspace, static_cast<size_t>(M), B, d, e, 0, 0);
   t.xh = resid_f16(dtb, d, taps);
 
   // Packed mode (pooled output only): under the causal mask nothing after a caption's EOT can reach the EOT row that
@@ -358,7 +455,7 @@ static int text_encode_impl(const cmh_text_weights* w, const int64_t* tokens, in
   const int32_t* md = nullptr;      // device-side row count of the packed matrix (the kernels read it themselves)
   int rows = M, mh = -1;
   if (packed_rows_out) {
-    CMH_CHECK_ARG(!key_padding_mask && !tokens_out && !taps, "text_encode_packed: pooled features only, no mask / taps");
+    CMH_CHECK_ARG(!key_padding_mask && !tokens_wanted && !taps, "text_encode_packed: pooled features only, no mask / taps");
     if ((rc = launch_text_pack_plan(tokens, B, L, t.seq, st))) return rc;
     seq_off = t.seq;
     if (amax || d % 256 != 0 || !gemm_wide_enabled()) {
@@ -382,18 +479,16 @@ static int text_encode_impl(const cmh_text_weights* w, const int64_t* tokens, in
   }
 
   // token_embedding gather + positional_embedding[:L]; EOT row = argmax(tokens)  (model.py:360-362,370)
-  if ((rc = launch_text_embed_packed(tokens, w->token_embedding, w->positional_embedding, t.x, t.xh, t.rows, B, L, d,
-                                     w->vocab_size, seq_off, st))) return rc;
-  const bool tail = feat && !tokens_out && !taps && !amax && !eot_rows_out && w->layers > 0 && pooled_tail_enabled();
-  void* x_pooled = nullptr;
-  for (int i = 0; i < w->layers; ++i) {
-    if (tail && i == w->layers - 1) {
-      if ((rc = run_block_pooled(w->blocks[i], dtb, t, B, L, d, /*causal=*/1, key_padding_mask, st, rows, seq_off, &x_pooled, md, mh))) return rc;
-      break;
-    }
-    if ((rc = run_block(w->blocks[i], dtb, t, B, L, d, /*causal=*/1, key_padding_mask, st, rows, seq_off, amax ? amax + 4 * i : nullptr, md, mh))) return rc;
-    if ((rc = tap(taps, 1 + i, t.x, static_cast<size_t>(M) * d * 4, st))) return rc;
-  }
+  r.dtb = dtb; r.d = d; r.B = B; r.T = L; r.M = rows; r.causal = 1; r.seq_off = seq_off; r.md = md; r.mh = mh;
+  return launch_text_embed_packed(tokens, w->token_embedding, w->positional_embedding, t.x, t.xh, t.rows, B, L, d, w->vocab_size, seq_off, st);
+}
+
+// ln_final (+ text_projection) after the last block: on every token (MITH trunk) and / or on the EOT rows
+static int text_finish(const cmh_text_weights* w, const TowerRun& r, void* x_pooled, float* feat, float* tokens_out, int32_t* eot_rows_out,
+                       hipStream_t st) {
+  const TowerBufs& t = r.t;
+  const int dt = r.dtb == CMH_FP8 ? CMH_BF16 : r.dtb, d = r.d, B = r.B, M = r.B * r.T;
+  int rc;
   if (tokens_out) {
     // MITH trunk (model/MITH.py:136-139): ln_final and text_projection on EVERY token
     if ((rc = launch_layernorm_x(t.x, t.xh, nullptr, w->ln_final_w, w->ln_final_b, t.h, dt == CMH_BF16, M, d, st))) return rc;
@@ -411,6 +506,32 @@ static int text_encode_impl(const cmh_text_weights* w, const int64_t* tokens, in
   return CMH_OK;
 }
 
+static int text_encode_impl(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
+                            const uint8_t* key_padding_mask, float* feat, float* tokens_out, int32_t* eot_rows_out,
+                            void* workspace, size_t workspace_bytes, const cmh_taps* taps, void* stream,
+                            int32_t* packed_rows_out = nullptr, float* amax = nullptr) {
+  hipStream_t st = as_stream(stream);
+  TowerRun r;
+  int rc = text_begin(w, tokens, batch, seq_len, key_padding_mask, feat || tokens_out, tokens_out != nullptr, workspace, workspace_bytes,
+                      taps, st, packed_rows_out, amax, r);
+  if (rc) return rc;
+  const TowerBufs& t = r.t;
+  const int dtb = r.dtb, d = r.d, B = r.B, L = r.T, M = B * L, rows = r.M, mh = r.mh;
+  const int32_t* seq_off = r.seq_off;
+  const int32_t* md = r.md;
+  const bool tail = feat && !tokens_out && !taps && !amax && !eot_rows_out && w->layers > 0 && pooled_tail_enabled();
+  void* x_pooled = nullptr;
+  for (int i = 0; i < w->layers; ++i) {
+    if (tail && i == w->layers - 1) {
+      if ((rc = run_block_pooled(w->blocks[i], dtb, t, B, L, d, /*causal=*/1, key_padding_mask, st, rows, seq_off, &x_pooled, md, mh))) return rc;
+      break;
+    }
+    if ((rc = run_block(w->blocks[i], dtb, t, B, L, d, /*causal=*/1, key_padding_mask, st, rows, seq_off, amax ? amax + 4 * i : nullptr, md, mh))) return rc;
+    if ((rc = tap(taps, 1 + i, t.x, static_cast<size_t>(M) * d * 4, st))) return rc;
+  }
+  return text_finish(w, r, x_pooled, feat, tokens_out, eot_rows_out, st);
+}
+
 extern "C" int cmh_text_encode(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
                                const uint8_t* key_padding_mask, float* feat, void* workspace,
                                size_t workspace_bytes, const cmh_taps* taps, void* stream) {
@@ -424,6 +545,62 @@ extern "C" int cmh_text_encode_packed(const cmh_text_weights* w, const int64_t* 
   CMH_CHECK_ARG(feat, "text_encode_packed: null pointer");
   return text_encode_impl(w, tokens, batch, seq_len, nullptr, feat, nullptr, nullptr, workspace, workspace_bytes, nullptr, stream,
                           rows_computed_dev ? rows_computed_dev : reinterpret_cast<int32_t*>(1));   // 1: packed, count not wanted
+}
+
+// encode_image + encode_text of one batch with the two towers in lock-step (reference model/modelbase.py:105-108 runs them back to
+// back; model/base/model.py:340-372): layer i of both towers shares its launches (run_block_pair).  Same features, bit for bit, as
+// cmh_vit_encode + cmh_text_encode[_packed].
+extern "C" int cmh_clip_encode_pair(const cmh_vit_weights* vw, const float* image, const cmh_text_weights* tw, const int64_t* tokens,
+                                    int32_t batch, int32_t seq_len, int32_t packed, float* feat_image, float* feat_text,
+                                    int32_t* rows_computed_dev, void* ws_image, size_t ws_image_bytes, void* ws_text,
+                                    size_t ws_text_bytes, void* stream) {
+  CMH_CHECK_ARG(vw && tw && feat_image && feat_text, "clip_encode_pair: null pointer");
+  CMH_CHECK_ARG(vw->gemm_dtype == tw->gemm_dtype, "clip_encode_pair: both towers must run in one arithmetic mode (%d / %d)", vw->gemm_dtype,
+                tw->gemm_dtype);
+  hipStream_t st = as_stream(stream);
+  TowerRun a, b;
+  int rc;
+  if ((rc = vit_begin(vw, image, batch, true, ws_image, ws_image_bytes, nullptr, st, nullptr, a))) return rc;
+  if ((rc = text_begin(tw, tokens, batch, seq_len, nullptr, true, false, ws_text, ws_text_bytes, nullptr, st,
+                       packed ? (rows_computed_dev ? rows_computed_dev : reinterpret_cast<int32_t*>(1)) : nullptr, nullptr, b))) return rc;
+  const bool tail = pooled_tail_enabled();
+  void *xa = nullptr, *xb = nullptr;
+  if (tail && vw->layers > 0 && (rc = launch_iota_rows(a.t.rows, a.B, a.T, st))) return rc;
+  const int deepest = vw->layers > tw->layers ? vw->layers : tw->layers;
+  for (int i = 0; i < deepest; ++i) {
+    const bool has_a = i < vw->layers, has_b = i < tw->layers;
+    const bool last_a = tail && i == vw->layers - 1, last_b = tail && i == tw->layers - 1;
+    if (has_a && has_b && last_a == last_b) {
+      if ((rc = run_block_pair(vw->blocks[i], tw->blocks[i], a, b, st, last_a))) return rc;
+      if (last_a) {       // the rest of the last block on the pooled rows of each tower (few-row kernels)
+        if ((rc = run_block_pooled(vw->blocks[i], a.dtb, a.t, a.B, a.T, a.d, 0, nullptr, st, a.M, nullptr, &xa, nullptr, -1, true))) return rc;
+        if ((rc = run_block_pooled(tw->blocks[i], b.dtb, b.t, b.B, b.T, b.d, 1, nullptr, st, b.M, b.seq_off, &xb, b.md, b.mh, true))) return rc;
+      }
+      continue;
+    }
+    if (has_a) {
+      if (last_a) { if ((rc = run_block_pooled(vw->blocks[i], a.dtb, a.t, a.B, a.T, a.d, 0, nullptr, st, a.M, nullptr, &xa))) return rc; }
+      else if ((rc = run_block(vw->blocks[i], a.dtb, a.t, a.B, a.T, a.d, 0, nullptr, st))) return rc;
+    }
+    if (has_b) {
+      if (last_b) { if ((rc = run_block_pooled(tw->blocks[i], b.dtb, b.t, b.B, b.T, b.d, 1, nullptr, st, b.M, b.seq_off, &xb, b.md, b.mh))) return rc; }
+      else if ((rc = run_block(tw->blocks[i], b.dtb, b.t, b.B, b.T, b.d, 1, nullptr, st, b.M, b.seq_off, nullptr, b.md, b.mh))) return rc;
+    }
+  }
+  if ((rc = vit_finish(vw, a, xa, feat_image, nullptr, st))) return rc;
+  return text_finish(tw, b, xb, feat_text, nullptr, nullptr, st);
+}
+
+extern "C" int cmh_linear_gemm_grouped(int32_t dtype, const cmh_gemm_problem* pa, const cmh_gemm_problem* pb, int32_t epilogue, void* stream) {
+  CMH_CHECK_ARG(pa && pb, "linear_gemm_grouped: null pointer");
+  CMH_CHECK_ARG(dtype == CMH_F32 || dtype == CMH_BF16 || dtype == CMH_FP8, "linear_gemm_grouped: bad dtype %d", dtype);
+  auto conv = [](const cmh_gemm_problem* g) {
+    return GemmProblem{g->x, g->w, g->bias, static_cast<const float*>(g->residual), g->out, g->M, g->N, g->K, g->m_dev, -1, g->colscale,
+                       g->alpha, g->out_scale > 0.f ? 1.0f / g->out_scale : 1.0f};      // (out = e4m3(v / out_scale), as cmh_linear_gemm_fp8)
+  };
+  for (const cmh_gemm_problem* g : {pa, pb})
+    CMH_CHECK_ARG(g->x && g->w && g->out && g->M > 0 && g->N > 0 && g->K > 0, "linear_gemm_grouped: null pointer / empty problem");
+  return launch_gemm_grouped(dtype, conv(pa), conv(pb), epilogue, as_stream(stream));
 }
 
 extern "C" int cmh_vit_calibrate_fp8(const cmh_vit_weights* w, const float* image, int32_t batch, float* feat, float* amax,

@@ -30,6 +30,12 @@ struct GemmProf {
   std::vector<double> flops;
   std::vector<std::array<int, 4>> dims;   // M, N, K, epi of each timed launch (CMH_GEMM_PROF_DUMP breakdown)
   std::vector<int> kind;                  // kernel of each timed launch: 0 gemm_wide_kernel, 1 gemm_rows_kernel, 2 the 128 x 128 fallbacks
+  // device-side row counts (packed text): copied, asynchronously, into a pinned slot at launch time and turned into FLOPs by _end()
+  // - the hook itself never waits for the stream, so a profiled region keeps the launch queue of an unprofiled one
+  struct Pending { size_t launch; int slot; int Mub; double flops_per_row; };
+  std::vector<Pending> pending;
+  int32_t* rows_pinned = nullptr;
+  size_t rows_cap = 0, rows_used = 0;
   size_t used = 0;
 };
 static GemmProf g_prof;
@@ -46,13 +52,15 @@ int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, co
                      int M, int N, int K, int epi, hipStream_t st, const float* colscale = nullptr, float alpha = 1.f,
                      float oscale = 1.f, const int32_t* m_dev = nullptr, int m_hint = -1);
 
-// the measurement hook counts algorithmic FLOPs on REAL rows: with a device-side row count it reads that count back (a stream
-// synchronisation, inside a profiled run only)
-static int prof_real_rows(int M, const int32_t* m_dev, hipStream_t st) {
-  if (!m_dev) return M;
-  int32_t v = M;
-  if (hipMemcpyAsync(&v, m_dev, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return M;
-  return v > 0 && v < M ? v : M;
+// the measurement hook counts algorithmic FLOPs on REAL rows: FLOPs of `flops_per_row` x the rows of launch `launch` (the entry
+// g_prof.flops[launch] is created by the caller with the upper bound's FLOPs and corrected by _end() once the count has arrived)
+static void prof_rows_later(size_t launch, int Mub, const int32_t* m_dev, double flops_per_row, hipStream_t st) {
+  if (!m_dev || !g_prof.rows_pinned || g_prof.rows_used >= g_prof.rows_cap) return;
+  const int slot = static_cast<int>(g_prof.rows_used);
+  g_prof.rows_pinned[slot] = -1;
+  if (hipMemcpyAsync(g_prof.rows_pinned + slot, m_dev, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return;
+  ++g_prof.rows_used;
+  g_prof.pending.push_back({launch, slot, Mub, flops_per_row});
 }
 
 // CMH_GEMM_WIDE=0 (A/B against round 1's 128 x 128 kernels): launches that do not need the wide kernel's epilogues avoid it
@@ -102,9 +110,9 @@ int launch_gemm(int dt, const void* A, const void* W, const float* bias, const f
   }
   if (timed) {
     if (!self_timed) (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
-    const int Mr = prof_real_rows(M, m_dev, st);
-    g_prof.flops.push_back(2.0 * Mr * static_cast<double>(N) * K);   // algorithmic FLOPs: real rows only
-    g_prof.dims.push_back({Mr, N, K, epi});
+    g_prof.flops.push_back(2.0 * M * static_cast<double>(N) * K);   // algorithmic FLOPs (real rows only: corrected by _end)
+    prof_rows_later(g_prof.flops.size() - 1, M, m_dev, 2.0 * static_cast<double>(N) * K, st);
+    g_prof.dims.push_back({M, N, K, epi});
     g_prof.kind.push_back(takes_rows ? 1 : (takes_wide ? 0 : 2));
     g_prof.used += 2;
   }
@@ -135,9 +143,9 @@ int launch_gemm_fp8(const void* A8, const void* W8, const float* colscale, float
     if (rc) return rc;
   }
   if (timed) {
-    const int Mr = prof_real_rows(M, m_dev, st);
-    g_prof.flops.push_back(2.0 * Mr * static_cast<double>(N) * K);
-    g_prof.dims.push_back({Mr, N, K, epi | EPI_SCALE});
+    g_prof.flops.push_back(2.0 * M * static_cast<double>(N) * K);
+    prof_rows_later(g_prof.flops.size() - 1, M, m_dev, 2.0 * static_cast<double>(N) * K, st);
+    g_prof.dims.push_back({M, N, K, epi | EPI_SCALE});
     g_prof.kind.push_back(takes_rows ? 1 : 0);
     g_prof.used += 2;
   }
@@ -146,6 +154,7 @@ int launch_gemm_fp8(const void* A8, const void* W8, const float* colscale, float
 }
 
 int launch_gemm_wide_grouped(int dt, const GemmProblem& a, const GemmProblem& b, int epi, hipStream_t st);   // gemm_wide.hip
+bool gemm_wide_grouping_pays(int dt, const GemmProblem& a, const GemmProblem& b, int epi);                   // gemm_wide.hip: cost model
 
 static int g_grouped = -1;   // cmh_set_gemm_grouped: -1 = environment (CMH_GEMM_GROUPED=0 switches grouping off)
 bool gemm_grouping_enabled() {
@@ -165,7 +174,7 @@ int launch_gemm_grouped(int dt, const GemmProblem& a, const GemmProblem& b, int 
                          !(epi & (EPI_MUL_DQGELU | EPI_SAVE_PRE)) &&
                          (fp8 ? (epi & (EPI_OUT_BF16 | EPI_OUT_F16 | EPI_OUT_FP8)) != 0
                               : (dt == CMH_BF16) == ((epi & (EPI_OUT_BF16 | EPI_OUT_F16)) != 0));
-  if (!groupable) {
+  if (!groupable || !gemm_wide_grouping_pays(dt, a.K >= b.K ? a : b, a.K >= b.K ? b : a, epi)) {
     for (const GemmProblem* g : {&a, &b}) {
       const int rc = fp8 ? launch_gemm_fp8(g->A, g->W, g->colscale, g->alpha, g->bias, g->residual, g->out, g->oscale, g->M, g->N, g->K,
                                            epi, st, g->m_dev, g->m_hint)
@@ -188,9 +197,10 @@ int launch_gemm_grouped(int dt, const GemmProblem& a, const GemmProblem& b, int 
   gemm_wide_time_next(nullptr, nullptr);
   if (rc) return rc;
   if (timed) {
-    const int Ma = prof_real_rows(a.M, a.m_dev, st), Mb = prof_real_rows(b.M, b.m_dev, st);
-    g_prof.flops.push_back(2.0 * Ma * static_cast<double>(a.N) * a.K + 2.0 * Mb * static_cast<double>(b.N) * b.K);
-    g_prof.dims.push_back({Ma + Mb, a.N + b.N, a.K, epi | (1 << 20)});   // (1 << 20: a grouped launch; rows / columns summed)
+    g_prof.flops.push_back(2.0 * a.M * static_cast<double>(a.N) * a.K + 2.0 * b.M * static_cast<double>(b.N) * b.K);
+    prof_rows_later(g_prof.flops.size() - 1, a.M, a.m_dev, 2.0 * static_cast<double>(a.N) * a.K, st);
+    prof_rows_later(g_prof.flops.size() - 1, b.M, b.m_dev, 2.0 * static_cast<double>(b.N) * b.K, st);
+    g_prof.dims.push_back({a.M + b.M, a.N + b.N, a.K, epi | (1 << 20)});   // (1 << 20: a grouped launch; rows / columns summed)
     g_prof.kind.push_back(0);
     g_prof.used += 2;
   }
@@ -200,6 +210,8 @@ int launch_gemm_grouped(int dt, const GemmProblem& a, const GemmProblem& b, int 
 
 }  // namespace cmh
 
+extern "C" int cmh_set_gemm_grouped(int32_t on) { cmh::g_grouped = on < 0 ? -1 : (on ? 1 : 0); return CMH_OK; }
+
 extern "C" int cmh_prof_gemm_begin(int32_t max_launches) {
   using namespace cmh;
   CMH_CHECK_ARG(max_launches > 0 && max_launches <= (1 << 20), "prof_gemm_begin: bad max_launches");
@@ -208,6 +220,17 @@ extern "C" int cmh_prof_gemm_begin(int32_t max_launches) {
     if (hipEventCreate(&e) != hipSuccess) return fail(CMH_ERR_LAUNCH, "prof_gemm_begin: hipEventCreate failed");
     g_prof.ev.push_back(e);
   }
+  if (g_prof.rows_cap < static_cast<size_t>(max_launches) * 2) {      // (profiling only: the product path never allocates here)
+    if (g_prof.rows_pinned) (void)hipHostFree(g_prof.rows_pinned);
+    g_prof.rows_pinned = nullptr;
+    g_prof.rows_cap = 0;
+    if (hipHostMalloc(reinterpret_cast<void**>(&g_prof.rows_pinned), static_cast<size_t>(max_launches) * 2 * 4, hipHostMallocDefault) == hipSuccess)
+      g_prof.rows_cap = static_cast<size_t>(max_launches) * 2;
+    else
+      g_prof.rows_pinned = nullptr;
+  }
+  g_prof.rows_used = 0;
+  g_prof.pending.clear();
   g_prof.used = 0;
   g_prof.flops.clear();
   g_prof.dims.clear();
@@ -235,6 +258,7 @@ extern "C" int cmh_prof_gemm_end(double* total_ms, double* total_flops, int64_t*
   using namespace cmh;
   CMH_CHECK_ARG(total_ms && total_flops && launches, "prof_gemm_end: null pointer");
   g_prof.on = false;
+  if (hipDeviceSynchronize() != hipSuccess) return fail(CMH_ERR_LAUNCH, "prof_gemm_end: device synchronisation failed");   // (the row-count copies too)
   double ms = 0.0, fl = 0.0;
   for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
     if (hipEventSynchronize(g_prof.ev[i + 1]) != hipSuccess) return fail(CMH_ERR_LAUNCH, "prof_gemm_end: event sync failed");
@@ -242,8 +266,17 @@ extern "C" int cmh_prof_gemm_end(double* total_ms, double* total_flops, int64_t*
     if (hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]) != hipSuccess)
       return fail(CMH_ERR_LAUNCH, "prof_gemm_end: hipEventElapsedTime failed");
     ms += t;
-    fl += g_prof.flops[i / 2];
   }
+  // every event has completed, so has every row-count copy queued before it: real rows instead of the upper bounds
+  for (const auto& p : g_prof.pending) {
+    const int got = g_prof.rows_pinned[p.slot];
+    if (got > 0 && got < p.Mub) {
+      g_prof.flops[p.launch] -= static_cast<double>(p.Mub - got) * p.flops_per_row;
+      g_prof.dims[p.launch][0] -= p.Mub - got;
+    }
+  }
+  g_prof.pending.clear();
+  for (size_t i = 0; i + 1 < g_prof.used; i += 2) fl += g_prof.flops[i / 2];
   if (getenv("CMH_GEMM_PROF_DUMP")) {   // per-shape breakdown of the timed launches, to stderr
     std::map<std::array<int, 4>, std::array<double, 3>> by;   // dims -> {ms, flops, launches}
     for (size_t i = 0; i + 1 < g_prof.used; i += 2) {

@@ -22,6 +22,7 @@
 // image with the XOR swizzle on the DMA source chunk and on the ds_read_b128, fused epilogue, XCD-aware tile order
 // (workgroups with equal blockIdx%8 share an XCD and take neighbouring tiles of one contiguous range, n fastest).
 #include <cstdlib>
+#include <cstring>
 
 #include "cmh_common.h"
 
@@ -481,7 +482,12 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
     sps = (NDEFER + nk - 1) / nk;
   };
   if constexpr (GRP) { if (n_first == 0) to_problem1(); }
-  const bool res_first = !FP8 && (epi & EPI_RESIDUAL) && !(epi & (EPI_QUICKGELU | EPI_GELU | EPI_RELU | EPI_SCALE)) && nk <= 16;
+  // Round 4: the rule holds for EVERY tile of such a GEMM, not only a workgroup's first one - (residual + sum) + bias and (sum + bias)
+  // + residual round differently, and which tiles come first in a workgroup depends on the tile height, the CU count and, in a grouped
+  // launch, on the other problem; results must depend on none of them.  A later tile's residual loads are issued at the top of the
+  // tile: younger than the stages in flight, they wait for those, which after an epilogue have long landed.
+  const bool res_cond = !FP8 && (epi & EPI_RESIDUAL) && !(epi & (EPI_QUICKGELU | EPI_GELU | EPI_RELU | EPI_SCALE));
+  auto res_first = [&]() { return res_cond && nk <= 16; };   // (nk: of the problem the compute side is in)
   auto mfma = [&](const w_u32x4_t& fw, const w_u32x4_t& fx, w_f32x4_t& c) {
     if constexpr (FP8) {
       (void)fw; (void)fx; (void)c;   // the fp8 K-step multiplies whole 128-k rows: mfma8 below
@@ -605,7 +611,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < MF; ++b) acc[a][b] = w_f32x4_t{0.f, 0.f, 0.f, 0.f};
-  if (res_first) {
+  if (res_first()) {
     int tm, tn;
     if constexpr (GRP) { int sp_; tile_coords(tile_logical(0, sp_), tm, tn); }
     else tile_coords(range_lo + slot, tm, tn);
@@ -697,6 +703,11 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
 #pragma unroll
         for (int b = 0; b < MF; ++b) acc[a][b] = w_f32x4_t{0.f, 0.f, 0.f, 0.f};
       if constexpr (GRP) { if (ti == n_first) to_problem1(); }
+      if (res_first()) {
+        int sp_, tm_r, tn_r;
+        tile_coords(tile_logical(ti, sp_), tm_r, tn_r);
+        add_residual(tm_r * BMt, tn_r * wBN);
+      }
     }
     if constexpr (TN) {
       if (sc.colsum) {
@@ -995,7 +1006,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
           for (int j = 0; j < 4; ++j)
             acc[a][b][j] = (epi & EPI_GELU) ? gelu_erf(acc[a][b][j]) : fmaxf(acc[a][b][j], 0.f);
     }
-    if ((epi & EPI_RESIDUAL) && !(res_first && ti == 0)) add_residual(m0, n0);
+    if ((epi & EPI_RESIDUAL) && !res_first()) add_residual(m0, n0);
     if constexpr (!FP8)
     if (epi & EPI_MUL_DQGELU) {
       // backward of c_fc's QuickGELU fused into the dgrad GEMM: acc *= d/dv [v sigmoid(1.702 v)] at the saved pre-activation
@@ -1346,24 +1357,43 @@ int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, co
 // Two problems in one persistent grid (template parameter GRP; see WideProblem).  `a` should be the problem with the longer K (its
 // tiles go first); both share dt, the output kind and the epilogue flags.  The tile height is the one whose WORST workgroup - the
 // kernel's own static assignment, replayed here - finishes first.
-int launch_gemm_wide_grouped(int dt, const GemmProblem& a, const GemmProblem& b, int epi, hipStream_t st) {
-  const size_t esz = dt == CMH_F32 ? 4 : (dt == CMH_FP8 ? 1 : 2);
-  for (const GemmProblem* g : {&a, &b})
-    if (static_cast<size_t>(g->M) * g->K * esz >= (1ull << 32) || static_cast<size_t>(wBN) * g->K * esz >= (1ull << 32))
-      return fail(CMH_ERR_INVALID, "gemm (grouped): operand of %zu bytes exceeds the 32-bit offset range of the wide kernel",
-                  static_cast<size_t>(g->M) * g->K * esz);
+// Does ONE grouped launch beat two plain ones?  The same cost units as the tile-height choice (K-steps + 4 per tile, x rows + 6),
+// the worst workgroup of the kernel's static assignment against the two plain launches' rounds, plus a fixed ~8 K-steps per LAUNCH
+// (first stage landing on every CU at once, last epilogue's store drain: profiles/r02_a_gemm_launch_timeline.txt).  Measured at batch
+// 256 (profiles/r04_b_grouped_per_shape.txt): QKV 74.5 -> 68.8 us, out_proj 41.8 -> 36.9, c_fc 104.8 -> 96.4 grouped - but c_proj 92.0
+// -> 98.3: one 48-K-step image tile per workgroup plus a 32-K-step text tile on every second one is a worse packing than two launches;
+// the model reproduces all four.
+static long long wide_plain_cost(int dt, const GemmProblem& g, int epi, int cus) {
+  const int nk = g.K / (dt == CMH_F32 ? 32 : (dt == CMH_FP8 ? 128 : 64));
+  const int M = g.m_dev && g.m_hint > 0 && g.m_hint <= g.M ? g.m_hint : g.M;
+  long long best = -1;
+  for (int mf = (dt == CMH_FP8 && !(epi & EPI_OUT_FP8)) ? 4 : 5; mf >= 3; --mf) {
+    const int tiles = (g.N / wBN) * ((M + 32 * mf - 1) / (32 * mf));
+    const long long c = static_cast<long long>((tiles + cus - 1) / cus) * (10 * mf + 6) * (nk + 4);
+    if (best < 0 || c < best) best = c;
+  }
+  return best;
+}
+static long long wide_grouped_cost(int dt, const GemmProblem& a, const GemmProblem& b, int epi, int cus, int* mf_out);
+
+bool gemm_wide_grouping_pays(int dt, const GemmProblem& a, const GemmProblem& b, int epi) {
+  static const bool always = []() { const char* e = getenv("CMH_GEMM_GROUPED"); return e && !strcmp(e, "always"); }();
+  if (always || g_force_rows > 0) return true;            // (a forced tile height: A/B runs and the tests that walk every variant)
   const int cus = wide_cus();
+  const long long fixed = 8 * 56;
+  return wide_grouped_cost(dt, a, b, epi, cus, nullptr) + fixed <= wide_plain_cost(dt, a, epi, cus) + wide_plain_cost(dt, b, epi, cus) + 2 * fixed;
+}
+
+static long long wide_grouped_cost(int dt, const GemmProblem& a, const GemmProblem& b, int epi, int cus, int* mf_out) {
   const int bk = dt == CMH_F32 ? 32 : (dt == CMH_FP8 ? 128 : 64);
   const int nk0 = a.K / bk, nk1 = b.K / bk;
   auto likely = [](const GemmProblem& g) { return g.m_dev && g.m_hint > 0 && g.m_hint <= g.M ? g.m_hint : g.M; };
   const int Ma = likely(a), Mb = likely(b);
   auto tiles_of = [](int M, int N, int mf) { return (N / wBN) * ((M + 32 * mf - 1) / (32 * mf)); };
-  auto grid_of = [&](int mf) {   // sized for the upper bounds: workgroups beyond the real tile count exit at once
-    const int total = tiles_of(a.M, a.N, mf) + tiles_of(b.M, b.N, mf);
-    return total < cus ? ((total + 7) & ~7) : cus;
-  };
   auto cost = [&](int mf) {
-    const int t0 = tiles_of(Ma, a.N, mf), t1 = tiles_of(Mb, b.N, mf), per = grid_of(mf) >> 3;
+    const int total = tiles_of(a.M, a.N, mf) + tiles_of(b.M, b.N, mf);
+    const int per = (total < cus ? ((total + 7) & ~7) : cus) >> 3;
+    const int t0 = tiles_of(Ma, a.N, mf), t1 = tiles_of(Mb, b.N, mf);
     long long worst = 0;
     for (int x = 0; x < 8; ++x) {
       const int len0 = (t0 >> 3) + (x < (t0 & 7)), len1 = (t1 >> 3) + (x < (t1 & 7));
@@ -1376,11 +1406,29 @@ int launch_gemm_wide_grouped(int dt, const GemmProblem& a, const GemmProblem& b,
     }
     return worst * (10 * mf + 6);
   };
-  const int forced = g_force_rows;
-  const bool fp8_160 = epi & EPI_OUT_FP8;       // (the 16-bit-output 160-row fp8 variant is an opt-in of the plain launches only)
-  int mf = dt == CMH_FP8 && !fp8_160 ? 4 : 5;
+  int mf = dt == CMH_FP8 && !(epi & EPI_OUT_FP8) ? 4 : 5;
   if (mf == 5 && cost(4) < cost(mf)) mf = 4;
   if (cost(3) < cost(mf)) mf = 3;
+  if (mf_out) *mf_out = mf;
+  return cost(mf);
+}
+
+int launch_gemm_wide_grouped(int dt, const GemmProblem& a, const GemmProblem& b, int epi, hipStream_t st) {
+  const size_t esz = dt == CMH_F32 ? 4 : (dt == CMH_FP8 ? 1 : 2);
+  for (const GemmProblem* g : {&a, &b})
+    if (static_cast<size_t>(g->M) * g->K * esz >= (1ull << 32) || static_cast<size_t>(wBN) * g->K * esz >= (1ull << 32))
+      return fail(CMH_ERR_INVALID, "gemm (grouped): operand of %zu bytes exceeds the 32-bit offset range of the wide kernel",
+                  static_cast<size_t>(g->M) * g->K * esz);
+  const int cus = wide_cus();
+  auto tiles_of = [](int M, int N, int mf) { return (N / wBN) * ((M + 32 * mf - 1) / (32 * mf)); };
+  auto grid_of = [&](int mf) {   // sized for the upper bounds: workgroups beyond the real tile count exit at once
+    const int total = tiles_of(a.M, a.N, mf) + tiles_of(b.M, b.N, mf);
+    return total < cus ? ((total + 7) & ~7) : cus;
+  };
+  const int forced = g_force_rows;
+  const bool fp8_160 = epi & EPI_OUT_FP8;       // (the 16-bit-output 160-row fp8 variant is an opt-in of the plain launches only)
+  int mf = 5;
+  (void)wide_grouped_cost(dt, a, b, epi, cus, &mf);
   if (forced == 96 || forced == 128 || (forced == 160 && (dt != CMH_FP8 || fp8_160))) mf = forced / 32;
   const int grid = grid_of(mf);
   const WideScales sc{a.colscale, a.alpha, a.oscale, 0, nullptr, a.m_dev};

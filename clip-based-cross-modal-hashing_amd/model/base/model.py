@@ -444,6 +444,36 @@ class CLIP(nn.Module):
                 "cmh_text_encode")
         return no_backward(feat, self.text_projection)
 
+    def encode_pair(self, image, text):
+        """(encode_image(image), encode_text(text)) with the two towers in lock-step: layer i of both shares its GEMM launches
+        (cmh_clip_encode_pair; reference model/modelbase.py:105-108 calls the two encoders back to back).  Bit-identical to the two
+        separate calls.  Inference (no tape); training, taps and masks take the single-tower entry points."""
+        if not self.assume_frozen and torch.is_grad_enabled():
+            from model.base import train_ops as T
+            if T.wants_grad(T.vit_params(self.visual)) or T.wants_grad(T.text_params(self)):
+                return self.encode_image(image), self.encode_text(text)
+        image = N.f32c(image)
+        N.require_gpu(image, text, self.visual.proj, self.text_projection)
+        text = text.to(torch.int64).contiguous()
+        if self._gemm_dtype == N.FP8 and not (self._fp8_scales_current("vit") and self._fp8_scales_current("text")):
+            self.calibrate_fp8(image=image, text=text)
+        sv, st = self._vit_struct(), self._text_struct()
+        B, L = text.shape
+        if tuple(image.shape) != (B, 3, sv.resolution, sv.resolution):
+            raise N.NativeError(f"encode_pair: expected image [{B},3,{sv.resolution},{sv.resolution}], got {tuple(image.shape)}")
+        fi = torch.empty(B, sv.embed_dim, dtype=torch.float32, device=image.device)
+        ft = torch.empty(B, st.embed_dim, dtype=torch.float32, device=image.device)
+        tag = N.stream_ptr(image.device)
+        wv = N.workspace(N.lib().cmh_vit_workspace_bytes(C.byref(sv), B), image.device, f"vit@{tag}")
+        wt = N.workspace(N.lib().cmh_text_workspace_bytes(C.byref(st), B, L), image.device, f"text@{tag}")
+        rows = torch.empty(1, dtype=torch.int32, device=image.device) if self.pack_text else None
+        N.check(N.lib().cmh_clip_encode_pair(C.byref(sv), N.ptr(image), C.byref(st), N.ptr(text), B, L, 1 if self.pack_text else 0,
+                                             N.ptr(fi), N.ptr(ft), N.ptr(rows), N.ptr(wv), wv.numel(), N.ptr(wt), wt.numel(), tag),
+                "cmh_clip_encode_pair")
+        if rows is not None:
+            self._last_text_rows = (rows, B * L)
+        return no_backward(fi, self.visual.proj), no_backward(ft, self.text_projection)
+
     def forward(self, image, text):
         """Cosine-similarity logits (reference :374-388); assembled from the two native encodes."""
         i = self.encode_image(image)

@@ -165,6 +165,15 @@ int cmh_text_calibrate_fp8(const cmh_text_weights* w, const int64_t* tokens, int
  * back once instead.)  Same workspace as cmh_text_encode. */
 int cmh_text_encode_packed(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len, float* feat,
                            int32_t* rows_computed_dev, void* workspace, size_t workspace_bytes, void* stream);
+/* encode_image + encode_text of one batch with the two towers in lock-step (reference model/modelbase.py:105-108 calls them back to
+ * back): layer i of both towers shares its GEMM launches (cmh_linear_gemm_grouped's kernel).  image f32 [batch,3,R,R], tokens i64
+ * [batch, seq_len]; packed != 0: the text tower skips the positions after each caption's EOT like cmh_text_encode_packed
+ * (rows_computed_dev as there, may be NULL).  Workspaces as for cmh_vit_encode / cmh_text_encode.  feat_image / feat_text
+ * [batch, embed_dim] f32: bit-identical to the two single-tower calls.  Both towers must share gemm_dtype. */
+int cmh_clip_encode_pair(const cmh_vit_weights* vw, const float* image, const cmh_text_weights* tw, const int64_t* tokens,
+                         int32_t batch, int32_t seq_len, int32_t packed, float* feat_image, float* feat_text,
+                         int32_t* rows_computed_dev, void* ws_image, size_t ws_image_bytes, void* ws_text, size_t ws_text_bytes,
+                         void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Building blocks of the towers, exported for unit-level parity tests and for heads that want them.
@@ -180,6 +189,29 @@ int cmh_linear_gemm(int32_t dtype, const void* x, const void* w, const float* bi
 /* LayerNorm over the last dim of x f32 [M,d] (eps 1e-5, fp32 statistics; model/base/model.py:153-159). */
 int cmh_layernorm(const float* x, const float* w, const float* b, void* out, int32_t out_dtype, int32_t M,
                   int32_t d, void* stream);
+/* Two GEMMs of the same kind as ONE launch (round 4: grouped launches; csrc/gemm_wide.hip, template parameter GRP).  The image and
+ * the text tower are 12 blocks of the same four Linear layers (reference model/base/model.py:167-207, instantiated twice by CLIP.__init__,
+ * :254-306): layer i of both runs as one persistent grid that walks the tiles of the longer-K problem first and continues into the
+ * other's.  Both problems share `dtype`, the output kind and `epilogue` (the flags of cmh_linear_gemm / cmh_linear_gemm_fp8); each
+ * brings its own pointers, shape and - CMH_FP8 - scales.  m_dev (optional, device int32): the real row count when M is an upper bound
+ * (packed captions).  Every output element is computed exactly as by the single launch: identical bits.  Shapes the wide kernel cannot
+ * take together (N % 256, M <= 2048 rows) run as two plain launches - the result never depends on the grouping. */
+typedef struct cmh_gemm_problem {
+  const void* x;          /* [M, K] dtype */
+  const void* w;          /* [N, K] dtype */
+  const float* bias;      /* [N] or NULL */
+  const void* residual;   /* [M, N] f32 / fp16 (CMH_EPI_RES_F16) or NULL */
+  void* out;              /* [M, N] */
+  int32_t M, N, K;
+  const int32_t* m_dev;   /* NULL, or the device word holding the real row count (<= M) */
+  const float* colscale;  /* CMH_FP8: [N] weight scales */
+  float alpha;            /* CMH_FP8: activation scale of x */
+  float out_scale;        /* CMH_FP8 with CMH_EPI_OUT_FP8: out = e4m3(clamp(v / out_scale, +-448)), as cmh_linear_gemm_fp8; > 0 */
+} cmh_gemm_problem;
+int cmh_linear_gemm_grouped(int32_t dtype, const cmh_gemm_problem* a, const cmh_gemm_problem* b, int32_t epilogue, void* stream);
+/* on = 0: grouped requests run as two plain launches (A/B measurements, the equality tests); 1 = grouped; -1 = environment
+ * (CMH_GEMM_GROUPED=0 is off).  Process-wide, not thread-safe. */
+int cmh_set_gemm_grouped(int32_t on);
 /* softmax(q k^T / 8 [+causal] [+key padding]) v per head (head dim 64) on packed qkv [B*T, 3d] -> o [B*T, d]. */
 int cmh_attention(int32_t dtype, const void* qkv, void* o, int32_t B, int32_t T, int32_t d, int32_t causal,
                   const uint8_t* key_padding_mask, void* stream);

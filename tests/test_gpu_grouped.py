@@ -1,0 +1,145 @@
+"""Grouped launches (round 4): layer i of the image and the text tower as ONE launch of the wide GEMM kernel
+(csrc/gemm_wide.hip, template parameter GRP; include/cmh.h: cmh_linear_gemm_grouped, cmh_clip_encode_pair).
+
+The contract is bit-identity: a grouped launch walks the same tiles with the same K order and the same epilogue as the two plain
+launches it replaces (reference: two independent nn.Linear calls, model/base/model.py:171-196, one per tower), so every comparison
+below is torch.equal - all three arithmetic modes, packed and dense captions, every tile height, device-side row counts."""
+import pytest
+import torch
+
+import recipe
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rand(shape, g, scale=1.0):
+    return torch.randn(*shape, generator=g) * scale
+
+
+# the four GEMMs of a block of both towers at batch 256 (packed text rows), plus shapes that stress the schedule: one problem with
+# fewer tiles than an XCD has workgroups, ragged last tiles, K-steps 8 vs 48
+SHAPES = [
+    ((12800, 2304, 768), (10499, 1536, 512)),     # QKV
+    ((12800, 768, 768), (10499, 512, 512)),       # out_proj (residual)
+    ((12800, 3072, 768), (10499, 2048, 512)),     # c_fc (QuickGELU)
+    ((12800, 768, 3072), (10499, 512, 2048)),     # c_proj (residual)
+    ((2100, 256, 512), (4000, 1024, 256)),        # 'a' shorter in K than 'b': the launcher swaps them
+    ((2049, 512, 1024), (2500, 256, 1024)),       # a handful of tiles each
+]
+
+
+@pytest.mark.parametrize("tile_rows", [-1, 96, 128, 160])
+@pytest.mark.parametrize("case", range(len(SHAPES)))
+def test_grouped_bf16_gemm_gives_the_plain_launches_bits(case, tile_rows):
+    import cmh_native as N
+    (Ma, Na, Ka), (Mb, Nb, Kb) = SHAPES[case]
+    g = torch.Generator().manual_seed(100 + case)
+    kind = case % 4                                   # 0 plain bias, 1 / 3 fp16 residual stream, 2 QuickGELU
+    probs = []
+    for (M, Nn, K) in ((Ma, Na, Ka), (Mb, Nb, Kb)):
+        p = {"x": _rand((M, K), g).bfloat16().to(DEV), "w": _rand((Nn, K), g, K ** -0.5).bfloat16().to(DEV), "bias": _rand((Nn,), g).to(DEV)}
+        if kind in (1, 3):
+            p["residual"] = _rand((M, Nn), g).half().to(DEV)
+        probs.append(p)
+    out = "f16" if kind in (1, 3) else "bf16"
+    try:
+        N.lib().cmh_gemm_tuning(tile_rows, -1)
+        ref = [N.linear_gemm(p["x"], p["w"], bias=p["bias"], residual=p.get("residual"), quickgelu=kind == 2, out_bf16=out == "bf16",
+                             out_f16=out == "f16") for p in probs]
+        got = N.linear_gemm_grouped(probs, quickgelu=kind == 2, out=out)
+        # a device-side row count for the second problem (packed captions): rows past it are never written
+        md = torch.tensor([Mb - 37], dtype=torch.int32, device=DEV)
+        got_md = N.linear_gemm_grouped(probs, quickgelu=kind == 2, out=out, m_dev=(None, md))
+    finally:
+        N.lib().cmh_gemm_tuning(-1, -1)
+    for r, o in zip(ref, got):
+        assert torch.equal(r, o)
+    assert torch.equal(got_md[0], ref[0]) and torch.equal(got_md[1][:Mb - 37], ref[1][:Mb - 37])
+
+
+@pytest.mark.parametrize("case", [0, 1, 3])
+def test_grouped_f32_gemm_gives_the_plain_launches_bits(case):
+    import cmh_native as N
+    (Ma, Na, Ka), (Mb, Nb, Kb) = SHAPES[case]
+    Ma, Mb = Ma // 4, Mb // 4                         # (the f32 MFMA runs at 1/16 of the bf16 rate)
+    g = torch.Generator().manual_seed(200 + case)
+    probs = []
+    for (M, Nn, K) in ((Ma, Na, Ka), (Mb, Nb, Kb)):
+        p = {"x": _rand((M, K), g).to(DEV), "w": _rand((Nn, K), g, K ** -0.5).to(DEV), "bias": _rand((Nn,), g).to(DEV)}
+        if case in (1, 3):
+            p["residual"] = _rand((M, Nn), g).to(DEV)
+        probs.append(p)
+    ref = [N.linear_gemm(p["x"], p["w"], bias=p["bias"], residual=p.get("residual")) for p in probs]
+    got = N.linear_gemm_grouped(probs)
+    for r, o in zip(ref, got):
+        assert torch.equal(r, o)
+
+
+@pytest.mark.parametrize("out", ["bf16", "f16", "fp8"])
+def test_grouped_fp8_gemm_gives_the_plain_launches_bits(out):
+    import cmh_native as N
+    (Ma, Na, Ka), (Mb, Nb, Kb) = SHAPES[{"bf16": 0, "f16": 1, "fp8": 2}[out]]
+    g = torch.Generator().manual_seed(300)
+    probs = []
+    for (M, Nn, K) in ((Ma, Na, Ka), (Mb, Nb, Kb)):
+        x8 = N.fp8_quantize(_rand((M, K), g).to(DEV), 1.0 / 64)
+        w8, cs = N.fp8_quantize_weight(_rand((Nn, K), g, K ** -0.5).to(DEV))
+        p = {"x": x8, "w": w8, "colscale": cs, "alpha": 1.0 / 64, "bias": _rand((Nn,), g).to(DEV), "out_scale": 3.0 if out == "fp8" else 1.0}
+        if out == "f16":
+            p["residual"] = _rand((M, Nn), g).half().to(DEV)
+        probs.append(p)
+    ref = [N.linear_gemm_fp8(p["x"], p["w"], p["colscale"], p["alpha"], bias=p["bias"], residual=p.get("residual"),
+                             quickgelu=out == "fp8", out=out, out_scale=p["out_scale"]) for p in probs]
+    got = N.linear_gemm_grouped(probs, quickgelu=out == "fp8", out=out)
+    for r, o in zip(ref, got):
+        assert torch.equal(r, o)
+
+
+def test_grouping_can_be_switched_off_and_small_shapes_fall_back():
+    """cmh_set_gemm_grouped(0) and shapes the wide kernel cannot take together (few rows, N % 256) run as two plain launches."""
+    import cmh_native as N
+    g = torch.Generator().manual_seed(5)
+    probs = [{"x": _rand((300, 256), g).bfloat16().to(DEV), "w": _rand((384, 256), g, 0.06).bfloat16().to(DEV)},
+             {"x": _rand((5000, 512), g).bfloat16().to(DEV), "w": _rand((512, 512), g, 0.04).bfloat16().to(DEV)}]
+    ref = [N.linear_gemm(p["x"], p["w"], out_bf16=True) for p in probs]
+    for on in (1, 0):
+        try:
+            N.set_gemm_grouped(on)
+            got = N.linear_gemm_grouped(probs, out="bf16")
+        finally:
+            N.set_gemm_grouped(-1)
+        assert all(torch.equal(r, o) for r, o in zip(ref, got))
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16", "fp8"])
+@pytest.mark.parametrize("B", [48, 256])
+def test_encode_pair_equals_the_two_single_tower_calls(mode, B):
+    """cmh_clip_encode_pair (CLIP.encode_pair): ViT-B/32 at its real size, packed and dense captions - the features of both towers
+    equal the separate encode_image / encode_text calls bit for bit; with grouping switched off the pair call still does."""
+    import cmh_native as N
+    from model.base.model import CLIP
+    if mode == "f32" and B == 256:
+        pytest.skip("the f32 mode at batch 256 adds 30 s for no new code path")
+    cfg = recipe.CLIP_VITB32
+    torch.manual_seed(21)
+    m = CLIP(**cfg).to(DEV).float().set_gemm_dtype("bf16" if mode == "fp8" else mode)
+    m.assume_frozen = True
+    img = torch.from_numpy(recipe.images(B, cfg["image_resolution"], 5)).to(DEV)
+    txt = torch.from_numpy(recipe.captions(B, 77, cfg["vocab_size"], 6)).to(DEV)
+    if mode == "fp8":
+        m.calibrate_fp8(img[:16], txt[:16])
+        m.set_gemm_dtype("fp8")
+    with torch.no_grad():
+        for pack in (True, False):
+            m.pack_text = pack
+            ref = (m.encode_image(img).clone(), m.encode_text(txt).clone())
+            got = tuple(t.clone() for t in m.encode_pair(img, txt))
+            try:
+                N.set_gemm_grouped(0)
+                off = tuple(t.clone() for t in m.encode_pair(img, txt))
+            finally:
+                N.set_gemm_grouped(-1)
+            for r, a, b in zip(ref, got, off):
+                assert torch.isfinite(r).all() and r.abs().sum() > 0
+                assert torch.equal(r, a) and torch.equal(r, b)

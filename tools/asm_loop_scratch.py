@@ -5,7 +5,7 @@ L = open(sys.argv[1]).read().split('\n')
 want = tuple(sys.argv[2:5])
 i = 0
 while i < len(L):
-    m = re.match(r'_ZN3cmh16gemm_wide_kernelILi(\d)ELi(\d)ELi(\d)ELb(\d)ELi(\d)', L[i])
+    m = re.match(r'_ZN3cmh16gemm_wide_kernelILi(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)', L[i])
     if not m:
         i += 1
         continue
@@ -22,5 +22,5 @@ while i < len(L):
         if 'scratch_' in l: by_depth[depth] = by_depth.get(depth, 0) + 1
         if 'v_mfma' in l: mf_by_depth[depth] = mf_by_depth.get(depth, 0) + 1
     if not want or key[:3] == want:
-        print('DT OK MF TN LN =', ' '.join(key), '| scratch ops by loop depth', dict(sorted(by_depth.items())), '| MFMAs by depth', dict(sorted(mf_by_depth.items())))
+        print('DT OK MF TN GRP =', ' '.join(key), '| scratch ops by loop depth', dict(sorted(by_depth.items())), '| MFMAs by depth', dict(sorted(mf_by_depth.items())))
     i = j
