@@ -193,7 +193,7 @@ def main():
     ap.add_argument("--train-step", action="store_true",
                     help="also time the training step when --gpus > 1 (default: single-GPU runs only, so that the secondary "
                          "metric's gradient all-reduce can never stall the headline scaling line)")
-    ap.add_argument("--towers", default="streams", choices=["pair", "streams", "serial"],
+    ap.add_argument("--towers", default="streams", choices=["pair", "streams", "pipelined", "serial"],
                     help="how a step runs the two towers: pair = in lock-step, layer i of both sharing its GEMM launches (cmh_clip_encode_pair); "
                          "streams = one HIP stream per tower; serial = the text tower after the image tower on one stream")
     ap.add_argument("--no-overlap-towers", action="store_true", help="= --towers serial")
@@ -245,9 +245,9 @@ def main():
             if how == "pair":       # both towers in lock-step: layer i of both is one grouped GEMM launch (csrc/encoders.hip)
                 fi, ft = clip.encode_pair(image, text)
                 hi, ht = finish(img_head, fi), finish(txt_head, ft)
-            elif how == "streams":   # the two towers are independent until the loss: one HIP stream each (streams.py)
+            elif how in ("streams", "pipelined"):   # the two towers are independent until the loss: one HIP stream each (streams.py)
                 hi, ht = overlapped(lambda: tower(clip.encode_image, img_head, image),
-                                    lambda: tower(clip.encode_text, txt_head, text))
+                                    lambda: tower(clip.encode_text, txt_head, text), inputs_ready=True if how == "pipelined" else None)
             else:
                 hi = tower(clip.encode_image, img_head, image)
                 ht = tower(clip.encode_text, txt_head, text)
@@ -271,7 +271,7 @@ def main():
     for _ in range(a.warmup):
         step()
     barrier()
-    overlap = towers == "streams"      # per-launch events overlap only when the towers run on two streams
+    overlap = towers in ("streams", "pipelined")      # per-launch events overlap only when the towers run on two streams
     reps = max(1, a.repeats)
     if not overlap:
         N.prof_gemm_begin(a.steps * reps * 128)
@@ -379,7 +379,9 @@ def main():
                    "seq_len": L, "bits": K, "weights": "random-init ViT-B/32", "parallelism": f"batch-shard x{world}",
                    "towers": towers,
                    "streams": {"pair": "one stream, the towers in lock-step: layer i of both shares its GEMM launches (grouped)",
-                               "streams": "image and text tower on one HIP stream each", "serial": "single stream, tower after tower"}[towers]},
+                               "streams": "image and text tower on one HIP stream each",
+                               "pipelined": "image and text tower on one HIP stream each; consecutive (independent) batches overlap: a tower's stream "
+                                            "starts batch n + 1 as soon as it has finished batch n", "serial": "single stream, tower after tower"}[towers]},
         "per_gpu_value": round(value / world, 2),
         "text_rows": {"computed": rows_c, "dense": rows_d,
                       "note": "caption tokens after the EOT cannot reach the pooled feature under the causal mask; they are not "

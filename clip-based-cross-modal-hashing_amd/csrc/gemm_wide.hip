@@ -224,6 +224,21 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   const int band = (tiles_m + 7) >> 3;
   auto tile_coords = [&](int logical, int& tm, int& tn) {
     if (ordG == 0) { tm = logical / tiles_n; tn = logical - tm * tiles_n; return; }
+    if (ordG >= 100) {
+      // n-BLOCKED order (round 4): blocks of ordG - 100 n-panels outermost, inside a block n-fastest over ALL m-tiles.  The XCDs'
+      // contiguous eighths of this order are (m-range x panel-block) rectangles: an XCD streams only its block of W (<= ~2 MB: it
+      // stays in the 4 MiB L2 across the XCD's rounds) and its m-range of X, which one or two other XCDs read as well - instead of
+      // ALL of W once per round (profiles/r04_c_gemm_read_traffic_split.txt: 27 W-sized fetches per QKV launch, 35 per c_fc launch).
+      const int nbw = ordG - 100;
+      const int bt = tiles_m * nbw;
+      const int nb = logical / bt;
+      const int rem = logical - nb * bt;
+      const int wdt = tiles_n - nb * nbw < nbw ? tiles_n - nb * nbw : nbw;   // the last block may be narrower
+      const int mi = rem / wdt;
+      tm = mi;
+      tn = nb * nbw + (rem - mi * wdt);
+      return;
+    }
     const int b = logical / (band * tiles_n);
     const int blen = tiles_m - b * band < band ? tiles_m - b * band : band;   // the last band may be shorter
     const int rem = logical - b * band * tiles_n;
@@ -1181,12 +1196,18 @@ static int g_force_order = []() { const char* e = getenv("CMH_GEMM_ORDER"); retu
 
 // n-panels per group of the tile order (see tile_coords in the kernel); 0 = the n-fastest order
 static int wide_order_group(int N) {
-  // Measured (round 2, tools/gemm_bench2.py + bench.py A/B on one box): groups of 3-4 panels are +6 % on a back-to-back chain
-  // of the four GEMMs of a block, but -6 ... -10 % on the QKV / c_fc launches INSIDE the encoder (their X operand was just
-  // written by the LayerNorm kernel and is shared by 9-12 concurrent tiles in the n-fastest order; grouped, it is re-read once
-  // per group after the outputs have passed through the L2).  Default: n-fastest.
-  (void)N;
-  return g_force_order >= 0 ? g_force_order : 0;
+  // Round 2 (tools/gemm_bench2.py + bench.py A/B on one box): GROUPS of 3-4 panels inside each XCD's band of m-tiles (ordG 1..64) are
+  // +6 % on a back-to-back chain of a block's four GEMMs but -6 ... -10 % on the QKV / c_fc launches INSIDE the encoder (an X tile
+  // is re-read once per group, after the outputs have passed through the L2): never the default.
+  // Round 4: panel BLOCKS outermost (ordG >= 100, see tile_coords): 2 blocks for 4..11 panels, 3 from 12 on.  Fabric reads per launch
+  // 116 -> 90 MB (QKV, N = 2304) and 185 -> 114 MB (c_fc, N = 3072), L2 hit rate 68-72 -> 76 % - and the SAME launch duration to
+  // +-1 % (profiles/r04_d_gemm_nblocked_order_ab.txt, r04_d_gemm_nblocked_order_traffic.txt): the K loop does not wait on L2 misses.
+  // It is the default for the traffic it saves the other tower's kernels (+0.4 % on the two-stream step, A/B/A/B on one box).
+  const int tn = N / wBN;
+  auto blocked = [&](int nb) { return tn >= 2 * nb ? 100 + (tn + nb - 1) / nb : 0; };
+  if (g_force_order <= -2) return blocked(-g_force_order);     // -NB: the n-blocked order with NB panel blocks
+  if (g_force_order >= 0) return g_force_order;                 // 0: plain n-fastest; 1..64: round 2's panel groups
+  return tn >= 12 ? blocked(3) : (tn >= 4 ? blocked(2) : 0);
 }
 
 static int wide_cus() {
@@ -1462,7 +1483,7 @@ int launch_gemm_wide_grouped(int dt, const GemmProblem& a, const GemmProblem& b,
 extern "C" int cmh_gemm_tuning(int32_t tile_rows, int32_t order_group) {
   using namespace cmh;
   CMH_CHECK_ARG(tile_rows == -1 || tile_rows == 96 || tile_rows == 128 || tile_rows == 160, "gemm_tuning: tile_rows %d (-1, 96, 128, 160)", tile_rows);
-  CMH_CHECK_ARG(order_group >= -1 && order_group <= 64, "gemm_tuning: order_group %d", order_group);
+  CMH_CHECK_ARG(order_group >= -8 && order_group <= 64, "gemm_tuning: order_group %d (-8..-2: n-blocked, -1: default, 0: n-fastest, > 0: panel groups)", order_group);
   g_force_rows = tile_rows;
   g_force_order = order_group;
   return CMH_OK;

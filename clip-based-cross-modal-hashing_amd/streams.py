@@ -11,9 +11,29 @@ import torch
 _streams = {}
 
 
-def overlapped(*fns):
+def _record(obj, stream):
+    """tell the caching allocator that `stream` reads these tensors too (they were allocated on a side stream)"""
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, (tuple, list)):
+        for o in obj:
+            _record(o, stream)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            _record(o, stream)
+
+
+def overlapped(*fns, inputs_ready=None):
     """Run independent zero-argument callables concurrently, one side stream each; returns their results in order.
-    Sequential when CMH_OVERLAP=0, on CPU tensors' behalf (no current CUDA device) or for a single callable."""
+    Sequential when CMH_OVERLAP=0, on CPU tensors' behalf (no current CUDA device) or for a single callable.
+
+    inputs_ready (a torch.cuda.Event, or True for "already resident"): PIPELINED form for loops over INDEPENDENT batches (database
+    encoding, train/base.py:130-148): the side streams wait only for that event instead of for everything queued on the caller's
+    stream, so the towers of batch n + 1 start while batch n's tail - the shorter tower's idle time, the heads, the caller's
+    bookkeeping - is still in flight.  The caller's stream still waits for the side streams, results may be used as usual (they are
+    registered with the allocator for the caller's stream); the callables must not read anything the caller's stream produced
+    after `inputs_ready`."""
     if len(fns) < 2 or os.environ.get("CMH_OVERLAP", "1") == "0" or not torch.cuda.is_available():
         return tuple(f() for f in fns)
     dev = torch.cuda.current_device()
@@ -23,9 +43,14 @@ def overlapped(*fns):
     cur = torch.cuda.current_stream(dev)
     out = []
     for s, f in zip(pool, fns):
-        s.wait_stream(cur)
+        if inputs_ready is None:
+            s.wait_stream(cur)
+        elif inputs_ready is not True:
+            s.wait_event(inputs_ready)
         with torch.cuda.stream(s):
             out.append(f())
     for s in pool[:len(fns)]:
         cur.wait_stream(s)
+    if inputs_ready is not None:
+        _record(out, cur)
     return tuple(out)

@@ -229,8 +229,10 @@ int cmh_prof_gemm_end(double* total_ms, double* total_flops, int64_t* launches);
 int cmh_prof_gemm_by_kernel(double* ms3, double* flops3, int64_t* launches3);
 
 /* Tuning overrides of the N % 256 == 0 GEMM kernel, for A/B measurements and for tests that must reach every variant:
- * tile_rows in {96, 128, 160} pins the tile height (-1: chosen per launch from M, N, K and the CU count); order_group = n-panels
- * per group of the L2-aware tile order (0: plain n-fastest order, -1: chosen per launch).  Results do not depend on either.
+ * tile_rows in {96, 128, 160} pins the tile height (-1: chosen per launch from M, N, K and the CU count); order_group picks the
+ * tile order: -1 chosen per launch (the n-blocked order for N >= 1024: panel blocks outermost, so an XCD keeps its block of W in
+ * its L2), 0 plain n-fastest, 1..64 n-panels per group inside each XCD's band (round 2), -2..-8 the n-blocked order with that many
+ * blocks.  Results do not depend on either.
  * Process-wide, not thread-safe.  (No reference counterpart: upstream's GEMMs are ATen's, model/base/model.py:167-196.) */
 int cmh_gemm_tuning(int32_t tile_rows, int32_t order_group);
 /* GEMMs of few rows (M <= 512: the pooled-row tail of the towers, small heads) run on 64 x 64 tiles (csrc/gemm_rows.hip) instead of

@@ -12,7 +12,11 @@ SHAPES = {"v_qkv": (12800, 2304, 768, E["bias"] | E["obf"]), "v_out": (12800, 76
           "v_fc2": (12800, 768, 3072, rx), "t_qkv": (T, 1536, 512, E["bias"] | E["obf"]), "t_out": (T, 512, 512, rx),
           "t_fc1": (T, 2048, 512, E["bias"] | E["qgelu"] | E["obf"]), "t_fc2": (T, 512, 2048, rx)}
 name, n = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 6
-M, Nn, K, epi = SHAPES[name]
+if name in SHAPES:
+    M, Nn, K, epi = SHAPES[name]
+else:                              # "MxNxK": bf16 output, bias epilogue (tools/pmc_traffic_split.sh)
+    M, Nn, K = (int(v) for v in name.split("x"))
+    epi = E["bias"] | E["obf"]
 g = torch.Generator().manual_seed(1)
 x = torch.randn(M, K, generator=g).to(dev).bfloat16()
 w = (torch.randn(Nn, K, generator=g) * K ** -0.5).to(dev).bfloat16()
