@@ -193,7 +193,7 @@ def main():
     ap.add_argument("--train-step", action="store_true",
                     help="also time the training step when --gpus > 1 (default: single-GPU runs only, so that the secondary "
                          "metric's gradient all-reduce can never stall the headline scaling line)")
-    ap.add_argument("--towers", default="streams", choices=["pair", "streams", "pipelined", "serial"],
+    ap.add_argument("--towers", default="streams", choices=["pair", "pair2", "streams", "pipelined", "serial"],
                     help="how a step runs the two towers: pair = in lock-step, layer i of both sharing its GEMM launches (cmh_clip_encode_pair); "
                          "streams = one HIP stream per tower; serial = the text tower after the image tower on one stream")
     ap.add_argument("--no-overlap-towers", action="store_true", help="= --towers serial")
@@ -239,9 +239,25 @@ def main():
         N.pack_codes(N.sign_codes(h), validate=False)
         return h
 
+    pair_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    pair_turn = [0]
+
     def step(overlap=None, how=None):
         how = how or ("serial" if overlap is False else towers)
         with torch.no_grad():
+            if how == "pair2":
+                # the lock-step pair path, consecutive (independent) batches alternating between two streams: the grouped GEMMs of one
+                # batch run beside the LayerNorm / attention launches and the launch gaps of the other
+                s2 = pair_streams[pair_turn[0] & 1]
+                pair_turn[0] += 1
+                cur = torch.cuda.current_stream(dev)
+                with torch.cuda.stream(s2):
+                    fi, ft = clip.encode_pair(image, text)
+                    hi, ht = finish(img_head, fi), finish(txt_head, ft)
+                    loss2 = hyp(hi, ht, label)
+                cur.wait_stream(s2)
+                loss2.record_stream(cur)
+                return loss2
             if how == "pair":       # both towers in lock-step: layer i of both is one grouped GEMM launch (csrc/encoders.hip)
                 fi, ft = clip.encode_pair(image, text)
                 hi, ht = finish(img_head, fi), finish(txt_head, ft)
@@ -271,7 +287,7 @@ def main():
     for _ in range(a.warmup):
         step()
     barrier()
-    overlap = towers in ("streams", "pipelined")      # per-launch events overlap only when the towers run on two streams
+    overlap = towers in ("streams", "pipelined", "pair2")      # per-launch events overlap only when kernels of two streams share the GPU
     reps = max(1, a.repeats)
     if not overlap:
         N.prof_gemm_begin(a.steps * reps * 128)
@@ -299,7 +315,7 @@ def main():
         # roofline leg therefore re-runs the same K steps with the towers serialized, right after the timed region.
         N.prof_gemm_begin(a.steps * 128)
         for _ in range(a.steps):
-            step(overlap=False)
+            step(how="pair" if towers == "pair2" else "serial")
         barrier()
     prof_steps = a.steps if overlap else a.steps * reps
     all_ms, all_flops, all_launches = N.prof_gemm_end()
@@ -349,7 +365,7 @@ def main():
                     total += M * K * e + Nn * K * e + M * Nn * osz + res * M * Nn * xs
                     n += 1
         total += B * 49 * 3072 * e + 768 * 3072 * e + B * 49 * 768 * 4                         # conv1 as a GEMM
-        if towers == "pair":      # layer i of both towers is ONE launch: 45 grouped launches + conv1
+        if towers in ("pair", "pair2"):      # layer i of both towers is ONE launch: 45 grouped launches + conv1
             n //= 2
         return total, n + 1
     # HBM-side bytes per GEMM launch cannot be counted from inside this process: they come from the two rocprofv3 --pmc
@@ -380,6 +396,7 @@ def main():
                    "towers": towers,
                    "streams": {"pair": "one stream, the towers in lock-step: layer i of both shares its GEMM launches (grouped)",
                                "streams": "image and text tower on one HIP stream each",
+                               "pair2": "the lock-step pair path; consecutive (independent) batches alternate between two HIP streams",
                                "pipelined": "image and text tower on one HIP stream each; consecutive (independent) batches overlap: a tower's stream "
                                             "starts batch n + 1 as soon as it has finished batch n", "serial": "single stream, tower after tower"}[towers]},
         "per_gpu_value": round(value / world, 2),
@@ -424,7 +441,7 @@ def main():
             f32_ms = (time.perf_counter() - tf0) / nf * 1e3
             N.prof_gemm_begin(nf * 128)
             for _ in range(nf):
-                step(how="pair" if towers == "pair" else "serial")
+                step(how="pair" if towers in ("pair", "pair2") else "serial")
             torch.cuda.synchronize()
             N.prof_gemm_end()
             g_ms, g_fl, g_n = N.prof_gemm_by_kernel()["gemm_wide_kernel"]
@@ -456,7 +473,7 @@ def main():
             fp8_ms = (time.perf_counter() - t8) / a.steps * 1e3
             N.prof_gemm_begin(a.steps * 128)
             for _ in range(a.steps):
-                step(how="pair" if towers == "pair" else "serial")
+                step(how="pair" if towers in ("pair", "pair2") else "serial")
             torch.cuda.synchronize()
             N.prof_gemm_end()
             by8 = N.prof_gemm_by_kernel()
