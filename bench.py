@@ -193,10 +193,13 @@ def main():
     ap.add_argument("--train-step", action="store_true",
                     help="also time the training step when --gpus > 1 (default: single-GPU runs only, so that the secondary "
                          "metric's gradient all-reduce can never stall the headline scaling line)")
-    ap.add_argument("--towers", default="streams", choices=["pair", "pair2", "streams", "pipelined", "serial"],
-                    help="how a step runs the two towers: pair = in lock-step, layer i of both sharing its GEMM launches (cmh_clip_encode_pair); "
-                         "streams = one HIP stream per tower; serial = the text tower after the image tower on one stream")
+    ap.add_argument("--towers", default="pair2", choices=["pair", "pair2", "streams", "pipelined", "serial"],
+                    help="how a step runs the two towers: pair = in lock-step on one stream, layer i of both sharing its launches "
+                         "(cmh_clip_encode_pair); pair2 (default) = the same, consecutive independent batches alternating between two HIP "
+                         "streams - the product's encode loop (train/base.py::_code_loop); streams = one HIP stream per tower (rounds 1-3); "
+                         "pipelined = streams without the per-step join of the side streams; serial = tower after tower on one stream")
     ap.add_argument("--no-overlap-towers", action="store_true", help="= --towers serial")
+    ap.add_argument("--no-towers-ab", action="store_true", help="skip the timed legs of the other tower modes (streams, pair)")
     ap.add_argument("--no-precision-legs", action="store_true", help="skip flip_rate_vs_f32 and the timed f32-mode / fp8-mode legs")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the one-number-per-BASELINE-config legs (bench_configs.py)")
     ap.add_argument("--map-queries", type=int, default=5000)
@@ -254,11 +257,10 @@ def main():
                 with torch.cuda.stream(s2):
                     fi, ft = clip.encode_pair(image, text)
                     hi, ht = finish(img_head, fi), finish(txt_head, ft)
-                    loss2 = hyp(hi, ht, label)
-                cur.wait_stream(s2)
-                loss2.record_stream(cur)
-                return loss2
-            if how == "pair":       # both towers in lock-step: layer i of both is one grouped GEMM launch (csrc/encoders.hip)
+                cur.wait_stream(s2)          # the exchange step and the loss stay on the caller's stream
+                hi.record_stream(cur)
+                ht.record_stream(cur)
+            elif how == "pair":       # both towers in lock-step: layer i of both is one grouped GEMM launch (csrc/encoders.hip)
                 fi, ft = clip.encode_pair(image, text)
                 hi, ht = finish(img_head, fi), finish(txt_head, ft)
             elif how in ("streams", "pipelined"):   # the two towers are independent until the loss: one HIP stream each (streams.py)
@@ -405,7 +407,8 @@ def main():
                               "computed (synthetic captions: EOT uniform in positions 3..75)"},
         "value_dense_text": None if value_dense is None else round(value_dense, 2),
         "end_to_end_tflops_per_gpu": round(value / world * flops_pair / 1e12, 2),
-        "roofline": {"bound": "mfma", "kernel": "cmh::gemm_wide_kernel<%s, *>" % ("true" if a.dtype == "f32" else "false"),
+        "roofline": {"bound": "mfma", "kernel": "cmh::gemm_wide_kernel<%s, 1, *>%s" % ("0" if a.dtype == "f32" else "1", " (grouped launches: layer i of both "
+                     "towers per launch)" if towers in ("pair", "pair2") else ""),
                      "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                      "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": round(gemm_algorithmic_bytes(rows_c)[0] / gemm_algorithmic_bytes(rows_c)[1]),
@@ -419,10 +422,49 @@ def main():
                      "all_gemm_launches": {"launches": int(all_launches), "ms_per_step": round(all_ms / prof_steps, 4),
                                            "tflops": round(all_flops / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else 0.0},
                      "measured_in": ("the timed region" if not overlap else
+                                     "a second pass of the same K steps on ONE stream (the lock-step pair path, batch after batch): in the "
+                                     "timed region the launches of two batches overlap, so per-launch events would not time the kernel; "
+                                     "value/ms_per_step are from the overlapped region (towers_ab.pair holds a roofline measured in ITS "
+                                     "timed region)" if towers == "pair2" else
                                      "a second pass of the same K steps with the two towers serialized (per-launch events "
                                      "overlap when the towers share the GPU); value/ms_per_step are from the overlapped region"),
                      "gemm_ms_per_step_serialized": round(gemm_ms / prof_steps, 4)},
     }
+
+    if world == 1 and not a.no_towers_ab:
+        # The other ways to run a step's two towers, timed on this very box (one region of --steps steps each), and - in the single-stream
+        # lock-step mode, where launches do not overlap - the GEMM roofline measured IN that timed region by the dispatches' own events
+        ab = {}
+        for how in ("streams", "pair", "pair2"):
+            if how == towers:
+                continue
+            try:
+                for _ in range(3):
+                    step(how=how)
+                barrier()
+                if how == "pair":
+                    N.prof_gemm_begin(a.steps * 128)
+                tb0 = time.perf_counter()
+                for _ in range(a.steps):
+                    step(how=how)
+                barrier()
+                tb_ms = (time.perf_counter() - tb0) / a.steps * 1e3
+                ab[how] = {"pairs_per_s": round(B / tb_ms * 1e3, 2), "ms_per_step": round(tb_ms, 4), "steps": a.steps,
+                           "vs_headline": round(out["ms_per_step"] / tb_ms, 4)}
+                if how == "pair":
+                    p_ms, p_fl, p_n = N.prof_gemm_end()
+                    pk = N.prof_gemm_by_kernel()["gemm_wide_kernel"]
+                    ab[how]["roofline"] = {"bound": "mfma", "achieved": round(pk[1] / (pk[0] * 1e-3) / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                                           "frac": round(pk[1] / (pk[0] * 1e-3) / 1e12 / peak, 4), "launches": int(pk[2]),
+                                           "avg_launch_us": round(pk[0] * 1e3 / max(pk[2], 1), 2), "measured_in": "the timed region",
+                                           "all_gemm_launches": {"launches": int(p_n), "ms_per_step": round(p_ms / a.steps, 4),
+                                                                 "tflops": round(p_fl / (p_ms * 1e-3) / 1e12, 2) if p_ms > 0 else 0.0}}
+            except Exception as exc:
+                ab[how] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        ab["what"] = ("streams: one HIP stream per tower (the default of rounds 1-3); pair: both towers in lock-step on ONE stream, layer i of both "
+                      "as one grouped launch (GEMM, LayerNorm, attention) - launches do not overlap, so its roofline is measured in the timed "
+                      "region; pair2: pair with consecutive batches alternating between two streams")
+        out["towers_ab"] = ab
 
     if world == 1 and a.dtype != "f32" and not a.no_precision_legs:      # (step() holds a collective when world > 1: single-GPU runs only)
         try:

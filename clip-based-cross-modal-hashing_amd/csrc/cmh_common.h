@@ -154,6 +154,11 @@ int launch_layernorm(const float* x, const int32_t* row_index, const float* w, c
 int launch_layernorm_x(const void* x, int x_f16, const int32_t* row_index, const float* w, const float* b,
                        void* out, int out_bf16, int M, int d, hipStream_t st, const int32_t* m_dev = nullptr);
 
+// the bf16 mode's LayerNorm (fp16 stream -> bf16 rows) of two row sets in ONE launch (the lock-step pair path); false = no kernel for
+// this pair of widths (or CMH_PAIR_KERNELS=0): launch the two singly
+bool launch_layernorm_h2b_pair(const void* x0, const float* w0, const float* b0, void* out0, int M0, int d0, const int32_t* md0,
+                               const void* x1, const float* w1, const float* b1, void* out1, int M1, int d1, const int32_t* md1,
+                               hipStream_t st);
 // image [B,3,R,R] f32 -> patches [B*g*g, 3*p*p] (dt)
 int launch_patchify(const float* image, void* patches, int dt, int B, int R, int p, hipStream_t st);
 // tokens: x[b,0]=cls+pos[0]; x[b,1+i]=patch_out[b*g2+i]+pos[1+i]; then ln_pre -> x f32|f16 [B*(g2+1), d]
@@ -214,6 +219,10 @@ int launch_attention(const void* qkv, void* o, int dt, int B, int T, int d, int 
 int launch_attention_varlen(const void* qkv, void* o, int dt, int B, int T, int d, int causal,
                             const uint8_t* key_padding_mask, const int32_t* seq_off, hipStream_t st,
                             float o8_inv_scale = 0.f);   // > 0 (bf16 qkv, T <= 128): o is e4m3 of o * o8_inv_scale (fp8 mode)
+// the bf16 MFMA attention of two towers (T <= 128, no key-padding mask) in ONE launch; false = no kernel for this pair (launch singly)
+bool launch_attention_pair(const void* qkv0, void* o0, int B0, int T0, int d0, int causal0, const int32_t* seq0, float o8s0,
+                           const void* qkv1, void* o1, int B1, int T1, int d1, int causal1, const int32_t* seq1, float o8s1,
+                           hipStream_t st);
 // fp8.hip: LayerNorm of the fp16 residual stream straight to e4m3 (y * inv_scale); max |x| into a device scalar (running maximum)
 int launch_layernorm_q(const void* x_f16, const float* w, const float* b, void* out_fp8, float inv_scale, int M, int d, hipStream_t st,
                        const int32_t* m_dev = nullptr);

@@ -228,8 +228,11 @@ static int run_block_pair(const cmh_block_weights& wa, const cmh_block_weights& 
     if ((rc = launch_gemm_grouped(CMH_FP8, problem_of(a, a.t.h, wa.in_proj_w, wa.in_proj_b, nullptr, a.t.qkv, 3 * a.d, a.d, wa.in_proj_cs, sa[0]),
                                   problem_of(b, b.t.h, wb.in_proj_w, wb.in_proj_b, nullptr, b.t.qkv, 3 * b.d, b.d, wb.in_proj_cs, sb[0]),
                                   EPI_BIAS | EPI_OUT_BF16, st))) return rc;
-    if ((rc = launch_attention_varlen(a.t.qkv, a.t.h, CMH_BF16, a.B, a.T, a.d, a.causal, nullptr, a.seq_off, st, 1.0f / sa[1]))) return rc;
-    if ((rc = launch_attention_varlen(b.t.qkv, b.t.h, CMH_BF16, b.B, b.T, b.d, b.causal, nullptr, b.seq_off, st, 1.0f / sb[1]))) return rc;
+    if (!launch_attention_pair(a.t.qkv, a.t.h, a.B, a.T, a.d, a.causal, a.seq_off, 1.0f / sa[1],
+                               b.t.qkv, b.t.h, b.B, b.T, b.d, b.causal, b.seq_off, 1.0f / sb[1], st)) {
+      if ((rc = launch_attention_varlen(a.t.qkv, a.t.h, CMH_BF16, a.B, a.T, a.d, a.causal, nullptr, a.seq_off, st, 1.0f / sa[1]))) return rc;
+      if ((rc = launch_attention_varlen(b.t.qkv, b.t.h, CMH_BF16, b.B, b.T, b.d, b.causal, nullptr, b.seq_off, st, 1.0f / sb[1]))) return rc;
+    }
     if (upto_attention) return CMH_OK;
     if ((rc = launch_gemm_grouped(CMH_FP8, problem_of(a, a.t.h, wa.out_proj_w, wa.out_proj_b, a.t.x, a.t.x, a.d, a.d, wa.out_proj_cs, sa[1]),
                                   problem_of(b, b.t.h, wb.out_proj_w, wb.out_proj_b, b.t.x, b.t.x, b.d, b.d, wb.out_proj_cs, sb[1]), rx, st))) return rc;
@@ -244,17 +247,25 @@ static int run_block_pair(const cmh_block_weights& wa, const cmh_block_weights& 
   const int dt = dtb;
   const int obf = dt == CMH_BF16 ? EPI_OUT_BF16 : 0;
   const int rx = EPI_BIAS | EPI_RESIDUAL | (a.t.xh ? EPI_RES_F16 | EPI_OUT_F16 : 0);
-  if ((rc = launch_layernorm_x(a.t.x, a.t.xh, nullptr, wa.ln1_w, wa.ln1_b, a.t.h, dt == CMH_BF16, a.M, a.d, st, a.md))) return rc;
-  if ((rc = launch_layernorm_x(b.t.x, b.t.xh, nullptr, wb.ln1_w, wb.ln1_b, b.t.h, dt == CMH_BF16, b.M, b.d, st, b.md))) return rc;
+  const bool ln_pair = dt == CMH_BF16 && a.t.xh && b.t.xh;     // fp16 stream -> bf16 rows: both towers' rows in one launch
+  if (!(ln_pair && launch_layernorm_h2b_pair(a.t.x, wa.ln1_w, wa.ln1_b, a.t.h, a.M, a.d, a.md, b.t.x, wb.ln1_w, wb.ln1_b, b.t.h, b.M, b.d, b.md, st))) {
+    if ((rc = launch_layernorm_x(a.t.x, a.t.xh, nullptr, wa.ln1_w, wa.ln1_b, a.t.h, dt == CMH_BF16, a.M, a.d, st, a.md))) return rc;
+    if ((rc = launch_layernorm_x(b.t.x, b.t.xh, nullptr, wb.ln1_w, wb.ln1_b, b.t.h, dt == CMH_BF16, b.M, b.d, st, b.md))) return rc;
+  }
   if ((rc = launch_gemm_grouped(dt, problem_of(a, a.t.h, wa.in_proj_w, wa.in_proj_b, nullptr, a.t.qkv, 3 * a.d, a.d),
                                 problem_of(b, b.t.h, wb.in_proj_w, wb.in_proj_b, nullptr, b.t.qkv, 3 * b.d, b.d), EPI_BIAS | obf, st))) return rc;
-  if ((rc = launch_attention_varlen(a.t.qkv, a.t.h, dt, a.B, a.T, a.d, a.causal, nullptr, a.seq_off, st))) return rc;
-  if ((rc = launch_attention_varlen(b.t.qkv, b.t.h, dt, b.B, b.T, b.d, b.causal, nullptr, b.seq_off, st))) return rc;
+  if (!(dt == CMH_BF16 && launch_attention_pair(a.t.qkv, a.t.h, a.B, a.T, a.d, a.causal, a.seq_off, 0.f,
+                                                b.t.qkv, b.t.h, b.B, b.T, b.d, b.causal, b.seq_off, 0.f, st))) {
+    if ((rc = launch_attention_varlen(a.t.qkv, a.t.h, dt, a.B, a.T, a.d, a.causal, nullptr, a.seq_off, st))) return rc;
+    if ((rc = launch_attention_varlen(b.t.qkv, b.t.h, dt, b.B, b.T, b.d, b.causal, nullptr, b.seq_off, st))) return rc;
+  }
   if (upto_attention) return CMH_OK;
   if ((rc = launch_gemm_grouped(dt, problem_of(a, a.t.h, wa.out_proj_w, wa.out_proj_b, a.t.x, a.t.x, a.d, a.d),
                                 problem_of(b, b.t.h, wb.out_proj_w, wb.out_proj_b, b.t.x, b.t.x, b.d, b.d), rx, st))) return rc;
-  if ((rc = launch_layernorm_x(a.t.x, a.t.xh, nullptr, wa.ln2_w, wa.ln2_b, a.t.h, dt == CMH_BF16, a.M, a.d, st, a.md))) return rc;
-  if ((rc = launch_layernorm_x(b.t.x, b.t.xh, nullptr, wb.ln2_w, wb.ln2_b, b.t.h, dt == CMH_BF16, b.M, b.d, st, b.md))) return rc;
+  if (!(ln_pair && launch_layernorm_h2b_pair(a.t.x, wa.ln2_w, wa.ln2_b, a.t.h, a.M, a.d, a.md, b.t.x, wb.ln2_w, wb.ln2_b, b.t.h, b.M, b.d, b.md, st))) {
+    if ((rc = launch_layernorm_x(a.t.x, a.t.xh, nullptr, wa.ln2_w, wa.ln2_b, a.t.h, dt == CMH_BF16, a.M, a.d, st, a.md))) return rc;
+    if ((rc = launch_layernorm_x(b.t.x, b.t.xh, nullptr, wb.ln2_w, wb.ln2_b, b.t.h, dt == CMH_BF16, b.M, b.d, st, b.md))) return rc;
+  }
   if ((rc = launch_gemm_grouped(dt, problem_of(a, a.t.h, wa.fc_w, wa.fc_b, nullptr, a.t.mlp, 4 * a.d, a.d),
                                 problem_of(b, b.t.h, wb.fc_w, wb.fc_b, nullptr, b.t.mlp, 4 * b.d, b.d), EPI_BIAS | EPI_QUICKGELU | obf, st))) return rc;
   return launch_gemm_grouped(dt, problem_of(a, a.t.mlp, wa.proj_w, wa.proj_b, a.t.x, a.t.x, a.d, 4 * a.d),

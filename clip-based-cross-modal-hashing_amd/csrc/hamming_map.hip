@@ -1045,8 +1045,9 @@ extern "C" size_t cmh_map_workspace_bytes(int32_t Q, int64_t N, int32_t bits, in
   if (Q <= 0 || N <= 0) return 0;
   const size_t slots = static_cast<size_t>(map_slots(Q));
   const MapMode mode = map_mode(N);       // (the same decision cmh_hamming_map takes, CMH_MAP_MODE included)
-  if (mode == MAP_GLOBAL) return slots * store_words(N) * 4 + 256;
-  if (mode == MAP_HYBRID || mode == MAP_HYBRID1) return slots * hybrid_glob_words(N) * 4 + 256;
+  const size_t stamps = getenv("CMH_MAP_STAMPS") ? 32768 : 0;      // diagnostics (tools/map_stamps.py): behind the slices
+  if (mode == MAP_GLOBAL) return slots * store_words(N) * 4 + 256 + stamps;
+  if (mode == MAP_HYBRID || mode == MAP_HYBRID1) return slots * hybrid_glob_words(N) * 4 + 256 + stamps;
   return 4096;                            // all-LDS placements: only the optional diagnostics stamps live here
 }
 
@@ -1071,7 +1072,13 @@ extern "C" int cmh_hamming_map(const uint32_t* q_sign, const uint32_t* q_nz, con
   a.gstore = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
   const MapMode mode = map_mode(N);
   // diagnostics stamps (tools/map_stamps.py, CMH_MAP_MODE=lds1): only where the workspace holds nothing else
-  a.stamps = getenv("CMH_MAP_STAMPS") && (mode == MAP_LDS1 || mode == MAP_LDS2) ? reinterpret_cast<unsigned long long*>(a.gstore) : nullptr;
+  a.stamps = nullptr;
+  if (getenv("CMH_MAP_STAMPS")) {
+    if (mode == MAP_LDS1 || mode == MAP_LDS2) a.stamps = reinterpret_cast<unsigned long long*>(a.gstore);
+    else      // behind the workgroups' slices (cmh_map_workspace_bytes reserved the room)
+      a.stamps = reinterpret_cast<unsigned long long*>(a.gstore + static_cast<size_t>(map_slots(Q)) *
+                                                       (mode == MAP_GLOBAL ? store_words(N) : hybrid_glob_words(N)));
+  }
   const size_t lds = mode == MAP_GLOBAL ? 0 : (mode == MAP_HYBRID || mode == MAP_HYBRID1 ? hybrid_lds_words(N) * 4 : lds_bytes_needed(N));
 #define MAP_GO(MODE, WAVES)                                                                                                      \
   do {                                                                                                                           \

@@ -92,17 +92,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
 // The bf16 mode's LayerNorm: fp16 row in, bf16 row out, d a multiple of 256.  HALF a wave per row: a lane owns 8 consecutive
 // elements of every 256-element block, so a row is d/256 16-byte loads per lane (the one-wave-per-row kernel above moves
 // 8 bytes per lane per load and has too few bytes in flight: 39 MB in 12.4 us = 3.2 TB/s at width 768).
-template <int NB>   // d / 256
-__global__ __launch_bounds__(256) void layernorm_h2b_kernel(const uint16_t* __restrict__ x, const int32_t* __restrict__ row_index,
-                                                            const float* __restrict__ w, const float* __restrict__ b,
-                                                            uint16_t* __restrict__ out, int M, const int32_t* __restrict__ m_dev) {
+template <int NB>   // d / 256; `block`: this workgroup's index among the blocks of its row set
+__device__ __forceinline__ void layernorm_h2b_rows(const uint16_t* __restrict__ x, const int32_t* __restrict__ row_index,
+                                                   const float* __restrict__ w, const float* __restrict__ b,
+                                                   uint16_t* __restrict__ out, int M, const int32_t* __restrict__ m_dev, int block) {
   constexpr int d = NB * 256;
   if (m_dev) { const int md = *m_dev; M = md < M ? md : M; }      // packed text: the real row count lives on the device
   constexpr int RPH = NB <= 2 ? 2 : 1;     // rows per half-wave: narrow rows (512 elements = two loads per lane) have too few bytes in
                                            // flight one at a time (10 499 x 512: 7.7 us = 2.8 TB/s); both rows' loads are issued first
   const int hl = threadIdx.x & 31;
   typedef __attribute__((ext_vector_type(4))) uint32_t u4;
-  const int row0 = (blockIdx.x * 8 + (threadIdx.x >> 5)) * RPH;
+  const int row0 = (block * 8 + (threadIdx.x >> 5)) * RPH;
   if (row0 >= M) return;
   float v[RPH][NB][8];
 #pragma unroll
@@ -154,6 +154,42 @@ __global__ __launch_bounds__(256) void layernorm_h2b_kernel(const uint16_t* __re
       *reinterpret_cast<u4*>(orow + e0) = pk;
     }
   }
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void layernorm_h2b_kernel(const uint16_t* __restrict__ x, const int32_t* __restrict__ row_index,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            uint16_t* __restrict__ out, int M, const int32_t* __restrict__ m_dev) {
+  layernorm_h2b_rows<NB>(x, row_index, w, b, out, M, m_dev, blockIdx.x);
+}
+
+// The same LayerNorm of BOTH towers' rows in one launch (round 4, the lock-step pair path of encoders.hip): blocks [0, blocks0) take
+// the first row set (width 256 * NB0), the rest the second (256 * NB1).  Every row sees layernorm_h2b_rows' arithmetic: identical bits.
+struct LnRows { const uint16_t* x; const float* w; const float* b; uint16_t* out; int M; const int32_t* m_dev; };
+template <int NB0, int NB1>
+__global__ __launch_bounds__(256) void layernorm_h2b_pair_kernel(LnRows r0, LnRows r1, int blocks0) {
+  if (static_cast<int>(blockIdx.x) < blocks0) layernorm_h2b_rows<NB0>(r0.x, nullptr, r0.w, r0.b, r0.out, r0.M, r0.m_dev, blockIdx.x);
+  else layernorm_h2b_rows<NB1>(r1.x, nullptr, r1.w, r1.b, r1.out, r1.M, r1.m_dev, blockIdx.x - blocks0);
+}
+
+// fp16 stream -> bf16 rows of two row sets; false when the pair is not one this file has a kernel for (the caller launches twice)
+bool launch_layernorm_h2b_pair(const void* x0, const float* w0, const float* b0, void* out0, int M0, int d0, const int32_t* md0,
+                               const void* x1, const float* w1, const float* b1, void* out1, int M1, int d1, const int32_t* md1,
+                               hipStream_t st) {
+  static const bool off = []() { const char* e = getenv("CMH_PAIR_KERNELS"); return e && e[0] == '0'; }();
+  if (off || M0 <= 0 || M1 <= 0) return false;
+  const LnRows r0{static_cast<const uint16_t*>(x0), w0, b0, static_cast<uint16_t*>(out0), M0, md0};
+  const LnRows r1{static_cast<const uint16_t*>(x1), w1, b1, static_cast<uint16_t*>(out1), M1, md1};
+  auto blocks = [](int M, int d) { return d <= 512 ? (M + 15) / 16 : (M + 7) / 8; };     // two rows per half-wave for d <= 512
+  const int bl0 = blocks(M0, d0), bl1 = blocks(M1, d1);
+  const dim3 grid(bl0 + bl1), block(256);
+  if (d0 == 768 && d1 == 512) hipLaunchKernelGGL((layernorm_h2b_pair_kernel<3, 2>), grid, block, 0, st, r0, r1, bl0);
+  else if (d0 == 768 && d1 == 768) hipLaunchKernelGGL((layernorm_h2b_pair_kernel<3, 3>), grid, block, 0, st, r0, r1, bl0);
+  else if (d0 == 1024 && d1 == 768) hipLaunchKernelGGL((layernorm_h2b_pair_kernel<4, 3>), grid, block, 0, st, r0, r1, bl0);
+  else if (d0 == 1024 && d1 == 512) hipLaunchKernelGGL((layernorm_h2b_pair_kernel<4, 2>), grid, block, 0, st, r0, r1, bl0);
+  else if (d0 == 512 && d1 == 512) hipLaunchKernelGGL((layernorm_h2b_pair_kernel<2, 2>), grid, block, 0, st, r0, r1, bl0);
+  else return false;
+  return hipGetLastError() == hipSuccess;
 }
 
 int launch_layernorm_x(const void* x, int x_f16, const int32_t* row_index, const float* w, const float* b, void* out,

@@ -386,6 +386,10 @@ class CLIP(nn.Module):
     # -- the two hot-path entry points -----------------------------------------------------------
     def encode_image(self, image, taps=None):
         """image f32 [B,3,R,R] -> [B, embed_dim] f32  (reference model/base/model.py:356-357,228-252)."""
+        if taps is None:
+            hit = self._stashed("image", image)
+            if hit is not None:
+                return hit
         image = N.f32c(image)
         N.require_gpu(image, self.visual.proj)
         if self._gemm_dtype == N.FP8 and not self._fp8_scales_current("vit"):
@@ -413,6 +417,10 @@ class CLIP(nn.Module):
 
     def encode_text(self, text, key_padding_mask=None, taps=None):
         """text i64 [B,L] -> [B, embed_dim] f32  (reference model/base/model.py:359-372)."""
+        if taps is None and key_padding_mask is None:
+            hit = self._stashed("text", text)
+            if hit is not None:
+                return hit
         N.require_gpu(text, self.text_projection)
         text = text.to(torch.int64).contiguous()
         if self._gemm_dtype == N.FP8 and not self._fp8_scales_current("text"):
@@ -443,6 +451,26 @@ class CLIP(nn.Module):
                                         None if tp is None else C.byref(tp), N.stream_ptr(text.device)),
                 "cmh_text_encode")
         return no_backward(feat, self.text_projection)
+
+    def prefetch_pair(self, image, text):
+        """Inference helper for code that calls encode_image(image) and encode_text(text) back to back (every method model's
+        encode_* does, model/modelbase.py:88-92): run both towers NOW in lock-step (encode_pair) and hand the two features out to
+        the next encode_image / encode_text call on these very tensors.  Bit-identical to the separate calls; a no-op when a
+        gradient is wanted."""
+        if torch.is_grad_enabled() and not self.assume_frozen:
+            return
+        fi, ft = self.encode_pair(image, text)
+        self._pair_stash = {"image": (image, fi), "text": (text, ft)}
+
+    def _stashed(self, side, x):
+        st = getattr(self, "_pair_stash", None)
+        if not st or side not in st:
+            return None
+        src, feat = st[side]
+        if src is not x:
+            return None
+        del st[side]
+        return feat
 
     def encode_pair(self, image, text):
         """(encode_image(image), encode_text(text)) with the two towers in lock-step: layer i of both shares its GEMM launches

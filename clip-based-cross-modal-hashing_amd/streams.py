@@ -54,3 +54,40 @@ def overlapped(*fns, inputs_ready=None):
     if inputs_ready is not None:
         _record(out, cur)
     return tuple(out)
+
+
+class AlternatingStreams:
+    """A loop over INDEPENDENT batches (database encoding: train/base.py:130-148 of the reference walks the loader batch by batch)
+    on two HIP streams in turn.  One batch's chain of launches leaves the GPU idle in places - launch gaps, the single-wave tails of
+    the persistent GEMMs, the bandwidth-bound LayerNorm / attention launches between them; the next batch's chain on the other
+    stream fills them.  With the lock-step pair path (CLIP.encode_pair: layer i of both towers shares its launches) as the chain,
+    this is the fastest form of the encode loop measured (bench.py --towers pair2: -3 % against one stream per tower).
+
+    run(fn, inputs, ready): fn() executes on the next stream once `ready` (an event on the caller's stream: the batch's inputs are
+    there) has passed; `inputs` are registered with the allocator for that stream.  Whatever fn writes (code buffers) belongs to
+    the side streams until join(), which makes the caller's stream wait for both."""
+
+    def __init__(self, device=None):
+        self.device = torch.cuda.current_device() if device is None else device
+        self.enabled = torch.cuda.is_available() and os.environ.get("CMH_OVERLAP", "1") != "0"
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(2)] if self.enabled else []
+        self.turn = 0
+
+    def run(self, fn, inputs=(), ready=None):
+        if not self.enabled:
+            return fn()
+        s = self.streams[self.turn & 1]
+        self.turn += 1
+        if ready is not None:
+            s.wait_event(ready)
+        elif self.turn <= 2:                       # first use of each stream: everything the caller queued so far
+            s.wait_stream(torch.cuda.current_stream(self.device))
+        _record(inputs, s)
+        with torch.cuda.stream(s):
+            return fn()
+
+    def join(self):
+        if self.enabled:
+            cur = torch.cuda.current_stream(self.device)
+            for s in self.streams:
+                cur.wait_stream(s)

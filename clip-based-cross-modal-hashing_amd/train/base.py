@@ -18,6 +18,7 @@ from torch.utils.data import DataLoader
 
 import cmh_native as N
 import dist_utils as du
+from streams import AlternatingStreams
 from utils import get_logger, get_summary_writer
 from utils.calc_utils import calc_map_k_matrix as calc_map_k
 
@@ -125,10 +126,15 @@ class TrainBase(object):
 
     # ---- code generation (train/base.py:130-223) ---------------------------------------------------
     def _code_loop(self, data_loader, length, encode):
+        """The reference walks the loader batch by batch and encodes image and text one after the other (train/base.py:130-148).  The
+        batches are independent, so here consecutive batches alternate between two HIP streams (streams.AlternatingStreams) and a
+        batch's two towers run in lock-step (CLIP.prefetch_pair: layer i of both shares its launches): same codes, bit for bit."""
         img_buffer = torch.empty(length, self.args.output_dim, dtype=torch.float).to(self.rank)
         text_buffer = torch.empty(length, self.args.output_dim, dtype=torch.float).to(self.rank)
         encoder_time = 0
         seen = []
+        clip = getattr(self.model, "clip", None)
+        pipe = AlternatingStreams(torch.device("cuda", self.rank) if isinstance(self.rank, int) else self.rank)
         with torch.no_grad():
             for batch in data_loader:
                 start_encoder_time = time.time()
@@ -136,11 +142,22 @@ class TrainBase(object):
                 image = image.to(self.rank, non_blocking=True)
                 text = text.to(self.rank, non_blocking=True)
                 index = index.to(self.rank)
-                image_hash, text_hash = encode(image, text, batch)
+                ready = torch.cuda.Event() if pipe.enabled else None
+                if ready is not None:
+                    ready.record()
+
+                def work(image=image, text=text, index=index, batch=batch):
+                    if clip is not None and hasattr(clip, "prefetch_pair") and image.shape[0] == text.shape[0] and \
+                            os.environ.get("CMH_PAIR", "1") != "0":          # (CMH_PAIR=0: the two encodes one after the other, for A/B)
+                        clip.prefetch_pair(image, text)
+                    image_hash, text_hash = encode(image, text, batch)
+                    img_buffer[index, :] = image_hash
+                    text_buffer[index, :] = text_hash
+
+                pipe.run(work, (image, text, index), ready)
                 encoder_time = time.time() - start_encoder_time
-                img_buffer[index, :] = image_hash
-                text_buffer[index, :] = text_hash
                 seen.append(index)
+        pipe.join()
         self._gather_code_shards(seen, img_buffer, text_buffer)
         return img_buffer, text_buffer, encoder_time
 

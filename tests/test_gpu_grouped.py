@@ -143,3 +143,52 @@ def test_encode_pair_equals_the_two_single_tower_calls(mode, B):
             for r, a, b in zip(ref, got, off):
                 assert torch.isfinite(r).all() and r.abs().sum() > 0
                 assert torch.equal(r, a) and torch.equal(r, b)
+
+
+def test_prefetch_pair_feeds_the_next_two_encodes():
+    """CLIP.prefetch_pair (the trainers' code loop, train/base.py::_code_loop): the lock-step pair path runs once, the following
+    encode_image / encode_text calls ON THE SAME TENSORS hand its features out (bit-identical to the separate calls), other tensors
+    and later calls take the ordinary path."""
+    from model.base.model import CLIP
+    cfg = recipe.CLIP_TINY
+    torch.manual_seed(3)
+    m = CLIP(cfg["embed_dim"], cfg["image_resolution"], cfg["vision_layers"], cfg["vision_width"], cfg["vision_patch_size"],
+             cfg["context_length"], cfg["vocab_size"], cfg["transformer_width"], cfg["transformer_heads"],
+             cfg["transformer_layers"]).to(DEV).float().set_gemm_dtype("f32")
+    img = torch.from_numpy(recipe.images(5, cfg["image_resolution"], 1)).to(DEV)
+    txt = torch.from_numpy(recipe.captions(5, 16, cfg["vocab_size"], 2)).to(DEV)
+    with torch.no_grad():
+        ref = (m.encode_image(img).clone(), m.encode_text(txt).clone())
+        m.prefetch_pair(img, txt)
+        assert set(m._pair_stash) == {"image", "text"}
+        other = m.encode_image(img.clone())                        # another tensor object: the ordinary path, stash untouched
+        assert torch.equal(other, ref[0]) and "image" in m._pair_stash
+        a, b = m.encode_image(img), m.encode_text(txt)
+        assert torch.equal(a, ref[0]) and torch.equal(b, ref[1]) and not m._pair_stash
+        assert torch.equal(m.encode_image(img), ref[0])            # consumed: the ordinary path again
+
+
+def test_alternating_streams_code_loop_equals_the_plain_loop(tmp_path, monkeypatch):
+    """train/base.py::_code_loop on two alternating streams with the lock-step pair path == the same loop with CMH_OVERLAP=0
+    and CMH_PAIR=0 (one stream, separate encodes): identical code buffers."""
+    import argparse
+    import os
+    import sys
+    import dataset.synthetic as ds
+    import main
+    ck = os.path.join(tmp_path, "clip.pt")
+    torch.save({k: torch.from_numpy(v) for k, v in recipe.clip_state_dict(dict(recipe.CLIP_TINY, embed_dim=512), 7).items()}, ck)
+    monkeypatch.setattr(ds, "SOT", 510)
+    monkeypatch.setattr(ds, "EOT", 511)
+    monkeypatch.setattr(sys, "argv", ["main.py", "-clip-path", ck, "--save-dir", os.path.join(tmp_path, "run"), "--batch-size", "8",
+                                      "--num-workers", "0", "--resolution", "64", "--max-words", "16", "--query-num", "20",
+                                      "--train-num", "30", "--synthetic-size", "70", "--gemm-dtype", "f32", "--epochs", "0"])
+    torch.manual_seed(1)
+    tr = main.trainers["DSPH"](argparse.Namespace(method="DSPH", dataset="synthetic", output_dim=16, is_train=True), 0)
+    tr.change_state(mode="valid")
+    piped = [t.clone() for t in tr.get_code(tr.retrieval_loader, tr.args.retrieval_num)[:2]]
+    monkeypatch.setenv("CMH_OVERLAP", "0")
+    monkeypatch.setenv("CMH_PAIR", "0")
+    plain = [t.clone() for t in tr.get_code(tr.retrieval_loader, tr.args.retrieval_num)[:2]]
+    assert torch.equal(piped[0], plain[0]) and torch.equal(piped[1], plain[1])
+    assert set(piped[0].unique().tolist()) <= {-1.0, 0.0, 1.0}

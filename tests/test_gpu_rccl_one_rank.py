@@ -75,7 +75,7 @@ def test_bench_multi_gpu_branch_on_rccl(tmp_path):
     data-parallel training step through gather_loss_inputs + GradSync) on RCCL in a group of one: the line the driver will ask for
     on 8 GPUs comes out whole."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--train-step", "--no-cpu-baseline",
-           "--no-dense-text", "--no-input-pipeline", "--no-config-legs", "--no-precision-legs"]
+           "--no-dense-text", "--no-input-pipeline", "--no-config-legs", "--no-precision-legs", "--no-towers-ab"]
     res = subprocess.run(cmd, env=_env(CMH_FORCE_DIST="1", CMH_DIST_BACKEND="nccl"), capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-3000:]
     line = json.loads(res.stdout.strip().splitlines()[-1])

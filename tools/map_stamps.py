@@ -1,11 +1,12 @@
 import os, sys
 os.environ["CMH_MAP_STAMPS"] = "1"
-os.environ.setdefault("CMH_MAP_MODE", "lds1")      # the stamps live in the workspace, which only the all-LDS placements leave free
+# usage: python tools/map_stamps.py [N] [bits] [classes]   (CMH_MAP_MODE=lds1|hybrid|global forces a placement where the size allows it)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "clip-based-cross-modal-hashing_amd"))
 import torch, cmh_native as N
 dev = torch.device("cuda:0")
-Q, Nn, K, C = 5000, int(sys.argv[1]) if len(sys.argv) > 1 else 15015, 64, 24
+Q, Nn = 5000, int(sys.argv[1]) if len(sys.argv) > 1 else 15015
+K, C = int(sys.argv[2]) if len(sys.argv) > 2 else 64, int(sys.argv[3]) if len(sys.argv) > 3 else 24
 g = torch.Generator().manual_seed(1234)
 rL = (torch.rand(Nn, C, generator=g) < 0.15).float(); qL = (torch.rand(Q, C, generator=g) < 0.15).float()
 W = torch.randn(C, K, generator=g)
@@ -16,10 +17,14 @@ for _ in range(2):
     N.hamming_map(qp, ql, rp, rl, K, C)
 torch.cuda.synchronize()
 ws = N.workspace(0, dev, "map")
-ws[:3072].zero_()              # the stamp area: levels the run never reaches must read as zero, not as whatever the buffer held
+need = N.lib().cmh_map_workspace_bytes(Q, Nn, K, 0)
+off = 0 if need <= 4096 + 32768 else (need - 32768 - 256)          # all-LDS placements: the stamps are the workspace; else behind the slices
+base = (ws.data_ptr() + 255) // 256 * 256 - ws.data_ptr() + off
+area = ws[base:base + 3072 * 8]
+area.zero_()                   # the stamp area: levels the run never reaches must read as zero, not as whatever the buffer held
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); N.hamming_map(qp, ql, rp, rl, K, C); e1.record(); torch.cuda.synchronize()
-full = ws[:3072].view(torch.int64).cpu().numpy()
+full = area.view(torch.int64).cpu().numpy()
 st = full[:6]
 d = [int(st[i + 1] - st[i]) for i in range(5)]
 print("one direction: %.3f ms; query 0 of workgroup 0, cycles per phase (100 MHz ticks?):" % e0.elapsed_time(e1))

@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmct; mkdir -p $O
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $O/$c -- python3 $R/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-map-eval --no-train-step --no-dense-text --no-input-pipeline --no-precision-legs --no-config-legs > $O/$c.log 2>&1 || echo "pass $c failed"
+  rocprofv3 --pmc $c --output-format csv -d $O/$c -- python3 $R/bench.py --steps 3 --warmup 1 --repeats 1 --towers pair --no-towers-ab --no-cpu-baseline --no-map-eval --no-train-step --no-dense-text --no-input-pipeline --no-precision-legs --no-config-legs > $O/$c.log 2>&1 || echo "pass $c failed"
 done
 python3 - <<'PY'
 import csv, glob, json, os
@@ -23,7 +23,7 @@ out = {"kernel": "cmh::gemm_wide_kernel", "launches": n, "FETCH_SIZE_KiB_per_lau
        "WRITE_SIZE_KiB_per_launch": round(write_kib, 1),
        "traffic_bytes_per_launch": round((2 * fetch_kib + write_kib) * 1024),
        "correction": "(2*FETCH_SIZE + WRITE_SIZE) * 1024: counters in KiB, gfx950 FETCH_SIZE counts wide reads at 1/2",
-       "command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> -- python3 bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-map-eval --no-train-step --no-dense-text --no-input-pipeline --no-precision-legs --no-config-legs"}
+       "command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> -- python3 bench.py --steps 3 --warmup 1 --repeats 1 --towers pair --no-towers-ab --no-cpu-baseline --no-map-eval --no-train-step --no-dense-text --no-input-pipeline --no-precision-legs --no-config-legs"}
 json.dump(out, open(f"{R}/gpurun_out/gemm_traffic.json", "w"), indent=1)
 print(json.dumps(out))
 PY

@@ -5,7 +5,7 @@ TAG=${1:-rXX}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; mkdir -p $O
 cd $R && python3 bench.py > $O/bench_line.json 2> $O/bench_line.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -- python3 $R/bench.py --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-overlap-towers --no-train-step --no-dense-text --no-input-pipeline --no-precision-legs --no-config-legs > $O/bench_serialized_under_rocprof.json 2> $O/bench_prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -- python3 $R/bench.py --steps 10 --warmup 3 --repeats 1 --towers pair --no-towers-ab --no-cpu-baseline --no-train-step --no-dense-text --no-input-pipeline --no-precision-legs --no-config-legs > $O/bench_serialized_under_rocprof.json 2> $O/bench_prof.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prep -- python3 $R/tools/prep_bench.py --cpu-sample 8 > $O/prep_bench.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -- python3 $R/tools/train_bench.py > $O/train_bench_under_rocprof.txt 2>&1
 cd $R && python3 tools/train_bench.py > $O/train_bench.txt 2>&1
