@@ -242,7 +242,8 @@ def main():
         N.pack_codes(N.sign_codes(h), validate=False)
         return h
 
-    pair_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    n_pair_streams = max(1, int(os.environ.get("CMH_PAIR_STREAMS", "2")))      # (diagnostic: more alternating streams)
+    pair_streams = [torch.cuda.Stream(device=dev) for _ in range(n_pair_streams)]
     pair_turn = [0]
 
     def step(overlap=None, how=None):
@@ -251,7 +252,7 @@ def main():
             if how == "pair2":
                 # the lock-step pair path, consecutive (independent) batches alternating between two streams: the grouped GEMMs of one
                 # batch run beside the LayerNorm / attention launches and the launch gaps of the other
-                s2 = pair_streams[pair_turn[0] & 1]
+                s2 = pair_streams[pair_turn[0] % n_pair_streams]
                 pair_turn[0] += 1
                 cur = torch.cuda.current_stream(dev)
                 with torch.cuda.stream(s2):
