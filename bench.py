@@ -244,6 +244,9 @@ def main():
 
     n_pair_streams = max(1, int(os.environ.get("CMH_PAIR_STREAMS", "2")))      # (diagnostic: more alternating streams)
     pair_streams = [torch.cuda.Stream(device=dev) for _ in range(n_pair_streams)]
+    import streams as _streams_mod
+    _streams_mod._streams[torch.cuda.current_device()] = list(pair_streams)    # every mode of this process uses the SAME side streams: a
+    # second set would share hardware queues with the first (the streams leg of towers_ab read 15 % slow that way)
     pair_turn = [0]
 
     def step(overlap=None, how=None):

@@ -405,40 +405,6 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const bf16_t* __rest
   attention_mfma_body<NKT>(qkv, o, Tmax, d, causal, kpm, seq_off, o8_inv_scale, blockIdx.x, sV);
 }
 
-// The attention of BOTH towers in one launch (round 4, the lock-step pair path): waves [0, blocks0) are the first tower's (batch,
-// head) pairs, the rest the second's; each side runs the body compiled for its own number of key tiles - identical bits.
-struct AttnSide { const bf16_t* qkv; bf16_t* o; int Tmax, d, causal; const int32_t* seq_off; float o8_inv_scale; };
-template <int NKT0, int NKT1>
-__global__ __launch_bounds__(64) void attention_mfma_pair_kernel(AttnSide s0, AttnSide s1, int blocks0) {
-  __shared__ __attribute__((aligned(16))) bf16_t sV[(NKT0 > NKT1 ? NKT0 : NKT1) * 16 * kAttnVST];
-  if (static_cast<int>(blockIdx.x) < blocks0)
-    attention_mfma_body<NKT0>(s0.qkv, s0.o, s0.Tmax, s0.d, s0.causal, nullptr, s0.seq_off, s0.o8_inv_scale, blockIdx.x, sV);
-  else
-    attention_mfma_body<NKT1>(s1.qkv, s1.o, s1.Tmax, s1.d, s1.causal, nullptr, s1.seq_off, s1.o8_inv_scale, blockIdx.x - blocks0, sV);
-}
-
-// bf16 qkv of two towers (no key-padding masks); false = no kernel for this pair of lengths (the caller launches twice)
-bool launch_attention_pair(const void* qkv0, void* o0, int B0, int T0, int d0, int causal0, const int32_t* seq0, float o8s0,
-                           const void* qkv1, void* o1, int B1, int T1, int d1, int causal1, const int32_t* seq1, float o8s1,
-                           hipStream_t st) {
-  static const bool off = []() { const char* e = getenv("CMH_PAIR_KERNELS"); return e && e[0] == '0'; }();
-  if (off || d0 % HD != 0 || d1 % HD != 0 || T0 <= 0 || T1 <= 0 || T0 > 128 || T1 > 128) return false;
-  const AttnSide s0{static_cast<const bf16_t*>(qkv0), static_cast<bf16_t*>(o0), T0, d0, causal0, seq0, o8s0};
-  const AttnSide s1{static_cast<const bf16_t*>(qkv1), static_cast<bf16_t*>(o1), T1, d1, causal1, seq1, o8s1};
-  const int bl0 = B0 * (d0 / HD), bl1 = B1 * (d1 / HD);
-  auto nkt = [](int T) { return T <= 32 ? 2 : (T <= 64 ? 4 : (T <= 96 ? 6 : 8)); };
-  const int k0 = nkt(T0), k1 = nkt(T1);
-  const dim3 grid(bl0 + bl1), block(64);
-#define ATT_PAIR(A, Bk) hipLaunchKernelGGL((attention_mfma_pair_kernel<A, Bk>), grid, block, 0, st, s0, s1, bl0)
-  if (k0 == 4 && k1 == 6) ATT_PAIR(4, 6);          // ViT-B/32 (50 tokens) + 77-token captions
-  else if (k0 == 4 && k1 == 2) ATT_PAIR(4, 2);     // + 32-token captions (configs[4])
-  else if (k0 == 4 && k1 == 4) ATT_PAIR(4, 4);
-  else if (k0 == 2 && k1 == 2) ATT_PAIR(2, 2);     // test-sized towers
-  else return false;
-#undef ATT_PAIR
-  return hipGetLastError() == hipSuccess;
-}
-
 template <int NKT>
 static void launch_attention_mfma(const void* qkv, void* o, int B, int T, int d, int causal, const uint8_t* kpm,
                                   const int32_t* seq_off, hipStream_t st, float o8_inv_scale) {

@@ -219,10 +219,6 @@ int launch_attention(const void* qkv, void* o, int dt, int B, int T, int d, int 
 int launch_attention_varlen(const void* qkv, void* o, int dt, int B, int T, int d, int causal,
                             const uint8_t* key_padding_mask, const int32_t* seq_off, hipStream_t st,
                             float o8_inv_scale = 0.f);   // > 0 (bf16 qkv, T <= 128): o is e4m3 of o * o8_inv_scale (fp8 mode)
-// the bf16 MFMA attention of two towers (T <= 128, no key-padding mask) in ONE launch; false = no kernel for this pair (launch singly)
-bool launch_attention_pair(const void* qkv0, void* o0, int B0, int T0, int d0, int causal0, const int32_t* seq0, float o8s0,
-                           const void* qkv1, void* o1, int B1, int T1, int d1, int causal1, const int32_t* seq1, float o8s1,
-                           hipStream_t st);
 // fp8.hip: LayerNorm of the fp16 residual stream straight to e4m3 (y * inv_scale); max |x| into a device scalar (running maximum)
 int launch_layernorm_q(const void* x_f16, const float* w, const float* b, void* out_fp8, float inv_scale, int M, int d, hipStream_t st,
                        const int32_t* m_dev = nullptr);

@@ -228,11 +228,11 @@ static int run_block_pair(const cmh_block_weights& wa, const cmh_block_weights& 
     if ((rc = launch_gemm_grouped(CMH_FP8, problem_of(a, a.t.h, wa.in_proj_w, wa.in_proj_b, nullptr, a.t.qkv, 3 * a.d, a.d, wa.in_proj_cs, sa[0]),
                                   problem_of(b, b.t.h, wb.in_proj_w, wb.in_proj_b, nullptr, b.t.qkv, 3 * b.d, b.d, wb.in_proj_cs, sb[0]),
                                   EPI_BIAS | EPI_OUT_BF16, st))) return rc;
-    if (!launch_attention_pair(a.t.qkv, a.t.h, a.B, a.T, a.d, a.causal, a.seq_off, 1.0f / sa[1],
-                               b.t.qkv, b.t.h, b.B, b.T, b.d, b.causal, b.seq_off, 1.0f / sb[1], st)) {
-      if ((rc = launch_attention_varlen(a.t.qkv, a.t.h, CMH_BF16, a.B, a.T, a.d, a.causal, nullptr, a.seq_off, st, 1.0f / sa[1]))) return rc;
-      if ((rc = launch_attention_varlen(b.t.qkv, b.t.h, CMH_BF16, b.B, b.T, b.d, b.causal, nullptr, b.seq_off, st, 1.0f / sb[1]))) return rc;
-    }
+    // (the two attentions stay two launches: one launch for both - each side's body compiled for its own key-tile count - runs every
+    // wave at the wider side's register budget, 2 waves per SIMD instead of 3 for the image side: 36.3 us against 16.6 + 16.1,
+    // profiles/r04_j_bench_kernel_stats.csv; removed again)
+    if ((rc = launch_attention_varlen(a.t.qkv, a.t.h, CMH_BF16, a.B, a.T, a.d, a.causal, nullptr, a.seq_off, st, 1.0f / sa[1]))) return rc;
+    if ((rc = launch_attention_varlen(b.t.qkv, b.t.h, CMH_BF16, b.B, b.T, b.d, b.causal, nullptr, b.seq_off, st, 1.0f / sb[1]))) return rc;
     if (upto_attention) return CMH_OK;
     if ((rc = launch_gemm_grouped(CMH_FP8, problem_of(a, a.t.h, wa.out_proj_w, wa.out_proj_b, a.t.x, a.t.x, a.d, a.d, wa.out_proj_cs, sa[1]),
                                   problem_of(b, b.t.h, wb.out_proj_w, wb.out_proj_b, b.t.x, b.t.x, b.d, b.d, wb.out_proj_cs, sb[1]), rx, st))) return rc;
@@ -254,11 +254,8 @@ static int run_block_pair(const cmh_block_weights& wa, const cmh_block_weights& 
   }
   if ((rc = launch_gemm_grouped(dt, problem_of(a, a.t.h, wa.in_proj_w, wa.in_proj_b, nullptr, a.t.qkv, 3 * a.d, a.d),
                                 problem_of(b, b.t.h, wb.in_proj_w, wb.in_proj_b, nullptr, b.t.qkv, 3 * b.d, b.d), EPI_BIAS | obf, st))) return rc;
-  if (!(dt == CMH_BF16 && launch_attention_pair(a.t.qkv, a.t.h, a.B, a.T, a.d, a.causal, a.seq_off, 0.f,
-                                                b.t.qkv, b.t.h, b.B, b.T, b.d, b.causal, b.seq_off, 0.f, st))) {
-    if ((rc = launch_attention_varlen(a.t.qkv, a.t.h, dt, a.B, a.T, a.d, a.causal, nullptr, a.seq_off, st))) return rc;
-    if ((rc = launch_attention_varlen(b.t.qkv, b.t.h, dt, b.B, b.T, b.d, b.causal, nullptr, b.seq_off, st))) return rc;
-  }
+  if ((rc = launch_attention_varlen(a.t.qkv, a.t.h, dt, a.B, a.T, a.d, a.causal, nullptr, a.seq_off, st))) return rc;
+  if ((rc = launch_attention_varlen(b.t.qkv, b.t.h, dt, b.B, b.T, b.d, b.causal, nullptr, b.seq_off, st))) return rc;
   if (upto_attention) return CMH_OK;
   if ((rc = launch_gemm_grouped(dt, problem_of(a, a.t.h, wa.out_proj_w, wa.out_proj_b, a.t.x, a.t.x, a.d, a.d),
                                 problem_of(b, b.t.h, wb.out_proj_w, wb.out_proj_b, b.t.x, b.t.x, b.d, b.d), rx, st))) return rc;

@@ -34,6 +34,7 @@ struct GemmProf {
   // - the hook itself never waits for the stream, so a profiled region keeps the launch queue of an unprofiled one
   struct Pending { size_t launch; int slot; int Mub; double flops_per_row; };
   std::vector<Pending> pending;
+  std::map<const int32_t*, int> slot_of;  // one copy per device word and session: every launch that names the word shares its slot
   int32_t* rows_pinned = nullptr;
   size_t rows_cap = 0, rows_used = 0;
   size_t used = 0;
@@ -55,11 +56,21 @@ int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, co
 // the measurement hook counts algorithmic FLOPs on REAL rows: FLOPs of `flops_per_row` x the rows of launch `launch` (the entry
 // g_prof.flops[launch] is created by the caller with the upper bound's FLOPs and corrected by _end() once the count has arrived)
 static void prof_rows_later(size_t launch, int Mub, const int32_t* m_dev, double flops_per_row, hipStream_t st) {
-  if (!m_dev || !g_prof.rows_pinned || g_prof.rows_used >= g_prof.rows_cap) return;
-  const int slot = static_cast<int>(g_prof.rows_used);
-  g_prof.rows_pinned[slot] = -1;
-  if (hipMemcpyAsync(g_prof.rows_pinned + slot, m_dev, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return;
-  ++g_prof.rows_used;
+  if (!m_dev || !g_prof.rows_pinned) return;
+  // (a copy per LAUNCH would put ~46 four-byte copies of 4-5 us each into every profiled step of the single-stream pair mode; the
+  // word is read once per profiling session - a session measures repetitions of one batch - by the first launch that names it)
+  auto it = g_prof.slot_of.find(m_dev);
+  int slot;
+  if (it != g_prof.slot_of.end()) {
+    slot = it->second;
+  } else {
+    if (g_prof.rows_used >= g_prof.rows_cap) return;
+    slot = static_cast<int>(g_prof.rows_used);
+    g_prof.rows_pinned[slot] = -1;
+    if (hipMemcpyAsync(g_prof.rows_pinned + slot, m_dev, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return;
+    ++g_prof.rows_used;
+    g_prof.slot_of[m_dev] = slot;
+  }
   g_prof.pending.push_back({launch, slot, Mub, flops_per_row});
 }
 
@@ -231,6 +242,7 @@ extern "C" int cmh_prof_gemm_begin(int32_t max_launches) {
   }
   g_prof.rows_used = 0;
   g_prof.pending.clear();
+  g_prof.slot_of.clear();
   g_prof.used = 0;
   g_prof.flops.clear();
   g_prof.dims.clear();

@@ -51,8 +51,8 @@ def overlapped(*fns, inputs_ready=None):
             out.append(f())
     for s in pool[:len(fns)]:
         cur.wait_stream(s)
-    if inputs_ready is not None:
-        _record(out, cur)
+    _record(out, cur)      # the results were allocated on the side streams and are read on the caller's: tell the allocator (the caller
+                           # may itself be one of several alternating streams, whose next overlapped() call does not wait for this one)
     return tuple(out)
 
 

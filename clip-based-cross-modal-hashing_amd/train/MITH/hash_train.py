@@ -144,16 +144,21 @@ class MITHTrainer(TrainBase):
         img_buffer = torch.empty(length, self.args.output_dim, dtype=torch.float).to(self.rank)
         text_buffer = torch.empty(length, self.args.output_dim, dtype=torch.float).to(self.rank)
         seen = []
-        with torch.no_grad():
-            for image, text, key_padding_mask, label, index in data_loader:
-                image = image.to(self.rank, non_blocking=True)
-                text = text.to(self.rank, non_blocking=True)
-                key_padding_mask = key_padding_mask.to(self.rank, non_blocking=True)
-                od = self.model(image, text, key_padding_mask)
-                index = index.to(self.rank)
-                img_buffer[index, :] = N.sign_codes(od['img_tokens_hash'] + od['img_cls_hash'])
-                text_buffer[index, :] = N.sign_codes(od['txt_tokens_hash'] + od['txt_cls_hash'])
-                seen.append(index)
+
+        def to_device(batch):
+            image, text, key_padding_mask, label, index = batch
+            out = (image.to(self.rank, non_blocking=True), text.to(self.rank, non_blocking=True),
+                   key_padding_mask.to(self.rank, non_blocking=True), index.to(self.rank))
+            seen.append(out[3])
+            return out
+
+        def work(image, text, key_padding_mask, index):
+            od = self.model(image, text, key_padding_mask)
+            img_buffer[index, :] = N.sign_codes(od['img_tokens_hash'] + od['img_cls_hash'])
+            text_buffer[index, :] = N.sign_codes(od['txt_tokens_hash'] + od['txt_cls_hash'])
+
+        # consecutive batches on two alternating streams (train/base.py); the token-returning trunk has no lock-step pair form
+        self._pipelined_batches(data_loader, to_device, work, pair=False)
         self._gather_code_shards(seen, img_buffer, text_buffer)
         return img_buffer, text_buffer, 0
 

@@ -133,20 +133,24 @@ class TwDHTrainer(TrainBase):
         s_img = {str(d): mk(d) for d in short_dims}
         s_txt = {str(d): mk(d) for d in short_dims}
         seen = []
-        with torch.no_grad():
-            for image, text, label, index in data_loader:
-                image = image.to(self.rank, non_blocking=True)
-                text = text.to(self.rank, non_blocking=True)
-                index = index.to(self.rank)
-                seen.append(index)
-                li, si = self.model.encode_image(image)
-                lt, st = self.model.encode_text(text)
-                long_img[index, :] = self.make_hash_code(li)
-                long_txt[index, :] = self.make_hash_code(lt)
-                for k, v in si.items():
-                    s_img[k][index, :] = self.make_hash_code(v)
-                for k, v in st.items():
-                    s_txt[k][index, :] = self.make_hash_code(v)
+
+        def to_device(batch):
+            image, text, label, index = batch
+            out = (image.to(self.rank, non_blocking=True), text.to(self.rank, non_blocking=True), index.to(self.rank))
+            seen.append(out[2])
+            return out
+
+        def work(image, text, index):
+            li, si = self.model.encode_image(image)
+            lt, st = self.model.encode_text(text)
+            long_img[index, :] = self.make_hash_code(li)
+            long_txt[index, :] = self.make_hash_code(lt)
+            for k, v in si.items():
+                s_img[k][index, :] = self.make_hash_code(v)
+            for k, v in st.items():
+                s_txt[k][index, :] = self.make_hash_code(v)
+
+        self._pipelined_batches(data_loader, to_device, work)      # two alternating streams, the towers in lock-step (train/base.py)
         self._gather_code_shards(seen, long_img, long_txt, *s_img.values(), *s_txt.values())
         return long_img, long_txt, s_img, s_txt
 

@@ -125,39 +125,52 @@ class TrainBase(object):
             self.model.eval()
 
     # ---- code generation (train/base.py:130-223) ---------------------------------------------------
-    def _code_loop(self, data_loader, length, encode):
-        """The reference walks the loader batch by batch and encodes image and text one after the other (train/base.py:130-148).  The
-        batches are independent, so here consecutive batches alternate between two HIP streams (streams.AlternatingStreams) and a
-        batch's two towers run in lock-step (CLIP.prefetch_pair: layer i of both shares its launches): same codes, bit for bit."""
-        img_buffer = torch.empty(length, self.args.output_dim, dtype=torch.float).to(self.rank)
-        text_buffer = torch.empty(length, self.args.output_dim, dtype=torch.float).to(self.rank)
-        encoder_time = 0
-        seen = []
+    def _pipelined_batches(self, data_loader, to_device, work, pair=True):
+        """The evaluation loops walk a loader batch by batch (reference train/base.py:130-148, train/TwDH/hash_train.py:165-204,
+        train/MITH/hash_train.py get_code): the batches are independent, so consecutive ones alternate between two HIP streams
+        (streams.AlternatingStreams) - one batch's launch gaps and bandwidth-bound kernels run beside the other's GEMMs - and, with
+        `pair`, a batch's two towers run in lock-step (CLIP.prefetch_pair: layer i of both shares its launches, the method model's
+        encode_image / encode_text calls then pick the features up).  Same values, bit for bit, as the plain loop
+        (CMH_OVERLAP=0 CMH_PAIR=0).  to_device(batch) -> tuple of device tensors (image, text, ...) moved on the CALLER's stream;
+        work(*tensors) runs on a side stream and writes its results into buffers the caller reads after the loop."""
         clip = getattr(self.model, "clip", None)
+        use_pair = pair and clip is not None and hasattr(clip, "prefetch_pair") and os.environ.get("CMH_PAIR", "1") != "0"
         pipe = AlternatingStreams(torch.device("cuda", self.rank) if isinstance(self.rank, int) else self.rank)
         with torch.no_grad():
             for batch in data_loader:
-                start_encoder_time = time.time()
-                image, text, index = batch[0], batch[1], batch[-1]
-                image = image.to(self.rank, non_blocking=True)
-                text = text.to(self.rank, non_blocking=True)
-                index = index.to(self.rank)
-                ready = torch.cuda.Event() if pipe.enabled else None
-                if ready is not None:
+                tensors = tuple(to_device(batch))
+                ready = None
+                if pipe.enabled:
+                    ready = torch.cuda.Event()
                     ready.record()
 
-                def work(image=image, text=text, index=index, batch=batch):
-                    if clip is not None and hasattr(clip, "prefetch_pair") and image.shape[0] == text.shape[0] and \
-                            os.environ.get("CMH_PAIR", "1") != "0":          # (CMH_PAIR=0: the two encodes one after the other, for A/B)
-                        clip.prefetch_pair(image, text)
-                    image_hash, text_hash = encode(image, text, batch)
-                    img_buffer[index, :] = image_hash
-                    text_buffer[index, :] = text_hash
+                def run(tensors=tensors):
+                    if use_pair and tensors[0].shape[0] == tensors[1].shape[0]:
+                        clip.prefetch_pair(tensors[0], tensors[1])
+                    work(*tensors)
 
-                pipe.run(work, (image, text, index), ready)
-                encoder_time = time.time() - start_encoder_time
-                seen.append(index)
+                pipe.run(run, tensors, ready)
         pipe.join()
+
+    def _code_loop(self, data_loader, length, encode):
+        img_buffer = torch.empty(length, self.args.output_dim, dtype=torch.float).to(self.rank)
+        text_buffer = torch.empty(length, self.args.output_dim, dtype=torch.float).to(self.rank)
+        seen = []
+
+        def to_device(batch):
+            image, text, index = batch[0], batch[1], batch[-1]
+            out = (image.to(self.rank, non_blocking=True), text.to(self.rank, non_blocking=True), index.to(self.rank))
+            seen.append(out[2])
+            return out
+
+        def work(image, text, index):
+            image_hash, text_hash = encode(image, text, None)
+            img_buffer[index, :] = image_hash
+            text_buffer[index, :] = text_hash
+
+        start_encoder_time = time.time()
+        self._pipelined_batches(data_loader, to_device, work)
+        encoder_time = time.time() - start_encoder_time
         self._gather_code_shards(seen, img_buffer, text_buffer)
         return img_buffer, text_buffer, encoder_time
 
