@@ -333,6 +333,150 @@ __device__ inline int partition_wave(const QueryStore& S, int f, int l, int lane
   return static_cast<int>(c1 < c2 ? c1 : c2);
 }
 
+// ---- chunked segments, round 4: the two position lists as BIT MASKS -----------------------------------------------------------------
+// Rounds 1-3 partitioned a segment of more than kChunk positions in four passes: count (L / R entries per chunk), write (every entry's
+// POSITION into the two lists, at its global rank), swap (pairs (L_i, R_i)), cut.  Whether position x belongs to L / R is one bit each,
+// and a bit needs no rank to be written: ONE pass stores, per 64 positions, the two ballots (16 bytes instead of up to 2 x 256) and
+// counts per chunk; a wave-parallel prefix over the chunk counts follows; the swap pass walks the masks - L ascending, R descending -
+// from the rank its piece starts at (located through the prefix: chunk, then group, then bit) and expands 64 ranks at a time into a
+// per-wave LDS buffer.  Same pairs, same swaps, same cut: the permutation is unchanged.
+// Used by the WORKSPACE placement only (introsort_phases<MASKS>): there the write pass and its lists are traffic (COCO 5000 x 117 218:
+// 35.3 ms against 39.3, NUS-WIDE 2100 x 190 834 x 128 bit: 28.9 against 31.0, profiles/r04_n_map_*.txt); with the elements in LDS the
+// walk's extra instructions cost more than the lists (MIRFlickr 5000 x 15 015: 4.4 ms against 2.8), so those placements keep the lists.
+// What bounds the workspace placement after this: every level still reads the element array twice (count, swap gathers) and writes it
+// once in partial lines - 64 GB per NUS-WIDE direction at 2.3 TB/s (FETCH_SIZE / WRITE_SIZE, same file); deeper unrolling of either
+// pass changes nothing, and finishing short segments in LDS (tried: copy in, sort, copy out) costs as many cycles per element as the
+// levels it replaces.
+#ifndef CMH_MAP_MASKS
+#define CMH_MAP_MASKS 1
+#endif
+#ifndef CMH_MAP_UNROLL_A
+#define CMH_MAP_UNROLL_A 4        // 64-position groups in flight per wave in the count pass (16: the same time)
+#endif
+#ifndef CMH_MAP_SWAP_BLOCKS
+#define CMH_MAP_SWAP_BLOCKS 1     // 64-rank blocks per iteration of the swap pass.  2: the same time, 4: +11 % (COCO 40.1 ms against 35.9): the
+#endif                            // levels run at the memory system's rate for this mix of gathers and partial-line writes, not at a wave's latency
+// mask area of a chunked segment [f, l): u32 words inside its tmp slice: [Lc, Rc, -, -], then per group g (positions f+1+64g ...) four
+// words: L lo, L hi, R lo, R hi.  4 + 4 * ceil((l-f-1)/64) <= (l-f) - 3 words for every l-f > kChunk.
+__device__ __forceinline__ uint32_t* mask_area(const QueryStore& S, int f) {      // 16-byte aligned ADDRESS (tmp itself may not be)
+  return reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(S.tmp + tmp_base(f)) + 15) & ~static_cast<uintptr_t>(15));
+}
+
+struct MaskCursor {        // one side of a segment's masks, walked by a whole wave (all fields wave-uniform except the window)
+  const uint32_t* mk;      // words of group 0 of this side (L: area + 4, R: area + 6)
+  int ngroups, xbase, gi, gwin;
+  bool desc;               // R: groups and bits from the top
+  uint32_t wlo, whi;       // per lane: the masks of group gwin + lane (gwin - lane when desc)
+  uint64_t m;              // what is left of group gi's mask
+};
+__device__ __forceinline__ void cursor_window(MaskCursor& c, int g0, int lane) {
+  c.gwin = g0;
+  const int g = c.desc ? g0 - lane : g0 + lane;
+  c.wlo = 0u; c.whi = 0u;
+  if (g >= 0 && g < c.ngroups) {
+    const uint32_t* q = c.mk + 4 * g;
+    c.wlo = q[0];
+    c.whi = q[1];
+  }
+}
+__device__ __forceinline__ uint64_t cursor_mask(MaskCursor& c, int g, int lane) {   // g in [0, ngroups)
+  int k = c.desc ? c.gwin - g : g - c.gwin;
+  if (k < 0 || k > 63) { cursor_window(c, g, lane); k = 0; }
+  const uint32_t lo = static_cast<uint32_t>(__shfl(static_cast<int>(c.wlo), k, 64)), hi = static_cast<uint32_t>(__shfl(static_cast<int>(c.whi), k, 64));
+  const uint32_t ulo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(lo)));      // (an int: no sign extension)
+  const uint32_t uhi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(hi)));
+  return static_cast<uint64_t>(ulo) | (static_cast<uint64_t>(uhi) << 32);
+}
+// bits of m above lane's own
+__device__ __forceinline__ int bits_above(uint64_t m, int lane) { return lane == 63 ? 0 : __popcll(m >> (lane + 1)); }
+
+// The entry of walk rank `target` (0-based; it exists): positions the cursor on its group with every earlier entry of that group
+// cleared.  pref[c] = entries in the chunks walked before chunk c (exclusive prefix, ascending for L, from the top for R).
+__device__ inline void cursor_seek(MaskCursor& c, const uint32_t* pref, int nc, int target, int lane) {
+  int cle = 0;
+  for (int c0 = 0; c0 < nc; c0 += 64) {
+    const int ci = c0 + lane;
+    cle += __popcll(__ballot(ci < nc && static_cast<int>(pref[ci]) <= target));
+  }
+  const int ch = c.desc ? nc - cle : cle - 1;
+  const int skip = target - static_cast<int>(pref[ch]);
+  // the chunk's groups in walk order on the first kGpc lanes
+  constexpr int kGpc = kChunk / 64;
+  static_assert(kChunk % 64 == 0 && kGpc <= 64, "a chunk is a whole number (<= 64) of 64-position groups");
+  const int gfirst = c.desc ? (kGpc * ch + kGpc - 1 < c.ngroups - 1 ? kGpc * ch + kGpc - 1 : c.ngroups - 1) : kGpc * ch;
+  const int g = c.desc ? gfirst - lane : gfirst + lane;
+  const bool valid = lane < kGpc && g >= kGpc * ch && g < c.ngroups && g < kGpc * ch + kGpc;
+  uint32_t wlo = 0u, whi = 0u;       // (plain scalars: element accesses of a vector type next to lane reads have miscompiled before)
+  if (valid) {
+    const uint32_t* q = c.mk + 4 * g;
+    wlo = q[0];
+    whi = q[1];
+  }
+  const int pc = __popc(wlo) + __popc(whi);
+  int incl = pc;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
+  }
+  const int gsel = __popcll(__ballot(valid && incl <= skip));           // first group (in walk order) whose inclusive count exceeds skip
+  const int local = skip - (__shfl(incl, gsel, 64) - __shfl(pc, gsel, 64));
+  const uint64_t m = (static_cast<uint64_t>(static_cast<uint32_t>(__shfl(static_cast<int>(whi), gsel, 64))) << 32) |
+                     static_cast<uint32_t>(__shfl(static_cast<int>(wlo), gsel, 64));
+  const bool bit = (m >> lane) & 1ull;
+  const int rank = c.desc ? bits_above(m, lane) : mbcnt64(m);
+  c.gi = c.desc ? gfirst - gsel : gfirst + gsel;
+  c.m = __ballot(bit && rank >= local);
+  cursor_window(c, c.gi, lane);
+}
+// the next (up to) `want` entries of the walk -> buf[0 ..]; returns how many there were
+__device__ inline int cursor_fill(MaskCursor& c, uint32_t* buf, int lane, int want) {
+  int have = 0;
+  while (have < want) {
+    if (c.m == 0ull) {
+      const int g = c.desc ? c.gi - 1 : c.gi + 1;
+      if (g < 0 || g >= c.ngroups) break;
+      c.gi = g;
+      c.m = cursor_mask(c, g, lane);
+      continue;
+    }
+    const uint64_t m = c.m;
+    const int cnt = __popcll(m);
+    const bool bit = (m >> lane) & 1ull;
+    const int rank = c.desc ? bits_above(m, lane) : mbcnt64(m);
+    const int slot = have + rank;
+    if (bit && slot < want) buf[slot] = static_cast<uint32_t>(c.xbase + 64 * c.gi + lane);
+    const int take = cnt < want - have ? cnt : want - have;
+    c.m = take < cnt ? __ballot(bit && rank >= take) : 0ull;
+    have += take;
+  }
+  return have;
+}
+__device__ __forceinline__ MaskCursor make_cursor(const QueryStore& S, int f, int l, bool desc) {
+  MaskCursor c;
+  c.mk = mask_area(S, f) + 4 + (desc ? 2 : 0);
+  c.ngroups = (l - f - 1 + 63) >> 6;
+  c.xbase = f + 1;
+  c.desc = desc;
+  c.gi = 0; c.gwin = -1000000; c.wlo = 0; c.whi = 0; c.m = 0ull;
+  return c;
+}
+// position of the entry of walk rank `target` (wave-uniform)
+__device__ inline int cursor_select(const QueryStore& S, int f, int l, bool desc, const uint32_t* pref, int nc, int target, int lane) {
+  MaskCursor c = make_cursor(S, f, l, desc);
+  cursor_seek(c, pref, nc, target, lane);
+  const int b = desc ? 63 - __clzll(static_cast<long long>(c.m)) : __ffsll(static_cast<long long>(c.m)) - 1;
+  return c.xbase + 64 * c.gi + b;
+}
+
+// ---- phases 1, 1b, 2 of one introsort: S.elem[0, N) with depth budget depth0 --------------------------------------------------------
+// The workgroup's static LDS (the kernel owns it; the phases only borrow it)
+struct WgCtx {
+  int* stask;       // [3]
+  int* sqcount;     // [2]
+  int* shist;       // [NWAVE * 64]
+  uint32_t* bufR;   // [NWAVE * 128 * CMH_MAP_SWAP_BLOCKS]: the mask walk's L and R positions of one iteration, per wave
+};
 // Children of a partition: > kSeqMax elements -> next breadth-first level; 17..kSeqMax -> parked for the sequential
 // finisher (start bit in smallbits, (end, depth budget) in the segment's own slice of tmp); <= 16 -> leaf.
 __device__ __forceinline__ void push_seg(const QueryStore& S, uint32_t* q, int* qcount, int f, int l, int depth) {
@@ -388,6 +532,407 @@ __device__ inline void seq_finish_segment(uint32_t* e, uint32_t* stack, uint32_t
   }
 }
 
+template <bool MASKS>
+__device__ __forceinline__ void introsort_phases(const QueryStore& S, int N, int depth0, const WgCtx& C, unsigned long long* st) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  uint32_t* e = S.elem;
+  const int bw = (N + 31) / 32;
+  int* stask = C.stask;
+  int* sqcount = C.sqcount;
+  for (int i = tid; i < bw; i += NT) { S.leafbits[i] = 0; S.smallbits[i] = 0; }
+  if (tid == 0) { sqcount[0] = 0; sqcount[1] = 0; }
+  __syncthreads();
+  if (st && tid == 0) st[1] = __builtin_readcyclecounter();
+  // ---- phase 1: introsort loop, breadth-first ------------------------------------------------------
+  int depth = depth0;
+  uint32_t* qcur = S.qa;
+  uint32_t* qnxt = S.qb;
+  int cur = 0, lvl = 0;
+  if (tid == 0) {
+    S.leafbits[0] = 1u;
+    push_seg(S, qcur, &sqcount[0], 0, N, depth0);
+  }
+  __syncthreads();
+  while (true) {
+    const int nseg = sqcount[cur];
+    if (nseg == 0) break;
+    if (st && tid == 0 && lvl < 28) {
+      st[8 + 2 * lvl] = __builtin_readcyclecounter();
+      st[9 + 2 * lvl] = static_cast<unsigned long long>(nseg);
+    }
+    ++lvl;
+    if (depth == 0) {                                       // depth budget exhausted -> heapsort each segment
+      for (int si = tid; si < nseg; si += NT) heap_sort_segment(e, static_cast<int>(qcur[2 * si]), static_cast<int>(qcur[2 * si + 1]));
+      break;
+    }
+    --depth;
+    if (tid == 0) { sqcount[cur ^ 1] = 0; stask[0] = 0; stask[1] = 0; stask[2] = 0; }      // tasks, chunks, next task
+    __syncthreads();
+    // -- work list of the level: a segment of more than kChunk positions is cut into chunk tasks (its median moves to the front
+    //    here), a shorter one is one task.  Tasks go to the waves round-robin, so one long segment no longer holds a level up.
+    for (int si = tid; si < nseg; si += NT) {
+      const int f = static_cast<int>(qcur[2 * si]), l = static_cast<int>(qcur[2 * si + 1]);
+      const int nc = (l - f - 1 > kChunk) ? (l - f - 2 + kChunk) / kChunk : 1;
+      const int base = atomicAdd(&stask[0], nc);
+      int cbase = 0;
+      if (nc > 1) { median_to_first(e, f, l); cbase = atomicAdd(&stask[1], nc); }
+      S.seginfo[si] = static_cast<uint32_t>(cbase) | (static_cast<uint32_t>(nc) << 16);
+      for (int j = 0; j < nc; ++j) S.task[base + j] = (static_cast<uint32_t>(si) << 11) | static_cast<uint32_t>(j);
+    }
+    __syncthreads();
+    if (st && tid == 0 && lvl <= 16) st[64 + 8 * (lvl - 1) + 0] = __builtin_readcyclecounter();
+    const int ntask = stask[0];
+    const bool chunked = stask[1] != 0;
+    uint32_t* cntL = S.cnt;
+    uint32_t* cntR = S.cnt + S.ccap;
+    uint32_t* cntS = S.cnt + 2 * S.ccap;
+    // -- A: whole short segments; L / R counts of the chunks
+    int guard = 0;
+    while (true) {                                            // tasks differ in length (33..kChunk+1 positions): first come, first served
+      int t = 0;
+      if (lane == 0) t = atomicAdd(&stask[2], 1);
+      t = __builtin_amdgcn_readfirstlane(t);
+      if (t >= ntask) break;
+      if (++guard > ntask) break;                            // a wave can never be handed more tasks than exist: bounds the loop whatever happens
+      const uint32_t tk = S.task[t];
+      const int si = static_cast<int>(tk >> 11), j = static_cast<int>(tk & 2047u);
+      const int f = static_cast<int>(qcur[2 * si]), l = static_cast<int>(qcur[2 * si + 1]);
+      const int n = l - f;
+      const uint32_t info = S.seginfo[si];
+      if ((info >> 16) == 1u) {
+        const int cut = n <= 65 ? partition_wave<1>(S, f, l, lane, depth) : n <= 129 ? partition_wave<2>(S, f, l, lane, depth) : partition_wave<4>(S, f, l, lane, depth);
+        if (lane == 0 && cut >= 0) {
+          atomicOr(&S.leafbits[cut >> 5], 1u << (cut & 31));
+          push_seg(S, qnxt, &sqcount[cur ^ 1], f, cut, depth);
+          push_seg(S, qnxt, &sqcount[cur ^ 1], cut, l, depth);
+        }
+      } else {
+        const int a = f + 1 + j * kChunk, b = a + kChunk < l ? a + kChunk : l;
+        const int p = ekey(e[f]);
+        int cL = 0, cR = 0;
+        uint32_t* mk = MASKS ? mask_area(S, f) + 4 + 4 * (j * (kChunk / 64)) : nullptr;       // this chunk's groups
+        constexpr int UA = CMH_MAP_UNROLL_A;                   // groups in flight per wave (the pass is latency-bound)
+        for (int x0 = a; x0 < b; x0 += 64 * UA) {
+          int k[UA];
+#pragma unroll
+          for (int u = 0; u < UA; ++u) {
+            const int x = x0 + 64 * u + lane;
+            k[u] = x < b ? ekey(e[x]) : -1;
+          }
+#pragma unroll
+          for (int u = 0; u < UA; ++u) {
+            const uint64_t mL = __ballot(k[u] >= p), mR = __ballot(k[u] >= 0 && k[u] <= p);
+            cL += __popcll(mL);
+            cR += __popcll(mR);
+            if (MASKS && lane == 0 && x0 + 64 * u < b)
+              *reinterpret_cast<uint4*>(mk + 4 * (((x0 - a) >> 6) + u)) =
+                  uint4{static_cast<uint32_t>(mL), static_cast<uint32_t>(mL >> 32), static_cast<uint32_t>(mR), static_cast<uint32_t>(mR >> 32)};
+          }
+        }
+        const int ci = static_cast<int>(info & 0xffffu) + j;
+        if (lane == 0) { cntL[ci] = static_cast<uint32_t>(cL); cntR[ci] = static_cast<uint32_t>(cR); }
+      }
+    }
+    if (MASKS && chunked) {
+      __syncthreads();
+      if (st && tid == 0 && lvl <= 16) st[64 + 8 * (lvl - 1) + 1] = __builtin_readcyclecounter();
+      // -- B: per chunked segment (a wave each), the chunk counts become exclusive prefixes - L ascending, R from the top - and the
+      //    totals go to the mask area's header
+      for (int si = wid; si < nseg; si += NWAVE) {
+        const uint32_t info = S.seginfo[si];
+        const int nc = static_cast<int>(info >> 16), base = static_cast<int>(info & 0xffffu);
+        if (nc == 1) continue;
+        const int f = static_cast<int>(qcur[2 * si]);
+        int carry = 0;
+        for (int c0 = 0; c0 < nc; c0 += 64) {
+          const int ci = c0 + lane;
+          const int v = ci < nc ? static_cast<int>(cntL[base + ci]) : 0;
+          int incl = v;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+          }
+          if (ci < nc) cntL[base + ci] = static_cast<uint32_t>(carry + incl - v);
+          carry += __builtin_amdgcn_readlane(incl, 63);
+        }
+        const int Lc = carry;
+        carry = 0;
+        for (int c0 = ((nc - 1) / 64) * 64; c0 >= 0; c0 -= 64) {
+          const int ci = c0 + lane;
+          const int v = ci < nc ? static_cast<int>(cntR[base + ci]) : 0;
+          int incl = v;                                         // inclusive SUFFIX sum over the block
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const int dn = __shfl_down(incl, o, 64);
+            if (lane + o < 64) incl += dn;
+          }
+          if (ci < nc) cntR[base + ci] = static_cast<uint32_t>(carry + incl - v);
+          carry += __builtin_amdgcn_readlane(incl, 0);
+        }
+        if (lane == 0) { uint32_t* hdr = mask_area(S, f); hdr[0] = static_cast<uint32_t>(Lc); hdr[1] = static_cast<uint32_t>(carry); }
+      }
+      __syncthreads();
+      if (st && tid == 0 && lvl <= 16) st[64 + 8 * (lvl - 1) + 2] = __builtin_readcyclecounter();
+      // -- C: the pairs (L_i, R_i), cut into as many pieces of ranks as the segment has chunks; a piece's wave walks the masks from
+      //    the piece's first rank and expands 64 ranks at a time
+      constexpr int CB = CMH_MAP_SWAP_BLOCKS, CW = 64 * CB;         // ranks per iteration: CB gathers of each side in flight
+      uint32_t* bufL = C.bufR + wid * 2 * CW;
+      uint32_t* bufR = bufL + CW;
+      for (int t = wid; t < ntask; t += NWAVE) {
+        const uint32_t tk = S.task[t];
+        const int si = static_cast<int>(tk >> 11), j = static_cast<int>(tk & 2047u);
+        const uint32_t info = S.seginfo[si];
+        const int nc = static_cast<int>(info >> 16), base = static_cast<int>(info & 0xffffu);
+        if (nc == 1) continue;
+        const int f = static_cast<int>(qcur[2 * si]), l = static_cast<int>(qcur[2 * si + 1]);
+        const int cap = (l - f) / 2 + 1;
+        const uint32_t* hdr = mask_area(S, f);
+        const int Lc = static_cast<int>(hdr[0]), Rc = static_cast<int>(hdr[1]);
+        int npairs = Lc < Rc ? Lc : Rc;
+        npairs = npairs < cap ? npairs : cap;
+        const int piece = (((cap + nc - 1) / nc) + 63) & ~63;
+        const int i0 = j * piece, i1 = i0 + piece < npairs ? i0 + piece : npairs;
+        int sw = 0;
+        if (i0 < i1) {
+          MaskCursor cl = make_cursor(S, f, l, false), cr = make_cursor(S, f, l, true);
+          cursor_seek(cl, cntL + base, nc, i0, lane);
+          cursor_seek(cr, cntR + base, nc, i0, lane);
+          for (int ib = i0; ib < i1; ib += CW) {
+            const int nl = cursor_fill(cl, bufL, lane, CW), nr = cursor_fill(cr, bufR, lane, CW);
+            wave_sync();
+            uint32_t xl[CB], xr[CB], vl[CB], vr[CB];
+            bool did[CB];
+#pragma unroll
+            for (int u = 0; u < CB; ++u) {
+              const int k = 64 * u + lane;
+              did[u] = false;
+              if (ib + k < i1 && k < nl && k < nr) {
+                xl[u] = bufL[k];
+                xr[u] = bufR[k];
+                did[u] = xl[u] < xr[u];
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < CB; ++u)
+              if (did[u]) { vl[u] = e[xl[u]]; vr[u] = e[xr[u]]; }
+            int c = 0;
+#pragma unroll
+            for (int u = 0; u < CB; ++u) {
+              if (did[u]) { e[xl[u]] = vr[u]; e[xr[u]] = vl[u]; }
+              c += __popcll(__ballot(did[u]));
+            }
+            sw += c;
+            wave_sync();
+            if (c < CW) break;                                 // the swapping pairs are a prefix
+          }
+        }
+        if (lane == 0) cntS[base + j] = static_cast<uint32_t>(sw);
+      }
+      __syncthreads();
+      if (st && tid == 0 && lvl <= 16) st[64 + 8 * (lvl - 1) + 3] = __builtin_readcyclecounter();
+      // -- D: cut and children of the chunked segments (a wave each): cut = min(L_s, R_{s-1}), s = the swaps made
+      for (int si = wid; si < nseg; si += NWAVE) {
+        const uint32_t info = S.seginfo[si];
+        const int nc = static_cast<int>(info >> 16), base = static_cast<int>(info & 0xffffu);
+        if (nc == 1) continue;
+        const int f = static_cast<int>(qcur[2 * si]), l = static_cast<int>(qcur[2 * si + 1]);
+        const int cap = (l - f) / 2 + 1;
+        int part = 0;
+        for (int c0 = 0; c0 < nc; c0 += 64) part += c0 + lane < nc ? static_cast<int>(cntS[base + c0 + lane]) : 0;
+        const int sw = wave_sum_i(part);
+        const uint32_t* hdr = mask_area(S, f);
+        const int Lc = static_cast<int>(hdr[0]);
+        const int lim = Lc < cap ? Lc : cap;
+        const uint32_t c1 = sw < lim ? static_cast<uint32_t>(cursor_select(S, f, l, false, cntL + base, nc, sw, lane)) : 0x7fffffffu;
+        const uint32_t c2 = sw >= 1 ? static_cast<uint32_t>(cursor_select(S, f, l, true, cntR + base, nc, sw - 1, lane)) : 0x7fffffffu;
+        const int cut = static_cast<int>(c1 < c2 ? c1 : c2);
+        if (lane == 0) {
+          atomicOr(&S.leafbits[cut >> 5], 1u << (cut & 31));
+          push_seg(S, qnxt, &sqcount[cur ^ 1], f, cut, depth);
+          push_seg(S, qnxt, &sqcount[cur ^ 1], cut, l, depth);
+        }
+      }
+    }
+    if (!MASKS && chunked) {
+      __syncthreads();
+      if (st && tid == 0 && lvl <= 16) st[64 + 8 * (lvl - 1) + 1] = __builtin_readcyclecounter();
+      // -- B: the chunks' positions go to the lists (L ascending from the chunks before, R descending from the chunks after)
+      for (int t = wid; t < ntask; t += NWAVE) {
+        const uint32_t tk = S.task[t];
+        const int si = static_cast<int>(tk >> 11), j = static_cast<int>(tk & 2047u);
+        const uint32_t info = S.seginfo[si];
+        const int nc = static_cast<int>(info >> 16), base = static_cast<int>(info & 0xffffu);
+        if (nc == 1) continue;
+        const int f = static_cast<int>(qcur[2 * si]), l = static_cast<int>(qcur[2 * si + 1]);
+        const int cap = (l - f) / 2 + 1;
+        int before = 0, after = 0;
+        for (int j0 = 0; j0 < nc; j0 += 64) {
+          const int jj = j0 + lane;
+          if (jj < j) before += static_cast<int>(cntL[base + jj]);
+          if (jj > j && jj < nc) after += static_cast<int>(cntR[base + jj]);
+        }
+        const int offL = wave_sum_i(before), offR = wave_sum_i(after);
+        const int ownR = static_cast<int>(cntR[base + j]);
+        uint32_t* tL = S.tmp + tmp_base(f);
+        uint32_t* tR = tL + cap;
+        const int a = f + 1 + j * kChunk, b = a + kChunk < l ? a + kChunk : l;
+        const int p = ekey(e[f]);
+        int runL = offL, runR = offR + ownR - 1;
+        for (int x0 = a; x0 < b; x0 += 256) {
+          int k[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int x = x0 + 64 * u + lane;
+            k[u] = x < b ? ekey(e[x]) : -1;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int x = x0 + 64 * u + lane;
+            const bool isL = k[u] >= p, isR = k[u] >= 0 && k[u] <= p;
+            const uint64_t mL = __ballot(isL), mR = __ballot(isR);
+            const int rl = runL + mbcnt64(mL), rr = runR - mbcnt64(mR);
+            if (isL && rl < cap) tL[rl] = static_cast<uint32_t>(x);
+            if (isR && rr < cap) tR[rr] = static_cast<uint32_t>(x);
+            runL += __popcll(mL);
+            runR -= __popcll(mR);
+          }
+        }
+      }
+      __syncthreads();
+      if (st && tid == 0 && lvl <= 16) st[64 + 8 * (lvl - 1) + 2] = __builtin_readcyclecounter();
+      // -- C: the pairs, cut into as many pieces as the segment has chunks
+      for (int t = wid; t < ntask; t += NWAVE) {
+        const uint32_t tk = S.task[t];
+        const int si = static_cast<int>(tk >> 11), j = static_cast<int>(tk & 2047u);
+        const uint32_t info = S.seginfo[si];
+        const int nc = static_cast<int>(info >> 16), base = static_cast<int>(info & 0xffffu);
+        if (nc == 1) continue;
+        const int f = static_cast<int>(qcur[2 * si]), l = static_cast<int>(qcur[2 * si + 1]);
+        const int cap = (l - f) / 2 + 1;
+        int sl = 0, sr = 0;
+        for (int j0 = 0; j0 < nc; j0 += 64) {
+          const int jj = j0 + lane;
+          if (jj < nc) { sl += static_cast<int>(cntL[base + jj]); sr += static_cast<int>(cntR[base + jj]); }
+        }
+        const int Lc = wave_sum_i(sl), Rc = wave_sum_i(sr);
+        int npairs = Lc < Rc ? Lc : Rc;
+        npairs = npairs < cap ? npairs : cap;
+        const int piece = (((cap + nc - 1) / nc) + 63) & ~63;
+        const int i0 = j * piece, i1 = i0 + piece < npairs ? i0 + piece : npairs;
+        const uint32_t* tL = S.tmp + tmp_base(f);
+        const uint32_t* tR = tL + cap;
+        int sw = 0;
+        for (int ib = i0; ib < i1; ib += 64) {
+          const int i = ib + lane;
+          bool did = false;
+          if (i < i1) {
+            const uint32_t xl = tL[i], xr = tR[i];
+            did = xl < xr;
+            if (did) {
+              const uint32_t t0 = e[xl];
+              e[xl] = e[xr];
+              e[xr] = t0;
+            }
+          }
+          const int c = __popcll(__ballot(did));
+          sw += c;
+          if (c < 64) break;                                 // the swapping pairs are a prefix
+        }
+        if (lane == 0) cntS[base + j] = static_cast<uint32_t>(sw);
+      }
+      __syncthreads();
+      if (st && tid == 0 && lvl <= 16) st[64 + 8 * (lvl - 1) + 3] = __builtin_readcyclecounter();
+      // -- D: cut and children of the chunked segments
+      for (int si = tid; si < nseg; si += NT) {
+        const uint32_t info = S.seginfo[si];
+        const int nc = static_cast<int>(info >> 16), base = static_cast<int>(info & 0xffffu);
+        if (nc == 1) continue;
+        const int f = static_cast<int>(qcur[2 * si]), l = static_cast<int>(qcur[2 * si + 1]);
+        const int cap = (l - f) / 2 + 1;
+        int sw = 0, Lc = 0;
+        for (int j = 0; j < nc; ++j) { sw += static_cast<int>(cntS[base + j]); Lc += static_cast<int>(cntL[base + j]); }
+        const uint32_t* tL = S.tmp + tmp_base(f);
+        const uint32_t* tR = tL + cap;
+        const int lim = Lc < cap ? Lc : cap;
+        const uint32_t c1 = sw < lim ? tL[sw] : 0x7fffffffu;
+        const uint32_t c2 = sw >= 1 ? tR[sw - 1] : 0x7fffffffu;
+        const int cut = static_cast<int>(c1 < c2 ? c1 : c2);
+        atomicOr(&S.leafbits[cut >> 5], 1u << (cut & 31));
+        push_seg(S, qnxt, &sqcount[cur ^ 1], f, cut, depth);
+        push_seg(S, qnxt, &sqcount[cur ^ 1], cut, l, depth);
+      }
+    }
+    __syncthreads();
+    if (st && tid == 0 && lvl <= 16) st[64 + 8 * (lvl - 1) + 4] = __builtin_readcyclecounter();
+    if (st && tid == 0 && lvl <= 16) { st[64 + 8 * (lvl - 1) + 5] = ntask; st[64 + 8 * (lvl - 1) + 6] = stask[1]; }
+    uint32_t* t = qcur; qcur = qnxt; qnxt = t;
+    cur ^= 1;
+  }
+  __syncthreads();
+
+  if (st && tid == 0) st[2] = __builtin_readcyclecounter();
+  // ---- phase 1b: parked segments (17..kSeqMax elements): the rest of their introsort + insertion sort, one lane each
+  for (int wi = tid; wi < bw; wi += NT) {
+    uint32_t bitsw = S.smallbits[wi];
+    while (bitsw) {
+      const int f = wi * 32 + __ffs(bitsw) - 1;
+      bitsw &= bitsw - 1;
+      uint32_t* slot = S.tmp + tmp_base(f);
+      const int l = static_cast<int>(slot[0]), d = static_cast<int>(slot[1]);
+      seq_finish_segment(e, slot, S.leafbits, f, l, d);
+    }
+  }
+  __syncthreads();
+
+  if (st && tid == 0) st[3] = __builtin_readcyclecounter();
+  // ---- phase 2: final insertion sort == stable sort of each <=16-element leaf ---------------------------
+  // One thread per 16 positions; a leaf that starts there is loaded into registers (padded with keys above every real one) and
+  // sorted by the insertion sort's own compare-exchange sequence on adjacent elements (a strict '<' swaps, so equal keys keep
+  // their order): no dependent LDS round trips, and a wave whose leaves are all in order already skips the network.
+  for (int hw = tid; hw < 2 * bw; hw += NT) {
+    const uint32_t w0 = S.leafbits[hw >> 1];
+    const uint32_t w1 = (hw >> 1) + 1 < bw ? S.leafbits[(hw >> 1) + 1] : 0u;
+    const uint64_t both = static_cast<uint64_t>(w0) | (static_cast<uint64_t>(w1) << 32);
+    uint32_t starts = (w0 >> (16 * (hw & 1))) & 0xffffu;
+    while (__ballot(starts != 0)) {                            // wave-uniform trip count: the ballots below need every lane
+      int s0 = 0, n = 0;
+      if (starts) {
+        const int bpos = 16 * (hw & 1) + __ffs(starts) - 1;
+        starts &= starts - 1;
+        s0 = (hw >> 1) * 32 + bpos;
+        const uint64_t rest = bpos == 63 ? 0ull : both >> (bpos + 1);
+        int d = rest ? __ffsll(static_cast<long long>(rest)) : 1 << 20;      // distance to the next segment start
+        d = s0 + d > N ? N - s0 : d;
+        n = d <= kLeaf ? d : 0;                                  // longer: heap-sorted or an all-equal run, in its final order already
+      }
+      uint32_t v[kLeaf];
+#pragma unroll
+      for (int i = 0; i < kLeaf; ++i) v[i] = i < n ? e[s0 + i] : 0xffffffffu;
+      bool unsorted = false;
+#pragma unroll
+      for (int i = 1; i < kLeaf; ++i) unsorted |= (v[i] >> kIdxBits) < (v[i - 1] >> kIdxBits);
+      if (__ballot(unsorted) == 0) continue;
+#pragma unroll
+      for (int i = 1; i < kLeaf; ++i) {
+#pragma unroll
+        for (int j = i; j >= 1; --j) {
+          const uint32_t lo = v[j - 1], hi = v[j];
+          const bool sw = (hi | kIdxMask) < (lo & ~kIdxMask);       // key(hi) < key(lo)
+          v[j - 1] = sw ? hi : lo;
+          v[j] = sw ? lo : hi;
+        }
+      }
+      if (unsorted) {
+#pragma unroll
+        for (int i = 0; i < kLeaf; ++i)
+          if (i < n) e[s0 + i] = v[i];
+      }
+    }
+  }
+  __syncthreads();
+}
+
 // ---- the per-query kernel ----------------------------------------------------------------------------------
 struct MapArgs {
   const uint32_t *q_sign, *q_nz, *q_label, *r_sign, *r_nz, *r_label;
@@ -411,7 +956,7 @@ __global__ __launch_bounds__(NT, WAVES) void map_query_kernel(MapArgs A) {
   __shared__ int sqcount[2];
   __shared__ int swork[NWAVE + 2];
   __shared__ double sred[NWAVE];
-  __shared__ int shist[NWAVE * 64];         // CMH_TIE_STABLE: (wave, digit) cells of the radix passes
+  __shared__ int shist[NWAVE * 64];         // CMH_TIE_STABLE: (wave, digit) cells of the radix passes; else: 64 L positions per wave
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int N = A.N, W = A.W, LW = A.LW;
@@ -421,6 +966,8 @@ __global__ __launch_bounds__(NT, WAVES) void map_query_kernel(MapArgs A) {
   else S = carve_store(A.gstore + static_cast<size_t>(blockIdx.x) * store_words(N), N);
   uint32_t* e = S.elem;
   const int bw = (N + 31) / 32;
+  // MODE 0: the dynamic LDS holds the mask walk's position buffers
+  const WgCtx C{stask, sqcount, shist, MODE == 0 ? dyn_smem : nullptr};
 
   for (int qi = blockIdx.x; qi < A.Q; qi += gridDim.x) {
     __syncthreads();
@@ -428,7 +975,7 @@ __global__ __launch_bounds__(NT, WAVES) void map_query_kernel(MapArgs A) {
     // ---- phase 0: keys + relevance ---------------------------------------------------------------
     if (tid < W) { sq[0][tid] = A.q_sign[static_cast<size_t>(qi) * W + tid]; sq[1][tid] = A.q_nz[static_cast<size_t>(qi) * W + tid]; }
     if (tid < LW) sq[2][tid] = A.q_label[static_cast<size_t>(qi) * LW + tid];
-    for (int i = tid; i < bw; i += NT) { S.leafbits[i] = 0; S.relbits[i] = 0; S.smallbits[i] = 0; }
+    for (int i = tid; i < bw; i += NT) S.relbits[i] = 0;
     __syncthreads();
     int myrel = 0;
     for (int j0 = 0; j0 < N; j0 += NT) {
@@ -460,7 +1007,6 @@ __global__ __launch_bounds__(NT, WAVES) void map_query_kernel(MapArgs A) {
     }
     myrel = wave_sum_i(myrel);
     if (lane == 0) swork[wid] = myrel;
-    if (tid == 0) { sqcount[0] = 0; sqcount[1] = 0; }
     __syncthreads();
     int tsum = 0;
     for (int w = 0; w < NWAVE; ++w) tsum += swork[w];
@@ -542,269 +1088,11 @@ __global__ __launch_bounds__(NT, WAVES) void map_query_kernel(MapArgs A) {
       }
       __syncthreads();
     } else {
-    if (A.stamps && blockIdx.x == 0 && qi == 0 && tid == 0) A.stamps[1] = __builtin_readcyclecounter();
-    // ---- phase 1: introsort loop, breadth-first ------------------------------------------------------
-    int depth = A.depth_limit >= 0 ? A.depth_limit : 2 * (31 - __clz(N));   // std::__lg(n) * 2
-    uint32_t* qcur = S.qa;
-    uint32_t* qnxt = S.qb;
-    int cur = 0, lvl = 0;
-    if (tid == 0) {
-      S.leafbits[0] = 1u;
+    {
+      const int depth0 = A.depth_limit >= 0 ? A.depth_limit : 2 * (31 - __clz(N));   // std::__lg(n) * 2
+      unsigned long long* st = A.stamps && blockIdx.x == 0 && qi == 0 ? A.stamps : nullptr;
+      introsort_phases<MODE == 0 && CMH_MAP_MASKS != 0>(S, N, depth0, C, st);
     }
-    __syncthreads();
-    if (tid == 0) push_seg(S, qcur, &sqcount[0], 0, N, A.depth_limit >= 0 ? A.depth_limit : 2 * (31 - __clz(N)));
-    __syncthreads();
-    while (true) {
-      const int nseg = sqcount[cur];
-      if (nseg == 0) break;
-      if (A.stamps && blockIdx.x == 0 && qi == 0 && tid == 0 && lvl < 28) {
-        A.stamps[8 + 2 * lvl] = __builtin_readcyclecounter();
-        A.stamps[9 + 2 * lvl] = static_cast<unsigned long long>(nseg);
-      }
-      ++lvl;
-      if (depth == 0) {                                       // depth budget exhausted -> heapsort each segment
-        for (int si = tid; si < nseg; si += NT) heap_sort_segment(e, static_cast<int>(qcur[2 * si]), static_cast<int>(qcur[2 * si + 1]));
-        break;
-      }
-      --depth;
-      if (tid == 0) { sqcount[cur ^ 1] = 0; stask[0] = 0; stask[1] = 0; stask[2] = 0; }      // tasks, chunks, next task
-      __syncthreads();
-      // -- work list of the level: a segment of more than kChunk positions is cut into chunk tasks (its median moves to the front
-      //    here), a shorter one is one task.  Tasks go to the waves round-robin, so one long segment no longer holds a level up.
-      for (int si = tid; si < nseg; si += NT) {
-        const int f = static_cast<int>(qcur[2 * si]), l = static_cast<int>(qcur[2 * si + 1]);
-        const int nc = (l - f - 1 > kChunk) ? (l - f - 2 + kChunk) / kChunk : 1;
-        const int base = atomicAdd(&stask[0], nc);
-        int cbase = 0;
-        if (nc > 1) { median_to_first(e, f, l); cbase = atomicAdd(&stask[1], nc); }
-        S.seginfo[si] = static_cast<uint32_t>(cbase) | (static_cast<uint32_t>(nc) << 16);
-        for (int j = 0; j < nc; ++j) S.task[base + j] = (static_cast<uint32_t>(si) << 11) | static_cast<uint32_t>(j);
-      }
-      __syncthreads();
-      if (A.stamps && blockIdx.x == 0 && qi == 0 && tid == 0 && lvl <= 16) A.stamps[64 + 8 * (lvl - 1) + 0] = __builtin_readcyclecounter();
-      const int ntask = stask[0];
-      const bool chunked = stask[1] != 0;
-      uint32_t* cntL = S.cnt;
-      uint32_t* cntR = S.cnt + S.ccap;
-      uint32_t* cntS = S.cnt + 2 * S.ccap;
-      // -- A: whole short segments; L / R counts of the chunks
-      int guard = 0;
-      while (true) {                                            // tasks differ in length (33..kChunk+1 positions): first come, first served
-        int t = 0;
-        if (lane == 0) t = atomicAdd(&stask[2], 1);
-        t = __builtin_amdgcn_readfirstlane(t);
-        if (t >= ntask) break;
-        if (++guard > ntask) break;                            // a wave can never be handed more tasks than exist: bounds the loop whatever happens
-        const uint32_t tk = S.task[t];
-        const int si = static_cast<int>(tk >> 11), j = static_cast<int>(tk & 2047u);
-        const int f = static_cast<int>(qcur[2 * si]), l = static_cast<int>(qcur[2 * si + 1]);
-        const int n = l - f;
-        const uint32_t info = S.seginfo[si];
-        if ((info >> 16) == 1u) {
-          const int cut = n <= 65 ? partition_wave<1>(S, f, l, lane, depth) : n <= 129 ? partition_wave<2>(S, f, l, lane, depth) : partition_wave<4>(S, f, l, lane, depth);
-          if (lane == 0 && cut >= 0) {
-            atomicOr(&S.leafbits[cut >> 5], 1u << (cut & 31));
-            push_seg(S, qnxt, &sqcount[cur ^ 1], f, cut, depth);
-            push_seg(S, qnxt, &sqcount[cur ^ 1], cut, l, depth);
-          }
-        } else {
-          const int a = f + 1 + j * kChunk, b = a + kChunk < l ? a + kChunk : l;
-          const int p = ekey(e[f]);
-          int cL = 0, cR = 0;
-          for (int x0 = a; x0 < b; x0 += 256) {
-            int k[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int x = x0 + 64 * u + lane;
-              k[u] = x < b ? ekey(e[x]) : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              cL += __popcll(__ballot(k[u] >= p));
-              cR += __popcll(__ballot(k[u] >= 0 && k[u] <= p));
-            }
-          }
-          const int ci = static_cast<int>(info & 0xffffu) + j;
-          if (lane == 0) { cntL[ci] = static_cast<uint32_t>(cL); cntR[ci] = static_cast<uint32_t>(cR); }
-        }
-      }
-      if (chunked) {
-        __syncthreads();
-        if (A.stamps && blockIdx.x == 0 && qi == 0 && tid == 0 && lvl <= 16) A.stamps[64 + 8 * (lvl - 1) + 1] = __builtin_readcyclecounter();
-        // -- B: the chunks' positions go to the lists (L ascending from the chunks before, R descending from the chunks after)
-        for (int t = wid; t < ntask; t += NWAVE) {
-          const uint32_t tk = S.task[t];
-          const int si = static_cast<int>(tk >> 11), j = static_cast<int>(tk & 2047u);
-          const uint32_t info = S.seginfo[si];
-          const int nc = static_cast<int>(info >> 16), base = static_cast<int>(info & 0xffffu);
-          if (nc == 1) continue;
-          const int f = static_cast<int>(qcur[2 * si]), l = static_cast<int>(qcur[2 * si + 1]);
-          const int cap = (l - f) / 2 + 1;
-          int before = 0, after = 0;
-          for (int j0 = 0; j0 < nc; j0 += 64) {
-            const int jj = j0 + lane;
-            if (jj < j) before += static_cast<int>(cntL[base + jj]);
-            if (jj > j && jj < nc) after += static_cast<int>(cntR[base + jj]);
-          }
-          const int offL = wave_sum_i(before), offR = wave_sum_i(after);
-          const int ownR = static_cast<int>(cntR[base + j]);
-          uint32_t* tL = S.tmp + tmp_base(f);
-          uint32_t* tR = tL + cap;
-          const int a = f + 1 + j * kChunk, b = a + kChunk < l ? a + kChunk : l;
-          const int p = ekey(e[f]);
-          int runL = offL, runR = offR + ownR - 1;
-          for (int x0 = a; x0 < b; x0 += 256) {
-            int k[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int x = x0 + 64 * u + lane;
-              k[u] = x < b ? ekey(e[x]) : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int x = x0 + 64 * u + lane;
-              const bool isL = k[u] >= p, isR = k[u] >= 0 && k[u] <= p;
-              const uint64_t mL = __ballot(isL), mR = __ballot(isR);
-              const int rl = runL + mbcnt64(mL), rr = runR - mbcnt64(mR);
-              if (isL && rl < cap) tL[rl] = static_cast<uint32_t>(x);
-              if (isR && rr < cap) tR[rr] = static_cast<uint32_t>(x);
-              runL += __popcll(mL);
-              runR -= __popcll(mR);
-            }
-          }
-        }
-        __syncthreads();
-        if (A.stamps && blockIdx.x == 0 && qi == 0 && tid == 0 && lvl <= 16) A.stamps[64 + 8 * (lvl - 1) + 2] = __builtin_readcyclecounter();
-        // -- C: the pairs, cut into as many pieces as the segment has chunks
-        for (int t = wid; t < ntask; t += NWAVE) {
-          const uint32_t tk = S.task[t];
-          const int si = static_cast<int>(tk >> 11), j = static_cast<int>(tk & 2047u);
-          const uint32_t info = S.seginfo[si];
-          const int nc = static_cast<int>(info >> 16), base = static_cast<int>(info & 0xffffu);
-          if (nc == 1) continue;
-          const int f = static_cast<int>(qcur[2 * si]), l = static_cast<int>(qcur[2 * si + 1]);
-          const int cap = (l - f) / 2 + 1;
-          int sl = 0, sr = 0;
-          for (int j0 = 0; j0 < nc; j0 += 64) {
-            const int jj = j0 + lane;
-            if (jj < nc) { sl += static_cast<int>(cntL[base + jj]); sr += static_cast<int>(cntR[base + jj]); }
-          }
-          const int Lc = wave_sum_i(sl), Rc = wave_sum_i(sr);
-          int npairs = Lc < Rc ? Lc : Rc;
-          npairs = npairs < cap ? npairs : cap;
-          const int piece = (((cap + nc - 1) / nc) + 63) & ~63;
-          const int i0 = j * piece, i1 = i0 + piece < npairs ? i0 + piece : npairs;
-          const uint32_t* tL = S.tmp + tmp_base(f);
-          const uint32_t* tR = tL + cap;
-          int sw = 0;
-          for (int ib = i0; ib < i1; ib += 64) {
-            const int i = ib + lane;
-            bool did = false;
-            if (i < i1) {
-              const uint32_t xl = tL[i], xr = tR[i];
-              did = xl < xr;
-              if (did) {
-                const uint32_t t0 = e[xl];
-                e[xl] = e[xr];
-                e[xr] = t0;
-              }
-            }
-            const int c = __popcll(__ballot(did));
-            sw += c;
-            if (c < 64) break;                                 // the swapping pairs are a prefix
-          }
-          if (lane == 0) cntS[base + j] = static_cast<uint32_t>(sw);
-        }
-        __syncthreads();
-        if (A.stamps && blockIdx.x == 0 && qi == 0 && tid == 0 && lvl <= 16) A.stamps[64 + 8 * (lvl - 1) + 3] = __builtin_readcyclecounter();
-        // -- D: cut and children of the chunked segments
-        for (int si = tid; si < nseg; si += NT) {
-          const uint32_t info = S.seginfo[si];
-          const int nc = static_cast<int>(info >> 16), base = static_cast<int>(info & 0xffffu);
-          if (nc == 1) continue;
-          const int f = static_cast<int>(qcur[2 * si]), l = static_cast<int>(qcur[2 * si + 1]);
-          const int cap = (l - f) / 2 + 1;
-          int sw = 0, Lc = 0;
-          for (int j = 0; j < nc; ++j) { sw += static_cast<int>(cntS[base + j]); Lc += static_cast<int>(cntL[base + j]); }
-          const uint32_t* tL = S.tmp + tmp_base(f);
-          const uint32_t* tR = tL + cap;
-          const int lim = Lc < cap ? Lc : cap;
-          const uint32_t c1 = sw < lim ? tL[sw] : 0x7fffffffu;
-          const uint32_t c2 = sw >= 1 ? tR[sw - 1] : 0x7fffffffu;
-          const int cut = static_cast<int>(c1 < c2 ? c1 : c2);
-          atomicOr(&S.leafbits[cut >> 5], 1u << (cut & 31));
-          push_seg(S, qnxt, &sqcount[cur ^ 1], f, cut, depth);
-          push_seg(S, qnxt, &sqcount[cur ^ 1], cut, l, depth);
-        }
-      }
-      __syncthreads();
-      if (A.stamps && blockIdx.x == 0 && qi == 0 && tid == 0 && lvl <= 16) A.stamps[64 + 8 * (lvl - 1) + 4] = __builtin_readcyclecounter();
-      if (A.stamps && blockIdx.x == 0 && qi == 0 && tid == 0 && lvl <= 16) { A.stamps[64 + 8 * (lvl - 1) + 5] = ntask; A.stamps[64 + 8 * (lvl - 1) + 6] = stask[1]; }
-      uint32_t* t = qcur; qcur = qnxt; qnxt = t;
-      cur ^= 1;
-    }
-    __syncthreads();
-
-    if (A.stamps && blockIdx.x == 0 && qi == 0 && tid == 0) A.stamps[2] = __builtin_readcyclecounter();
-    // ---- phase 1b: parked segments (17..kSeqMax elements): the rest of their introsort + insertion sort, one lane each
-    for (int wi = tid; wi < bw; wi += NT) {
-      uint32_t bitsw = S.smallbits[wi];
-      while (bitsw) {
-        const int f = wi * 32 + __ffs(bitsw) - 1;
-        bitsw &= bitsw - 1;
-        uint32_t* slot = S.tmp + tmp_base(f);
-        const int l = static_cast<int>(slot[0]), d = static_cast<int>(slot[1]);
-        seq_finish_segment(e, slot, S.leafbits, f, l, d);
-      }
-    }
-    __syncthreads();
-
-    if (A.stamps && blockIdx.x == 0 && qi == 0 && tid == 0) A.stamps[3] = __builtin_readcyclecounter();
-    // ---- phase 2: final insertion sort == stable sort of each <=16-element leaf ---------------------------
-    // One thread per 16 positions; a leaf that starts there is loaded into registers (padded with keys above every real one) and
-    // sorted by the insertion sort's own compare-exchange sequence on adjacent elements (a strict '<' swaps, so equal keys keep
-    // their order): no dependent LDS round trips, and a wave whose leaves are all in order already skips the network.
-    for (int hw = tid; hw < 2 * bw; hw += NT) {
-      const uint32_t w0 = S.leafbits[hw >> 1];
-      const uint32_t w1 = (hw >> 1) + 1 < bw ? S.leafbits[(hw >> 1) + 1] : 0u;
-      const uint64_t both = static_cast<uint64_t>(w0) | (static_cast<uint64_t>(w1) << 32);
-      uint32_t starts = (w0 >> (16 * (hw & 1))) & 0xffffu;
-      while (__ballot(starts != 0)) {                            // wave-uniform trip count: the ballots below need every lane
-        int s0 = 0, n = 0;
-        if (starts) {
-          const int bpos = 16 * (hw & 1) + __ffs(starts) - 1;
-          starts &= starts - 1;
-          s0 = (hw >> 1) * 32 + bpos;
-          const uint64_t rest = bpos == 63 ? 0ull : both >> (bpos + 1);
-          int d = rest ? __ffsll(static_cast<long long>(rest)) : 1 << 20;      // distance to the next segment start
-          d = s0 + d > N ? N - s0 : d;
-          n = d <= kLeaf ? d : 0;                                  // longer: heap-sorted or an all-equal run, in its final order already
-        }
-        uint32_t v[kLeaf];
-#pragma unroll
-        for (int i = 0; i < kLeaf; ++i) v[i] = i < n ? e[s0 + i] : 0xffffffffu;
-        bool unsorted = false;
-#pragma unroll
-        for (int i = 1; i < kLeaf; ++i) unsorted |= (v[i] >> kIdxBits) < (v[i - 1] >> kIdxBits);
-        if (__ballot(unsorted) == 0) continue;
-#pragma unroll
-        for (int i = 1; i < kLeaf; ++i) {
-#pragma unroll
-          for (int j = i; j >= 1; --j) {
-            const uint32_t lo = v[j - 1], hi = v[j];
-            const bool sw = (hi | kIdxMask) < (lo & ~kIdxMask);       // key(hi) < key(lo)
-            v[j - 1] = sw ? hi : lo;
-            v[j] = sw ? lo : hi;
-          }
-        }
-        if (unsorted) {
-#pragma unroll
-          for (int i = 0; i < kLeaf; ++i)
-            if (i < n) e[s0 + i] = v[i];
-        }
-      }
-    }
-    __syncthreads();
 
     }
     if (A.stamps && blockIdx.x == 0 && qi == 0 && tid == 0) A.stamps[4] = __builtin_readcyclecounter();
@@ -947,7 +1235,7 @@ __global__ __launch_bounds__(256) void neighbor_kernel(const uint32_t* __restric
 }
 
 static size_t lds_bytes_needed(int64_t N) { return store_words(N) * 4; }
-constexpr size_t kLdsOne = 150 * 1024;   // one workgroup per CU: of 160 KiB; static __shared__ of the kernel takes ~5 KiB
+constexpr size_t kLdsOne = 150 * 1024;   // one workgroup per CU: of 160 KiB; static __shared__ of the kernel takes ~9.2 KiB
 constexpr size_t kLdsTwo = 74 * 1024;    // two workgroups per CU
 
 // Where a query's working set lives: MAP_LDS2 everything in LDS, two queries per CU (N <= ~7.6 k); MAP_HYBRID elements in LDS, position
@@ -1079,7 +1367,7 @@ extern "C" int cmh_hamming_map(const uint32_t* q_sign, const uint32_t* q_nz, con
       a.stamps = reinterpret_cast<unsigned long long*>(a.gstore + static_cast<size_t>(map_slots(Q)) *
                                                        (mode == MAP_GLOBAL ? store_words(N) : hybrid_glob_words(N)));
   }
-  const size_t lds = mode == MAP_GLOBAL ? 0 : (mode == MAP_HYBRID || mode == MAP_HYBRID1 ? hybrid_lds_words(N) * 4 : lds_bytes_needed(N));
+  const size_t lds = mode == MAP_GLOBAL ? (CMH_MAP_MASKS ? NWAVE * 128 * CMH_MAP_SWAP_BLOCKS * 4 : 0) : (mode == MAP_HYBRID || mode == MAP_HYBRID1 ? hybrid_lds_words(N) * 4 : lds_bytes_needed(N));
 #define MAP_GO(MODE, WAVES)                                                                                                      \
   do {                                                                                                                           \
     if (lds && hipFuncSetAttribute(reinterpret_cast<const void*>(map_query_kernel<MODE, WAVES>),                                 \

@@ -6,7 +6,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "clip-based-cross-modal-hashing_amd"))
 import torch, cmh_native as N
 dev = torch.device("cuda:0")
+only = sys.argv[1:]                # optional: the scales to run
 for name, (Q, Nn, K, C) in {"flickr": (5000, 15015, 64, 24), "coco": (5000, 117218, 64, 80), "nuswide": (2100, 190834, 128, 21)}.items():
+    if only and name not in only:
+        continue
     g = torch.Generator().manual_seed(1)
     rL = (torch.rand(Nn, C, generator=g) < 0.1).float(); qL = (torch.rand(Q, C, generator=g) < 0.1).float()
     W = torch.randn(C, K, generator=g)

@@ -27,7 +27,7 @@ e0.record(); N.hamming_map(qp, ql, rp, rl, K, C); e1.record(); torch.cuda.synchr
 full = area.view(torch.int64).cpu().numpy()
 st = full[:6]
 d = [int(st[i + 1] - st[i]) for i in range(5)]
-print("one direction: %.3f ms; query 0 of workgroup 0, cycles per phase (100 MHz ticks?):" % e0.elapsed_time(e1))
+print("one direction: %.3f ms; query 0 of workgroup 0, cycles per phase (shader clock, ~2.1 GHz):" % e0.elapsed_time(e1))
 for name, v in zip(["keys", "bfs", "parked-seq", "leaf", "ap"], d):
     print(f"  {name:10s} {v:10d}")
 # a level was reached iff its stamp lies inside the breadth-first phase of this query
