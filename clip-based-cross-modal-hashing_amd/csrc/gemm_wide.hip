@@ -133,8 +133,9 @@ struct WideProblem {
 __device__ const uint4 g_wide_zero[16] = {};   // 256 zero bytes: the source of k-rows past the end of the Xk operand
 typedef __attribute__((ext_vector_type(2))) uint32_t w_u32x2_t;
 
-template <int DT, int OK, int MF, bool TN = false, bool GRP = false>   // DT: 0 f32, 1 bf16, 2 fp8 operands; OK: 0 f32, 1 16-bit (bf16 /
-                                    // fp16), 2 fp8 outputs; MF = 16-row m-fragments per wave: tile rows = 32*MF (160, 128 or 96); TN, GRP: above
+template <int DT, int OK, int MF, bool TN = false, bool GRP = false, bool DGE = false>   // DT: 0 f32, 1 bf16, 2 fp8 operands; OK: 0 f32, 1 16-bit (bf16 /
+                                    // fp16), 2 fp8 outputs; MF = 16-row m-fragments per wave: tile rows = 32*MF (160, 128 or 96); TN, GRP: above;
+                                    // DGE: the QuickGELU of a tile runs under the NEXT tile's MFMAs (see "deferred QuickGELU" below)
 __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__ X, const char* __restrict__ W,
                                                         const float* __restrict__ bias_a, const float* residual_a,
                                                         void* out_a, int Mub, int N_a, int K, int epi, int ksplit, int ordG,
@@ -168,6 +169,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   static_assert(MF >= 3 && MF <= 5, "wave layout: 2(m) x 4(n) waves of MF x 4 fragments");
   static_assert(!TN || (DT == 1 && OK == 0 && MF == 4), "TN: bf16 operands, f32 (split-K) output, 128-row tile");
   static_assert(!GRP || !TN, "grouped launches: the NT forward GEMMs only (no split-K, plain n-fastest tile order)");
+  static_assert(!DGE || (DT == 1 && OK == 1 && MF == 4 && !TN), "deferred QuickGELU: bf16 operands, 16-bit output, 128-row tile");
   constexpr int PSTEP = MF == 3 ? 2 : 3;             // one LDS-DMA piece per PSTEP MFMAs: 6 (MF = 3, 4) or 7 pieces in 4*MF MFMAs
   __shared__ __attribute__((aligned(1024))) char lds[3 * STG];
 
@@ -448,19 +450,57 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
 
   // ---- deferred stores of the previous tile (bf16 outputs only) --------------------------------------------
   constexpr bool DEFER = true;
-  w_u32x4_t pend[NPEND];
+  w_u32x4_t pend[DGE ? 1 : NPEND];
   bool pend_valid = false;
+  // Deferred QuickGELU (DGE, round 4).  Measured from outside (tools/gemm_tile_cost.py, profiles/r04_o_gemm_tile_cost.txt): a K-step of
+  // the 160-row tile costs 0.96 us and a tile switch 2.2 us - but 5.0 us when the epilogue carries QuickGELU: 80 accumulators per lane
+  // through v_exp_f32 + v_rcp_f32 (quarter rate) while the matrix pipe idles, a third of a c_fc tile at K = 768.  Here the tile's
+  // pre-activations (accumulator + bias, f32) move to 64 registers of their own instead of 32 packed ones, the next tile's K loop
+  // starts at once, and each of its first 8 K-steps activates, packs and stores one 16-byte piece per lane in the issue slots the MFMAs
+  // leave free.  Same arithmetic per element, same bits.  Only the 128-row tile has the registers (64 + 64 + 64 fragments).
+  w_f32x4_t pendf[DGE ? 4 : 1][DGE ? MF : 1];
   char* pend_ptr = nullptr;            // &out[(m0 + wm*WR + frow) * N + col] of the pending tile
   constexpr int OEL = OUT8 ? 1 : 2;    // bytes per output element of the packed store paths
   size_t row16 = static_cast<size_t>(16) * N * OEL;   // bytes between the 16-row fragments of a wave
   size_t pend_row16 = row16;                          // GRP: the same of the PENDING tile (it may belong to the first problem still)
   int sps = (NDEFER + nk - 1) / nk;   // stores per K-step so that all of them leave within one tile's K loop
   auto store_pending = [&](int idx) {
+    if constexpr (DGE) {
+      // piece idx = (m-fragment b, n-tile pair pr): its 8 pre-activations -> QuickGELU -> two packed words per n-tile -> the lane-pair
+      // exchange of the epilogue below -> one 16-byte store
+      auto gelu2 = [](float x, float y) {
+        const w_f32x2_t v = {x, y};
+        const w_f32x2_t t = v * w_f32x2_t{-2.4554669595930157f, -2.4554669595930157f};
+        const w_f32x2_t d = w_f32x2_t{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + w_f32x2_t{1.0f, 1.0f};
+        return v * w_f32x2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+      };
+      // (the pre-activations are read where they lie - a copy per piece would cost 8 more registers next to 192 that cannot move)
+      auto piece = [&](const w_f32x4_t& va, const w_f32x4_t& vb) __attribute__((always_inline)) {
+        uint32_t lo[2], hi[2];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          const w_f32x2_t ga = gelu2(va[2 * w], va[2 * w + 1]);
+          lo[w] = (epi & EPI_OUT_F16) ? pack_f16x2(ga[0], ga[1]) : pack_bf16x2(ga[0], ga[1]);
+          const w_f32x2_t gb = gelu2(vb[2 * w], vb[2 * w + 1]);
+          hi[w] = (epi & EPI_OUT_F16) ? pack_f16x2(gb[0], gb[1]) : pack_bf16x2(gb[0], gb[1]);
+        }
+        const w_u2_t s0 = __builtin_amdgcn_permlane16_swap(lo[0], hi[0], false, false);
+        const w_u2_t s1 = __builtin_amdgcn_permlane16_swap(lo[1], hi[1], false, false);
+        w_store16(pend_ptr + (idx / 2) * (GRP ? pend_row16 : row16) + (idx % 2) * 64, w_u32x4_t{s0[0], s1[0], s0[1], s1[1]});
+      };
+      switch (idx) {   // compile-time register choice per case
+#define W_PF(j) case j: piece(pendf[2 * (j % 2)][(j / 2) < MF ? (j / 2) : 0], pendf[2 * (j % 2) + 1][(j / 2) < MF ? (j / 2) : 0]); break;
+        W_PF(0) W_PF(1) W_PF(2) W_PF(3) W_PF(4) W_PF(5) W_PF(6)
+#undef W_PF
+        default: piece(pendf[2][MF - 1], pendf[3][MF - 1]); break;
+      }
+    } else {
     switch (idx) {   // compile-time register choice per case: no dynamically indexed vector arrays (they would go to scratch)
 #define W_ST(j) case j: if constexpr (j < NPEND) w_store16(pend_ptr + (OUT8 ? j : j / 2) * (GRP ? pend_row16 : row16) + (OUT8 ? 0 : (j % 2) * 64), pend[j < NPEND ? j : 0]); break;
       W_ST(0) W_ST(1) W_ST(2) W_ST(3) W_ST(4) W_ST(5) W_ST(6) W_ST(7) W_ST(8) W_ST(9)
 #undef W_ST
       default: break;
+    }
     }
   };
 
@@ -734,7 +774,109 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
       }
     }
 
-    for (int kt = 0; kt < nk; ++kt) {
+    // DGE: the bf16 K-step below with piece J of the previous tile's deferred QuickGELU BETWEEN this wave's own MFMAs (J < 0: none).
+    // In-order issue is what bounds a K-step (a wave issues in ~30 % of its cycles): the same 36 VALU instructions placed in front of
+    // the MFMA burst cost the K-step what they cost the epilogue (tile switch 3.4 us either way, tools/gemm_tile_cost.py), while one
+    // v_exp / v_mul behind every MFMA of EVERY K-step costs 5 % of a K-step (diagnostic build) - so: one 2-value step of
+    // the activation behind each MFMA of the half in which this wave issues no LDS-DMA, four MFMAs per pair of values, the lane-pair
+    // exchange and the 16-byte store after the sixteenth.  The piece is a compile-time index: its registers are named, not indexed.
+    [[maybe_unused]] auto kstep_dge = [&](auto jc) __attribute__((always_inline)) {
+      if constexpr (DGE) {
+        constexpr int J = decltype(jc)::value;
+        constexpr int PB = J >= 0 ? J / 2 : 0, PR = J >= 0 ? J % 2 : 0;
+        w_f32x2_t gx[4];
+        uint32_t gword[4];
+        auto micro = [&](int i) __attribute__((always_inline)) {
+          if constexpr (J >= 0) {
+            const int pq = i >> 2, ph = i & 3;                      // pair 0: tile 2PR values 0,1; 1: tile 2PR+1 values 0,1; 2, 3: values 2,3
+            const w_f32x4_t& src = (pq & 1) ? pendf[2 * PR + 1][PB] : pendf[2 * PR][PB];
+            const w_f32x2_t v = {src[2 * (pq >> 1)], src[2 * (pq >> 1) + 1]};
+            if (ph == 0) {
+              gx[pq] = v * w_f32x2_t{-2.4554669595930157f, -2.4554669595930157f};
+            } else if (ph == 1) {
+              gx[pq] = w_f32x2_t{__builtin_amdgcn_exp2f(gx[pq][0]), __builtin_amdgcn_exp2f(gx[pq][1])};
+            } else if (ph == 2) {
+              const w_f32x2_t d = gx[pq] + w_f32x2_t{1.0f, 1.0f};
+              gx[pq] = w_f32x2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+            } else {
+              const w_f32x2_t o = v * gx[pq];
+              gword[pq] = (epi & EPI_OUT_F16) ? pack_f16x2(o[0], o[1]) : pack_bf16x2(o[0], o[1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        };
+        auto piece_out = [&]() __attribute__((always_inline)) {
+          if constexpr (J >= 0) {
+            const w_u2_t s0 = __builtin_amdgcn_permlane16_swap(gword[0], gword[1], false, false);
+            const w_u2_t s1 = __builtin_amdgcn_permlane16_swap(gword[2], gword[3], false, false);
+            w_store16(pend_ptr + PB * (GRP ? pend_row16 : row16) + PR * 64, w_u32x4_t{s0[0], s1[0], s0[1], s1[1]});
+            ++ns;
+          }
+        };
+        load_frags(f1w, f1x, cur, 1);
+        W_WAIT_FRAGS(8, f0w, f0x);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(GB ? 0 : 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+          if constexpr (GB) { if (i % PSTEP == 0) issue_piece(i / PSTEP); }
+          mfma(f0w[i / MF], f0x[i % MF], acc[i / MF][i % MF]);
+          if constexpr (!GB) micro(i);
+          if constexpr (GB) { if (i % 3 == 2) __builtin_amdgcn_sched_barrier(0); }
+        }
+        if constexpr (GB) issue_done();
+        if constexpr (!GB) piece_out();
+        __builtin_amdgcn_sched_barrier(0);
+        W_WAIT_FRAGS(0, f1w, f1x);
+        if (ns == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (ns == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        ns = 0;
+        __builtin_amdgcn_s_barrier();
+        const int nxt = cur == 2 ? 0 : cur + 1;
+        {
+          const uint32_t bo = static_cast<uint32_t>(nxt) * STG;
+          const uint32_t nW = aW + bo, nX = aX + bo;
+          __builtin_amdgcn_s_setprio(GB ? 1 : 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < NM; ++i) {
+            if constexpr (!GB) { if (i % PSTEP == 0) issue_piece(i / PSTEP); }
+            if (i == 1) W_READ(f0w[0], nW, 0);
+            if (i == 2) W_READ(f0w[1], nW, 2048);
+            if (i == 3) W_READ(f0w[2], nW, 4096);
+            if (i == 4) W_READ(f0w[3], nW, 6144);
+            if (i == 5) W_READ(f0x[0], nX, 0);
+            if (i == 6) W_READ(f0x[1], nX, 2048);
+            if (i == 7) W_READ(f0x[2], nX, 4096);
+            if (i == 8) W_READ(f0x[MF >= 4 ? 3 : 0], nX, 6144);
+            mfma(f1w[i / MF], f1x[i % MF], acc[i / MF][i % MF]);
+            if constexpr (GB) micro(i);
+            if (i % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+          }
+          if constexpr (!GB) issue_done();
+          if constexpr (GB) piece_out();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+      }
+    };
+    int kt_first = 0;
+    if constexpr (DGE) {
+      // straight-line: the first 8 K-steps of a tile that follows a deferred one carry its pieces (nk >= 8: wide_dge_applies)
+      if (pend_valid) {
+        kstep_dge(std::integral_constant<int, 0>{}); kstep_dge(std::integral_constant<int, 1>{});
+        kstep_dge(std::integral_constant<int, 2>{}); kstep_dge(std::integral_constant<int, 3>{});
+        kstep_dge(std::integral_constant<int, 4>{}); kstep_dge(std::integral_constant<int, 5>{});
+        kstep_dge(std::integral_constant<int, 6>{}); kstep_dge(std::integral_constant<int, 7>{});
+        kt_first = NPEND;
+      }
+    }
+    for (int kt = kt_first; kt < nk; ++kt) {
+      if constexpr (DGE) {
+        kstep_dge(std::integral_constant<int, -1>{});
+      } else
       if constexpr (TN) {
         // ---- TN K-step: the bf16 step below with every ds_read_b128 replaced by two transposing 8-byte reads ----------------
         {
@@ -946,6 +1088,32 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
         if (mc < M) sc.colsum[static_cast<size_t>(split) * M + mc] = csacc[0];
       }
     }
+    if constexpr (DGE) {
+      // ---- deferred QuickGELU: epi = [bias] + QuickGELU + 16-bit output, nothing else (wide_dge_applies).  The pre-activations move to
+      // pendf - the accumulators are free for the next tile at once; a workgroup's last tile and partial tiles finish here.
+      {
+        w_f32x4_t bv[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+          bv[a] = (epi & EPI_BIAS) ? *reinterpret_cast<const w_f32x4_t*>(bias + n0 + wn * 64 + a * 16 + fq * 4) : w_f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < MF; ++b) pendf[a][b] = acc[a][b] + bv[a];
+      }
+      pend_ptr = static_cast<char*>(out) + (static_cast<size_t>(m0 + wm * WR + frow) * N + n0 + wn * 64 + (fq & 1) * 16 + (fq & 2) * 4) * 2;
+      if constexpr (GRP) pend_row16 = row16;
+      const bool full = m0 + BMt <= M;
+      if (full && ti + 1 < my_tiles) {
+        pend_valid = true;
+      } else {
+#pragma unroll
+        for (int j = 0; j < NPEND; ++j)
+          if (m0 + wm * WR + (j / 2) * 16 + frow < M) store_pending(j);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ns = 0;
+      }
+    } else {
     // All loads first, then all stores: a load issued behind a store (or waited for with DMA in flight) would wait for
     // every older store to be acknowledged.
     if (FP8 && (epi & EPI_SCALE)) {   // dequantisation of fp8 operands, fused with the bias: acc * (alpha * colscale[n]) + bias[n]
@@ -1151,6 +1319,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
     // Epilogue-issued stores are younger than every DMA in flight, so the next counted waits (P + ns outstanding) would
     // simply also retire the DMAs: safe, slightly conservative.  A partial tile may have skipped store instructions.
     if (!full) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ns = 0; }
+    }
     if (ti == my_tiles - 1) W_TL(4);   // last epilogue's stores issued
   }
   };
@@ -1193,6 +1362,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // Tuning overrides (cmh_gemm_tuning; initial values from CMH_GEMM_BM / CMH_GEMM_ORDER): -1 = decided per launch
 static int g_force_rows = []() { const char* e = getenv("CMH_GEMM_BM"); return e ? atoi(e) : -1; }();
 static int g_force_order = []() { const char* e = getenv("CMH_GEMM_ORDER"); return e ? atoi(e) : -1; }();
+
+// Deferred QuickGELU (template parameter DGE): which launches take it, and what the activation costs a tile switch in the cost
+// models below, in K-steps (tools/gemm_tile_cost.py: switch 1.70 / 1.77 / 2.19 us with a bias epilogue, 3.02 / 3.40 / 5.04 us with
+// QuickGELU at 96 / 128 / 160 rows, K-steps of 0.68 / 0.80 / 0.96 us).  CMH_GEMM_DGE=0 turns the variant off (A/B runs).
+static bool wide_dge_enabled() {
+  static const bool off = []() { const char* e = getenv("CMH_GEMM_DGE"); return e && e[0] == '0'; }();
+  return !off;
+}
+static bool wide_dge_applies(int dt, int epi, int mf, int kmin) {   // kmin: the shortest K of the launch - a tile's 8 pieces need 8 K-steps of the next
+  return wide_dge_enabled() && dt == CMH_BF16 && mf == 4 && kmin >= 8 * 64 && (epi & EPI_QUICKGELU) && (epi & (EPI_OUT_BF16 | EPI_OUT_F16)) &&
+         !(epi & ~(EPI_BIAS | EPI_QUICKGELU | EPI_OUT_BF16 | EPI_OUT_F16));
+}
+static int wide_gelu_ksteps(int dt, int epi, int mf, int kmin) {
+  if (!(epi & EPI_QUICKGELU) || wide_dge_applies(dt, epi, mf, kmin)) return 0;
+  return mf == 5 ? 3 : 2;
+}
 
 // n-panels per group of the tile order (see tile_coords in the kernel); 0 = the n-fastest order
 static int wide_order_group(int N) {
@@ -1308,7 +1493,7 @@ int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, co
   const int Mc = m_dev && m_hint > 0 && m_hint <= M ? m_hint : M;   // the tile height is chosen for the likely row count
   auto cost = [&](int mf) {   // rounds x (rows + the per-K-step cost that does not shrink with the tile: W fragment reads, barrier) x K-steps
     const int tiles = (N / wBN) * ((Mc + 32 * mf - 1) / (32 * mf));
-    return static_cast<long long>((tiles + cus - 1) / cus) * (10 * mf + 6) * (nk + 4);
+    return static_cast<long long>((tiles + cus - 1) / cus) * (10 * mf + 6) * (nk + 4 + wide_gelu_ksteps(dt, epi, mf, K));
   };
   const int forced = g_force_rows;
   // fp8: 160 rows by default only with e4m3 OUTPUT (the c_fc launches).  The 160-row variant needs 56 fragment registers live across the epilogue
@@ -1343,7 +1528,13 @@ int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, co
   const bool obf = epi & (EPI_OUT_BF16 | EPI_OUT_F16);   // 16-bit outputs share the packed store path
   const bool o8 = epi & EPI_OUT_FP8;
   if (dt == CMH_F32) { if (obf) W_LAUNCH(0, 1); else W_LAUNCH(0, 0); }
-  else if (dt == CMH_BF16) { if (obf) W_LAUNCH(1, 1); else W_LAUNCH(1, 0); }
+  else if (dt == CMH_BF16) {
+    if (obf && wide_dge_applies(dt, epi, mf, K))
+      W_GO((gemm_wide_kernel<1, 1, 4, false, false, true>), grid, st, static_cast<const char*>(A), static_cast<const char*>(W), bias,
+           residual, out, M, N, K, epi, 1, ordg, sc, WideProblem{});
+    else if (obf) W_LAUNCH(1, 1);
+    else W_LAUNCH(1, 0);
+  }
   else {
 #undef W_LAUNCH
 #define W_LAUNCH(DT, OK)                                                                                                  \
@@ -1390,7 +1581,7 @@ static long long wide_plain_cost(int dt, const GemmProblem& g, int epi, int cus)
   long long best = -1;
   for (int mf = (dt == CMH_FP8 && !(epi & EPI_OUT_FP8)) ? 4 : 5; mf >= 3; --mf) {
     const int tiles = (g.N / wBN) * ((M + 32 * mf - 1) / (32 * mf));
-    const long long c = static_cast<long long>((tiles + cus - 1) / cus) * (10 * mf + 6) * (nk + 4);
+    const long long c = static_cast<long long>((tiles + cus - 1) / cus) * (10 * mf + 6) * (nk + 4 + wide_gelu_ksteps(dt, epi, mf, g.K));
     if (best < 0 || c < best) best = c;
   }
   return best;
@@ -1421,7 +1612,8 @@ static long long wide_grouped_cost(int dt, const GemmProblem& a, const GemmProbl
       for (int sl = 0; sl < per; ++sl) {
         const int n0 = sl < len0 ? (len0 - sl + per - 1) / per : 0;
         const int nall = sl < len0 + len1 ? (len0 + len1 - sl + per - 1) / per : 0;
-        const long long c = static_cast<long long>(n0) * (nk0 + 4) + static_cast<long long>(nall - n0) * (nk1 + 4);
+        const int ge = wide_gelu_ksteps(dt, epi, mf, a.K < b.K ? a.K : b.K);
+        const long long c = static_cast<long long>(n0) * (nk0 + 4 + ge) + static_cast<long long>(nall - n0) * (nk1 + 4 + ge);
         worst = c > worst ? c : worst;
       }
     }
@@ -1466,7 +1658,11 @@ int launch_gemm_wide_grouped(int dt, const GemmProblem& a, const GemmProblem& b,
     W_LAUNCH_G3(0, 0);
   } else if (dt == CMH_BF16) {
     if (!obf) return fail(CMH_ERR_INVALID, "gemm (grouped): bf16 operands come with 16-bit outputs");
-    W_LAUNCH_G3(1, 1);
+    if (wide_dge_applies(dt, epi, mf, a.K < b.K ? a.K : b.K))
+      W_GO((gemm_wide_kernel<1, 1, 4, false, true, true>), grid, st, static_cast<const char*>(a.A), static_cast<const char*>(a.W), a.bias,
+           a.residual, a.out, a.M, a.N, a.K, epi, 1, 0, sc, p1);
+    else
+      W_LAUNCH_G3(1, 1);
   } else if (epi & EPI_OUT_FP8) {
     W_LAUNCH_G3(2, 2);
   } else {

@@ -5,7 +5,7 @@ L = open(sys.argv[1]).read().split('\n')
 want = tuple(sys.argv[2:5])
 i = 0
 while i < len(L):
-    m = re.match(r'_ZN3cmh16gemm_wide_kernelILi(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)', L[i])
+    m = re.match(r'_ZN3cmh16gemm_wide_kernelILi(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)(?:ELb(\d))?', L[i])
     if not m:
         i += 1
         continue

@@ -22,6 +22,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--iters", type=int, default=100)
 ap.add_argument("--only", default="")
+ap.add_argument("--quickgelu", action="store_true", help="bias + QuickGELU epilogue (the c_fc launches)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 tot_t = tot_f = 0.0
@@ -33,12 +34,12 @@ for name, (M, Nn, K) in SHAPES.items():
     w = (torch.randn(Nn, K, device=dev) * K ** -0.5).to(dt)
     b = torch.randn(Nn, device=dev)
     for _ in range(max(3, a.iters // 4)):   # also lets the clocks settle
-        N.linear_gemm(x, w, bias=b, out_bf16=(a.dtype == "bf16"))
+        N.linear_gemm(x, w, bias=b, quickgelu=a.quickgelu, out_bf16=(a.dtype == "bf16"))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
     for _ in range(a.iters):
-        N.linear_gemm(x, w, bias=b, out_bf16=(a.dtype == "bf16"))
+        N.linear_gemm(x, w, bias=b, quickgelu=a.quickgelu, out_bf16=(a.dtype == "bf16"))
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / a.iters
