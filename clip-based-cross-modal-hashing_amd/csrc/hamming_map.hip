@@ -942,6 +942,7 @@ struct MapArgs {
   int stable;                 // CMH_TIE_STABLE: full sort of (key, index) instead of the introsort emulation
   float* ap;
   int32_t* perm;              // may be null
+  const uint32_t* r_all_nz;   // device word, nonzero: every database code has all `bits` positions nonzero (+-1 codes) - r_nz is not read
   uint32_t* gstore;           // workspace slices (MODE 0: gridDim.x * store_words(N); MODE 2: gridDim.x * hybrid_glob_words(N))
   unsigned long long* stamps; // optional: 6 cycle stamps of (workgroup 0, first query) at the phase boundaries (diagnostics)
 };
@@ -978,17 +979,26 @@ __global__ __launch_bounds__(NT, WAVES) void map_query_kernel(MapArgs A) {
     for (int i = tid; i < bw; i += NT) S.relbits[i] = 0;
     __syncthreads();
     int myrel = 0;
+    const bool r_full = *A.r_all_nz != 0u;
     for (int j0 = 0; j0 < N; j0 += NT) {
       const int j = j0 + tid;
       bool rel = false;
       if (j < N) {
         int both = 0, diff = 0;
         const uint32_t* rs = A.r_sign + static_cast<size_t>(j) * W;
+        if (r_full) {               // +-1 database codes: nz(r) is all ones on the code's bits, which nz(q) has already been cut to
+          for (int w = 0; w < W; ++w) {
+            const uint32_t nz = sq[1][w];
+            both += __popc(nz);
+            diff += __popc((sq[0][w] ^ rs[w]) & nz);
+          }
+        } else {
         const uint32_t* rn = A.r_nz + static_cast<size_t>(j) * W;
         for (int w = 0; w < W; ++w) {
           const uint32_t nz = sq[1][w] & rn[w];
           both += __popc(nz);
           diff += __popc((sq[0][w] ^ rs[w]) & nz);
+        }
         }
         const int key = A.bits - (both - 2 * diff);        // = K - q.r, in [0, 2K]
         e[j] = (static_cast<uint32_t>(key) << kIdxBits) | static_cast<uint32_t>(j);
@@ -1139,6 +1149,18 @@ __global__ __launch_bounds__(NT, WAVES) void map_query_kernel(MapArgs A) {
       if (A.stamps && blockIdx.x == 0 && qi == 0) A.stamps[5] = __builtin_readcyclecounter();
     }
   }
+}
+
+// Does every database code have all of its `bits` positions nonzero?  (codes are sign() of real features: zeros essentially never
+// occur, and then the nz plane - half of the 6 MB of codes a NUS-WIDE query streams in its key phase - need not be read at all.)
+// flag: preset nonzero; any word that differs from the full mask clears it.
+__global__ __launch_bounds__(256) void nz_all_ones_kernel(const uint32_t* __restrict__ nz, int64_t n, int bits, int W, uint32_t* flag) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n * W) return;
+  const int w = static_cast<int>(i % W);
+  const int cntb = bits - w * 32 < 32 ? bits - w * 32 : 32;
+  const uint32_t full = cntb == 32 ? 0xffffffffu : (1u << cntb) - 1u;
+  if (nz[i] != full) *flag = 0u;
 }
 
 // map = (((ap[0] + ap[1]) + ...) / Q) in f32, query order, like the reference's `map += AP` (:37-38)
@@ -1334,9 +1356,10 @@ extern "C" size_t cmh_map_workspace_bytes(int32_t Q, int64_t N, int32_t bits, in
   const size_t slots = static_cast<size_t>(map_slots(Q));
   const MapMode mode = map_mode(N);       // (the same decision cmh_hamming_map takes, CMH_MAP_MODE included)
   const size_t stamps = getenv("CMH_MAP_STAMPS") ? 32768 : 0;      // diagnostics (tools/map_stamps.py): behind the slices
-  if (mode == MAP_GLOBAL) return slots * store_words(N) * 4 + 256 + stamps;
-  if (mode == MAP_HYBRID || mode == MAP_HYBRID1) return slots * hybrid_glob_words(N) * 4 + 256 + stamps;
-  return 4096;                            // all-LDS placements: only the optional diagnostics stamps live here
+  // (+ 64: the "database codes have no zeros" word, behind everything else)
+  if (mode == MAP_GLOBAL) return slots * store_words(N) * 4 + 256 + stamps + 64;
+  if (mode == MAP_HYBRID || mode == MAP_HYBRID1) return slots * hybrid_glob_words(N) * 4 + 256 + stamps + 64;
+  return 4096 + 64;                       // all-LDS placements: only the optional diagnostics stamps live here
 }
 
 extern "C" int cmh_hamming_map(const uint32_t* q_sign, const uint32_t* q_nz, const uint32_t* q_label,
@@ -1360,6 +1383,14 @@ extern "C" int cmh_hamming_map(const uint32_t* q_sign, const uint32_t* q_nz, con
   a.gstore = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
   const MapMode mode = map_mode(N);
   // diagnostics stamps (tools/map_stamps.py, CMH_MAP_MODE=lds1): only where the workspace holds nothing else
+  {
+    uint32_t* flag = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(workspace) + need - 64 + 3) & ~static_cast<uintptr_t>(3));
+    const int64_t words = N * a.W;
+    if (hipMemsetAsync(flag, 1, 4, st) != hipSuccess) return fail(CMH_ERR_LAUNCH, "hamming_map: memset failed");
+    hipLaunchKernelGGL(nz_all_ones_kernel, dim3(static_cast<unsigned>((words + 255) / 256)), dim3(256), 0, st, r_nz, N, bits, a.W, flag);
+    CMH_CHECK_LAUNCH("nz_all_ones");
+    a.r_all_nz = flag;
+  }
   a.stamps = nullptr;
   if (getenv("CMH_MAP_STAMPS")) {
     if (mode == MAP_LDS1 || mode == MAP_LDS2) a.stamps = reinterpret_cast<unsigned long long*>(a.gstore);

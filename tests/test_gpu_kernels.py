@@ -43,6 +43,29 @@ def test_gemm_epilogues(M, N, K, mode):
     torch.testing.assert_close(out.cpu().double(), base + b.double() + r.double(), **tol)
 
 
+@pytest.mark.parametrize("M,N,K", [(12800, 3072, 768), (10499, 2048, 512), (6500, 1024, 1024)])
+@pytest.mark.parametrize("out", ["bf16", "f16"])
+def test_deferred_quickgelu_gives_the_epilogue_bits(M, N, K, out):
+    """csrc/gemm_wide.hip, DGE: on the 128-row tile the QuickGELU of a tile runs between the NEXT tile's MFMAs (several tiles per
+    workgroup at these sizes, the last one partial).  Same arithmetic per element as the 160- and 96-row tiles' epilogues: equal bits."""
+    import cmh_native as Nn
+    g = torch.Generator().manual_seed(M + N + K)
+    xd = torch.randn(M, K, generator=g).bfloat16().to(_dev())
+    wd = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().to(_dev())
+    bd = torch.randn(N, generator=g).to(_dev())
+    outs = {}
+    try:
+        for rows in (128, 160, 96, -1):
+            Nn.gemm_tuning(rows, -1)
+            outs[rows] = Nn.linear_gemm(xd, wd, bias=bd, quickgelu=True, out_bf16=out == "bf16", out_f16=out == "f16")
+    finally:
+        Nn.gemm_tuning(-1, -1)
+    v = xd[:64].double() @ wd.double().t() + bd.double()
+    torch.testing.assert_close(outs[128][:64].double(), v * torch.sigmoid(1.702 * v), rtol=1e-2, atol=1e-2)
+    for rows in (160, 96, -1):
+        assert torch.equal(outs[128], outs[rows]), rows
+
+
 @pytest.mark.parametrize("M,N,K", [(1000, 2304, 768), (10499, 512, 512), (3000, 1536, 512), (777, 768, 3072)])
 def test_gemm_wide_tile_variants(M, N, K):
     """Every tile height (96 / 128 / 160 rows) and both tile orders of the wide kernel give the SAME bits (an output element is

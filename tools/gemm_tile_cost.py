@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=60)
 ap.add_argument("--rows", type=int, default=10240)
 ap.add_argument("--epi", default="", help="only the epilogues whose name contains this")
+ap.add_argument("--fp8", action="store_true", help="e4m3 operands (K-steps of 128), e4m3 output for the bias / QuickGELU legs")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 M = a.rows
@@ -33,6 +34,13 @@ for epi_name, kw in (("bias", {}), ("bias + QuickGELU", {"quickgelu": True}), ("
                 k2["residual"] = torch.randn(M, Nn, device=dev)
                 obf = False
             f = lambda: N.linear_gemm(x, w, bias=b, out_bf16=obf, **k2)
+            if a.fp8:
+                if not obf:
+                    continue
+                x8 = torch.randint(0, 120, (M, K), dtype=torch.uint8, device=dev)
+                w8 = torch.randint(0, 120, (Nn, K), dtype=torch.uint8, device=dev)
+                cs = torch.ones(Nn, device=dev)
+                f = lambda: N.linear_gemm_fp8(x8, w8, cs, 1e-3, bias=b, out="fp8", out_scale=1.0, **k2)
             for _ in range(15):
                 f()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -41,7 +49,7 @@ for epi_name, kw in (("bias", {}), ("bias + QuickGELU", {"quickgelu": True}), ("
                 f()
             e1.record(); torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / a.iters
-            nk = K // 64
+            nk = K // (128 if a.fp8 else 64)
             rows.append([1.0, R * nk, R - 1]); ts.append(us)
             print(f"  {epi_name:30s} R={R} K={K:5d}: {us:8.2f} us  ({2.0 * M * Nn * K / us / 1e6:7.1f} TF/s)", flush=True)
     sol, res, *_ = np.linalg.lstsq(np.array(rows), np.array(ts), rcond=None)

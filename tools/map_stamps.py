@@ -18,7 +18,7 @@ for _ in range(2):
 torch.cuda.synchronize()
 ws = N.workspace(0, dev, "map")
 need = N.lib().cmh_map_workspace_bytes(Q, Nn, K, 0)
-off = 0 if need <= 4096 + 32768 else (need - 32768 - 256)          # all-LDS placements: the stamps are the workspace; else behind the slices
+off = 0 if need <= 4096 + 64 + 32768 else (need - 32768 - 256 - 64)          # all-LDS placements: the stamps are the workspace; else behind the slices
 base = (ws.data_ptr() + 255) // 256 * 256 - ws.data_ptr() + off
 area = ws[base:base + 3072 * 8]
 area.zero_()                   # the stamp area: levels the run never reaches must read as zero, not as whatever the buffer held
