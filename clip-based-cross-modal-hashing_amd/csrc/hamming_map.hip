@@ -45,6 +45,15 @@ constexpr int kMaxWords = 64;      // K <= 2048 bits
 #define CMH_MAP_SEQMAX 32
 #endif
 constexpr int kChunk = CMH_MAP_CHUNK;       // a longer segment is partitioned in chunks of this many positions, one wave per chunk
+#ifndef CMH_MAP_CHUNK_MASKS
+#define CMH_MAP_CHUNK_MASKS 4096
+#endif
+// ... and of this many where the chunk passes work on bit masks (the workspace placement): fewer, longer walks per level.  A/B on one
+// box, one direction: COCO 5000 x 117 218: 35.7 ms (1024) / 32.7 (2048) / 32.4 (4096), NUS-WIDE 2100 x 190 834 x 128 bit: 28.8 / 26.1 /
+// 25.4; 512: 43.4 / 34.9.  (The LDS placements lose with 2048: MIRFlickr 2.77 -> 2.93 ms.)  64 groups of 64 positions is the most a
+// wave's one-pass seek inside a chunk covers.
+constexpr int kChunkMasks = CMH_MAP_CHUNK_MASKS;
+static_assert(kChunk % 64 == 0 && kChunkMasks % 64 == 0 && kChunkMasks >= kChunk, "chunks are whole 64-position groups; the stores are sized for kChunk");
 constexpr int kLeaf = 16;          // libstdc++ _S_threshold
 constexpr int kSeqMax = CMH_MAP_SEQMAX;        // segments of 17..kSeqMax elements are finished sequentially, one lane each
 
@@ -354,8 +363,11 @@ __device__ inline int partition_wave(const QueryStore& S, int f, int l, int lane
 #define CMH_MAP_UNROLL_A 4        // 64-position groups in flight per wave in the count pass (16: the same time)
 #endif
 #ifndef CMH_MAP_SWAP_BLOCKS
-#define CMH_MAP_SWAP_BLOCKS 1     // 64-rank blocks per iteration of the swap pass.  2: the same time, 4: +11 % (COCO 40.1 ms against 35.9): the
-#endif                            // levels run at the memory system's rate for this mix of gathers and partial-line writes, not at a wave's latency
+#define CMH_MAP_SWAP_BLOCKS 1     // 64-rank blocks per iteration of the swap pass.  2: the same time, 4: +11 % (COCO 40.1 ms against 35.9).
+#endif                            // (Also tried: no rank buffers - what is left of the current L group paired directly with what is left of the
+                                  // current R group, ~20 pairs per step: swap pass 0.5-0.65 M -> 0.75-1.26 M cycles per level, NUS-WIDE 25.2 -> 29.5 ms:
+                                  // the pass costs one dependent gather -> scatter round trip per step, so fewer, fuller steps win.  And the
+                                  // full fence of wave_sync() in this loop (it also waits for the stores) against an LDS-only wait: no difference.)
 // mask area of a chunked segment [f, l): u32 words inside its tmp slice: [Lc, Rc, -, -], then per group g (positions f+1+64g ...) four
 // words: L lo, L hi, R lo, R hi.  4 + 4 * ceil((l-f-1)/64) <= (l-f) - 3 words for every l-f > kChunk.
 __device__ __forceinline__ uint32_t* mask_area(const QueryStore& S, int f) {      // 16-byte aligned ADDRESS (tmp itself may not be)
@@ -382,9 +394,10 @@ __device__ __forceinline__ void cursor_window(MaskCursor& c, int g0, int lane) {
 __device__ __forceinline__ uint64_t cursor_mask(MaskCursor& c, int g, int lane) {   // g in [0, ngroups)
   int k = c.desc ? c.gwin - g : g - c.gwin;
   if (k < 0 || k > 63) { cursor_window(c, g, lane); k = 0; }
-  const uint32_t lo = static_cast<uint32_t>(__shfl(static_cast<int>(c.wlo), k, 64)), hi = static_cast<uint32_t>(__shfl(static_cast<int>(c.whi), k, 64));
-  const uint32_t ulo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(lo)));      // (an int: no sign extension)
-  const uint32_t uhi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(hi)));
+  // lane k's words, by v_readlane (k is wave-uniform; a __shfl here is two LDS round trips on the walk's critical path)
+  const int ks = __builtin_amdgcn_readfirstlane(k);
+  const uint32_t ulo = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(c.wlo), ks));      // (ints: no sign extension)
+  const uint32_t uhi = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(c.whi), ks));
   return static_cast<uint64_t>(ulo) | (static_cast<uint64_t>(uhi) << 32);
 }
 // bits of m above lane's own
@@ -392,6 +405,7 @@ __device__ __forceinline__ int bits_above(uint64_t m, int lane) { return lane ==
 
 // The entry of walk rank `target` (0-based; it exists): positions the cursor on its group with every earlier entry of that group
 // cleared.  pref[c] = entries in the chunks walked before chunk c (exclusive prefix, ascending for L, from the top for R).
+template <int kGpc>      // 64-position groups per chunk
 __device__ inline void cursor_seek(MaskCursor& c, const uint32_t* pref, int nc, int target, int lane) {
   int cle = 0;
   for (int c0 = 0; c0 < nc; c0 += 64) {
@@ -401,8 +415,7 @@ __device__ inline void cursor_seek(MaskCursor& c, const uint32_t* pref, int nc, 
   const int ch = c.desc ? nc - cle : cle - 1;
   const int skip = target - static_cast<int>(pref[ch]);
   // the chunk's groups in walk order on the first kGpc lanes
-  constexpr int kGpc = kChunk / 64;
-  static_assert(kChunk % 64 == 0 && kGpc <= 64, "a chunk is a whole number (<= 64) of 64-position groups");
+  static_assert(kGpc >= 1 && kGpc <= 64, "a chunk is a whole number (<= 64) of 64-position groups");
   const int gfirst = c.desc ? (kGpc * ch + kGpc - 1 < c.ngroups - 1 ? kGpc * ch + kGpc - 1 : c.ngroups - 1) : kGpc * ch;
   const int g = c.desc ? gfirst - lane : gfirst + lane;
   const bool valid = lane < kGpc && g >= kGpc * ch && g < c.ngroups && g < kGpc * ch + kGpc;
@@ -462,9 +475,10 @@ __device__ __forceinline__ MaskCursor make_cursor(const QueryStore& S, int f, in
   return c;
 }
 // position of the entry of walk rank `target` (wave-uniform)
+template <int kGpc>
 __device__ inline int cursor_select(const QueryStore& S, int f, int l, bool desc, const uint32_t* pref, int nc, int target, int lane) {
   MaskCursor c = make_cursor(S, f, l, desc);
-  cursor_seek(c, pref, nc, target, lane);
+  cursor_seek<kGpc>(c, pref, nc, target, lane);
   const int b = desc ? 63 - __clzll(static_cast<long long>(c.m)) : __ffsll(static_cast<long long>(c.m)) - 1;
   return c.xbase + 64 * c.gi + b;
 }
@@ -534,6 +548,7 @@ __device__ inline void seq_finish_segment(uint32_t* e, uint32_t* stack, uint32_t
 
 template <bool MASKS>
 __device__ __forceinline__ void introsort_phases(const QueryStore& S, int N, int depth0, const WgCtx& C, unsigned long long* st) {
+  constexpr int CH = MASKS ? kChunkMasks : kChunk;      // positions per chunk task
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   uint32_t* e = S.elem;
   const int bw = (N + 31) / 32;
@@ -568,11 +583,11 @@ __device__ __forceinline__ void introsort_phases(const QueryStore& S, int N, int
     --depth;
     if (tid == 0) { sqcount[cur ^ 1] = 0; stask[0] = 0; stask[1] = 0; stask[2] = 0; }      // tasks, chunks, next task
     __syncthreads();
-    // -- work list of the level: a segment of more than kChunk positions is cut into chunk tasks (its median moves to the front
+    // -- work list of the level: a segment of more than CH positions is cut into chunk tasks (its median moves to the front
     //    here), a shorter one is one task.  Tasks go to the waves round-robin, so one long segment no longer holds a level up.
     for (int si = tid; si < nseg; si += NT) {
       const int f = static_cast<int>(qcur[2 * si]), l = static_cast<int>(qcur[2 * si + 1]);
-      const int nc = (l - f - 1 > kChunk) ? (l - f - 2 + kChunk) / kChunk : 1;
+      const int nc = (l - f - 1 > CH) ? (l - f - 2 + CH) / CH : 1;
       const int base = atomicAdd(&stask[0], nc);
       int cbase = 0;
       if (nc > 1) { median_to_first(e, f, l); cbase = atomicAdd(&stask[1], nc); }
@@ -588,7 +603,7 @@ __device__ __forceinline__ void introsort_phases(const QueryStore& S, int N, int
     uint32_t* cntS = S.cnt + 2 * S.ccap;
     // -- A: whole short segments; L / R counts of the chunks
     int guard = 0;
-    while (true) {                                            // tasks differ in length (33..kChunk+1 positions): first come, first served
+    while (true) {                                            // tasks differ in length (33..CH+1 positions): first come, first served
       int t = 0;
       if (lane == 0) t = atomicAdd(&stask[2], 1);
       t = __builtin_amdgcn_readfirstlane(t);
@@ -607,10 +622,10 @@ __device__ __forceinline__ void introsort_phases(const QueryStore& S, int N, int
           push_seg(S, qnxt, &sqcount[cur ^ 1], cut, l, depth);
         }
       } else {
-        const int a = f + 1 + j * kChunk, b = a + kChunk < l ? a + kChunk : l;
+        const int a = f + 1 + j * CH, b = a + CH < l ? a + CH : l;
         const int p = ekey(e[f]);
         int cL = 0, cR = 0;
-        uint32_t* mk = MASKS ? mask_area(S, f) + 4 + 4 * (j * (kChunk / 64)) : nullptr;       // this chunk's groups
+        uint32_t* mk = MASKS ? mask_area(S, f) + 4 + 4 * (j * (CH / 64)) : nullptr;       // this chunk's groups
         constexpr int UA = CMH_MAP_UNROLL_A;                   // groups in flight per wave (the pass is latency-bound)
         for (int x0 = a; x0 < b; x0 += 64 * UA) {
           int k[UA];
@@ -696,8 +711,8 @@ __device__ __forceinline__ void introsort_phases(const QueryStore& S, int N, int
         int sw = 0;
         if (i0 < i1) {
           MaskCursor cl = make_cursor(S, f, l, false), cr = make_cursor(S, f, l, true);
-          cursor_seek(cl, cntL + base, nc, i0, lane);
-          cursor_seek(cr, cntR + base, nc, i0, lane);
+          cursor_seek<CH / 64>(cl, cntL + base, nc, i0, lane);
+          cursor_seek<CH / 64>(cr, cntR + base, nc, i0, lane);
           for (int ib = i0; ib < i1; ib += CW) {
             const int nl = cursor_fill(cl, bufL, lane, CW), nr = cursor_fill(cr, bufR, lane, CW);
             wave_sync();
@@ -744,8 +759,8 @@ __device__ __forceinline__ void introsort_phases(const QueryStore& S, int N, int
         const uint32_t* hdr = mask_area(S, f);
         const int Lc = static_cast<int>(hdr[0]);
         const int lim = Lc < cap ? Lc : cap;
-        const uint32_t c1 = sw < lim ? static_cast<uint32_t>(cursor_select(S, f, l, false, cntL + base, nc, sw, lane)) : 0x7fffffffu;
-        const uint32_t c2 = sw >= 1 ? static_cast<uint32_t>(cursor_select(S, f, l, true, cntR + base, nc, sw - 1, lane)) : 0x7fffffffu;
+        const uint32_t c1 = sw < lim ? static_cast<uint32_t>(cursor_select<CH / 64>(S, f, l, false, cntL + base, nc, sw, lane)) : 0x7fffffffu;
+        const uint32_t c2 = sw >= 1 ? static_cast<uint32_t>(cursor_select<CH / 64>(S, f, l, true, cntR + base, nc, sw - 1, lane)) : 0x7fffffffu;
         const int cut = static_cast<int>(c1 < c2 ? c1 : c2);
         if (lane == 0) {
           atomicOr(&S.leafbits[cut >> 5], 1u << (cut & 31));
@@ -776,7 +791,7 @@ __device__ __forceinline__ void introsort_phases(const QueryStore& S, int N, int
         const int ownR = static_cast<int>(cntR[base + j]);
         uint32_t* tL = S.tmp + tmp_base(f);
         uint32_t* tR = tL + cap;
-        const int a = f + 1 + j * kChunk, b = a + kChunk < l ? a + kChunk : l;
+        const int a = f + 1 + j * CH, b = a + CH < l ? a + CH : l;
         const int p = ekey(e[f]);
         int runL = offL, runR = offR + ownR - 1;
         for (int x0 = a; x0 < b; x0 += 256) {
