@@ -1425,7 +1425,7 @@ extern "C" int cmh_hamming_map(const uint32_t* q_sign, const uint32_t* q_nz, con
   else if (mode == MAP_HYBRID) MAP_GO(2, 8);
   else if (mode == MAP_HYBRID1) MAP_GO(2, 4);
   else if (mode == MAP_LDS1) MAP_GO(1, 4);
-  else MAP_GO(0, 8);
+  else MAP_GO(0, 8);        // (one 1024-thread workgroup per CU with 128 registers and no spills: COCO 32.2 -> 44.0 ms, NUS-WIDE 25.5 -> 33.1)
 #undef MAP_GO
   CMH_CHECK_LAUNCH("hamming_map");
   hipLaunchKernelGGL(map_mean_kernel, dim3(1), dim3(64), 0, st, ap, Q, map);
