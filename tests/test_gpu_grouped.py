@@ -26,6 +26,8 @@ SHAPES = [
     ((12800, 768, 3072), (10499, 512, 2048)),     # c_proj (residual)
     ((2100, 256, 512), (4000, 1024, 256)),        # 'a' shorter in K than 'b': the launcher swaps them
     ((2049, 512, 1024), (2500, 256, 1024)),       # a handful of tiles each
+    ((9000, 1024, 512), (4100, 512, 1024)),       # QuickGELU again (kind 2): ragged last tiles, 8 / 16 K-steps, several tiles per workgroup
+                                                  # at 128 rows - the deferred-activation variant of the wide kernel across a problem switch
 ]
 
 
