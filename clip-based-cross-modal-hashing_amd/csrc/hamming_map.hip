@@ -149,6 +149,13 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// A value every lane holds alike, said so to the compiler.  What a wave reads from the task list, the segment queue or a header is the same
+// in all 64 lanes, but a vector load's result counts as divergent: without this every count, bound and loop condition derived from it
+// is computed per lane (v_bcnt, v_cmp + exec masks) - in the mask walk's fill loop ~22 vector instructions per 64-position group where
+// ~8 are needed, on a CU whose 32 waves all queue for the vector ALU.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); }
+
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -278,7 +285,7 @@ __device__ inline int partition_wave(const QueryStore& S, int f, int l, int lane
   if (all_equal_shortcut(S, f, l, lane, budget)) return -1;
   if (lane == 0) median_to_first(e, f, l);
   wave_sync();
-  const int p = ekey(e[f]);
+  const int p = uni(ekey(e[f]));
   const int cap = n / 2 + 1;
   uint32_t* tL = S.tmp + tmp_base(f);
   uint32_t* tR = tL + cap;
@@ -353,14 +360,16 @@ __device__ inline int partition_wave(const QueryStore& S, int f, int l, int lane
 // 35.3 ms against 39.3, NUS-WIDE 2100 x 190 834 x 128 bit: 28.9 against 31.0, profiles/r04_n_map_*.txt); with the elements in LDS the
 // walk's extra instructions cost more than the lists (MIRFlickr 5000 x 15 015: 4.4 ms against 2.8), so those placements keep the lists.
 // What bounds the workspace placement after this: every level still reads the element array twice (count, swap gathers) and writes it
-// once in partial lines - 64 GB per NUS-WIDE direction at 2.3 TB/s (FETCH_SIZE / WRITE_SIZE, same file); deeper unrolling of either
-// pass changes nothing, and finishing short segments in LDS (tried: copy in, sort, copy out) costs as many cycles per element as the
-// levels it replaces.
+// once in partial lines - 60 GB per NUS-WIDE direction at 2.3-2.5 TB/s (FETCH_SIZE / WRITE_SIZE, profiles/r04_*_map_traffic_nuswide.txt);
+// deeper unrolling of the count pass changes nothing (4 / 8 / 16 groups in flight: 22.9 / 22.9 / 23.5 ms), and finishing short segments
+// in LDS (tried: copy in, sort, copy out) costs as many cycles per element as the levels it replaces.  What DID pay after the masks:
+// chunks of 4096 positions (kChunkMasks), the swap count known before the swap pass (pass B below: equal pieces, no idle pieces), and
+// telling the compiler which loaded values are wave-uniform (uni()): the walk's loops ran on vector compares and exec masks.
 #ifndef CMH_MAP_MASKS
 #define CMH_MAP_MASKS 1
 #endif
 #ifndef CMH_MAP_UNROLL_A
-#define CMH_MAP_UNROLL_A 4        // 64-position groups in flight per wave in the count pass (16: the same time)
+#define CMH_MAP_UNROLL_A 4        // 64-position groups in flight per wave in the count pass (8, 16: the same time)
 #endif
 #ifndef CMH_MAP_SWAP_BLOCKS
 #define CMH_MAP_SWAP_BLOCKS 1     // 64-rank blocks per iteration of the swap pass.  2: the same time, 4: +11 % (COCO 40.1 ms against 35.9).
@@ -413,7 +422,7 @@ __device__ inline void cursor_seek(MaskCursor& c, const uint32_t* pref, int nc, 
     cle += __popcll(__ballot(ci < nc && static_cast<int>(pref[ci]) <= target));
   }
   const int ch = c.desc ? nc - cle : cle - 1;
-  const int skip = target - static_cast<int>(pref[ch]);
+  const int skip = target - static_cast<int>(uni(pref[ch]));
   // the chunk's groups in walk order on the first kGpc lanes
   static_assert(kGpc >= 1 && kGpc <= 64, "a chunk is a whole number (<= 64) of 64-position groups");
   const int gfirst = c.desc ? (kGpc * ch + kGpc - 1 < c.ngroups - 1 ? kGpc * ch + kGpc - 1 : c.ngroups - 1) : kGpc * ch;
@@ -433,9 +442,9 @@ __device__ inline void cursor_seek(MaskCursor& c, const uint32_t* pref, int nc, 
     if (lane >= o) incl += up;
   }
   const int gsel = __popcll(__ballot(valid && incl <= skip));           // first group (in walk order) whose inclusive count exceeds skip
-  const int local = skip - (__shfl(incl, gsel, 64) - __shfl(pc, gsel, 64));
-  const uint64_t m = (static_cast<uint64_t>(static_cast<uint32_t>(__shfl(static_cast<int>(whi), gsel, 64))) << 32) |
-                     static_cast<uint32_t>(__shfl(static_cast<int>(wlo), gsel, 64));
+  const int local = skip - (__builtin_amdgcn_readlane(incl, gsel) - __builtin_amdgcn_readlane(pc, gsel));
+  const uint64_t m = (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(whi), gsel))) << 32) |
+                     static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(wlo), gsel));
   const bool bit = (m >> lane) & 1ull;
   const int rank = c.desc ? bits_above(m, lane) : mbcnt64(m);
   c.gi = c.desc ? gfirst - gsel : gfirst + gsel;
@@ -609,11 +618,11 @@ __device__ __forceinline__ void introsort_phases(const QueryStore& S, int N, int
       t = __builtin_amdgcn_readfirstlane(t);
       if (t >= ntask) break;
       if (++guard > ntask) break;                            // a wave can never be handed more tasks than exist: bounds the loop whatever happens
-      const uint32_t tk = S.task[t];
+      const uint32_t tk = uni(S.task[t]);
       const int si = static_cast<int>(tk >> 11), j = static_cast<int>(tk & 2047u);
-      const int f = static_cast<int>(qcur[2 * si]), l = static_cast<int>(qcur[2 * si + 1]);
+      const int f = static_cast<int>(uni(qcur[2 * si])), l = static_cast<int>(uni(qcur[2 * si + 1]));
       const int n = l - f;
-      const uint32_t info = S.seginfo[si];
+      const uint32_t info = uni(S.seginfo[si]);
       if ((info >> 16) == 1u) {
         const int cut = n <= 65 ? partition_wave<1>(S, f, l, lane, depth) : n <= 129 ? partition_wave<2>(S, f, l, lane, depth) : partition_wave<4>(S, f, l, lane, depth);
         if (lane == 0 && cut >= 0) {
@@ -623,7 +632,7 @@ __device__ __forceinline__ void introsort_phases(const QueryStore& S, int N, int
         }
       } else {
         const int a = f + 1 + j * CH, b = a + CH < l ? a + CH : l;
-        const int p = ekey(e[f]);
+        const int p = uni(ekey(e[f]));
         int cL = 0, cR = 0;
         uint32_t* mk = MASKS ? mask_area(S, f) + 4 + 4 * (j * (CH / 64)) : nullptr;       // this chunk's groups
         constexpr int UA = CMH_MAP_UNROLL_A;                   // groups in flight per wave (the pass is latency-bound)
@@ -654,10 +663,10 @@ __device__ __forceinline__ void introsort_phases(const QueryStore& S, int N, int
       // -- B: per chunked segment (a wave each), the chunk counts become exclusive prefixes - L ascending, R from the top - and the
       //    totals go to the mask area's header
       for (int si = wid; si < nseg; si += NWAVE) {
-        const uint32_t info = S.seginfo[si];
+        const uint32_t info = uni(S.seginfo[si]);
         const int nc = static_cast<int>(info >> 16), base = static_cast<int>(info & 0xffffu);
         if (nc == 1) continue;
-        const int f = static_cast<int>(qcur[2 * si]);
+        const int f = static_cast<int>(uni(qcur[2 * si]));
         int carry = 0;
         for (int c0 = 0; c0 < nc; c0 += 64) {
           const int ci = c0 + lane;
@@ -685,30 +694,78 @@ __device__ __forceinline__ void introsort_phases(const QueryStore& S, int N, int
           if (ci < nc) cntR[base + ci] = static_cast<uint32_t>(carry + incl - v);
           carry += __builtin_amdgcn_readlane(incl, 0);
         }
-        if (lane == 0) { uint32_t* hdr = mask_area(S, f); hdr[0] = static_cast<uint32_t>(Lc); hdr[1] = static_cast<uint32_t>(carry); }
+        // The number of pairs that swap, s = #{i : L_i < R_i} (a prefix of the ranks), BEFORE the swap pass, so that the pass cuts
+        // exactly [0, s) into equal pieces (cut over all min(|L|, |R|) candidate ranks, only the pieces below s had work and the wave
+        // holding two of them set the pace).  With a(x) = L entries below position x and b(x) = R entries at or above it,
+        // s = max_x min(a(x), b(x)): pair i swaps iff x = R_i has a, b >= i + 1.  a rises and b falls with x, so the maximum sits where
+        // they cross - located in three wave-wide steps: the chunk (from the two prefixes just written), the 64-position group inside
+        // it (from the masks' popcounts), the position inside that (from the bits).  (A bisection on the rank - two selects per probe,
+        // ~34 selects - cost 0.1-0.24 M cycles per level.)
+        wave_sync();                                            // the prefixes above are read back by other lanes
+        const int l = static_cast<int>(uni(qcur[2 * si + 1]));
+        const int Rc = carry;
+        int cstar = -1;
+        for (int c0 = 0; c0 < nc; c0 += 64) {
+          const int ci = c0 + lane;
+          bool ok = false;
+          if (ci < nc) {
+            const int a = static_cast<int>(cntL[base + ci]);
+            const int b = ci == 0 ? Rc : static_cast<int>(cntR[base + ci - 1]);
+            ok = a <= b;
+          }
+          cstar += __popcll(__ballot(ok));
+        }
+        const int a0 = static_cast<int>(uni(cntL[base + cstar])), bend = static_cast<int>(uni(cntR[base + cstar]));
+        constexpr int kGpc = CH / 64;
+        const uint32_t* mk = mask_area(S, f) + 4;
+        const int ngroups = (l - f - 1 + 63) >> 6;
+        const int g = kGpc * cstar + lane;
+        const bool gvalid = lane < kGpc && g < ngroups;
+        uint32_t w0 = 0u, w1 = 0u, w2 = 0u, w3 = 0u;
+        if (gvalid) { const uint4 q = *reinterpret_cast<const uint4*>(mk + 4 * g); w0 = q.x; w1 = q.y; w2 = q.z; w3 = q.w; }
+        const int pl = __popc(w0) + __popc(w1), pr = __popc(w2) + __popc(w3);
+        int ia = pl, ib = pr;                                    // inclusive prefix of pl, inclusive suffix of pr
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int up = __shfl_up(ia, o, 64), dn = __shfl_down(ib, o, 64);
+          if (lane >= o) ia += up;
+          if (lane + o < 64) ib += dn;
+        }
+        const int ag = a0 + ia - pl, bg = bend + ib;             // a, b at the START of group g
+        const int gstar = __popcll(__ballot(gvalid && ag <= bg)) - 1;      // (lane 0 always qualifies: a0 <= b at the chunk's start)
+        const int aS = __builtin_amdgcn_readlane(ag, gstar);
+        const int bE = __builtin_amdgcn_readlane(bg, gstar) - __builtin_amdgcn_readlane(pr, gstar);
+        const uint64_t mL = (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w1), gstar))) << 32) |
+                            static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w0), gstar));
+        const uint64_t mR = (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w3), gstar))) << 32) |
+                            static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(w2), gstar));
+        const int ax = aS + mbcnt64(mL);                         // L entries below this lane's position
+        const int bx = bE + bits_above(mR, lane) + static_cast<int>((mR >> lane) & 1ull);
+        int best = ax < bx ? ax : bx;
+        const int aend = aS + __popcll(mL);                      // ... and the boundary behind the group
+        best = lane == 63 ? (best > (aend < bE ? aend : bE) ? best : (aend < bE ? aend : bE)) : best;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(best, o, 64); best = best > other ? best : other; }
+        const int lo = best;
+        if (lane == 0) { uint32_t* hdr = mask_area(S, f); hdr[0] = static_cast<uint32_t>(Lc); hdr[1] = static_cast<uint32_t>(carry); hdr[2] = static_cast<uint32_t>(lo); }
       }
       __syncthreads();
       if (st && tid == 0 && lvl <= 16) st[64 + 8 * (lvl - 1) + 2] = __builtin_readcyclecounter();
-      // -- C: the pairs (L_i, R_i), cut into as many pieces of ranks as the segment has chunks; a piece's wave walks the masks from
-      //    the piece's first rank and expands 64 ranks at a time
+      // -- C: the s swapping pairs (L_i, R_i), cut into as many equal pieces of ranks as the segment has chunks; a piece's wave walks the
+      //    masks from the piece's first rank and expands 64 ranks at a time
       constexpr int CB = CMH_MAP_SWAP_BLOCKS, CW = 64 * CB;         // ranks per iteration: CB gathers of each side in flight
       uint32_t* bufL = C.bufR + wid * 2 * CW;
       uint32_t* bufR = bufL + CW;
       for (int t = wid; t < ntask; t += NWAVE) {
-        const uint32_t tk = S.task[t];
+        const uint32_t tk = uni(S.task[t]);
         const int si = static_cast<int>(tk >> 11), j = static_cast<int>(tk & 2047u);
-        const uint32_t info = S.seginfo[si];
+        const uint32_t info = uni(S.seginfo[si]);
         const int nc = static_cast<int>(info >> 16), base = static_cast<int>(info & 0xffffu);
         if (nc == 1) continue;
-        const int f = static_cast<int>(qcur[2 * si]), l = static_cast<int>(qcur[2 * si + 1]);
-        const int cap = (l - f) / 2 + 1;
-        const uint32_t* hdr = mask_area(S, f);
-        const int Lc = static_cast<int>(hdr[0]), Rc = static_cast<int>(hdr[1]);
-        int npairs = Lc < Rc ? Lc : Rc;
-        npairs = npairs < cap ? npairs : cap;
-        const int piece = (((cap + nc - 1) / nc) + 63) & ~63;
+        const int f = static_cast<int>(uni(qcur[2 * si])), l = static_cast<int>(uni(qcur[2 * si + 1]));
+        const int npairs = static_cast<int>(uni(mask_area(S, f)[2]));             // exactly the pairs that swap
+        const int piece = (((npairs + nc - 1) / nc) + 63) & ~63;
         const int i0 = j * piece, i1 = i0 + piece < npairs ? i0 + piece : npairs;
-        int sw = 0;
         if (i0 < i1) {
           MaskCursor cl = make_cursor(S, f, l, false), cr = make_cursor(S, f, l, true);
           cursor_seek<CH / 64>(cl, cntL + base, nc, i0, lane);
@@ -731,33 +788,25 @@ __device__ __forceinline__ void introsort_phases(const QueryStore& S, int N, int
 #pragma unroll
             for (int u = 0; u < CB; ++u)
               if (did[u]) { vl[u] = e[xl[u]]; vr[u] = e[xr[u]]; }
-            int c = 0;
 #pragma unroll
-            for (int u = 0; u < CB; ++u) {
+            for (int u = 0; u < CB; ++u)
               if (did[u]) { e[xl[u]] = vr[u]; e[xr[u]] = vl[u]; }
-              c += __popcll(__ballot(did[u]));
-            }
-            sw += c;
             wave_sync();
-            if (c < CW) break;                                 // the swapping pairs are a prefix
           }
         }
-        if (lane == 0) cntS[base + j] = static_cast<uint32_t>(sw);
       }
       __syncthreads();
       if (st && tid == 0 && lvl <= 16) st[64 + 8 * (lvl - 1) + 3] = __builtin_readcyclecounter();
-      // -- D: cut and children of the chunked segments (a wave each): cut = min(L_s, R_{s-1}), s = the swaps made
+      // -- D: cut and children of the chunked segments (a wave each): cut = min(L_s, R_{s-1}) (they wait for C: a parked child's slot
+      //    lies in the mask area)
       for (int si = wid; si < nseg; si += NWAVE) {
-        const uint32_t info = S.seginfo[si];
+        const uint32_t info = uni(S.seginfo[si]);
         const int nc = static_cast<int>(info >> 16), base = static_cast<int>(info & 0xffffu);
         if (nc == 1) continue;
-        const int f = static_cast<int>(qcur[2 * si]), l = static_cast<int>(qcur[2 * si + 1]);
+        const int f = static_cast<int>(uni(qcur[2 * si])), l = static_cast<int>(uni(qcur[2 * si + 1]));
         const int cap = (l - f) / 2 + 1;
-        int part = 0;
-        for (int c0 = 0; c0 < nc; c0 += 64) part += c0 + lane < nc ? static_cast<int>(cntS[base + c0 + lane]) : 0;
-        const int sw = wave_sum_i(part);
         const uint32_t* hdr = mask_area(S, f);
-        const int Lc = static_cast<int>(hdr[0]);
+        const int Lc = static_cast<int>(uni(hdr[0])), sw = static_cast<int>(uni(hdr[2]));
         const int lim = Lc < cap ? Lc : cap;
         const uint32_t c1 = sw < lim ? static_cast<uint32_t>(cursor_select<CH / 64>(S, f, l, false, cntL + base, nc, sw, lane)) : 0x7fffffffu;
         const uint32_t c2 = sw >= 1 ? static_cast<uint32_t>(cursor_select<CH / 64>(S, f, l, true, cntR + base, nc, sw - 1, lane)) : 0x7fffffffu;
@@ -774,12 +823,12 @@ __device__ __forceinline__ void introsort_phases(const QueryStore& S, int N, int
       if (st && tid == 0 && lvl <= 16) st[64 + 8 * (lvl - 1) + 1] = __builtin_readcyclecounter();
       // -- B: the chunks' positions go to the lists (L ascending from the chunks before, R descending from the chunks after)
       for (int t = wid; t < ntask; t += NWAVE) {
-        const uint32_t tk = S.task[t];
+        const uint32_t tk = uni(S.task[t]);
         const int si = static_cast<int>(tk >> 11), j = static_cast<int>(tk & 2047u);
-        const uint32_t info = S.seginfo[si];
+        const uint32_t info = uni(S.seginfo[si]);
         const int nc = static_cast<int>(info >> 16), base = static_cast<int>(info & 0xffffu);
         if (nc == 1) continue;
-        const int f = static_cast<int>(qcur[2 * si]), l = static_cast<int>(qcur[2 * si + 1]);
+        const int f = static_cast<int>(uni(qcur[2 * si])), l = static_cast<int>(uni(qcur[2 * si + 1]));
         const int cap = (l - f) / 2 + 1;
         int before = 0, after = 0;
         for (int j0 = 0; j0 < nc; j0 += 64) {
@@ -792,7 +841,7 @@ __device__ __forceinline__ void introsort_phases(const QueryStore& S, int N, int
         uint32_t* tL = S.tmp + tmp_base(f);
         uint32_t* tR = tL + cap;
         const int a = f + 1 + j * CH, b = a + CH < l ? a + CH : l;
-        const int p = ekey(e[f]);
+        const int p = uni(ekey(e[f]));
         int runL = offL, runR = offR + ownR - 1;
         for (int x0 = a; x0 < b; x0 += 256) {
           int k[4];
@@ -818,12 +867,12 @@ __device__ __forceinline__ void introsort_phases(const QueryStore& S, int N, int
       if (st && tid == 0 && lvl <= 16) st[64 + 8 * (lvl - 1) + 2] = __builtin_readcyclecounter();
       // -- C: the pairs, cut into as many pieces as the segment has chunks
       for (int t = wid; t < ntask; t += NWAVE) {
-        const uint32_t tk = S.task[t];
+        const uint32_t tk = uni(S.task[t]);
         const int si = static_cast<int>(tk >> 11), j = static_cast<int>(tk & 2047u);
-        const uint32_t info = S.seginfo[si];
+        const uint32_t info = uni(S.seginfo[si]);
         const int nc = static_cast<int>(info >> 16), base = static_cast<int>(info & 0xffffu);
         if (nc == 1) continue;
-        const int f = static_cast<int>(qcur[2 * si]), l = static_cast<int>(qcur[2 * si + 1]);
+        const int f = static_cast<int>(uni(qcur[2 * si])), l = static_cast<int>(uni(qcur[2 * si + 1]));
         const int cap = (l - f) / 2 + 1;
         int sl = 0, sr = 0;
         for (int j0 = 0; j0 < nc; j0 += 64) {
