@@ -192,8 +192,9 @@ __device__ __forceinline__ void attention_mfma_body(const bf16_t* __restrict__ q
   const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
   const int heads = d / HD;
   const int b = block / heads, h = block - b * heads;
-  const int Tn = seq_off ? seq_off[b + 1] - seq_off[b] : Tmax;
-  const size_t srow = seq_off ? static_cast<size_t>(seq_off[b]) : static_cast<size_t>(b) * Tmax;
+  // (the packed offsets are the same in every lane; said so, the sequence length and the row base stay in scalar registers)
+  const int Tn = seq_off ? __builtin_amdgcn_readfirstlane(seq_off[b + 1] - seq_off[b]) : Tmax;
+  const size_t srow = seq_off ? static_cast<size_t>(__builtin_amdgcn_readfirstlane(seq_off[b])) : static_cast<size_t>(b) * Tmax;
   const size_t ld = static_cast<size_t>(3) * d;
   const bf16_t* base = qkv + srow * ld + h * HD;
 
