@@ -1180,7 +1180,11 @@ __global__ __launch_bounds__(NT, WAVES) void map_query_kernel(MapArgs A) {
       const int x = x0 + lane;
       bool r = false;
       if (x < b) { const int id = eidx(e[x]); r = (S.relbits[id >> 5] >> (id & 31)) & 1u; }
-      crel += __popcll(__ballot(r));
+      const uint64_t m = __ballot(r);
+      crel += __popcll(m);
+      // the relevance bits of these 64 positions wait in the (now free) list area for the second pass: it then reads 8 bytes per group
+      // instead of the elements and their bitmap words again
+      if (lane == 0) { S.tmp[2 * (x0 >> 6)] = static_cast<uint32_t>(m); S.tmp[2 * (x0 >> 6) + 1] = static_cast<uint32_t>(m >> 32); }
     }
     __syncthreads();
     if (lane == 0) swork[wid] = crel;
@@ -1191,10 +1195,10 @@ __global__ __launch_bounds__(NT, WAVES) void map_query_kernel(MapArgs A) {
     int run = 0;
     for (int x0 = a; x0 < b; x0 += 64) {
       const int x = x0 + lane;
-      bool r = false;
       int id = 0;
-      if (x < b) { id = eidx(e[x]); r = (S.relbits[id >> 5] >> (id & 31)) & 1u; }
-      const uint64_t m = __ballot(r);
+      if (A.perm && x < b) id = eidx(e[x]);
+      const uint64_t m = static_cast<uint64_t>(uni(S.tmp[2 * (x0 >> 6)])) | (static_cast<uint64_t>(uni(S.tmp[2 * (x0 >> 6) + 1])) << 32);
+      const bool r = (m >> lane) & 1ull;
       if (r) {
         const int rank = off + run + __popcll(m & lanemask_lt(lane)) + 1;
         if (rank <= total) acc += static_cast<double>(static_cast<float>(rank) / static_cast<float>(x + 1));
