@@ -18,7 +18,8 @@ ap.add_argument("--fp8", action="store_true", help="e4m3 operands (K-steps of 12
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 M = a.rows
-for epi_name, kw in (("bias", {}), ("bias + QuickGELU", {"quickgelu": True}), ("bias + f32 residual (f32 out)", {"residual": True})):
+for epi_name, kw in (("bias", {}), ("bias + QuickGELU", {"quickgelu": True}), ("bias + f32 residual (f32 out)", {"residual": True}),
+                     ("bias + f16 residual (f16 out)", {"residual": "f16"})):
     if a.epi and a.epi not in epi_name:
         continue
     rows, ts = [], []
@@ -30,12 +31,17 @@ for epi_name, kw in (("bias", {}), ("bias + QuickGELU", {"quickgelu": True}), ("
             b = torch.randn(Nn, device=dev)
             k2 = dict(kw)
             obf = True
-            if k2.pop("residual", False):
+            res = k2.pop("residual", False)
+            if res == "f16":                          # the bf16 mode's fp16 residual stream (out_proj / c_proj launches)
+                k2["residual"] = torch.randn(M, Nn, device=dev).half()
+                k2["out_f16"] = True
+                obf = False
+            elif res:
                 k2["residual"] = torch.randn(M, Nn, device=dev)
                 obf = False
             f = lambda: N.linear_gemm(x, w, bias=b, out_bf16=obf, **k2)
             if a.fp8:
-                if not obf:
+                if not obf or "residual" in k2:
                     continue
                 x8 = torch.randint(0, 120, (M, K), dtype=torch.uint8, device=dev)
                 w8 = torch.randint(0, 120, (Nn, K), dtype=torch.uint8, device=dev)
