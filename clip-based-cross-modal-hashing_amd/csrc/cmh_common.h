@@ -144,6 +144,11 @@ bool gemm_wide_tn_supported(int Mm, int Nn, int Kd);
 // colsum_partial (optional): [*colsum_slices, Mm] partial column sums of Xk (wgrad's bias gradient, first stage), <= 64 slices
 int launch_gemm_wide_tn(const void* Xk, const void* Wk, float* out, float* partials, size_t part_bytes, int Mm, int Nn, int Kd,
                         hipStream_t st, float* colsum_partial = nullptr, int* colsum_slices = nullptr);
+// several wgrad GEMMs in one launch (gemm_wide.hip: gemm_wide_tn_multi_kernel); out_i[Mm, Nn] = Xk_i^T Wk_i over Kd rows
+struct TnMultiJob { const void* Xk; const void* Wk; float* out; float* colsum; int Mm, Nn, Kd; };
+bool gemm_wide_tn_multi_enabled();
+bool gemm_wide_tn_multi_fits(const TnMultiJob* jobs, int n);
+int launch_gemm_wide_tn_multi(const TnMultiJob* jobs, int n, float* partials, size_t part_bytes, hipStream_t st, int* slices);
 
 // LayerNorm over rows of x[M,d] (f32) -> out (f32 or bf16 per out_bf16). rows optionally gathered:
 // row r reads x[row_index[r]] when row_index != null.

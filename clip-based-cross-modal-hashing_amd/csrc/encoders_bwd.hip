@@ -284,26 +284,38 @@ int block_backward(const cmh_block_weights& w, const BlockGradPtrs& g, int dt, i
   const int wR[4] = {d, 4 * d, d, 3 * d}, wC[4] = {4 * d, d, d, d};
   if ((rc = launch_transpose_multi(wsrc, wdst, wR, wC, 4, ek, st))) return rc;
   if (pooled_rows && (rc = zero_pad_buffers(t, static_cast<size_t>(B), st))) return rc;      // the tail's transposes are B rows wide
+  // Round 4: the block's four weight gradients as ONE launch (gemm_wide.hip: gemm_wide_tn_multi_kernel), issued after the last dgrad
+  // and before ln_1's backward: together they are one round of the chip with little or no K split, no partial planes, one launch's
+  // fixed cost instead of four.  Their operands must all still be there at that point: the residual gradient as a GEMM operand exists
+  // in two versions per block (at the block's entry: c_proj's dY; after ln_2: out_proj's), so ln_2's backward writes its copy to a
+  // second buffer (t.dx2, otherwise only the pooled tail's) and ln_1's, as before, to t.dxe - the next block's entry.
+  const TnMultiJob probe[4] = {{nullptr, nullptr, nullptr, nullptr, d, 4 * d, M}, {nullptr, nullptr, nullptr, nullptr, 4 * d, d, M},
+                               {nullptr, nullptr, nullptr, nullptr, d, d, M}, {nullptr, nullptr, nullptr, nullptr, 3 * d, d, M}};
+  const bool multi = dt == CMH_BF16 && !pooled_rows && batched && dx_copy && gemm_wide_tn_multi_enabled() && gemm_wide_tn_multi_fits(probe, 4) &&
+                     db_slice >= static_cast<size_t>(64) * d * 4 + 256;
+  void* dx_copy2 = multi ? static_cast<void*>(t.dx2) : dx_copy;      // where ln_2's backward leaves the bf16 copy of the new dx
   // 1. MLP projection (dxe_ready: the previous block's ln_1 backward already wrote t.dxe)
   const size_t mtd = static_cast<size_t>(Mt) * d;
   if (dxe_ready && dx_copy) dxe = t.dxe;
   else if ((rc = as_gemm_operand(dt, dxt, t.dxe, mtd, st, &dxe))) return rc;
+  const void* dxe_entry = dxe;
   if ((rc = dgrad(dt, dxe, w.proj_w, d, 4 * d, Mt, L.pre, t.dpre, EPI_MUL_DQGELU | obf, t, st, wdst[0]))) return rc;
-  if ((rc = wgrad(dt, dxt, kF32, d, L.act, ek, 4 * d, Mt, g.proj_w, g.proj_b, t, st, dj, batched ? off_proj : 0,
-                  dt == CMH_BF16 ? dxe : nullptr))) return rc;
+  if (!multi && (rc = wgrad(dt, dxt, kF32, d, L.act, ek, 4 * d, Mt, g.proj_w, g.proj_b, t, st, dj, batched ? off_proj : 0,
+                            dt == CMH_BF16 ? dxe : nullptr))) return rc;
   // 2. c_fc
   if ((rc = dgrad(dt, t.dpre, w.fc_w, 4 * d, d, Mt, nullptr, t.dh, obf, t, st, wdst[1]))) return rc;
-  if ((rc = wgrad(dt, t.dpre, ek, 4 * d, L.h2, ek, d, Mt, g.fc_w, g.fc_b, t, st, dj, batched ? off_fc : 0))) return rc;
+  if (!multi && (rc = wgrad(dt, t.dpre, ek, 4 * d, L.h2, ek, d, Mt, g.fc_w, g.fc_b, t, st, dj, batched ? off_fc : 0))) return rc;
   // 3. ln_2
   if ((rc = launch_layernorm_backward(L.x_mid, xk, t.dh, ek, w.ln2_w, nullptr, Mt, d, dxt, 1, g.ln2_w, g.ln2_b,
-                                      batched ? red + off_ln2 : red, batched ? ln_ws : t.red_bytes, st, dx_copy, dj))) return rc;
+                                      batched ? red + off_ln2 : red, batched ? ln_ws : t.red_bytes, st, dx_copy2, dj))) return rc;
   // 4. out_proj
-  if (dx_copy) dxe = t.dxe;
+  if (dx_copy2) dxe = dx_copy2;
   else if ((rc = as_gemm_operand(dt, dxt, t.dxe, mtd, st, &dxe))) return rc;
+  const void* dxe_mid = dxe;
   const void* attn_rows = pooled_rows ? static_cast<const char*>(L.h2) + static_cast<size_t>(B) * d * esz : L.attn;
   if ((rc = dgrad(dt, dxe, w.out_proj_w, d, d, Mt, nullptr, t.dh, obf, t, st, wdst[2]))) return rc;
-  if ((rc = wgrad(dt, dxt, kF32, d, attn_rows, ek, d, Mt, g.out_w, g.out_b, t, st, dj, batched ? off_out : 0,
-                  dt == CMH_BF16 ? dxe : nullptr))) return rc;
+  if (!multi && (rc = wgrad(dt, dxt, kF32, d, attn_rows, ek, d, Mt, g.out_w, g.out_b, t, st, dj, batched ? off_out : 0,
+                            dt == CMH_BF16 ? dxe : nullptr))) return rc;
   const void* dattn = t.dh;
   if (pooled_rows) {
     // back to full size: d(attention output) is zero off the pooled rows (t.dxe is free now), the residual gradient likewise
@@ -318,7 +330,18 @@ int block_backward(const cmh_block_weights& w, const BlockGradPtrs& g, int dt, i
   if ((rc = launch_attention_backward(dt, L.qkv, L.attn, dattn, t.dqkv, B, T, d, causal, kpm, seq_off, st))) return rc;
   // 6. in_proj
   if ((rc = dgrad(dt, t.dqkv, w.in_proj_w, 3 * d, d, M, nullptr, t.dh, obf, t, st, wdst[3]))) return rc;
-  if ((rc = wgrad(dt, t.dqkv, ek, 3 * d, L.h1, ek, d, M, g.in_w, g.in_b, t, st, dj, batched ? off_in : 0))) return rc;
+  if (!multi && (rc = wgrad(dt, t.dqkv, ek, 3 * d, L.h1, ek, d, M, g.in_w, g.in_b, t, st, dj, batched ? off_in : 0))) return rc;
+  if (multi) {
+    auto dbp = [&](size_t off) { return reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(red + off) + 255) & ~static_cast<uintptr_t>(255)); };
+    const TnMultiJob jobs4[4] = {{dxe_entry, L.act, g.proj_w, dbp(off_proj), d, 4 * d, M},
+                                 {t.dpre, L.h2, g.fc_w, dbp(off_fc), 4 * d, d, M},
+                                 {dxe_mid, L.attn, g.out_w, dbp(off_out), d, d, M},
+                                 {t.dqkv, L.h1, g.in_w, dbp(off_in), 3 * d, d, M}};
+    float* const dbs[4] = {g.proj_b, g.fc_b, g.out_b, g.in_b};
+    int slices[4] = {0, 0, 0, 0};
+    if ((rc = launch_gemm_wide_tn_multi(jobs4, 4, t.part, t.part_bytes, st, slices))) return rc;
+    for (int i = 0; i < 4; ++i) jobs.add(jobs4[i].colsum, slices[i], jobs4[i].Mm, dbs[i]);
+  }
   // 7. ln_1
   if ((rc = launch_layernorm_backward(L.x_in, xk, t.dh, ek, w.ln1_w, nullptr, M, d, t.dx, 1, g.ln1_w, g.ln1_b,
                                       batched ? red + off_ln1 : red, batched ? ln_ws : t.red_bytes, st, dx_copy, dj))) return rc;

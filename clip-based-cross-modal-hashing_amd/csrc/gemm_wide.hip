@@ -133,13 +133,17 @@ struct WideProblem {
 __device__ const uint4 g_wide_zero[16] = {};   // 256 zero bytes: the source of k-rows past the end of the Xk operand
 typedef __attribute__((ext_vector_type(2))) uint32_t w_u32x2_t;
 
-template <int DT, int OK, int MF, bool TN = false, bool GRP = false, bool DGE = false>   // DT: 0 f32, 1 bf16, 2 fp8 operands; OK: 0 f32, 1 16-bit (bf16 /
+// The kernel's body.  ONE: the workgroup computes exactly the (virtual) tile `one_tile` instead of its share of the persistent tile
+// walk - what the multi-problem wgrad launch below needs (gemm_wide_tn_multi_kernel: every workgroup looks its problem up and runs one
+// long-K tile of it); all other launches pass ONE = false and nothing of it remains in their code.
+template <int DT, int OK, int MF, bool TN = false, bool GRP = false, bool DGE = false, bool ONE = false>   // DT: 0 f32, 1 bf16, 2 fp8 operands; OK: 0 f32, 1 16-bit (bf16 /
                                     // fp16), 2 fp8 outputs; MF = 16-row m-fragments per wave: tile rows = 32*MF (160, 128 or 96); TN, GRP: above;
                                     // DGE: the QuickGELU of a tile runs under the NEXT tile's MFMAs (see "deferred QuickGELU" below)
-__global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__ X, const char* __restrict__ W,
-                                                        const float* __restrict__ bias_a, const float* residual_a,
-                                                        void* out_a, int Mub, int N_a, int K, int epi, int ksplit, int ordG,
-                                                        WideScales sc_a, WideProblem p1) {
+__device__ __forceinline__ void gemm_wide_body(const char* __restrict__ X, const char* __restrict__ W,
+                                               const float* __restrict__ bias_a, const float* residual_a,
+                                               void* out_a, int Mub, int N_a, int K, int epi, int ksplit, int ordG,
+                                               WideScales sc_a, WideProblem p1, int one_tile) {
+  static_assert(!ONE || (TN && !GRP && !DGE), "single-tile workgroups: the multi-problem wgrad launch only");
   // The names the compute side (K loop, epilogue) reads.  Plain launches never reassign them - they ARE the arguments; a grouped
   // launch moves them to the second problem once per workgroup (to_problem1 below).  The issue side, which runs up to three stages
   // ahead of the compute side, keeps its own view (i_* in set_issue_tile).
@@ -196,10 +200,10 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   // [split * nk, (split + 1) * nk) into the f32 partial plane out + split * M * N (summed by splitk_reduce_kernel)
   const int base_total = tiles_n * tiles_m;
   const int total = base_total * ksplit;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd_blocks = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7, slot = ONE ? 0 : blockIdx.x >> 3, per_xcd_blocks = ONE ? 1 : gridDim.x >> 3;
   const int q = total >> 3, r = total & 7;
-  const int range_lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  const int range_len = xcd < r ? q + 1 : q;
+  const int range_lo = ONE ? one_tile : (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q);
+  const int range_len = ONE ? 1 : (xcd < r ? q + 1 : q);
   // GRP: this XCD's contiguous range of the SECOND problem's tiles follows its range of the first in the workgroups' stride:
   // position j = slot + ti * per_xcd_blocks of the concatenation, so a workgroup's first n_first tiles are the first problem's
   int tiles_n1 = 0, range_lo1 = 0, range_len1 = 0, n_first = 0;
@@ -1332,6 +1336,33 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__
   W_TL(5);   // everything this workgroup issued has completed
 }
 
+template <int DT, int OK, int MF, bool TN = false, bool GRP = false, bool DGE = false>
+__global__ __launch_bounds__(512) void gemm_wide_kernel(const char* __restrict__ X, const char* __restrict__ W,
+                                                        const float* __restrict__ bias_a, const float* residual_a,
+                                                        void* out_a, int Mub, int N_a, int K, int epi, int ksplit, int ordG,
+                                                        WideScales sc_a, WideProblem p1) {
+  gemm_wide_body<DT, OK, MF, TN, GRP, DGE, false>(X, W, bias_a, residual_a, out_a, Mub, N_a, K, epi, ksplit, ordG, sc_a, p1, 0);
+}
+
+// Several wgrad GEMMs (TN, see above) in ONE launch: the four weight gradients of a transformer block.  Launched one by one, each of
+// them splits its K (= the batch's rows) over S groups of workgroups to fill the chip (S = 4 / 14 / 3 / 3 on the image tower's
+// [2304|768|3072|768 x 768|3072] gradients), pays a launch's fixed ~10 us, writes S f32 planes and needs a reduce launch; together they
+// have 216 output tiles - one round of the 256 CUs with NO split at all (text tower: 96 tiles, S = 2).  Every workgroup looks up the
+// job its blockIdx falls in and runs one (virtual) tile of it through the kernel body.
+struct TnJob {
+  const char* Xk; const char* Wk; float* out; float* colsum;
+  int Mm, Nn, Kpad, kreal, S, first;      // first: this job's first workgroup
+};
+struct TnMulti { int n; TnJob j[4]; };
+__global__ __launch_bounds__(512) void gemm_wide_tn_multi_kernel(TnMulti tab) {
+  int p = 0;
+  for (int i = 1; i < tab.n; ++i) p = static_cast<int>(blockIdx.x) >= tab.j[i].first ? i : p;
+  const TnJob J = tab.j[p];
+  const WideScales sc{nullptr, 1.f, 1.f, J.kreal, J.colsum, nullptr};
+  gemm_wide_body<1, 0, 4, true, false, false, true>(J.Xk, J.Wk, nullptr, nullptr, J.out, J.Mm, J.Nn, J.Kpad, 0, J.S, 0, sc, WideProblem{},
+                                                    static_cast<int>(blockIdx.x) - J.first);
+}
+
 bool gemm_wide_supported(int N) { return N % wBN == 0; }
 
 // bench.py's roofline leg (cmh_prof_gemm_*): when launch_gemm hands over an event pair, the forward launch goes through
@@ -1472,6 +1503,77 @@ int launch_gemm_wide_tn(const void* Xk, const void* Wk, float* out, float* parti
     const size_t blocks = (n / 4 + 255) / 256;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, partials, S,
                        n, out);
+  }
+  return 0;
+}
+
+// n <= 4 wgrad GEMMs (out_i[Mm_i, Nn_i] = Xk_i^T Wk_i over Kd_i rows) as ONE launch (gemm_wide_tn_multi_kernel).  All jobs take the
+// same split S: the largest that still fits the chip with every (tile, split) on its own workgroup; S > 1 puts job i's planes at
+// partials + sum_{j<i} S Mm_j Nn_j and sums them afterwards.  colsum_slices[i] = S.  Returns CMH_ERR_INVALID when a shape does not fit
+// (the caller then launches them one by one).
+bool gemm_wide_tn_multi_enabled() {      // CMH_WGRAD_MULTI=0: the four launches of rounds 1-3 (read per call: the tests flip it)
+  const char* e = getenv("CMH_WGRAD_MULTI");
+  return !(e && e[0] == '0');
+}
+bool gemm_wide_tn_multi_fits(const TnMultiJob* jobs, int n) {
+  if (n < 1 || n > 4) return false;
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!gemm_wide_tn_supported(jobs[i].Mm, jobs[i].Nn, jobs[i].Kd) || jobs[i].Kd < 8 * 64) return false;
+    tiles += (jobs[i].Nn / wBN) * (jobs[i].Mm / 128);
+  }
+  return tiles <= wide_cus();
+}
+int launch_gemm_wide_tn_multi(const TnMultiJob* jobs, int n, float* partials, size_t part_bytes, hipStream_t st, int* slices) {
+  if (n < 1 || n > 4) return fail(CMH_ERR_INVALID, "gemm_tn_multi: %d jobs", n);
+  const int cus = wide_cus();
+  int tiles = 0, min_nkt = 1 << 30;
+  for (int i = 0; i < n; ++i) {
+    if (!gemm_wide_tn_supported(jobs[i].Mm, jobs[i].Nn, jobs[i].Kd))
+      return fail(CMH_ERR_INVALID, "gemm_tn_multi: unsupported shape Mm=%d Nn=%d Kd=%d", jobs[i].Mm, jobs[i].Nn, jobs[i].Kd);
+    tiles += (jobs[i].Nn / wBN) * (jobs[i].Mm / 128);
+    const int nkt = (jobs[i].Kd + 63) / 64;
+    min_nkt = nkt < min_nkt ? nkt : min_nkt;
+  }
+  if (tiles > cus) return fail(CMH_ERR_INVALID, "gemm_tn_multi: %d tiles for %d CUs", tiles, cus);
+  int S = cus / tiles;
+  if (S > min_nkt / 8) S = min_nkt / 8;
+  if (S > 64) S = 64;
+  if (S < 1) S = 1;
+  size_t need = 0;
+  for (int i = 0; i < n; ++i) need += static_cast<size_t>(S) * jobs[i].Mm * jobs[i].Nn * 4;
+  while (S > 1 && need > part_bytes) {
+    --S;
+    need = 0;
+    for (int i = 0; i < n; ++i) need += static_cast<size_t>(S) * jobs[i].Mm * jobs[i].Nn * 4;
+  }
+  TnMulti tab;
+  tab.n = n;
+  int first = 0;
+  float* plane = partials;
+  for (int i = 0; i < n; ++i) {
+    const TnMultiJob& g = jobs[i];
+    const int nkt = (g.Kd + 63) / 64, nk_per = (nkt + S - 1) / S;
+    TnJob& J = tab.j[i];
+    J.Xk = static_cast<const char*>(g.Xk); J.Wk = static_cast<const char*>(g.Wk);
+    J.out = S > 1 ? plane : g.out;
+    J.colsum = g.colsum;
+    J.Mm = g.Mm; J.Nn = g.Nn; J.Kpad = S * nk_per * 64; J.kreal = g.Kd; J.S = S; J.first = first;
+    first += (g.Nn / wBN) * (g.Mm / 128) * S;
+    plane += static_cast<size_t>(S) * g.Mm * g.Nn;
+    if (slices) slices[i] = S;
+  }
+  for (int i = n; i < 4; ++i) tab.j[i] = TnJob{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 1, 1 << 30};
+  hipLaunchKernelGGL(gemm_wide_tn_multi_kernel, dim3(first), dim3(512), 0, st, tab);
+  if (S > 1) {
+    plane = partials;
+    for (int i = 0; i < n; ++i) {
+      const size_t cnt = static_cast<size_t>(jobs[i].Mm) * jobs[i].Nn;
+      const size_t blocks = (cnt / 4 + 255) / 256;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, plane, S, cnt,
+                         jobs[i].out);
+      plane += static_cast<size_t>(S) * cnt;
+    }
   }
   return 0;
 }

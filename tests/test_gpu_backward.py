@@ -374,6 +374,44 @@ def test_bf16_mode_gradients_track_f32_mode():
     print(f"bf16 vs f32 gradients: worst cosine {worst[0]:.5f} ({worst[1]})")
 
 
+def test_block_wgrads_in_one_launch_match_the_four_launches(monkeypatch):
+    """csrc/encoders_bwd.hip block_backward: the four weight gradients of a block as ONE multi-problem TN launch (the default where
+    the shapes allow it) against the four launches of rounds 1-3 (CMH_WGRAD_MULTI=0): the same products summed in another split
+    of the batch rows - equal to f32 rounding of the partial sums - and both track the f32 mode.  3 layers, width 256, 128 samples so
+    that two blocks per tower take the path (the last block runs its pooled tail)."""
+    from model.base.model import CLIP
+    cfg = dict(embed_dim=128, image_resolution=224, vision_layers=3, vision_width=256, vision_patch_size=32, context_length=40,
+               vocab_size=512, transformer_width=256, transformer_heads=4, transformer_layers=3)
+    torch.manual_seed(5)
+    m = CLIP(**cfg).to(DEV).float()
+    B = 128
+    img = torch.randn(B, 3, 224, 224, device=DEV)
+    txt = torch.randint(1, 500, (B, 40), device=DEV)
+    txt[:, -1] = 511
+    gi, gt = torch.randn(B, 128, device=DEV), torch.randn(B, 128, device=DEV)
+
+    def grads_of(mode):
+        m.set_gemm_dtype(mode)
+        m.zero_grad(set_to_none=True)
+        ((m.encode_image(img) * gi).sum() + (m.encode_text(txt) * gt).sum()).backward()
+        return {n: p.grad.detach().double().flatten().cpu() for n, p in m.named_parameters() if p.grad is not None}
+
+    monkeypatch.setenv("CMH_WGRAD_MULTI", "1")
+    one = grads_of("bf16")
+    monkeypatch.setenv("CMH_WGRAD_MULTI", "0")
+    four = grads_of("bf16")
+    ref = grads_of("f32")
+    moved = 0
+    for n, a in four.items():
+        b = one[n]
+        scale = float(a.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= 2e-4 * scale, (n, float((a - b).abs().max()), scale)
+        moved += int(not torch.equal(a, b))
+        cos = float(ref[n] @ b / (ref[n].norm() * b.norm() + 1e-30))
+        assert cos > 0.99, (n, cos)
+    assert moved > 0          # the path was taken: some weight gradient is summed in another order
+
+
 @pytest.mark.parametrize("B,K,C,fn,lt", [(32, 16, 24, "euclidean", "l2"), (32, 16, 24, "cosine", "l2"), (24, 64, 24, "euclidean", "l1"),
                                          (24, 64, 80, "cosine", "l1")])
 def test_dchmt_loss_gradients_match_reference_goldens(golden, B, K, C, fn, lt):
