@@ -1093,7 +1093,7 @@ __device__ __forceinline__ void gemm_wide_body(const char* __restrict__ X, const
       }
     }
     if constexpr (DGE) {
-      // ---- deferred QuickGELU: epi = [bias] + QuickGELU + 16-bit output, nothing else (wide_dge_applies).  The pre-activations move to
+      // ---- deferred QuickGELU: epi = [bias] + QuickGELU [+ the saved pre-activation] + 16-bit output, nothing else (wide_dge_applies).  The pre-activations move to
       // pendf - the accumulators are free for the next tile at once; a workgroup's last tile and partial tiles finish here.
       {
         w_f32x4_t bv[4];
@@ -1104,6 +1104,27 @@ __device__ __forceinline__ void gemm_wide_body(const char* __restrict__ X, const
         for (int a = 0; a < 4; ++a)
 #pragma unroll
           for (int b = 0; b < MF; ++b) pendf[a][b] = acc[a][b] + bv[a];
+      }
+      if (epi & EPI_SAVE_PRE) {
+        // training forward of c_fc: the pre-activation leaves from here as bf16 (the generic epilogue's layout), only the activation waits
+        char* p2 = reinterpret_cast<char*>(const_cast<float*>(residual)) +
+                   (static_cast<size_t>(m0 + wm * WR + frow) * N + n0 + wn * 64 + (fq & 1) * 16 + (fq & 2) * 4) * 2;
+#pragma unroll
+        for (int b = 0; b < MF; ++b) {
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            uint32_t lo[2], hi[2];
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+              lo[w] = pack_bf16x2(pendf[2 * pr][b][2 * w], pendf[2 * pr][b][2 * w + 1]);
+              hi[w] = pack_bf16x2(pendf[2 * pr + 1][b][2 * w], pendf[2 * pr + 1][b][2 * w + 1]);
+            }
+            const w_u2_t s0 = __builtin_amdgcn_permlane16_swap(lo[0], hi[0], false, false);
+            const w_u2_t s1 = __builtin_amdgcn_permlane16_swap(lo[1], hi[1], false, false);
+            if (m0 + wm * WR + b * 16 + frow < M)
+              *reinterpret_cast<w_u32x4_t*>(p2 + b * row16 + pr * 64) = w_u32x4_t{s0[0], s1[0], s0[1], s1[1]};
+          }
+        }
       }
       pend_ptr = static_cast<char*>(out) + (static_cast<size_t>(m0 + wm * WR + frow) * N + n0 + wn * 64 + (fq & 1) * 16 + (fq & 2) * 4) * 2;
       if constexpr (GRP) pend_row16 = row16;
@@ -1403,7 +1424,7 @@ static bool wide_dge_enabled() {
 }
 static bool wide_dge_applies(int dt, int epi, int mf, int kmin) {   // kmin: the shortest K of the launch - a tile's 8 pieces need 8 K-steps of the next
   return wide_dge_enabled() && dt == CMH_BF16 && mf == 4 && kmin >= 8 * 64 && (epi & EPI_QUICKGELU) && (epi & (EPI_OUT_BF16 | EPI_OUT_F16)) &&
-         !(epi & ~(EPI_BIAS | EPI_QUICKGELU | EPI_OUT_BF16 | EPI_OUT_F16));
+         !(epi & ~(EPI_BIAS | EPI_QUICKGELU | EPI_OUT_BF16 | EPI_OUT_F16 | EPI_SAVE_PRE)) && (!(epi & EPI_SAVE_PRE) || (epi & EPI_OUT_BF16));
 }
 static int wide_gelu_ksteps(int dt, int epi, int mf, int kmin) {
   if (!(epi & EPI_QUICKGELU) || wide_dge_applies(dt, epi, mf, kmin)) return 0;
