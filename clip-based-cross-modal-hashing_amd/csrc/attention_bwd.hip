@@ -175,6 +175,18 @@ __device__ __forceinline__ ab_bf16x8_t ab_frag_tr(uint32_t lds_base, int ld, int
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi));
   return __builtin_bit_cast(ab_bf16x8_t, uint4{lo.x, lo.y, hi.x, hi.y});
 }
+// the same, reads only (the caller waits once for several fragments); by value - a fragment handed out through references went to scratch
+struct AbHalves { uint2 lo, hi; };
+__device__ __forceinline__ AbHalves ab_frag_tr_issue(uint32_t lds_base, int ld, int k0, int col0, int g, int c, int rows, uint32_t zero_addr) {
+  const int r0 = k0 + 4 * g + (c >> 2);
+  const uint32_t off = static_cast<uint32_t>((r0 * ld + col0 + 4 * (c & 3)) * 2);
+  const uint32_t a0 = r0 < rows ? lds_base + off : zero_addr;
+  const uint32_t a1 = r0 + 16 < rows ? lds_base + off + static_cast<uint32_t>(16 * ld * 2) : zero_addr;
+  AbHalves h;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(h.lo) : "v"(a0));
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(h.hi) : "v"(a1));
+  return h;
+}
 // fragment of a row-major image M[row][k] in the same k order: two 8-byte reads
 __device__ __forceinline__ ab_bf16x8_t ab_frag_perm(const bf16_t* M, int ld, int row, int k0, int g) {
   const uint2 lo = *reinterpret_cast<const uint2*>(M + static_cast<size_t>(row) * ld + k0 + 4 * g);
@@ -230,15 +242,38 @@ __global__ __launch_bounds__(NT <= 4 ? 256 : 512) void attention_bwd_mfma_kernel
   const bf16_t* dob = dout + row0 * d + h * HDB;
   bf16_t* dqb = dqkv + row0 * ld + h * HDB;
 
-  // ---- stage: zero everything (padding rows / columns must be exact zeros), then the real rows ------------------------
+  // ---- stage: zero everything (padding rows / columns must be exact zeros), then the real rows.  Round 4: the rows' global loads are
+  // issued FIRST (every 16-byte slot of Q, K, V, dO a thread owns: 8 loads in flight), the zero fill runs under their latency, and the
+  // rows are stored after the barrier - the first form zeroed, waited, and only then loaded, slot by slot.
+  constexpr int NIT = (TR * 8 + NTH - 1) / NTH;              // slots per thread and image (1 or 2)
+  // (named registers, not arrays: the arrays of the first form of this went through scratch)
+  static_assert(NIT == 1 || NIT == 2, "one or two slots per thread");
+  const int slot0 = tid, r0s = slot0 >> 3, ch0 = slot0 & 7, rc0 = r0s < Tn ? r0s : Tn - 1;      // clamped: the loads are unconditional
+  const int slot1 = tid + NTH, r1s = slot1 >> 3, ch1 = slot1 & 7, rc1 = r1s < Tn ? r1s : Tn - 1;
+  const uint4 q0 = *reinterpret_cast<const uint4*>(qb + static_cast<size_t>(rc0) * ld + ch0 * 8);
+  const uint4 k0 = *reinterpret_cast<const uint4*>(qb + d + static_cast<size_t>(rc0) * ld + ch0 * 8);
+  const uint4 v0 = *reinterpret_cast<const uint4*>(qb + 2 * d + static_cast<size_t>(rc0) * ld + ch0 * 8);
+  const uint4 o0 = *reinterpret_cast<const uint4*>(dob + static_cast<size_t>(rc0) * d + ch0 * 8);
+  uint4 q1 = q0, k1 = k0, v1 = v0, o1 = o0;
+  if constexpr (NIT == 2) {
+    q1 = *reinterpret_cast<const uint4*>(qb + static_cast<size_t>(rc1) * ld + ch1 * 8);
+    k1 = *reinterpret_cast<const uint4*>(qb + d + static_cast<size_t>(rc1) * ld + ch1 * 8);
+    v1 = *reinterpret_cast<const uint4*>(qb + 2 * d + static_cast<size_t>(rc1) * ld + ch1 * 8);
+    o1 = *reinterpret_cast<const uint4*>(dob + static_cast<size_t>(rc1) * d + ch1 * 8);
+  }
   for (int i = tid; i < kTotal / 8; i += NTH) reinterpret_cast<uint4*>(sm)[i] = uint4{0u, 0u, 0u, 0u};
   __syncthreads();
-  for (int slot = tid; slot < Tn * 8; slot += NTH) {
-    const int r = slot >> 3, ch = slot & 7;
-    *reinterpret_cast<uint4*>(sQ + r * LR + ch * 8) = *reinterpret_cast<const uint4*>(qb + static_cast<size_t>(r) * ld + ch * 8);
-    *reinterpret_cast<uint4*>(sK + r * LR + ch * 8) = *reinterpret_cast<const uint4*>(qb + d + static_cast<size_t>(r) * ld + ch * 8);
-    *reinterpret_cast<uint4*>(sV + r * LR + ch * 8) = *reinterpret_cast<const uint4*>(qb + 2 * d + static_cast<size_t>(r) * ld + ch * 8);
-    *reinterpret_cast<uint4*>(sDO + r * LR + ch * 8) = *reinterpret_cast<const uint4*>(dob + static_cast<size_t>(r) * d + ch * 8);
+  if (r0s < Tn) {
+    *reinterpret_cast<uint4*>(sQ + r0s * LR + ch0 * 8) = q0;
+    *reinterpret_cast<uint4*>(sK + r0s * LR + ch0 * 8) = k0;
+    *reinterpret_cast<uint4*>(sV + r0s * LR + ch0 * 8) = v0;
+    *reinterpret_cast<uint4*>(sDO + r0s * LR + ch0 * 8) = o0;
+  }
+  if (NIT == 2 && r1s < Tn) {
+    *reinterpret_cast<uint4*>(sQ + r1s * LR + ch1 * 8) = q1;
+    *reinterpret_cast<uint4*>(sK + r1s * LR + ch1 * 8) = k1;
+    *reinterpret_cast<uint4*>(sV + r1s * LR + ch1 * 8) = v1;
+    *reinterpret_cast<uint4*>(sDO + r1s * LR + ch1 * 8) = o1;
   }
   __syncthreads();
 
@@ -331,11 +366,26 @@ __global__ __launch_bounds__(NT <= 4 ? 256 : 512) void attention_bwd_mfma_kernel
     const uint32_t aA = prod == 0 ? aDO : (prod == 1 ? aQ : aK);
     const bf16_t* Bn = prod == 0 ? sPT : sDST;
     ab_f32x4_t acc = ab_f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // every fragment read of the job is issued before the one wait (a wait per fragment put 2 KS LDS round trips in front of each MFMA)
+    uint2 alo[KS], ahi[KS], blo[KS], bhi[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const ab_bf16x8_t fa = ab_frag_tr(aA, LR, ks * 32, th * 16, g, c, TR, aZero);          // dO^T / Q^T / K^T [hd][row k]
-      const ab_bf16x8_t fb = prod == 2 ? ab_frag_tr(aDST, LT, ks * 32, tr * 16, g, c, TR, aZero)   // dS [q][key k] = (dS^T)^T
-                                       : ab_frag_perm(Bn, LT, tr * 16 + c, ks * 32, g);     // P^T / dS^T [key][q k]
+      const AbHalves ha = ab_frag_tr_issue(aA, LR, ks * 32, th * 16, g, c, TR, aZero);          // dO^T / Q^T / K^T [hd][row k]
+      alo[ks] = ha.lo; ahi[ks] = ha.hi;
+      if (prod == 2) {
+        const AbHalves hb = ab_frag_tr_issue(aDST, LT, ks * 32, tr * 16, g, c, TR, aZero);      // dS [q][key k] = (dS^T)^T
+        blo[ks] = hb.lo; bhi[ks] = hb.hi;
+      } else {                                                                                  // P^T / dS^T [key][q k]
+        blo[ks] = *reinterpret_cast<const uint2*>(Bn + static_cast<size_t>(tr * 16 + c) * LT + ks * 32 + 4 * g);
+        bhi[ks] = *reinterpret_cast<const uint2*>(Bn + static_cast<size_t>(tr * 16 + c) * LT + ks * 32 + 16 + 4 * g);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(alo[ks]), "+v"(ahi[ks]), "+v"(blo[ks]), "+v"(bhi[ks]));
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const ab_bf16x8_t fa = __builtin_bit_cast(ab_bf16x8_t, uint4{alo[ks].x, alo[ks].y, ahi[ks].x, ahi[ks].y});
+      const ab_bf16x8_t fb = __builtin_bit_cast(ab_bf16x8_t, uint4{blo[ks].x, blo[ks].y, bhi[ks].x, bhi[ks].y});
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc, 0, 0, 0);
     }
     const int row = tr * 16 + c;
