@@ -381,6 +381,44 @@ __global__ __launch_bounds__(256) void pool_dgrad_kernel(const float* __restrict
     dpool[static_cast<size_t>(b) * d + i] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   }
 }
+// bf16 weights, d % 8 == 0: a thread owns 8 consecutive outputs and reads them as ONE 16-byte load per j (the kernel above issues a
+// 2-byte load per output and j: 3 x 512 of them per thread in chains of 8 - 72 us at batch 256, and more of them in flight was slower,
+// not faster).  Every output keeps the kernel above's arithmetic: chain u = j mod 8, the same final tree - same bits.
+__global__ __launch_bounds__(128) void pool_dgrad_v8_kernel(const float* __restrict__ dfeat, const bf16_t* __restrict__ proj_t,
+                                                            float* __restrict__ dpool, int B, int d, int E) {
+  __shared__ float row[2048];
+  const int b = blockIdx.x;
+  for (int j = threadIdx.x; j < E; j += 128) row[j] = dfeat[static_cast<size_t>(b) * E + j];
+  __syncthreads();
+  for (int i8 = threadIdx.x; i8 < d / 8; i8 += 128) {
+    float acc[8][8];                                   // [column][chain]
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[c][u] = 0.f;
+    auto fma8 = [&](const uint4& q, float x, int u) __attribute__((always_inline)) {
+      const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        acc[2 * h][u] = fmaf(x, __uint_as_float(w[h] << 16), acc[2 * h][u]);
+        acc[2 * h + 1][u] = fmaf(x, __uint_as_float(w[h] & 0xffff0000u), acc[2 * h + 1][u]);
+      }
+    };
+    int j = 0;
+    for (; j + 8 <= E; j += 8) {
+      uint4 q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[u] = *reinterpret_cast<const uint4*>(proj_t + static_cast<size_t>(j + u) * d + i8 * 8);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) fma8(q[u], row[j + u], u);
+    }
+    for (; j < E; ++j) fma8(*reinterpret_cast<const uint4*>(proj_t + static_cast<size_t>(j) * d + i8 * 8), row[j], 0);
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      dpool[static_cast<size_t>(b) * d + i8 * 8 + c] =
+          ((acc[c][0] + acc[c][1]) + (acc[c][2] + acc[c][3])) + ((acc[c][4] + acc[c][5]) + (acc[c][6] + acc[c][7]));
+  }
+}
 // dproj[i, j] = sum_b pool[b, i] * dfeat[b, j]      (the reference's [width, embed_dim] parameter layout)
 template <typename T>
 __global__ __launch_bounds__(256) void pool_wgrad_kernel(const T* __restrict__ pool, const float* __restrict__ dfeat,
@@ -409,7 +447,10 @@ int pooled_backward(int dt, int xh, const void* x_last, const int32_t* rows, con
     hipLaunchKernelGGL(pool_dgrad_kernel<float>, dim3(B), dim3(256), 0, st, dfeat, static_cast<const float*>(proj_t), dpool, B, d, E);
     hipLaunchKernelGGL(pool_wgrad_kernel<float>, dim3(d), dim3(256), 0, st, static_cast<const float*>(pool), dfeat, dproj, B, d, E);
   } else {
-    hipLaunchKernelGGL(pool_dgrad_kernel<bf16_t>, dim3(B), dim3(256), 0, st, dfeat, static_cast<const bf16_t*>(proj_t), dpool, B, d, E);
+    if (d % 8 == 0 && E <= 2048 && (reinterpret_cast<uintptr_t>(proj_t) & 15) == 0)
+      hipLaunchKernelGGL(pool_dgrad_v8_kernel, dim3(B), dim3(128), 0, st, dfeat, static_cast<const bf16_t*>(proj_t), dpool, B, d, E);
+    else
+      hipLaunchKernelGGL(pool_dgrad_kernel<bf16_t>, dim3(B), dim3(256), 0, st, dfeat, static_cast<const bf16_t*>(proj_t), dpool, B, d, E);
     hipLaunchKernelGGL(pool_wgrad_kernel<bf16_t>, dim3(d), dim3(256), 0, st, static_cast<const bf16_t*>(pool), dfeat, dproj, B, d, E);
   }
   CMH_CHECK_LAUNCH("pooled projection backward");
