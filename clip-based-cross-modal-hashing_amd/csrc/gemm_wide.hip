@@ -1411,6 +1411,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+// the same for up to four (planes, out) pairs in one launch: blockIdx.y names the job (the multi-problem wgrad launch's sums)
+struct ReduceJobs { const float* partial[4]; float* out[4]; size_t n[4]; int S; };
+__global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(ReduceJobs J) {
+  const int job = blockIdx.y;
+  const float* __restrict__ partial = J.partial[job];
+  float* __restrict__ out = J.out[job];
+  const size_t n = J.n[job], n4 = n / 4;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < n4; i += static_cast<size_t>(gridDim.x) * 256) {
+    w_f32x4_t a = *reinterpret_cast<const w_f32x4_t*>(partial + i * 4);
+    for (int s = 1; s < J.S; ++s) a += *reinterpret_cast<const w_f32x4_t*>(partial + static_cast<size_t>(s) * n + i * 4);
+    *reinterpret_cast<w_f32x4_t*>(out + i * 4) = a;
+  }
+}
+
 // Tuning overrides (cmh_gemm_tuning; initial values from CMH_GEMM_BM / CMH_GEMM_ORDER): -1 = decided per launch
 static int g_force_rows = []() { const char* e = getenv("CMH_GEMM_BM"); return e ? atoi(e) : -1; }();
 static int g_force_order = []() { const char* e = getenv("CMH_GEMM_ORDER"); return e ? atoi(e) : -1; }();
@@ -1587,14 +1601,18 @@ int launch_gemm_wide_tn_multi(const TnMultiJob* jobs, int n, float* partials, si
   for (int i = n; i < 4; ++i) tab.j[i] = TnJob{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 1, 1 << 30};
   hipLaunchKernelGGL(gemm_wide_tn_multi_kernel, dim3(first), dim3(512), 0, st, tab);
   if (S > 1) {
+    ReduceJobs R;
+    R.S = S;
     plane = partials;
-    for (int i = 0; i < n; ++i) {
-      const size_t cnt = static_cast<size_t>(jobs[i].Mm) * jobs[i].Nn;
-      const size_t blocks = (cnt / 4 + 255) / 256;
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, plane, S, cnt,
-                         jobs[i].out);
+    size_t most = 0;
+    for (int i = 0; i < 4; ++i) {
+      const size_t cnt = i < n ? static_cast<size_t>(jobs[i].Mm) * jobs[i].Nn : 0;
+      R.partial[i] = plane; R.out[i] = i < n ? jobs[i].out : nullptr; R.n[i] = cnt;
       plane += static_cast<size_t>(S) * cnt;
+      most = cnt > most ? cnt : most;
     }
+    const size_t blocks = (most / 4 + 255) / 256;
+    hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3(static_cast<unsigned>(blocks < 1024 ? blocks : 1024), n), dim3(256), 0, st, R);
   }
   return 0;
 }
