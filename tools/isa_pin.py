@@ -25,7 +25,7 @@ PINS = os.path.join(ROOT, "tests", "golden", "isa_pins.json")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=on", "-S", "--cuda-device-only",
          "-I", os.path.join(ROOT, "include")]
 # (file, regex on the demangled kernel name): the kernels of the default encode / training step
-WATCH = [("gemm_wide.hip", r"gemm_wide_kernel<"), ("gemm_rows.hip", r"gemm_rows_kernel<")]
+WATCH = [("gemm_wide.hip", r"gemm_wide_kernel<|gemm_wide_tn_multi_kernel"), ("gemm_rows.hip", r"gemm_rows_kernel<")]
 
 
 def assemble(src):
