@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CMH_LIB") or os.path.join(_HERE, "csrc", "build", "libcmh.so")   # CMH_LIB: A/B a kernel build
 
-ABI_VERSION = 5            # include/cmh.h CMH_VERSION: bumped whenever a struct layout or a signature changes
+ABI_VERSION = 6            # include/cmh.h CMH_VERSION: bumped whenever a struct layout or a signature changes
 F32, BF16, FP8 = 0, 1, 2
 ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
 TIE_REFERENCE, TIE_STABLE = 0, 1
@@ -105,6 +105,7 @@ SIGNATURES = {
     "cmh_set_pooled_tail": (C.c_int, [_i32]),
     "cmh_set_gemm_rows": (C.c_int, [_i32]),
     "cmh_set_gemm_grouped": (C.c_int, [_i32]),
+    "cmh_set_gemm_lc": (C.c_int, [_i32]),
     "cmh_linear_gemm_grouped": (C.c_int, [_i32, C.POINTER(GemmProblem), C.POINTER(GemmProblem), _i32, _p]),
     "cmh_clip_encode_pair": (C.c_int, [C.POINTER(VitWeights), _p, C.POINTER(TextWeights), _p, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p, _sz, _p]),
     "cmh_msl_workspace_bytes": (_sz, [_i32]),
@@ -404,6 +405,11 @@ def set_pooled_tail(on: bool):
 def set_gemm_rows(on: int = -1):
     """Few-row GEMMs (M <= 512) on 64 x 64 tiles (csrc/gemm_rows.hip): 1 on (default), 0 = the wide kernel takes them, -1 = environment."""
     check(lib().cmh_set_gemm_rows(int(on)), "cmh_set_gemm_rows")
+
+
+def set_gemm_lc(mode: int):
+    """Loader / consumer GEMM kernel (csrc/gemm_lc.hip): 0 never, 1 every eligible launch, 2 all but QuickGELU launches, 3 cost model."""
+    check(lib().cmh_set_gemm_lc(int(mode)), "cmh_set_gemm_lc")
 
 
 def gemm_tuning(tile_rows: int = -1, order_group: int = -1):

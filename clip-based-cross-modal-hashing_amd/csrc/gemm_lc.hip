@@ -1,0 +1,520 @@
+// GEMM "lc" (loader / consumer waves, round 5): out[M,N] = epi(X[M,K].W[N,K]^T), bf16 operands, 16-bit output, 128(m) x 256(n) tile per
+// 512-thread workgroup, persistent like the wide kernel (gemm_wide.hip) - but with the two jobs of its K loop on DIFFERENT waves.
+//
+// Why.  The wide kernel's eight waves each issue their share of a stage's LDS-DMA pieces between their own MFMAs.  A wave issues in
+// order: while it sits in the ~60-180 cycle issue of a `global_load_lds_dwordx4` (the CU's address path moves 64 B/clk) it issues
+// no MFMA, and its SIMD partner has only its own 20 MFMAs of that half-step to cover the hole (anti-phase issue).  Ablation
+// of round 1: the same loop with the DMA compiled out runs 19 % faster; the K-step costs 1750-2000 cycles against 1280 of MFMA work.
+// Here waves 0..3 (one per SIMD) do nothing but stage operands: 12 pieces of 1 KiB per wave and K-step, a counted `s_waitcnt vmcnt`,
+// the barrier.  Waves 4..7 (the other wave of each SIMD) do nothing but multiply: 64 x 128 of the tile each, 64 MFMAs per K-step
+// issued back to back from ONE wave (a single wave keeps a SIMD's matrix pipe full: 16 cycles per v_mfma_f32_16x16x32_bf16,
+// MI355X_MICROARCH cycle table), fragment reads in the MFMAs' issue gaps.  Their vmcnt queue holds only their own epilogue's loads and
+// stores: nothing in the K loop ever waits for a store.
+//
+// Ring and protocol (the wide kernel's): 3 stages x 48 KB (W 256 rows x 128 B | X 128 rows x 128 B, lane-linear image, XOR swizzle on
+// the DMA source chunk and on the ds_read_b128); K-step s lives in buffer s % 3; ONE s_barrier per K-step, placed after the MFMA
+// waves hold every fragment of stage s in registers: behind it the loaders overwrite buffer s % 3 with stage s + 3 (two K-steps of
+// flight) and the MFMA waves start reading stage s + 1, which the loaders' counted wait in front of the barrier has seen land.
+// Fragments: the W operand's eight 16-row fragments are refilled IN PLACE (fragment a of the next half-step is read as soon as the
+// four MFMAs that use fragment a have issued), the X operand's four are double-buffered: 64 fragment registers + 128 accumulators.
+// Same k order per output element as the wide kernel (k = 64 kt + 32 ks + 8 fq + j inside v_mfma_f32_16x16x32_bf16, K-steps in
+// sequence), same epilogue operation order, same residual-first rule: the SAME BITS (tests/test_gpu_lc.py compares with torch.equal).
+#include <cstdlib>
+#include <cstring>
+
+#include "cmh_common.h"
+
+#include <hip/hip_ext.h>
+
+namespace cmh {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 lc_bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float lc_f32x4_t;
+typedef __attribute__((ext_vector_type(2))) float lc_f32x2_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t lc_u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned lc_u2_t;
+typedef const __attribute__((address_space(1))) void* lc_gptr_t;
+typedef __attribute__((address_space(3))) void* lc_lptr_t;
+
+constexpr int lcBM = 128, lcBN = 256;
+constexpr int lcRowBytes = 128;                    // one K-step of one row: 64 bf16
+constexpr int lcWBytes = lcBN * lcRowBytes;        // 32 KB
+constexpr int lcSTG = lcWBytes + lcBM * lcRowBytes;   // 48 KB per stage
+
+struct LcProblem {
+  const char* X; const char* W; const float* bias; const void* residual; void* out;
+  const int* m_dev;      // optional: the real row count on the device (Mub is then an upper bound)
+  int Mub, N, K;
+};
+
+__device__ __forceinline__ int lc_swz(int row, int chunk) { return row * lcRowBytes + ((chunk ^ (row & 7)) << 4); }
+
+#define LC_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+
+// RF: the residual-first rule applies to this launch (short K with a residual: the accumulators start as the residual tile); a template
+// parameter so that a tile's first K-step is one straight path - C = 0 inside the first MFMAs, or the loaded residual
+// ABL (diagnostic instantiations only, CMH_LC_ABL): 1 the MFMA waves skip their MFMAs (what the feed alone sustains), 2 the loaders stage
+// nothing after the prologue (what the MFMA side alone sustains), 4 one stage in flight instead of two
+template <bool GRP, bool RF, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm_lc_kernel(LcProblem p0, LcProblem p1, int epi) {
+  __shared__ __attribute__((aligned(1024))) char lds[3 * lcSTG + 2 * 1024];      // the ring + two bias rows (tile parity)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // every field the kernel reads, as wave-uniform locals (selecting between the two by-value structs at run time would put them on the stack)
+  const char* const X0 = p0.X; const char* const W0 = p0.W; const float* const B0 = p0.bias;
+  const void* const R0 = p0.residual; void* const O0 = p0.out;
+  const int N0 = p0.N, K0 = p0.K;
+  const char* const X1 = p1.X; const char* const W1 = p1.W; const float* const B1 = p1.bias;
+  const void* const R1 = p1.residual; void* const O1 = p1.out;
+  const int N1 = p1.N, K1 = p1.K;
+  int M0 = p0.Mub;
+  if (p0.m_dev) { const int md = *p0.m_dev; M0 = md < M0 ? md : M0; }
+  M0 = __builtin_amdgcn_readfirstlane(M0);        // (a loaded value: the compiler cannot know that it is uniform)
+  int M1 = 0;
+  if constexpr (GRP) {
+    M1 = p1.Mub;
+    if (p1.m_dev) { const int md = *p1.m_dev; M1 = md < M1 ? md : M1; }
+    M1 = __builtin_amdgcn_readfirstlane(M1);
+  }
+  // ---- this workgroup's tiles: the wide kernel's static assignment.  XCD x = blockIdx % 8 owns a contiguous eighth of each problem's
+  // n-fastest tile order; workgroup `slot` of the XCD takes positions slot, slot + per, ... of the concatenation of the two eighths.
+  const int tiles_n0 = N0 / lcBN, tiles_n1 = GRP ? N1 / lcBN : 1;
+  const int total0 = tiles_n0 * ((M0 + lcBM - 1) / lcBM);
+  const int total1 = GRP ? tiles_n1 * ((M1 + lcBM - 1) / lcBM) : 0;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
+  const int q0 = total0 >> 3, r0 = total0 & 7, q1 = total1 >> 3, r1 = total1 & 7;
+  const int lo0 = xcd < r0 ? xcd * (q0 + 1) : r0 * (q0 + 1) + (xcd - r0) * q0, len0 = xcd < r0 ? q0 + 1 : q0;
+  const int lo1 = xcd < r1 ? xcd * (q1 + 1) : r1 * (q1 + 1) + (xcd - r1) * q1, len1 = xcd < r1 ? q1 + 1 : q1;
+  const int n_first = slot < len0 ? (len0 - slot + per - 1) / per : 0;
+  const int span = len0 + len1;
+  const int my_tiles = slot < span ? (span - slot + per - 1) / per : 0;
+  if (my_tiles == 0) return;
+  const int nk0 = K0 / 64, nk1 = GRP ? K1 / 64 : 0;
+  const int S = n_first * nk0 + (my_tiles - n_first) * nk1;      // K-steps of this workgroup = barriers after the prologue's
+  // tile ti -> (second problem?, m0, n0)
+  auto tile_of = [&](int ti, bool& second, int& m0, int& n0) {
+    const int j = slot + ti * per;
+    second = GRP && ti >= n_first;
+    const int logical = second ? lo1 + (j - len0) : lo0 + j;
+    const int tn_cnt = second ? tiles_n1 : tiles_n0;
+    const int tm = logical / tn_cnt;
+    m0 = tm * lcBM;
+    n0 = (logical - tm * tn_cnt) * lcBN;
+  };
+
+  if (wid < 4) {
+    // =================================================== loader waves ===============================================================
+    // Piece = 1 KiB = 8 rows x 128 B: lane i fills (row 8 piece + i / 8, physical chunk i % 8) and fetches logical chunk (i % 8) ^ (row & 7).
+    // Wave l stages W pieces 8 l .. 8 l + 7 and X pieces 4 l .. 4 l + 3 of every stage.  Source = uniform base + 32-bit lane offset.
+    const int sub = lane >> 3, ch = lane & 7;
+    uint32_t offW[8], offX[4];
+    const char* Wt = nullptr;
+    const char* Xt = nullptr;
+    const char* Bt = nullptr;      // &bias[n0] of the tile being staged
+    int i_nk = 0;
+    int w_prob = -1;               // the problem offW was computed for
+    auto set_tile = [&](int ti) {
+      bool second; int m0, n0;
+      tile_of(ti, second, m0, n0);
+      const uint32_t rs = static_cast<uint32_t>(second ? K1 : K0) * 2;
+      if (w_prob != static_cast<int>(second)) {      // once per problem: the W offsets follow its row stride
+        w_prob = static_cast<int>(second);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int row = (wid * 8 + i) * 8 + sub;
+          offW[i] = static_cast<uint32_t>(row) * rs + ((ch ^ (row & 7)) << 4);
+        }
+      }
+      i_nk = second ? nk1 : nk0;
+      const int Mp = second ? M1 : M0;
+      Wt = (second ? W1 : W0) + static_cast<size_t>(n0) * rs;
+      Xt = second ? X1 : X0;
+      Bt = reinterpret_cast<const char*>((second ? B1 : B0) + n0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (wid * 4 + i) * 8 + sub;
+        int xr = m0 + row;
+        xr = xr < Mp ? xr : Mp - 1;               // rows past M are computed on duplicated data and never stored
+        offX[i] = static_cast<uint32_t>(xr) * rs + ((ch ^ (row & 7)) << 4);      // < 4 GiB: checked on the host
+      }
+    };
+    int i_tile = 0, i_kt = 0, ibuf = 0;
+    set_tile(0);
+    const bool bias_wave = wid == 0 && (epi & EPI_BIAS);
+    auto issue_stage = [&]() {
+      char* base = lds + ibuf * lcSTG;
+      const uint32_t koff = static_cast<uint32_t>(i_kt) * lcRowBytes;
+      // The tile's 256 bias values (1 KiB) go to LDS with its first stage: OLDER than that stage's pieces in this wave's queue, so
+      // every counted wait that retires the stage retires them too.  Slot = tile parity: tile t - 2's epilogue is over before the
+      // loaders reach tile t (three stages ahead of the MFMA waves at most, and a tile has >= 4 K-steps).
+      if (i_kt == 0 && bias_wave)
+        __builtin_amdgcn_global_load_lds((lc_gptr_t)(Bt + lane * 16), (lc_lptr_t)(lds + 3 * lcSTG + (i_tile & 1) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_global_load_lds((lc_gptr_t)(Wt + koff + offW[i]), (lc_lptr_t)(base + (wid * 8 + i) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((lc_gptr_t)(Xt + koff + offX[i]), (lc_lptr_t)(base + lcWBytes + (wid * 4 + i) * 1024), 16, 0, 0);
+      ibuf = ibuf == 2 ? 0 : ibuf + 1;
+      if (++i_kt == i_nk) {
+        i_kt = 0;
+        if (++i_tile < my_tiles) set_tile(i_tile);
+      }
+    };
+    issue_stage();
+    if (S > 1) issue_stage();
+    if (S > 2) issue_stage();
+    if (S > 2) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");        // stage 0 landed; two younger stages may fly
+    else if (S > 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int s = 0; s < S; ++s) {
+      // in front of barrier s: stage s + 1 has landed (stage s + 2 may fly)
+      if (s + 2 < S && !(ABL & 4)) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      // behind it nobody reads buffer s % 3 any more
+      if (s + 3 < S && !(ABL & 2)) issue_stage();
+    }
+    return;
+  }
+
+  // ===================================================== MFMA waves ===================================================================
+  const int c = wid - 4;
+  const int wm = c >> 1, wn = c & 1;              // 2 (m) x 2 (n) waves of 64 x 128
+  const int frow = lane & 15, fq = lane >> 4;
+  const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lc_lptr_t)lds));
+  const uint32_t aW = lds_base + lc_swz(wn * 128 + frow, fq);
+  const uint32_t aX = lds_base + lcWBytes + lc_swz(wm * 64 + frow, fq);
+
+  lc_f32x4_t acc[8][4];                            // [n-fragment][m-fragment]
+  lc_u32x4_t fw[8], fxa[4], fxb[4];
+
+  // the compute side's view of its problem
+  const void* residual = R0;
+  void* out = O0;
+  int N = N0, M = M0, nk = nk0;
+  [[maybe_unused]] auto to_problem1 = [&]() {
+    residual = R1; out = O1; N = N1; M = M1; nk = nk1;
+  };
+  if constexpr (GRP) { if (n_first == 0) to_problem1(); }
+  // the wide kernel's residual-first rule: short K -> the accumulators START as the residual tile ((residual + sum) + bias), long K ->
+  // the residual is added behind the bias; per GEMM, never per tile position
+  // (RF is decided on the host from the same condition: EPI_RESIDUAL without an activation, and nk <= 16 for every problem of the launch)
+
+  // fp16 residual rows in the 16-byte layout of the packed output (lane = one row x 8 consecutive n), brought to the accumulator layout
+  // by v_permlane16_swap; one 16-row fragment (b) at a time: 4 loads of 16 bytes in flight per lane
+  auto add_residual = [&](int m0, int n0) __attribute__((always_inline)) {
+    const uint16_t* res16 = reinterpret_cast<const uint16_t*>(residual);
+    const int col = n0 + wn * 128 + (fq & 1) * 16 + (fq & 2) * 4;      // + 32 * pair
+#pragma unroll
+    for (int bg = 0; bg < 4; bg += 2) {
+      lc_u32x4_t r[2][4];
+#pragma unroll
+      for (int b = bg; b < bg + 2; ++b) {
+        int m = m0 + wm * 64 + b * 16 + frow;
+        m = m < M ? m : M - 1;
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) r[b - bg][pr] = *reinterpret_cast<const lc_u32x4_t*>(res16 + static_cast<size_t>(m) * N + col + 32 * pr);
+      }
+#pragma unroll
+      for (int b = bg; b < bg + 2; ++b) {
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+          const lc_u32x4_t qv = r[b - bg][pr];
+          const lc_u2_t s0 = __builtin_amdgcn_permlane16_swap(qv[0], qv[2], false, false);
+          const lc_u2_t s1 = __builtin_amdgcn_permlane16_swap(qv[1], qv[3], false, false);
+          acc[2 * pr][b][0] += f16lo_to_f32(s0[0]); acc[2 * pr][b][1] += f16hi_to_f32(s0[0]);
+          acc[2 * pr][b][2] += f16lo_to_f32(s1[0]); acc[2 * pr][b][3] += f16hi_to_f32(s1[0]);
+          acc[2 * pr + 1][b][0] += f16lo_to_f32(s0[1]); acc[2 * pr + 1][b][1] += f16hi_to_f32(s0[1]);
+          acc[2 * pr + 1][b][2] += f16lo_to_f32(s1[1]); acc[2 * pr + 1][b][3] += f16hi_to_f32(s1[1]);
+        }
+      }
+    }
+  };
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = lc_f32x4_t{0.f, 0.f, 0.f, 0.f};
+  };
+  auto mfma = [&](const lc_u32x4_t& w, const lc_u32x4_t& x, const lc_f32x4_t& cin) __attribute__((always_inline)) {
+    if constexpr (ABL & 1) {      // keep the operands alive, skip the instruction
+      asm volatile("" ::"v"(w), "v"(x));
+      return cin;
+    } else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lc_bf16x8_t, w), __builtin_bit_cast(lc_bf16x8_t, x), cin, 0, 0, 0);
+  };
+#define LC_WAIT5(cnt, r0, r1, r2, r3, r4) \
+  asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4)::"memory")
+#define LC_WAIT1(cnt, r0) asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(r0)::"memory")
+#define LC_WAIT_ALLW(cnt) \
+  asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(fw[0]), "+v"(fw[1]), "+v"(fw[2]), "+v"(fw[3]), "+v"(fw[4]), "+v"(fw[5]), "+v"(fw[6]), "+v"(fw[7])::"memory")
+
+  // W fragment a / X fragment b of (buffer byte offset bo, half ks): 16-row fragments sit 2048 bytes apart, the second 32-deep half is
+  // the first one's address XOR 64
+#define LC_READ_W(a, addr)                                                       \
+  do {                                                                           \
+    if constexpr ((a) == 0) LC_READ(fw[0], addr, 0);                             \
+    else if constexpr ((a) == 1) LC_READ(fw[1], addr, 2048);                     \
+    else if constexpr ((a) == 2) LC_READ(fw[2], addr, 4096);                     \
+    else if constexpr ((a) == 3) LC_READ(fw[3], addr, 6144);                     \
+    else if constexpr ((a) == 4) LC_READ(fw[4], addr, 8192);                     \
+    else if constexpr ((a) == 5) LC_READ(fw[5], addr, 10240);                    \
+    else if constexpr ((a) == 6) LC_READ(fw[6], addr, 12288);                    \
+    else LC_READ(fw[7], addr, 14336);                                            \
+  } while (0)
+#define LC_READ_X(fx, b, addr)                                                   \
+  do {                                                                           \
+    if constexpr ((b) == 0) LC_READ(fx[0], addr, 0);                             \
+    else if constexpr ((b) == 1) LC_READ(fx[1], addr, 2048);                     \
+    else if constexpr ((b) == 2) LC_READ(fx[2], addr, 4096);                     \
+    else LC_READ(fx[3], addr, 6144);                                             \
+  } while (0)
+
+  // ---- prologue: the first tile's residual rows (if they come first) are on their way while stage 0 lands ----------------------
+  int cur = 0;
+  {
+    bool second; int m0, n0;
+    tile_of(0, second, m0, n0);
+    if constexpr (RF) { zero_acc(); add_residual(m0, n0); }
+  }
+  __builtin_amdgcn_s_barrier();                    // stage 0 has landed
+  // fragments of (stage 0, k 0..31): X then W, the order every later half-step issues them in
+  LC_READ_X(fxa, 0, aX); LC_READ_X(fxa, 1, aX); LC_READ_X(fxa, 2, aX); LC_READ_X(fxa, 3, aX);
+  LC_READ_W(0, aW); LC_READ_W(1, aW); LC_READ_W(2, aW); LC_READ_W(3, aW);
+  LC_READ_W(4, aW); LC_READ_W(5, aW); LC_READ_W(6, aW); LC_READ_W(7, aW);
+
+  // One K-step.  Half 0 multiplies (fxa, fw) = k 0..31 and reads k 32..63 of the same stage (fxb; fw in place); half 1 multiplies those,
+  // passes the barrier after its second fragment group - every read of this stage was issued at least 8 MFMAs earlier - and reads
+  // k 0..31 of the next stage (fxa; fw in place).  LDS returns a wave's reads in order, so "fragment a has landed" is a count of the
+  // reads issued after it: 11 in the steady state of half 0 (7 - a older W fragments still to come, the 4 X reads and the a W reads of
+  // the next half-step issued since), 7 - a at the top of half 1.
+  auto kstep = [&](auto zc) __attribute__((always_inline)) {
+    constexpr bool ZC = decltype(zc)::value;      // first K-step of a tile whose accumulators start at zero: C = 0 instead of 128 v_mov
+    const uint32_t bo = static_cast<uint32_t>(cur) * lcSTG;
+    const uint32_t w1 = (aW + bo) ^ 64u, x1 = (aX + bo) ^ 64u;
+    // ---------------- half 0 ----------------
+    LC_WAIT5(7, fxa[0], fxa[1], fxa[2], fxa[3], fw[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#define LC_MFMA0(a, b) acc[a][b] = mfma(fw[a], fxa[b], ZC ? lc_f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[a][b])
+#define LC_GROUP0(a)                                                                                   \
+  do {                                                                                                 \
+    if constexpr ((a) > 0) { LC_WAIT1(11, fw[a]); __builtin_amdgcn_sched_barrier(0); }                 \
+    if constexpr ((a) == 0) LC_READ_X(fxb, 0, x1);                                                     \
+    LC_MFMA0(a, 0);                                                                                    \
+    if constexpr ((a) == 0) LC_READ_X(fxb, 1, x1);                                                     \
+    LC_MFMA0(a, 1);                                                                                    \
+    if constexpr ((a) == 0) LC_READ_X(fxb, 2, x1);                                                     \
+    LC_MFMA0(a, 2);                                                                                    \
+    if constexpr ((a) == 0) LC_READ_X(fxb, 3, x1);                                                     \
+    LC_MFMA0(a, 3);                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    LC_READ_W(a, w1);                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+  } while (0)
+    LC_GROUP0(0); LC_GROUP0(1); LC_GROUP0(2); LC_GROUP0(3); LC_GROUP0(4); LC_GROUP0(5); LC_GROUP0(6); LC_GROUP0(7);
+#undef LC_GROUP0
+#undef LC_MFMA0
+    // ---------------- half 1 ----------------
+    const int nxt = cur == 2 ? 0 : cur + 1;
+    const uint32_t bn = static_cast<uint32_t>(nxt) * lcSTG;
+    const uint32_t w0 = aW + bn, x0 = aX + bn;
+#define LC_MFMA1(a, b) acc[a][b] = mfma(fw[a], fxb[b], acc[a][b])
+    LC_WAIT5(7, fxb[0], fxb[1], fxb[2], fxb[3], fw[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    LC_MFMA1(0, 0); LC_MFMA1(0, 1); LC_MFMA1(0, 2); LC_MFMA1(0, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    LC_WAIT1(6, fw[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    LC_MFMA1(1, 0); LC_MFMA1(1, 1); LC_MFMA1(1, 2); LC_MFMA1(1, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    LC_WAIT_ALLW(0);                               // every fragment of this stage is in registers
+    __builtin_amdgcn_s_barrier();                  // ... in every MFMA wave; the next stage has landed
+    __builtin_amdgcn_sched_barrier(0);
+    // group 2 carries the X reads of the next stage and the two W fragments whose MFMAs ran in front of the barrier
+    LC_READ_X(fxa, 0, x0);
+    LC_MFMA1(2, 0);
+    LC_READ_X(fxa, 1, x0);
+    LC_MFMA1(2, 1);
+    LC_READ_X(fxa, 2, x0);
+    LC_MFMA1(2, 2);
+    LC_READ_X(fxa, 3, x0);
+    LC_MFMA1(2, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    LC_READ_W(0, w0);
+    LC_READ_W(1, w0);
+    LC_READ_W(2, w0);
+    __builtin_amdgcn_sched_barrier(0);
+#define LC_GROUP1(a)                                                                                   \
+  do {                                                                                                 \
+    LC_MFMA1(a, 0); LC_MFMA1(a, 1); LC_MFMA1(a, 2); LC_MFMA1(a, 3);                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    LC_READ_W(a, w0);                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+  } while (0)
+    LC_GROUP1(3); LC_GROUP1(4); LC_GROUP1(5); LC_GROUP1(6); LC_GROUP1(7);
+#undef LC_GROUP1
+#undef LC_MFMA1
+    cur = nxt;
+  };
+
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    bool second; int m0, n0;
+    tile_of(ti, second, m0, n0);
+    if constexpr (GRP) { if (ti == n_first && ti > 0) to_problem1(); }
+    constexpr bool rf = RF;
+    if constexpr (RF) { if (ti > 0) { zero_acc(); add_residual(m0, n0); } }
+    kstep(std::integral_constant<bool, !RF>{});
+    for (int kt = 1; kt < nk; ++kt) kstep(std::false_type{});
+
+    // ---- epilogue (the loaders are already staging the next tile; its first fragments are on their way into fxa / fw) -------------
+    // One wave per SIMD: nobody covers a memory round trip here.  The bias row comes from LDS (staged by the loaders with the tile's
+    // first stage), four fragments at a time; residual rows (long K only) two 16-row fragments at a time.
+    if (epi & EPI_BIAS) {
+      const uint32_t ab = lds_base + 3 * lcSTG + (ti & 1) * 1024 + (wn * 128 + fq * 4) * 4;
+#pragma unroll
+      for (int ag = 0; ag < 8; ag += 4) {
+        lc_f32x4_t bv[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bv[a]) : "v"(ab), "n"((ag + a) * 64));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3])::"memory");
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[ag + a][b] += bv[a];
+      }
+    }
+    if (epi & EPI_QUICKGELU) {
+      // two values at a time, the wide kernel's instruction sequence (packed-f32 multiply / add, v_exp_f32 / v_rcp_f32 per value)
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int j = 0; j < 4; j += 2) {
+            const lc_f32x2_t v = {acc[a][b][j], acc[a][b][j + 1]};
+            const lc_f32x2_t t = v * lc_f32x2_t{-2.4554669595930157f, -2.4554669595930157f};
+            const lc_f32x2_t d = lc_f32x2_t{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + lc_f32x2_t{1.0f, 1.0f};
+            const lc_f32x2_t o = v * lc_f32x2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+            acc[a][b][j] = o[0];
+            acc[a][b][j + 1] = o[1];
+          }
+    }
+    if ((epi & EPI_RESIDUAL) && !rf) add_residual(m0, n0);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      // v_permlane16_swap exchanges, between the lane pairs (l, l + 16), the packed words of two neighbouring n-fragments: an even
+      // lane-row then owns 8 consecutive n of fragment 2 pr and an odd lane-row 8 consecutive n of fragment 2 pr + 1 -> 16-byte stores
+      const int col = n0 + wn * 128 + (fq & 1) * 16 + (fq & 2) * 4;      // + 32 * pair
+      char* optr = static_cast<char*>(out) + (static_cast<size_t>(m0 + wm * 64 + frow) * N + col) * 2;
+      const size_t row16 = static_cast<size_t>(16) * N * 2;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const bool row_ok = m0 + wm * 64 + b * 16 + frow < M;
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+          uint32_t lo[2], hi[2];
+#pragma unroll
+          for (int w = 0; w < 2; ++w) {
+            if (epi & EPI_OUT_F16) {
+              lo[w] = pack_f16x2(acc[2 * pr][b][2 * w], acc[2 * pr][b][2 * w + 1]);
+              hi[w] = pack_f16x2(acc[2 * pr + 1][b][2 * w], acc[2 * pr + 1][b][2 * w + 1]);
+            } else {
+              lo[w] = pack_bf16x2(acc[2 * pr][b][2 * w], acc[2 * pr][b][2 * w + 1]);
+              hi[w] = pack_bf16x2(acc[2 * pr + 1][b][2 * w], acc[2 * pr + 1][b][2 * w + 1]);
+            }
+          }
+          const lc_u2_t s0 = __builtin_amdgcn_permlane16_swap(lo[0], hi[0], false, false);
+          const lc_u2_t s1 = __builtin_amdgcn_permlane16_swap(lo[1], hi[1], false, false);
+          if (row_ok && !(epi & 256))          // 256 = timing-only ablation: skip stores
+            *reinterpret_cast<lc_u32x4_t*>(optr + b * row16 + pr * 64) = lc_u32x4_t{s0[0], s1[0], s0[1], s1[1]};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads issued past the last stage
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------------------
+static int lc_env_mode() { static const int m = []() { const char* e = getenv("CMH_GEMM_LC"); return e ? atoi(e) : 0; }(); return m; }
+static int g_lc_mode = -1;         // cmh_set_gemm_lc: -1 = environment (CMH_GEMM_LC, default 0 = off)
+int gemm_lc_mode() { return g_lc_mode < 0 ? lc_env_mode() : g_lc_mode; }
+void gemm_lc_set_mode(int m) { g_lc_mode = m; }
+
+// bf16 operands, 16-bit output, the forward epilogues of a transformer block (bias, + QuickGELU, + fp16 residual), N % 256 == 0
+bool gemm_lc_takes(int dt, int N, int K, int epi) {
+  if (dt != CMH_BF16 || N % lcBN != 0 || K % 64 != 0 || K < 256) return false;      // >= 4 K-steps per tile: the bias slots' reuse distance
+  if (!(epi & (EPI_OUT_BF16 | EPI_OUT_F16)) || ((epi & EPI_OUT_BF16) && (epi & EPI_OUT_F16))) return false;
+  if (epi & ~(EPI_BIAS | EPI_QUICKGELU | EPI_RESIDUAL | EPI_RES_F16 | EPI_OUT_BF16 | EPI_OUT_F16 | 256)) return false;
+  if ((epi & EPI_RESIDUAL) && !(epi & EPI_RES_F16)) return false;      // the 16-bit-output launches carry the fp16 stream
+  if ((epi & EPI_RESIDUAL) && (epi & EPI_QUICKGELU)) return false;
+  return true;
+}
+
+// the wide kernel's residual-first rule (gemm_wide.hip, res_first): per GEMM
+bool gemm_lc_res_first(int epi, int K) {
+  return (epi & EPI_RESIDUAL) && !(epi & (EPI_QUICKGELU | EPI_GELU | EPI_RELU)) && K / 64 <= 16;
+}
+
+static int lc_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus < 8) cus = 256;
+    cus &= ~7;
+  }
+  return cus;
+}
+
+// b == nullptr: one problem.  The problem with the longer K goes first (its tiles are the long jobs of the static schedule).
+int launch_gemm_lc(const GemmProblem& a, const GemmProblem* b, int epi, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+  for (const GemmProblem* g : {&a, b}) {
+    if (!g) continue;
+    if (static_cast<size_t>(g->M) * g->K * 2 >= (1ull << 32) || static_cast<size_t>(lcBN) * g->K * 2 >= (1ull << 32))
+      return fail(CMH_ERR_INVALID, "gemm (lc): operand of %zu bytes exceeds the 32-bit offset range", static_cast<size_t>(g->M) * g->K * 2);
+  }
+  auto prob = [](const GemmProblem& g) {
+    return LcProblem{static_cast<const char*>(g.A), static_cast<const char*>(g.W), g.bias, g.residual, g.out, g.m_dev, g.M, g.N, g.K};
+  };
+  auto tiles_of = [](const GemmProblem& g) { return (g.N / lcBN) * ((g.M + lcBM - 1) / lcBM); };
+  const int cus = lc_cus();
+  const int total = tiles_of(a) + (b ? tiles_of(*b) : 0);
+  const int grid = total < cus ? ((total + 7) & ~7) : cus;     // sized for the upper bounds: workgroups without a tile exit at once
+  const LcProblem P0 = prob(a), P1 = b ? prob(*b) : LcProblem{};
+  const bool rf = gemm_lc_res_first(epi, a.K);      // (the caller has checked that both problems agree)
+#define LC_GO(G, R)                                                                                                          \
+  do {                                                                                                                       \
+    if (ev0) hipExtLaunchKernelGGL((gemm_lc_kernel<G, R>), dim3(grid), dim3(512), 0, st, ev0, ev1, 0, P0, P1, epi);          \
+    else hipLaunchKernelGGL((gemm_lc_kernel<G, R>), dim3(grid), dim3(512), 0, st, P0, P1, epi);                              \
+  } while (0)
+  static const int abl = []() { const char* e = getenv("CMH_LC_ABL"); return e ? atoi(e) : 0; }();
+  if (abl && !b && !rf) {      // diagnostic builds of the plain, residual-free form only
+#define LC_GO_A(A)                                                                                                            \
+  do {                                                                                                                       \
+    if (ev0) hipExtLaunchKernelGGL((gemm_lc_kernel<false, false, A>), dim3(grid), dim3(512), 0, st, ev0, ev1, 0, P0, P1, epi); \
+    else hipLaunchKernelGGL((gemm_lc_kernel<false, false, A>), dim3(grid), dim3(512), 0, st, P0, P1, epi);                    \
+  } while (0)
+    if (abl == 1) LC_GO_A(1); else if (abl == 2) LC_GO_A(2); else if (abl == 3) LC_GO_A(3); else LC_GO_A(4);
+#undef LC_GO_A
+    return 0;
+  }
+  if (b) { if (rf) LC_GO(true, true); else LC_GO(true, false); }
+  else { if (rf) LC_GO(false, true); else LC_GO(false, false); }
+#undef LC_GO
+  return 0;
+}
+
+}  // namespace cmh
+
+extern "C" int cmh_set_gemm_lc(int32_t mode) {
+  CMH_CHECK_ARG(mode >= -1 && mode <= 3, "set_gemm_lc: mode %d (-1 environment, 0 off, 1 every eligible launch, 2 all but QuickGELU launches, 3 by cost model)", mode);
+  cmh::gemm_lc_set_mode(mode);
+  return CMH_OK;
+}

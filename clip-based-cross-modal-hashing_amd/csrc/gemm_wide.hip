@@ -1391,6 +1391,18 @@ bool gemm_wide_supported(int N) { return N % wBN == 0; }
 // instead of bracketing the launch with two hipEventRecord marker packets (those add the inter-packet gaps to every launch).
 static hipEvent_t g_wide_ev0 = nullptr, g_wide_ev1 = nullptr;
 void gemm_wide_time_next(hipEvent_t start, hipEvent_t stop) { g_wide_ev0 = start; g_wide_ev1 = stop; }
+// gemm_lc.hip: the loader / consumer form of this GEMM (round 5): same bits, other wave roles
+int gemm_lc_mode();
+bool gemm_lc_takes(int dt, int N, int K, int epi);
+bool gemm_lc_res_first(int epi, int K);
+int launch_gemm_lc(const GemmProblem& a, const GemmProblem* b, int epi, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+bool g_force_rows_set();
+static bool wide_goes_lc(int dt, int epi) {
+  const int mode = gemm_lc_mode();
+  if (mode == 0 || g_force_rows_set()) return false;
+  if (mode == 2 && (epi & EPI_QUICKGELU)) return false;
+  return dt == CMH_BF16;
+}
 #define W_GO(KERNEL, GRID, ST, ...)                                                                              \
   do {                                                                                                          \
     if (g_wide_ev0) {                                                                                           \
@@ -1427,6 +1439,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(ReduceJobs J) 
 
 // Tuning overrides (cmh_gemm_tuning; initial values from CMH_GEMM_BM / CMH_GEMM_ORDER): -1 = decided per launch
 static int g_force_rows = []() { const char* e = getenv("CMH_GEMM_BM"); return e ? atoi(e) : -1; }();
+bool g_force_rows_set() { return g_force_rows > 0; }      // a pinned tile height names the wide kernel's own variants
 static int g_force_order = []() { const char* e = getenv("CMH_GEMM_ORDER"); return e ? atoi(e) : -1; }();
 
 // Deferred QuickGELU (template parameter DGE): which launches take it, and what the activation costs a tile switch in the cost
@@ -1620,6 +1633,12 @@ int launch_gemm_wide_tn_multi(const TnMultiJob* jobs, int n, float* partials, si
 int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, const float* residual, void* out,
                      int M, int N, int K, int epi, hipStream_t st, const float* colscale, float alpha, float oscale,
                      const int32_t* m_dev, int m_hint) {
+  if (wide_goes_lc(dt, epi) && gemm_lc_takes(dt, N, K, epi)) {
+    const GemmProblem g{A, W, bias, residual, out, M, N, K, m_dev, m_hint, nullptr, 1.f, 1.f};
+    const int rc = launch_gemm_lc(g, nullptr, epi, st, g_wide_ev0, g_wide_ev1);
+    g_wide_ev0 = g_wide_ev1 = nullptr;
+    return rc;
+  }
   const WideScales sc{colscale, alpha, oscale, 0, nullptr, m_dev};
   const size_t esz = dt == CMH_F32 ? 4 : (dt == CMH_FP8 ? 1 : 2);
   if (static_cast<size_t>(M) * K * esz >= (1ull << 32) || static_cast<size_t>(wBN) * K * esz >= (1ull << 32))
@@ -1768,6 +1787,12 @@ static long long wide_grouped_cost(int dt, const GemmProblem& a, const GemmProbl
 }
 
 int launch_gemm_wide_grouped(int dt, const GemmProblem& a, const GemmProblem& b, int epi, hipStream_t st) {
+  if (wide_goes_lc(dt, epi) && gemm_lc_takes(dt, a.N, a.K, epi) && gemm_lc_takes(dt, b.N, b.K, epi) &&
+      gemm_lc_res_first(epi, a.K) == gemm_lc_res_first(epi, b.K)) {
+    const int rc = launch_gemm_lc(a, &b, epi, st, g_wide_ev0, g_wide_ev1);
+    g_wide_ev0 = g_wide_ev1 = nullptr;
+    return rc;
+  }
   const size_t esz = dt == CMH_F32 ? 4 : (dt == CMH_FP8 ? 1 : 2);
   for (const GemmProblem* g : {&a, &b})
     if (static_cast<size_t>(g->M) * g->K * esz >= (1ull << 32) || static_cast<size_t>(wBN) * g->K * esz >= (1ull << 32))

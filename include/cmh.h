@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define CMH_VERSION 5   /* = the round that last changed a struct layout or a signature; cmh_native.lib() refuses any other */
+#define CMH_VERSION 6   /* = the round that last changed a struct layout or a signature; cmh_native.lib() refuses any other */
 
 typedef enum cmh_status {
   CMH_OK = 0,
@@ -239,6 +239,12 @@ int cmh_gemm_tuning(int32_t tile_rows, int32_t order_group);
  * the wide kernel's 96..160 x 256 ones: same bits per output element (same MFMA chain over K, same epilogue order), more workgroups.
  * on = 0 sends them to the wide kernel again (A/B, tests), 1 forces the default, -1 = environment (CMH_GEMM_ROWS=0 is off). */
 int cmh_set_gemm_rows(int32_t on);
+/* Round 5: the loader / consumer form of the N % 256 == 0 GEMM (csrc/gemm_lc.hip: four waves of a workgroup only stage operands by
+ * LDS-DMA, the other four only multiply; 128 x 256 tiles; bf16 operands with 16-bit outputs and the forward epilogues of a transformer
+ * block: bias, + QuickGELU, + fp16 residual; plain and grouped launches).  Same bits per output element as the wide kernel (same MFMA
+ * chain over K, same epilogue order).  mode 0: never; 1: every launch it can take; 2: every such launch without QuickGELU;
+ * 3: where the host's cost model expects it to be faster; -1: the environment's CMH_GEMM_LC (default).  Process-wide, not thread-safe. */
+int cmh_set_gemm_lc(int32_t mode);
 
 /* encode_image / encode_text return one pooled row per sample (model/base/model.py:247-250, 366-370), and past the last block's
  * attention every operation is row-wise, so cmh_vit_encode / cmh_text_encode[_packed] carry only those B rows through the last

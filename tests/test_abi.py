@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     exported = set(re.findall(r" T (cmh_[a-z0-9_]+)", out))
     assert set(declared) <= exported, sorted(set(declared) - exported)
     assert set(N.SIGNATURES) == set(declared)
-    assert lib.cmh_version() == N.ABI_VERSION == 5
+    assert lib.cmh_version() == N.ABI_VERSION == 6
     assert lib.cmh_last_error() is not None
 
 
