@@ -197,6 +197,7 @@ __device__ __forceinline__ void attention_mfma_body(const bf16_t* __restrict__ q
   const size_t srow = seq_off ? static_cast<size_t>(__builtin_amdgcn_readfirstlane(seq_off[b])) : static_cast<size_t>(b) * Tmax;
   const size_t ld = static_cast<size_t>(3) * d;
   const bf16_t* base = qkv + srow * ld + h * HD;
+  if (Tn <= 0) return;      // an empty sequence has no rows to read or write (the clamps below would reach row -1); one wave per block
 
   // Round 4: every load of the prologue is issued before anything waits.  The first form staged V with a rolled loop - one 16-byte
   // load in flight per lane, a wait and an LDS store per iteration: eight (NKT = 4) to sixteen serial memory round trips in front of

@@ -159,9 +159,9 @@ int launch_layernorm(const float* x, const int32_t* row_index, const float* w, c
 int launch_layernorm_x(const void* x, int x_f16, const int32_t* row_index, const float* w, const float* b,
                        void* out, int out_bf16, int M, int d, hipStream_t st, const int32_t* m_dev = nullptr);
 
-// the bf16 mode's LayerNorm (fp16 stream -> bf16 rows) of two row sets in ONE launch (the lock-step pair path); false = no kernel for
-// this pair of widths (or CMH_PAIR_KERNELS=0): launch the two singly
-bool launch_layernorm_h2b_pair(const void* x0, const float* w0, const float* b0, void* out0, int M0, int d0, const int32_t* md0,
+// the bf16 mode's LayerNorm (fp16 stream -> bf16 rows) of two row sets in ONE launch (the lock-step pair path); CMH_OK = launched,
+// 1 = no kernel for this pair of widths (or CMH_PAIR_KERNELS=0): launch the two singly; < 0 = the launch itself failed
+int launch_layernorm_h2b_pair(const void* x0, const float* w0, const float* b0, void* out0, int M0, int d0, const int32_t* md0,
                                const void* x1, const float* w1, const float* b1, void* out1, int M1, int d1, const int32_t* md1,
                                hipStream_t st);
 // image [B,3,R,R] f32 -> patches [B*g*g, 3*p*p] (dt)

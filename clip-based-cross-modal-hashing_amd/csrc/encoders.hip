@@ -246,9 +246,12 @@ static int run_block_pair(const cmh_block_weights& wa, const cmh_block_weights& 
   }
   const int dt = dtb;
   const int obf = dt == CMH_BF16 ? EPI_OUT_BF16 : 0;
+  CMH_CHECK_ARG(a.t.xh == b.t.xh, "run_block_pair: the towers' residual streams differ in kind (the caller runs such towers one by one)");
   const int rx = EPI_BIAS | EPI_RESIDUAL | (a.t.xh ? EPI_RES_F16 | EPI_OUT_F16 : 0);
   const bool ln_pair = dt == CMH_BF16 && a.t.xh && b.t.xh;     // fp16 stream -> bf16 rows: both towers' rows in one launch
-  if (!(ln_pair && launch_layernorm_h2b_pair(a.t.x, wa.ln1_w, wa.ln1_b, a.t.h, a.M, a.d, a.md, b.t.x, wb.ln1_w, wb.ln1_b, b.t.h, b.M, b.d, b.md, st))) {
+  rc = ln_pair ? launch_layernorm_h2b_pair(a.t.x, wa.ln1_w, wa.ln1_b, a.t.h, a.M, a.d, a.md, b.t.x, wb.ln1_w, wb.ln1_b, b.t.h, b.M, b.d, b.md, st) : 1;
+  if (rc < 0) return rc;
+  if (rc > 0) {
     if ((rc = launch_layernorm_x(a.t.x, a.t.xh, nullptr, wa.ln1_w, wa.ln1_b, a.t.h, dt == CMH_BF16, a.M, a.d, st, a.md))) return rc;
     if ((rc = launch_layernorm_x(b.t.x, b.t.xh, nullptr, wb.ln1_w, wb.ln1_b, b.t.h, dt == CMH_BF16, b.M, b.d, st, b.md))) return rc;
   }
@@ -259,7 +262,9 @@ static int run_block_pair(const cmh_block_weights& wa, const cmh_block_weights& 
   if (upto_attention) return CMH_OK;
   if ((rc = launch_gemm_grouped(dt, problem_of(a, a.t.h, wa.out_proj_w, wa.out_proj_b, a.t.x, a.t.x, a.d, a.d),
                                 problem_of(b, b.t.h, wb.out_proj_w, wb.out_proj_b, b.t.x, b.t.x, b.d, b.d), rx, st))) return rc;
-  if (!(ln_pair && launch_layernorm_h2b_pair(a.t.x, wa.ln2_w, wa.ln2_b, a.t.h, a.M, a.d, a.md, b.t.x, wb.ln2_w, wb.ln2_b, b.t.h, b.M, b.d, b.md, st))) {
+  rc = ln_pair ? launch_layernorm_h2b_pair(a.t.x, wa.ln2_w, wa.ln2_b, a.t.h, a.M, a.d, a.md, b.t.x, wb.ln2_w, wb.ln2_b, b.t.h, b.M, b.d, b.md, st) : 1;
+  if (rc < 0) return rc;
+  if (rc > 0) {
     if ((rc = launch_layernorm_x(a.t.x, a.t.xh, nullptr, wa.ln2_w, wa.ln2_b, a.t.h, dt == CMH_BF16, a.M, a.d, st, a.md))) return rc;
     if ((rc = launch_layernorm_x(b.t.x, b.t.xh, nullptr, wb.ln2_w, wb.ln2_b, b.t.h, dt == CMH_BF16, b.M, b.d, st, b.md))) return rc;
   }
@@ -578,7 +583,9 @@ extern "C" int cmh_clip_encode_pair(const cmh_vit_weights* vw, const float* imag
   for (int i = 0; i < deepest; ++i) {
     const bool has_a = i < vw->layers, has_b = i < tw->layers;
     const bool last_a = tail && i == vw->layers - 1, last_b = tail && i == tw->layers - 1;
-    if (has_a && has_b && last_a == last_b) {
+    // lock-step only when both towers carry the same kind of residual stream (fp16 for widths that are multiples of 256 in the bf16
+    // mode, else f32: resid_f16 decides per tower): a grouped launch has ONE set of epilogue flags
+    if (has_a && has_b && last_a == last_b && a.t.xh == b.t.xh) {
       if ((rc = run_block_pair(vw->blocks[i], tw->blocks[i], a, b, st, last_a))) return rc;
       if (last_a) {       // the rest of the last block on the pooled rows of each tower (few-row kernels)
         if ((rc = run_block_pooled(vw->blocks[i], a.dtb, a.t, a.B, a.T, a.d, 0, nullptr, st, a.M, nullptr, &xa, nullptr, -1, true))) return rc;

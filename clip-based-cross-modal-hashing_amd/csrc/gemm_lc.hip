@@ -503,11 +503,13 @@ int launch_gemm_lc(const GemmProblem& a, const GemmProblem* b, int epi, hipStrea
   } while (0)
     if (abl == 1) LC_GO_A(1); else if (abl == 2) LC_GO_A(2); else if (abl == 3) LC_GO_A(3); else LC_GO_A(4);
 #undef LC_GO_A
+    CMH_CHECK_LAUNCH("gemm (lc, diagnostic)");
     return 0;
   }
   if (b) { if (rf) LC_GO(true, true); else LC_GO(true, false); }
   else { if (rf) LC_GO(false, true); else LC_GO(false, false); }
 #undef LC_GO
+  CMH_CHECK_LAUNCH("gemm (lc)");
   return 0;
 }
 

@@ -1613,6 +1613,7 @@ int launch_gemm_wide_tn_multi(const TnMultiJob* jobs, int n, float* partials, si
   }
   for (int i = n; i < 4; ++i) tab.j[i] = TnJob{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 1, 1 << 30};
   hipLaunchKernelGGL(gemm_wide_tn_multi_kernel, dim3(first), dim3(512), 0, st, tab);
+  CMH_CHECK_LAUNCH("gemm_tn_multi");
   if (S > 1) {
     ReduceJobs R;
     R.S = S;
@@ -1626,6 +1627,7 @@ int launch_gemm_wide_tn_multi(const TnMultiJob* jobs, int n, float* partials, si
     }
     const size_t blocks = (most / 4 + 255) / 256;
     hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3(static_cast<unsigned>(blocks < 1024 ? blocks : 1024), n), dim3(256), 0, st, R);
+    CMH_CHECK_LAUNCH("gemm_tn_multi (reduce)");
   }
   return 0;
 }
@@ -1837,6 +1839,7 @@ int launch_gemm_wide_grouped(int dt, const GemmProblem& a, const GemmProblem& b,
   }
 #undef W_LAUNCH_G3
 #undef W_LAUNCH_G
+  CMH_CHECK_LAUNCH("gemm (grouped)");
   return 0;
 }
 

@@ -173,11 +173,11 @@ __global__ __launch_bounds__(256) void layernorm_h2b_pair_kernel(LnRows r0, LnRo
 }
 
 // fp16 stream -> bf16 rows of two row sets; false when the pair is not one this file has a kernel for (the caller launches twice)
-bool launch_layernorm_h2b_pair(const void* x0, const float* w0, const float* b0, void* out0, int M0, int d0, const int32_t* md0,
+int launch_layernorm_h2b_pair(const void* x0, const float* w0, const float* b0, void* out0, int M0, int d0, const int32_t* md0,
                                const void* x1, const float* w1, const float* b1, void* out1, int M1, int d1, const int32_t* md1,
                                hipStream_t st) {
   static const bool off = []() { const char* e = getenv("CMH_PAIR_KERNELS"); return e && e[0] == '0'; }();
-  if (off || M0 <= 0 || M1 <= 0) return false;
+  if (off || M0 <= 0 || M1 <= 0) return 1;
   const LnRows r0{static_cast<const uint16_t*>(x0), w0, b0, static_cast<uint16_t*>(out0), M0, md0};
   const LnRows r1{static_cast<const uint16_t*>(x1), w1, b1, static_cast<uint16_t*>(out1), M1, md1};
   auto blocks = [](int M, int d) { return d <= 512 ? (M + 15) / 16 : (M + 7) / 8; };     // two rows per half-wave for d <= 512
@@ -188,8 +188,9 @@ bool launch_layernorm_h2b_pair(const void* x0, const float* w0, const float* b0,
   else if (d0 == 1024 && d1 == 768) hipLaunchKernelGGL((layernorm_h2b_pair_kernel<4, 3>), grid, block, 0, st, r0, r1, bl0);
   else if (d0 == 1024 && d1 == 512) hipLaunchKernelGGL((layernorm_h2b_pair_kernel<4, 2>), grid, block, 0, st, r0, r1, bl0);
   else if (d0 == 512 && d1 == 512) hipLaunchKernelGGL((layernorm_h2b_pair_kernel<2, 2>), grid, block, 0, st, r0, r1, bl0);
-  else return false;
-  return hipGetLastError() == hipSuccess;
+  else return 1;
+  CMH_CHECK_LAUNCH("layernorm (pair)");
+  return CMH_OK;
 }
 
 int launch_layernorm_x(const void* x, int x_f16, const int32_t* row_index, const float* w, const float* b, void* out,

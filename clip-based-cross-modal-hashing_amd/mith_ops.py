@@ -51,7 +51,7 @@ def vit_encode_tokens(clip, image):
     B = image.shape[0]
     T = (s.resolution // s.patch) ** 2 + 1
     out = torch.empty(B * T, s.embed_dim, dtype=torch.float32, device=image.device)
-    ws = N.workspace(N.lib().cmh_vit_workspace_bytes(C.byref(s), B), image.device, "vit")
+    ws = N.workspace(N.lib().cmh_vit_workspace_bytes(C.byref(s), B), image.device, f"vit@{N.stream_ptr(image.device)}")      # one scratch per stream: the eval loops run batches on alternating streams
     N.check(N.lib().cmh_vit_encode_tokens(C.byref(s), N.ptr(image), B, N.ptr(out), N.ptr(ws), ws.numel(),
                                           N.stream_ptr(image.device)), "cmh_vit_encode_tokens")
     return out.view(B, T, s.embed_dim)
@@ -65,7 +65,7 @@ def text_encode_tokens(clip, text, key_padding_mask):
     out = torch.empty(B * L, s.embed_dim, dtype=torch.float32, device=text.device)
     rows = torch.empty(B, dtype=torch.int32, device=text.device)
     kpm = None if key_padding_mask is None else key_padding_mask.to(torch.uint8).contiguous()
-    ws = N.workspace(N.lib().cmh_text_workspace_bytes(C.byref(s), B, L), text.device, "text")
+    ws = N.workspace(N.lib().cmh_text_workspace_bytes(C.byref(s), B, L), text.device, f"text@{N.stream_ptr(text.device)}")
     N.check(N.lib().cmh_text_encode_tokens(C.byref(s), N.ptr(text), B, L, N.ptr(kpm), N.ptr(out), N.ptr(rows), N.ptr(ws),
                                            ws.numel(), N.stream_ptr(text.device)), "cmh_text_encode_tokens")
     return out.view(B, L, s.embed_dim), rows
@@ -75,7 +75,7 @@ def transformer_blocks(block_array, layers, x, B, T, dtype=N.F32):
     """x f32 [B*T, d] -> same shape, after `layers` ResidualAttentionBlocks (no mask); block_array's GEMM weights in `dtype`."""
     x = N.f32c(x).clone()
     d = x.shape[1]
-    ws = N.workspace(N.lib().cmh_blocks_workspace_bytes(dtype, B, T, d), x.device, "blocks")
+    ws = N.workspace(N.lib().cmh_blocks_workspace_bytes(dtype, B, T, d), x.device, f"blocks@{N.stream_ptr(x.device)}")
     N.check(N.lib().cmh_transformer_blocks(C.cast(block_array, C.POINTER(N.BlockWeights)), layers, dtype, N.ptr(x), B, T,
                                            d, 0, None, N.ptr(ws), ws.numel(), N.stream_ptr(x.device)),
             "cmh_transformer_blocks")
@@ -136,7 +136,7 @@ def _scalar(dev):
 def sq_diff_sum(a, b):
     a, b = N.f32c(a), N.f32c(b)
     N.fit("sq_diff_sum", (b, a.shape))
-    out, ws = _scalar(a.device), N.workspace(256, a.device, "loss")
+    out, ws = _scalar(a.device), N.workspace(256, a.device, f"loss@{N.stream_ptr(a.device)}")
     N.check(N.lib().cmh_sq_diff_sum(N.ptr(a), N.ptr(b), a.numel(), N.ptr(out), N.ptr(ws), ws.numel(), N.stream_ptr(a.device)),
             "cmh_sq_diff_sum")
     return out[0]
@@ -146,7 +146,7 @@ def bayesian_loss(bank, batch, bank_label, label):
     bank, batch, bank_label, label = (N.f32c(t) for t in (bank, batch, bank_label, label))
     N.fit("bayesian_loss", (batch, (batch.shape[0], bank.shape[1])), (bank_label, (bank.shape[0], label.shape[1])),
           (label, (batch.shape[0], label.shape[1])))
-    out, ws = _scalar(bank.device), N.workspace(256, bank.device, "loss")
+    out, ws = _scalar(bank.device), N.workspace(256, bank.device, f"loss@{N.stream_ptr(bank.device)}")
     N.check(N.lib().cmh_mith_bayesian_loss(N.ptr(bank), N.ptr(batch), N.ptr(bank_label), N.ptr(label), bank.shape[0],
                                            batch.shape[0], bank.shape[1], label.shape[1], N.ptr(out), N.ptr(ws), ws.numel(),
                                            N.stream_ptr(bank.device)), "cmh_mith_bayesian_loss")
@@ -159,7 +159,7 @@ def info_nce(a, b, group=None, temperature=0.07):
     D = a.shape[-1]
     R = a.numel() // D
     G = R if group is None else group
-    out, ws = _scalar(a.device), N.workspace(N.lib().cmh_info_nce_workspace_bytes(R, G), a.device, "nce")
+    out, ws = _scalar(a.device), N.workspace(N.lib().cmh_info_nce_workspace_bytes(R, G), a.device, f"nce@{N.stream_ptr(a.device)}")
     N.check(N.lib().cmh_info_nce(N.ptr(a), N.ptr(b), R, G, D, float(temperature), N.ptr(out), N.ptr(ws), ws.numel(),
                                  N.stream_ptr(a.device)), "cmh_info_nce")
     return out[0]

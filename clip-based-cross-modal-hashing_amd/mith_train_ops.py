@@ -180,7 +180,7 @@ class BayesianLossFn(torch.autograd.Function):
         Bn, Cn = label.shape
         db = torch.empty_like(batch)
         g = N.f32c(g).reshape(1)
-        ws = N.workspace(N.lib().cmh_mith_bayesian_backward_workspace_bytes(Bn, K), bank.device, "bayes")
+        ws = N.workspace(N.lib().cmh_mith_bayesian_backward_workspace_bytes(Bn, K), bank.device, f"bayes@{N.stream_ptr(bank.device)}")
         N.check(N.lib().cmh_mith_bayesian_loss_backward(N.ptr(bank), N.ptr(batch), N.ptr(bank_label), N.ptr(label), Mb, Bn, K, Cn, N.ptr(g),
                                                         N.ptr(db), N.ptr(ws), ws.numel(), N.stream_ptr(bank.device)),
                 "cmh_mith_bayesian_loss_backward")
@@ -205,7 +205,7 @@ class InfoNceFn(torch.autograd.Function):
         G = R if ctx.group is None else ctx.group
         da, db = torch.empty_like(a), torch.empty_like(b)
         g = N.f32c(g).reshape(1)
-        ws = N.workspace(N.lib().cmh_info_nce_workspace_bytes(R, G), a.device, "nce")
+        ws = N.workspace(N.lib().cmh_info_nce_workspace_bytes(R, G), a.device, f"nce@{N.stream_ptr(a.device)}")
         N.check(N.lib().cmh_info_nce_backward(N.ptr(a), N.ptr(b), R, G, D, ctx.temperature, N.ptr(g), N.ptr(da), N.ptr(db), N.ptr(ws),
                                               ws.numel(), N.stream_ptr(a.device)), "cmh_info_nce_backward")
         return da, db, None, None

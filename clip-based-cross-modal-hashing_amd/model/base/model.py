@@ -460,17 +460,32 @@ class CLIP(nn.Module):
         if torch.is_grad_enabled() and not self.assume_frozen:
             return
         fi, ft = self.encode_pair(image, text)
-        self._pair_stash = {"image": (image, fi), "text": (text, ft)}
+        key = self._stash_key()
+        self._pair_stash = {"image": (image, fi, key), "text": (text, ft, key)}
 
     def _stashed(self, side, x):
         st = getattr(self, "_pair_stash", None)
         if not st or side not in st:
             return None
-        src, feat = st[side]
-        if src is not x:
+        src, feat, key = st[side]
+        if src is not x or key != self._stash_key():
             return None
         del st[side]
         return feat
+
+    def _stash_key(self):
+        """what a stashed feature depends on besides its input tensor: the arithmetic mode and the weights' versions"""
+        text = [self.token_embedding.weight, self.positional_embedding, self.ln_final.weight, self.ln_final.bias,
+                self.text_projection] + list(self.transformer.parameters())
+        return (self.pack_text, self._key(list(self.visual.parameters())), self._key(text))
+
+    def drop_pair_stash(self):
+        """Forget features prefetch_pair computed and nobody picked up; counts them (`pair_stash_misses`) so that a model whose
+        encode_* calls never hit the stash - a mask, taps, other tensors - shows up instead of silently paying for both paths."""
+        st = getattr(self, "_pair_stash", None)
+        if st:
+            self.pair_stash_misses = getattr(self, "pair_stash_misses", 0) + len(st)
+        self._pair_stash = {}
 
     def encode_pair(self, image, text):
         """(encode_image(image), encode_text(text)) with the two towers in lock-step: layer i of both shares its GEMM launches

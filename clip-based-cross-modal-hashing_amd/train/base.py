@@ -147,7 +147,11 @@ class TrainBase(object):
                 def run(tensors=tensors):
                     if use_pair and tensors[0].shape[0] == tensors[1].shape[0]:
                         clip.prefetch_pair(tensors[0], tensors[1])
-                    work(*tensors)
+                    try:
+                        work(*tensors)
+                    finally:
+                        if use_pair:
+                            clip.drop_pair_stash()      # a work() that took one side only (or raised) must not pin the batch
 
                 pipe.run(run, tensors, ready)
         pipe.join()

@@ -170,6 +170,58 @@ def test_prefetch_pair_feeds_the_next_two_encodes():
         assert torch.equal(m.encode_image(img), ref[0])            # consumed: the ordinary path again
 
 
+@pytest.mark.parametrize("cfg_over", [
+    dict(vision_width=256, transformer_width=128, transformer_heads=2),      # fp16 stream on the image side only (width % 256)
+    dict(vision_width=128, transformer_width=256, transformer_heads=4),      # ... on the text side only
+    dict(vision_width=256, transformer_width=256, transformer_heads=4, vision_layers=3, transformer_layers=2),   # depths differ
+    dict(vision_width=256, transformer_width=256, transformer_heads=4, vision_layers=1, transformer_layers=3),
+])
+def test_encode_pair_with_towers_of_different_stream_kinds_and_depths(cfg_over):
+    """The lock-step path shares ONE set of epilogue flags per grouped launch: towers whose residual streams differ in kind (fp16 for
+    widths that are multiples of 256 in the bf16 mode, f32 otherwise) or whose depths differ must fall back, block by block, to the
+    single-tower calls - same bits as encode_image + encode_text (round-4 advisor finding: the pair path took tower a's flags for both)."""
+    from model.base.model import CLIP
+    cfg = dict(recipe.CLIP_TINY, **cfg_over)
+    torch.manual_seed(31)
+    m = CLIP(cfg["embed_dim"], cfg["image_resolution"], cfg["vision_layers"], cfg["vision_width"], cfg["vision_patch_size"],
+             cfg["context_length"], cfg["vocab_size"], cfg["transformer_width"], cfg["transformer_heads"],
+             cfg["transformer_layers"]).to(DEV).float().set_gemm_dtype("bf16")
+    m.assume_frozen = True
+    img = torch.from_numpy(recipe.images(40, cfg["image_resolution"], 1)).to(DEV)
+    txt = torch.from_numpy(recipe.captions(40, 16, cfg["vocab_size"], 2)).to(DEV)
+    with torch.no_grad():
+        for pack in (True, False):
+            m.pack_text = pack
+            ref = (m.encode_image(img).clone(), m.encode_text(txt).clone())
+            got = tuple(t.clone() for t in m.encode_pair(img, txt))
+            assert torch.isfinite(ref[0]).all() and torch.isfinite(ref[1]).all()
+            assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])
+
+
+def test_unclaimed_prefetch_is_dropped_and_counted():
+    """A work() that takes one side only must not pin the batch: train/base.py::_pipelined_batches drops the stash after every batch
+    (CLIP.drop_pair_stash counts what nobody picked up); features computed under other weights are never handed out."""
+    from model.base.model import CLIP
+    cfg = recipe.CLIP_TINY
+    torch.manual_seed(3)
+    m = CLIP(cfg["embed_dim"], cfg["image_resolution"], cfg["vision_layers"], cfg["vision_width"], cfg["vision_patch_size"],
+             cfg["context_length"], cfg["vocab_size"], cfg["transformer_width"], cfg["transformer_heads"],
+             cfg["transformer_layers"]).to(DEV).float().set_gemm_dtype("f32")
+    img = torch.from_numpy(recipe.images(5, cfg["image_resolution"], 1)).to(DEV)
+    txt = torch.from_numpy(recipe.captions(5, 16, cfg["vocab_size"], 2)).to(DEV)
+    with torch.no_grad():
+        m.prefetch_pair(img, txt)
+        _ = m.encode_image(img)
+        m.drop_pair_stash()
+        assert not m._pair_stash and m.pair_stash_misses == 1
+        m.prefetch_pair(img, txt)
+        m.visual.proj.mul_(2.0)                                  # the weights change between the prefetch and the use
+        fresh = m.encode_image(img)
+        assert "image" in m._pair_stash                          # refused: computed under the old weights
+        m.drop_pair_stash()
+        assert torch.equal(fresh, m.encode_image(img))
+
+
 def test_alternating_streams_code_loop_equals_the_plain_loop(tmp_path, monkeypatch):
     """train/base.py::_code_loop on two alternating streams with the lock-step pair path == the same loop with CMH_OVERLAP=0
     and CMH_PAIR=0 (one stream, separate encodes): identical code buffers."""
