@@ -722,7 +722,12 @@ def main():
         for name, leg in bench_configs.LEGS:
             try:
                 t_leg = time.perf_counter()
-                out[name] = leg(dev) if name != "dchmt_epoch" else leg(dev, cpu_sample=not a.no_cpu_baseline)
+                if name == "dchmt_epoch":
+                    out[name] = leg(dev, cpu_sample=not a.no_cpu_baseline)
+                elif name == "code_loop":
+                    out[name] = leg(dev, headline_pairs_per_s=out["value"], L=L, bits=K, batch=B)
+                else:
+                    out[name] = leg(dev)
                 out[name]["leg_wallclock_s"] = round(time.perf_counter() - t_leg, 1)
             except Exception as exc:
                 out[name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}

@@ -5,6 +5,8 @@
                                 through this repository's own trainer; beside it the same step's arithmetic on the host cores
   configs[2]  mith_step         MITH, 64 bit, batch 256: all-token ViT-B/32 trunk + HashingModel forward at 32 / 77 caption tokens
                                 (model/MITH.py:427-453) and the full training step at 32 tokens (train/MITH/hash_train.py:80-201)
+  configs[1]  code_loop         the headline's arithmetic driven by the trainer: DSPHTrainer.get_code over 20 480 pairs at batch 256
+                                (train/base.py:130-148), batches resident / through pinned H2D
   configs[3]  map_eval_nuswide  5 000 queries x 190 834 database codes x 128 bit, 21 classes, the four directions, reference tie
                                 order (utils/calc_utils.py:16-39 at NUS-WIDE scale)
   configs[4]  twdh_fp8          TwDH long (128 bit) + short (16 bit) codes through the fp8 towers (model/TwDH.py:146-167), scales
@@ -51,8 +53,11 @@ def map_eval_nuswide(dev, Q=5000, Nn=190834, K=128, C=21):
     return {"ms": round(out["reference"][0], 2), "directions": 4, "Q": Q, "N": Nn, "bits": K, "classes": C,
             "code_pairs_per_s": round(4.0 * Q * Nn / (out["reference"][0] * 1e-3), 1),
             "algorithmic_GBps": round(alg / (out["reference"][0] * 1e-3) / 1e9, 3),
+            "bound": "ranking (emulated introsort per query; at this N the element arrays live in the caller's workspace: ~55 GB of 4-byte "
+                     "gathers and partial-line writes per direction at ~2.6 TB/s), not HBM on the algorithmic bytes: the packed inputs are 3.74 MB per direction",
             "tie_order": "reference (libstdc++ introsort)", "mAP_i2t": round(out["reference"][1], 6),
-            "stable_tie_order": {"ms": round(out["stable"][0], 2), "mAP_i2t": round(out["stable"][1], 6)},
+            "stable_tie_order": {"ms": round(out["stable"][0], 2), "mAP_i2t": round(out["stable"][1], 6),
+                                 "note": "CMH_TIE_STABLE (ties by index): not the reference's ranking"},
             "what": "configs[3] DNPH nuswide 128 bit: full-database Hamming mAP, 4 directions, codes resident (one GPU: all queries)"}
 
 
@@ -163,6 +168,92 @@ def twdh_fp8(dev, B=256, K=128, S=16, C=21):
                     "activation scales calibrated on a different seeded batch"}
 
 
+def code_loop(dev, headline_pairs_per_s=None, pairs=20480, batch=256, bits=64, L=77):
+    """The product's own encode loop behind the reference's plugin API: the DSPH trainer's `get_code(loader, length)`
+    (train/base.py::_code_loop; reference train/base.py:130-148) over `pairs` image+caption pairs at batch 256, 64 bit, bf16 mode -
+    once from a loader whose batches are already on the device (what dataset/base.py::DeviceLoader's cached epoch hands out), once
+    from pinned host batches through the loop's own `.to(rank, non_blocking=True)` (154 MB of pixels per batch over PCIe).  bench.py's
+    headline times the bare step over ONE resident batch; this is the same arithmetic driven by the trainer: per batch the H2D /
+    no-op moves, CLIP.prefetch_pair on alternating streams, the heads, sign(), the scatter of the codes into [length, K] buffers at
+    the batch's dataset indices."""
+    import main
+    from bench import synthetic_batch
+    from train.DSPH.hash_train import DSPHTrainer
+    tmp = "/tmp/cmh_bench_codeloop"
+    os.makedirs(tmp, exist_ok=True)
+    ck = os.path.join(tmp, "vitb32_random.pt")
+    torch.save(_vitb32_state(11), ck)
+    argv, run = sys.argv, DSPHTrainer.run
+    sys.argv = ["main.py", "-clip-path", ck, "--save-dir", os.path.join(tmp, "run"), "--batch-size", str(batch), "--num-workers", "0",
+                "--query-num", "64", "--train-num", "64", "--synthetic-size", "256", "--max-words", str(L), "--gemm-dtype", "bf16",
+                "--epochs", "1", "--save-mat", "false"]
+    DSPHTrainer.run = lambda self: None
+    try:
+        torch.manual_seed(1)
+        tr = main.trainers["DSPH"](argparse.Namespace(method="DSPH", dataset="synthetic", output_dim=bits, is_train=True), dev.index or 0)
+    finally:
+        sys.argv, DSPHTrainer.run = argv, run
+    tr.change_state(mode="valid")
+    tr.model.clip.assume_frozen = True                 # evaluation: the weight copies are built once (as in bench.py's headline)
+    nb = pairs // batch
+    pool_n = 8                                         # distinct batches behind the loop (1.2 GB of pixels); indices are all distinct
+    pool = [synthetic_batch(batch, L, 24, 7000 + i, dev)[:2] for i in range(pool_n)]
+
+    class Loader:
+        def __init__(self, where):
+            self.batches = pool if where == "device" else [(im.cpu().pin_memory(), tx.cpu().pin_memory()) for im, tx in pool]
+
+        def __len__(self):
+            return nb
+
+        def __iter__(self):
+            for i in range(nb):
+                im, tx = self.batches[i % pool_n]
+                yield im, tx, torch.arange(i * batch, (i + 1) * batch)
+
+    out = {"pairs": nb * batch, "batch": batch, "bits": bits, "seq_len": L}
+    codes = {}
+    for where in ("device", "pinned"):
+        ld = Loader(where)
+        tr.get_code(ld, nb * batch)                    # warm-up pass: weight copies, workspaces, the allocator's blocks
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        img_c, txt_c, _ = tr.get_code(ld, nb * batch)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        codes[where] = (img_c, txt_c)
+        out[where] = {"s": round(dt, 4), "pairs_per_s": round(nb * batch / dt, 1), "ms_per_batch": round(dt / nb * 1e3, 4)}
+        if headline_pairs_per_s:
+            out[where]["vs_headline"] = round(nb * batch / dt / headline_pairs_per_s, 4)
+    # the same loop on one stream with separate encodes (CMH_OVERLAP=0 CMH_PAIR=0): the codes must not depend on how the loop runs
+    env0 = {k: os.environ.get(k) for k in ("CMH_OVERLAP", "CMH_PAIR")}
+    os.environ["CMH_OVERLAP"], os.environ["CMH_PAIR"] = "0", "0"
+    try:
+        ld = Loader("device")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        img_p, txt_p, _ = tr.get_code(ld, nb * batch)
+        torch.cuda.synchronize()
+        dtp = time.perf_counter() - t0
+    finally:
+        for k, v in env0.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    out["plain_loop"] = {"s": round(dtp, 4), "pairs_per_s": round(nb * batch / dtp, 1),
+                         "what": "CMH_OVERLAP=0 CMH_PAIR=0: one stream, encode_image then encode_text per batch"}
+    out["codes_equal_plain_loop"] = bool(torch.equal(codes["device"][0], img_p) and torch.equal(codes["device"][1], txt_p) and
+                                         torch.equal(codes["pinned"][0], img_p) and torch.equal(codes["pinned"][1], txt_p))
+    out["stash_misses"] = int(getattr(tr.model.clip, "pair_stash_misses", 0))
+    out["what"] = ("configs[1] through the trainer: DSPHTrainer.get_code(loader, length) over %d pairs (batch %d, %d bit, %d-token "
+                   "captions, bf16 mode): `device` = batches already resident (a cached DeviceLoader epoch), `pinned` = pinned host "
+                   "batches moved by the loop itself; vs_headline = against bench.py's bare step on one resident batch" % (nb * batch, batch, bits, L))
+    del tr
+    torch.cuda.empty_cache()
+    return out
+
+
 def dchmt_trainer(dev, pairs=1000, batch=32, bits=16):
     """The DCHMT trainer of configs[0] on a resident synthetic set (constructed, not run)."""
     import main
@@ -182,11 +273,12 @@ def dchmt_trainer(dev, pairs=1000, batch=32, bits=16):
     import dataset.synthetic as ds
     signal0, ds.SyntheticPairs.signal = ds.SyntheticPairs.signal, 2.0
     tile0, ds.SyntheticPairs.tile = ds.SyntheticPairs.tile, 32      # patch-periodic patterns: see dataset/synthetic.py
+    ctok0, ds.SyntheticPairs.caption_tokens = ds.SyntheticPairs.caption_tokens, 4      # captions made of their classes' tokens
     try:
         torch.manual_seed(1)
         tr = main.trainers["DCHMT"](argparse.Namespace(method="DCHMT", dataset="synthetic", output_dim=bits, is_train=True), dev.index or 0)
     except BaseException:
-        ds.SyntheticPairs.signal, ds.SyntheticPairs.tile = signal0, tile0
+        ds.SyntheticPairs.signal, ds.SyntheticPairs.tile, ds.SyntheticPairs.caption_tokens = signal0, tile0, ctok0
         raise
     finally:
         sys.argv, DCHMTTrainer.run = argv, run
@@ -211,7 +303,7 @@ def dchmt_trainer(dev, pairs=1000, batch=32, bits=16):
     try:
         tr.train_loader, tr.query_loader, tr.retrieval_loader = (resident(l) for l in (tr.train_loader, tr.query_loader, tr.retrieval_loader))
     finally:
-        ds.SyntheticPairs.signal, ds.SyntheticPairs.tile = signal0, tile0     # the items are materialised: the class attributes go back
+        ds.SyntheticPairs.signal, ds.SyntheticPairs.tile, ds.SyntheticPairs.caption_tokens = signal0, tile0, ctok0     # the items are materialised: the class attributes go back
     tr.save_model = lambda epoch: None
     return tr
 
@@ -299,4 +391,4 @@ def _dchmt_cpu_sample(pairs, batch, bits):
                     f"{steps} steps; calc_map_k by the C++ restatement of the reference's algorithm (one direction)"}
 
 
-LEGS = (("map_eval_nuswide", map_eval_nuswide), ("twdh_fp8", twdh_fp8), ("mith_step", mith_step), ("dchmt_epoch", dchmt_epoch))
+LEGS = (("code_loop", code_loop), ("map_eval_nuswide", map_eval_nuswide), ("twdh_fp8", twdh_fp8), ("mith_step", mith_step), ("dchmt_epoch", dchmt_epoch))

@@ -20,6 +20,11 @@ class SyntheticPairs(Dataset):
     # embedding then moves the same way, which survives the near-uniform attention of a random-init tower - a full-size noise
     # pattern averages out over the 49 patches and every image collapses onto one hash code); 0: a full-size pattern
     tile = 0
+    # caption_tokens > 0 (with signal > 0): a caption is MADE of its classes' tokens - every class owns this many, the body cycles
+    # through the tokens of the item's classes with one position in five left to noise.  Three class tokens dropped into ~15 random
+    # ones (the default) vanish in the causal averaging of a random-init text tower: round 4's configs[0] database held 13 distinct
+    # text codes in 1 000 items
+    caption_tokens = 0
 
     def __init__(self, ids, labels, max_words, resolution, seed):
         self.ids, self.labels = ids, labels
@@ -50,8 +55,16 @@ class SyntheticPairs(Dataset):
                 else:
                     image += self.signal * proto.standard_normal(image.shape).astype(np.float32)
                 words = proto.integers(1, SOT, size=3)                       # the class's caption tokens
-                for w in words:
-                    cap[int(rng.integers(1, max(n, 2)))] = w
+                if self.caption_tokens == 0:
+                    for w in words:
+                        cap[int(rng.integers(1, max(n, 2)))] = w
+            if self.caption_tokens > 0 and len(classes) and n > 1:
+                own = np.concatenate([np.random.default_rng([self.seed, 104729, int(c)]).integers(1, SOT, size=self.caption_tokens)
+                                      for c in classes])
+                body = own[np.arange(n - 1) % len(own)]
+                noise = rng.random(n - 1) < 0.2
+                body[noise] = cap[1:n][noise]
+                cap[1:n] = body
         return torch.from_numpy(image), torch.from_numpy(cap), torch.from_numpy(self.labels[index]), index
 
 

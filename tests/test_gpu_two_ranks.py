@@ -73,3 +73,27 @@ def test_two_ranks_equal_one_rank(tmp_path, method):
             scale = float(np.abs(g_ref[name]).max())
             tol = (2e-4 if method == "MITH" else 2e-5) * scale + 1e-12
             assert float(np.abs(g[name] - g_ref[name]).max()) <= tol, (name, float(np.abs(g[name] - g_ref[name]).max()), scale)
+
+
+def test_bench_self_launch_two_ranks_end_to_end():
+    """`python bench.py --gpus 2` exactly as a user (or the driver's 8-GPU node) starts it bare: the launcher parent never touches the
+    GPU, starts two fresh ranks under torch.distributed.run and passes rank 0's JSON line through.  Here both ranks share the test
+    box's one GPU and the collectives run on gloo (CMH_DIST_BACKEND) - what is proved is the launcher, the rendezvous, the N > 1
+    branch of the step (fused all-gather -> global-batch loss), the max-over-ranks timing and the shape of the line; RCCL itself is
+    covered by tests/test_gpu_rccl_one_rank.py."""
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "CMH_FORCE_DIST")}
+    env.update(CMH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "2", "--batch", "32",
+           "--no-cpu-baseline", "--no-dense-text", "--map-queries", "64", "--map-db", "500", "--train-step"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, res.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["collectives"] == "gloo" and rec["scaling"] == "weak"
+    assert rec["config"]["global_batch"] == 64 and rec["config"]["per_gpu_batch"] == 32
+    assert rec["value"] > 0 and rec["ms_per_step"] > 0 and abs(rec["per_gpu_value"] * 2 - rec["value"]) < 1e-6 * rec["value"] + 0.02
+    assert "relaunched" not in rec
+    assert "error" not in rec["train_step"] and rec["train_step"]["loss"] == rec["train_step"]["loss"]      # finite: the N > 1 training step ran
+    assert rec["map_eval"]["mAP_i2t"] > 0
