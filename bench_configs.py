@@ -83,11 +83,16 @@ def mith_step(dev, B=256, K=64, C=80, bank=10000):
     img = torch.randn(B, 3, 224, 224, device=dev)
     out = {"batch": B, "bits": K, "what": "configs[2] MITH coco 64 bit: ViT-B/32 trunk returning every token + HashingModel (bf16 GEMMs)"}
 
+    from streams import overlapped
+
+    def model(txt, kpm):
+        # MITH.forward (model/MITH.py): the two towers of the trunk are independent until the HashingModel - one HIP stream each
+        (seq_i, _, cls_i), (seq_t, _, nk, eos) = overlapped(lambda: clip.encode_image(img), lambda: clip.encode_text(txt, kpm))
+        return hm(seq_i, seq_t, cls_i, eos, nk)
+
     def fwd(txt, kpm):
         with torch.no_grad():
-            seq_i, _, cls_i = clip.encode_image(img)
-            seq_t, _, nk, eos = clip.encode_text(txt, kpm)
-            od = hm(seq_i, seq_t, cls_i, eos, nk)            # codes as the trainer's evaluation forms them (train/MITH/hash_train.py:127-131)
+            od = model(txt, kpm)            # codes as the trainer's evaluation forms them (train/MITH/hash_train.py:127-131)
             return N.sign_codes(od['img_tokens_hash'] + od['img_cls_hash']), N.sign_codes(od['txt_tokens_hash'] + od['txt_cls_hash'])
     for L in (32, 77):
         txt = torch.from_numpy(recipe.captions(B, L, 49408, 1)).to(dev)
@@ -113,9 +118,7 @@ def mith_step(dev, B=256, K=64, C=80, bank=10000):
     me._grad = MITHTrainer._grad
 
     def step():
-        seq_i, _, cls_i = clip.encode_image(img)
-        seq_t, _, nk, eos = clip.encode_text(txt, kpm)
-        loss = sum(MITHTrainer.compute_loss(me, hm(seq_i, seq_t, cls_i, eos, nk), label).values())
+        loss = sum(MITHTrainer.compute_loss(me, model(txt, kpm), label).values())
         opt.zero_grad()
         loss.backward()
         opt.step()

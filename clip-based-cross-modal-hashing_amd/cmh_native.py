@@ -258,8 +258,10 @@ _ws_cache: dict = {}
 
 
 def workspace(nbytes: int, device, tag: str = "") -> torch.Tensor:
-    """Per-(device, tag) grow-only scratch buffer (uint8, 256-byte aligned by the caching allocator)."""
-    key = (str(device), tag)
+    """Per-(device, CURRENT STREAM, tag) grow-only scratch buffer (uint8, 256-byte aligned by the caching allocator).  One buffer per
+    stream: the towers, the two branches of MITH's HashingModel and consecutive batches of the evaluation loops run on different
+    streams at the same time, and a scratch buffer shared between them would be a data race (round-4 advisor finding)."""
+    key = (str(device), int(torch.cuda.current_stream(device).cuda_stream) if torch.cuda.is_available() else 0, tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)

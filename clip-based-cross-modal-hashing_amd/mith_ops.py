@@ -21,12 +21,16 @@ def weight_bf16(w):
     return hit[1]
 
 
-def gemm(x, w, bias=None, residual=None, act=None, dtype=N.F32):
-    """f32 out = act(x @ w.T + bias) (+ residual); act in {None,'gelu','relu','quickgelu'}.  dtype F32: exact-fp32 MFMA path on the
-    f32 tensors; BF16: the operands are cast to bf16 (weights cached), accumulation / bias / residual / output stay f32."""
+def gemm(x, w, bias=None, residual=None, act=None, dtype=N.F32, out_bf16=False):
+    """out = act(x @ w.T + bias) (+ residual); act in {None,'gelu','relu','quickgelu'}.  dtype F32: exact-fp32 MFMA path on the
+    f32 tensors; BF16: the operands are cast to bf16 (weights cached; an x that is bf16 already is taken as it is), accumulation /
+    bias / residual stay f32.  out_bf16 (BF16 only): the result leaves the epilogue as bf16 - the next GEMM's operand - instead of f32
+    followed by a cast pass: the same bits (one round-to-nearest-even of the same f32 value either way)."""
     N.require_gpu(x, w, bias, residual)
+    if out_bf16 and dtype != N.BF16:
+        raise N.NativeError("gemm: out_bf16 needs dtype BF16")
     if dtype == N.BF16:
-        x, w = N.cast_bf16(x), weight_bf16(w)
+        x, w = (x.contiguous() if x.dtype == torch.bfloat16 else N.cast_bf16(x)), weight_bf16(w)
     else:
         x, w = N.f32c(x), N.f32c(w)
     M, K = x.shape
@@ -35,8 +39,8 @@ def gemm(x, w, bias=None, residual=None, act=None, dtype=N.F32):
             (residual is not None and tuple(residual.shape) != (M, Nn)):
         raise N.NativeError(f"gemm: x {tuple(x.shape)}, w {tuple(w.shape)}, bias {None if bias is None else tuple(bias.shape)}, "
                             f"residual {None if residual is None else tuple(residual.shape)} do not fit together")
-    out = torch.empty(M, Nn, dtype=torch.float32, device=x.device)
-    epi = (EPI_BIAS if bias is not None else 0) | (EPI_RESIDUAL if residual is not None else 0)
+    out = torch.empty(M, Nn, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    epi = (EPI_BIAS if bias is not None else 0) | (EPI_RESIDUAL if residual is not None else 0) | (EPI_OUT_BF16 if out_bf16 else 0)
     epi |= {None: 0, "gelu": EPI_GELU, "relu": EPI_RELU, "quickgelu": EPI_QUICKGELU}[act]
     N.check(N.lib().cmh_linear_gemm(dtype, N.ptr(x), N.ptr(w), N.ptr(None if bias is None else N.f32c(bias)),
                                     N.ptr(None if residual is None else N.f32c(residual)), N.ptr(out), M, Nn, K, epi,

@@ -99,10 +99,11 @@ class ResidualMLPs(nn.Module):
     def forward(self, x):
         shape = x.shape
         x = N.f32c(x).reshape(-1, shape[-1])
-        for i in range(self.num_layers):
-            h = N.layernorm(x, self.lns[i].weight, self.lns[i].bias)
-            dt = getattr(self, "_gemm_dt", N.F32)
-            u = M.gemm(h, self.mlps[i][0].weight, self.mlps[i][0].bias, act=self.activation, dtype=dt)
+        dt = getattr(self, "_gemm_dt", N.F32)
+        lp = dt == N.BF16      # bf16 GEMMs: LayerNorm and the first GEMM hand their result on as the bf16 operand the next GEMM reads
+        for i in range(self.num_layers):        # (round 5: two cast passes per layer over [tokens, 512] / [tokens, 2048] gone; same bits)
+            h = N.layernorm(x, self.lns[i].weight, self.lns[i].bias, out_bf16=lp)
+            u = M.gemm(h, self.mlps[i][0].weight, self.mlps[i][0].bias, act=self.activation, dtype=dt, out_bf16=lp)
             x = M.gemm(u, self.mlps[i][3].weight, self.mlps[i][3].bias, residual=x, dtype=dt)
         return x.reshape(shape)
 
@@ -241,50 +242,59 @@ class HashingModel(nn.Module):
                 raise ValueError(f"HashingModel was built for {D}-d CLIP features, {name} has {t.shape[-1]}")
         if torch.is_grad_enabled() and (img_tokens.requires_grad or self.img_concept_proj.weight.requires_grad):
             return self._forward_train(img_tokens, txt_tokens, img_cls, txt_eos, key_padding_mask)
-        out = {}
-        nb = lambda t: t
-        res_img_cls, img_cls_hash = self.gcl_i(img_cls)
-        res_txt_cls, txt_cls_hash = self.gcl_t(txt_eos)
-        out['img_cls_hash'], out['txt_cls_hash'] = nb(img_cls_hash), nb(txt_cls_hash)
-        out['res_img_cls'] = nb(M.l2_normalize_rows(res_img_cls))
-        out['res_txt_cls'] = nb(M.l2_normalize_rows(res_txt_cls))
-        it = img_tokens.permute(1, 0, 2).contiguous()                                    # [N, 49, D]
-        tt = txt_tokens.permute(1, 0, 2).contiguous()                                    # [N, L, D]
-        sim_i = self.gcl_i(it)[1]
-        sim_t = self.gcl_t(tt)[1]
-        hash_i, trans_i = self.lct_i(it, sim_i, 0, it.shape[1], None)
-        hash_t, trans_t = self.lct_t(tt, sim_t, 0, tt.shape[1], key_padding_mask)
-        out['img_tokens_hash'], out['txt_tokens_hash'] = nb(hash_i), nb(hash_t)
-        Nb, K, D = trans_i.shape
         dt = getattr(self, "_gemm_dt", N.F32)
-        pi = M.gemm(trans_i.reshape(Nb * K, D), self.img_concept_proj.weight, self.img_concept_proj.bias, dtype=dt)
-        pt = M.gemm(trans_t.reshape(Nb * K, D), self.txt_concept_proj.weight, self.txt_concept_proj.bias, dtype=dt)
-        out['trans_tokens_i'] = nb(M.l2_normalize_rows(pi).reshape(Nb, K, D).permute(1, 0, 2))
-        out['trans_tokens_t'] = nb(M.l2_normalize_rows(pt).reshape(Nb, K, D).permute(1, 0, 2))
+
+        def branch(gcl, lct, proj, cls, tokens, kpm):
+            """one modality: the cls-level concepts, the token-level concepts, their aggregation and the concept transformer"""
+            res_cls, cls_hash = gcl(cls)
+            tok = tokens.permute(1, 0, 2).contiguous()                                   # [N, L, D]
+            hash_tok, trans = lct(tok, gcl(tok)[1], 0, tok.shape[1], kpm)
+            Nb, K, Dd = trans.shape
+            p = M.gemm(trans.reshape(Nb * K, Dd), proj.weight, proj.bias, dtype=dt)
+            return cls_hash, M.l2_normalize_rows(res_cls), hash_tok, M.l2_normalize_rows(p).reshape(Nb, K, Dd).permute(1, 0, 2)
+
+        # the image side and the text side meet only in the losses (model/MITH.py:427-453 runs them one after the other): one HIP
+        # stream each (round 5; every scratch buffer is per stream, cmh_native.workspace).  gcl_i IS gcl_t (one shared module,
+        # model/MITH.py:407): its cached bf16 weight copies are (re)made here, on the caller's stream, before the branches fork
+        self._prime_shared_weights(dt)
+        bi, bt = overlapped(lambda: branch(self.gcl_i, self.lct_i, self.img_concept_proj, img_cls, img_tokens, None),
+                            lambda: branch(self.gcl_t, self.lct_t, self.txt_concept_proj, txt_eos, txt_tokens, key_padding_mask))
+        out = {}
+        out['img_cls_hash'], out['res_img_cls'], out['img_tokens_hash'], out['trans_tokens_i'] = bi
+        out['txt_cls_hash'], out['res_txt_cls'], out['txt_tokens_hash'], out['trans_tokens_t'] = bt
         return out
 
+    def _prime_shared_weights(self, dt):
+        """gcl_i IS gcl_t (one shared module, model/MITH.py:407): its cached bf16 weight copies are (re)made on the caller's stream,
+        before the two modality branches fork onto their own streams"""
+        if dt == N.BF16:
+            for m in self.gcl_i.modules():
+                if isinstance(m, nn.Linear):
+                    M.weight_bf16(m.weight)
 
     def _forward_train(self, img_tokens, txt_tokens, img_cls, txt_eos, key_padding_mask):
-        """forward() through autograd Functions; layouts as in forward()."""
+        """forward() through autograd Functions; layouts as in forward().  Like forward(): one HIP stream per modality (autograd
+        replays every backward on the stream its forward ran on, so the backward pass of the two branches overlaps the same way)."""
         import mith_train_ops as T
-        out = {}
-        res_img_cls, out['img_cls_hash'] = self.gcl_i.forward_train(img_cls)
-        res_txt_cls, out['txt_cls_hash'] = self.gcl_t.forward_train(txt_eos)
-        out['res_img_cls'] = T.L2NormFn.apply(res_img_cls)
-        out['res_txt_cls'] = T.L2NormFn.apply(res_txt_cls)
-        it = img_tokens.permute(1, 0, 2).contiguous()
-        tt = txt_tokens.permute(1, 0, 2).contiguous()
-        with torch.no_grad():                                        # gcl(tokens)[1].detach() upstream (:441-442)
-            sim_i = self.gcl_i(it)[1]
-            sim_t = self.gcl_t(tt)[1]
-        out['img_tokens_hash'], trans_i = self.lct_i.forward_train(it, sim_i, 0, it.shape[1], None)
-        out['txt_tokens_hash'], trans_t = self.lct_t.forward_train(tt, sim_t, 0, tt.shape[1], key_padding_mask)
-        Nb, K, D = trans_i.shape
         dt = getattr(self, "_gemm_dt", N.F32)
-        pi = T.GemmLinear.apply(trans_i.reshape(Nb * K, D), self.img_concept_proj.weight, self.img_concept_proj.bias, dt)
-        pt = T.GemmLinear.apply(trans_t.reshape(Nb * K, D), self.txt_concept_proj.weight, self.txt_concept_proj.bias, dt)
-        out['trans_tokens_i'] = T.L2NormFn.apply(pi).reshape(Nb, K, D).permute(1, 0, 2)
-        out['trans_tokens_t'] = T.L2NormFn.apply(pt).reshape(Nb, K, D).permute(1, 0, 2)
+
+        def branch(gcl, lct, proj, cls, tokens, kpm):
+            res_cls, cls_hash = gcl.forward_train(cls)
+            res = T.L2NormFn.apply(res_cls)
+            tok = tokens.permute(1, 0, 2).contiguous()
+            with torch.no_grad():                                    # gcl(tokens)[1].detach() upstream (:441-442)
+                sim = gcl(tok)[1]
+            hash_tok, trans = lct.forward_train(tok, sim, 0, tok.shape[1], kpm)
+            Nb, K, D = trans.shape
+            p = T.GemmLinear.apply(trans.reshape(Nb * K, D), proj.weight, proj.bias, dt)
+            return cls_hash, res, hash_tok, T.L2NormFn.apply(p).reshape(Nb, K, D).permute(1, 0, 2)
+
+        self._prime_shared_weights(dt)
+        bi, bt = overlapped(lambda: branch(self.gcl_i, self.lct_i, self.img_concept_proj, img_cls, img_tokens, None),
+                            lambda: branch(self.gcl_t, self.lct_t, self.txt_concept_proj, txt_eos, txt_tokens, key_padding_mask))
+        out = {}
+        out['img_cls_hash'], out['res_img_cls'], out['img_tokens_hash'], out['trans_tokens_i'] = bi
+        out['txt_cls_hash'], out['res_txt_cls'], out['txt_tokens_hash'], out['trans_tokens_t'] = bt
         return out
 
 
