@@ -30,7 +30,7 @@ def _plain(N, p, kind):
 PLAIN = [
     (12800, 2304, 768, 0), (12800, 768, 768, 1), (12800, 3072, 768, 2), (12800, 768, 3072, 1),       # the image tower's block, batch 256
     (10499, 1536, 512, 0), (10499, 512, 512, 1), (10499, 2048, 512, 2), (10499, 512, 2048, 1),       # packed text rows
-    (2049, 256, 512, 0),          # 8 K-steps (the shortest tile the kernel takes), 17 row tiles, the last one a single row
+    (2049, 256, 256, 0),          # 4 K-steps (the shortest tile the kernel takes), 17 row tiles, the last one a single row
     (130, 512, 1024, 1),          # fewer tiles than an XCD has workgroups; 16 K-steps: the residual still comes first
     (300, 256, 1088, 1),          # 17 K-steps: the residual behind the bias
     (5000, 1024, 576, 2),         # K not a multiple of 128: 9 K-steps
