@@ -16,7 +16,6 @@
 //   pool e   [B, d]    ln_post / ln_final of the pooled rows
 #include <cstdlib>
 #include <cstring>
-#include <map>
 #include <mutex>
 
 #include "cmh_common.h"
@@ -209,44 +208,6 @@ static GemmProblem problem_of(const TowerRun& r, const void* A, const void* W, c
   return GemmProblem{A, W, bias, static_cast<const float*>(residual), out, r.M, N, K, r.md, r.mh, colscale, alpha, oscale};
 }
 
-// The two attentions of a layer (one wave per (sample, head), latency-bound: every wave loads, then computes, then stores - the phases
-// of a launch do not overlap) are independent kernels between two grouped GEMMs.  Back to back on one stream they cost
-// 16.6 + 16.1 us; here the second runs on a SIDE stream of the caller's stream (fork behind the QKV GEMM, join in front of out_proj),
-// so the two launches' phases interleave.  One side stream + two events per caller stream, created on first use (the library owns no
-// device memory; it does own these handles, like the packed-rows hint's event).  CMH_ATTN_FORK=0 keeps both on the caller's stream.
-namespace {
-struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
-std::mutex g_side_mu;
-std::map<hipStream_t, SideStream> g_side;
-}  // namespace
-static SideStream* side_stream_of(hipStream_t st) {
-  static const bool off = []() { const char* e = getenv("CMH_ATTN_FORK"); return e && e[0] == '0'; }();
-  if (off) return nullptr;
-  std::lock_guard<std::mutex> lk(g_side_mu);
-  SideStream& x = g_side[st];
-  if (!x.s) {
-    if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess) { x.s = nullptr; return nullptr; }
-    if (hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess) {
-      (void)hipStreamDestroy(x.s);
-      x = SideStream{};
-      return nullptr;
-    }
-  }
-  return &x;
-}
-// attention of tower a on `st`, of tower b beside it
-static int attention_pair(const TowerRun& a, const TowerRun& b, int dt, float inv_a, float inv_b, hipStream_t st) {
-  int rc;
-  SideStream* sd = side_stream_of(st);
-  if (sd && (hipEventRecord(sd->fork, st) != hipSuccess || hipStreamWaitEvent(sd->s, sd->fork, 0) != hipSuccess)) sd = nullptr;
-  hipStream_t sb = sd ? sd->s : st;
-  if ((rc = launch_attention_varlen(b.t.qkv, b.t.h, dt, b.B, b.T, b.d, b.causal, nullptr, b.seq_off, sb, inv_b))) return rc;
-  if ((rc = launch_attention_varlen(a.t.qkv, a.t.h, dt, a.B, a.T, a.d, a.causal, nullptr, a.seq_off, st, inv_a))) return rc;
-  if (sd && (hipEventRecord(sd->join, sd->s) != hipSuccess || hipStreamWaitEvent(st, sd->join, 0) != hipSuccess))
-    return fail(CMH_ERR_LAUNCH, "clip_encode_pair: joining the attention side stream failed");
-  return CMH_OK;
-}
-
 // the full-size part of a block for both towers: ln_1, QKV, attention (then, unless `upto_attention`, out_proj, ln_2, c_fc, c_proj)
 static int run_block_pair(const cmh_block_weights& wa, const cmh_block_weights& wb, const TowerRun& a, const TowerRun& b, hipStream_t st,
                           bool upto_attention) {
@@ -270,7 +231,8 @@ static int run_block_pair(const cmh_block_weights& wa, const cmh_block_weights& 
     // (the two attentions stay two launches: one launch for both - each side's body compiled for its own key-tile count - runs every
     // wave at the wider side's register budget, 2 waves per SIMD instead of 3 for the image side: 36.3 us against 16.6 + 16.1,
     // profiles/r04_j_bench_kernel_stats.csv; removed again)
-    if ((rc = attention_pair(a, b, CMH_BF16, 1.0f / sa[1], 1.0f / sb[1], st))) return rc;
+    if ((rc = launch_attention_varlen(a.t.qkv, a.t.h, CMH_BF16, a.B, a.T, a.d, a.causal, nullptr, a.seq_off, st, 1.0f / sa[1]))) return rc;
+    if ((rc = launch_attention_varlen(b.t.qkv, b.t.h, CMH_BF16, b.B, b.T, b.d, b.causal, nullptr, b.seq_off, st, 1.0f / sb[1]))) return rc;
     if (upto_attention) return CMH_OK;
     if ((rc = launch_gemm_grouped(CMH_FP8, problem_of(a, a.t.h, wa.out_proj_w, wa.out_proj_b, a.t.x, a.t.x, a.d, a.d, wa.out_proj_cs, sa[1]),
                                   problem_of(b, b.t.h, wb.out_proj_w, wb.out_proj_b, b.t.x, b.t.x, b.d, b.d, wb.out_proj_cs, sb[1]), rx, st))) return rc;
@@ -295,7 +257,8 @@ static int run_block_pair(const cmh_block_weights& wa, const cmh_block_weights& 
   }
   if ((rc = launch_gemm_grouped(dt, problem_of(a, a.t.h, wa.in_proj_w, wa.in_proj_b, nullptr, a.t.qkv, 3 * a.d, a.d),
                                 problem_of(b, b.t.h, wb.in_proj_w, wb.in_proj_b, nullptr, b.t.qkv, 3 * b.d, b.d), EPI_BIAS | obf, st))) return rc;
-  if ((rc = attention_pair(a, b, dt, 0.f, 0.f, st))) return rc;
+  if ((rc = launch_attention_varlen(a.t.qkv, a.t.h, dt, a.B, a.T, a.d, a.causal, nullptr, a.seq_off, st))) return rc;
+  if ((rc = launch_attention_varlen(b.t.qkv, b.t.h, dt, b.B, b.T, b.d, b.causal, nullptr, b.seq_off, st))) return rc;
   if (upto_attention) return CMH_OK;
   if ((rc = launch_gemm_grouped(dt, problem_of(a, a.t.h, wa.out_proj_w, wa.out_proj_b, a.t.x, a.t.x, a.d, a.d),
                                 problem_of(b, b.t.h, wb.out_proj_w, wb.out_proj_b, b.t.x, b.t.x, b.d, b.d), rx, st))) return rc;
