@@ -257,6 +257,7 @@ class GradSync:
         self._sent = [False] * len(self.groups)
         self._late, self._pending, self._handles = [], [], []
         self._buckets, self._via_bucket = [], set()           # in-place messages of this step; ids of the parameters they cover
+        self._deferred = []                                   # CMH_GRADSYNC_DEFER=1: buckets held back until finish()
         self.bucket_log = []                                  # (elements, parameters) of every in-place message of the last step
         if self.on:
             for g in self.groups:
@@ -298,7 +299,10 @@ class GradSync:
         # remember WHERE each gradient lies, not the view objects: autograd adopts a returned gradient as p.grad only while nobody
         # else holds a reference to it (otherwise it clones it)
         spans = [(v.storage_offset() - flat.storage_offset(), v.numel()) for v in views]
-        self._buckets.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, params, spans))
+        if os.environ.get("CMH_GRADSYNC_DEFER") == "1":       # measurement only (tools/gradsync_overlap.sh): every bucket leaves from finish()
+            self._deferred.append((flat, params, spans))
+        else:
+            self._buckets.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, params, spans))
         self._via_bucket.update(id(p) for p in params)
 
     def _send(self, params):
@@ -326,6 +330,9 @@ class GradSync:
                 self._send(self._arrived[gi])
         if self._late:
             self._send(self._late)
+        for flat, params, spans in self._deferred:
+            self._buckets.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, params, spans))
+        self._deferred = []
         on_gpu = torch.cuda.is_available()
         self.bucket_log = []
         for work, flat, params, spans in self._buckets:
