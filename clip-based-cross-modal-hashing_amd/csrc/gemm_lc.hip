@@ -51,12 +51,24 @@ __device__ __forceinline__ int lc_swz(int row, int chunk) { return row * lcRowBy
 
 #define LC_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
 
+#ifdef LC_STAMPS   // diagnostic build only (tools/lc_stamps.py; make BUILD=build_st EXTRA=-DLC_STAMPS): per workgroup, MFMA wave 0: shader-clock
+                   // ticks (s_memtime) of the whole kernel, until the first stage, inside the K loops, inside the epilogues; and the 100 MHz
+                   // wall clock over the same span (clock = ticks / wall)
+__device__ unsigned long long g_lc_stamps[256 * 8];
+#define LC_T() __builtin_amdgcn_s_memtime()
+#endif
+
 // RF: the residual-first rule applies to this launch (short K with a residual: the accumulators start as the residual tile); a template
 // parameter so that a tile's first K-step is one straight path - C = 0 inside the first MFMAs, or the loaded residual
 // ABL (diagnostic instantiations only, CMH_LC_ABL): 1 the MFMA waves skip their MFMAs (what the feed alone sustains), 2 the loaders stage
 // nothing after the prologue (what the MFMA side alone sustains), 4 one stage in flight instead of two
-template <bool GRP, bool RF, int ABL = 0>
+// F16O: the 16-bit output is IEEE fp16 (the residual stream) instead of bf16 - compile-time, like RF: inside the epilogue every taken
+// branch costs a lone wave ~16 issue cycles, and there were three per 16-byte store
+// RES: 0 no residual, 1 residual first (RF), 2 residual behind the bias (long K) - compile-time as well: with the late-residual code in
+// the epilogue of the launches that never take it, the allocator spilled 165 registers around it
+template <bool GRP, int RES, bool F16O, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm_lc_kernel(LcProblem p0, LcProblem p1, int epi) {
+  constexpr bool RF = RES == 1;
   __shared__ __attribute__((aligned(1024))) char lds[3 * lcSTG + 2 * 1024];      // the ring + two bias rows (tile parity)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -274,6 +286,10 @@ __global__ __launch_bounds__(512) void gemm_lc_kernel(LcProblem p0, LcProblem p1
     else LC_READ(fx[3], addr, 6144);                                             \
   } while (0)
 
+#ifdef LC_STAMPS
+  const unsigned long long st_t0 = LC_T(), st_r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long st_first = 0, st_k = 0, st_e = 0, st_mark = 0;
+#endif
   // ---- prologue: the first tile's residual rows (if they come first) are on their way while stage 0 lands ----------------------
   int cur = 0;
   {
@@ -282,6 +298,10 @@ __global__ __launch_bounds__(512) void gemm_lc_kernel(LcProblem p0, LcProblem p1
     if constexpr (RF) { zero_acc(); add_residual(m0, n0); }
   }
   __builtin_amdgcn_s_barrier();                    // stage 0 has landed
+#ifdef LC_STAMPS
+  st_first = LC_T() - st_t0;
+  st_mark = LC_T();
+#endif
   // fragments of (stage 0, k 0..31): X then W, the order every later half-step issues them in
   LC_READ_X(fxa, 0, aX); LC_READ_X(fxa, 1, aX); LC_READ_X(fxa, 2, aX); LC_READ_X(fxa, 3, aX);
   LC_READ_W(0, aW); LC_READ_W(1, aW); LC_READ_W(2, aW); LC_READ_W(3, aW);
@@ -292,6 +312,11 @@ __global__ __launch_bounds__(512) void gemm_lc_kernel(LcProblem p0, LcProblem p1
   // k 0..31 of the next stage (fxa; fw in place).  LDS returns a wave's reads in order, so "fragment a has landed" is a count of the
   // reads issued after it: 11 in the steady state of half 0 (7 - a older W fragments still to come, the 4 X reads and the a W reads of
   // the next half-step issued since), 7 - a at the top of half 1.
+  // (Deferred stores, the wide kernel's answer to a CU that drains stores at ~10-13 B/clk - a tile's 64 KB keep the lone wave of each
+  // SIMD in the epilogue for ~4 900 cycles, tools/lc_stamps.py - were built here too: eight of the sixteen 16-byte pieces per lane
+  // parked in registers and issued one or two per K-step among the next tile's MFMAs.  Measured WORSE on the grouped launches
+  // (QKV 68.2 -> 72.5 us; profiles/r05_j): a store in the lone MFMA wave's in-order stream waits for the address path behind the
+  // stage's 48 DMA pieces, and nobody else issues MFMAs on that SIMD meanwhile.  Not kept.)
   auto kstep = [&](auto zc) __attribute__((always_inline)) {
     constexpr bool ZC = decltype(zc)::value;      // first K-step of a tile whose accumulators start at zero: C = 0 instead of 128 v_mov
     const uint32_t bo = static_cast<uint32_t>(cur) * lcSTG;
@@ -365,28 +390,29 @@ __global__ __launch_bounds__(512) void gemm_lc_kernel(LcProblem p0, LcProblem p1
     bool second; int m0, n0;
     tile_of(ti, second, m0, n0);
     if constexpr (GRP) { if (ti == n_first && ti > 0) to_problem1(); }
-    constexpr bool rf = RF;
+    // (zeroed with 128 v_mov here rather than by C = 0 in a peeled first K-step: a second copy of the K-step body leaves the allocator
+    // two register assignments to reconcile at every tile boundary, and it does so through scratch)
     if constexpr (RF) { if (ti > 0) { zero_acc(); add_residual(m0, n0); } }
-    kstep(std::integral_constant<bool, !RF>{});
-    for (int kt = 1; kt < nk; ++kt) kstep(std::false_type{});
+    else zero_acc();
+    for (int kt = 0; kt < nk; ++kt) kstep(std::false_type{});
 
     // ---- epilogue (the loaders are already staging the next tile; its first fragments are on their way into fxa / fw) -------------
-    // One wave per SIMD: nobody covers a memory round trip here.  The bias row comes from LDS (staged by the loaders with the tile's
-    // first stage), four fragments at a time; residual rows (long K only) two 16-row fragments at a time.
+    // One wave per SIMD: nobody covers a memory round trip or a taken branch here.  The bias row comes from LDS (staged by the loaders
+    // with the tile's first stage): eight reads, ONE wait; the output kind is a template parameter; a full tile's stores carry no
+    // lane mask; a lane's store address is a uniform base + one 32-bit offset.
+#ifdef LC_STAMPS
+    { const unsigned long long t_ = LC_T(); st_k += t_ - st_mark; st_mark = t_; }
+#endif
     if (epi & EPI_BIAS) {
       const uint32_t ab = lds_base + 3 * lcSTG + (ti & 1) * 1024 + (wn * 128 + fq * 4) * 4;
+      lc_f32x4_t bv[8];
 #pragma unroll
-      for (int ag = 0; ag < 8; ag += 4) {
-        lc_f32x4_t bv[4];
+      for (int a = 0; a < 8; ++a) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bv[a]) : "v"(ab), "n"(a * 64));
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]), "+v"(bv[4]), "+v"(bv[5]), "+v"(bv[6]), "+v"(bv[7])::"memory");
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bv[a]) : "v"(ab), "n"((ag + a) * 64));
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3])::"memory");
+      for (int a = 0; a < 8; ++a)
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) acc[ag + a][b] += bv[a];
-      }
+        for (int b = 0; b < 4; ++b) acc[a][b] += bv[a];
     }
     if (epi & EPI_QUICKGELU) {
       // two values at a time, the wide kernel's instruction sequence (packed-f32 multiply / add, v_exp_f32 / v_rcp_f32 per value)
@@ -404,23 +430,24 @@ __global__ __launch_bounds__(512) void gemm_lc_kernel(LcProblem p0, LcProblem p1
             acc[a][b][j + 1] = o[1];
           }
     }
-    if ((epi & EPI_RESIDUAL) && !rf) add_residual(m0, n0);
+    if constexpr (RES == 2) add_residual(m0, n0);
     __builtin_amdgcn_sched_barrier(0);
     {
       // v_permlane16_swap exchanges, between the lane pairs (l, l + 16), the packed words of two neighbouring n-fragments: an even
       // lane-row then owns 8 consecutive n of fragment 2 pr and an odd lane-row 8 consecutive n of fragment 2 pr + 1 -> 16-byte stores
-      const int col = n0 + wn * 128 + (fq & 1) * 16 + (fq & 2) * 4;      // + 32 * pair
-      char* optr = static_cast<char*>(out) + (static_cast<size_t>(m0 + wm * 64 + frow) * N + col) * 2;
-      const size_t row16 = static_cast<size_t>(16) * N * 2;
+      char* const obase = static_cast<char*>(out) + (static_cast<size_t>(m0) * N + n0) * 2;       // uniform
+      const uint32_t ldn = static_cast<uint32_t>(N) * 2;
+      const uint32_t off0 = static_cast<uint32_t>(wm * 64 + frow) * ldn + static_cast<uint32_t>(wn * 128 + (fq & 1) * 16 + (fq & 2) * 4) * 2;
+      const bool full = m0 + lcBM <= M && !(epi & 256);      // uniform (256 = timing-only ablation: skip stores)
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const bool row_ok = m0 + wm * 64 + b * 16 + frow < M;
+        const uint32_t offb = off0 + static_cast<uint32_t>(b * 16) * ldn;
 #pragma unroll
         for (int pr = 0; pr < 4; ++pr) {
           uint32_t lo[2], hi[2];
 #pragma unroll
           for (int w = 0; w < 2; ++w) {
-            if (epi & EPI_OUT_F16) {
+            if constexpr (F16O) {
               lo[w] = pack_f16x2(acc[2 * pr][b][2 * w], acc[2 * pr][b][2 * w + 1]);
               hi[w] = pack_f16x2(acc[2 * pr + 1][b][2 * w], acc[2 * pr + 1][b][2 * w + 1]);
             } else {
@@ -430,13 +457,23 @@ __global__ __launch_bounds__(512) void gemm_lc_kernel(LcProblem p0, LcProblem p1
           }
           const lc_u2_t s0 = __builtin_amdgcn_permlane16_swap(lo[0], hi[0], false, false);
           const lc_u2_t s1 = __builtin_amdgcn_permlane16_swap(lo[1], hi[1], false, false);
-          if (row_ok && !(epi & 256))          // 256 = timing-only ablation: skip stores
-            *reinterpret_cast<lc_u32x4_t*>(optr + b * row16 + pr * 64) = lc_u32x4_t{s0[0], s1[0], s0[1], s1[1]};
+          const lc_u32x4_t val = {s0[0], s1[0], s0[1], s1[1]};
+          if (full) *reinterpret_cast<lc_u32x4_t*>(obase + (offb + pr * 64)) = val;
+          else if (m0 + wm * 64 + b * 16 + frow < M && !(epi & 256)) *reinterpret_cast<lc_u32x4_t*>(obase + (offb + pr * 64)) = val;
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
     }
+#ifdef LC_STAMPS
+    { const unsigned long long t_ = LC_T(); st_e += t_ - st_mark; st_mark = t_; }
+#endif
   }
+#ifdef LC_STAMPS
+  if (c == 0 && lane == 0 && blockIdx.x < 256) {
+    unsigned long long* o = g_lc_stamps + blockIdx.x * 8;
+    o[0] = LC_T() - st_t0; o[1] = __builtin_amdgcn_s_memrealtime() - st_r0; o[2] = st_first; o[3] = st_k; o[4] = st_e;
+    o[5] = static_cast<unsigned long long>(S); o[6] = static_cast<unsigned long long>(my_tiles); o[7] = static_cast<unsigned long long>(my_tiles);
+  }
+#endif
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads issued past the last stage
 }
 
@@ -451,7 +488,7 @@ bool gemm_lc_takes(int dt, int N, int K, int epi) {
   if (dt != CMH_BF16 || N % lcBN != 0 || K % 64 != 0 || K < 256) return false;      // >= 4 K-steps per tile: the bias slots' reuse distance
   if (!(epi & (EPI_OUT_BF16 | EPI_OUT_F16)) || ((epi & EPI_OUT_BF16) && (epi & EPI_OUT_F16))) return false;
   if (epi & ~(EPI_BIAS | EPI_QUICKGELU | EPI_RESIDUAL | EPI_RES_F16 | EPI_OUT_BF16 | EPI_OUT_F16 | 256)) return false;
-  if ((epi & EPI_RESIDUAL) && !(epi & EPI_RES_F16)) return false;      // the 16-bit-output launches carry the fp16 stream
+  if ((epi & EPI_RESIDUAL) && !((epi & EPI_RES_F16) && (epi & EPI_OUT_F16))) return false;      // a residual = the fp16 stream, in and out
   if ((epi & EPI_RESIDUAL) && (epi & EPI_QUICKGELU)) return false;
   return true;
 }
@@ -489,17 +526,27 @@ int launch_gemm_lc(const GemmProblem& a, const GemmProblem* b, int epi, hipStrea
   const int grid = total < cus ? ((total + 7) & ~7) : cus;     // sized for the upper bounds: workgroups without a tile exit at once
   const LcProblem P0 = prob(a), P1 = b ? prob(*b) : LcProblem{};
   const bool rf = gemm_lc_res_first(epi, a.K);      // (the caller has checked that both problems agree)
-#define LC_GO(G, R)                                                                                                          \
+  const bool f16o = (epi & EPI_OUT_F16) != 0;
+#define LC_GO2(G, R, F)                                                                                                      \
   do {                                                                                                                       \
-    if (ev0) hipExtLaunchKernelGGL((gemm_lc_kernel<G, R>), dim3(grid), dim3(512), 0, st, ev0, ev1, 0, P0, P1, epi);          \
-    else hipLaunchKernelGGL((gemm_lc_kernel<G, R>), dim3(grid), dim3(512), 0, st, P0, P1, epi);                              \
+    if (ev0) hipExtLaunchKernelGGL((gemm_lc_kernel<G, R, F>), dim3(grid), dim3(512), 0, st, ev0, ev1, 0, P0, P1, epi);       \
+    else hipLaunchKernelGGL((gemm_lc_kernel<G, R, F>), dim3(grid), dim3(512), 0, st, P0, P1, epi);                           \
+  } while (0)
+  // five forms: no residual -> bf16 or fp16 output; a residual (the fp16 stream, fp16 output) first or behind the bias
+  const int res = !(epi & EPI_RESIDUAL) ? 0 : (rf ? 1 : 2);
+#define LC_GO(G, R_unused)                                                                                                   \
+  do {                                                                                                                       \
+    if (res == 1) LC_GO2(G, 1, true);                                                                                        \
+    else if (res == 2) LC_GO2(G, 2, true);                                                                                   \
+    else if (f16o) LC_GO2(G, 0, true);                                                                                       \
+    else LC_GO2(G, 0, false);                                                                                                \
   } while (0)
   static const int abl = []() { const char* e = getenv("CMH_LC_ABL"); return e ? atoi(e) : 0; }();
-  if (abl && !b && !rf) {      // diagnostic builds of the plain, residual-free form only
+  if (abl && !b && !rf && !(epi & EPI_OUT_F16)) {      // diagnostic builds of the plain, residual-free, bf16-output form only
 #define LC_GO_A(A)                                                                                                            \
   do {                                                                                                                       \
-    if (ev0) hipExtLaunchKernelGGL((gemm_lc_kernel<false, false, A>), dim3(grid), dim3(512), 0, st, ev0, ev1, 0, P0, P1, epi); \
-    else hipLaunchKernelGGL((gemm_lc_kernel<false, false, A>), dim3(grid), dim3(512), 0, st, P0, P1, epi);                    \
+    if (ev0) hipExtLaunchKernelGGL((gemm_lc_kernel<false, 0, false, A>), dim3(grid), dim3(512), 0, st, ev0, ev1, 0, P0, P1, epi); \
+    else hipLaunchKernelGGL((gemm_lc_kernel<false, 0, false, A>), dim3(grid), dim3(512), 0, st, P0, P1, epi);                    \
   } while (0)
     if (abl == 1) LC_GO_A(1); else if (abl == 2) LC_GO_A(2); else if (abl == 3) LC_GO_A(3); else LC_GO_A(4);
 #undef LC_GO_A
@@ -509,11 +556,18 @@ int launch_gemm_lc(const GemmProblem& a, const GemmProblem* b, int epi, hipStrea
   if (b) { if (rf) LC_GO(true, true); else LC_GO(true, false); }
   else { if (rf) LC_GO(false, true); else LC_GO(false, false); }
 #undef LC_GO
+#undef LC_GO2
   CMH_CHECK_LAUNCH("gemm (lc)");
   return 0;
 }
 
 }  // namespace cmh
+
+#ifdef LC_STAMPS
+extern "C" int cmh_debug_lc_stamps(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(cmh::g_lc_stamps), sizeof(unsigned long long) * 256 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int cmh_set_gemm_lc(int32_t mode) {
   CMH_CHECK_ARG(mode >= -1 && mode <= 3, "set_gemm_lc: mode %d (-1 environment, 0 off, 1 every eligible launch, 2 all but QuickGELU launches, 3 by cost model)", mode);

@@ -23,15 +23,8 @@ for name, (M, Nn, K, epi) in shapes.items():
         assert N.lib().cmh_debug_lc_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
         s = buf.reshape(256, 8).astype(np.float64)
         s = s[s[:, 6] == s[:, 6].max()]          # the workgroups with the most tiles set the launch's length
-        tot, wall, first, kl, ep, ks, tiles, nt = s.mean(0)      # ks / nt: K-steps / tiles the stamped wave's group multiplied
+        tot, wall, first, kl, ep, ks, tiles, nt = s.mean(0)      # ks: K-steps, nt: tiles of the stamped workgroup
         ghz = tot / (wall * 10.0) if wall else 0.0      # ticks per 10 ns
         print(f"{name:7s} {data:6s}: {tiles:.0f} tiles ({nt:.0f} multiplied by the stamped group, {ks:.0f} K-steps)  kernel {tot:8.0f} ticks = {wall / 100:6.2f} us -> {ghz:4.2f} GHz "
               f"| first stage {first:6.0f} | its K loops {kl:8.0f} ({kl / max(ks, 1):6.0f} per K-step, {kl / max(ks, 1) / ghz / 1e3:5.3f} us) "
               f"| behind them (epilogue set-up / direct epilogue) {ep:7.0f} ({ep / max(nt, 1):6.0f} per tile)", flush=True)
-        b2 = np.zeros(256 * 8, dtype=np.uint64)
-        if hasattr(N.lib(), "cmh_debug_lc_stamps2") and N.lib().cmh_debug_lc_stamps2(b2.ctypes.data_as(ctypes.c_void_p)) == 0:
-            t = b2.reshape(256, 8).astype(np.float64)
-            t = t[t[:, 5] == t[:, 5].max()]
-            w_, d_, sl_, st_, ns_ = t.mean(0)[:5]
-            print(f"        staging wave 4: {st_:.0f} steps ({ns_:.0f} with a slice): wait + barrier {w_ / max(st_, 1):6.0f}, DMA issue {d_ / max(st_, 1):6.0f}, "
-                  f"slice {sl_ / max(ns_, 1):6.0f} ticks per step", flush=True)
