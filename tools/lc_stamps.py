@@ -8,7 +8,9 @@ sys.path.insert(0, os.path.join(ROOT, "clip-based-cross-modal-hashing_amd"))
 import numpy as np, torch, cmh_native as N
 dev = torch.device("cuda:0")
 shapes = {"v_qkv": (12800, 2304, 768, 9), "t_qkv": (10499, 1536, 512, 9), "v_fc1": (12800, 3072, 768, 11), "v_fc2": (12800, 768, 3072, 9),
-          "sq4096": (4096, 4096, 4096, 9)}
+          "sq4096": (4096, 4096, 4096, 9),
+          # few workgroups busy (36 / 72 tiles of the same N, K): is a tile's store tail the CU's own limit or the chip's, all CUs storing at once?
+          "qkv_36wg": (512, 2304, 768, 9), "qkv_72wg": (1024, 2304, 768, 9), "qkv_144wg": (2048, 2304, 768, 9)}
 N.set_gemm_lc(1)
 for name, (M, Nn, K, epi) in shapes.items():
     x = torch.randn(M, K, device=dev).bfloat16(); w = (torch.randn(Nn, K, device=dev) * K ** -0.5).bfloat16()
@@ -21,7 +23,7 @@ for name, (M, Nn, K, epi) in shapes.items():
         torch.cuda.synchronize()
         buf = np.zeros(256 * 8, dtype=np.uint64)
         assert N.lib().cmh_debug_lc_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
-        s = buf.reshape(256, 8).astype(np.float64)
+        s = buf.reshape(256, 8).astype(np.float64)[:min(256, -(-M // 128) * (Nn // 256))]      # (workgroups this launch did not have keep older stamps)
         s = s[s[:, 6] == s[:, 6].max()]          # the workgroups with the most tiles set the launch's length
         tot, wall, first, kl, ep, ks, tiles, nt = s.mean(0)      # ks: K-steps, nt: tiles of the stamped workgroup
         ghz = tot / (wall * 10.0) if wall else 0.0      # ticks per 10 ns
