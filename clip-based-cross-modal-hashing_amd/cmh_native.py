@@ -106,6 +106,7 @@ SIGNATURES = {
     "cmh_set_gemm_rows": (C.c_int, [_i32]),
     "cmh_set_gemm_grouped": (C.c_int, [_i32]),
     "cmh_set_gemm_lc": (C.c_int, [_i32]),
+    "cmh_set_grad_stream16": (C.c_int, [_i32]),
     "cmh_linear_gemm_grouped": (C.c_int, [_i32, C.POINTER(GemmProblem), C.POINTER(GemmProblem), _i32, _p]),
     "cmh_clip_encode_pair": (C.c_int, [C.POINTER(VitWeights), _p, C.POINTER(TextWeights), _p, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p, _sz, _p]),
     "cmh_msl_workspace_bytes": (_sz, [_i32]),
@@ -407,6 +408,11 @@ def set_pooled_tail(on: bool):
 def set_gemm_rows(on: int = -1):
     """Few-row GEMMs (M <= 512) on 64 x 64 tiles (csrc/gemm_rows.hip): 1 on (default), 0 = the wide kernel takes them, -1 = environment."""
     check(lib().cmh_set_gemm_rows(int(on)), "cmh_set_gemm_rows")
+
+
+def set_grad_stream16(on: int):
+    """bf16 training mode: carry the towers' residual-gradient stream as bf16 (1, the default), as f32 (0); -1 = CMH_GRAD_STREAM16"""
+    check(lib().cmh_set_grad_stream16(int(on)), "cmh_set_grad_stream16")
 
 
 def set_gemm_lc(mode: int):

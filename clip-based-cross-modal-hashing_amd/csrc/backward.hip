@@ -211,7 +211,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
                                                             int dykind, const float* __restrict__ g, float* __restrict__ dx,
                                                             int accumulate, int M, int d, float* __restrict__ pg,
                                                             float* __restrict__ pb, const int32_t* __restrict__ row_index,
-                                                            bf16_t* __restrict__ dx_bf16) {
+                                                            bf16_t* __restrict__ dx_bf16, const bf16_t* __restrict__ acc16,
+                                                            int write_f32) {
   __shared__ float red[2][4][1024];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   float gam[NV][4], dg[NV][4], db[NV][4];
@@ -226,7 +227,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
   const int rbase = blockIdx.x * kLnRows;
   // two rows per wave and iteration: both rows' loads are issued before either is reduced, so the second row's memory latency hides
   // under the first row's three butterflies (one row at a time the kernel ran at 2.8 TB/s: 49 us for the 137 MB of a vision layer)
-  auto load_row = [&](int row, float (&xv)[NV][4], float (&dv)[NV][4]) -> size_t {
+  // acc16 (the 16-bit gradient stream of the bf16 training mode): the sum the new dx is added to comes as bf16 from ANOTHER buffer - its
+  // 8 bytes per lane and slice are fetched with the row, not behind the three butterflies
+  auto load_row = [&](int row, float (&xv)[NV][4], float (&dv)[NV][4], uint2 (&av)[NV]) -> size_t {
     const size_t xrow = row_index ? static_cast<size_t>(row_index[row]) : static_cast<size_t>(row);   // x / dx row (pooled rows)
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -234,12 +237,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
       const bool ok = e0 < d;
       const float4 xa = ok ? load4_as_f32(x, xrow * d + e0, xkind) : float4{0.f, 0.f, 0.f, 0.f};
       const float4 da = ok ? load4_as_f32(dy, static_cast<size_t>(row) * d + e0, dykind) : float4{0.f, 0.f, 0.f, 0.f};
+      av[j] = (ok && acc16) ? *reinterpret_cast<const uint2*>(acc16 + xrow * d + e0) : uint2{0u, 0u};
       xv[j][0] = xa.x; xv[j][1] = xa.y; xv[j][2] = xa.z; xv[j][3] = xa.w;
       dv[j][0] = da.x; dv[j][1] = da.y; dv[j][2] = da.z; dv[j][3] = da.w;
     }
     return xrow;
   };
-  auto do_row = [&](size_t xrow, float (&xv)[NV][4], float (&dv)[NV][4]) {
+  auto do_row = [&](size_t xrow, float (&xv)[NV][4], float (&dv)[NV][4], const uint2 (&av)[NV]) {
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) s += (xv[j][0] + xv[j][1]) + (xv[j][2] + xv[j][3]);
@@ -284,7 +288,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
         float4 v = float4{rstd * (dv[j][0] - ma - xv[j][0] * max_), rstd * (dv[j][1] - ma - xv[j][1] * max_),
                           rstd * (dv[j][2] - ma - xv[j][2] * max_), rstd * (dv[j][3] - ma - xv[j][3] * max_)};
         if (accumulate) { const float4 c = *o; v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
-        *o = v;
+        else if (acc16) {
+          v.x += __uint_as_float(av[j].x << 16); v.y += __uint_as_float(av[j].x & 0xffff0000u);
+          v.z += __uint_as_float(av[j].y << 16); v.w += __uint_as_float(av[j].y & 0xffff0000u);
+        }
+        if (write_f32) *o = v;
         // the next GEMMs take this gradient as a bf16 operand: write it here instead of a cast pass over the f32 stream
         if (dx_bf16) *reinterpret_cast<uint2*>(dx_bf16 + xrow * d + e0) = uint2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
       }
@@ -295,10 +303,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
     if (row >= M) break;
     const bool two = row + 1 < M;
     float xa[NV][4], da[NV][4], xb[NV][4], dbv[NV][4];
-    const size_t ra = load_row(row, xa, da);
-    const size_t rb = load_row(two ? row + 1 : row, xb, dbv);
-    do_row(ra, xa, da);
-    if (two) do_row(rb, xb, dbv);
+    uint2 aa[NV], ab[NV];
+    const size_t ra = load_row(row, xa, da, aa);
+    const size_t rb = load_row(two ? row + 1 : row, xb, dbv, ab);
+    do_row(ra, xa, da, aa);
+    if (two) do_row(rb, xb, dbv, ab);
   }
   // combine the 4 waves' dg / db columns, one partial row per workgroup
 #pragma unroll
@@ -415,8 +424,11 @@ extern "C" size_t cmh_layernorm_backward_workspace_bytes(int32_t M, int32_t d) {
 namespace cmh {
 int launch_layernorm_backward(const void* x, int x_kind, const void* dy, int dy_kind, const float* gamma, const int32_t* row_index,
                               int M, int d, float* dx, int accumulate, float* dgamma, float* dbeta, void* workspace,
-                              size_t workspace_bytes, hipStream_t st, void* dx_bf16, FinalJobs* defer) {
+                              size_t workspace_bytes, hipStream_t st, void* dx_bf16, FinalJobs* defer, const void* acc16,
+                              bool write_f32) {
   CMH_CHECK_ARG(x && dy && gamma && dx && dgamma && dbeta && workspace && M > 0, "layernorm_backward: bad arguments");
+  CMH_CHECK_ARG(!acc16 || (!accumulate && dx_bf16 && acc16 != dx_bf16 && !row_index), "layernorm_backward: the 16-bit sum comes from another buffer, instead of the f32 one");
+  CMH_CHECK_ARG(write_f32 || dx_bf16, "layernorm_backward: no output");
   CMH_CHECK_ARG(d % 4 == 0 && d <= 1024, "layernorm_backward: d=%d must be a multiple of 4 and <= 1024", d);
   CMH_CHECK_ARG((x_kind == kF32 || x_kind == kF16) && (dy_kind == kF32 || dy_kind == kBF16), "layernorm_backward: bad kinds");
   if (workspace_bytes < cmh_layernorm_backward_workspace_bytes(M, d)) return fail(CMH_ERR_WORKSPACE, "layernorm_backward: workspace too small");
@@ -425,7 +437,7 @@ int launch_layernorm_backward(const void* x, int x_kind, const void* dy, int dy_
   float* pb = pg + static_cast<size_t>(nb) * d;
 #define LN_BWD(NV)                                                                                                          \
   hipLaunchKernelGGL(layernorm_bwd_kernel<NV>, dim3(nb), dim3(256), 0, st, x, x_kind, dy, dy_kind, gamma, dx, accumulate, M, d, pg, \
-                     pb, row_index, static_cast<bf16_t*>(dx_bf16))
+                     pb, row_index, static_cast<bf16_t*>(dx_bf16), static_cast<const bf16_t*>(acc16), write_f32 ? 1 : 0)
   if (d <= 256) LN_BWD(1);
   else if (d <= 512) LN_BWD(2);
   else if (d <= 768) LN_BWD(3);

@@ -216,7 +216,9 @@ int launch_colsum_partial(const void* x, int kind, int rows, int cols, float* pa
 int launch_layernorm_backward(const void* x, int x_kind, const void* dy, int dy_kind, const float* gamma, const int32_t* row_index,
                               int M, int d, float* dx, int accumulate, float* dgamma, float* dbeta, void* workspace,
                               size_t workspace_bytes, hipStream_t st, void* dx_bf16 = nullptr,   // + a bf16 copy of the new dx
-                              FinalJobs* defer = nullptr);                                        // queue dgamma / dbeta's final stage
+                              FinalJobs* defer = nullptr,                                         // queue dgamma / dbeta's final stage
+                              const void* acc16 = nullptr,      // the new dx is added to THIS bf16 buffer's values (accumulate = 0)
+                              bool write_f32 = true);           // false: only the bf16 copy leaves (the 16-bit gradient stream)
 
 // attention over qkv [B*T, 3d] (dt) -> o [B*T, d] (dt); heads = d/64; causal adds the -inf triu mask
 int launch_attention(const void* qkv, void* o, int dt, int B, int T, int d, int causal,

@@ -250,12 +250,21 @@ int dgrad(int dt, const void* dYe, const void* W, int O, int I, int M, const voi
 
 int zero_pad_buffers(TrainBufs& t, size_t M, hipStream_t st);
 
+static int g_grad_stream16 = -1;      // cmh_set_grad_stream16: -1 = from the environment (CMH_GRAD_STREAM16=0 switches it off)
+bool grad_stream16_enabled() {
+  static const bool env_on = []() { const char* e = getenv("CMH_GRAD_STREAM16"); return !(e && e[0] == '0'); }();
+  return g_grad_stream16 < 0 ? env_on : g_grad_stream16 != 0;
+}
+
 // pooled_rows / dxp (the last block after block_forward_train(..., pooled_rows)): the incoming gradient is dxp [B, d] f32 on the
 // pooled rows; steps 1-4 run on those B rows, then the two gradients that go on - d(attention output) and the residual stream -
 // are scattered into zeroed full-size buffers for the attention backward and ln_1.
+// keep_f32: the caller reads the f32 gradient stream (t.dx) behind this block (the embeddings' backward after block 0; the
+// caller-visible dx of cmh_blocks_backward) - see the 16-bit stream below.
 int block_backward(const cmh_block_weights& w, const BlockGradPtrs& g, int dt, int xh, const LayerTape& L, TrainBufs& t, int B,
                    int T, int d, int causal, const uint8_t* kpm, hipStream_t st, bool dxe_ready, int rows = -1,
-                   const int32_t* seq_off = nullptr, const int32_t* pooled_rows = nullptr, float* dxp = nullptr) {
+                   const int32_t* seq_off = nullptr, const int32_t* pooled_rows = nullptr, float* dxp = nullptr,
+                   bool keep_f32 = true) {
   const int M = rows >= 0 ? rows : B * T;
   const int Mt = pooled_rows ? B : M;                  // rows of the row-wise tail (steps 1-4)
   float* dxt = pooled_rows ? dxp : t.dx;               // its gradient stream
@@ -294,6 +303,14 @@ int block_backward(const cmh_block_weights& w, const BlockGradPtrs& g, int dt, i
   const bool multi = dt == CMH_BF16 && !pooled_rows && batched && dx_copy && gemm_wide_tn_multi_enabled() && gemm_wide_tn_multi_fits(probe, 4) &&
                      db_slice >= static_cast<size_t>(64) * d * 4 + 256;
   void* dx_copy2 = multi ? static_cast<void*>(t.dx2) : dx_copy;      // where ln_2's backward leaves the bf16 copy of the new dx
+  // Round 5: the 16-bit gradient stream.  The residual gradient is needed twice per block as a bf16 GEMM operand (c_proj's and
+  // out_proj's dY) and twice as the sum a LayerNorm backward adds to; kept in f32 the two LayerNorm launches read AND write it
+  // beside the bf16 copy they leave anyway (14 bytes per element: x 2, dy 2, dx 4 + 4, copy 2).  In the bf16 mode's multi-launch
+  // blocks the bf16 copy IS the stream: ln_2 adds to the entry copy (t.dxe) and writes t.dx2, ln_1 adds to t.dx2 and writes t.dxe
+  // - 8 bytes per element; the sum is formed in f32 and rounded to bf16 once per LayerNorm (24 roundings along a 12-block tower,
+  // each 2^-9 relative: below what the bf16 GEMM operands already cost, tests/test_gpu_backward.py).  t.dx is written only where
+  // somebody reads it (keep_f32).  The f32 mode, the pooled last block and CMH_GRAD_STREAM16=0 keep the f32 stream.
+  const bool s16 = multi && grad_stream16_enabled();
   // 1. MLP projection (dxe_ready: the previous block's ln_1 backward already wrote t.dxe)
   const size_t mtd = static_cast<size_t>(Mt) * d;
   if (dxe_ready && dx_copy) dxe = t.dxe;
@@ -306,8 +323,9 @@ int block_backward(const cmh_block_weights& w, const BlockGradPtrs& g, int dt, i
   if ((rc = dgrad(dt, t.dpre, w.fc_w, 4 * d, d, Mt, nullptr, t.dh, obf, t, st, wdst[1]))) return rc;
   if (!multi && (rc = wgrad(dt, t.dpre, ek, 4 * d, L.h2, ek, d, Mt, g.fc_w, g.fc_b, t, st, dj, batched ? off_fc : 0))) return rc;
   // 3. ln_2
-  if ((rc = launch_layernorm_backward(L.x_mid, xk, t.dh, ek, w.ln2_w, nullptr, Mt, d, dxt, 1, g.ln2_w, g.ln2_b,
-                                      batched ? red + off_ln2 : red, batched ? ln_ws : t.red_bytes, st, dx_copy2, dj))) return rc;
+  if ((rc = launch_layernorm_backward(L.x_mid, xk, t.dh, ek, w.ln2_w, nullptr, Mt, d, dxt, s16 ? 0 : 1, g.ln2_w, g.ln2_b,
+                                      batched ? red + off_ln2 : red, batched ? ln_ws : t.red_bytes, st, dx_copy2, dj,
+                                      s16 ? dxe_entry : nullptr, !s16))) return rc;
   // 4. out_proj
   if (dx_copy2) dxe = dx_copy2;
   else if ((rc = as_gemm_operand(dt, dxt, t.dxe, mtd, st, &dxe))) return rc;
@@ -343,8 +361,9 @@ int block_backward(const cmh_block_weights& w, const BlockGradPtrs& g, int dt, i
     for (int i = 0; i < 4; ++i) jobs.add(jobs4[i].colsum, slices[i], jobs4[i].Mm, dbs[i]);
   }
   // 7. ln_1
-  if ((rc = launch_layernorm_backward(L.x_in, xk, t.dh, ek, w.ln1_w, nullptr, M, d, t.dx, 1, g.ln1_w, g.ln1_b,
-                                      batched ? red + off_ln1 : red, batched ? ln_ws : t.red_bytes, st, dx_copy, dj))) return rc;
+  if ((rc = launch_layernorm_backward(L.x_in, xk, t.dh, ek, w.ln1_w, nullptr, M, d, t.dx, s16 ? 0 : 1, g.ln1_w, g.ln1_b,
+                                      batched ? red + off_ln1 : red, batched ? ln_ws : t.red_bytes, st, dx_copy, dj,
+                                      s16 ? dxe_mid : nullptr, !s16 || keep_f32))) return rc;
   return launch_final_jobs(jobs, st);
 }
 
@@ -678,7 +697,8 @@ static int vit_backward_impl(const cmh_vit_weights* w, int32_t batch, const floa
   for (int i = layer_hi - 1; i >= layer_lo; --i) {
     const bool last = i == w->layers - 1;
     if ((rc = block_backward(w->blocks[i], grads_of(gr->blocks[i]), dt, xh, t.L[i], t, B, T, d, 0, nullptr, st,
-                             !last || dtokens != nullptr, -1, nullptr, tail && last ? t.rows : nullptr, tail && last ? t.dx2 : nullptr))) return rc;
+                             !last || dtokens != nullptr, -1, nullptr, tail && last ? t.rows : nullptr, tail && last ? t.dx2 : nullptr,
+                             /*keep_f32=*/i == 0))) return rc;
   }
   if (layer_lo > 0) return CMH_OK;
   // ln_pre, then the embeddings: x_pre[b,0] = cls + pos[0], x_pre[b,1+i] = patch_out[b*g2+i] + pos[1+i]
@@ -692,6 +712,12 @@ static int vit_backward_impl(const cmh_vit_weights* w, int32_t batch, const floa
                        B, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(CMH_ERR_LAUNCH, "vit_backward: compaction failed");
   if ((rc = zero_pad_buffers(t, static_cast<size_t>(B) * g2, st))) return rc;
   return wgrad(dt, t.dx, kF32, d, t.patches, ekind(dt), pk, B * g2, gr->conv1_w, nullptr, t, st);
+}
+
+extern "C" int cmh_set_grad_stream16(int32_t on) {
+  CMH_CHECK_ARG(on >= -1 && on <= 1, "set_grad_stream16: %d (-1 environment, 0 off, 1 on)", on);
+  g_grad_stream16 = on;
+  return CMH_OK;
 }
 
 extern "C" int cmh_vit_backward(const cmh_vit_weights* w, int32_t batch, const float* dfeat, const cmh_vit_grads* gr, void* tape,
@@ -839,7 +865,8 @@ static int text_backward_impl(const cmh_text_weights* w, const int64_t* tokens, 
   for (int i = layer_hi - 1; i >= layer_lo; --i) {
     const bool last = i == w->layers - 1;
     if ((rc = block_backward(w->blocks[i], grads_of(gr->blocks[i]), dt, xh, t.L[i], t, B, L, d, 1, key_padding_mask, st,
-                             !last || dtokens != nullptr, rows, seq_off, tail && last ? t.rows : nullptr, tail && last ? t.dx2 : nullptr))) return rc;
+                             !last || dtokens != nullptr, rows, seq_off, tail && last ? t.rows : nullptr, tail && last ? t.dx2 : nullptr,
+                             /*keep_f32=*/i == 0))) return rc;
   }
   if (layer_lo > 0) return CMH_OK;
   // x_0[b, t] = token_embedding[tokens[b, t]] + positional_embedding[t]
@@ -922,7 +949,8 @@ extern "C" int cmh_blocks_backward(const cmh_block_weights* blocks, const cmh_bl
   if ((rc = zero_pad_buffers(t, M, st))) return rc;
   if (hipMemcpyAsync(t.dx, dy, M * d * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(CMH_ERR_LAUNCH, "blocks_backward: copy failed");
   for (int i = layers - 1; i >= 0; --i)
-    if ((rc = block_backward(blocks[i], grads_of(grads[i]), dtype, /*xh=*/0, t.L[i], t, B, T, d, 0, nullptr, st, i != layers - 1))) return rc;
+    if ((rc = block_backward(blocks[i], grads_of(grads[i]), dtype, /*xh=*/0, t.L[i], t, B, T, d, 0, nullptr, st, i != layers - 1, -1, nullptr,
+                             nullptr, nullptr, /*keep_f32=*/i == 0))) return rc;
   if (hipMemcpyAsync(dx, t.dx, M * d * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(CMH_ERR_LAUNCH, "blocks_backward: copy failed");
   return CMH_OK;
 }

@@ -19,6 +19,17 @@
 // four MFMAs that use fragment a have issued), the X operand's four are double-buffered: 64 fragment registers + 128 accumulators.
 // Same k order per output element as the wide kernel (k = 64 kt + 32 ks + 8 fq + j inside v_mfma_f32_16x16x32_bf16, K-steps in
 // sequence), same epilogue operation order, same residual-first rule: the SAME BITS (tests/test_gpu_lc.py compares with torch.equal).
+//
+// Outcome (round 5): an EXPERIMENT, off by default (CMH_GEMM_LC / cmh_set_gemm_lc), not the product path.  The K loop does
+// what it was built for - 1 240-1 300 cycles per K-step against 1 024 of MFMA issue, no store or DMA instruction in the MFMA waves'
+// stream - and WITHOUT its output stores the kernel beats the wide kernel by 7 % (QKV 42.9 against 46.1 us).  With them it loses:
+// the epilogue of the ONE MFMA wave a SIMD has (4 850-4 930 cycles per tile: ~400 VALU instructions and 16 KB of stores through a CU
+// write path that moves ~16-20 B/clk, the same with 36 busy CUs as with 256) is covered by nobody, where the wide kernel's second
+// wave per SIMD multiplies meanwhile; the drained stores also slow the next K-steps' DMA (1 292 -> 1 554 cycles).  Stores cost
+// this kernel 21-24 % of a launch, the wide kernel 3-11 % (profiles/r05_l, r05_m, r05_n).  Built and measured on the way, none
+// kept: the epilogue handed to the staging waves (role swap: they have ~370 idle cycles per K-step, not the 1 600 a tile's epilogue
+// needs), stores deferred into the next tile's K-steps (a store in the lone MFMA wave's in-order stream stalls its SIMD).  Routing
+// the output through LDS to the staging waves' idle registers fails on capacity: ring 144 KB + bias 2 KB leave 14 KB of 160.
 #include <cstdlib>
 #include <cstring>
 

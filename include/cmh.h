@@ -252,6 +252,13 @@ int cmh_set_gemm_lc(int32_t mode);
  * (A/B measurements, the equality test); also CMH_POOLED_TAIL=0 in the environment.  Process-wide, not thread-safe. */
 int cmh_set_pooled_tail(int32_t on);
 
+/* bf16 training mode: the residual-gradient stream between the blocks of a tower's backward pass (cmh_vit_backward[_part],
+ * cmh_text_backward[_part], cmh_blocks_backward; reference: autograd through model/base/model.py:167-207) is carried as bf16 - the
+ * copy the LayerNorm backward kernels leave as the next GEMMs' operand anyway - instead of f32 beside that copy: each LayerNorm
+ * backward forms (new dx + stream) in f32 and rounds once.  on = 0 keeps the f32 stream (also CMH_GRAD_STREAM16=0); -1: the
+ * environment (default on).  The f32 mode never uses it.  Process-wide, not thread-safe. */
+int cmh_set_grad_stream16(int32_t on);
+
 /* ---------------------------------------------------------------------------------------------
  * fp8 encoder mode (CMH_FP8).  Mirrors the reference's precision hook convert_weights (model/base/model.py:391-412): the same
  * tensors it lowers to fp16 - Linear / MultiheadAttention weights - go to e4m3 here, with the activations that feed them.
