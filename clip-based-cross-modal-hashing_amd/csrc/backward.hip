@@ -207,7 +207,7 @@ __global__ __launch_bounds__(1024) void colsum_final_multi_kernel(FinalJobs jobs
 constexpr int kLnRows = 16;   // rows per workgroup: 800 workgroups for a 12 800-row layer (32 rows left the CUs at 1.5 waves per SIMD; 8 rows
                               // double the partial rows the final reduction has to add: measured slower in total)
 template <int NV>   // 256-column slices a lane owns: d <= 256 NV (sized to d: a 768-wide row keeps 3 slices of dg / db / gamma, not 4)
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ x, int xkind, const void* __restrict__ dy,
+__global__ __launch_bounds__(256, (NV <= 3 ? 4 : 1)) void layernorm_bwd_kernel(const void* __restrict__ x, int xkind, const void* __restrict__ dy,
                                                             int dykind, const float* __restrict__ g, float* __restrict__ dx,
                                                             int accumulate, int M, int d, float* __restrict__ pg,
                                                             float* __restrict__ pb, const int32_t* __restrict__ row_index,
