@@ -94,7 +94,8 @@ def mith_step(dev, B=256, K=64, C=80, bank=10000):
         with torch.no_grad():
             od = model(txt, kpm)            # codes as the trainer's evaluation forms them (train/MITH/hash_train.py:127-131)
             return N.sign_codes(od['img_tokens_hash'] + od['img_cls_hash']), N.sign_codes(od['txt_tokens_hash'] + od['txt_cls_hash'])
-    for L in (32, 77):
+    only = os.environ.get("CMH_LEG_TOKENS")            # (tools/leg_trace.sh: a kernel trace of ONE caption length's forward)
+    for L in ((int(only),) if only else (32, 77)):
         txt = torch.from_numpy(recipe.captions(B, L, 49408, 1)).to(dev)
         kpm = txt == 0
         for _ in range(2):
