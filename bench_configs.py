@@ -79,6 +79,7 @@ def mith_step(dev, B=256, K=64, C=80, bank=10000):
     from train.MITH.hash_train import MITHTrainer
     torch.manual_seed(0)
     clip = build_model(_vitb32_state(1)).to(dev).float().set_gemm_dtype("bf16")
+    clip.padded_tokens_unused = True           # as model/MITH.py::MITH sets it: HashingModel is the only reader of the text tokens
     hm = HashingModel(clip_embed_dim=512, args=SimpleNamespace(output_dim=K, **mu.ARGS)).to(dev).eval().set_gemm_dtype("bf16")
     img = torch.randn(B, 3, 224, 224, device=dev)
     out = {"batch": B, "bits": K, "what": "configs[2] MITH coco 64 bit: ViT-B/32 trunk returning every token + HashingModel (bf16 GEMMs)"}

@@ -107,6 +107,7 @@ SIGNATURES = {
     "cmh_set_gemm_grouped": (C.c_int, [_i32]),
     "cmh_set_gemm_lc": (C.c_int, [_i32]),
     "cmh_set_grad_stream16": (C.c_int, [_i32]),
+    "cmh_set_text_token_packing": (C.c_int, [_i32]),
     "cmh_linear_gemm_grouped": (C.c_int, [_i32, C.POINTER(GemmProblem), C.POINTER(GemmProblem), _i32, _p]),
     "cmh_clip_encode_pair": (C.c_int, [C.POINTER(VitWeights), _p, C.POINTER(TextWeights), _p, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p, _sz, _p]),
     "cmh_msl_workspace_bytes": (_sz, [_i32]),
@@ -149,6 +150,7 @@ SIGNATURES = {
     "cmh_dnph_loss": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _f, _f, _p, _p, _sz, _p]),
     "cmh_vit_encode_tokens": (C.c_int, [C.POINTER(VitWeights), _p, _i32, _p, _p, _sz, _p]),
     "cmh_text_encode_tokens": (C.c_int, [C.POINTER(TextWeights), _p, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
+    "cmh_text_encode_tokens_packed": (C.c_int, [C.POINTER(TextWeights), _p, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
     "cmh_blocks_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "cmh_transformer_blocks": (C.c_int, [C.POINTER(BlockWeights), _i32, _i32, _p, _i32, _i32, _i32, _i32, _p, _p, _sz, _p]),
     "cmh_mith_lta": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
@@ -181,6 +183,7 @@ SIGNATURES = {
     "cmh_vit_forward_train_tokens": (C.c_int, [C.POINTER(VitWeights), _p, _i32, _p, _p, _sz, _p]),
     "cmh_vit_backward_tokens": (C.c_int, [C.POINTER(VitWeights), _i32, _p, C.POINTER(VitGrads), _p, _sz, _p]),
     "cmh_text_forward_train_tokens": (C.c_int, [C.POINTER(TextWeights), _p, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
+    "cmh_text_forward_train_tokens_packed": (C.c_int, [C.POINTER(TextWeights), _p, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
     "cmh_text_backward_tokens": (C.c_int, [C.POINTER(TextWeights), _p, _i32, _i32, _p, _p, C.POINTER(TextGrads), _p, _sz, _p]),
     "cmh_blocks_train_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
     "cmh_blocks_forward_train": (C.c_int, [C.POINTER(BlockWeights), _i32, _i32, _p, _p, _i32, _i32, _i32, _p, _sz, _p]),
@@ -408,6 +411,12 @@ def set_pooled_tail(on: bool):
 def set_gemm_rows(on: int = -1):
     """Few-row GEMMs (M <= 512) on 64 x 64 tiles (csrc/gemm_rows.hip): 1 on (default), 0 = the wide kernel takes them, -1 = environment."""
     check(lib().cmh_set_gemm_rows(int(on)), "cmh_set_gemm_rows")
+
+
+def set_text_token_packing(on: int):
+    """the all-token text trunk (MITH) skips the positions behind a caption's last unpadded token (1, the default); 0: computes every
+    position; -1 = CMH_TEXT_PACK_TOKENS"""
+    check(lib().cmh_set_text_token_packing(int(on)), "cmh_set_text_token_packing")
 
 
 def set_grad_stream16(on: int):

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64) void attention_kernel(const T* __restrict__ qkv
       }
       const int kg = k0 + j;
       bool ok = kg < Tn && (!causal || kg <= row);
-      if (kpm && kg < Tn) ok = ok && (kpm[srow + kg] == 0);
+      if (kpm && kg < Tn) ok = ok && (kpm[static_cast<size_t>(b) * Tmax + kg] == 0);
       s[j] = ok ? (a0 + a1) + (a2 + a3) : -1e30f;
       tmax = fmaxf(tmax, s[j]);
     }
@@ -243,7 +243,7 @@ __device__ __forceinline__ void attention_mfma_body(const bf16_t* __restrict__ q
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = kt * 16 + 4 * g + r;
-        kb[kt][r] = kpm[srow + (key < Tn ? key : Tn - 1)];
+        kb[kt][r] = kpm[static_cast<size_t>(b) * Tmax + (key < Tn ? key : Tn - 1)];      // the mask is [B, Tmax] whatever the row layout (packed rows: seq_off)
       }
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)

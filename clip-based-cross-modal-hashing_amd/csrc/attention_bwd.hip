@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const T* __restrict_
 #pragma unroll 16
     for (int c = 0; c < HDB; ++c) acc += bufA[i * 65 + c] * bufB[j * 65 + c];
     bool ok = !(causal && j > i);
-    if (ok && kpm) ok = kpm[rowq + j] == 0;
+    if (ok && kpm) ok = kpm[static_cast<size_t>(b) * Tmax + j] == 0;
     S[i * ST + j] = ok ? acc * 0.125f : -1e30f;
   }
   __syncthreads();
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(NT <= 4 ? 256 : 512) void attention_bwd_mfma_kernel
     for (int tj = 0; tj < NT; ++tj) {
       const int key = tj * 16 + c;
       bool kok = key < Tn;
-      if (kok && kpm) kok = kpm[row0 + key] == 0;
+      if (kok && kpm) kok = kpm[static_cast<size_t>(b) * Tmax + key] == 0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int q = ti * 16 + 4 * g + r;

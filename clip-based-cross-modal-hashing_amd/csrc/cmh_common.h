@@ -174,9 +174,17 @@ int launch_vit_assemble_lnpre(const float* patch_out, const float* cls, const fl
 int launch_text_embed(const int64_t* tokens, const float* tok_emb, const float* pos, void* x, int x_f16,
                       int32_t* eot_row, int B, int L, int d, int vocab, hipStream_t st);
 // packed text rows (tokens up to the EOT only): offsets plan and the embedding into packed rows
-int launch_text_pack_plan(const int64_t* tokens, int B, int L, int32_t* seq_off, hipStream_t st);
+// (kpm + eot_pos: the all-token form - rows up to the last unpadded position, the EOT's position into eot_pos; launch_text_embed_packed
+// with eot_is_pos then turns eot_row[b] from that position into the packed row)
+int launch_text_pack_plan(const int64_t* tokens, int B, int L, int32_t* seq_off, hipStream_t st, const uint8_t* kpm = nullptr,
+                          int32_t* eot_pos = nullptr);
 int launch_text_embed_packed(const int64_t* tokens, const float* tok_emb, const float* pos, void* x, int x_f16, int32_t* eot_row,
-                             int B, int L, int d, int vocab, const int32_t* seq_off, hipStream_t st);
+                             int B, int L, int d, int vocab, const int32_t* seq_off, hipStream_t st, bool eot_is_pos = false);
+bool text_token_packing();      // CMH_TEXT_PACK_TOKENS / cmh_set_text_token_packing (encoders.hip)
+// packed f32 rows <-> the dense [B, L, E] layout (zeros behind each caption's kept rows); EOT rows as dense indices
+int launch_unpack_token_rows(const float* packed, const int32_t* seq_off, float* dense, int B, int L, int E, const int32_t* eot_packed,
+                             int32_t* eot_dense, hipStream_t st);
+int launch_pack_token_rows(const float* dense, const int32_t* seq_off, float* packed, int B, int L, int E, hipStream_t st);
 // cls_row[b] = b*T
 int launch_iota_rows(int32_t* rows, int B, int T, hipStream_t st);
 int launch_scatter_rows(const void* src, const int32_t* rows, void* dst, int B, int row_bytes, hipStream_t st);

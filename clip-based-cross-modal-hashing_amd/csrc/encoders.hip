@@ -145,6 +145,13 @@ bool pooled_tail_enabled() {
   return g_pooled_tail < 0 ? env_on : g_pooled_tail != 0;
 }
 
+// CMH_TEXT_PACK_TOKENS=0 / cmh_set_text_token_packing(0): the all-token text trunk computes every position, as in rounds 1-4
+static int g_pack_tokens = -1;
+bool text_token_packing() {
+  static const bool env_on = []() { const char* e = getenv("CMH_TEXT_PACK_TOKENS"); return !(e && !strcmp(e, "0")); }();
+  return g_pack_tokens < 0 ? env_on : g_pack_tokens != 0;
+}
+
 static int run_block_pooled(const cmh_block_weights& w, int dtb, const TowerBufs& t, int B, int T, int d, int causal,
                             const uint8_t* kpm, hipStream_t st, int M, const int32_t* seq_off, void** x_pooled,
                             const int32_t* md = nullptr, int mh = -1,
@@ -201,6 +208,7 @@ struct TowerRun {
   const int32_t* seq_off = nullptr;                      // packed text: per-caption row offsets
   const int32_t* md = nullptr;                           // packed text: the row count on the device
   int mh = -1;                                           // ... and its likely value (tile heights only)
+  bool packed_tokens = false;                            // packed text, every kept row is an output (the MITH trunk)
 };
 
 static GemmProblem problem_of(const TowerRun& r, const void* A, const void* W, const float* bias, const void* residual, void* out, int N,
@@ -331,6 +339,11 @@ using namespace cmh;
 
 extern "C" const char* cmh_last_error(void) { return err_buf(); }
 extern "C" int cmh_set_pooled_tail(int32_t on) { g_pooled_tail = on ? 1 : 0; return CMH_OK; }
+extern "C" int cmh_set_text_token_packing(int32_t on) {
+  CMH_CHECK_ARG(on >= -1 && on <= 1, "set_text_token_packing: %d (-1 environment, 0 off, 1 on)", on);
+  g_pack_tokens = on;
+  return CMH_OK;
+}
 extern "C" int cmh_version(void) { return CMH_VERSION; }
 
 extern "C" size_t cmh_vit_workspace_bytes(const cmh_vit_weights* w, int32_t batch) {
@@ -442,7 +455,7 @@ extern "C" size_t cmh_text_workspace_bytes(const cmh_text_weights* w, int32_t ba
 // validation + everything before the first block: the pack plan (packed mode), token + positional embedding, the EOT rows
 static int text_begin(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len, const uint8_t* key_padding_mask,
                       bool want_out, bool tokens_wanted, void* workspace, size_t workspace_bytes, const cmh_taps* taps, hipStream_t st,
-                      int32_t* packed_rows_out, float* amax, TowerRun& r) {
+                      int32_t* packed_rows_out, float* amax, TowerRun& r, bool pack_tokens_req = false) {
   CMH_CHECK_ARG(w && tokens && want_out && workspace, "text_encode: null pointer");
   CMH_CHECK_ARG(batch > 0 && seq_len > 0, "text_encode: batch %d seq_len %d", batch, seq_len);
   int rc = check_tower(w->gemm_dtype, w->width, w->layers, w->embed_dim, w->blocks);
@@ -467,9 +480,19 @@ static int text_begin(const cmh_text_weights* w, const int64_t* tokens, int32_t 
   const int32_t* seq_off = nullptr;
   const int32_t* md = nullptr;      // device-side row count of the packed matrix (the kernels read it themselves)
   int rows = M, mh = -1;
+  // Round 5: the all-token trunk of MITH (model/MITH.py:120-144 returns every position; HashingModel gives the padded ones weight 0
+  // in LocalizedTokenAggregation, :349-376, and reads them nowhere else) is packed too: a caption's rows run to its last unpadded
+  // position, the projected tokens go back to their dense [B, L, E] places with zeros behind (text_finish).  Kept rows see the dense
+  // path's arithmetic (the mask is still applied to the keys inside the kept prefix): same bits there.
+  // (asked for per call - cmh_text_encode_tokens_packed: the caller promises not to read the padded positions - and only then)
+  const bool pack_tokens = pack_tokens_req && tokens_wanted && key_padding_mask && !packed_rows_out && !taps && !amax && text_token_packing() &&
+                           w->embed_dim % 128 == 0 && d % (dt == CMH_F32 ? 32 : 64) == 0 &&      // the packed projection is a GEMM launch
+                           static_cast<size_t>(w->embed_dim) * 4 <= static_cast<size_t>(4) * d * e;   // ... into the MLP scratch
+  if (pack_tokens) packed_rows_out = reinterpret_cast<int32_t*>(1);
+  r.packed_tokens = pack_tokens;
   if (packed_rows_out) {
-    CMH_CHECK_ARG(!key_padding_mask && !tokens_wanted && !taps, "text_encode_packed: pooled features only, no mask / taps");
-    if ((rc = launch_text_pack_plan(tokens, B, L, t.seq, st))) return rc;
+    CMH_CHECK_ARG(pack_tokens || (!key_padding_mask && !tokens_wanted && !taps), "text_encode_packed: pooled features only, no mask / taps");
+    if ((rc = launch_text_pack_plan(tokens, B, L, t.seq, st, pack_tokens ? key_padding_mask : nullptr, pack_tokens ? t.rows : nullptr))) return rc;
     seq_off = t.seq;
     if (amax || d % 256 != 0 || !gemm_wide_enabled()) {
       // the calibration pass reduces over whole buffers on the host's row count, and widths that are not a multiple of 256 (the
@@ -493,7 +516,8 @@ static int text_begin(const cmh_text_weights* w, const int64_t* tokens, int32_t 
 
   // token_embedding gather + positional_embedding[:L]; EOT row = argmax(tokens)  (model.py:360-362,370)
   r.dtb = dtb; r.d = d; r.B = B; r.T = L; r.M = rows; r.causal = 1; r.seq_off = seq_off; r.md = md; r.mh = mh;
-  return launch_text_embed_packed(tokens, w->token_embedding, w->positional_embedding, t.x, t.xh, t.rows, B, L, d, w->vocab_size, seq_off, st);
+  return launch_text_embed_packed(tokens, w->token_embedding, w->positional_embedding, t.x, t.xh, t.rows, B, L, d, w->vocab_size, seq_off, st,
+                                  pack_tokens);
 }
 
 // ln_final (+ text_projection) after the last block: on every token (MITH trunk) and / or on the EOT rows
@@ -502,12 +526,18 @@ static int text_finish(const cmh_text_weights* w, const TowerRun& r, void* x_poo
   const TowerBufs& t = r.t;
   const int dt = r.dtb == CMH_FP8 ? CMH_BF16 : r.dtb, d = r.d, B = r.B, M = r.B * r.T;
   int rc;
-  if (tokens_out) {
+  if (tokens_out && r.packed_tokens) {
+    // the kept rows only (device row count), then back to their dense places; the EOT rows leave as dense indices with them
+    float* tmp = static_cast<float*>(t.mlp);      // [rows, E] f32: the MLP scratch is free behind the last block (text_begin checked the sizes)
+    if ((rc = launch_layernorm_x(t.x, t.xh, nullptr, w->ln_final_w, w->ln_final_b, t.h, dt == CMH_BF16, r.M, d, st, r.md))) return rc;
+    if ((rc = launch_gemm(dt, t.h, w->text_projection_t, nullptr, nullptr, tmp, r.M, w->embed_dim, d, 0, st, r.md, r.mh))) return rc;
+    if ((rc = launch_unpack_token_rows(tmp, r.seq_off, tokens_out, B, r.T, w->embed_dim, t.rows, eot_rows_out, st))) return rc;
+  } else if (tokens_out) {
     // MITH trunk (model/MITH.py:136-139): ln_final and text_projection on EVERY token
     if ((rc = launch_layernorm_x(t.x, t.xh, nullptr, w->ln_final_w, w->ln_final_b, t.h, dt == CMH_BF16, M, d, st))) return rc;
     if ((rc = final_projection(dt, t.h, w->text_projection_t, tokens_out, M, w->embed_dim, d, st))) return rc;
   }
-  if (eot_rows_out &&
+  if (eot_rows_out && !(tokens_out && r.packed_tokens) &&
       hipMemcpyAsync(eot_rows_out, t.rows, static_cast<size_t>(B) * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
     return fail(CMH_ERR_LAUNCH, "text_encode: eot row copy failed");
   if (feat) {
@@ -522,11 +552,11 @@ static int text_finish(const cmh_text_weights* w, const TowerRun& r, void* x_poo
 static int text_encode_impl(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
                             const uint8_t* key_padding_mask, float* feat, float* tokens_out, int32_t* eot_rows_out,
                             void* workspace, size_t workspace_bytes, const cmh_taps* taps, void* stream,
-                            int32_t* packed_rows_out = nullptr, float* amax = nullptr) {
+                            int32_t* packed_rows_out = nullptr, float* amax = nullptr, bool pack_tokens_req = false) {
   hipStream_t st = as_stream(stream);
   TowerRun r;
   int rc = text_begin(w, tokens, batch, seq_len, key_padding_mask, feat || tokens_out, tokens_out != nullptr, workspace, workspace_bytes,
-                      taps, st, packed_rows_out, amax, r);
+                      taps, st, packed_rows_out, amax, r, pack_tokens_req);
   if (rc) return rc;
   const TowerBufs& t = r.t;
   const int dtb = r.dtb, d = r.d, B = r.B, L = r.T, M = B * L, rows = r.M, mh = r.mh;
@@ -638,6 +668,16 @@ extern "C" int cmh_text_encode_tokens(const cmh_text_weights* w, const int64_t* 
   CMH_CHECK_ARG(tokens_out, "text_encode_tokens: null pointer");
   return text_encode_impl(w, tokens, batch, seq_len, key_padding_mask, nullptr, tokens_out, eot_rows_out, workspace,
                           workspace_bytes, nullptr, stream);
+}
+
+// The same with the promise that nothing reads the padded positions of tokens_out (MITH: HashingModel masks them, model/MITH.py:349-376):
+// positions behind a caption's last unpadded token are not computed and come back as zeros (cmh_set_text_token_packing)
+extern "C" int cmh_text_encode_tokens_packed(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
+                                             const uint8_t* key_padding_mask, float* tokens_out, int32_t* eot_rows_out,
+                                             void* workspace, size_t workspace_bytes, void* stream) {
+  CMH_CHECK_ARG(tokens_out, "text_encode_tokens_packed: null pointer");
+  return text_encode_impl(w, tokens, batch, seq_len, key_padding_mask, nullptr, tokens_out, eot_rows_out, workspace,
+                          workspace_bytes, nullptr, stream, nullptr, nullptr, /*pack_tokens_req=*/true);
 }
 
 // A stack of ResidualAttentionBlocks on a caller-owned f32 residual stream x [B*T, d] (in place): the 2-layer

@@ -65,6 +65,7 @@ struct TrainBufs {
   void* tB;            // [rmax, Mpad] e   X^T
   void* wT;            // [max(12 d, rmax) * d] e   W^T of the block's four weight matrices (one launch), or of one head matrix
   void* tokE;          // [M, embed] e
+  float* tokP;         // [M, embed] f32   packed all-token head: projected rows before they go to their dense places / packed dtokens
   float* projT;        // [embed, d] f32
   float* small;        // [2*B*max(d,E)] f32
   void* red;           // reduction workspace
@@ -113,6 +114,7 @@ TrainBufs carve_train(void* ws, size_t M, size_t B, size_t d, size_t e, size_t x
   t.tB = a.take(t.tAB_bytes);
   t.wT = a.take((12 * d > rmax ? 12 * d : rmax) * d * e);   // the four W^T of a block side by side (12 d^2), or one head matrix
   t.tokE = a.take(M * embed * e);                           // all-token head: dtokens as a GEMM operand
+  t.tokP = a.take<float>(g2rows ? 0 : M * embed * 4);       // text only
   t.projT = a.take<float>(embed * d * 4);                   //                 d(proj^T) [embed, d] before its transpose
   const size_t wide = d > embed ? d : embed;
   t.small = a.take<float>(2 * B * wide * 4);
@@ -749,6 +751,10 @@ void remember_tape_rows(const void* tape, int rows) {
   if (g_tape_rows.size() > 64) g_tape_rows.clear();      // tapes of long-gone steps
   g_tape_rows[tape] = rows;
 }
+void forget_tape_rows(const void* tape) {
+  std::lock_guard<std::mutex> lk(g_tape_rows_mu);
+  g_tape_rows.erase(tape);
+}
 int recall_tape_rows(const void* tape) {
   std::lock_guard<std::mutex> lk(g_tape_rows_mu);
   const auto it = g_tape_rows.find(tape);
@@ -764,7 +770,7 @@ extern "C" size_t cmh_text_train_bytes(const cmh_text_weights* w, int32_t batch,
 
 static int text_forward_train_impl(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
                                    const uint8_t* key_padding_mask, float* feat, float* tokens_out, int32_t* eot_rows_out, void* tape,
-                                   size_t tape_bytes, void* stream) {
+                                   size_t tape_bytes, void* stream, bool pack_tokens_req = false) {
   CMH_CHECK_ARG(w && tokens && (feat || tokens_out) && tape && batch > 0 && seq_len > 0, "text_forward_train: bad arguments");
   int rc = check_train_tower(w->gemm_dtype, w->width, w->layers, w->embed_dim, w->blocks);
   if (rc) return rc;
@@ -779,8 +785,13 @@ static int text_forward_train_impl(const cmh_text_weights* w, const int64_t* tok
   // packed like encode_text (encoders.hip): only the tokens 0..EOT of every caption are run through the blocks
   const int32_t* seq_off = nullptr;
   int rows = M;
-  if (!tokens_out && text_packing(key_padding_mask)) {      // every token is an output of the MITH trunk: nothing to skip there
-    if ((rc = launch_text_pack_plan(tokens, B, L, t.seq_off, st))) return rc;
+  // the all-token trunk (MITH): packed only on the caller's word that the padded positions of tokens_out are read by nobody
+  // (cmh_text_forward_train_tokens_packed; encoders.hip text_begin has the reasoning) - their gradient is then exactly zero as well
+  const int bk0 = dt == CMH_F32 ? 32 : 64;
+  const bool pack_tokens = tokens_out && pack_tokens_req && key_padding_mask && text_token_packing() && w->embed_dim % 128 == 0 && d % bk0 == 0;
+  if (tokens_out && !pack_tokens) forget_tape_rows(tape);
+  if ((!tokens_out && text_packing(key_padding_mask)) || pack_tokens) {
+    if ((rc = launch_text_pack_plan(tokens, B, L, t.seq_off, st, pack_tokens ? key_padding_mask : nullptr, pack_tokens ? t.rows : nullptr))) return rc;
     int32_t total = 0;
     if (hipMemcpyAsync(&total, t.seq_off + B, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
       return fail(CMH_ERR_LAUNCH, "text_forward_train: reading the packed row count failed");
@@ -790,13 +801,17 @@ static int text_forward_train_impl(const cmh_text_weights* w, const int64_t* tok
     remember_tape_rows(tape, rows);
   }
   if ((rc = launch_text_embed_packed(tokens, w->token_embedding, w->positional_embedding, t.L[0].x_in, xh, t.rows, B, L, d,
-                                     w->vocab_size, seq_off, st))) return rc;
+                                     w->vocab_size, seq_off, st, pack_tokens))) return rc;
   // (the gathered attention rows are parked behind the first B rows of the h2 slot: the pooled tail needs 2 B rows of tape there)
   const bool tail = !tokens_out && train_pooled_tail() && rows >= 2 * B;      // the same rule in text_backward_impl
   for (int i = 0; i < w->layers; ++i) {
     void* nxt = i + 1 < w->layers ? t.L[i + 1].x_in : t.x_last;
     if ((rc = block_forward_train(w->blocks[i], dt, xh, t.L[i], nxt, B, L, d, 1, key_padding_mask, st, rows, seq_off,
                                   tail && i == w->layers - 1 ? t.rows : nullptr))) return rc;
+  }
+  if (tokens_out && pack_tokens) {
+    if ((rc = tokens_head_forward(dt, xh, t, w->ln_final_w, w->ln_final_b, w->text_projection_t, t.tokP, rows, d, w->embed_dim, st))) return rc;
+    return launch_unpack_token_rows(t.tokP, t.seq_off, tokens_out, B, L, w->embed_dim, t.rows, eot_rows_out, st);
   }
   if (tokens_out) {
     if (eot_rows_out && hipMemcpyAsync(eot_rows_out, t.rows, static_cast<size_t>(B) * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
@@ -822,6 +837,14 @@ extern "C" int cmh_text_forward_train_tokens(const cmh_text_weights* w, const in
                                              size_t tape_bytes, void* stream) {
   CMH_CHECK_ARG(tokens_out, "text_forward_train_tokens: null output pointer");
   return text_forward_train_impl(w, tokens, batch, seq_len, key_padding_mask, nullptr, tokens_out, eot_rows_out, tape, tape_bytes, stream);
+}
+
+extern "C" int cmh_text_forward_train_tokens_packed(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
+                                                    const uint8_t* key_padding_mask, float* tokens_out, int32_t* eot_rows_out, void* tape,
+                                                    size_t tape_bytes, void* stream) {
+  CMH_CHECK_ARG(tokens_out, "text_forward_train_tokens_packed: null output pointer");
+  return text_forward_train_impl(w, tokens, batch, seq_len, key_padding_mask, nullptr, tokens_out, eot_rows_out, tape, tape_bytes, stream,
+                                 /*pack_tokens_req=*/true);
 }
 
 static int text_backward_impl(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
@@ -853,12 +876,21 @@ static int text_backward_impl(const cmh_text_weights* w, const int64_t* tokens, 
     seq_off = t.seq_off;
     rows = total;
   }
+  if (dtokens) {       // a tape that cmh_text_forward_train_tokens_packed filled holds a packed plan: the forward call remembered its row count
+    const int32_t total = recall_tape_rows(tape);
+    if (total > 0 && total <= M) { seq_off = t.seq_off; rows = total; }
+  }
   const bool tail = !dtokens && train_pooled_tail() && rows >= 2 * B;
   if (layer_hi == w->layers) {
     if ((rc = zero_pad_buffers(t, static_cast<size_t>(rows), st))) return rc;
     if (dtokens) {
-      if ((rc = tokens_head_backward(dt, xh, t, w->ln_final_w, w->ln_final_b, w->text_projection_t, dtokens, gr->text_projection,
-                                     gr->ln_final_w, gr->ln_final_b, M, d, E, st))) return rc;
+      const float* dtok = dtokens;
+      if (seq_off) {   // the kept rows of the dense [B, L, E] gradient (the padded rows' gradient is zero by the caller's promise)
+        if ((rc = launch_pack_token_rows(dtokens, seq_off, t.tokP, B, L, E, st))) return rc;
+        dtok = t.tokP;
+      }
+      if ((rc = tokens_head_backward(dt, xh, t, w->ln_final_w, w->ln_final_b, w->text_projection_t, dtok, gr->text_projection,
+                                     gr->ln_final_w, gr->ln_final_b, rows, d, E, st))) return rc;
     } else if ((rc = pooled_backward(dt, xh, t.x_last, t.rows, t.pool, w->text_projection_t, w->ln_final_w, dfeat, gr->text_projection,
                                      gr->ln_final_w, gr->ln_final_b, t, B, rows, d, E, st, tail))) return rc;
   }

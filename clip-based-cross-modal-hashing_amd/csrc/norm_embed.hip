@@ -347,14 +347,16 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int64_t* __restri
                                                          const float* __restrict__ tok_emb,
                                                          const float* __restrict__ pos, void* __restrict__ x,
                                                          int x_f16, int32_t* __restrict__ eot_row, int B, int L, int d,
-                                                         int vocab, const int32_t* __restrict__ seq_off) {
+                                                         int vocab, const int32_t* __restrict__ seq_off, int eot_is_pos) {
   const int lane = threadIdx.x & 63;
   int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= B * L) return;
   const int b = row / L, t = row - b * L;
   if (seq_off) {                           // packed: only the tokens up to the EOT exist, sequence b = rows [seq_off[b], seq_off[b+1])
     if (t >= seq_off[b + 1] - seq_off[b]) return;
-    if (t == 0 && lane == 0) eot_row[b] = seq_off[b + 1] - 1;
+    // (eot_is_pos: the plan kept the rows up to the last unpadded position and left the EOT's POSITION in eot_row[b]; one thread per
+    // caption turns it into the packed row)
+    if (t == 0 && lane == 0) eot_row[b] = eot_is_pos ? seq_off[b] + eot_row[b] : seq_off[b + 1] - 1;
   }
   const int orow = seq_off ? seq_off[b] + t : row;
   int64_t id = tokens[row];
@@ -391,8 +393,12 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int64_t* __restri
 // seq_off[b] = sum_{b' < b} (argmax(tokens[b']) + 1): the packed row offsets of encode_text without padding.  One workgroup of
 // 16 waves: a wave takes whole captions (coalesced row reads, first-maximum argmax by a butterfly on (value, index)), then wave 0
 // turns the lengths into offsets with 64-wide prefix scans.  (Round 1's one-thread-per-caption loop took 37 us at B = 256.)
+// kpm / eot_pos (the all-token trunk of MITH, model/MITH.py:120-144): the kept rows of caption b run to its LAST UNPADDED position
+// (or its EOT, whichever is later) - everything behind is masked as a key, never read as a query's output (LocalizedTokenAggregation
+// gives padded positions weight 0, model/MITH.py:349-376) - and the EOT's position goes to eot_pos[b].
 __global__ __launch_bounds__(256) void text_pack_plan_kernel(const int64_t* __restrict__ tokens, int B, int L,
-                                                             int32_t* __restrict__ seq_off) {
+                                                             int32_t* __restrict__ seq_off, const uint8_t* __restrict__ kpm,
+                                                             int32_t* __restrict__ eot_pos) {
   // One THREAD per caption: a running (max, first index) over its tokens - no cross-lane traffic at all.
   // Then an inclusive scan of the lengths over the workgroup, 256 captions per pass.
   __shared__ int wsum[4];
@@ -416,6 +422,20 @@ __global__ __launch_bounds__(256) void text_pack_plan_kernel(const int64_t* __re
           if (v[u] > best) { best = v[u]; besti = i0 + u; }      // strict >: the first maximum, like torch.argmax
       }
       len = besti + 1;
+      if (kpm) {
+        const uint8_t* mrow = kpm + static_cast<size_t>(b) * L;
+        int last = -1;
+        for (int i0 = 0; i0 < L; i0 += 16) {
+          uint8_t m[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) m[u] = i0 + u < L ? mrow[i0 + u] : 1;
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+            if (!m[u]) last = i0 + u;
+        }
+        len = last + 1 > len ? last + 1 : len;
+      }
+      if (eot_pos) eot_pos[b] = besti;
     }
     int v = len;
 #pragma unroll
@@ -435,8 +455,8 @@ __global__ __launch_bounds__(256) void text_pack_plan_kernel(const int64_t* __re
   if (tid == 0) seq_off[0] = 0;
 }
 
-int launch_text_pack_plan(const int64_t* tokens, int B, int L, int32_t* seq_off, hipStream_t st) {
-  hipLaunchKernelGGL(text_pack_plan_kernel, dim3(1), dim3(256), 0, st, tokens, B, L, seq_off);
+int launch_text_pack_plan(const int64_t* tokens, int B, int L, int32_t* seq_off, hipStream_t st, const uint8_t* kpm, int32_t* eot_pos) {
+  hipLaunchKernelGGL(text_pack_plan_kernel, dim3(1), dim3(256), 0, st, tokens, B, L, seq_off, kpm, eot_pos);
   CMH_CHECK_LAUNCH("text_pack_plan");
   return CMH_OK;
 }
@@ -447,12 +467,59 @@ int launch_text_embed(const int64_t* tokens, const float* tok_emb, const float* 
 }
 
 int launch_text_embed_packed(const int64_t* tokens, const float* tok_emb, const float* pos, void* x, int x_f16, int32_t* eot_row,
-                             int B, int L, int d, int vocab, const int32_t* seq_off, hipStream_t st) {
+                             int B, int L, int d, int vocab, const int32_t* seq_off, hipStream_t st, bool eot_is_pos) {
   CMH_CHECK_ARG(d % 4 == 0, "text_embed: width %d unsupported", d);
   const int rows = B * L;
   hipLaunchKernelGGL(text_embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, tokens, tok_emb, pos, x, x_f16,
-                     eot_row, B, L, d, vocab, seq_off);
+                     eot_row, B, L, d, vocab, seq_off, eot_is_pos ? 1 : 0);
   CMH_CHECK_LAUNCH("text_embed");
+  return CMH_OK;
+}
+
+// dense[b, t, :] = t < len_b ? packed[seq_off[b] + t, :] : 0  (f32 rows of E floats, E % 4 == 0); eot_dense[b] = b L + (eot_packed[b] - seq_off[b]).
+// One pass writes every byte of `dense`: no memset in front.
+__global__ __launch_bounds__(256) void unpack_token_rows_kernel(const float* __restrict__ packed, const int32_t* __restrict__ seq_off,
+                                                                float* __restrict__ dense, int B, int L, int E,
+                                                                const int32_t* __restrict__ eot_packed, int32_t* __restrict__ eot_dense) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B * L) return;
+  const int b = row / L, t = row - b * L;
+  const int s0 = seq_off[b], len = seq_off[b + 1] - s0;
+  if (t == 0 && lane == 0 && eot_dense) eot_dense[b] = b * L + (eot_packed[b] - s0);
+  float4* o = reinterpret_cast<float4*>(dense + static_cast<size_t>(row) * E);
+  if (t < len) {
+    const float4* p = reinterpret_cast<const float4*>(packed + static_cast<size_t>(s0 + t) * E);
+    for (int i = lane; i < E / 4; i += 64) o[i] = p[i];
+  } else {
+    for (int i = lane; i < E / 4; i += 64) o[i] = float4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+int launch_unpack_token_rows(const float* packed, const int32_t* seq_off, float* dense, int B, int L, int E, const int32_t* eot_packed,
+                             int32_t* eot_dense, hipStream_t st) {
+  CMH_CHECK_ARG(E % 4 == 0, "unpack_token_rows: E %d", E);
+  hipLaunchKernelGGL(unpack_token_rows_kernel, dim3((B * L + 3) / 4), dim3(256), 0, st, packed, seq_off, dense, B, L, E, eot_packed, eot_dense);
+  CMH_CHECK_LAUNCH("unpack_token_rows");
+  return CMH_OK;
+}
+
+// packed[seq_off[b] + t, :] = dense[b, t, :] for the kept rows (the gradient of the all-token head on its way into the packed backward)
+__global__ __launch_bounds__(256) void pack_token_rows_kernel(const float* __restrict__ dense, const int32_t* __restrict__ seq_off,
+                                                              float* __restrict__ packed, int B, int L, int E) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B * L) return;
+  const int b = row / L, t = row - b * L;
+  const int s0 = seq_off[b], len = seq_off[b + 1] - s0;
+  if (t >= len) return;
+  const float4* p = reinterpret_cast<const float4*>(dense + static_cast<size_t>(row) * E);
+  float4* o = reinterpret_cast<float4*>(packed + static_cast<size_t>(s0 + t) * E);
+  for (int i = lane; i < E / 4; i += 64) o[i] = p[i];
+}
+
+int launch_pack_token_rows(const float* dense, const int32_t* seq_off, float* packed, int B, int L, int E, hipStream_t st) {
+  CMH_CHECK_ARG(E % 4 == 0, "pack_token_rows: E %d", E);
+  hipLaunchKernelGGL(pack_token_rows_kernel, dim3((B * L + 3) / 4), dim3(256), 0, st, dense, seq_off, packed, B, L, E);
+  CMH_CHECK_LAUNCH("pack_token_rows");
   return CMH_OK;
 }
 

@@ -61,7 +61,9 @@ def vit_encode_tokens(clip, image):
     return out.view(B, T, s.embed_dim)
 
 
-def text_encode_tokens(clip, text, key_padding_mask):
+def text_encode_tokens(clip, text, key_padding_mask, padded_unused=False):
+    """padded_unused: the caller reads no padded position of the result (MITH: HashingModel masks them) - they are then not computed
+    and come back as zeros (cmh_text_encode_tokens_packed)"""
     N.require_gpu(text)
     text = text.to(torch.int64).contiguous()
     s = clip._text_struct()
@@ -70,8 +72,9 @@ def text_encode_tokens(clip, text, key_padding_mask):
     rows = torch.empty(B, dtype=torch.int32, device=text.device)
     kpm = None if key_padding_mask is None else key_padding_mask.to(torch.uint8).contiguous()
     ws = N.workspace(N.lib().cmh_text_workspace_bytes(C.byref(s), B, L), text.device, f"text@{N.stream_ptr(text.device)}")
-    N.check(N.lib().cmh_text_encode_tokens(C.byref(s), N.ptr(text), B, L, N.ptr(kpm), N.ptr(out), N.ptr(rows), N.ptr(ws),
-                                           ws.numel(), N.stream_ptr(text.device)), "cmh_text_encode_tokens")
+    fn = N.lib().cmh_text_encode_tokens_packed if padded_unused and kpm is not None else N.lib().cmh_text_encode_tokens
+    N.check(fn(C.byref(s), N.ptr(text), B, L, N.ptr(kpm), N.ptr(out), N.ptr(rows), N.ptr(ws), ws.numel(), N.stream_ptr(text.device)),
+            "cmh_text_encode_tokens")
     return out.view(B, L, s.embed_dim), rows
 
 

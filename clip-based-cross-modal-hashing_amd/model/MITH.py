@@ -47,7 +47,8 @@ class CLIP1(CLIP):
             tok, rows = T.TextTrainTokens.apply(self, text, kpm, *params)
             tok = tok.view(text.shape[0], text.shape[1], -1)
         else:
-            tok, rows = M.text_encode_tokens(self, text, key_padding_mask)   # [B, L, E]
+            tok, rows = M.text_encode_tokens(self, text, key_padding_mask,   # [B, L, E]
+                                             padded_unused=bool(getattr(self, "padded_tokens_unused", False)))
         B, L, E = tok.shape
         new_kpm = key_padding_mask + (text == 49407)                 # model/MITH.py:134 (bool OR)
         eos = tok.reshape(B * L, E)[rows.long()]
@@ -304,6 +305,9 @@ class MITH(nn.Module):
         self.args = args
         self.clip = load_download_clip(self.args.clip_path)
         self.hash = HashingModel(clip_embed_dim=512, args=args)
+        # HashingModel is the only reader of the text tokens and LocalizedTokenAggregation gives padded positions weight 0
+        # (reference model/MITH.py:349-376): the trunk does not compute them (cmh_text_encode_tokens_packed; zeros come back)
+        self.clip.padded_tokens_unused = True
 
     def forward(self, image, text, key_padding_mask):
         (img_tokens, _, img_cls), (txt_tokens, _, new_key_padding_mask, txt_eos) = overlapped(

@@ -194,8 +194,11 @@ class TextTrainTokens(torch.autograd.Function):
         tok = torch.empty(B * L, s.embed_dim, dtype=torch.float32, device=text.device)
         rows = torch.empty(B, dtype=torch.int32, device=text.device)
         tape = torch.empty(N.lib().cmh_text_train_bytes(C.byref(s), B, L), dtype=torch.uint8, device=text.device)
-        N.check(N.lib().cmh_text_forward_train_tokens(C.byref(s), N.ptr(text), B, L, N.ptr(kpm), N.ptr(tok), N.ptr(rows), N.ptr(tape),
-                                                      tape.numel(), N.stream_ptr(text.device)), "cmh_text_forward_train_tokens")
+        # (padded_tokens_unused, set by MITH: nobody reads the padded positions - they are neither computed nor differentiated)
+        packed = bool(getattr(clip, "padded_tokens_unused", False)) and kpm is not None
+        fn = N.lib().cmh_text_forward_train_tokens_packed if packed else N.lib().cmh_text_forward_train_tokens
+        N.check(fn(C.byref(s), N.ptr(text), B, L, N.ptr(kpm), N.ptr(tok), N.ptr(rows), N.ptr(tape), tape.numel(), N.stream_ptr(text.device)),
+                "cmh_text_forward_train_tokens")
         ctx.tape, ctx.struct, ctx.text, ctx.kpm, ctx.params = tape, s, text, kpm, params
         ctx.mark_non_differentiable(rows)
         return tok, rows

@@ -259,6 +259,14 @@ int cmh_set_pooled_tail(int32_t on);
  * environment (default on).  The f32 mode never uses it.  Process-wide, not thread-safe. */
 int cmh_set_grad_stream16(int32_t on);
 
+/* cmh_text_encode_tokens / cmh_text_forward_train_tokens with a key_padding_mask (the MITH trunk, model/MITH.py:120-144): positions
+ * behind a caption's last unpadded token are never read by the reference's HashingModel (LocalizedTokenAggregation gives them weight
+ * 0, model/MITH.py:349-376), so only the rows up to that position run through the tower; the projected tokens are written back to
+ * their dense [B, L, E] places with ZEROS in the padded positions (the reference computes finite values there that nothing reads), the
+ * EOT rows are dense indices as before.  Kept positions: the same bits as the dense path.  on = 0: every position is computed
+ * (also CMH_TEXT_PACK_TOKENS=0); -1: the environment (default on).  Process-wide, not thread-safe. */
+int cmh_set_text_token_packing(int32_t on);
+
 /* ---------------------------------------------------------------------------------------------
  * fp8 encoder mode (CMH_FP8).  Mirrors the reference's precision hook convert_weights (model/base/model.py:391-412): the same
  * tensors it lowers to fp16 - Linear / MultiheadAttention weights - go to e4m3 here, with the activations that feed them.
@@ -474,6 +482,12 @@ int cmh_vit_encode_tokens(const cmh_vit_weights* w, const float* image, int32_t 
 int cmh_text_encode_tokens(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
                            const uint8_t* key_padding_mask, float* tokens_out, int32_t* eot_rows_out,
                            void* workspace, size_t workspace_bytes, void* stream);
+/* The same, with the caller's promise that nothing reads the padded positions of tokens_out - MITH's HashingModel gives them weight 0
+ * (model/MITH.py:349-376): rows behind a caption's last unpadded token are not computed and come back as ZEROS; every other position
+ * carries the bits of cmh_text_encode_tokens.  key_padding_mask NULL, or cmh_set_text_token_packing(0): exactly cmh_text_encode_tokens. */
+int cmh_text_encode_tokens_packed(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
+                                  const uint8_t* key_padding_mask, float* tokens_out, int32_t* eot_rows_out,
+                                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* `layers` ResidualAttentionBlocks applied in place to a caller-owned residual stream x f32 [B*T, d]
  * (MITH's 2-layer concept transformer, model/MITH.py:385-395). */
@@ -684,6 +698,12 @@ int cmh_text_backward_part(const cmh_text_weights* w, const int64_t* tokens, int
 int cmh_text_forward_train_tokens(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
                                   const uint8_t* key_padding_mask, float* tokens_out, int32_t* eot_rows_out, void* tape,
                                   size_t tape_bytes, void* stream);
+/* cmh_text_forward_train_tokens with the promise of cmh_text_encode_tokens_packed (then the padded positions' gradient is zero too):
+ * tape and backward run on the kept rows; cmh_text_backward_tokens on this tape takes the dense [B*L, embed_dim] gradient as before
+ * and ignores its padded rows. */
+int cmh_text_forward_train_tokens_packed(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
+                                         const uint8_t* key_padding_mask, float* tokens_out, int32_t* eot_rows_out, void* tape,
+                                         size_t tape_bytes, void* stream);
 int cmh_text_backward_tokens(const cmh_text_weights* w, const int64_t* tokens, int32_t batch, int32_t seq_len,
                              const uint8_t* key_padding_mask, const float* dtokens, const cmh_text_grads* grads, void* tape,
                              size_t tape_bytes, void* stream);

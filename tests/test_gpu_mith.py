@@ -36,6 +36,96 @@ def test_trunk_returns_all_tokens(golden):
     np.testing.assert_allclose(eos.cpu().numpy(), g["trunk_eos_t"], **tol)
 
 
+def _ragged_text(B, L, vocab, seed):
+    """captions with their EOT anywhere, zeros behind it, and - the reference's quirk - one '!' (token id 0, which `text == 0` masks
+    like padding) INSIDE a caption's prefix"""
+    text = recipe.captions(B, L, vocab, seed).copy()
+    eot = text.argmax(1)
+    b = int(np.argmax(eot))            # the longest caption gets the inner zero
+    if eot[b] >= 3:
+        text[b, 2] = 0
+    return text
+
+
+_PACK_CFGS = {"w128": (dict(mu.CLIP_TINY512), 16),                  # width 128: the GEMMs take their row count from the host (one read-back)
+              "w256": (dict(mu.CLIP_TINY512, context_length=24, transformer_width=256, transformer_heads=4), 24)}   # device-side row count, fp16 stream in bf16 mode
+
+
+@pytest.mark.parametrize("cfgname", ["w128", "w256"])
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_token_packing_keeps_the_bits_of_every_position_somebody_reads(mode, cfgname):
+    """cmh_text_encode_tokens_packed (round 5; what MITH.forward runs): rows behind a caption's last unpadded token are not computed.
+    Against the dense call: every position up to there carries the same bits - the key-padding mask still applies to the keys inside
+    the kept prefix -, the positions behind are zeros, the EOT rows and features are the same, and HashingModel (the only reader,
+    reference model/MITH.py:349-376, 424-453) returns the same bits from either."""
+    import cmh_native as Nn
+    import mith_ops as M
+    from model.MITH import HashingModel, build_model
+    (cfg, L), seed, B = _PACK_CFGS[cfgname], 7, 6
+    clip = build_model({k: torch.from_numpy(v) for k, v in recipe.clip_state_dict(cfg, seed).items()}).to(DEV).float().set_gemm_dtype(mode)
+    text_np = _ragged_text(B, L, cfg["vocab_size"], seed)
+    text, kpm = tt(text_np), tt(text_np == 0)
+    with torch.no_grad():
+        dense, rows_d = M.text_encode_tokens(clip, text, kpm)
+        packed, rows_p = M.text_encode_tokens(clip, text, kpm, padded_unused=True)
+        try:
+            Nn.set_text_token_packing(0)
+            off, rows_o = M.text_encode_tokens(clip, text, kpm, padded_unused=True)      # the switch: exactly the dense call
+        finally:
+            Nn.set_text_token_packing(-1)
+    assert torch.equal(rows_d, rows_p) and torch.equal(off, dense) and torch.equal(rows_o, rows_d)
+    last = np.array([np.flatnonzero(r != 0).max() for r in text_np])
+    keep = torch.from_numpy(np.arange(L)[None, :] <= np.maximum(last, text_np.argmax(1))[:, None]).to(DEV)
+    assert 0 < int((~keep).sum()) < B * L                                     # something was skipped, something kept
+    assert torch.equal(packed[keep], dense[keep])
+    # (the packed projection lands in the tower's MLP scratch: 4 d e bytes per row must hold embed_dim f32 - every real tower's do, the
+    # 128-wide test tower's bf16 scratch does not, and that call stays dense)
+    packs = 512 * 4 <= 4 * cfg["transformer_width"] * (2 if mode == "bf16" else 4)
+    assert (float(packed[~keep].abs().max()) == 0.0) == packs
+    hm = HashingModel(clip_embed_dim=512, args=SimpleNamespace(output_dim=16, **mu.ARGS)).to(DEV).eval().set_gemm_dtype(mode)
+    img_tokens, img_cls = torch.randn(9, B, 512, device=DEV), torch.randn(B, 512, device=DEV)
+    new_kpm = kpm + (text == 49407)
+    with torch.no_grad():
+        outs = []
+        for tok, rows in ((dense, rows_d), (packed, rows_p)):
+            eos = tok.reshape(B * L, -1)[rows.long()]
+            outs.append(hm(img_tokens, tok.permute(1, 0, 2), img_cls, eos, new_kpm))
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+
+
+@pytest.mark.parametrize("cfgname", ["w128", "w256"])
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_token_packing_under_training_matches_the_dense_tape(mode, cfgname):
+    """cmh_text_forward_train_tokens_packed + cmh_text_backward_tokens on its tape against the dense pair, with a loss that - like
+    MITH's - puts no weight on padded positions: same tokens at the kept positions, every parameter gradient equal up to the
+    summation order of the weight gradients (fewer rows in the contraction)."""
+    from model.MITH import build_model
+    (cfg, L), seed, B = _PACK_CFGS[cfgname], 7, 6
+    text_np = _ragged_text(B, L, cfg["vocab_size"], seed)
+    text, kpm = tt(text_np), tt(text_np == 0)
+    last = np.array([np.flatnonzero(r != 0).max() for r in text_np])
+    keep = torch.from_numpy(np.arange(L)[None, :] <= np.maximum(last, text_np.argmax(1))[:, None]).to(DEV)
+    gen = torch.Generator().manual_seed(5)
+    G = torch.randn(L, B, 512, generator=gen).to(DEV) * keep.T[:, :, None]          # no weight on the padded positions
+    Ge = torch.randn(B, 512, generator=gen).to(DEV)
+    res = {}
+    for packed in (False, True):
+        clip = build_model({k: torch.from_numpy(v) for k, v in recipe.clip_state_dict(cfg, seed).items()}).to(DEV).float().set_gemm_dtype(mode)
+        clip.padded_tokens_unused = packed
+        seq_t, _, _, eos = clip.encode_text(text, kpm)
+        ((seq_t * G).sum() + (eos * Ge).sum()).backward()
+        res[packed] = (seq_t.detach().clone(), eos.detach().clone(), {n: p.grad.detach().clone() for n, p in clip.named_parameters() if p.grad is not None})
+    assert torch.equal(res[True][1], res[False][1])
+    assert torch.equal(res[True][0][keep.T], res[False][0][keep.T]) and float(res[True][0][~keep.T].abs().max()) == 0.0      # (the tape has its own [M, E] f32 region)
+    assert res[True][2].keys() == res[False][2].keys() and len(res[True][2]) > 20
+    tol = 2e-5 if mode == "f32" else 4e-3
+    for name, ref in res[False][2].items():
+        got = res[True][2][name]
+        err = float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-6)
+        assert err < tol, (name, err)
+
+
 @pytest.mark.parametrize("Nb,L,K", [(3, 12, 16), (4, 32, 64)])
 def test_hashing_model_matches_reference(golden, Nb, L, K):
     from model.MITH import HashingModel
