@@ -746,14 +746,17 @@ extern "C" int cmh_vit_backward_tokens(const cmh_vit_weights* w, int32_t batch, 
 namespace {
 std::mutex g_tape_rows_mu;
 std::unordered_map<const void*, int> g_tape_rows;
+std::vector<const void*> g_tape_order;                    // insertion order: the OLDEST entry goes when the table is full
 void remember_tape_rows(const void* tape, int rows) {
   std::lock_guard<std::mutex> lk(g_tape_rows_mu);
-  if (g_tape_rows.size() > 64) g_tape_rows.clear();      // tapes of long-gone steps
+  if (g_tape_rows.find(tape) == g_tape_rows.end()) {
+    if (g_tape_order.size() >= 64) {                      // tapes of long-gone steps; a forward's entry outlives the 63 forwards after it
+      g_tape_rows.erase(g_tape_order.front());
+      g_tape_order.erase(g_tape_order.begin());
+    }
+    g_tape_order.push_back(tape);
+  }
   g_tape_rows[tape] = rows;
-}
-void forget_tape_rows(const void* tape) {
-  std::lock_guard<std::mutex> lk(g_tape_rows_mu);
-  g_tape_rows.erase(tape);
 }
 int recall_tape_rows(const void* tape) {
   std::lock_guard<std::mutex> lk(g_tape_rows_mu);
@@ -789,7 +792,7 @@ static int text_forward_train_impl(const cmh_text_weights* w, const int64_t* tok
   // (cmh_text_forward_train_tokens_packed; encoders.hip text_begin has the reasoning) - their gradient is then exactly zero as well
   const int bk0 = dt == CMH_F32 ? 32 : 64;
   const bool pack_tokens = tokens_out && pack_tokens_req && key_padding_mask && text_token_packing() && w->embed_dim % 128 == 0 && d % bk0 == 0;
-  if (tokens_out && !pack_tokens) forget_tape_rows(tape);
+  if (tokens_out && !pack_tokens) remember_tape_rows(tape, 0);      // 0: this tape's all-token head is dense (text_backward_impl)
   if ((!tokens_out && text_packing(key_padding_mask)) || pack_tokens) {
     if ((rc = launch_text_pack_plan(tokens, B, L, t.seq_off, st, pack_tokens ? key_padding_mask : nullptr, pack_tokens ? t.rows : nullptr))) return rc;
     int32_t total = 0;
@@ -876,9 +879,13 @@ static int text_backward_impl(const cmh_text_weights* w, const int64_t* tokens, 
     seq_off = t.seq_off;
     rows = total;
   }
-  if (dtokens) {       // a tape that cmh_text_forward_train_tokens_packed filled holds a packed plan: the forward call remembered its row count
-    const int32_t total = recall_tape_rows(tape);
-    if (total > 0 && total <= M) { seq_off = t.seq_off; rows = total; }
+  if (dtokens) {       // a tape that cmh_text_forward_train_tokens_packed filled holds a packed plan: the forward call remembered its row
+                       // count (0 for a dense tape, whose forward also zeroed seq_off); a tape this process does not remember is asked
+    int32_t total = recall_tape_rows(tape);
+    if (total < 0 && (hipMemcpyAsync(&total, t.seq_off + B, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess))
+      return fail(CMH_ERR_LAUNCH, "text_backward_tokens: reading the packed row count failed");
+    CMH_CHECK_ARG(total >= 0 && total <= M, "text_backward_tokens: the tape holds a bad packed row count %d", total);
+    if (total > 0) { seq_off = t.seq_off; rows = total; }
   }
   const bool tail = !dtokens && train_pooled_tail() && rows >= 2 * B;
   if (layer_hi == w->layers) {

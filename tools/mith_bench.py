@@ -10,6 +10,7 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 sd = {k: torch.from_numpy(v) for k, v in recipe.clip_state_dict(recipe.CLIP_VITB32, 1).items()}
 clip = build_model(sd).to(dev).float().set_gemm_dtype("bf16")
+clip.padded_tokens_unused = True      # as model/MITH.py::MITH sets it (HashingModel is the only reader of the text tokens)
 hm = HashingModel(clip_embed_dim=512, args=SimpleNamespace(output_dim=64, dropout=0.0, transformer_layers=2, activation="gelu",
                                                            top_k_label=8, res_mlp_layers=2)).to(dev).eval()
 B = 128

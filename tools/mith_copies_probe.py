@@ -11,6 +11,7 @@ from streams import overlapped
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 clip = build_model(bench_configs._vitb32_state(1)).to(dev).float().set_gemm_dtype("bf16")
+clip.padded_tokens_unused = True      # as model/MITH.py::MITH sets it (HashingModel is the only reader of the text tokens)
 hm = HashingModel(clip_embed_dim=512, args=SimpleNamespace(output_dim=64, **mu.ARGS)).to(dev).eval().set_gemm_dtype("bf16")
 B = 256
 img = torch.randn(B, 3, 224, 224, device=dev)

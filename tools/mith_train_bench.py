@@ -21,6 +21,7 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 sd = {k: torch.from_numpy(v) for k, v in recipe.clip_state_dict(recipe.CLIP_VITB32, 1).items()}
 clip = build_model(sd).to(dev).float().set_gemm_dtype(a.dtype)
+clip.padded_tokens_unused = True      # as model/MITH.py::MITH sets it (HashingModel is the only reader of the text tokens)
 K, C, Mb, B, L = 64, 80, 10000, a.batch, 32
 hm = HashingModel(clip_embed_dim=512, args=SimpleNamespace(output_dim=K, **mu.ARGS)).to(dev).train().set_gemm_dtype(a.dtype)
 model = torch.nn.Module(); model.clip, model.hash = clip, hm
