@@ -488,6 +488,330 @@ __global__ __launch_bounds__(512) void gemm_lc_kernel(LcProblem p0, LcProblem p1
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads issued past the last stage
 }
 
+// ---- "lc2": the same split with TWO MFMA waves per SIMD ---------------------------------------------------------------------------------
+// What the lc kernel lacks is somebody to multiply while a SIMD's MFMA wave is in its epilogue, and somebody to cover the issue of a
+// store.  Here a workgroup has 12 waves, 3 per SIMD (168 VGPRs): waves 0..3 stage exactly as above, waves 4..11 multiply 64 x 64 each
+// (2 (m) x 4 (n) of the same 128 x 256 tile; the two MFMA waves of a SIMD share their W columns): 32 MFMAs per wave and K-step, 4 W
+// fragments refilled in place, X double-buffered: 64 accumulators + 48 fragment registers + the previous tile's 32 packed output
+// registers, which leave one 16-byte store per K-step under the next tile's MFMAs (the wide kernel's deferred stores - there is a
+// partner wave to cover their issue now).  No residual forms yet: bias / bias + QuickGELU with bf16 output (QKV, c_fc).
+// Same k order per output element, same epilogue order: the same bits.
+template <bool GRP>
+__global__ __launch_bounds__(768) void gemm_lc2_kernel(LcProblem p0, LcProblem p1, int epi) {
+  __shared__ __attribute__((aligned(1024))) char lds[3 * lcSTG + 2 * 1024];      // the ring + two bias rows (tile parity)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const char* const X0 = p0.X; const char* const W0 = p0.W; const float* const B0 = p0.bias; void* const O0 = p0.out;
+  const int N0 = p0.N, K0 = p0.K;
+  const char* const X1 = p1.X; const char* const W1 = p1.W; const float* const B1 = p1.bias; void* const O1 = p1.out;
+  const int N1 = p1.N, K1 = p1.K;
+  int M0 = p0.Mub;
+  if (p0.m_dev) { const int md = *p0.m_dev; M0 = md < M0 ? md : M0; }
+  M0 = __builtin_amdgcn_readfirstlane(M0);
+  int M1 = 0;
+  if constexpr (GRP) {
+    M1 = p1.Mub;
+    if (p1.m_dev) { const int md = *p1.m_dev; M1 = md < M1 ? md : M1; }
+    M1 = __builtin_amdgcn_readfirstlane(M1);
+  }
+  const int tiles_n0 = N0 / lcBN, tiles_n1 = GRP ? N1 / lcBN : 1;
+  const int total0 = tiles_n0 * ((M0 + lcBM - 1) / lcBM);
+  const int total1 = GRP ? tiles_n1 * ((M1 + lcBM - 1) / lcBM) : 0;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
+  const int q0 = total0 >> 3, r0 = total0 & 7, q1 = total1 >> 3, r1 = total1 & 7;
+  const int lo0 = xcd < r0 ? xcd * (q0 + 1) : r0 * (q0 + 1) + (xcd - r0) * q0, len0 = xcd < r0 ? q0 + 1 : q0;
+  const int lo1 = xcd < r1 ? xcd * (q1 + 1) : r1 * (q1 + 1) + (xcd - r1) * q1, len1 = xcd < r1 ? q1 + 1 : q1;
+  const int n_first = slot < len0 ? (len0 - slot + per - 1) / per : 0;
+  const int span = len0 + len1;
+  const int my_tiles = slot < span ? (span - slot + per - 1) / per : 0;
+  if (my_tiles == 0) return;
+  const int nk0 = K0 / 64, nk1 = GRP ? K1 / 64 : 0;
+  const int S = n_first * nk0 + (my_tiles - n_first) * nk1;
+  auto tile_of = [&](int ti, bool& second, int& m0, int& n0) {
+    const int j = slot + ti * per;
+    second = GRP && ti >= n_first;
+    const int logical = second ? lo1 + (j - len0) : lo0 + j;
+    const int tn_cnt = second ? tiles_n1 : tiles_n0;
+    const int tm = logical / tn_cnt;
+    m0 = tm * lcBM;
+    n0 = (logical - tm * tn_cnt) * lcBN;
+  };
+
+  if (wid < 4) {
+    // ---- loader waves: the lc kernel's, piece for piece ----
+    const int sub = lane >> 3, ch = lane & 7;
+    uint32_t offW[8], offX[4];
+    const char* Wt = nullptr;
+    const char* Xt = nullptr;
+    const char* Bt = nullptr;
+    int i_nk = 0;
+    int w_prob = -1;
+    auto set_tile = [&](int ti) {
+      bool second; int m0, n0;
+      tile_of(ti, second, m0, n0);
+      const uint32_t rs = static_cast<uint32_t>(second ? K1 : K0) * 2;
+      if (w_prob != static_cast<int>(second)) {
+        w_prob = static_cast<int>(second);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int row = (wid * 8 + i) * 8 + sub;
+          offW[i] = static_cast<uint32_t>(row) * rs + ((ch ^ (row & 7)) << 4);
+        }
+      }
+      i_nk = second ? nk1 : nk0;
+      const int Mp = second ? M1 : M0;
+      Wt = (second ? W1 : W0) + static_cast<size_t>(n0) * rs;
+      Xt = second ? X1 : X0;
+      Bt = reinterpret_cast<const char*>((second ? B1 : B0) + n0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (wid * 4 + i) * 8 + sub;
+        int xr = m0 + row;
+        xr = xr < Mp ? xr : Mp - 1;
+        offX[i] = static_cast<uint32_t>(xr) * rs + ((ch ^ (row & 7)) << 4);
+      }
+    };
+    int i_tile = 0, i_kt = 0, ibuf = 0;
+    set_tile(0);
+    const bool bias_wave = wid == 0 && (epi & EPI_BIAS);
+    auto issue_stage = [&]() {
+      char* base = lds + ibuf * lcSTG;
+      const uint32_t koff = static_cast<uint32_t>(i_kt) * lcRowBytes;
+      if (i_kt == 0 && bias_wave)
+        __builtin_amdgcn_global_load_lds((lc_gptr_t)(Bt + lane * 16), (lc_lptr_t)(lds + 3 * lcSTG + (i_tile & 1) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_global_load_lds((lc_gptr_t)(Wt + koff + offW[i]), (lc_lptr_t)(base + (wid * 8 + i) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((lc_gptr_t)(Xt + koff + offX[i]), (lc_lptr_t)(base + lcWBytes + (wid * 4 + i) * 1024), 16, 0, 0);
+      ibuf = ibuf == 2 ? 0 : ibuf + 1;
+      if (++i_kt == i_nk) {
+        i_kt = 0;
+        if (++i_tile < my_tiles) set_tile(i_tile);
+      }
+    };
+    issue_stage();
+    if (S > 1) issue_stage();
+    if (S > 2) issue_stage();
+    if (S > 2) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (S > 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int s = 0; s < S; ++s) {
+      if (s + 2 < S) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (s + 3 < S) issue_stage();
+    }
+    return;
+  }
+
+  // ---- MFMA waves ----
+  const int c = wid - 4;
+  const int wm = c >> 2, wn = c & 3;              // 2 (m) x 4 (n) waves of 64 x 64; the SIMD of wave c is c & 3: its two waves share wn
+  const int frow = lane & 15, fq = lane >> 4;
+  const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lc_lptr_t)lds));
+  const uint32_t aW = lds_base + lc_swz(wn * 64 + frow, fq);
+  const uint32_t aX = lds_base + lcWBytes + lc_swz(wm * 64 + frow, fq);
+
+  lc_f32x4_t acc[4][4];                            // [n-fragment][m-fragment]
+  lc_u32x4_t fw[4], fxa[4], fxb[4];
+  lc_u32x4_t pend[8];                              // the previous tile's packed outputs: piece (b, pr) at 2 b + pr
+  bool pend_valid = false;
+  char* pend_base = nullptr;
+  uint32_t pend_off0 = 0, pend_ldn = 0;
+
+  void* out = O0;
+  int N = N0, M = M0, nk = nk0;
+  [[maybe_unused]] auto to_problem1 = [&]() { out = O1; N = N1; M = M1; nk = nk1; };
+  if constexpr (GRP) { if (n_first == 0) to_problem1(); }
+
+  auto mfma = [&](const lc_u32x4_t& w, const lc_u32x4_t& x, const lc_f32x4_t& cin) __attribute__((always_inline)) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lc_bf16x8_t, w), __builtin_bit_cast(lc_bf16x8_t, x), cin, 0, 0, 0);
+  };
+  auto store_pending = [&](int idx) __attribute__((always_inline)) {      // idx is wave-uniform: a jump, not a select
+    char* p = pend_base + (pend_off0 + static_cast<uint32_t>(idx >> 1) * 16u * pend_ldn + static_cast<uint32_t>(idx & 1) * 64u);
+    switch (idx) {
+      case 0: *reinterpret_cast<lc_u32x4_t*>(p) = pend[0]; break;
+      case 1: *reinterpret_cast<lc_u32x4_t*>(p) = pend[1]; break;
+      case 2: *reinterpret_cast<lc_u32x4_t*>(p) = pend[2]; break;
+      case 3: *reinterpret_cast<lc_u32x4_t*>(p) = pend[3]; break;
+      case 4: *reinterpret_cast<lc_u32x4_t*>(p) = pend[4]; break;
+      case 5: *reinterpret_cast<lc_u32x4_t*>(p) = pend[5]; break;
+      case 6: *reinterpret_cast<lc_u32x4_t*>(p) = pend[6]; break;
+      default: *reinterpret_cast<lc_u32x4_t*>(p) = pend[7]; break;
+    }
+  };
+#define L2_WAIT5(cnt, r0, r1, r2, r3, r4) \
+  asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4)::"memory")
+#define L2_WAIT1(cnt, r0) asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(r0)::"memory")
+#define L2_WAIT_ALLW(cnt) asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(fw[0]), "+v"(fw[1]), "+v"(fw[2]), "+v"(fw[3])::"memory")
+#define L2_READ_W(a, addr)                                                       \
+  do {                                                                           \
+    if constexpr ((a) == 0) LC_READ(fw[0], addr, 0);                             \
+    else if constexpr ((a) == 1) LC_READ(fw[1], addr, 2048);                     \
+    else if constexpr ((a) == 2) LC_READ(fw[2], addr, 4096);                     \
+    else LC_READ(fw[3], addr, 6144);                                             \
+  } while (0)
+#define L2_READ_X(fx, b, addr)                                                   \
+  do {                                                                           \
+    if constexpr ((b) == 0) LC_READ(fx[0], addr, 0);                             \
+    else if constexpr ((b) == 1) LC_READ(fx[1], addr, 2048);                     \
+    else if constexpr ((b) == 2) LC_READ(fx[2], addr, 4096);                     \
+    else LC_READ(fx[3], addr, 6144);                                             \
+  } while (0)
+
+  int cur = 0;
+  __builtin_amdgcn_s_barrier();                    // stage 0 has landed
+  L2_READ_X(fxa, 0, aX); L2_READ_X(fxa, 1, aX); L2_READ_X(fxa, 2, aX); L2_READ_X(fxa, 3, aX);
+  L2_READ_W(0, aW); L2_READ_W(1, aW); L2_READ_W(2, aW); L2_READ_W(3, aW);
+
+  // One K-step.  LDS returns a wave's reads in order; at the top of half 0 the outstanding ones are X''0..3, W''0, W''1, W''2, W''3
+  // (issued in half 1 of the K-step before): fragment W''0 has landed when 3 younger reads may still fly; W''a (a >= 1) when 7 may
+  // (the rest of the W'' plus the four X' and the a W' reads issued since).  Half 1: X'0..3, W'0 | W'1 | W'2 | W'3 -> 3, 2, then all.
+  auto kstep = [&](int kt) __attribute__((always_inline)) {
+    const uint32_t bo = static_cast<uint32_t>(cur) * lcSTG;
+    const uint32_t w1 = (aW + bo) ^ 64u, x1 = (aX + bo) ^ 64u;
+    L2_WAIT5(3, fxa[0], fxa[1], fxa[2], fxa[3], fw[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#define L2_MFMA0(a, b) acc[a][b] = mfma(fw[a], fxa[b], acc[a][b])
+#define L2_GROUP0(a)                                                                                   \
+  do {                                                                                                 \
+    if constexpr ((a) > 0) { L2_WAIT1(7, fw[a]); __builtin_amdgcn_sched_barrier(0); }                  \
+    if constexpr ((a) == 0) L2_READ_X(fxb, 0, x1);                                                     \
+    L2_MFMA0(a, 0);                                                                                    \
+    if constexpr ((a) == 0) L2_READ_X(fxb, 1, x1);                                                     \
+    L2_MFMA0(a, 1);                                                                                    \
+    if constexpr ((a) == 0) L2_READ_X(fxb, 2, x1);                                                     \
+    L2_MFMA0(a, 2);                                                                                    \
+    if constexpr ((a) == 0) L2_READ_X(fxb, 3, x1);                                                     \
+    L2_MFMA0(a, 3);                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    L2_READ_W(a, w1);                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+  } while (0)
+    L2_GROUP0(0); L2_GROUP0(1);
+    if (pend_valid && kt < 8) { store_pending(kt); __builtin_amdgcn_sched_barrier(0); }      // one 16-byte piece of the previous tile per K-step
+    L2_GROUP0(2); L2_GROUP0(3);
+#undef L2_GROUP0
+#undef L2_MFMA0
+    const int nxt = cur == 2 ? 0 : cur + 1;
+    const uint32_t bn = static_cast<uint32_t>(nxt) * lcSTG;
+    const uint32_t w0 = aW + bn, x0 = aX + bn;
+#define L2_MFMA1(a, b) acc[a][b] = mfma(fw[a], fxb[b], acc[a][b])
+    L2_WAIT5(3, fxb[0], fxb[1], fxb[2], fxb[3], fw[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    L2_MFMA1(0, 0); L2_MFMA1(0, 1); L2_MFMA1(0, 2); L2_MFMA1(0, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    L2_WAIT1(2, fw[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    L2_MFMA1(1, 0); L2_MFMA1(1, 1); L2_MFMA1(1, 2); L2_MFMA1(1, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    L2_WAIT_ALLW(0);                               // every fragment of this stage is in registers
+    __builtin_amdgcn_s_barrier();                  // ... in every MFMA wave; the next stage has landed
+    __builtin_amdgcn_sched_barrier(0);
+    L2_READ_X(fxa, 0, x0);
+    L2_MFMA1(2, 0);
+    L2_READ_X(fxa, 1, x0);
+    L2_MFMA1(2, 1);
+    L2_READ_X(fxa, 2, x0);
+    L2_MFMA1(2, 2);
+    L2_READ_X(fxa, 3, x0);
+    L2_MFMA1(2, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    L2_READ_W(0, w0);
+    L2_READ_W(1, w0);
+    L2_READ_W(2, w0);
+    __builtin_amdgcn_sched_barrier(0);
+    L2_MFMA1(3, 0); L2_MFMA1(3, 1); L2_MFMA1(3, 2); L2_MFMA1(3, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    L2_READ_W(3, w0);
+    __builtin_amdgcn_sched_barrier(0);
+#undef L2_MFMA1
+    cur = nxt;
+  };
+
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    bool second; int m0, n0;
+    tile_of(ti, second, m0, n0);
+    if constexpr (GRP) { if (ti == n_first && ti > 0) to_problem1(); }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = lc_f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) kstep(kt);
+    pend_valid = false;                            // nk >= 8 (host): every parked piece has left
+
+    if (epi & EPI_BIAS) {
+      const uint32_t ab = lds_base + 3 * lcSTG + (ti & 1) * 1024 + (wn * 64 + fq * 4) * 4;
+      lc_f32x4_t bv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bv[a]) : "v"(ab), "n"(a * 64));
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3])::"memory");
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] += bv[a];
+    }
+    if (epi & EPI_QUICKGELU) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int j = 0; j < 4; j += 2) {
+            const lc_f32x2_t v = {acc[a][b][j], acc[a][b][j + 1]};
+            const lc_f32x2_t t = v * lc_f32x2_t{-2.4554669595930157f, -2.4554669595930157f};
+            const lc_f32x2_t d = lc_f32x2_t{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + lc_f32x2_t{1.0f, 1.0f};
+            const lc_f32x2_t o = v * lc_f32x2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+            acc[a][b][j] = o[0];
+            acc[a][b][j + 1] = o[1];
+          }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      char* const obase = static_cast<char*>(out) + (static_cast<size_t>(m0) * N + n0) * 2;       // uniform
+      const uint32_t ldn = static_cast<uint32_t>(N) * 2;
+      const uint32_t off0 = static_cast<uint32_t>(wm * 64 + frow) * ldn + static_cast<uint32_t>(wn * 64 + (fq & 1) * 16 + (fq & 2) * 4) * 2;
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          uint32_t lo[2], hi[2];
+#pragma unroll
+          for (int w = 0; w < 2; ++w) {
+            lo[w] = pack_bf16x2(acc[2 * pr][b][2 * w], acc[2 * pr][b][2 * w + 1]);
+            hi[w] = pack_bf16x2(acc[2 * pr + 1][b][2 * w], acc[2 * pr + 1][b][2 * w + 1]);
+          }
+          const lc_u2_t s0 = __builtin_amdgcn_permlane16_swap(lo[0], hi[0], false, false);
+          const lc_u2_t s1 = __builtin_amdgcn_permlane16_swap(lo[1], hi[1], false, false);
+          pend[2 * b + pr] = lc_u32x4_t{s0[0], s1[0], s0[1], s1[1]};
+        }
+      pend_base = obase; pend_off0 = off0; pend_ldn = ldn;
+      const bool full = m0 + lcBM <= M;
+      if (full && ti + 1 < my_tiles && !(epi & 256)) {
+        pend_valid = true;                         // the next tile's first eight K-steps carry the pieces out
+      } else if (!(epi & 256)) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr)
+            if (m0 + wm * 64 + b * 16 + frow < M)
+              *reinterpret_cast<lc_u32x4_t*>(obase + (off0 + static_cast<uint32_t>(b * 16) * ldn + pr * 64)) = pend[2 * b + pr];
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads issued past the last stage
+#undef L2_WAIT5
+#undef L2_WAIT1
+#undef L2_WAIT_ALLW
+#undef L2_READ_W
+#undef L2_READ_X
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------------------------
 static int lc_env_mode() { static const int m = []() { const char* e = getenv("CMH_GEMM_LC"); return e ? atoi(e) : 0; }(); return m; }
 static int g_lc_mode = -1;         // cmh_set_gemm_lc: -1 = environment (CMH_GEMM_LC, default 0 = off)
@@ -497,6 +821,10 @@ void gemm_lc_set_mode(int m) { g_lc_mode = m; }
 // bf16 operands, 16-bit output, the forward epilogues of a transformer block (bias, + QuickGELU, + fp16 residual), N % 256 == 0
 bool gemm_lc_takes(int dt, int N, int K, int epi) {
   if (dt != CMH_BF16 || N % lcBN != 0 || K % 64 != 0 || K < 256) return false;      // >= 4 K-steps per tile: the bias slots' reuse distance
+  if (gemm_lc_mode() >= 4) {      // the 12-wave form (lc2): bias / bias + QuickGELU with bf16 output; its parked stores need 8 K-steps per tile
+    if (K < 512 || (epi & (EPI_RESIDUAL | EPI_OUT_F16)) || !(epi & EPI_OUT_BF16)) return false;
+    if (gemm_lc_mode() == 5 && (epi & EPI_QUICKGELU)) return false;
+  }
   if (!(epi & (EPI_OUT_BF16 | EPI_OUT_F16)) || ((epi & EPI_OUT_BF16) && (epi & EPI_OUT_F16))) return false;
   if (epi & ~(EPI_BIAS | EPI_QUICKGELU | EPI_RESIDUAL | EPI_RES_F16 | EPI_OUT_BF16 | EPI_OUT_F16 | 256)) return false;
   if ((epi & EPI_RESIDUAL) && !((epi & EPI_RES_F16) && (epi & EPI_OUT_F16))) return false;      // a residual = the fp16 stream, in and out
@@ -536,6 +864,17 @@ int launch_gemm_lc(const GemmProblem& a, const GemmProblem* b, int epi, hipStrea
   const int total = tiles_of(a) + (b ? tiles_of(*b) : 0);
   const int grid = total < cus ? ((total + 7) & ~7) : cus;     // sized for the upper bounds: workgroups without a tile exit at once
   const LcProblem P0 = prob(a), P1 = b ? prob(*b) : LcProblem{};
+  if (gemm_lc_mode() >= 4) {
+    if (b) {
+      if (ev0) hipExtLaunchKernelGGL((gemm_lc2_kernel<true>), dim3(grid), dim3(768), 0, st, ev0, ev1, 0, P0, P1, epi);
+      else hipLaunchKernelGGL((gemm_lc2_kernel<true>), dim3(grid), dim3(768), 0, st, P0, P1, epi);
+    } else {
+      if (ev0) hipExtLaunchKernelGGL((gemm_lc2_kernel<false>), dim3(grid), dim3(768), 0, st, ev0, ev1, 0, P0, P1, epi);
+      else hipLaunchKernelGGL((gemm_lc2_kernel<false>), dim3(grid), dim3(768), 0, st, P0, P1, epi);
+    }
+    CMH_CHECK_LAUNCH("gemm (lc2)");
+    return 0;
+  }
   const bool rf = gemm_lc_res_first(epi, a.K);      // (the caller has checked that both problems agree)
   const bool f16o = (epi & EPI_OUT_F16) != 0;
 #define LC_GO2(G, R, F)                                                                                                      \
@@ -581,7 +920,7 @@ extern "C" int cmh_debug_lc_stamps(unsigned long long* host_out) {
 #endif
 
 extern "C" int cmh_set_gemm_lc(int32_t mode) {
-  CMH_CHECK_ARG(mode >= -1 && mode <= 3, "set_gemm_lc: mode %d (-1 environment, 0 off, 1 every eligible launch, 2 all but QuickGELU launches, 3 by cost model)", mode);
+  CMH_CHECK_ARG(mode >= -1 && mode <= 5, "set_gemm_lc: mode %d (-1 environment, 0 off, 1 every eligible launch, 2 all but QuickGELU launches, 3 by cost model, 4 / 5 the 12-wave form for the residual-free launches / without the QuickGELU ones)", mode);
   cmh::gemm_lc_set_mode(mode);
   return CMH_OK;
 }

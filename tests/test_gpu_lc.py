@@ -105,3 +105,51 @@ def test_lc_kernel_never_writes_rows_past_the_device_side_count():
     finally:
         N.set_gemm_lc(-1)
     assert bool((outs[1][1234:] == -7.0).all()) and not bool((outs[1][:1234] == -7.0).all()) and not bool((outs[0] == -7.0).any())
+
+
+# ---- the 12-wave form (cmh_set_gemm_lc(4)): 4 staging waves + 8 MFMA waves of 64 x 64, stores deferred into the next tile's K-steps.
+# It takes the residual-free launches with K >= 512 (bias / bias + QuickGELU, bf16 output); everything else stays on the wide kernel.
+LC2_PLAIN = [(12800, 2304, 768, 0), (12800, 3072, 768, 2), (10499, 1536, 512, 0), (10499, 2048, 512, 2),
+             (2049, 256, 512, 0),          # 8 K-steps (the shortest tile it takes), the last row tile a single row
+             (5000, 1024, 576, 2),         # 9 K-steps
+             (130, 512, 1024, 0)]          # fewer tiles than an XCD has workgroups: every tile is its workgroup's last (direct stores)
+
+
+@pytest.mark.parametrize("case", range(len(LC2_PLAIN)))
+def test_lc2_kernel_gives_the_wide_kernels_bits(case):
+    import cmh_native as N
+    M, Nn, K, kind = LC2_PLAIN[case]
+    g = torch.Generator().manual_seed(700 + case)
+    p = _problem(M, Nn, K, kind, g)
+    try:
+        N.set_gemm_rows(0)
+        N.set_gemm_lc(0)
+        ref = _plain(N, p, kind)
+        N.set_gemm_lc(4)
+        N.prof_gemm_begin(8)
+        got = _plain(N, p, kind)
+        N.prof_gemm_end()
+    finally:
+        N.set_gemm_lc(-1)
+        N.set_gemm_rows(-1)
+    assert torch.equal(ref, got)
+
+
+@pytest.mark.parametrize("case", [0, 2, 4, 6])
+def test_lc2_grouped_launch_gives_the_wide_kernels_bits(case):
+    import cmh_native as N
+    (Ma, Na, Ka), (Mb, Nb, Kb), kind = GROUPED[case] if case != 4 else ((2100, 256, 512), (4000, 1024, 1024), 0)
+    g = torch.Generator().manual_seed(800 + case)
+    probs = [_problem(Ma, Na, Ka, kind, g), _problem(Mb, Nb, Kb, kind, g)]
+    md = torch.tensor([Mb - 37], dtype=torch.int32, device=DEV)
+    try:
+        N.set_gemm_lc(0)
+        ref = [_plain(N, p, kind) for p in probs]
+        N.set_gemm_lc(4)
+        got = N.linear_gemm_grouped(probs, quickgelu=kind == 2, out="bf16")
+        got_md = N.linear_gemm_grouped(probs, quickgelu=kind == 2, out="bf16", m_dev=(None, md))
+    finally:
+        N.set_gemm_lc(-1)
+    for r, o in zip(ref, got):
+        assert torch.equal(r, o)
+    assert torch.equal(got_md[0], ref[0]) and torch.equal(got_md[1][:Mb - 37], ref[1][:Mb - 37])

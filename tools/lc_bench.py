@@ -18,6 +18,7 @@ ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--check", action="store_true", help="compare the two kernels' outputs (torch.equal)")
 ap.add_argument("--only", default="")
+ap.add_argument("--mode", type=int, default=1, help="cmh_set_gemm_lc mode of the lc column: 1 the 8-wave kernel, 4 the 12-wave form (takes only the residual-free launches)")
 ap.add_argument("--nostore", action="store_true", help="timing-only ablation (epi | 256): skip the output stores of the lc kernel")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -73,7 +74,7 @@ for name, fn, flops in cases:
     if a.check:
         N.set_gemm_lc(0)
         ref = fn()
-        N.set_gemm_lc(1)
+        N.set_gemm_lc(a.mode)
         got = fn()
         ref = ref if isinstance(ref, (list, tuple)) else [ref]
         got = got if isinstance(got, (list, tuple)) else [got]
@@ -88,7 +89,7 @@ for name, fn, flops in cases:
     nl = {}
     for _ in range(a.rounds):
         for mode in (0, 1):
-            N.set_gemm_lc(mode)
+            N.set_gemm_lc(a.mode if mode else 0)
             us, fl, n = timed(fn, a.iters)
             best[mode].append(us)
             nl[mode] = n
