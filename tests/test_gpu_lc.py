@@ -108,8 +108,10 @@ def test_lc_kernel_never_writes_rows_past_the_device_side_count():
 
 
 # ---- the 12-wave form (cmh_set_gemm_lc(4)): 4 staging waves + 8 MFMA waves of 64 x 64, stores deferred into the next tile's K-steps.
-# It takes the residual-free launches with K >= 512 (bias / bias + QuickGELU, bf16 output); everything else stays on the wide kernel.
+# It takes every block launch with K >= 512 (bias, + QuickGELU, + fp16 residual first / behind the bias).
 LC2_PLAIN = [(12800, 2304, 768, 0), (12800, 3072, 768, 2), (10499, 1536, 512, 0), (10499, 2048, 512, 2),
+             (12800, 768, 768, 1), (12800, 768, 3072, 1), (10499, 512, 512, 1), (10499, 512, 2048, 1),      # the residual launches: first (K <= 1024) / behind the bias
+             (300, 256, 1088, 1), (2049, 512, 1024, 1),
              (2049, 256, 512, 0),          # 8 K-steps (the shortest tile it takes), the last row tile a single row
              (5000, 1024, 576, 2),         # 9 K-steps
              (130, 512, 1024, 0)]          # fewer tiles than an XCD has workgroups: every tile is its workgroup's last (direct stores)
@@ -135,7 +137,7 @@ def test_lc2_kernel_gives_the_wide_kernels_bits(case):
     assert torch.equal(ref, got)
 
 
-@pytest.mark.parametrize("case", [0, 2, 4, 6])
+@pytest.mark.parametrize("case", range(len(GROUPED)))
 def test_lc2_grouped_launch_gives_the_wide_kernels_bits(case):
     import cmh_native as N
     (Ma, Na, Ka), (Mb, Nb, Kb), kind = GROUPED[case] if case != 4 else ((2100, 256, 512), (4000, 1024, 1024), 0)
@@ -146,8 +148,9 @@ def test_lc2_grouped_launch_gives_the_wide_kernels_bits(case):
         N.set_gemm_lc(0)
         ref = [_plain(N, p, kind) for p in probs]
         N.set_gemm_lc(4)
-        got = N.linear_gemm_grouped(probs, quickgelu=kind == 2, out="bf16")
-        got_md = N.linear_gemm_grouped(probs, quickgelu=kind == 2, out="bf16", m_dev=(None, md))
+        out = "f16" if kind == 1 else "bf16"
+        got = N.linear_gemm_grouped(probs, quickgelu=kind == 2, out=out)
+        got_md = N.linear_gemm_grouped(probs, quickgelu=kind == 2, out=out, m_dev=(None, md))
     finally:
         N.set_gemm_lc(-1)
     for r, o in zip(ref, got):
