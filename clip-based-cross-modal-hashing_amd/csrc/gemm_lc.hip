@@ -30,6 +30,7 @@
 // kept: the epilogue handed to the staging waves (role swap: they have ~370 idle cycles per K-step, not the 1 600 a tile's epilogue
 // needs), stores deferred into the next tile's K-steps (a store in the lone MFMA wave's in-order stream stalls its SIMD).  Routing
 // the output through LDS to the staging waves' idle registers fails on capacity: ring 144 KB + bias 2 KB leave 14 KB of 160.
+// What does work is the 12-wave form further down (gemm_lc2_kernel): two MFMA waves per SIMD again, the staging still on its own waves.
 #include <cstdlib>
 #include <cstring>
 
