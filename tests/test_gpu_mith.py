@@ -36,6 +36,37 @@ def test_trunk_returns_all_tokens(golden):
     np.testing.assert_allclose(eos.cpu().numpy(), g["trunk_eos_t"], **tol)
 
 
+_PACK_CFGS = {"w128": (dict(mu.CLIP_TINY512), 16),                  # width 128: the GEMMs take their row count from the host (one read-back)
+              "w256": (dict(mu.CLIP_TINY512, context_length=24, transformer_width=256, transformer_heads=4), 24)}   # device-side row count, fp16 stream in bf16 mode
+
+
+def test_token_packing_edge_captions():
+    """an all-zero caption (every position padded: the EOT's argmax is position 0, one row is kept), a caption without any padding, and
+    a batch with no padded position at all (the packed plan is the dense one): kept positions equal the dense call's bits"""
+    import mith_ops as M
+    from model.MITH import build_model
+    cfg, L = _PACK_CFGS["w256"]
+    seed, B = 3, 4
+    clip = build_model({k: torch.from_numpy(v) for k, v in recipe.clip_state_dict(cfg, seed).items()}).to(DEV).float().set_gemm_dtype("bf16")
+    text_np = recipe.captions(B, L, cfg["vocab_size"], seed).copy()
+    text_np[1, :] = 0                                         # nothing but padding
+    text_np[2, :] = np.arange(5, 5 + L); text_np[2, -1] = cfg["vocab_size"] - 1      # no padding at all, EOT last
+    full = np.tile(text_np[2], (B, 1))
+    for t_np in (text_np, full):
+        text, kpm = tt(t_np), tt(t_np == 0)
+        with torch.no_grad():
+            dense, rows_d = M.text_encode_tokens(clip, text, kpm)
+            packed, rows_p = M.text_encode_tokens(clip, text, kpm, padded_unused=True)
+        assert torch.equal(rows_d, rows_p)
+        last = np.array([np.flatnonzero(r != 0).max() if (r != 0).any() else -1 for r in t_np])
+        keep = torch.from_numpy(np.arange(L)[None, :] <= np.maximum(last, t_np.argmax(1))[:, None]).to(DEV)
+        # (the all-padded caption has every key masked: its one kept row is NaN in the reference, in the dense call and here)
+        nn = lambda t: torch.nan_to_num(t, nan=12345.0)
+        assert torch.equal(nn(packed[keep]), nn(dense[keep])) and (bool(keep.all()) or float(packed[~keep].abs().max()) == 0.0)
+        ok_rows = torch.from_numpy((t_np != 0).any(1)).to(DEV)
+        assert bool(torch.isfinite(packed[ok_rows]).all())
+
+
 def _ragged_text(B, L, vocab, seed):
     """captions with their EOT anywhere, zeros behind it, and - the reference's quirk - one '!' (token id 0, which `text == 0` masks
     like padding) INSIDE a caption's prefix"""
@@ -45,10 +76,6 @@ def _ragged_text(B, L, vocab, seed):
     if eot[b] >= 3:
         text[b, 2] = 0
     return text
-
-
-_PACK_CFGS = {"w128": (dict(mu.CLIP_TINY512), 16),                  # width 128: the GEMMs take their row count from the host (one read-back)
-              "w256": (dict(mu.CLIP_TINY512, context_length=24, transformer_width=256, transformer_heads=4), 24)}   # device-side row count, fp16 stream in bf16 mode
 
 
 @pytest.mark.parametrize("cfgname", ["w128", "w256"])
