@@ -747,9 +747,6 @@ __global__ __launch_bounds__(768) void gemm_lc2_kernel(LcProblem p0, LcProblem p
     if constexpr (RES != 0) {
       if (kt == res_kt) { fetch_residual(res_tile); __builtin_amdgcn_sched_barrier(0); }
     }
-#ifdef LC2_DELAY_BACK      // diagnostic: stall this wave at one K-step of every tile (does the staging protocol depend on timing?)
-    if (kt == nk - LC2_DELAY_BACK) { __builtin_amdgcn_s_sleep(64); __builtin_amdgcn_s_sleep(64); __builtin_amdgcn_sched_barrier(0); }
-#endif
     L2_GROUP0(2); L2_GROUP0(3);
 #undef L2_GROUP0
 #undef L2_MFMA0
@@ -800,14 +797,10 @@ __global__ __launch_bounds__(768) void gemm_lc2_kernel(LcProblem p0, LcProblem p
         for (int b = 0; b < 4; ++b) acc[a][b] = lc_f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
     if constexpr (RES == 1) { res_tile = ti + 1; res_kt = ti + 1 < my_tiles ? 4 : -1; }      // the NEXT tile's rows, once the parked pieces are out
-#if defined(LC2_RES2_BACK)
-    if constexpr (RES == 2) { res_tile = ti; res_kt = nk - LC2_RES2_BACK; }
-#else
-    // this tile's own rows, at the same K-step (the registers are free from there on; fetched at nk - 3 instead, ONE build of this
-    // kernel returned garbage in the first row block of some lanes, run to run - nk - 6 / - 2 / - 1 and the same build with a sleep
-    // beside it did not; not understood: tools/lc2_stress.py hammers the kept form)
+    // this tile's own rows, at the same K-step: the registers are free from there on.  (Fetched at K-step nk - 3 instead, ONE build of
+    // this kernel returned garbage in the first row block of some lanes, run to run; the same source rebuilt with a diagnostic macro
+    // beside it - and nk - 6 / - 2 / - 1 - did not.  Not reproduced since, not understood: tools/lc2_stress.py hammers the kept form.)
     if constexpr (RES == 2) { res_tile = ti; res_kt = 4; }
-#endif
     if constexpr (RES != 0) asm volatile("" : "+s"(res_kt));
     for (int kt = 0; kt < nk; ++kt) {
       asm volatile("" : "+s"(kt));
