@@ -907,9 +907,10 @@ void gemm_lc_set_mode(int m) { g_lc_mode = m; }
 // bf16 operands, 16-bit output, the forward epilogues of a transformer block (bias, + QuickGELU, + fp16 residual), N % 256 == 0
 bool gemm_lc_takes(int dt, int N, int K, int epi) {
   if (dt != CMH_BF16 || N % lcBN != 0 || K % 64 != 0 || K < 256) return false;      // >= 4 K-steps per tile: the bias slots' reuse distance
-  if (gemm_lc_mode() >= 4) {      // the 12-wave form (lc2): bias / bias + QuickGELU with bf16 output; its parked stores need 8 K-steps per tile
+  if (gemm_lc_mode() >= 4) {      // the 12-wave form (lc2): its parked stores need 8 K-steps per tile
     if (K < 512) return false;
-    if (gemm_lc_mode() == 5 && (epi & EPI_QUICKGELU)) return false;
+    if (gemm_lc_mode() >= 5 && (epi & EPI_QUICKGELU)) return false;
+    if (gemm_lc_mode() == 6 && (epi & EPI_RESIDUAL) && K / 64 > 16) return false;      // 6: QKV and out_proj only (where it measured level or better)
   }
   if (!(epi & (EPI_OUT_BF16 | EPI_OUT_F16)) || ((epi & EPI_OUT_BF16) && (epi & EPI_OUT_F16))) return false;
   if (epi & ~(EPI_BIAS | EPI_QUICKGELU | EPI_RESIDUAL | EPI_RES_F16 | EPI_OUT_BF16 | EPI_OUT_F16 | 256)) return false;
@@ -1016,7 +1017,7 @@ extern "C" int cmh_debug_lc_stamps(unsigned long long* host_out) {
 #endif
 
 extern "C" int cmh_set_gemm_lc(int32_t mode) {
-  CMH_CHECK_ARG(mode >= -1 && mode <= 5, "set_gemm_lc: mode %d (-1 environment, 0 off, 1 every eligible launch, 2 all but QuickGELU launches, 3 by cost model, 4 / 5 the 12-wave form for the residual-free launches / without the QuickGELU ones)", mode);
+  CMH_CHECK_ARG(mode >= -1 && mode <= 6, "set_gemm_lc: mode %d (-1 environment, 0 off, 1 every eligible launch, 2 all but QuickGELU launches, 3 by cost model, 4 / 5 / 6 the 12-wave form for every block launch / without the QuickGELU ones / for QKV and out_proj only)", mode);
   cmh::gemm_lc_set_mode(mode);
   return CMH_OK;
 }
