@@ -57,6 +57,8 @@ struct LcProblem {
   const char* X; const char* W; const float* bias; const void* residual; void* out;
   const int* m_dev;      // optional: the real row count on the device (Mub is then an upper bound)
   int Mub, N, K;
+  const float* colscale = nullptr;      // fp8 operands (gemm_lc2q_kernel): out = epi(alpha * colscale[n] * (X8 . W8^T) + bias)
+  float alpha = 1.f, oscale = 1.f;
 };
 
 __device__ __forceinline__ int lc_swz(int row, int chunk) { return row * lcRowBytes + ((chunk ^ (row & 7)) << 4); }
@@ -898,6 +900,258 @@ __global__ __launch_bounds__(768) void gemm_lc2_kernel(LcProblem p0, LcProblem p
 #undef L2_READ_X
 }
 
+int gemm_lc_mode();
+// ---- "lc2q": the 12-wave form on e4m3 operands (the fp8 mode, BASELINE configs[4]) -------------------------------------------------------
+// A K-step of fp8 operands moves the same 48 KB as a bf16 one for half as many MFMA cycles per k (v_mfma_scale_f32_16x16x128_f8f6f4:
+// one instruction per 16 x 16 x 128), so a K = 768 tile has only SIX K-steps and the wide kernel's fp8 launches are dominated by what
+// is not the loop: DMA issue inside the MFMA streams (half as many MFMAs to hide it under) and the tile switch.  Here: the 4 staging
+// waves of lc2, 8 MFMA waves of 64 x 64 whose fragments (8 registers each: both 16-byte halves of a lane's 32 k) are refilled in place.
+// First form: bias + dequantisation, bf16 output, no residual, direct stores.  Same operand registers per MFMA as the wide kernel's
+// fp8 K-step (chunks fq and fq + 4 of the 128-byte row), same epilogue expression: the same bits.
+template <bool GRP>
+__global__ __launch_bounds__(768) void gemm_lc2q_kernel(LcProblem p0, LcProblem p1, int epi) {
+  static_assert(!GRP, "first form: plain launches");
+  __shared__ __attribute__((aligned(1024))) char lds[3 * lcSTG];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const char* const X0 = p0.X; const char* const W0 = p0.W; const float* const B0 = p0.bias; void* const O0 = p0.out;
+  const float* const CS0 = p0.colscale; const float alpha0 = p0.alpha;
+  const int N0 = p0.N, K0 = p0.K;
+  int M0 = p0.Mub;
+  if (p0.m_dev) { const int md = *p0.m_dev; M0 = md < M0 ? md : M0; }
+  M0 = __builtin_amdgcn_readfirstlane(M0);
+  const int tiles_n0 = N0 / lcBN;
+  const int total0 = tiles_n0 * ((M0 + lcBM - 1) / lcBM);
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
+  const int q0 = total0 >> 3, r0 = total0 & 7;
+  const int lo0 = xcd < r0 ? xcd * (q0 + 1) : r0 * (q0 + 1) + (xcd - r0) * q0, len0 = xcd < r0 ? q0 + 1 : q0;
+  const int my_tiles = slot < len0 ? (len0 - slot + per - 1) / per : 0;
+  if (my_tiles == 0) return;
+  const int nk0 = K0 / 128;                        // 128 k per K-step (rows of 128 bytes)
+  const int S = my_tiles * nk0;
+  auto tile_of = [&](int ti, int& m0, int& n0) {
+    const int logical = lo0 + slot + ti * per;
+    const int tm = logical / tiles_n0;
+    m0 = tm * lcBM;
+    n0 = (logical - tm * tiles_n0) * lcBN;
+  };
+  if (wid < 4) {
+    // ---- loader waves: the lc kernel's (a row of either operand is 128 bytes per K-step, whatever the element type) ----
+    const int sub = lane >> 3, ch = lane & 7;
+    uint32_t offW[8], offX[4];
+    const char* Wt = nullptr;
+    const uint32_t rs = static_cast<uint32_t>(K0);      // bytes per row
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = (wid * 8 + i) * 8 + sub;
+      offW[i] = static_cast<uint32_t>(row) * rs + ((ch ^ (row & 7)) << 4);
+    }
+    auto set_tile = [&](int ti) {
+      int m0, n0;
+      tile_of(ti, m0, n0);
+      Wt = W0 + static_cast<size_t>(n0) * rs;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (wid * 4 + i) * 8 + sub;
+        int xr = m0 + row;
+        xr = xr < M0 ? xr : M0 - 1;
+        offX[i] = static_cast<uint32_t>(xr) * rs + ((ch ^ (row & 7)) << 4);
+      }
+    };
+    int i_tile = 0, i_kt = 0, ibuf = 0;
+    set_tile(0);
+    auto issue_stage = [&]() {
+      char* base = lds + ibuf * lcSTG;
+      const uint32_t koff = static_cast<uint32_t>(i_kt) * lcRowBytes;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_global_load_lds((lc_gptr_t)(Wt + koff + offW[i]), (lc_lptr_t)(base + (wid * 8 + i) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((lc_gptr_t)(X0 + koff + offX[i]), (lc_lptr_t)(base + lcWBytes + (wid * 4 + i) * 1024), 16, 0, 0);
+      ibuf = ibuf == 2 ? 0 : ibuf + 1;
+      if (++i_kt == nk0) {
+        i_kt = 0;
+        if (++i_tile < my_tiles) set_tile(i_tile);
+      }
+    };
+    issue_stage();
+    if (S > 1) issue_stage();
+    if (S > 2) issue_stage();
+    if (S > 2) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (S > 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int s = 0; s < S; ++s) {
+      if (s + 2 < S) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (s + 3 < S) issue_stage();
+    }
+    return;
+  }
+  // ---- MFMA waves ----
+  const int c = wid - 4;
+  const int wm = c >> 2, wn = c & 3;
+  const int frow = lane & 15, fq = lane >> 4;
+  const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lc_lptr_t)lds));
+  const uint32_t aW = lds_base + lc_swz(wn * 64 + frow, fq);
+  const uint32_t aX = lds_base + lcWBytes + lc_swz(wm * 64 + frow, fq);
+  typedef __attribute__((ext_vector_type(8))) int lc_i32x8_t;
+  lc_f32x4_t acc[4][4];
+  lc_u32x4_t fw[4][2], fx[4][2];                   // [fragment][16-byte half: chunk fq, chunk fq + 4]
+  // 64 accumulators + 64 fragment registers leave room for HALF of a tile's packed outputs (16 registers: row blocks 2 and 3); they
+  // leave two per K-step under the next tile's first two K-steps, row blocks 0 and 1 are stored by the epilogue itself
+  lc_u32x4_t pend[4];
+  int pend_idx = 4;
+  char* pend_base = nullptr;
+  uint32_t pend_off0 = 0, pend_ldn = 0;
+  auto store_pending = [&](int idx) __attribute__((always_inline)) {
+    char* p = pend_base + (pend_off0 + static_cast<uint32_t>(2 + (idx >> 1)) * 16u * pend_ldn + static_cast<uint32_t>(idx & 1) * 64u);
+    switch (idx) {
+      case 0: *reinterpret_cast<lc_u32x4_t*>(p) = pend[0]; break;
+      case 1: *reinterpret_cast<lc_u32x4_t*>(p) = pend[1]; break;
+      case 2: *reinterpret_cast<lc_u32x4_t*>(p) = pend[2]; break;
+      default: *reinterpret_cast<lc_u32x4_t*>(p) = pend[3]; break;
+    }
+  };
+  auto mfma8 = [&](int a, int b) __attribute__((always_inline)) {
+    lc_i32x8_t va, vb;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      va[j] = static_cast<int>(fw[a][0][j]); va[4 + j] = static_cast<int>(fw[a][1][j]);
+      vb[j] = static_cast<int>(fx[b][0][j]); vb[4 + j] = static_cast<int>(fx[b][1][j]);
+    }
+    acc[a][b] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(va, vb, acc[a][b], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+  };
+#define Q_READ2(dst, addr, off)                                                                                   \
+  do {                                                                                                            \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[0]) : "v"(addr), "n"(off));                          \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[1]) : "v"((addr) ^ 64u), "n"(off));                  \
+  } while (0)
+#define Q_WAIT_ALL()                                                                                               \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                             \
+               : "+v"(fw[0][0]), "+v"(fw[0][1]), "+v"(fw[1][0]), "+v"(fw[1][1]), "+v"(fw[2][0]), "+v"(fw[2][1]), "+v"(fw[3][0]), "+v"(fw[3][1]), \
+                 "+v"(fx[0][0]), "+v"(fx[0][1]), "+v"(fx[1][0]), "+v"(fx[1][1]), "+v"(fx[2][0]), "+v"(fx[2][1]), "+v"(fx[3][0]), "+v"(fx[3][1])::"memory")
+  int cur = 0;
+  __builtin_amdgcn_s_barrier();                    // stage 0 has landed
+  Q_READ2(fx[0], aX, 0); Q_READ2(fx[1], aX, 2048); Q_READ2(fx[2], aX, 4096); Q_READ2(fx[3], aX, 6144);
+  Q_READ2(fw[0], aW, 0); Q_READ2(fw[1], aW, 2048); Q_READ2(fw[2], aW, 4096); Q_READ2(fw[3], aW, 6144);
+  // One K-step: every fragment of the stage is in registers (read during the K-step before), the barrier says so for every MFMA wave
+  // and that the next stage has landed; then 16 MFMAs, each fragment refilled from the next stage as soon as its last MFMA has issued.
+  auto kstep = [&]() __attribute__((always_inline)) {
+    Q_WAIT_ALL();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    const int nxt = cur == 2 ? 0 : cur + 1;
+    const uint32_t bn = static_cast<uint32_t>(nxt) * lcSTG;
+    const uint32_t w0 = aW + bn, x0 = aX + bn;
+    mfma8(0, 0); mfma8(0, 1); mfma8(0, 2); mfma8(0, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    Q_READ2(fw[0], w0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(1, 0); mfma8(1, 1); mfma8(1, 2); mfma8(1, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    if (pend_idx < 4) {
+      store_pending(pend_idx); store_pending(pend_idx + 1);
+      pend_idx += 2;
+      asm volatile("" : "+s"(pend_idx));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    Q_READ2(fw[1], w0, 2048);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(2, 0); mfma8(2, 1); mfma8(2, 2); mfma8(2, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    Q_READ2(fw[2], w0, 4096);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(3, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    Q_READ2(fx[0], x0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(3, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    Q_READ2(fx[1], x0, 2048);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(3, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    Q_READ2(fx[2], x0, 4096);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma8(3, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    Q_READ2(fx[3], x0, 6144);
+    Q_READ2(fw[3], w0, 6144);
+    __builtin_amdgcn_sched_barrier(0);
+    cur = nxt;
+  };
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    int m0, n0;
+    tile_of(ti, m0, n0);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = lc_f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk0; ++kt) kstep();
+    // dequantisation fused with the bias: acc * (alpha * colscale[n]) + bias[n]  (the wide kernel's expression)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const lc_f32x4_t cs = *reinterpret_cast<const lc_f32x4_t*>(CS0 + n0 + wn * 64 + a * 16 + fq * 4) * alpha0;
+      const lc_f32x4_t bv = (epi & EPI_BIAS) ? *reinterpret_cast<const lc_f32x4_t*>(B0 + n0 + wn * 64 + a * 16 + fq * 4) : lc_f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = acc[a][b] * cs + bv;
+    }
+    char* const obase = static_cast<char*>(O0) + (static_cast<size_t>(m0) * N0 + n0) * 2;
+    const uint32_t ldn = static_cast<uint32_t>(N0) * 2;
+    const uint32_t off0 = static_cast<uint32_t>(wm * 64 + frow) * ldn + static_cast<uint32_t>(wn * 64 + (fq & 1) * 16 + (fq & 2) * 4) * 2;
+    const bool park = m0 + lcBM <= M0 && ti + 1 < my_tiles && !(epi & 256);      // nk >= 4 (host): both parked K-steps exist
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        uint32_t lo[2], hi[2];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          lo[w] = pack_bf16x2(acc[2 * pr][b][2 * w], acc[2 * pr][b][2 * w + 1]);
+          hi[w] = pack_bf16x2(acc[2 * pr + 1][b][2 * w], acc[2 * pr + 1][b][2 * w + 1]);
+        }
+        const lc_u2_t s0 = __builtin_amdgcn_permlane16_swap(lo[0], hi[0], false, false);
+        const lc_u2_t s1 = __builtin_amdgcn_permlane16_swap(lo[1], hi[1], false, false);
+        const lc_u32x4_t val = {s0[0], s1[0], s0[1], s1[1]};
+        if (b >= 2) pend[(b - 2) * 2 + pr] = val;
+        if ((b < 2 || !park) && m0 + wm * 64 + b * 16 + frow < M0 && !(epi & 256))
+          *reinterpret_cast<lc_u32x4_t*>(obase + (off0 + static_cast<uint32_t>(b * 16) * ldn + pr * 64)) = val;
+      }
+    if (park) {
+      pend_base = obase; pend_off0 = off0; pend_ldn = ldn;
+      pend_idx = 0;
+      asm volatile("" : "+s"(pend_idx));
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#undef Q_READ2
+#undef Q_WAIT_ALL
+}
+
+int launch_gemm_lc2q(const GemmProblem& g, int epi, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+  if (static_cast<size_t>(g.M) * g.K >= (1ull << 32)) return fail(CMH_ERR_INVALID, "gemm (lc2q): operand exceeds the 32-bit offset range");
+  LcProblem P0{static_cast<const char*>(g.A), static_cast<const char*>(g.W), g.bias, g.residual, g.out, g.m_dev, g.M, g.N, g.K};
+  P0.colscale = g.colscale; P0.alpha = g.alpha; P0.oscale = g.oscale;
+  const LcProblem P1{};
+  const int total = (g.N / lcBN) * ((g.M + lcBM - 1) / lcBM);
+  int cus = 256;
+  { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8) cus = prop.multiProcessorCount & ~7; }
+  const int grid = total < cus ? ((total + 7) & ~7) : cus;
+  if (ev0) hipExtLaunchKernelGGL((gemm_lc2q_kernel<false>), dim3(grid), dim3(768), 0, st, ev0, ev1, 0, P0, P1, epi);
+  else hipLaunchKernelGGL((gemm_lc2q_kernel<false>), dim3(grid), dim3(768), 0, st, P0, P1, epi);
+  CMH_CHECK_LAUNCH("gemm (lc2q)");
+  return 0;
+}
+// first form: bias (+ the implied scale), bf16 output, no residual, no activation
+bool gemm_lc2q_takes(int N, int K, int epi) {
+  return gemm_lc_mode() == 7 && N % lcBN == 0 && K % 128 == 0 && K >= 512 &&
+         (epi & ~(EPI_BIAS | EPI_SCALE | 256)) == EPI_OUT_BF16;
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------------------------
 static int lc_env_mode() { static const int m = []() { const char* e = getenv("CMH_GEMM_LC"); return e ? atoi(e) : 0; }(); return m; }
 static int g_lc_mode = -1;         // cmh_set_gemm_lc: -1 = environment (CMH_GEMM_LC, default 0 = off)
@@ -1017,7 +1271,7 @@ extern "C" int cmh_debug_lc_stamps(unsigned long long* host_out) {
 #endif
 
 extern "C" int cmh_set_gemm_lc(int32_t mode) {
-  CMH_CHECK_ARG(mode >= -1 && mode <= 6, "set_gemm_lc: mode %d (-1 environment, 0 off, 1 every eligible launch, 2 all but QuickGELU launches, 3 by cost model, 4 / 5 / 6 the 12-wave form for every block launch / without the QuickGELU ones / for QKV and out_proj only)", mode);
+  CMH_CHECK_ARG(mode >= -1 && mode <= 7, "set_gemm_lc: mode %d (-1 environment, 0 off, 1 every eligible launch, 2 all but QuickGELU launches, 3 by cost model, 4 / 5 / 6 the 12-wave form for every block launch / without the QuickGELU ones / for QKV and out_proj only)", mode);
   cmh::gemm_lc_set_mode(mode);
   return CMH_OK;
 }

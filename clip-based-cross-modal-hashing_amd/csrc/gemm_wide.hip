@@ -1400,9 +1400,11 @@ bool gemm_lc_takes(int dt, int N, int K, int epi);
 bool gemm_lc_res_first(int epi, int K);
 int launch_gemm_lc(const GemmProblem& a, const GemmProblem* b, int epi, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 bool g_force_rows_set();
+int launch_gemm_lc2q(const GemmProblem& g, int epi, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+bool gemm_lc2q_takes(int N, int K, int epi);
 static bool wide_goes_lc(int dt, int epi) {
   const int mode = gemm_lc_mode();
-  if (mode == 0 || g_force_rows_set()) return false;
+  if (mode == 0 || mode == 7 || g_force_rows_set()) return false;
   if (mode == 2 && (epi & EPI_QUICKGELU)) return false;
   return dt == CMH_BF16;
 }
@@ -1641,6 +1643,12 @@ int launch_gemm_wide(int dt, const void* A, const void* W, const float* bias, co
   if (wide_goes_lc(dt, epi) && gemm_lc_takes(dt, N, K, epi)) {
     const GemmProblem g{A, W, bias, residual, out, M, N, K, m_dev, m_hint, nullptr, 1.f, 1.f};
     const int rc = launch_gemm_lc(g, nullptr, epi, st, g_wide_ev0, g_wide_ev1);
+    g_wide_ev0 = g_wide_ev1 = nullptr;
+    return rc;
+  }
+  if (dt == CMH_FP8 && !g_force_rows_set() && gemm_lc2q_takes(N, K, epi)) {      // the 12-wave form on e4m3 operands (experiment, CMH_GEMM_LC=7)
+    const GemmProblem g{A, W, bias, residual, out, M, N, K, m_dev, m_hint, colscale, alpha, oscale};
+    const int rc = launch_gemm_lc2q(g, epi, st, g_wide_ev0, g_wide_ev1);
     g_wide_ev0 = g_wide_ev1 = nullptr;
     return rc;
   }

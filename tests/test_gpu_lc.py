@@ -156,3 +156,26 @@ def test_lc2_grouped_launch_gives_the_wide_kernels_bits(case):
     for r, o in zip(ref, got):
         assert torch.equal(r, o)
     assert torch.equal(got_md[0], ref[0]) and torch.equal(got_md[1][:Mb - 37], ref[1][:Mb - 37])
+
+
+# ---- the 12-wave form on e4m3 operands (cmh_set_gemm_lc(7)): bias + dequantisation, bf16 output - the fp8 mode's QKV launches
+@pytest.mark.parametrize("M,Nn,K", [(12800, 2304, 768), (10499, 1536, 512), (2049, 256, 512), (130, 512, 1024)])
+def test_lc2q_kernel_gives_the_wide_fp8_kernels_bits(M, Nn, K):
+    import cmh_native as N
+    g = torch.Generator().manual_seed(900 + M)
+    e4m3 = lambda shape, sc: (torch.randn(*shape, generator=g) * sc).to(torch.float8_e4m3fn).view(torch.uint8).to(DEV)
+    x, w = e4m3((M, K), 1.0), e4m3((Nn, K), 8 * K ** -0.5)
+    cs, b = (torch.rand(Nn, generator=g) * 0.1 + 0.05).to(DEV), _rand((Nn,), g).to(DEV)
+    try:
+        N.set_gemm_rows(0)
+        N.set_gemm_lc(0)
+        ref = N.linear_gemm_fp8(x, w, cs, 0.37, bias=b, out="bf16")
+        N.set_gemm_lc(7)
+        got = N.linear_gemm_fp8(x, w, cs, 0.37, bias=b, out="bf16")
+        other = N.linear_gemm_fp8(x, w, cs, 0.37, bias=b, out="f16")      # a form it does not take: the wide kernel runs
+        N.set_gemm_lc(0)
+        other_ref = N.linear_gemm_fp8(x, w, cs, 0.37, bias=b, out="f16")
+    finally:
+        N.set_gemm_lc(-1)
+        N.set_gemm_rows(-1)
+    assert torch.equal(ref, got) and torch.equal(other, other_ref)
