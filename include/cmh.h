@@ -244,7 +244,7 @@ int cmh_set_gemm_rows(int32_t on);
  * block: bias, + QuickGELU, + fp16 residual; plain and grouped launches).  Same bits per output element as the wide kernel (same MFMA
  * chain over K, same epilogue order).  mode 0: never; 1: every launch it can take; 2: every such launch without QuickGELU;
  * 3: where the host's cost model expects it to be faster; 4 / 5 / 6: the 12-wave form (4 staging + 8 MFMA waves, stores deferred) for
- * every block launch with K >= 512 / for those without QuickGELU / for QKV and out_proj only, the wide kernel elsewhere; -1: the environment's
+ * every block launch with K >= 512 / for those without QuickGELU / for QKV and out_proj only, the wide kernel elsewhere; 7: the form on e4m3 operands (fp8 QKV launches); -1: the environment's
  * CMH_GEMM_LC (default).  Process-wide, not thread-safe. */
 int cmh_set_gemm_lc(int32_t mode);
 
