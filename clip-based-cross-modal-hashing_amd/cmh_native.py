@@ -110,6 +110,7 @@ SIGNATURES = {
     "cmh_set_text_token_packing": (C.c_int, [_i32]),
     "cmh_linear_gemm_grouped": (C.c_int, [_i32, C.POINTER(GemmProblem), C.POINTER(GemmProblem), _i32, _p]),
     "cmh_clip_encode_pair": (C.c_int, [C.POINTER(VitWeights), _p, C.POINTER(TextWeights), _p, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p, _sz, _p]),
+    "cmh_clip_encode_pair2": (C.c_int, [C.POINTER(VitWeights), _p, _i32, _p, _i32, C.POINTER(TextWeights), _p, _i32, _i32, _p, _p, _p, _p, _sz, _p, _sz, _p]),
     "cmh_msl_workspace_bytes": (_sz, [_i32]),
     "cmh_msl_loss": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _sz, _p]),
     "cmh_msl_loss_backward": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),

@@ -355,8 +355,10 @@ extern "C" size_t cmh_vit_workspace_bytes(const cmh_vit_weights* w, int32_t batc
 }
 
 // validation + everything before the first block: conv1 as a patch-matrix GEMM, [class ; patches] + positional, ln_pre
+// image_b / batch_a (cmh_clip_encode_pair2): the batch's images come as TWO tensors - rows [0, batch_a) from `image`, the rest from
+// image_b - patchified into consecutive rows of the one patch matrix; nothing behind that knows.
 static int vit_begin(const cmh_vit_weights* w, const float* image, int32_t batch, bool want_out, void* workspace, size_t workspace_bytes,
-                     const cmh_taps* taps, hipStream_t st, float* amax, TowerRun& r) {
+                     const cmh_taps* taps, hipStream_t st, float* amax, TowerRun& r, const float* image_b = nullptr, int32_t batch_a = 0) {
   CMH_CHECK_ARG(w && image && want_out && workspace, "vit_encode: null pointer");
   CMH_CHECK_ARG(batch > 0, "vit_encode: batch %d", batch);
   int rc = check_tower(w->gemm_dtype, w->width, w->layers, w->embed_dim, w->blocks);
@@ -381,7 +383,12 @@ static int vit_begin(const cmh_vit_weights* w, const float* image, int32_t batch
   float* patch_out = static_cast<float*>(t.qkv);
 
   // conv1 (kernel = stride = patch, no bias) as patch-matrix GEMM  (model.py:215,231-235)
-  if ((rc = launch_patchify(image, patches, dt, B, w->resolution, w->patch, st))) return rc;
+  if (image_b) {
+    CMH_CHECK_ARG(batch_a > 0 && batch_a < B, "vit_encode: split batch %d of %d", batch_a, B);
+    if ((rc = launch_patchify(image, patches, dt, batch_a, w->resolution, w->patch, st))) return rc;
+    if ((rc = launch_patchify(image_b, static_cast<char*>(patches) + static_cast<size_t>(batch_a) * g2 * pk * e, dt, B - batch_a, w->resolution,
+                              w->patch, st))) return rc;
+  } else if ((rc = launch_patchify(image, patches, dt, B, w->resolution, w->patch, st))) return rc;
   if ((rc = launch_gemm(dt, patches, w->conv1_w, nullptr, nullptr, patch_out, B * g2, d, pk, 0, st))) return rc;
   // [class ; patches] + positional, ln_pre  (:237-239)
   if ((rc = launch_vit_assemble_lnpre(patch_out, w->class_embedding, w->positional_embedding, w->ln_pre_w,
@@ -593,17 +600,18 @@ extern "C" int cmh_text_encode_packed(const cmh_text_weights* w, const int64_t* 
 // encode_image + encode_text of one batch with the two towers in lock-step (reference model/modelbase.py:105-108 runs them back to
 // back; model/base/model.py:340-372): layer i of both towers shares its launches (run_block_pair).  Same features, bit for bit, as
 // cmh_vit_encode + cmh_text_encode[_packed].
-extern "C" int cmh_clip_encode_pair(const cmh_vit_weights* vw, const float* image, const cmh_text_weights* tw, const int64_t* tokens,
-                                    int32_t batch, int32_t seq_len, int32_t packed, float* feat_image, float* feat_text,
-                                    int32_t* rows_computed_dev, void* ws_image, size_t ws_image_bytes, void* ws_text,
-                                    size_t ws_text_bytes, void* stream) {
+static int clip_encode_pair_impl(const cmh_vit_weights* vw, const float* image, const float* image_b, int32_t batch_a,
+                                 const cmh_text_weights* tw, const int64_t* tokens,
+                                 int32_t batch, int32_t seq_len, int32_t packed, float* feat_image, float* feat_text,
+                                 int32_t* rows_computed_dev, void* ws_image, size_t ws_image_bytes, void* ws_text,
+                                 size_t ws_text_bytes, void* stream) {
   CMH_CHECK_ARG(vw && tw && feat_image && feat_text, "clip_encode_pair: null pointer");
   CMH_CHECK_ARG(vw->gemm_dtype == tw->gemm_dtype, "clip_encode_pair: both towers must run in one arithmetic mode (%d / %d)", vw->gemm_dtype,
                 tw->gemm_dtype);
   hipStream_t st = as_stream(stream);
   TowerRun a, b;
   int rc;
-  if ((rc = vit_begin(vw, image, batch, true, ws_image, ws_image_bytes, nullptr, st, nullptr, a))) return rc;
+  if ((rc = vit_begin(vw, image, batch, true, ws_image, ws_image_bytes, nullptr, st, nullptr, a, image_b, batch_a))) return rc;
   if ((rc = text_begin(tw, tokens, batch, seq_len, nullptr, true, false, ws_text, ws_text_bytes, nullptr, st,
                        packed ? (rows_computed_dev ? rows_computed_dev : reinterpret_cast<int32_t*>(1)) : nullptr, nullptr, b))) return rc;
   const bool tail = pooled_tail_enabled();
@@ -634,6 +642,25 @@ extern "C" int cmh_clip_encode_pair(const cmh_vit_weights* vw, const float* imag
   }
   if ((rc = vit_finish(vw, a, xa, feat_image, nullptr, st))) return rc;
   return text_finish(tw, b, xb, feat_text, nullptr, nullptr, st);
+}
+
+extern "C" int cmh_clip_encode_pair(const cmh_vit_weights* vw, const float* image, const cmh_text_weights* tw, const int64_t* tokens,
+                                    int32_t batch, int32_t seq_len, int32_t packed, float* feat_image, float* feat_text,
+                                    int32_t* rows_computed_dev, void* ws_image, size_t ws_image_bytes, void* ws_text,
+                                    size_t ws_text_bytes, void* stream) {
+  return clip_encode_pair_impl(vw, image, nullptr, 0, tw, tokens, batch, seq_len, packed, feat_image, feat_text, rows_computed_dev, ws_image,
+                               ws_image_bytes, ws_text, ws_text_bytes, stream);
+}
+
+// TWO loader batches as one: images as two tensors (batch_a + batch_b rows), the captions of both as one [batch_a + batch_b, seq_len]
+// matrix.  Every row sees the arithmetic of cmh_clip_encode_pair on its own batch: the same features, half as many launches per pair.
+extern "C" int cmh_clip_encode_pair2(const cmh_vit_weights* vw, const float* image_a, int32_t batch_a, const float* image_b, int32_t batch_b,
+                                     const cmh_text_weights* tw, const int64_t* tokens, int32_t seq_len, int32_t packed,
+                                     float* feat_image, float* feat_text, int32_t* rows_computed_dev, void* ws_image,
+                                     size_t ws_image_bytes, void* ws_text, size_t ws_text_bytes, void* stream) {
+  CMH_CHECK_ARG(image_a && image_b && batch_a > 0 && batch_b > 0, "clip_encode_pair2: two non-empty batches");
+  return clip_encode_pair_impl(vw, image_a, image_b, batch_a, tw, tokens, batch_a + batch_b, seq_len, packed, feat_image, feat_text,
+                               rows_computed_dev, ws_image, ws_image_bytes, ws_text, ws_text_bytes, stream);
 }
 
 extern "C" int cmh_linear_gemm_grouped(int32_t dtype, const cmh_gemm_problem* pa, const cmh_gemm_problem* pb, int32_t epilogue, void* stream) {

@@ -136,24 +136,50 @@ class TrainBase(object):
         clip = getattr(self.model, "clip", None)
         use_pair = pair and clip is not None and hasattr(clip, "prefetch_pair") and os.environ.get("CMH_PAIR", "1") != "0"
         pipe = AlternatingStreams(torch.device("cuda", self.rank) if isinstance(self.rank, int) else self.rank)
+        # Round 5: two consecutive loader batches share ONE run of the towers (CLIP.prefetch_pairs -> cmh_clip_encode_pair2): a launch's
+        # fixed costs - ramp, first stage, last epilogue: ~10 us of a 50 us GEMM launch at batch 256 - are paid once per 512 pairs
+        # (profiles/r05_k: -10 % GEMM time per pair).  work() still runs per loader batch; same values, bit for bit.  CMH_COALESCE=1: off.
+        group = 2 if (use_pair and pipe.enabled and hasattr(clip, "prefetch_pairs") and os.environ.get("CMH_COALESCE", "2") != "1") else 1
+
+        def dispatch(held):
+            ready = None
+            if pipe.enabled:
+                ready = torch.cuda.Event()
+                ready.record()
+
+            def run(held=held):
+                ok = [use_pair and t[0].shape[0] == t[1].shape[0] for t in held]
+                try:
+                    if len(held) == 2 and all(ok) and held[0][0].shape[1:] == held[1][0].shape[1:] and held[0][1].shape[1:] == held[1][1].shape[1:]:
+                        clip.prefetch_pairs([(t[0], t[1]) for t in held])
+                        for t in held:
+                            work(*t)
+                    else:
+                        for t, o in zip(held, ok):
+                            if o:
+                                clip.prefetch_pair(t[0], t[1])
+                            work(*t)
+                            if use_pair:
+                                clip.drop_pair_stash()
+                finally:
+                    if use_pair:
+                        clip.drop_pair_stash()      # a work() that took one side only (or raised) must not pin the batch
+
+            pipe.run(run, tuple(x for t in held for x in t), ready)
+
         with torch.no_grad():
+            held = []
             for batch in data_loader:
-                tensors = tuple(to_device(batch))
-                ready = None
-                if pipe.enabled:
-                    ready = torch.cuda.Event()
-                    ready.record()
-
-                def run(tensors=tensors):
-                    if use_pair and tensors[0].shape[0] == tensors[1].shape[0]:
-                        clip.prefetch_pair(tensors[0], tensors[1])
-                    try:
-                        work(*tensors)
-                    finally:
-                        if use_pair:
-                            clip.drop_pair_stash()      # a work() that took one side only (or raised) must not pin the batch
-
-                pipe.run(run, tensors, ready)
+                # only batches that are ALREADY on the device wait for a partner (dataset/base.py::DeviceLoader's cached epochs hand
+                # those out): a batch still on the host has its 154 MB of pixels to copy first, and holding the towers back until two
+                # copies are through costs more (-5 % measured) than the shared launches return
+                resident = isinstance(batch[0], torch.Tensor) and batch[0].is_cuda
+                held.append(tuple(to_device(batch)))
+                if len(held) == group or not resident:
+                    dispatch(held)
+                    held = []
+            if held:
+                dispatch(held)
         pipe.join()
 
     def _code_loop(self, data_loader, length, encode):

@@ -174,6 +174,14 @@ int cmh_clip_encode_pair(const cmh_vit_weights* vw, const float* image, const cm
                          int32_t batch, int32_t seq_len, int32_t packed, float* feat_image, float* feat_text,
                          int32_t* rows_computed_dev, void* ws_image, size_t ws_image_bytes, void* ws_text, size_t ws_text_bytes,
                          void* stream);
+/* The same for TWO loader batches in one call (the evaluation loop train/base.py:130-148 walks independent batches): the images of
+ * the two batches stay two tensors (batch_a, batch_b rows), their captions come as one [batch_a + batch_b, seq_len] matrix; feat_image /
+ * feat_text [batch_a + batch_b, embed_dim], batch a's rows first.  Same bits per row as cmh_clip_encode_pair on each batch; the
+ * workspaces are sized for batch_a + batch_b. */
+int cmh_clip_encode_pair2(const cmh_vit_weights* vw, const float* image_a, int32_t batch_a, const float* image_b, int32_t batch_b,
+                          const cmh_text_weights* tw, const int64_t* tokens, int32_t seq_len, int32_t packed,
+                          float* feat_image, float* feat_text, int32_t* rows_computed_dev, void* ws_image,
+                          size_t ws_image_bytes, void* ws_text, size_t ws_text_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Building blocks of the towers, exported for unit-level parity tests and for heads that want them.

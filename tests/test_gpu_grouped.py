@@ -147,6 +147,32 @@ def test_encode_pair_equals_the_two_single_tower_calls(mode, B):
                 assert torch.equal(r, a) and torch.equal(r, b)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp8"])
+def test_two_loader_batches_in_one_call_equal_two_calls(mode):
+    """cmh_clip_encode_pair2 (CLIP.encode_pair2 / prefetch_pairs; the evaluation loop coalesces two loader batches, train/base.py
+    ::_pipelined_batches): ViT-B/32, batches of 48 and 32 pairs as ONE run of the towers - every row's features equal the two
+    separate encode_pair calls bit for bit, packed and dense captions, and prefetch_pairs hands each batch its own rows."""
+    from model.base.model import CLIP
+    cfg = recipe.CLIP_VITB32
+    torch.manual_seed(23)
+    m = CLIP(**cfg).to(DEV).float().set_gemm_dtype("bf16")
+    m.assume_frozen = True
+    ia, ib = (torch.from_numpy(recipe.images(n, cfg["image_resolution"], s)).to(DEV) for n, s in ((48, 5), (32, 6)))
+    ta, tb = (torch.from_numpy(recipe.captions(n, 77, cfg["vocab_size"], s)).to(DEV) for n, s in ((48, 7), (32, 8)))
+    if mode == "fp8":
+        m.calibrate_fp8(ia[:16], ta[:16])
+        m.set_gemm_dtype("fp8")
+    with torch.no_grad():
+        for pack in (True, False):
+            m.pack_text = pack
+            ra, rb = [t.clone() for t in m.encode_pair(ia, ta)], [t.clone() for t in m.encode_pair(ib, tb)]
+            fi, ft = m.encode_pair2(ia, ta, ib, tb)
+            assert torch.equal(fi[:48], ra[0]) and torch.equal(fi[48:], rb[0]) and torch.equal(ft[:48], ra[1]) and torch.equal(ft[48:], rb[1])
+        m.prefetch_pairs([(ia, ta), (ib, tb)])
+        assert torch.equal(m.encode_image(ib), rb[0]) and torch.equal(m.encode_text(ta), ra[1])      # any order, by tensor identity
+        assert torch.equal(m.encode_image(ia), ra[0]) and torch.equal(m.encode_text(tb), rb[1]) and not m._pair_stash
+
+
 def test_prefetch_pair_feeds_the_next_two_encodes():
     """CLIP.prefetch_pair (the trainers' code loop, train/base.py::_code_loop): the lock-step pair path runs once, the following
     encode_image / encode_text calls ON THE SAME TENSORS hand its features out (bit-identical to the separate calls), other tensors
