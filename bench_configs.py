@@ -180,7 +180,8 @@ def code_loop(dev, headline_pairs_per_s=None, pairs=20480, batch=256, bits=64, L
     from pinned host batches through the loop's own `.to(rank, non_blocking=True)` (154 MB of pixels per batch over PCIe).  bench.py's
     headline times the bare step over ONE resident batch; this is the same arithmetic driven by the trainer: per batch the H2D /
     no-op moves, CLIP.prefetch_pair on alternating streams, the heads, sign(), the scatter of the codes into [length, K] buffers at
-    the batch's dataset indices."""
+    the batch's dataset indices.  Since round 5 two consecutive device-resident batches share one run of the towers
+    (CLIP.prefetch_pairs / cmh_clip_encode_pair2; CMH_COALESCE=1 switches it off): the resident loop is faster than the bare step."""
     import main
     from bench import synthetic_batch
     from train.DSPH.hash_train import DSPHTrainer
